@@ -1,0 +1,182 @@
+/*
+ * sfm_hip.h — C-ABI of libsfmhip.so, the MI355X (gfx950) back-end for the
+ * incremental-SfM hot path of FlagArihant2000/sfm-mvs.
+ *
+ * The reference has no FFI of its own: its operator boundary is the set of
+ * cv2.* calls made by sfm.py.  Each entry point below names the reference call
+ * site (file:line under /root/reference) whose arithmetic it replaces; the
+ * ctypes stubs a maintainer would add to sfm.py are shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only.  Every `*_dev` pointer is a
+ *     DEVICE pointer (HBM) owned by the caller; `stream` is a hipStream_t
+ *     passed as void* (NULL = the null stream).
+ *   - All functions are stream-ordered and asynchronous; none synchronises.
+ *   - The library allocates nothing persistent: scratch is caller-provided
+ *     workspace, sized by the `_ws_bytes` twin of each call.
+ *   - Return value: 0 = OK, negative = error code below; a human-readable
+ *     message for the calling thread's last error is at sfm_last_error().
+ *   - There is NO CPU fallback.  If no HIP device is usable the call fails
+ *     with SFM_ERR_DEVICE.
+ */
+#ifndef SFM_HIP_H
+#define SFM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SFM_ABI_VERSION 1
+
+#define SFM_OK             0
+#define SFM_ERR_ARG       -1   /* null pointer, negative size, unsupported dim, misaligned pointer/stride */
+#define SFM_ERR_WORKSPACE -2   /* ws_bytes smaller than the _ws_bytes twin reports */
+#define SFM_ERR_DEVICE    -3   /* HIP runtime error (launch failure, no device) */
+
+int         sfm_abi_version(void);
+const char* sfm_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * A2  cv2.BFMatcher().knnMatch(des0, des1, k=2)           sfm.py:259-260
+ *     (also isfm.py:47,71; test.py:41-42,225,352)
+ *
+ * Brute-force L2 2-nearest-neighbour of every query row among the train rows.
+ * Semantics of OpenCV's batchDistance(NORM_L2, K=2): dist = sqrtf(sum (q-t)^2)
+ * in float32, best-2 kept sorted ascending, a candidate replaces only on
+ * strict `<`, so on ties the LOWER train index stays ahead.
+ *
+ *   q_dev   [nq x dim] float32, row stride ldq (elements)   — des0
+ *   t_dev   [nt x dim] float32, row stride ldt (elements)   — des1
+ *   idx_dev [nq x 2]   int32   trainIdx of 1st / 2nd neighbour (-1 if nt < k)
+ *   dist_dev[nq x 2]   float32 DMatch.distance            (+inf if nt < k)
+ *   stats_dev (optional, may be NULL) int32[4]:
+ *       [0] queries resolved by the exact full-scan fallback
+ *       [1] train split count S used   [2] streams per query   [3] reserved
+ *
+ * dim must be 128 (SIFT); q_dev/t_dev 16-byte aligned; ldq, ldt multiples of 4.
+ * The result is bit-identical to the direct-form float32 evaluation for ANY
+ * finite input (see DESIGN.md "certified filter + exact refine").
+ * ---------------------------------------------------------------------- */
+size_t sfm_knn2_l2_f32_ws_bytes(int64_t nq, int64_t nt, int dim);
+int    sfm_knn2_l2_f32(const float* q_dev, int64_t nq, int64_t ldq,
+                       const float* t_dev, int64_t nt, int64_t ldt, int dim,
+                       int32_t* idx_dev, float* dist_dev, int32_t* stats_dev,
+                       void* ws_dev, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
+ * A3  Lowe ratio loop + gather                           sfm.py:262-268
+ *     `if m.distance < 0.70 * n.distance: good.append(m)`
+ *
+ * The reference compares float32 distances promoted to Python double against
+ * a double constant; the kernel does exactly that in fp64.  Survivors are
+ * written in ascending queryIdx order (the order of the Python loop).
+ *
+ *   out_q_dev, out_t_dev [nq] int32   queryIdx / trainIdx of survivors
+ *   out_count_dev        [1]  int32   number of survivors M
+ *   mask_dev (optional)  [nq] uint8   1 where the query passed
+ * ---------------------------------------------------------------------- */
+int sfm_ratio_compact(const int32_t* idx_dev, const float* dist_dev, int64_t nq,
+                      double ratio, int32_t* out_q_dev, int32_t* out_t_dev,
+                      int32_t* out_count_dev, uint8_t* mask_dev, void* stream);
+
+/* Gather keypoint coordinates of the survivors: pts0 = kp0[out_q], pts1 = kp1[out_t]
+ * (sfm.py:267-268).  kp*_dev are [n x 2] float32 (KeyPoint.pt); count_dev is the
+ * device scalar written by sfm_ratio_compact; capacity = rows available in pts*_dev. */
+int sfm_gather_matches(const float* kp0_dev, const float* kp1_dev,
+                       const int32_t* out_q_dev, const int32_t* out_t_dev,
+                       const int32_t* count_dev, int64_t capacity,
+                       float* pts0_dev, float* pts1_dev, void* stream);
+
+/* ------------------------------------------------------------------------
+ * A4  cv2.triangulatePoints(P1, P2, points1, points2)    sfm.py:53
+ *     + `cloud = cloud / cloud[3]`                        sfm.py:54
+ *
+ * Per correspondence: homogeneous DLT in fp64, X = right singular vector of the
+ * smallest singular value (one-sided Jacobi as in OpenCV's SVD), cast to
+ * float32.  rows = 4 → modern 4x4 system (x*P3-P1, y*P3-P2 per view);
+ * rows = 6 → legacy cvTriangulatePoints 6x4 system (adds x*P2-y*P1).
+ * normalise_w != 0 additionally performs the reference's float32 division by w.
+ *
+ *   P1, P2        HOST pointers, 12 doubles each, row-major 3x4
+ *   x1_dev,x2_dev float32; point i has x at [i*stride_pt] and y at
+ *                 [i*stride_pt + stride_xy] — covers (2,N) (stride_pt=1,
+ *                 stride_xy=N), (N,2) (2,1) and the reference's transposed views
+ *   X4_dev        float32 [4 x n] row-major (the cv2 output layout)
+ * ---------------------------------------------------------------------- */
+int sfm_triangulate_dlt(const double* P1_host, const double* P2_host,
+                        const float* x1_dev, const float* x2_dev, int64_t n,
+                        int64_t stride_pt, int64_t stride_xy, int rows,
+                        int normalise_w, float* X4_dev, void* stream);
+
+/* ------------------------------------------------------------------------
+ * A5  ReprojectionError: cv2.Rodrigues + cv2.projectPoints + cv2.norm
+ *                                                        sfm.py:79-100
+ * A6  solvePnPRansac inlier scoring                      sfm.py:67
+ * A8  OptimReprojectionError / BundleAdjustment sweep    sfm.py:104-157
+ *
+ * One sweep over `nobs` observations.  Observation o sees point pt_idx[o]
+ * through camera cam_idx[o]; either index array may be NULL (NULL cam_idx =
+ * camera 0; NULL pt_idx = point o).  Projection is OpenCV's distortion-free
+ * projectPoints in fp64: X' = R(rvec) X + t, u = fx X'/Z' + cx, v = fy Y'/Z' + cy
+ * (skew ignored).  Optional outputs (pass NULL to skip):
+ *   proj_dev    [nobs x 2] float32  projected pixel (the `p` of sfm.py:88-90)
+ *   sumsq_dev   [1] float64  sum over o of ||f32(proj) - obs||^2, i.e. the
+ *               square of cv2.norm(p, pts, NORM_L2) (sfm.py:93,95); caller
+ *               zeroes it; accumulation is a fixed-order two-level sum
+ *   inlier_dev  [nobs] uint8  1 iff float32 squared error <= thr2 (PnP-RANSAC)
+ *   JtJ_cam_dev [ncam x 36], Jtr_cam_dev [ncam x 6] float64: Gauss-Newton normal
+ *               equations per camera in (rvec, tvec), residual = proj - obs
+ *   JtJ_pt_dev  [npt x 9],  Jtr_pt_dev [npt x 3] float64: same per 3D point
+ *   cams_dev    [ncam x 6] float64 (rvec3, tvec3);  K_host 9 doubles row-major
+ *   X_dev       [npt x 3] float32 with row stride ldx
+ * ---------------------------------------------------------------------- */
+size_t sfm_project_residual_ws_bytes(int64_t nobs, int64_t ncam, int64_t npt);
+int sfm_project_residual(const double* cams_dev, int64_t ncam, const double* K_host,
+                         const float* X_dev, int64_t npt, int64_t ldx,
+                         const float* obs_dev, const int32_t* cam_idx_dev,
+                         const int32_t* pt_idx_dev, int64_t nobs,
+                         float* proj_dev, double* sumsq_dev,
+                         uint8_t* inlier_dev, float thr2,
+                         double* JtJ_cam_dev, double* Jtr_cam_dev,
+                         double* JtJ_pt_dev, double* Jtr_pt_dev,
+                         void* ws_dev, size_t ws_bytes, void* stream);
+
+/* Dense visibility variant (BASELINE config 4: every camera sees every point).
+ * obs_dev is [ncam x npt x 2] float32.  Same arithmetic as above; per-camera
+ * blocks are reduced in registers and per-point blocks are owned by one lane,
+ * so the result is deterministic and needs no atomics. */
+size_t sfm_ba_dense_sweep_ws_bytes(int64_t ncam, int64_t npt);
+int sfm_ba_dense_sweep(const double* cams_dev, int64_t ncam, const double* K_host,
+                       const float* X_dev, int64_t npt, int64_t ldx,
+                       const float* obs_dev, double* sumsq_dev,
+                       double* JtJ_cam_dev, double* Jtr_cam_dev,
+                       double* JtJ_pt_dev, double* Jtr_pt_dev,
+                       void* ws_dev, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
+ * A7  cv2.findEssentialMat RANSAC scoring                sfm.py:307
+ *
+ * For h candidate essential matrices (host-generated by the 5-point solver)
+ * score n K-normalised correspondences with the Sampson distance in fp64,
+ * cast to float32 and compared `<= thr2` as OpenCV's RANSAC does.
+ *   E_dev [h x 9] f64;  x1n_dev, x2n_dev [n x 2] f64
+ *   counts_dev [h] int32;  mask_dev (optional) [h x n] uint8
+ * ---------------------------------------------------------------------- */
+int sfm_score_essential(const double* E_dev, int h, const double* x1n_dev,
+                        const double* x2n_dev, int64_t n, float thr2,
+                        int32_t* counts_dev, uint8_t* mask_dev, void* stream);
+
+/* PnP-RANSAC scoring for h hypotheses (rvec,tvec) over n 3D-2D pairs:
+ * err = ||proj - obs||^2 as float32, inlier iff err <= thr2 (sfm.py:67 defaults:
+ * reprojectionError 8.0 → thr2 = 64). */
+int sfm_score_pnp(const double* poses_dev, int h, const double* K_host,
+                  const float* X_dev, const float* obs_dev, int64_t n, float thr2,
+                  int32_t* counts_dev, uint8_t* mask_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SFM_HIP_H */

@@ -1,0 +1,189 @@
+"""NumPy-facing ctypes wrapper of liboracle.so — TEST INFRASTRUCTURE ONLY.
+
+Importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.  The product
+package (sfm_mvs_amd/) must never import this module.  Parity status: see sfm_oracle.h
+("parity unpinned" for the cv2-backed functions).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PATH = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-C", _HERE, "-s"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_PATH):
+            build()
+        _lib = C.CDLL(_PATH)
+        _lib.orc_l2sqr_f32.restype = C.c_float
+        _lib.orc_ratio_filter.restype = C.c_int64
+        _lib.orc_common_points.restype = C.c_int64
+        _lib.orc_to_ply_filter.restype = C.c_int64
+        _lib.orc_reprojection_error.restype = C.c_double
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def knn2(q, t, nthreads=1):
+    q, t = _f32(q), _f32(t)
+    nq, dim = q.shape
+    nt = t.shape[0]
+    idx = np.empty((nq, 2), np.int32)
+    dist = np.empty((nq, 2), np.float32)
+    lib().orc_knn2_l2_f32(_p(q), C.c_int64(nq), C.c_int64(dim), _p(t), C.c_int64(nt), C.c_int64(dim), C.c_int(dim),
+                          _p(idx), _p(dist), C.c_int(nthreads))
+    return idx, dist
+
+
+def l2sqr(a, b):
+    a, b = _f32(a).ravel(), _f32(b).ravel()
+    return float(lib().orc_l2sqr_f32(_p(a), _p(b), C.c_int(a.size)))
+
+
+def ratio_filter(idx, dist, ratio=0.70):
+    idx = np.ascontiguousarray(idx, np.int32)
+    dist = _f32(dist)
+    nq = idx.shape[0]
+    oq = np.empty(nq, np.int32)
+    ot = np.empty(nq, np.int32)
+    mask = np.empty(nq, np.uint8)
+    m = lib().orc_ratio_filter(_p(idx), _p(dist), C.c_int64(nq), C.c_double(ratio), _p(oq), _p(ot), _p(mask))
+    return oq[:m].copy(), ot[:m].copy(), mask
+
+
+def triangulate(P1, P2, pts1, pts2, rows=4, normalise_w=False):
+    """pts1/pts2: (2,N) like cv2.triangulatePoints.  Returns (4,N) float32."""
+    P1, P2 = _f64(P1).reshape(12), _f64(P2).reshape(12)
+    x1, x2 = _f32(pts1), _f32(pts2)
+    n = x1.shape[1]
+    X4 = np.empty((4, n), np.float32)
+    lib().orc_triangulate_dlt(_p(P1), _p(P2), _p(x1), _p(x2), C.c_int64(n), C.c_int64(1), C.c_int64(n),
+                              C.c_int(rows), C.c_int(int(normalise_w)), _p(X4))
+    return X4
+
+
+def jacobi_svd(A):
+    A = _f64(A)
+    m, n = A.shape
+    w = np.empty(n)
+    U = np.empty((m, n))
+    Vt = np.empty((n, n))
+    lib().orc_jacobi_svd(_p(A), C.c_int(m), C.c_int(n), _p(w), _p(U), _p(Vt))
+    return U, w, Vt
+
+
+def rodrigues_vec2mat(r, want_jac=False):
+    r = _f64(r).reshape(3)
+    R = np.empty(9)
+    J = np.empty(27) if want_jac else None
+    lib().orc_rodrigues_vec2mat(_p(r), _p(R), _p(J))
+    return (R.reshape(3, 3), J.reshape(3, 9)) if want_jac else R.reshape(3, 3)
+
+
+def rodrigues_mat2vec(R):
+    R = _f64(R).reshape(9)
+    r = np.empty(3)
+    lib().orc_rodrigues_mat2vec(_p(R), _p(r))
+    return r
+
+
+def project_points(rvec, tvec, K, X):
+    X = _f32(X).reshape(-1, 3)
+    n = X.shape[0]
+    p64 = np.empty((n, 2))
+    p32 = np.empty((n, 2), np.float32)
+    lib().orc_project_points(_p(_f64(rvec).reshape(3)), _p(_f64(tvec).reshape(3)), _p(_f64(K).reshape(9)), _p(X),
+                             C.c_int64(n), C.c_int64(3), _p(p64), _p(p32))
+    return p64, p32
+
+
+def reprojection_error(Rt, K, X, obs):
+    """X (N,3) float32, obs (N,2) float32 → (error, projected float32 (N,2))."""
+    X = _f32(X).reshape(-1, 3)
+    obs = _f32(obs).reshape(-1, 2)
+    n = X.shape[0]
+    p32 = np.empty((n, 2), np.float32)
+    e = lib().orc_reprojection_error(_p(_f64(Rt).reshape(12)), _p(_f64(K).reshape(9)), _p(X), C.c_int64(n),
+                                     C.c_int64(3), _p(obs), _p(p32))
+    return float(e), p32
+
+
+def project_residual(cams, K, X, obs, cam_idx=None, pt_idx=None, thr2=64.0, want_jac=True):
+    cams = _f64(cams).reshape(-1, 6)
+    X = _f32(X).reshape(-1, 3)
+    obs = _f32(obs).reshape(-1, 2)
+    ncam, npt, nobs = cams.shape[0], X.shape[0], obs.shape[0]
+    ci = None if cam_idx is None else np.ascontiguousarray(cam_idx, np.int32)
+    pi = None if pt_idx is None else np.ascontiguousarray(pt_idx, np.int32)
+    out = dict(proj=np.empty((nobs, 2), np.float32), sumsq=np.zeros(1), inlier=np.empty(nobs, np.uint8))
+    if want_jac:
+        out.update(JtJ_cam=np.zeros((ncam, 36)), Jtr_cam=np.zeros((ncam, 6)), JtJ_pt=np.zeros((npt, 9)),
+                   Jtr_pt=np.zeros((npt, 3)))
+    lib().orc_project_residual(_p(cams), C.c_int64(ncam), _p(_f64(K).reshape(9)), _p(X), C.c_int64(npt), C.c_int64(3),
+                               _p(obs), _p(ci), _p(pi), C.c_int64(nobs), _p(out["proj"]), _p(out["sumsq"]),
+                               _p(out["inlier"]), C.c_float(thr2), _p(out.get("JtJ_cam")), _p(out.get("Jtr_cam")),
+                               _p(out.get("JtJ_pt")), _p(out.get("Jtr_pt")), C.c_int(1))
+    return out
+
+
+def common_points(pts1, pts2, pts3):
+    """Mirror of sfm.py:215-239: returns (indx1, indx2, temp_array1, temp_array2)."""
+    pts1, pts2, pts3 = _f32(pts1).reshape(-1, 2), _f32(pts2).reshape(-1, 2), _f32(pts3).reshape(-1, 2)
+    n1, n2 = pts1.shape[0], pts2.shape[0]
+    i1 = np.empty(max(n1, 1), np.int64)
+    i2 = np.empty(max(n1, 1), np.int64)
+    keep = np.empty(max(n2, 1), np.uint8)
+    m = lib().orc_common_points(_p(pts1), C.c_int64(n1), _p(pts2), C.c_int64(n2), _p(i1), _p(i2), _p(keep))
+    k = keep[:n2].astype(bool)
+    return i1[:m].copy(), i2[:m].copy(), pts2[k], pts3[k]
+
+
+def to_ply_filter(points):
+    pts = _f64(points).reshape(-1, 3)
+    n = pts.shape[0]
+    scaled = np.empty((n, 3))
+    keep = np.empty(n, np.uint8)
+    lib().orc_to_ply_filter(_p(pts), C.c_int64(n), _p(scaled), _p(keep))
+    return scaled, keep.astype(bool)
+
+
+def score_essential(E, x1n, x2n, thr2):
+    E = _f64(E).reshape(-1, 9)
+    x1n, x2n = _f64(x1n).reshape(-1, 2), _f64(x2n).reshape(-1, 2)
+    h, n = E.shape[0], x1n.shape[0]
+    counts = np.empty(h, np.int32)
+    mask = np.empty((h, n), np.uint8)
+    lib().orc_score_essential(_p(E), C.c_int(h), _p(x1n), _p(x2n), C.c_int64(n), C.c_float(thr2), _p(counts), _p(mask))
+    return counts, mask
+
+
+def score_pnp(poses, K, X, obs, thr2=64.0):
+    poses = _f64(poses).reshape(-1, 6)
+    X, obs = _f32(X).reshape(-1, 3), _f32(obs).reshape(-1, 2)
+    h, n = poses.shape[0], X.shape[0]
+    counts = np.empty(h, np.int32)
+    mask = np.empty((h, n), np.uint8)
+    lib().orc_score_pnp(_p(poses), C.c_int(h), _p(_f64(K).reshape(9)), _p(X), _p(obs), C.c_int64(n), C.c_float(thr2),
+                        _p(counts), _p(mask))
+    return counts, mask

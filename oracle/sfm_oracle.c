@@ -1,0 +1,599 @@
+/*
+ * sfm_oracle.c — CPU restatement of the hot path of FlagArihant2000/sfm-mvs (sfm.py).
+ *
+ * TEST INFRASTRUCTURE ONLY: loaded by tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg; never by the product (sfm_mvs_amd/).
+ *
+ * PARITY UNPINNED for the cv2-backed functions: the arithmetic of this path lives in
+ * OpenCV (third-party, un-vendored, version-unpinned in the reference; cv2 cannot be
+ * installed here).  Each function restates OpenCV's published algorithm as reached
+ * from the cited sfm.py call site; choices that differ between OpenCV releases are
+ * called out where they are made.  Pure-NumPy helpers (common_points, to_ply) are
+ * pinned by golden vectors produced by running the reference functions themselves.
+ *
+ * Build: see oracle/Makefile (gcc -O3 -ffp-contract=off -fopenmp).  No fused
+ * multiply-adds anywhere: the reference's SIMD paths round mul and add separately.
+ */
+#include "sfm_oracle.h"
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------------
+ * A2  knnMatch → batchDistance(NORM_L2, K=2)                                  sfm.py:259-260
+ * OpenCV normL2Sqr_(float): 128-bit SIMD path = two 4-lane accumulators over blocks of 8
+ * (d0 += t0*t0, d1 += t1*t1), lanes folded as (d0+d1) then buf[0]+buf[1]+buf[2]+buf[3];
+ * then a 4-wide scalar block and a scalar tail.  dist = sqrtf(that).
+ * (AVX2 builds use one 8-lane accumulator and a different fold; unpinned.  For real SIFT
+ * descriptors — integers 0..255 — every order gives the same exact sum.)
+ * ---------------------------------------------------------------------------------------- */
+float orc_l2sqr_f32(const float* a, const float* b, int n) {
+    int j = 0;
+    float d = 0.f;
+    if (n >= 8) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (; j <= n - 8; j += 8)
+            for (int l = 0; l < 8; ++l) {
+                const float t = a[j + l] - b[j + l];
+                acc[l] = acc[l] + t * t;
+            }
+        const float s0 = acc[0] + acc[4], s1 = acc[1] + acc[5], s2 = acc[2] + acc[6], s3 = acc[3] + acc[7];
+        d = ((s0 + s1) + s2) + s3;
+    }
+    for (; j <= n - 4; j += 4) {
+        const float t0 = a[j] - b[j], t1 = a[j + 1] - b[j + 1], t2 = a[j + 2] - b[j + 2], t3 = a[j + 3] - b[j + 3];
+        d += t0 * t0 + t1 * t1 + t2 * t2 + t3 * t3;
+    }
+    for (; j < n; ++j) {
+        const float t = a[j] - b[j];
+        d += t * t;
+    }
+    return d;
+}
+
+static void knn_row(const float* qrow, const float* t, int64_t nt, int64_t ldt, int dim, int32_t* idx, float* dist) {
+    /* best-K kept sorted; replace only on strict '<' so the lower train index wins ties */
+    float d0 = INFINITY, d1 = INFINITY;
+    int32_t i0 = -1, i1 = -1;
+    for (int64_t j = 0; j < nt; ++j) {
+        const float d = sqrtf(orc_l2sqr_f32(qrow, t + j * ldt, dim));
+        if (d < d1) {
+            if (d < d0) {
+                d1 = d0; i1 = i0;
+                d0 = d;  i0 = (int32_t)j;
+            } else {
+                d1 = d;  i1 = (int32_t)j;
+            }
+        }
+    }
+    idx[0] = i0; idx[1] = i1;
+    dist[0] = d0; dist[1] = d1;
+}
+
+void orc_knn2_l2_f32(const float* q, int64_t nq, int64_t ldq, const float* t, int64_t nt, int64_t ldt, int dim,
+                     int32_t* idx, float* dist, int nthreads) {
+    /* OpenCV parallelises batchDistance over query rows (parallel_for_); so do we. */
+#ifdef _OPENMP
+    if (nthreads > 1) {
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nthreads)
+        for (int64_t i = 0; i < nq; ++i) knn_row(q + i * ldq, t, nt, ldt, dim, idx + 2 * i, dist + 2 * i);
+        return;
+    }
+#endif
+    (void)nthreads;
+    for (int64_t i = 0; i < nq; ++i) knn_row(q + i * ldq, t, nt, ldt, dim, idx + 2 * i, dist + 2 * i);
+}
+
+/* A3  `if m.distance < 0.70 * n.distance` — float32 attributes promoted to Python double.  sfm.py:262-265 */
+int64_t orc_ratio_filter(const int32_t* idx, const float* dist, int64_t nq, double ratio, int32_t* out_q,
+                         int32_t* out_t, uint8_t* mask) {
+    int64_t m = 0;
+    for (int64_t i = 0; i < nq; ++i) {
+        const int pass = idx[2 * i + 1] >= 0 && (double)dist[2 * i] < ratio * (double)dist[2 * i + 1];
+        if (mask) mask[i] = (uint8_t)pass;
+        if (pass) {
+            if (out_q) out_q[m] = (int32_t)i;
+            if (out_t) out_t[m] = idx[2 * i];
+            ++m;
+        }
+    }
+    return m;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * One-sided (Hestenes) Jacobi SVD as OpenCV's cv::SVD does it for double: rows of `At` are the
+ * COLUMNS of A; pairs (i<j) are swept cyclically; a pair is skipped when
+ * |p| <= eps*sqrt(a*b), eps = 10*DBL_EPSILON; at most max(m,30) sweeps; singular values are
+ * sorted descending by selection sort.  Dot products / rotated norms use the 2-lane
+ * accumulation of the 128-bit double SIMD path when m >= 4 and plain sequential sums
+ * otherwise (OpenCV 4.x VBLAS<double>; 3.4 folds the tail differently for m=6 — unpinned).
+ * ---------------------------------------------------------------------------------------- */
+static double svd_hypot(double a, double b) {
+    a = fabs(a);
+    b = fabs(b);
+    if (a > b) {
+        b /= a;
+        return a * sqrt(1 + b * b);
+    }
+    if (b > 0) {
+        a /= b;
+        return b * sqrt(1 + a * a);
+    }
+    return 0;
+}
+
+static double dot_lanes(const double* x, const double* y, int m) {
+    double p = 0;
+    int k = 0;
+    if (m >= 4) {
+        double s0 = 0, s1 = 0;
+        for (; k <= m - 2; k += 2) {
+            s0 = s0 + x[k] * y[k];
+            s1 = s1 + x[k + 1] * y[k + 1];
+        }
+        p = s0 + s1;
+    }
+    for (; k < m; ++k) p += x[k] * y[k];
+    return p;
+}
+
+#define SVD_MAXN 12
+#define SVD_MAXM 32
+
+static void jacobi_core(double* At /* n x m */, int m, int n, double* W, double* Vt /* n x n */) {
+    const double eps = DBL_EPSILON * 10;
+    const int max_iter = m > 30 ? m : 30;
+    for (int i = 0; i < n; ++i) {
+        double sd = 0;
+        for (int k = 0; k < m; ++k) {
+            const double t = At[i * m + k];
+            sd += t * t;
+        }
+        W[i] = sd;
+        for (int k = 0; k < n; ++k) Vt[i * n + k] = 0;
+        Vt[i * n + i] = 1;
+    }
+    for (int iter = 0; iter < max_iter; ++iter) {
+        int changed = 0;
+        for (int i = 0; i < n - 1; ++i)
+            for (int j = i + 1; j < n; ++j) {
+                double* Ai = At + i * m;
+                double* Aj = At + j * m;
+                double a = W[i], b = W[j];
+                double p = dot_lanes(Ai, Aj, m);
+                if (fabs(p) <= eps * sqrt(a * b)) continue;
+                p *= 2;
+                const double beta = a - b, gamma = svd_hypot(p, beta);
+                double c, s;
+                if (beta < 0) {
+                    const double delta = (gamma - beta) * 0.5;
+                    s = sqrt(delta / gamma);
+                    c = p / (gamma * s * 2);
+                } else {
+                    c = sqrt((gamma + beta) / (gamma * 2));
+                    s = p / (gamma * c * 2);
+                }
+                /* rotate the two columns; new squared norms in the same lane order as dot_lanes */
+                {
+                    int k = 0;
+                    a = b = 0;
+                    if (m >= 4) {
+                        double a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+                        for (; k <= m - 2; k += 2) {
+                            const double t0 = c * Ai[k] + s * Aj[k], t1 = c * Aj[k] - s * Ai[k];
+                            const double u0 = c * Ai[k + 1] + s * Aj[k + 1], u1 = c * Aj[k + 1] - s * Ai[k + 1];
+                            Ai[k] = t0; Aj[k] = t1; Ai[k + 1] = u0; Aj[k + 1] = u1;
+                            a0 = a0 + t0 * t0; b0 = b0 + t1 * t1;
+                            a1 = a1 + u0 * u0; b1 = b1 + u1 * u1;
+                        }
+                        a = a0 + a1;
+                        b = b0 + b1;
+                    }
+                    for (; k < m; ++k) {
+                        const double t0 = c * Ai[k] + s * Aj[k], t1 = -s * Ai[k] + c * Aj[k];
+                        Ai[k] = t0; Aj[k] = t1;
+                        a += t0 * t0;
+                        b += t1 * t1;
+                    }
+                }
+                W[i] = a;
+                W[j] = b;
+                changed = 1;
+                double* Vi = Vt + i * n;
+                double* Vj = Vt + j * n;
+                for (int k = 0; k < n; ++k) {
+                    const double t0 = c * Vi[k] + s * Vj[k], t1 = -s * Vi[k] + c * Vj[k];
+                    Vi[k] = t0; Vj[k] = t1;
+                }
+            }
+        if (!changed) break;
+    }
+    for (int i = 0; i < n; ++i) {
+        double sd = 0;
+        for (int k = 0; k < m; ++k) {
+            const double t = At[i * m + k];
+            sd += t * t;
+        }
+        W[i] = sqrt(sd);
+    }
+    for (int i = 0; i < n - 1; ++i) {
+        int j = i;
+        for (int k = i + 1; k < n; ++k)
+            if (W[j] < W[k]) j = k;
+        if (i != j) {
+            double tmp = W[i]; W[i] = W[j]; W[j] = tmp;
+            for (int k = 0; k < m; ++k) { tmp = At[i * m + k]; At[i * m + k] = At[j * m + k]; At[j * m + k] = tmp; }
+            for (int k = 0; k < n; ++k) { tmp = Vt[i * n + k]; Vt[i * n + k] = Vt[j * n + k]; Vt[j * n + k] = tmp; }
+        }
+    }
+}
+
+void orc_jacobi_svd(const double* A, int m, int n, double* w, double* U, double* Vt) {
+    double At[SVD_MAXN * SVD_MAXM];
+    if (n > SVD_MAXN || m > SVD_MAXM || m < n) return;
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < m; ++k) At[i * m + k] = A[k * n + i];
+    jacobi_core(At, m, n, w, Vt);
+    if (U) {
+        /* left vectors = rotated columns / singular value (zero columns stay zero) */
+        for (int i = 0; i < n; ++i) {
+            const double s = w[i] > DBL_MIN ? 1 / w[i] : 0;
+            for (int k = 0; k < m; ++k) U[k * n + i] = At[i * m + k] * s;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A4  cv2.triangulatePoints(P1, P2, points1, points2); cloud / cloud[3]        sfm.py:53-54
+ * rows=4: current OpenCV (per view x*P[2]-P[0], y*P[2]-P[1]);  rows=6: legacy
+ * cvTriangulatePoints (third row x*P[1]-y*P[0]) — the release the reference ran is unknown.
+ * X = last row of Vt in fp64, stored as float32 (the dtype of the 2-D points); the reference
+ * then divides all four rows by row 3 in float32.
+ * ---------------------------------------------------------------------------------------- */
+void orc_triangulate_dlt(const double* P1, const double* P2, const float* x1, const float* x2, int64_t n,
+                         int64_t stride_pt, int64_t stride_xy, int rows, int normalise_w, float* X4) {
+    const double* P[2] = {P1, P2};
+    const float* xs[2] = {x1, x2};
+    const int per = rows / 2; /* 2 or 3 rows per view */
+    for (int64_t i = 0; i < n; ++i) {
+        double A[6 * 4], w[4], Vt[16];
+        for (int v = 0; v < 2; ++v) {
+            const double x = (double)xs[v][i * stride_pt];
+            const double y = (double)xs[v][i * stride_pt + stride_xy];
+            for (int k = 0; k < 4; ++k) {
+                A[(v * per + 0) * 4 + k] = x * P[v][8 + k] - P[v][0 + k];
+                A[(v * per + 1) * 4 + k] = y * P[v][8 + k] - P[v][4 + k];
+                if (per == 3) A[(v * per + 2) * 4 + k] = x * P[v][4 + k] - y * P[v][0 + k];
+            }
+        }
+        orc_jacobi_svd(A, rows, 4, w, NULL, Vt);
+        float X[4];
+        for (int k = 0; k < 4; ++k) X[k] = (float)Vt[12 + k];
+        if (normalise_w) {
+            const float ww = X[3];
+            for (int k = 0; k < 4; ++k) X[k] = X[k] / ww;
+        }
+        for (int k = 0; k < 4; ++k) X4[k * n + i] = X[k];
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * cv2.Rodrigues                                                            sfm.py:69,84,119
+ * vec→mat: R = cos(th) I + (1-cos(th)) r r^T + sin(th) [r]x, th = |rvec|, r = rvec/th;
+ * th < DBL_EPSILON → identity.  J = dR/drvec (3x9), derived from the same closed form.
+ * mat→vec: orthonormalise by SVD (R ← U Vt), axis from the antisymmetric part, angle
+ * from the trace; the near-pi branch recovers the axis from the diagonal.
+ * ---------------------------------------------------------------------------------------- */
+void orc_rodrigues_vec2mat(const double* rv, double* R, double* J) {
+    const double theta = sqrt(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
+    if (theta < DBL_EPSILON) {
+        for (int k = 0; k < 9; ++k) R[k] = (k % 4 == 0) ? 1.0 : 0.0;
+        if (J) {
+            memset(J, 0, 27 * sizeof(double));
+            /* dR/dr at 0 is the generator of rotations: d[r]x/dr_i */
+            J[5] = J[15] = J[19] = -1;
+            J[7] = J[11] = J[21] = 1;
+        }
+        return;
+    }
+    const double c = cos(theta), s = sin(theta), c1 = 1. - c, itheta = 1. / theta;
+    const double r[3] = {rv[0] * itheta, rv[1] * itheta, rv[2] * itheta};
+    const double rrt[9] = {r[0] * r[0], r[0] * r[1], r[0] * r[2], r[0] * r[1], r[1] * r[1],
+                           r[1] * r[2], r[0] * r[2], r[1] * r[2], r[2] * r[2]};
+    const double rx[9] = {0, -r[2], r[1], r[2], 0, -r[0], -r[1], r[0], 0};
+    for (int k = 0; k < 9; ++k) R[k] = c * ((k % 4 == 0) ? 1.0 : 0.0) + c1 * rrt[k] + s * rx[k];
+    if (J) {
+        /* d(r r^T)/dr_i (of the UNIT axis) and d[r]x/dr_i, laid out 3 x 9 */
+        const double drrt[27] = {r[0] + r[0], r[1], r[2], r[1], 0, 0, r[2], 0, 0,
+                                 0, r[0], 0, r[0], r[1] + r[1], r[2], 0, r[2], 0,
+                                 0, 0, r[0], 0, 0, r[1], r[0], r[1], r[2] + r[2]};
+        const double drx[27] = {0, 0, 0, 0, 0, -1, 0, 1, 0,
+                                0, 0, 1, 0, 0, 0, -1, 0, 0,
+                                0, -1, 0, 1, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 3; ++i) {
+            const double ri = r[i];
+            const double a0 = -s * ri, a1 = (s - 2 * c1 * itheta) * ri, a2 = c1 * itheta;
+            const double a3 = (c - s * itheta) * ri, a4 = s * itheta;
+            for (int k = 0; k < 9; ++k)
+                J[i * 9 + k] = a0 * ((k % 4 == 0) ? 1.0 : 0.0) + a1 * rrt[k] + a2 * drrt[i * 9 + k] + a3 * rx[k] +
+                               a4 * drx[i * 9 + k];
+        }
+    }
+}
+
+void orc_rodrigues_mat2vec(const double* Rin, double* r) {
+    double w[3], U[9], Vt[9], R[9];
+    orc_jacobi_svd(Rin, 3, 3, w, U, Vt);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = 0;
+            for (int k = 0; k < 3; ++k) s += U[i * 3 + k] * Vt[k * 3 + j];
+            R[i * 3 + j] = s;
+        }
+    double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
+    const double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
+    double c = (R[0] + R[4] + R[8] - 1) * 0.5;
+    c = c > 1. ? 1. : c < -1. ? -1. : c;
+    double theta = acos(c);
+    if (s < 1e-5) {
+        if (c > 0) {
+            rx = ry = rz = 0;
+        } else {
+            double t;
+            t = (R[0] + 1) * 0.5;
+            rx = sqrt(t > 0. ? t : 0.);
+            t = (R[4] + 1) * 0.5;
+            ry = sqrt(t > 0. ? t : 0.) * (R[1] < 0 ? -1. : 1.);
+            t = (R[8] + 1) * 0.5;
+            rz = sqrt(t > 0. ? t : 0.) * (R[2] < 0 ? -1. : 1.);
+            if (fabs(rx) < fabs(ry) && fabs(rx) < fabs(rz) && (R[5] > 0) != (ry * rz > 0)) rz = -rz;
+            theta /= sqrt(rx * rx + ry * ry + rz * rz);
+            rx *= theta; ry *= theta; rz *= theta;
+        }
+    } else {
+        double vth = 1 / (2 * s);
+        vth *= theta;
+        rx *= vth; ry *= vth; rz *= vth;
+    }
+    r[0] = rx; r[1] = ry; r[2] = rz;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * cv2.projectPoints(X, r, t, K, distCoeffs=None)                              sfm.py:88,121
+ * fp64: X' = R X + t; z = 1/Z' (1 if Z'==0); x = X' z; y = Y' z; u = x fx + cx; v = y fy + cy.
+ * Skew K[0][1] is ignored.  Output dtype follows the object points (float32 at sfm.py:88).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    double R[9], t[3], fx, fy, cx, cy;
+} cam_t;
+
+static void cam_init(cam_t* c, const double* rvec, const double* tvec, const double* K, double* dRdr) {
+    orc_rodrigues_vec2mat(rvec, c->R, dRdr);
+    c->t[0] = tvec[0]; c->t[1] = tvec[1]; c->t[2] = tvec[2];
+    c->fx = K[0]; c->fy = K[4]; c->cx = K[2]; c->cy = K[5];
+}
+
+static inline void cam_project(const cam_t* c, double X, double Y, double Z, double* u, double* v, double* xyz) {
+    const double* R = c->R;
+    double x = R[0] * X + R[1] * Y + R[2] * Z + c->t[0];
+    double y = R[3] * X + R[4] * Y + R[5] * Z + c->t[1];
+    double z = R[6] * X + R[7] * Y + R[8] * Z + c->t[2];
+    z = z ? 1. / z : 1;
+    x *= z;
+    y *= z;
+    *u = x * c->fx + c->cx;
+    *v = y * c->fy + c->cy;
+    if (xyz) { xyz[0] = x; xyz[1] = y; xyz[2] = z; }
+}
+
+void orc_project_points(const double* rvec, const double* tvec, const double* K, const float* X, int64_t n,
+                        int64_t ldx, double* proj64, float* proj32) {
+    cam_t c;
+    cam_init(&c, rvec, tvec, K, NULL);
+    for (int64_t i = 0; i < n; ++i) {
+        double u, v;
+        cam_project(&c, X[i * ldx], X[i * ldx + 1], X[i * ldx + 2], &u, &v, NULL);
+        if (proj64) { proj64[2 * i] = u; proj64[2 * i + 1] = v; }
+        if (proj32) { proj32[2 * i] = (float)u; proj32[2 * i + 1] = (float)v; }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A5  ReprojectionError                                                        sfm.py:79-100
+ * r = Rodrigues(R); p = float32(projectPoints(X, r, t, K)); err = cv2.norm(p, pts, NORM_L2)/len(p)
+ * cv2.norm on float32: differences in float32, squares accumulated in double, 4 at a time.
+ * ---------------------------------------------------------------------------------------- */
+double orc_reprojection_error(const double* Rt, const double* K, const float* X, int64_t n, int64_t ldx,
+                              const float* obs, float* proj32) {
+    double R[9], t[3], rvec[3];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) R[i * 3 + j] = Rt[i * 4 + j];
+        t[i] = Rt[i * 4 + 3];
+    }
+    orc_rodrigues_mat2vec(R, rvec);
+    float* p = proj32 ? proj32 : (float*)malloc(sizeof(float) * 2 * (size_t)(n > 0 ? n : 1));
+    orc_project_points(rvec, t, K, X, n, ldx, NULL, p);
+    const int64_t len = 2 * n;
+    int64_t i = 0;
+    double s = 0;
+    for (; i <= len - 4; i += 4) {
+        const double v0 = (double)(p[i] - obs[i]), v1 = (double)(p[i + 1] - obs[i + 1]);
+        const double v2 = (double)(p[i + 2] - obs[i + 2]), v3 = (double)(p[i + 3] - obs[i + 3]);
+        s += v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3;
+    }
+    for (; i < len; ++i) {
+        const double v = (double)(p[i] - obs[i]);
+        s += v * v;
+    }
+    if (!proj32) free(p);
+    return sqrt(s) / (double)n;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Observation sweep (A5/A6/A8): projection, residual = proj - obs, analytic Jacobians in
+ * (rvec, tvec) and X exactly as projectPoints' dpdr/dpdt produce them, Gauss-Newton blocks.
+ * Sums run in observation order (fp64).
+ * ---------------------------------------------------------------------------------------- */
+void orc_project_residual(const double* cams, int64_t ncam, const double* K, const float* X, int64_t npt,
+                          int64_t ldx, const float* obs, const int32_t* cam_idx, const int32_t* pt_idx,
+                          int64_t nobs, float* proj, double* sumsq, uint8_t* inlier, float thr2, double* JtJ_cam,
+                          double* Jtr_cam, double* JtJ_pt, double* Jtr_pt, int nthreads) {
+    (void)nthreads;
+    (void)npt;
+    cam_t* cs = (cam_t*)malloc(sizeof(cam_t) * (size_t)ncam);
+    double* dR = (double*)malloc(sizeof(double) * 27 * (size_t)ncam);
+    for (int64_t c = 0; c < ncam; ++c) cam_init(&cs[c], cams + 6 * c, cams + 6 * c + 3, K, dR + 27 * c);
+    const int want_j = JtJ_cam || Jtr_cam || JtJ_pt || Jtr_pt;
+    double ss = 0;
+    for (int64_t o = 0; o < nobs; ++o) {
+        const int64_t ci = cam_idx ? cam_idx[o] : 0, pi = pt_idx ? pt_idx[o] : o;
+        const cam_t* c = &cs[ci];
+        const double Xw = X[pi * ldx], Yw = X[pi * ldx + 1], Zw = X[pi * ldx + 2];
+        double u, v, xyz[3];
+        cam_project(c, Xw, Yw, Zw, &u, &v, xyz);
+        const float pu = (float)u, pv = (float)v;
+        if (proj) { proj[2 * o] = pu; proj[2 * o + 1] = pv; }
+        const float dxf = pu - obs[2 * o], dyf = pv - obs[2 * o + 1];
+        ss += (double)dxf * (double)dxf;
+        ss += (double)dyf * (double)dyf;
+        if (inlier) {
+            /* PnPRansacCallback::computeError: float diff (obs - proj), squared norm in double, cast to float */
+            const float ex = obs[2 * o] - pu, ey = obs[2 * o + 1] - pv;
+            const float e = (float)((double)ex * (double)ex + (double)ey * (double)ey);
+            inlier[o] = e <= thr2;
+        }
+        if (want_j) {
+            const double x = xyz[0], y = xyz[1], z = xyz[2];
+            const double ru = u - (double)obs[2 * o], rv = v - (double)obs[2 * o + 1];
+            double Jc[2][6], Jp[2][3];
+            const double* dRdr = dR + 27 * ci;
+            for (int j = 0; j < 3; ++j) {
+                const double dx0 = Xw * dRdr[j * 9 + 0] + Yw * dRdr[j * 9 + 1] + Zw * dRdr[j * 9 + 2];
+                const double dy0 = Xw * dRdr[j * 9 + 3] + Yw * dRdr[j * 9 + 4] + Zw * dRdr[j * 9 + 5];
+                const double dz0 = Xw * dRdr[j * 9 + 6] + Yw * dRdr[j * 9 + 7] + Zw * dRdr[j * 9 + 8];
+                Jc[0][j] = c->fx * (z * (dx0 - x * dz0));
+                Jc[1][j] = c->fy * (z * (dy0 - y * dz0));
+            }
+            Jc[0][3] = c->fx * z; Jc[0][4] = 0;          Jc[0][5] = c->fx * (-x * z);
+            Jc[1][3] = 0;         Jc[1][4] = c->fy * z;  Jc[1][5] = c->fy * (-y * z);
+            for (int k = 0; k < 3; ++k) {
+                Jp[0][k] = c->fx * (z * (c->R[k] - x * c->R[6 + k]));
+                Jp[1][k] = c->fy * (z * (c->R[3 + k] - y * c->R[6 + k]));
+            }
+            if (JtJ_cam)
+                for (int a = 0; a < 6; ++a)
+                    for (int b = 0; b < 6; ++b) JtJ_cam[ci * 36 + a * 6 + b] += Jc[0][a] * Jc[0][b] + Jc[1][a] * Jc[1][b];
+            if (Jtr_cam)
+                for (int a = 0; a < 6; ++a) Jtr_cam[ci * 6 + a] += Jc[0][a] * ru + Jc[1][a] * rv;
+            if (JtJ_pt)
+                for (int a = 0; a < 3; ++a)
+                    for (int b = 0; b < 3; ++b) JtJ_pt[pi * 9 + a * 3 + b] += Jp[0][a] * Jp[0][b] + Jp[1][a] * Jp[1][b];
+            if (Jtr_pt)
+                for (int a = 0; a < 3; ++a) Jtr_pt[pi * 3 + a] += Jp[0][a] * ru + Jp[1][a] * rv;
+        }
+    }
+    if (sumsq) *sumsq += ss;
+    free(cs);
+    free(dR);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A9  common_points                                                          sfm.py:215-239
+ * np.where(pts2 == pts1[i, :]) broadcasts element-wise: a row of pts2 "matches" when its x OR
+ * its y equals (bit-exact float ==); a[0][0] is the first such row.  Duplicates in idx2 are
+ * allowed.  The complement is `mask[idx2] = True` then compressed().
+ * ---------------------------------------------------------------------------------------- */
+int64_t orc_common_points(const float* pts1, int64_t n1, const float* pts2, int64_t n2, int64_t* idx1,
+                          int64_t* idx2, uint8_t* keep2) {
+    int64_t m = 0;
+    for (int64_t r = 0; r < n2; ++r) keep2[r] = 1;
+    for (int64_t i = 0; i < n1; ++i) {
+        const float x = pts1[2 * i], y = pts1[2 * i + 1];
+        for (int64_t r = 0; r < n2; ++r)
+            if (pts2[2 * r] == x || pts2[2 * r + 1] == y) {
+                idx1[m] = i;
+                idx2[m] = r;
+                ++m;
+                break;
+            }
+    }
+    for (int64_t k = 0; k < m; ++k) keep2[idx2[k]] = 0;
+    return m;
+}
+
+/* sfm.py:169-181  to_ply: scale by 200, keep rows with dist < mean(dist) + 300 about the centroid. */
+int64_t orc_to_ply_filter(const double* pts, int64_t n, double* scaled, uint8_t* keep) {
+    double mean[3] = {0, 0, 0};
+    for (int64_t i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) {
+            scaled[3 * i + k] = pts[3 * i + k] * 200;
+            mean[k] += scaled[3 * i + k];
+        }
+    for (int k = 0; k < 3; ++k) mean[k] /= (double)n;
+    double* dist = (double*)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    double md = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const double a = scaled[3 * i] - mean[0], b = scaled[3 * i + 1] - mean[1], c = scaled[3 * i + 2] - mean[2];
+        dist[i] = sqrt(a * a + b * b + c * c);
+        md += dist[i];
+    }
+    md /= (double)n;
+    int64_t kept = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        keep[i] = dist[i] < md + 300;
+        kept += keep[i];
+    }
+    free(dist);
+    return kept;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * A7  findEssentialMat RANSAC error: Sampson distance on K-normalised points, as float32.
+ *                                                                              sfm.py:307
+ * ---------------------------------------------------------------------------------------- */
+void orc_score_essential(const double* Es, int h, const double* x1n, const double* x2n, int64_t n, float thr2,
+                         int32_t* counts, uint8_t* mask) {
+    for (int m = 0; m < h; ++m) {
+        const double* E = Es + 9 * m;
+        int32_t cnt = 0;
+        for (int64_t i = 0; i < n; ++i) {
+            const double x1[3] = {x1n[2 * i], x1n[2 * i + 1], 1.}, x2[3] = {x2n[2 * i], x2n[2 * i + 1], 1.};
+            double Ex1[3], Etx2[3];
+            for (int r = 0; r < 3; ++r) {
+                Ex1[r] = E[r * 3] * x1[0] + E[r * 3 + 1] * x1[1] + E[r * 3 + 2] * x1[2];
+                Etx2[r] = E[r] * x2[0] + E[3 + r] * x2[1] + E[6 + r] * x2[2];
+            }
+            const double x2tEx1 = x2[0] * Ex1[0] + x2[1] * Ex1[1] + x2[2] * Ex1[2];
+            const double a = Ex1[0] * Ex1[0], b = Ex1[1] * Ex1[1], c = Etx2[0] * Etx2[0], d = Etx2[1] * Etx2[1];
+            const float err = (float)(x2tEx1 * x2tEx1 / (a + b + c + d));
+            const int in = err <= thr2;
+            if (mask) mask[(int64_t)m * n + i] = (uint8_t)in;
+            cnt += in;
+        }
+        counts[m] = cnt;
+    }
+}
+
+/* A6  solvePnPRansac model scoring: float32 projection, float diff, squared norm → float ≤ thr2.  sfm.py:67 */
+void orc_score_pnp(const double* poses, int h, const double* K, const float* X, const float* obs, int64_t n,
+                   float thr2, int32_t* counts, uint8_t* mask) {
+    for (int m = 0; m < h; ++m) {
+        cam_t c;
+        cam_init(&c, poses + 6 * m, poses + 6 * m + 3, K, NULL);
+        int32_t cnt = 0;
+        for (int64_t i = 0; i < n; ++i) {
+            double u, v;
+            cam_project(&c, X[3 * i], X[3 * i + 1], X[3 * i + 2], &u, &v, NULL);
+            const float ex = obs[2 * i] - (float)u, ey = obs[2 * i + 1] - (float)v;
+            const float e = (float)((double)ex * (double)ex + (double)ey * (double)ey);
+            const int in = e <= thr2;
+            if (mask) mask[(int64_t)m * n + i] = (uint8_t)in;
+            cnt += in;
+        }
+        counts[m] = cnt;
+    }
+}

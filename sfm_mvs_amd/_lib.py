@@ -1,0 +1,86 @@
+"""ctypes binding of libsfmhip.so (include/sfm_hip.h).
+
+The HIP library is the ONLY implementation of the hot path: if it is missing or a call
+fails this module raises — there is no CPU or PyTorch fallback.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (loads the ROCm runtime torch was built with before our .so binds to it)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsfmhip.so")
+
+ABI_VERSION = 1
+
+
+class SfmHipError(RuntimeError):
+    """A libsfmhip.so entry point returned a negative status."""
+
+
+_c = ctypes
+_i64, _i32, _int, _f32, _f64, _sz, _vp = (_c.c_int64, _c.c_int32, _c.c_int, _c.c_float, _c.c_double,
+                                          _c.c_size_t, _c.c_void_p)
+
+# name -> (restype, argtypes); mirrors include/sfm_hip.h one to one
+SIGNATURES = {
+    "sfm_abi_version": (_int, []),
+    "sfm_last_error": (_c.c_char_p, []),
+    "sfm_knn2_l2_f32_ws_bytes": (_sz, [_i64, _i64, _int]),
+    "sfm_knn2_l2_f32": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _int, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sfm_ratio_compact": (_int, [_vp, _vp, _i64, _f64, _vp, _vp, _vp, _vp, _vp]),
+    "sfm_gather_matches": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "sfm_triangulate_dlt": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _int, _int, _vp, _vp]),
+    "sfm_project_residual_ws_bytes": (_sz, [_i64, _i64, _i64]),
+    "sfm_project_residual": (_int, [_vp, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _f32,
+                                    _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sfm_ba_dense_sweep_ws_bytes": (_sz, [_i64, _i64]),
+    "sfm_ba_dense_sweep": (_int, [_vp, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sfm_score_essential": (_int, [_vp, _int, _vp, _vp, _i64, _f32, _vp, _vp, _vp]),
+    "sfm_score_pnp": (_int, [_vp, _int, _vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libsfmhip.so once; raise loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` (or `make -C sfm_mvs_amd/csrc`). "
+            "There is no CPU fallback for the hot path.")
+    handle = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(handle, name)  # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    got = handle.sfm_abi_version()
+    if got != ABI_VERSION:
+        raise ImportError(f"libsfmhip.so ABI {got} != binding ABI {ABI_VERSION}; rebuild")
+    _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().sfm_last_error()
+        raise SfmHipError(f"{what} failed (status {rc}): {msg.decode() if msg else '?'}")
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise SfmHipError("libsfmhip operates on device (HBM) tensors only; got a CPU tensor — "
+                              "there is no CPU fallback")
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,59 @@
+// Shared host-side helpers for libsfmhip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include "../../include/sfm_hip.h"
+
+namespace sfm {
+
+void set_error(const char* fmt, ...);
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Carve aligned sub-buffers out of the caller's workspace.
+struct Carver {
+    char* base;
+    size_t off = 0;
+    explicit Carver(void* p) : base(static_cast<char*>(p)) {}
+    template <typename T> T* take(size_t count) {
+        off = align_up(off, 256);
+        T* p = reinterpret_cast<T*>(base + off);
+        off += count * sizeof(T);
+        return p;
+    }
+    size_t used() const { return align_up(off, 256); }
+};
+
+}  // namespace sfm
+
+#define SFM_CHECK_ARG(cond, ...)                 \
+    do {                                         \
+        if (!(cond)) {                           \
+            sfm::set_error(__VA_ARGS__);         \
+            return SFM_ERR_ARG;                  \
+        }                                        \
+    } while (0)
+
+#define SFM_CHECK_HIP(expr)                                                           \
+    do {                                                                              \
+        hipError_t e_ = (expr);                                                       \
+        if (e_ != hipSuccess) {                                                       \
+            sfm::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),     \
+                           __FILE__, __LINE__);                                       \
+            return SFM_ERR_DEVICE;                                                    \
+        }                                                                             \
+    } while (0)
+
+#define SFM_CHECK_LAUNCH()                                                            \
+    do {                                                                              \
+        hipError_t e_ = hipGetLastError();                                            \
+        if (e_ != hipSuccess) {                                                       \
+            sfm::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), \
+                           __FILE__, __LINE__);                                       \
+            return SFM_ERR_DEVICE;                                                    \
+        }                                                                             \
+    } while (0)
