@@ -146,8 +146,9 @@ int sfm_project_residual(const double* cams_dev, int64_t ncam, const double* K_h
 
 /* Dense visibility variant (BASELINE config 4: every camera sees every point).
  * obs_dev is [ncam x npt x 2] float32.  Same arithmetic as above; per-camera
- * blocks are reduced in registers and per-point blocks are owned by one lane,
- * so the result is deterministic and needs no atomics. */
+ * blocks are reduced in a fixed order and per-point blocks are owned by one lane,
+ * so the result is deterministic and needs no atomics.  All outputs (sumsq
+ * included) are OVERWRITTEN, not accumulated; JtJ_* / Jtr_* may be NULL. */
 size_t sfm_ba_dense_sweep_ws_bytes(int64_t ncam, int64_t npt);
 int sfm_ba_dense_sweep(const double* cams_dev, int64_t ncam, const double* K_host,
                        const float* X_dev, int64_t npt, int64_t ldx,
@@ -175,6 +176,17 @@ int sfm_score_essential(const double* E_dev, int h, const double* x1n_dev,
 int sfm_score_pnp(const double* poses_dev, int h, const double* K_host,
                   const float* X_dev, const float* obs_dev, int64_t n, float thr2,
                   int32_t* counts_dev, uint8_t* mask_dev, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Measurement hook (no reference counterpart): when enabled, the library brackets
+ * its dominant kernels with hipEvents recorded on the launch stream.
+ * sfm_profile_read synchronises those events, returns the summed device time
+ * and launch count of one slot, and resets the slot.
+ *   slot 0 knn filter (MFMA)   1 knn refine+fallback   2 triangulate
+ *        3 dense BA sweep       4 indexed residual sweep
+ * ---------------------------------------------------------------------- */
+int sfm_profile_enable(int on);
+int sfm_profile_read(int slot, double* total_ms_host, int64_t* launches_host);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,332 @@
+// Dense-visibility Gauss-Newton sweep (BASELINE config 4: 500 cameras x 200 000 points = 1e8
+// observations): the residual function of sfm.py:104-136 (OptimReprojectionError) with its analytic
+// Jacobians, accumulated into the per-camera 6x6 / 6 and per-point 3x3 / 3 normal-equation blocks a
+// sparse BA solver consumes — instead of the reference's (5N+22) finite-difference evaluations per
+// Jacobian (scipy least_squares, sfm.py:146).
+//
+// Layout / roofline: obs is [ncam][npt][2] float32, streamed exactly once with 8-byte coalesced
+// loads (8 B per observation is the algorithmic HBM traffic); points are float32 [npt][ldx].
+// Arithmetic is fp64 (~210 DP instructions per observation) so the kernel sits on the fp64 VALU
+// roof, not HBM — both are reported by bench.py --workload ba.
+//
+// Decomposition: block = 256 lanes, lane owns PP points (registers hold their 3x3+3 accumulators
+// for the whole camera loop); blockIdx.y selects a camera chunk.  Per camera the 27+1 camera-side
+// sums of the block's 256*PP observations are reduced in a fixed order through LDS
+// ([value][segment][lane] with odd strides: conflict-free writes, <=2-way reads) and written as one
+// partial row per (tile, camera).  Two small fixed-order kernels fold the partials → deterministic,
+// no floating-point atomics anywhere.
+#include "common.h"
+#include <cfloat>
+
+namespace {
+
+constexpr int kCamStride = 40;
+constexpr int kNAcc = 28;          // 21 upper JtJ + 6 Jtr + 1 sumsq
+constexpr int kSegStride = 33;     // doubles; 32 lanes + 1 pad
+constexpr int kValStride = 8 * kSegStride + 1;
+
+struct Intrin {
+    double fx, fy, cx, cy;
+};
+
+__device__ void rodrigues_dev2(const double* __restrict__ rv, double* __restrict__ R, double* __restrict__ J) {
+    const double theta = sqrt(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
+    if (theta < DBL_EPSILON) {
+        for (int k = 0; k < 9; ++k) R[k] = (k % 4 == 0) ? 1.0 : 0.0;
+        for (int k = 0; k < 27; ++k) J[k] = 0;
+        J[5] = J[15] = J[19] = -1;
+        J[7] = J[11] = J[21] = 1;
+        return;
+    }
+    const double c = cos(theta), s = sin(theta), c1 = 1. - c, itheta = 1. / theta;
+    const double r[3] = {rv[0] * itheta, rv[1] * itheta, rv[2] * itheta};
+    const double rrt[9] = {r[0] * r[0], r[0] * r[1], r[0] * r[2], r[0] * r[1], r[1] * r[1],
+                           r[1] * r[2], r[0] * r[2], r[1] * r[2], r[2] * r[2]};
+    const double rx[9] = {0, -r[2], r[1], r[2], 0, -r[0], -r[1], r[0], 0};
+    for (int k = 0; k < 9; ++k) R[k] = c * ((k % 4 == 0) ? 1.0 : 0.0) + c1 * rrt[k] + s * rx[k];
+    const double drrt[27] = {r[0] + r[0], r[1], r[2], r[1], 0, 0, r[2], 0, 0,
+                             0, r[0], 0, r[0], r[1] + r[1], r[2], 0, r[2], 0,
+                             0, 0, r[0], 0, 0, r[1], r[0], r[1], r[2] + r[2]};
+    const double drx[27] = {0, 0, 0, 0, 0, -1, 0, 1, 0, 0, 0, 1, 0, 0, 0, -1, 0, 0, 0, -1, 0, 1, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 3; ++i) {
+        const double ri = r[i];
+        const double a0 = -s * ri, a1 = (s - 2 * c1 * itheta) * ri, a2 = c1 * itheta;
+        const double a3 = (c - s * itheta) * ri, a4 = s * itheta;
+        for (int k = 0; k < 9; ++k)
+            J[i * 9 + k] = a0 * ((k % 4 == 0) ? 1.0 : 0.0) + a1 * rrt[k] + a2 * drrt[i * 9 + k] + a3 * rx[k] +
+                           a4 * drx[i * 9 + k];
+    }
+}
+
+__global__ void dense_cam_prepare_kernel(const double* __restrict__ cams, int64_t ncam, double* __restrict__ table) {
+    const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (c >= ncam) return;
+    double R[9], J[27];
+    rodrigues_dev2(cams + 6 * c, R, J);
+    double* e = table + c * kCamStride;
+    for (int k = 0; k < 9; ++k) e[k] = R[k];
+    for (int k = 0; k < 3; ++k) e[9 + k] = cams[6 * c + 3 + k];
+    for (int k = 0; k < 27; ++k) e[12 + k] = J[k];
+    e[39] = 0;
+}
+
+template <int PP>
+__global__ __launch_bounds__(256) void ba_dense_kernel(const double* __restrict__ table, Intrin K, int ncam,
+                                                       const float* __restrict__ X, int64_t npt, int64_t ldx,
+                                                       const float* __restrict__ obs, int nch,
+                                                       double* __restrict__ cam_part /*[tiles][ncam][28]*/,
+                                                       double* __restrict__ pt_part /*[nch][npt][9]*/) {
+    extern __shared__ __attribute__((aligned(16))) double red[];   // kNAcc * kValStride doubles
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x, ch = blockIdx.y;
+    const int c_begin = (int)((int64_t)ncam * ch / nch), c_end = (int)((int64_t)ncam * (ch + 1) / nch);
+    const int64_t p0 = (int64_t)tile * (256 * PP) + tid;
+
+    double Xw[PP], Yw[PP], Zw[PP];
+    bool live[PP];
+    double pacc[PP][9];   // 6 upper 3x3 + 3
+#pragma unroll
+    for (int pp = 0; pp < PP; ++pp) {
+        const int64_t p = p0 + 256 * pp;
+        live[pp] = p < npt;
+        const int64_t ps = live[pp] ? p : 0;
+        Xw[pp] = X[ps * ldx];
+        Yw[pp] = X[ps * ldx + 1];
+        Zw[pp] = X[ps * ldx + 2];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) pacc[pp][k] = 0;
+    }
+
+    const int wseg = tid >> 5, wlane = tid & 31;   // LDS slot of this lane's contribution
+    const int rk = tid >> 3, rseg = tid & 7;       // reducer role: value rk (<28), segment rseg
+
+    for (int c = c_begin; c < c_end; ++c) {
+        const double* __restrict__ e = table + (int64_t)c * kCamStride;
+        double cacc[kNAcc];
+#pragma unroll
+        for (int k = 0; k < kNAcc; ++k) cacc[k] = 0;
+        float2 ob[PP];
+#pragma unroll
+        for (int pp = 0; pp < PP; ++pp) {
+            const int64_t p = p0 + 256 * pp;
+            ob[pp] = live[pp] ? *reinterpret_cast<const float2*>(obs + ((int64_t)c * npt + p) * 2) : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int pp = 0; pp < PP; ++pp) {
+            if (!live[pp]) continue;
+            double x = e[0] * Xw[pp] + e[1] * Yw[pp] + e[2] * Zw[pp] + e[9];
+            double y = e[3] * Xw[pp] + e[4] * Yw[pp] + e[5] * Zw[pp] + e[10];
+            double z = e[6] * Xw[pp] + e[7] * Yw[pp] + e[8] * Zw[pp] + e[11];
+            z = z != 0.0 ? 1. / z : 1.;
+            x *= z;
+            y *= z;
+            const double u = x * K.fx + K.cx, v = y * K.fy + K.cy;
+            const float dxf = (float)u - ob[pp].x, dyf = (float)v - ob[pp].y;
+            cacc[27] += (double)dxf * (double)dxf + (double)dyf * (double)dyf;
+            const double ru = u - (double)ob[pp].x, rv = v - (double)ob[pp].y;
+            double Ju[6], Jv[6];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double* d = e + 12 + 9 * j;
+                const double dx0 = Xw[pp] * d[0] + Yw[pp] * d[1] + Zw[pp] * d[2];
+                const double dy0 = Xw[pp] * d[3] + Yw[pp] * d[4] + Zw[pp] * d[5];
+                const double dz0 = Xw[pp] * d[6] + Yw[pp] * d[7] + Zw[pp] * d[8];
+                Ju[j] = K.fx * (z * (dx0 - x * dz0));
+                Jv[j] = K.fy * (z * (dy0 - y * dz0));
+            }
+            Ju[3] = K.fx * z; Ju[4] = 0;        Ju[5] = K.fx * (-x * z);
+            Jv[3] = 0;        Jv[4] = K.fy * z; Jv[5] = K.fy * (-y * z);
+            {
+                int q = 0;
+#pragma unroll
+                for (int a = 0; a < 6; ++a)
+#pragma unroll
+                    for (int b = a; b < 6; ++b) {
+                        cacc[q] += Ju[a] * Ju[b] + Jv[a] * Jv[b];
+                        ++q;
+                    }
+#pragma unroll
+                for (int a = 0; a < 6; ++a) cacc[21 + a] += Ju[a] * ru + Jv[a] * rv;
+            }
+            double Pu[3], Pv[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                Pu[k] = K.fx * (z * (e[k] - x * e[6 + k]));
+                Pv[k] = K.fy * (z * (e[3 + k] - y * e[6 + k]));
+            }
+            {
+                int q = 0;
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int b = a; b < 3; ++b) {
+                        pacc[pp][q] += Pu[a] * Pu[b] + Pv[a] * Pv[b];
+                        ++q;
+                    }
+#pragma unroll
+                for (int a = 0; a < 3; ++a) pacc[pp][6 + a] += Pu[a] * ru + Pv[a] * rv;
+            }
+        }
+        // fixed-order block reduction of the 28 camera-side sums
+        __syncthreads();   // previous camera's readers are done
+#pragma unroll
+        for (int k = 0; k < kNAcc; ++k) red[k * kValStride + wseg * kSegStride + wlane] = cacc[k];
+        __syncthreads();
+        if (rk < kNAcc) {
+            const double* src = red + rk * kValStride + rseg * kSegStride;
+            double s = 0;
+#pragma unroll 8
+            for (int i = 0; i < 32; ++i) s += src[i];
+            s += __shfl_xor(s, 1, 64);
+            s += __shfl_xor(s, 2, 64);
+            s += __shfl_xor(s, 4, 64);
+            if (rseg == 0) cam_part[((int64_t)tile * ncam + c) * kNAcc + rk] = s;
+        }
+    }
+
+#pragma unroll
+    for (int pp = 0; pp < PP; ++pp) {
+        const int64_t p = p0 + 256 * pp;
+        if (live[pp]) {
+            double* dst = pt_part + ((int64_t)ch * npt + p) * 9;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) dst[k] = pacc[pp][k];
+        }
+    }
+}
+
+// one block per camera: thread k sums partial k over tiles in tile order
+__global__ void dense_cam_reduce_kernel(const double* __restrict__ cam_part, int tiles, int ncam,
+                                        double* __restrict__ JtJ_cam, double* __restrict__ Jtr_cam,
+                                        double* __restrict__ cam_sumsq) {
+    const int c = blockIdx.x, k = threadIdx.x;
+    if (k >= kNAcc) return;
+    double s = 0;
+    for (int t = 0; t < tiles; ++t) s += cam_part[((int64_t)t * ncam + c) * kNAcc + k];
+    if (k == 27) {
+        cam_sumsq[c] = s;
+    } else if (k >= 21) {
+        if (Jtr_cam) Jtr_cam[c * 6 + (k - 21)] = s;
+    } else if (JtJ_cam) {
+        int a = 0, rem = k;
+        while (rem >= 6 - a) { rem -= 6 - a; ++a; }
+        const int b = a + rem;
+        JtJ_cam[c * 36 + a * 6 + b] = s;
+        JtJ_cam[c * 36 + b * 6 + a] = s;
+    }
+}
+
+__global__ void dense_sumsq_kernel(const double* __restrict__ cam_sumsq, int ncam, double* __restrict__ sumsq) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0;
+        for (int c = 0; c < ncam; ++c) s += cam_sumsq[c];
+        *sumsq = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void dense_pt_reduce_kernel(const double* __restrict__ pt_part, int nch, int64_t npt,
+                                                              double* __restrict__ JtJ_pt, double* __restrict__ Jtr_pt) {
+    const int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (p >= npt) return;
+    double s[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s[k] = 0;
+    for (int ch = 0; ch < nch; ++ch) {
+        const double* src = pt_part + ((int64_t)ch * npt + p) * 9;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) s[k] += src[k];
+    }
+    if (JtJ_pt) {
+        double* d = JtJ_pt + p * 9;
+        d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+        d[3] = s[1]; d[4] = s[3]; d[5] = s[4];
+        d[6] = s[2]; d[7] = s[4]; d[8] = s[5];
+    }
+    if (Jtr_pt) {
+        Jtr_pt[p * 3 + 0] = s[6];
+        Jtr_pt[p * 3 + 1] = s[7];
+        Jtr_pt[p * 3 + 2] = s[8];
+    }
+}
+
+struct DensePlan {
+    int pp, tiles, nch;
+};
+
+DensePlan dense_plan(int64_t ncam, int64_t npt) {
+    DensePlan d;
+    d.pp = npt >= 256 * 1024 ? 4 : 2;
+    d.tiles = (int)((npt + 256 * d.pp - 1) / (256 * d.pp));
+    int nch = d.tiles > 0 ? (1024 + d.tiles - 1) / d.tiles : 1;
+    if (nch > ncam / 16) nch = (int)(ncam / 16);
+    if (nch < 1) nch = 1;
+    if (nch > 64) nch = 64;
+    d.nch = nch;
+    return d;
+}
+
+struct DenseWs {
+    double *table, *cam_part, *pt_part, *cam_sumsq;
+    size_t bytes;
+};
+
+DenseWs dense_carve(void* base, int64_t ncam, int64_t npt, const DensePlan& d) {
+    sfm::Carver c(base);
+    DenseWs w;
+    w.table = c.take<double>((size_t)ncam * kCamStride);
+    w.cam_sumsq = c.take<double>((size_t)ncam);
+    w.cam_part = c.take<double>((size_t)d.tiles * ncam * kNAcc);
+    w.pt_part = c.take<double>((size_t)d.nch * npt * 9);
+    w.bytes = c.used();
+    return w;
+}
+
+}  // namespace
+
+extern "C" size_t sfm_ba_dense_sweep_ws_bytes(int64_t ncam, int64_t npt) {
+    if (ncam < 1 || npt < 1) return 0;
+    return dense_carve(nullptr, ncam, npt, dense_plan(ncam, npt)).bytes + 256;
+}
+
+extern "C" int sfm_ba_dense_sweep(const double* cams, int64_t ncam, const double* K_host, const float* X, int64_t npt,
+                                  int64_t ldx, const float* obs, double* sumsq, double* JtJ_cam, double* Jtr_cam,
+                                  double* JtJ_pt, double* Jtr_pt, void* ws, size_t ws_bytes, void* stream_) {
+    SFM_CHECK_ARG(ncam >= 1 && npt >= 1 && ldx >= 3 && ncam < (1 << 24), "sfm_ba_dense_sweep: bad sizes");
+    SFM_CHECK_ARG(cams && K_host && X && obs, "sfm_ba_dense_sweep: null pointer");
+    SFM_CHECK_ARG(((uintptr_t)obs & 7) == 0, "sfm_ba_dense_sweep: obs must be 8-byte aligned");
+    const DensePlan d = dense_plan(ncam, npt);
+    const size_t need = sfm_ba_dense_sweep_ws_bytes(ncam, npt);
+    if (!ws || ws_bytes < need) {
+        sfm::set_error("sfm_ba_dense_sweep: workspace too small (%zu < %zu)", ws_bytes, need);
+        return SFM_ERR_WORKSPACE;
+    }
+    hipStream_t stream = sfm::as_stream(stream_);
+    const DenseWs w = dense_carve(reinterpret_cast<void*>(sfm::align_up((size_t)(uintptr_t)ws, 256)), ncam, npt, d);
+    const Intrin K{K_host[0], K_host[4], K_host[2], K_host[5]};
+    hipLaunchKernelGGL(dense_cam_prepare_kernel, dim3((unsigned)((ncam + 63) / 64)), dim3(64), 0, stream, cams, ncam, w.table);
+    SFM_CHECK_LAUNCH();
+    const size_t lds = (size_t)kNAcc * kValStride * sizeof(double);
+    const dim3 grid((unsigned)d.tiles, (unsigned)d.nch);
+    sfm::prof_begin(sfm::kProfBaDense, stream);
+    if (d.pp == 4)
+        hipLaunchKernelGGL(ba_dense_kernel<4>, grid, dim3(256), lds, stream, w.table, K, (int)ncam, X, npt, ldx, obs, d.nch,
+                           w.cam_part, w.pt_part);
+    else
+        hipLaunchKernelGGL(ba_dense_kernel<2>, grid, dim3(256), lds, stream, w.table, K, (int)ncam, X, npt, ldx, obs, d.nch,
+                           w.cam_part, w.pt_part);
+    sfm::prof_end(sfm::kProfBaDense, stream);
+    SFM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(dense_cam_reduce_kernel, dim3((unsigned)ncam), dim3(64), 0, stream, w.cam_part, d.tiles, (int)ncam,
+                       JtJ_cam, Jtr_cam, w.cam_sumsq);
+    SFM_CHECK_LAUNCH();
+    if (sumsq) {
+        hipLaunchKernelGGL(dense_sumsq_kernel, dim3(1), dim3(64), 0, stream, w.cam_sumsq, (int)ncam, sumsq);
+        SFM_CHECK_LAUNCH();
+    }
+    if (JtJ_pt || Jtr_pt) {
+        hipLaunchKernelGGL(dense_pt_reduce_kernel, dim3((unsigned)((npt + 255) / 256)), dim3(256), 0, stream, w.pt_part, d.nch,
+                           npt, JtJ_pt, Jtr_pt);
+        SFM_CHECK_LAUNCH();
+    }
+    return SFM_OK;
+}

@@ -12,6 +12,11 @@ void set_error(const char* fmt, ...);
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Optional per-kernel HIP-event timing (sfm_profile_enable): slot ids
+enum ProfSlot { kProfKnnFilter = 0, kProfKnnRefine = 1, kProfTriangulate = 2, kProfBaDense = 3, kProfResidual = 4, kProfSlots = 5 };
+void prof_begin(int slot, hipStream_t s);
+void prof_end(int slot, hipStream_t s);
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // Carve aligned sub-buffers out of the caller's workspace.

@@ -1,6 +1,9 @@
 // Error channel + ABI version of libsfmhip.so.
 #include "common.h"
 #include <cstring>
+#include <mutex>
+#include <utility>
+#include <vector>
 
 namespace sfm {
 static thread_local char g_err[512] = "";
@@ -11,7 +14,65 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+// ---- measurement hook: HIP events recorded on the launch stream around selected kernels --------
+namespace {
+struct ProfState {
+    bool on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[kProfSlots];
+    size_t used[kProfSlots] = {0};
+    hipEvent_t pending[kProfSlots] = {nullptr};
+};
+ProfState g_prof;
+std::mutex g_prof_mu;
+}  // namespace
+
+void prof_begin(int slot, hipStream_t s) {
+    if (!g_prof.on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    auto& v = g_prof.ev[slot];
+    if (g_prof.used[slot] == v.size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+        v.emplace_back(a, b);
+    }
+    (void)hipEventRecord(v[g_prof.used[slot]].first, s);
+}
+
+void prof_end(int slot, hipStream_t s) {
+    if (!g_prof.on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    auto& v = g_prof.ev[slot];
+    if (g_prof.used[slot] >= v.size()) return;
+    (void)hipEventRecord(v[g_prof.used[slot]].second, s);
+    ++g_prof.used[slot];
+}
 }  // namespace sfm
+
+extern "C" int sfm_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(sfm::g_prof_mu);
+    sfm::g_prof.on = on != 0;
+    for (int k = 0; k < sfm::kProfSlots; ++k) sfm::g_prof.used[k] = 0;
+    return SFM_OK;
+}
+
+extern "C" int sfm_profile_read(int slot, double* total_ms, int64_t* launches) {
+    SFM_CHECK_ARG(slot >= 0 && slot < sfm::kProfSlots && total_ms && launches, "sfm_profile_read: bad argument");
+    std::lock_guard<std::mutex> lk(sfm::g_prof_mu);
+    double tot = 0;
+    const size_t n = sfm::g_prof.used[slot];
+    for (size_t i = 0; i < n; ++i) {
+        auto& e = sfm::g_prof.ev[slot][i];
+        SFM_CHECK_HIP(hipEventSynchronize(e.second));
+        float ms = 0;
+        SFM_CHECK_HIP(hipEventElapsedTime(&ms, e.first, e.second));
+        tot += ms;
+    }
+    *total_ms = tot;
+    *launches = (int64_t)n;
+    sfm::g_prof.used[slot] = 0;
+    return SFM_OK;
+}
 
 extern "C" int sfm_abi_version(void) { return SFM_ABI_VERSION; }
 extern "C" const char* sfm_last_error(void) { return sfm::g_err; }

@@ -537,18 +537,22 @@ extern "C" int sfm_knn2_l2_f32(const float* q, int64_t nq, int64_t ldq, const fl
     }
     const size_t lds = 2 * (size_t)kBufFloats * sizeof(float);
     const dim3 grid((unsigned)(p.n_rb * p.S));
+    sfm::prof_begin(sfm::kProfKnnFilter, stream);
     if (p.qg == 2)
         hipLaunchKernelGGL(knn_filter_kernel<2>, grid, dim3(kThreads), lds, stream, q, ldq, (int)nq, t, ldt, (int)nt, w.tn,
                            p.S, p.tiles, w.cand_s, w.cand_i);
     else
         hipLaunchKernelGGL(knn_filter_kernel<1>, grid, dim3(kThreads), lds, stream, q, ldq, (int)nq, t, ldt, (int)nt, w.tn,
                            p.S, p.tiles, w.cand_s, w.cand_i);
+    sfm::prof_end(sfm::kProfKnnFilter, stream);
     SFM_CHECK_LAUNCH();
+    sfm::prof_begin(sfm::kProfKnnRefine, stream);
     hipLaunchKernelGGL(knn_refine_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream, q, ldq, (int)nq, t, ldt,
                        w.cand_s, w.cand_i, p.NS, w.tmax, idx, dist, w.flag_count, w.flag_list);
     SFM_CHECK_LAUNCH();
     hipLaunchKernelGGL(knn_fallback_kernel, dim3(256), dim3(256), 0, stream, q, ldq, t, ldt, (int)nt, w.flag_count,
                        w.flag_list, idx, dist, stats, p.S, p.NS);
+    sfm::prof_end(sfm::kProfKnnRefine, stream);
     SFM_CHECK_LAUNCH();
     return SFM_OK;
 }

@@ -107,3 +107,134 @@ def match_pair(des0, des1, ratio=0.70):
     out_q, out_t, count = ratio_compact(idx, dist, ratio)
     m = int(count.item())
     return out_q[:m], out_t[:m], idx, dist
+
+
+def triangulate(P1, P2, pts1, pts2, rows=4, normalise_w=False):
+    """cv2.triangulatePoints on device (sfm.py:53) [+ `cloud / cloud[3]` (sfm.py:54)].
+
+    P1, P2: 3x4 host matrices (float64).  pts1/pts2: float32 CUDA tensors shaped (2,N) like cv2's
+    argument — any strides, so the reference's transposed views of (N,2) arrays work unchanged.
+    Returns X4 (4,N) float32 CUDA tensor.
+    """
+    require_cuda(pts1, pts2)
+    if pts1.dtype != torch.float32 or pts2.dtype != torch.float32:
+        raise SfmHipError("triangulate: points must be float32")
+    if pts1.dim() != 2 or pts1.shape[0] != 2 or pts2.shape != pts1.shape:
+        raise SfmHipError("triangulate: expected two (2,N) arrays")
+    n = pts1.shape[1]
+    if pts2.stride() != pts1.stride():
+        pts2 = pts2.contiguous()
+        pts1 = pts1.contiguous()
+    p1 = _f64_host(P1, 12, "P1")
+    p2 = _f64_host(P2, 12, "P2")
+    X4 = torch.empty((4, n), dtype=torch.float32, device=pts1.device)
+    spt, sxy = (pts1.stride(1), pts1.stride(0)) if n > 0 else (1, 1)
+    with torch.cuda.device(pts1.device):
+        check(_lib.lib().sfm_triangulate_dlt(p1.ctypes.data_as(ctypes.c_void_p), p2.ctypes.data_as(ctypes.c_void_p),
+                                             ptr(pts1), ptr(pts2), n, spt, sxy, int(rows), int(bool(normalise_w)),
+                                             ptr(X4), stream_ptr()), "sfm_triangulate_dlt")
+    return X4
+
+
+def project_residual(cams, K, X, obs, cam_idx=None, pt_idx=None, thr2=64.0, want_proj=True, want_inlier=False,
+                     want_jac=False, want_pt_jac=False):
+    """Reprojection sweep (sfm.py:79-100 / :67 scoring / :104-136 residual).
+
+    cams [ncam,6] float64 CUDA (rvec, tvec); K 3x3 host; X [npt,3] float32 CUDA; obs [nobs,2] float32 CUDA.
+    Returns a dict of CUDA tensors: proj, sumsq (1,), inlier, JtJ_cam, Jtr_cam, JtJ_pt, Jtr_pt (as requested).
+    """
+    require_cuda(cams, X, obs, cam_idx, pt_idx)
+    cams = cams.contiguous().to(torch.float64).reshape(-1, 6)
+    if X.dtype != torch.float32 or obs.dtype != torch.float32:
+        raise SfmHipError("project_residual: X and obs must be float32")
+    if X.stride(-1) != 1:
+        X = X.contiguous()
+    obs = obs.contiguous().reshape(-1, 2)
+    ncam, npt, nobs = cams.shape[0], X.shape[0], obs.shape[0]
+    dev = X.device
+    k = _f64_host(K, 9, "K")
+    out = {"sumsq": torch.zeros(1, dtype=torch.float64, device=dev)}
+    if want_proj:
+        out["proj"] = torch.empty((nobs, 2), dtype=torch.float32, device=dev)
+    if want_inlier:
+        out["inlier"] = torch.empty(nobs, dtype=torch.uint8, device=dev)
+    if want_jac:
+        out["JtJ_cam"] = torch.zeros((ncam, 36), dtype=torch.float64, device=dev)
+        out["Jtr_cam"] = torch.zeros((ncam, 6), dtype=torch.float64, device=dev)
+    if want_pt_jac:
+        out["JtJ_pt"] = torch.zeros((npt, 9), dtype=torch.float64, device=dev)
+        out["Jtr_pt"] = torch.zeros((npt, 3), dtype=torch.float64, device=dev)
+    lib = _lib.lib()
+    ws = _workspace(dev, lib.sfm_project_residual_ws_bytes(nobs, ncam, npt))
+    ci = None if cam_idx is None else cam_idx.contiguous().to(torch.int32)
+    pi = None if pt_idx is None else pt_idx.contiguous().to(torch.int32)
+    with torch.cuda.device(dev):
+        check(lib.sfm_project_residual(ptr(cams), ncam, k.ctypes.data_as(ctypes.c_void_p), ptr(X), npt,
+                                       X.stride(0) if npt > 1 else 3, ptr(obs), ptr(ci), ptr(pi), nobs,
+                                       ptr(out.get("proj")), ptr(out["sumsq"]), ptr(out.get("inlier")), float(thr2),
+                                       ptr(out.get("JtJ_cam")), ptr(out.get("Jtr_cam")), ptr(out.get("JtJ_pt")),
+                                       ptr(out.get("Jtr_pt")), ptr(ws), ws.numel(), stream_ptr()),
+              "sfm_project_residual")
+    return out
+
+
+def ba_dense_sweep(cams, K, X, obs, want_cam=True, want_pt=True):
+    """Dense-visibility residual / J^T J sweep (config 4).  obs [ncam,npt,2] float32 CUDA."""
+    require_cuda(cams, X, obs)
+    cams = cams.contiguous().to(torch.float64).reshape(-1, 6)
+    ncam, npt = cams.shape[0], X.shape[0]
+    if obs.dtype != torch.float32 or X.dtype != torch.float32 or tuple(obs.shape) != (ncam, npt, 2):
+        raise SfmHipError("ba_dense_sweep: obs must be float32 [ncam,npt,2], X float32 [npt,3]")
+    obs = obs.contiguous()
+    if X.stride(-1) != 1:
+        X = X.contiguous()
+    dev = X.device
+    k = _f64_host(K, 9, "K")
+    out = {"sumsq": torch.zeros(1, dtype=torch.float64, device=dev)}
+    if want_cam:
+        out["JtJ_cam"] = torch.empty((ncam, 36), dtype=torch.float64, device=dev)
+        out["Jtr_cam"] = torch.empty((ncam, 6), dtype=torch.float64, device=dev)
+    if want_pt:
+        out["JtJ_pt"] = torch.empty((npt, 9), dtype=torch.float64, device=dev)
+        out["Jtr_pt"] = torch.empty((npt, 3), dtype=torch.float64, device=dev)
+    lib = _lib.lib()
+    ws = _workspace(dev, lib.sfm_ba_dense_sweep_ws_bytes(ncam, npt))
+    with torch.cuda.device(dev):
+        check(lib.sfm_ba_dense_sweep(ptr(cams), ncam, k.ctypes.data_as(ctypes.c_void_p), ptr(X), npt, X.stride(0),
+                                     ptr(obs), ptr(out["sumsq"]), ptr(out.get("JtJ_cam")), ptr(out.get("Jtr_cam")),
+                                     ptr(out.get("JtJ_pt")), ptr(out.get("Jtr_pt")), ptr(ws), ws.numel(), stream_ptr()),
+              "sfm_ba_dense_sweep")
+    return out
+
+
+def score_essential(E, x1n, x2n, thr2, want_mask=False):
+    """Sampson-distance inlier counts for h candidate essential matrices (sfm.py:307 RANSAC scoring)."""
+    require_cuda(E, x1n, x2n)
+    E = E.contiguous().to(torch.float64).reshape(-1, 9)
+    x1n = x1n.contiguous().to(torch.float64).reshape(-1, 2)
+    x2n = x2n.contiguous().to(torch.float64).reshape(-1, 2)
+    h, n = E.shape[0], x1n.shape[0]
+    counts = torch.empty(h, dtype=torch.int32, device=E.device)
+    mask = torch.empty((h, n), dtype=torch.uint8, device=E.device) if want_mask else None
+    with torch.cuda.device(E.device):
+        check(_lib.lib().sfm_score_essential(ptr(E), h, ptr(x1n), ptr(x2n), n, float(thr2), ptr(counts), ptr(mask),
+                                             stream_ptr()), "sfm_score_essential")
+    return (counts, mask) if want_mask else counts
+
+
+def score_pnp(poses, K, X, obs, thr2=64.0, want_mask=False):
+    """Reprojection inlier counts for h PnP hypotheses (rvec,tvec) (sfm.py:67 RANSAC scoring)."""
+    require_cuda(poses, X, obs)
+    poses = poses.contiguous().to(torch.float64).reshape(-1, 6)
+    X = X.contiguous().reshape(-1, 3)
+    obs = obs.contiguous().reshape(-1, 2)
+    if X.dtype != torch.float32 or obs.dtype != torch.float32:
+        raise SfmHipError("score_pnp: X and obs must be float32")
+    h, n = poses.shape[0], X.shape[0]
+    k = _f64_host(K, 9, "K")
+    counts = torch.empty(h, dtype=torch.int32, device=X.device)
+    mask = torch.empty((h, n), dtype=torch.uint8, device=X.device) if want_mask else None
+    with torch.cuda.device(X.device):
+        check(_lib.lib().sfm_score_pnp(ptr(poses), h, k.ctypes.data_as(ctypes.c_void_p), ptr(X), ptr(obs), n,
+                                       float(thr2), ptr(counts), ptr(mask), stream_ptr()), "sfm_score_pnp")
+    return (counts, mask) if want_mask else counts

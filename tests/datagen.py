@@ -1,0 +1,111 @@
+"""Seeded synthetic inputs shared by the CPU and GPU tests (SURVEY.md §8c/§8d fixtures)."""
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def sift_like(rng, n):
+    """Integer-valued 0..255 float32 descriptors with ||d|| ~ 512, like cv2 SIFT output."""
+    d = np.abs(rng.standard_normal((n, 128))) ** 2
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d = np.minimum(d, 0.2)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return np.clip(np.rint(d * 512), 0, 255).astype(np.float32)
+
+
+def planted_pair(rng, nq, nt, frac=0.3, noise=2.0):
+    """SIFT-like query/train sets where `frac` of the queries have a planted noisy twin in train.
+    Returns q, t, planted (array of (query, train) pairs)."""
+    q, t = sift_like(rng, nq), sift_like(rng, nt)
+    k = int(frac * min(nq, nt))
+    qi = rng.permutation(nq)[:k]
+    ti = rng.permutation(nt)[:k]
+    t[ti] = np.clip(q[qi] + np.rint(rng.normal(0, noise, (k, 128))), 0, 255).astype(np.float32)
+    return q, t, np.stack([qi, ti], 1)
+
+
+def load_pose_csv():
+    """K (3x3) and the 57 projection matrices of the reference's Gustav run (sfm.py:423 format)."""
+    v = np.loadtxt(os.path.join(GOLDEN, "pose.csv"))
+    K = v[:9].reshape(3, 3)
+    P = v[9:].reshape(-1, 3, 4)
+    return K, P
+
+
+def sparse_points():
+    """Subset of the reference's sparse.ply vertices in world units (file stores them x200)."""
+    z = np.load(os.path.join(GOLDEN, "sparse_ply_subset.npz"))
+    return z["verts"][:, :3] / 200.0
+
+
+def project(P, X):
+    x = P @ np.hstack([X, np.ones((len(X), 1))]).T
+    return (x[:2] / x[2]).T, x[2]
+
+
+def gustav_pair(k, n, sigma, seed):
+    """Cameras k, k+1 of pose.csv looking at reference cloud points visible in both; pixel noise sigma.
+    Returns K, P1, P2, X (n,3) float64 truth, x1, x2 (n,2) float32."""
+    K, P = load_pose_csv()
+    rng = np.random.default_rng(seed)
+    X = sparse_points()
+    x1, z1 = project(P[k], X)
+    x2, z2 = project(P[k + 1], X)
+    ok = (z1 > 0.5) & (z2 > 0.5) & (x1[:, 0] > 0) & (x1[:, 0] < 968) & (x1[:, 1] > 0) & (x1[:, 1] < 648) \
+        & (x2[:, 0] > 0) & (x2[:, 0] < 968) & (x2[:, 1] > 0) & (x2[:, 1] < 648)
+    sel = np.flatnonzero(ok)
+    if len(sel) < n:   # widen with jittered copies so every pair yields n points
+        extra = X[rng.choice(sel, n - len(sel))] + rng.normal(0, 0.02, (n - len(sel), 3))
+        Xs = np.vstack([X[sel], extra])
+    else:
+        Xs = X[rng.permutation(sel)[:n]]
+    x1, _ = project(P[k], Xs)
+    x2, _ = project(P[k + 1], Xs)
+    x1 = (x1 + rng.normal(0, sigma, x1.shape)).astype(np.float32)
+    x2 = (x2 + rng.normal(0, sigma, x2.shape)).astype(np.float32)
+    return K, P[k], P[k + 1], Xs, x1, x2
+
+
+def decompose_P(K, P):
+    """[R|t] = K^-1 P (valid for pose.csv: P = K [R|t])."""
+    Rt = np.linalg.solve(K, P)
+    return Rt[:, :3], Rt[:, 3]
+
+
+def ring_cameras(ncam, radius=8.0):
+    """Cameras on a ring looking at the origin → (ncam,6) rvec,tvec (config-4 geometry)."""
+    from scipy.spatial.transform import Rotation
+    cams = np.zeros((ncam, 6))
+    for i in range(ncam):
+        a = 2 * np.pi * i / ncam
+        C = np.array([radius * np.cos(a), 0.3 * np.sin(3 * a), radius * np.sin(a)])
+        zc = -C / np.linalg.norm(C)
+        xc = np.cross([0, 1, 0], zc)
+        xc /= np.linalg.norm(xc)
+        yc = np.cross(zc, xc)
+        R = np.stack([xc, yc, zc])
+        cams[i, :3] = Rotation.from_matrix(R).as_rotvec()
+        cams[i, 3:] = -R @ C
+    return cams
+
+
+def ba_problem(ncam, npt, sigma, seed, perturb=0.01):
+    """Dense config-4 style problem: returns K, cams (perturbed), X float32, obs (ncam,npt,2) float32."""
+    rng = np.random.default_rng(seed)
+    K, _ = load_pose_csv()
+    cams = ring_cameras(ncam)
+    X = rng.normal(0, 1, (npt, 3))
+    X /= np.maximum(1.0, np.linalg.norm(X, axis=1, keepdims=True) / rng.uniform(0.2, 1.0, (npt, 1)))
+    from scipy.spatial.transform import Rotation
+    obs = np.empty((ncam, npt, 2), np.float32)
+    for c in range(ncam):
+        R = Rotation.from_rotvec(cams[c, :3]).as_matrix()
+        Xc = X @ R.T + cams[c, 3:]
+        obs[c, :, 0] = K[0, 0] * Xc[:, 0] / Xc[:, 2] + K[0, 2]
+        obs[c, :, 1] = K[1, 1] * Xc[:, 1] / Xc[:, 2] + K[1, 2]
+    obs += rng.normal(0, sigma, obs.shape).astype(np.float32)
+    cams_p = cams * (1 + perturb * rng.standard_normal(cams.shape))
+    Xp = (X * (1 + perturb * rng.standard_normal(X.shape))).astype(np.float32)
+    return K, cams_p, Xp, obs

@@ -1,0 +1,114 @@
+"""HIP path vs oracle for the descriptor 2-NN + Lowe ratio (sfm.py:259-268), through the C-ABI.
+Bar: indices, masks and float32 distances bit-identical."""
+import numpy as np
+import pytest
+import torch
+
+from datagen import planted_pair, sift_like
+
+pytestmark = pytest.mark.gpu
+
+
+def run(hip, q, t, stats=False):
+    out = hip.knn2(torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda(), return_stats=stats)
+    torch.cuda.synchronize()
+    return tuple(o.cpu().numpy() for o in out)
+
+
+def assert_bit_equal(got, want):
+    (gi, gd), (wi, wd) = got, want
+    assert np.array_equal(gi, wi), f"{(gi != wi).any(1).sum()} rows differ"
+    assert np.array_equal(gd.view(np.uint32), wd.view(np.uint32))
+
+
+@pytest.mark.parametrize("nq,nt", [(1, 2), (5, 3), (31, 33), (64, 64), (129, 1000), (777, 1234), (3000, 2500), (6200, 700)])
+def test_random_float_descriptors_bit_exact(hip, oracle, nq, nt):
+    rng = np.random.default_rng(nq * 7919 + nt)
+    q, t = rng.random((nq, 128), dtype=np.float32), rng.random((nt, 128), dtype=np.float32)
+    assert_bit_equal(run(hip, q, t), oracle.knn2(q, t, nthreads=8))
+
+
+def test_signed_and_scaled_floats(hip, oracle):
+    rng = np.random.default_rng(5)
+    q = (rng.standard_normal((500, 128)) * 37.5).astype(np.float32)
+    t = (rng.standard_normal((900, 128)) * 37.5 + 3).astype(np.float32)
+    assert_bit_equal(run(hip, q, t), oracle.knn2(q, t, nthreads=8))
+
+
+def test_sift_like_planted_matches_and_ratio_mask(hip, oracle):
+    rng = np.random.default_rng(6)
+    q, t, planted = planted_pair(rng, 2000, 3001, 0.3)
+    gi, gd = run(hip, q, t)
+    wi, wd = oracle.knn2(q, t, nthreads=8)
+    assert_bit_equal((gi, gd), (wi, wd))
+    oq, ot, cnt, mask = hip.ratio_compact(torch.from_numpy(gi).cuda(), torch.from_numpy(gd).cuda(), 0.70, want_mask=True)
+    m = int(cnt.item())
+    wq, wt, wmask = oracle.ratio_filter(wi, wd, 0.70)
+    assert m == len(wq) and m > 500
+    assert np.array_equal(oq[:m].cpu().numpy(), wq) and np.array_equal(ot[:m].cpu().numpy(), wt)
+    assert np.array_equal(mask.cpu().numpy(), wmask)
+    assert (gi[planted[:, 0], 0] == planted[:, 1]).mean() > 0.98
+
+
+def test_exact_ties_resolve_to_lower_index_via_fallback(hip, oracle):
+    """Four identical train rows inside ONE filter stream (same 32-row tile, same half: rows r, r+8,
+    r+16, r+24) cannot be certified from a top-3 list → the exact full-scan fallback must fire and
+    reproduce the lower-index rule."""
+    rng = np.random.default_rng(7)
+    t = sift_like(rng, 1024)
+    q = sift_like(rng, 96)
+    for k in range(0, 96, 3):
+        base = 32 * (k // 3)
+        for r in (1, 9, 17, 25):
+            t[base + r] = q[k]
+    gi, gd, stats = run(hip, q, t, stats=True)
+    assert_bit_equal((gi, gd), oracle.knn2(q, t, nthreads=4))
+    assert stats[0] >= 32                     # fallback exercised
+    assert np.all(gd[::3, :] == 0) and np.all(gi[::3, 0] % 32 == 1) and np.all(gi[::3, 1] % 32 == 9)
+
+
+def test_duplicated_train_set(hip, oracle):
+    rng = np.random.default_rng(8)
+    base = rng.random((100, 128), dtype=np.float32)
+    t = np.tile(base, (6, 1))
+    q = rng.random((300, 128), dtype=np.float32)
+    assert_bit_equal(run(hip, q, t), oracle.knn2(q, t, nthreads=4))
+
+
+def test_single_train_row_and_empty_query(hip, oracle):
+    q = np.ones((40, 128), np.float32)
+    t = np.zeros((1, 128), np.float32)
+    gi, gd = run(hip, q, t)
+    assert gi.tolist() == [[0, -1]] * 40 and np.all(np.isinf(gd[:, 1])) and np.all(gd[:, 0] == np.float32(np.sqrt(128.0)))
+    gi, gd = run(hip, np.zeros((0, 128), np.float32), t)
+    assert gi.shape == (0, 2)
+
+
+def test_strided_rows(hip, oracle):
+    rng = np.random.default_rng(9)
+    big = torch.from_numpy(rng.random((400, 256), dtype=np.float32)).cuda()
+    q, t = big[:150, :128], big[150:, 128:]       # row stride 256, t starts at a 512-byte offset
+    gi, gd = hip.knn2(q, t)
+    assert_bit_equal((gi.cpu().numpy(), gd.cpu().numpy()), oracle.knn2(q.cpu().numpy(), t.cpu().numpy()))
+
+
+def test_config2_size_properties_and_parity(hip, oracle):
+    """BASELINE config 2: 10k x 10k uniform float32.  Full oracle parity (the 8-thread CPU oracle needs
+    a few seconds) plus size-independent properties."""
+    gq = torch.Generator(device="cpu").manual_seed(0)
+    q = torch.rand((10000, 128), generator=gq)
+    t = torch.rand((10000, 128), generator=torch.Generator(device="cpu").manual_seed(1))
+    gi, gd, stats = run(hip, q.numpy(), t.numpy(), stats=True)
+    assert np.all(gd[:, 0] <= gd[:, 1]) and np.all(gi[:, 0] != gi[:, 1]) and gi.min() >= 0 and gi.max() < 10000
+    # idempotence / determinism
+    gi2, gd2 = run(hip, q.numpy(), t.numpy())
+    assert np.array_equal(gi, gi2) and np.array_equal(gd, gd2)
+    # self-match property: appending the queries to the train set makes every query its own 1-NN at distance 0
+    t2 = torch.cat([t, q])
+    si, sd = run(hip, q.numpy(), t2.numpy())
+    assert np.array_equal(si[:, 0], np.arange(10000) + 10000) and np.all(sd[:, 0] == 0)
+    assert np.array_equal(si[:, 1], gi[:, 0]) and np.array_equal(sd[:, 1], gd[:, 0])
+    assert_bit_equal((gi, gd), oracle.knn2(q.numpy(), t.numpy(), nthreads=8))
+    # purely random data: nothing passes the 0.7 ratio test
+    _, _, cnt = hip.ratio_compact(torch.from_numpy(gi).cuda(), torch.from_numpy(gd).cuda(), 0.70)
+    assert int(cnt.item()) == 0
