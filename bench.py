@@ -1,0 +1,291 @@
+#!/usr/bin/env python
+"""Hot-path benchmark (contract in the task prompt; workload = BASELINE.json configs[1]).
+
+  python bench.py --gpus 1 --steps K --warmup W                      # config 2: 10k x 10k BF-KNN + ratio
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N   # pair-sharded, weak scaling
+
+A "step" is one pass of the hot path over one batch: knnMatch(k=2) + Lowe ratio for one image pair of
+10 000 x 10 000 128-D float32 descriptors per rank, inputs resident in HBM.  For N > 1 every rank owns
+its own pair (the path shards by query image) and the step ends with the path's only
+exchange: one RCCL all-gather of the fixed-stride match records.
+
+Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events around the dominant
+kernel (knn_filter_kernel, v_mfma_f32_32x32x2_f32) via the library's sfm_profile_* hook;
+`cpu_baseline` times the CPU oracle (a port of OpenCV's batchDistance semantics) on a bounded
+sample of the same workload with all host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+FLOP_PER_DISTANCE = 256           # GEMM form 2*D
+HBM_PEAK_GBS = 8000.0
+FP64_VALU_PEAK_TFLOPS = 78.6
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="knn", choices=["knn", "tri", "ba"])
+    ap.add_argument("--nq", type=int, default=10000)
+    ap.add_argument("--nt", type=int, default=10000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    return ap.parse_args()
+
+
+def init_dist(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+        local = 0
+    if world != args.gpus and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    return world, rank, local
+
+
+def barrier_sync(world):
+    torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        torch.cuda.synchronize()
+
+
+def max_over_ranks(x, world, dev):
+    if world == 1:
+        return x
+    import torch.distributed as dist
+    t = torch.tensor([x], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def cpu_knn_baseline(nq, nt, seed_q, seed_t):
+    """Oracle (kind 'port') on all host cores, bounded to roughly 10-30 s."""
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    q = torch.rand((nq, 128), generator=torch.Generator().manual_seed(seed_q)).numpy()
+    t = torch.rand((nt, 128), generator=torch.Generator().manual_seed(seed_t)).numpy()
+    probe = min(nq, 64 * cores)
+    t0 = time.perf_counter()
+    O.knn2(q[:probe], t, nthreads=cores)
+    rate = probe * nt / (time.perf_counter() - t0)
+    rows = int(min(nq, max(probe, rate * 12.0 / nt)))
+    passes = max(1, int(round(rate * 12.0 / (rows * nt))))          # ~12 s of CPU work in total
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        O.knn2(q[:rows], t, nthreads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": passes * rows * nt / dt, "unit": "distances/s", "cores": cores, "kind": "port",
+            "sample": f"{passes} pass(es) over the first {rows} of {nq} query rows x {nt} train rows of the same synthetic "
+                      f"set, oracle orc_knn2_l2_f32 (direct-form f32, OpenMP over query rows, {cores} threads), {dt:.1f} s"}
+
+
+def bench_knn(args, world, rank, dev):
+    from sfm_mvs_amd import ops
+    nq, nt = args.nq, args.nt
+    q = torch.rand((nq, 128), generator=torch.Generator().manual_seed(2 * rank)).to(dev)
+    t = torch.rand((nt, 128), generator=torch.Generator().manual_seed(2 * rank + 1)).to(dev)
+    pm = ops.PairMatcher(nq, nt, dev, ratio=0.70)
+    if world > 1:
+        import torch.distributed as dist
+        rec = torch.empty((nq, 4), dtype=torch.int32, device=dev)          # {q, t, d1, d2} 16-byte records
+        gathered = torch.empty((world * nq, 4), dtype=torch.int32, device=dev)
+
+    def step():
+        idx, d, oq, ot, cnt = pm.run(q, t)
+        if world > 1:
+            rec[:, 0] = torch.arange(nq, device=dev, dtype=torch.int32)
+            rec[:, 1] = idx[:, 0]
+            rec[:, 2:] = d.view(torch.int32)
+            dist.all_gather_into_tensor(gathered, rec)
+
+    for _ in range(args.warmup):
+        step()
+    barrier_sync(world)
+    ops.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier_sync(world)
+    elapsed = time.perf_counter() - t0
+    filt_ms, filt_n = ops.profile_read(0)
+    ref_ms, ref_n = ops.profile_read(1)
+    ops.profile_enable(False)
+    elapsed = max_over_ranks(elapsed, world, dev)
+    stats = pm.stats.cpu().tolist()
+
+    value = world * nq * nt * args.steps / elapsed
+    filt_avg_ms = filt_ms / max(filt_n, 1)
+    achieved = nq * nt * FLOP_PER_DISTANCE / (filt_avg_ms * 1e-3) / 1e12
+    out = {
+        "metric": "descriptor-pair distances/sec (BF-KNN k=2 + Lowe ratio)", "value": value, "unit": "distances/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: 10k x 10k uniform[0,1) float32 128-D descriptors, BF-KNN k=2 + "
+                               "Lowe ratio 0.70, one image pair per GPU per step", "nq": nq, "nt": nt, "dim": 128,
+                   "parallelism": f"pair-sharded x{world}" + (" + RCCL all-gather of match records" if world > 1 else "")},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                     "kernel": "knn_filter_kernel", "avg_launch_ms": filt_avg_ms, "launches": filt_n,
+                     "algorithmic_flop_per_launch": nq * nt * FLOP_PER_DISTANCE},
+        "kernels_ms": {"knn_filter": filt_avg_ms, "knn_refine_plus_fallback": ref_ms / max(ref_n, 1)},
+        "knn_stats": {"fallback_queries": stats[0], "train_splits": stats[1], "streams_per_query": stats[2]},
+    }
+    return out
+
+
+def extras(dev):
+    """The metric's other two legs, measured outside the timed region: triangulated points/s and the
+    reprojection error of the HIP path relative to the oracle on the same inputs."""
+    from sfm_mvs_amd import ops
+    from oracle import oracle as O
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from datagen import decompose_P, gustav_pair
+    K, P1, P2, X, x1, x2 = gustav_pair(1, 4000, 0.3, seed=2)
+    n = 1_000_000
+    reps = n // 4000
+    a = torch.from_numpy(np.tile(x1, (reps, 1)).T.copy()).to(dev)
+    b = torch.from_numpy(np.tile(x2, (reps, 1)).T.copy()).to(dev)
+    for _ in range(3):
+        ops.triangulate(P1, P2, a, b, normalise_w=True)
+    torch.cuda.synchronize()
+    ops.profile_enable(True)
+    iters = 20
+    for _ in range(iters):
+        X4 = ops.triangulate(P1, P2, a, b, normalise_w=True)
+    ms, cnt = ops.profile_read(2)
+    ops.profile_enable(False)
+    tri_rate = n * cnt / (ms * 1e-3)
+    # reprojection error vs oracle on the first 4000 points
+    R, tv = decompose_P(K, P2)
+    rvec = O.rodrigues_mat2vec(R)
+    Xf = X4[:3, :4000].t().contiguous()
+    out = ops.project_residual(torch.from_numpy(np.hstack([rvec, tv])[None]).to(dev), K, Xf, torch.from_numpy(x2).to(dev))
+    got = float(np.sqrt(out["sumsq"].item()) / 4000)
+    Xo = O.triangulate(P1, P2, x1.T, x2.T, normalise_w=True)
+    ref, _ = O.reprojection_error(np.hstack([R, tv[:, None]]), K, np.ascontiguousarray(Xo[:3].T), x2)
+    return {"triangulated_pts_per_sec": tri_rate, "triangulate_1e6_ms": ms / cnt,
+            "triangulate_hbm_GBs": 32.0 * n / (ms / cnt * 1e-3) / 1e9,
+            "reproj_error_hip": got, "reproj_error_oracle": ref, "reproj_error_rel_diff": abs(got - ref) / ref}
+
+
+def bench_tri(args, world, rank, dev):
+    from sfm_mvs_amd import ops
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from datagen import gustav_pair
+    K, P1, P2, X, x1, x2 = gustav_pair(1, 4000, 0.3, seed=2 + rank)
+    n = 10_000_000
+    a = torch.from_numpy(np.tile(x1, (n // 4000, 1)).T.copy()).to(dev)
+    b = torch.from_numpy(np.tile(x2, (n // 4000, 1)).T.copy()).to(dev)
+    for _ in range(args.warmup):
+        ops.triangulate(P1, P2, a, b, normalise_w=True)
+    barrier_sync(world)
+    ops.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ops.triangulate(P1, P2, a, b, normalise_w=True)
+    barrier_sync(world)
+    elapsed = max_over_ranks(time.perf_counter() - t0, world, dev)
+    ms, cnt = ops.profile_read(2)
+    ops.profile_enable(False)
+    gbs = 32.0 * n / (ms / cnt * 1e-3) / 1e9
+    return {"metric": "triangulated points/sec (DLT, cv2.triangulatePoints)", "value": world * n * args.steps / elapsed,
+            "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "north-star synthetic: 1e7 correspondences, pose.csv cameras 1,2, sigma 0.3 px", "n": n},
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "triangulate_kernel<4>", "avg_launch_ms": ms / cnt,
+                         "note": "fp64-VALU bound in practice (one-sided Jacobi, ~2 kFLOP/pt vs 32 B/pt)"}}
+
+
+def bench_ba(args, world, rank, dev):
+    from sfm_mvs_amd import ops
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from datagen import load_pose_csv, ring_cameras
+    ncam, npt = 500, 200_000
+    K, _ = load_pose_csv()
+    g = torch.Generator(device="cpu").manual_seed(3 + rank)
+    cams = torch.from_numpy(ring_cameras(ncam)).to(dev)
+    X = torch.randn((npt, 3), generator=g)
+    X = (X / X.norm(dim=1, keepdim=True).clamp(min=1.0) * torch.rand((npt, 1), generator=g).clamp(min=0.2)).to(dev)
+    obs = torch.empty((ncam, npt, 2), dtype=torch.float32, device=dev)
+    # synthesise observations on device with the library's own projection (proj output), + noise
+    idx_pts = torch.arange(npt, device=dev, dtype=torch.int32)
+    for c in range(ncam):
+        o = ops.project_residual(cams[c:c + 1], K, X, torch.zeros((npt, 2), device=dev), want_proj=True)
+        obs[c] = o["proj"]
+    obs += 0.5 * torch.randn(obs.shape, device=dev)
+    cams_p = cams * (1 + 0.01 * torch.randn(cams.shape, device=dev, dtype=torch.float64))
+    del idx_pts
+    for _ in range(max(args.warmup, 1)):
+        ops.ba_dense_sweep(cams_p, K, X, obs)
+    barrier_sync(world)
+    ops.profile_enable(True)
+    steps = args.steps
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ops.ba_dense_sweep(cams_p, K, X, obs)
+    barrier_sync(world)
+    elapsed = max_over_ranks(time.perf_counter() - t0, world, dev)
+    ms, cnt = ops.profile_read(3)
+    ops.profile_enable(False)
+    nobs = ncam * npt
+    gbs = 8.2 * nobs / (ms / cnt * 1e-3) / 1e9
+    return {"metric": "BA observations/sec (residual + J^T J sweep)", "value": world * nobs * steps / elapsed,
+            "unit": "observations/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[3]: 500 cameras x 200k points dense, sigma 0.5 px", "ncam": ncam, "npt": npt},
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         "traffic": None, "kernel": "ba_dense_kernel", "avg_launch_ms": ms / cnt,
+                         "fp64_valu_TFLOPs_at_420_flop_per_obs": 420.0 * nobs / (ms / cnt * 1e-3) / 1e12,
+                         "fp64_valu_peak_TFLOPs": FP64_VALU_PEAK_TFLOPS}}
+
+
+def main():
+    args = parse()
+    world, rank, local = init_dist(args)
+    dev = torch.device("cuda", local)
+    import sfm_mvs_amd
+    sfm_mvs_amd.lib()      # fail loudly if the HIP extension is missing
+    if args.workload == "knn":
+        out = bench_knn(args, world, rank, dev)
+        if rank == 0 and world == 1:
+            if not args.no_extras:
+                out["extra"] = extras(dev)
+            if not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_knn_baseline(args.nq, args.nt, 0, 1)
+    elif args.workload == "tri":
+        out = bench_tri(args, world, rank, dev)
+    else:
+        out = bench_ba(args, world, rank, dev)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

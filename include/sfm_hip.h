@@ -54,7 +54,8 @@ const char* sfm_last_error(void);
  *   dist_dev[nq x 2]   float32 DMatch.distance            (+inf if nt < k)
  *   stats_dev (optional, may be NULL) int32[4]:
  *       [0] queries resolved by the exact full-scan fallback
- *       [1] train split count S used   [2] streams per query   [3] reserved
+ *       [1] filter workgroups launched   [2] candidate streams reserved per query
+ *       [3] train chunks per fallback query
  *
  * dim must be 128 (SIFT); q_dev/t_dev 16-byte aligned; ldq, ldt multiples of 4.
  * The result is bit-identical to the direct-form float32 evaluation for ANY
@@ -186,6 +187,9 @@ int sfm_score_pnp(const double* poses_dev, int h, const double* K_host,
  *        3 dense BA sweep       4 indexed residual sweep
  * ---------------------------------------------------------------------- */
 int sfm_profile_enable(int on);
+/* Dev diagnostics: when non-NULL, every knn filter workgroup b writes int64[4] =
+ * {start tick, end tick (100 MHz), HW_ID, XCC_ID} at dev_buf[4*b..]; NULL disables. */
+int sfm_debug_set_trace(void* dev_buf);
 int sfm_profile_read(int slot, double* total_ms_host, int64_t* launches_host);
 
 #ifdef __cplusplus

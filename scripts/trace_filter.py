@@ -1,0 +1,28 @@
+"""Dev diagnostics: per-workgroup start/end/placement of the knn filter kernel."""
+import os, sys, ctypes
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sfm_mvs_amd import ops, _lib
+nq = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+nt = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
+q = torch.rand((nq, 128)).cuda(); t = torch.rand((nt, 128)).cuda()
+pm = ops.PairMatcher(nq, nt, q.device)
+for _ in range(3): pm.run(q, t)
+tr = torch.zeros((4096, 4), dtype=torch.int64, device="cuda")
+_lib.lib().sfm_debug_set_trace(ctypes.c_void_p(tr.data_ptr()))
+pm.run(q, t); torch.cuda.synchronize()
+_lib.lib().sfm_debug_set_trace(None)
+G = int(pm.stats[1].item()); a = tr[:G].cpu().numpy()
+t0 = a[:, 0].min(); st = (a[:, 0] - t0) / 100.0; en = (a[:, 1] - t0) / 100.0   # us
+hw = a[:, 2]; xcc = a[:, 3] & 0xF
+cu = (hw >> 8) & 0xF; sh = (hw >> 12) & 1; se = (hw >> 13) & 0x7
+key = xcc * 10000 + se * 100 + sh * 16 + cu
+print("G", G, "start us: min %.1f max %.1f | end us: min %.1f max %.1f | dur: min %.1f med %.1f max %.1f" % (st.min(), st.max(), en.min(), en.max(), (en-st).min(), np.median(en-st), (en-st).max()))
+u, c = np.unique(key, return_counts=True)
+print("distinct CUs used:", len(u), "blocks/CU histogram:", dict(zip(*np.unique(c, return_counts=True))))
+print("blocks per XCC:", dict(zip(*np.unique(xcc, return_counts=True))))
+late = st > 5
+print("late starters:", late.sum(), "their start range", (st[late].min() if late.any() else 0), (st[late].max() if late.any() else 0))
+for k in u[c == c.max()][:3]:
+    sel = key == k; print(" CU", k, "blocks", np.flatnonzero(sel), "start", st[sel].round(1), "end", en[sel].round(1))
+

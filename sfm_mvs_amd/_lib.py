@@ -39,6 +39,7 @@ SIGNATURES = {
     "sfm_score_essential": (_int, [_vp, _int, _vp, _vp, _i64, _f32, _vp, _vp, _vp]),
     "sfm_score_pnp": (_int, [_vp, _int, _vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp]),
     "sfm_profile_enable": (_int, [_int]),
+    "sfm_debug_set_trace": (_int, [_vp]),
     "sfm_profile_read": (_int, [_int, _c.POINTER(_f64), _c.POINTER(_i64)]),
 }
 

@@ -5,16 +5,19 @@
 //   2. knn_filter_kernel  s(q,t) = ||t||^2 - 2 q.t on v_mfma_f32_32x32x2_f32 with the
 //                         OPERANDS SWAPPED (A = train tile from LDS, B = query fragment
 //                         resident in VGPRs) so that a lane owns ONE query column and the
-//                         running top-3 per lane needs no cross-lane traffic.  Every
-//                         (train split, half-wave) pair is an independent "stream" that
-//                         emits its 3 best (s, idx).
+//                         running top-3 per lane needs no cross-lane traffic.  Train tiles
+//                         stream HBM/L2 -> LDS by buffer_load ... lds (XOR-swizzled image);
+//                         32 queries per wave, 4 workgroups per CU, stream-K work split.
+//                         Every (workgroup segment, half-wave) pair is an independent
+//                         "stream" that emits its 3 best (s, idx).
 //   3. knn_refine_kernel  one wave per query: re-evaluates the few candidates that can
 //                         still be in the top-2 with the reference's direct-form float32
 //                         arithmetic (sub, mul, add — no FMA — in OpenCV's 2x4-lane
 //                         accumulation order, then sqrtf), orders them by (dist, idx) and
 //                         CERTIFIES the answer against the lower bound of everything the
 //                         filter discarded.  Uncertifiable queries are queued …
-//   4. knn_fallback_kernel … and resolved by an exact direct-form scan of all trains.
+//   4. knn_fallback_*      … and resolved by an exact direct-form scan of all trains (chunked over
+//                         the whole chip, then merged).
 //
 // The GEMM-form value is therefore never returned: indices and distances are bit-identical
 // to the direct-form oracle (oracle/sfm_oracle.c: orc_knn2_l2_f32) for any finite input.
@@ -25,56 +28,93 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kDim = 128;
 constexpr int kTileT = 32;             // train rows per LDS tile (= MFMA M)
-constexpr int kLdsRow = kDim + 4;      // +4 floats: ds_read_b128 of 32 rows is conflict-free
 constexpr int kWaves = 4;
 constexpr int kThreads = kWaves * 64;
-constexpr int kMaxSplit = 32;
-constexpr int kTargetBlocks = 512;     // 256 CUs x 2 resident workgroups
+constexpr int kResidentBlocks = 1024;  // 256 CUs x 4 resident workgroups (launch_bounds(256, 4))
+constexpr int kMaxSlots = 34;          // cap on filter blocks that may touch one query row block
 constexpr float kInf = __builtin_huge_valf();
 
+// Work decomposition ("stream-K" over the flattened (query row block, train tile) unit space):
+// block b owns units [units*b/G, units*(b+1)/G).  Every block gets the same number of units (+-1),
+// so all 2x256 resident workgroups finish together whatever nq, nt are; a block that crosses a
+// row-block boundary flushes its candidates and reloads the query fragment.
 struct Plan {
-    int qg;           // 32-query groups per wave (1 or 2)
     int rows_per_block;
-    int n_rb;         // query row blocks
-    int tiles;        // train tiles of 32
-    int S;            // train splits
-    int NS;           // streams per query = 2*S
+    int n_rb;          // query row blocks
+    int tiles;         // train tiles of 32
+    int64_t units;     // n_rb * tiles
+    int G;             // filter blocks
+    int smax;          // candidate slots reserved per row block (>= blocks touching it)
+    int fb_nch;        // fallback: train chunks per flagged query
+    int fb_chunk;      // fallback: trains per chunk
 };
+
+__host__ __device__ inline int64_t unit_begin(int64_t units, int G, int b) { return units * b / G; }
+
+// block that owns unit u
+__host__ __device__ inline int block_of_unit(int64_t units, int G, int64_t u) {
+    int b = (int)(u * G / units);
+    if (b >= G) b = G - 1;
+    while (b + 1 < G && unit_begin(units, G, b + 1) <= u) ++b;
+    while (b > 0 && unit_begin(units, G, b) > u) --b;
+    return b;
+}
 
 Plan make_plan(int64_t nq, int64_t nt) {
     Plan p;
-    p.qg = (nq >= 256 * 24) ? 2 : 1;
-    p.rows_per_block = kWaves * 32 * p.qg;
+    p.rows_per_block = kWaves * 32;
     p.n_rb = (int)((nq + p.rows_per_block - 1) / p.rows_per_block);
     p.tiles = (int)((nt + kTileT - 1) / kTileT);
-    int s = p.n_rb > 0 ? kTargetBlocks / p.n_rb : 1;
-    if (s < 1) s = 1;
-    if (s > kMaxSplit) s = kMaxSplit;
-    if (s > p.tiles) s = p.tiles > 0 ? p.tiles : 1;
-    p.S = s;
-    p.NS = 2 * s;
+    p.units = (int64_t)p.n_rb * p.tiles;
+    int64_t g = kResidentBlocks;
+    if (g > p.units) g = p.units;
+    if (g > (int64_t)p.n_rb * (kMaxSlots - 2)) g = (int64_t)p.n_rb * (kMaxSlots - 2);
+    if (g < 1) g = 1;
+    p.G = (int)g;
+    p.smax = p.n_rb > 0 ? p.G / p.n_rb + 2 : 1;
+    // fallback chunks: 256 trains each when the worst-case partial buffer (every query flagged) stays small
+    int64_t cap = nq > 0 ? (int64_t)(1 << 21) / nq : 1;
+    if (cap < 2) cap = 2;
+    int64_t nch = (nt + 255) / 256;
+    if (nch > cap) nch = cap;
+    if (nch < 1) nch = 1;
+    p.fb_nch = (int)nch;
+    p.fb_chunk = (int)((nt + nch - 1) / nch);
+    if (p.fb_chunk < 1) p.fb_chunk = 1;
     return p;
 }
 
 // ---------------------------------------------------------------- norms
+// ||t||^2 per train row (32 lanes per row, one float4 each) + one max per block (no atomics: a
+// single hot atomicMax address costs ~12 ns per arrival).  Block 0 also zeroes the fallback counter,
+// so the pipeline needs no memset launch.
+constexpr int kNormBlocks = 256;
+
 __global__ __launch_bounds__(256) void knn_norms_kernel(const float* __restrict__ T, int64_t ldt, int nt,
-                                                        float* __restrict__ tn, unsigned* __restrict__ tmax_bits) {
-    // 32 lanes per row, one float4 each.
-    const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
+                                                        float* __restrict__ tn, float* __restrict__ bmax,
+                                                        int* __restrict__ flag_count) {
+    __shared__ float wmax[4];
     const int l = threadIdx.x & 31;
-    float s = 0.f;
-    if (row < nt) {
+    float mx = 0.f;
+    for (int row = blockIdx.x * 8 + (threadIdx.x >> 5); row < nt; row += gridDim.x * 8) {
         const float4 v = *reinterpret_cast<const float4*>(T + (int64_t)row * ldt + 4 * l);
-        s = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        float s = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+#pragma unroll
+        for (int m = 16; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+        if (l == 0) tn[row] = s;
+        mx = fmaxf(mx, s);
     }
 #pragma unroll
-    for (int m = 16; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
-    if (row < nt && l == 0) {
-        tn[row] = s;
-        atomicMax(tmax_bits, __float_as_uint(s));   // s >= 0: uint order == float order
+    for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        bmax[blockIdx.x] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+        if (blockIdx.x == 0) *flag_count = 0;
     }
 }
 
@@ -89,157 +129,147 @@ __device__ __forceinline__ void top3_insert(float v, int id, float (&s)[3], int 
     ix[0] = lt0 ? id : ix[0];
 }
 
-struct StageRegs {
-    float4 v[4];
-    float tn;
-};
+// 32 queries per wave, 4 waves per workgroup, FOUR workgroups per CU (<=128 VGPRs): four waves
+// per SIMD take turns on the matrix pipe, so one wave's top-3 epilogue / LDS round trips / barrier
+// waits are covered by the other three.  The train tile goes HBM/L2 -> LDS with global_load_lds
+// (no staging VGPRs, no ds_write pass); the LDS image is therefore lane-linear [32 rows][32 x 16 B]
+// and bank conflicts are removed by XOR-swizzling the 16-byte chunk index with (row & 15) on the
+// SOURCE address and on the fragment read (ds_read_b128: 16-lane groups hit 16 distinct slots).
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
 
-__device__ __forceinline__ void stage_load(StageRegs& r, const float* __restrict__ T, int64_t ldt, int nt,
-                                           const float* __restrict__ tn, int tile) {
-    const int tid = threadIdx.x;
+constexpr int kTileFloats = kTileT * kDim;            // 4096 floats = 16 KiB, linear
+constexpr int kLdsFloats = 2 * kTileFloats + 2 * kTileT;
+
+// Train tile -> LDS: 4 buffer_load_dwordx4 ... lds per wave (1 KiB each).  Addressing through a buffer
+// descriptor keeps the per-lane state to ONE 32-bit offset register and makes rows past nt read as
+// zeros in hardware (their ||t||^2 is +inf, so they never become candidates).
+__device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t trs, int row_bytes, int lane_off, const float* __restrict__ tn,
+                                         int nt, int tile, float* __restrict__ tile_buf, float* __restrict__ tn_buf, int wave) {
+    const int soff = tile * kTileT * row_bytes;
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
-        const int f = tid + kThreads * n;
-        const int row = tile * kTileT + (f >> 5);
-        const int c4 = f & 31;
-        r.v[n] = (row < nt) ? *reinterpret_cast<const float4*>(T + (int64_t)row * ldt + 4 * c4)
-                            : make_float4(0.f, 0.f, 0.f, 0.f);
+        float* dst = tile_buf + (wave * 4 + n) * 256;               // wave-uniform, 1 KiB per instruction
+        // row r = wave*8 + 2n + h holds source chunk p ^ (r & 15) = (p ^ (r0 & 15)) ^ 2n at position p
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(trs, (lptr_t)dst, 16, (lane_off ^ (32 * n)) + 2 * n * row_bytes, soff, 0, 0);
     }
-    r.tn = kInf;
-    if (tid < kTileT) {
-        const int row = tile * kTileT + tid;
-        if (row < nt) r.tn = tn[row];
+    if (threadIdx.x < kTileT) {
+        const int row = tile * kTileT + threadIdx.x;
+        tn_buf[threadIdx.x] = row < nt ? tn[row] : kInf;
     }
 }
 
-__device__ __forceinline__ void stage_store(const StageRegs& r, float* __restrict__ buf) {
-    const int tid = threadIdx.x;
-#pragma unroll
-    for (int n = 0; n < 4; ++n) {
-        const int f = tid + kThreads * n;
-        *reinterpret_cast<float4*>(buf + (f >> 5) * kLdsRow + 4 * (f & 31)) = r.v[n];
-    }
-    if (tid < kTileT) buf[kTileT * kLdsRow + tid] = r.tn;
-}
-
-constexpr int kBufFloats = kTileT * kLdsRow + kTileT;   // tile + its ||t||^2 row
-
-template <int QG>
-__global__ __launch_bounds__(kThreads, 2) void knn_filter_kernel(
+__global__ __launch_bounds__(kThreads, 4) void knn_filter_kernel(
     const float* __restrict__ Q, int64_t ldq, int nq, const float* __restrict__ T, int64_t ldt, int nt,
-    const float* __restrict__ tn, int S, int tiles, float* __restrict__ cand_s, int* __restrict__ cand_i) {
+    const float* __restrict__ tn, int tiles, int64_t units, int smax, float* __restrict__ cand_s,
+    int* __restrict__ cand_i, long long* __restrict__ trace) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (trace && threadIdx.x == 0) {
+        trace[4 * blockIdx.x + 0] = wall_clock64();
+        trace[4 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg(0xF804);
+        trace[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg(0xF814);
+    }
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int j = lane & 31;   // MFMA column  = query within group / train row for A loads
-    const int h = lane >> 5;   // k-half selector / C row block selector
-    const int rb = blockIdx.x / S;
-    const int sp = blockIdx.x - rb * S;
-    const int q0 = rb * (kWaves * 32 * QG) + wave * (32 * QG);
-    const int t_begin = (int)((int64_t)tiles * sp / S);
-    const int t_end = (int)((int64_t)tiles * (sp + 1) / S);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably uniform: no waterfall loops
+    const int j = lane & 31;
+    const int h = lane >> 5;
+    const int hm = h ^ (j & 15);                 // swizzled position of chunk (2c + h) is (2c) ^ hm
+    const int G = gridDim.x;
+    const int64_t u_end = unit_begin(units, G, blockIdx.x + 1);
+    int64_t u = unit_begin(units, G, blockIdx.x);
+    float* const tnb = smem + 2 * kTileFloats;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;   // LDS byte offset of smem
+    const int row_bytes = (int)ldt * 4;
+    const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc((void*)T, 0, nt * row_bytes, 0x00020000);
+    // staging offset of this lane for n = 0: row r0 = wave*8 + h, byte position of chunk (p ^ (r0 & 15))
+    const int lane_off = (wave * 8 + h) * row_bytes + (((lane & 31) ^ ((wave * 8 + h) & 15)) << 4);
 
-    // Query fragment (MFMA B operand), pre-scaled by -2 (exact), resident for the whole block.
-    // k-order: MFMA step 4c+e of half h consumes k = 8c + 4h + e — the same permutation
-    // is applied to the A (train) operand, so the dot product is complete.
-    float bq[QG][64];
-#pragma unroll
-    for (int g = 0; g < QG; ++g) {
-        const int row = q0 + 32 * g + j;
-        const bool ok = row < nq;
-        const float* src = Q + (int64_t)(ok ? row : 0) * ldq + 4 * h;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            float4 v = *reinterpret_cast<const float4*>(src + 8 * c);
-            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            bq[g][4 * c + 0] = -2.f * v.x;
-            bq[g][4 * c + 1] = -2.f * v.y;
-            bq[g][4 * c + 2] = -2.f * v.z;
-            bq[g][4 * c + 3] = -2.f * v.w;
-        }
-    }
+    while (u < u_end) {
+        const int rb = (int)(u / tiles);
+        const int t_begin = (int)(u - (int64_t)rb * tiles);
+        const int t_end = (int)min((int64_t)tiles, t_begin + (u_end - u));
+        const int slot = blockIdx.x - block_of_unit(units, G, (int64_t)rb * tiles);
+        const int qrow = rb * (kWaves * 32) + wave * 32 + j;
+        const bool qok = qrow < nq;
 
-    float bs[QG][3];
-    int bi[QG][3];
-#pragma unroll
-    for (int g = 0; g < QG; ++g)
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            bs[g][r] = kInf;
-            bi[g][r] = -1;
-        }
+        __syncthreads();   // every wave is done with both buffers of the previous segment
+        stage_tile(trs, row_bytes, lane_off, tn, nt, t_begin, smem, tnb, wave);
 
-    StageRegs sr;
-    if (t_begin < t_end) {
-        stage_load(sr, T, ldt, nt, tn, t_begin);
-        stage_store(sr, smem);
-    }
-    __syncthreads();
-
-    for (int t = t_begin; t < t_end; ++t) {
-        const float* buf = smem + ((t - t_begin) & 1) * kBufFloats;
-        float* nbuf = smem + (((t - t_begin) & 1) ^ 1) * kBufFloats;
-        const bool more = (t + 1 < t_end);
-        if (more) stage_load(sr, T, ldt, nt, tn, t + 1);   // in flight behind the MFMAs
-
-        // C init = ||t||^2 of the 16 train rows this lane owns: row(r) = (r&3) + 8*(r>>2) + 4h
-        f32x16 acc[QG];
+        float bq[64];
         {
-            const float* tnp = buf + kTileT * kLdsRow + 4 * h;
-            f32x16 c0;
+            const float* src = Q + (int64_t)(qok ? qrow : 0) * ldq + 4 * h;
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const float4 v = *reinterpret_cast<const float4*>(tnp + 8 * b);
-                c0[4 * b + 0] = v.x;
-                c0[4 * b + 1] = v.y;
-                c0[4 * b + 2] = v.z;
-                c0[4 * b + 3] = v.w;
+            for (int c = 0; c < 16; ++c) {
+                float4 v = *reinterpret_cast<const float4*>(src + 8 * c);
+                if (!qok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                bq[4 * c + 0] = -2.f * v.x;
+                bq[4 * c + 1] = -2.f * v.y;
+                bq[4 * c + 2] = -2.f * v.z;
+                bq[4 * c + 3] = -2.f * v.w;
             }
+        }
+        float bs[3] = {kInf, kInf, kInf};
+        int bi[3] = {-1, -1, -1};
+        __syncthreads();   // tile t_begin landed (the barrier's release waits for the LDS-DMA: vmcnt(0))
+
+        for (int t = t_begin; t < t_end; ++t) {
+            const int cur = (t - t_begin) & 1;
+            if (t + 1 < t_end) stage_tile(trs, row_bytes, lane_off, tn, nt, t + 1, smem + (cur ^ 1) * kTileFloats, tnb + (cur ^ 1) * kTileT, wave);
+
+            f32x16 acc;
+            {
+                const float* tnp = tnb + cur * kTileT + 4 * h;
 #pragma unroll
-            for (int g = 0; g < QG; ++g) acc[g] = c0;
+                for (int b = 0; b < 4; ++b) {
+                    const float4 v = *reinterpret_cast<const float4*>(tnp + 8 * b);
+                    acc[4 * b + 0] = v.x;
+                    acc[4 * b + 1] = v.y;
+                    acc[4 * b + 2] = v.z;
+                    acc[4 * b + 3] = v.w;
+                }
+            }
+            // A fragments: hand-placed ds_read_b128 two chunks (8 MFMAs = 512 pipe cycles) ahead of use.
+            // hipcc sinks such reads next to their consumer (and then blocks the in-order wave on the LDS
+            // round trip every 4 MFMAs), so the reads and their counted waits are inline asm:
+            //   issue r(c+2); s_waitcnt lgkmcnt(2) => r(c) has landed, r(c+1), r(c+2) stay in flight.
+            const unsigned abase = lds0 + (unsigned)(cur * kTileFloats + j * kDim) * 4u + ((unsigned)hm << 4);
+            f32x4 af[3];
+            asm volatile("ds_read_b128 %0, %1" : "=v"(af[0]) : "v"(abase));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(af[1]) : "v"(abase ^ 32u));
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                if (c + 2 < 16) {
+                    const unsigned ad = (abase ^ (32u * ((c + 2) & 7))) + ((c + 2) >= 8 ? 256u : 0u);
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(af[(c + 2) % 3]) : "v"(ad));
+                    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(af[c % 3]));
+                } else if (c + 1 < 16) {
+                    asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(af[c % 3]));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[c % 3]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c % 3][0], bq[4 * c + 0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c % 3][1], bq[4 * c + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c % 3][2], bq[4 * c + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c % 3][3], bq[4 * c + 3], acc, 0, 0, 0);
+            }
+            const int id0 = t * kTileT + 4 * h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) top3_insert(acc[r], id0 + (r & 3) + 8 * (r >> 2), bs, bi);
+            __syncthreads();
         }
 
-        const float* arow = buf + j * kLdsRow + 4 * h;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            const float4 a = *reinterpret_cast<const float4*>(arow + 8 * c);
-#pragma unroll
-            for (int g = 0; g < QG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bq[g][4 * c + 0], acc[g], 0, 0, 0);
-#pragma unroll
-            for (int g = 0; g < QG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bq[g][4 * c + 1], acc[g], 0, 0, 0);
-#pragma unroll
-            for (int g = 0; g < QG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bq[g][4 * c + 2], acc[g], 0, 0, 0);
-#pragma unroll
-            for (int g = 0; g < QG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bq[g][4 * c + 3], acc[g], 0, 0, 0);
-        }
-
-        // Lane-local running top-3 (ascending train index within the lane ⇒ strict '<' keeps
-        // the earlier index on equal s; ordering among equals is settled exactly by refine).
-        const int id0 = t * kTileT + 4 * h;
-#pragma unroll
-        for (int g = 0; g < QG; ++g)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) top3_insert(acc[g][r], id0 + (r & 3) + 8 * (r >> 2), bs[g], bi[g]);
-
-        if (more) stage_store(sr, nbuf);
-        __syncthreads();
-    }
-
-    // One stream per (split, half-wave): 3 candidates each.
-    const int NS = 2 * S;
-    const int stream = 2 * sp + h;
-#pragma unroll
-    for (int g = 0; g < QG; ++g) {
-        const int row = q0 + 32 * g + j;
-        if (row < nq) {
-            const int64_t o = ((int64_t)row * NS + stream) * 3;
+        if (qok) {
+            const int64_t o = ((int64_t)qrow * (2 * smax) + 2 * slot + h) * 3;
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                cand_s[o + r] = bs[g][r];
-                cand_i[o + r] = bi[g][r];
+                cand_s[o + r] = bs[r];
+                cand_i[o + r] = bi[r];
             }
         }
+        u += t_end - t_begin;
     }
+    if (trace && threadIdx.x == 0) trace[4 * blockIdx.x + 1] = wall_clock64();
 }
 
 // ---------------------------------------------------------------- exact direct-form distance
@@ -303,8 +333,8 @@ __device__ __forceinline__ void best2_wave_reduce(Best2& b) {
 // ---------------------------------------------------------------- refine
 __global__ __launch_bounds__(256) void knn_refine_kernel(
     const float* __restrict__ Q, int64_t ldq, int nq, const float* __restrict__ T, int64_t ldt,
-    const float* __restrict__ cand_s, const int* __restrict__ cand_i, int NS,
-    const unsigned* __restrict__ tmax_bits, int* __restrict__ idx_out, float* __restrict__ dist_out,
+    const float* __restrict__ cand_s, const int* __restrict__ cand_i, int rows_per_block, int tiles, int64_t units,
+    int G, int smax, const float* __restrict__ bmax, int* __restrict__ idx_out, float* __restrict__ dist_out,
     int* __restrict__ flag_count, int* __restrict__ flag_list) {
     __shared__ __attribute__((aligned(16))) float qrows[4][kDim];
     const int lane = threadIdx.x & 63;
@@ -326,13 +356,19 @@ __global__ __launch_bounds__(256) void knn_refine_kernel(
     // Slack that dominates: GEMM-form rounding of the filter (<= 2*gamma_130*(|q|+|t|)^2),
     // rounding of the direct-form sums (<= 24u*d^2), of ||q||^2, ||t||^2 (gamma_128 each) and the
     // final sqrtf merge (8u*d^2), u = 2^-24.  600u*(|q|+|t|max)^2 covers their sum with >1.5x room.
-    const float tmax = __uint_as_float(*tmax_bits);
+    float tmax = fmaxf(fmaxf(bmax[lane], bmax[lane + 64]), fmaxf(bmax[lane + 128], bmax[lane + 192]));
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, m, 64));
     const float nsum = sqrtf(qq) + sqrtf(tmax);
     const float eps = 600.f * 5.9604645e-8f * 1.01f * nsum * nsum;
 
-    const int NC = NS * 3;
-    const float* cs = cand_s + (int64_t)q * NC;
-    const int* ci = cand_i + (int64_t)q * NC;
+    // streams of this query's row block = filter blocks that touched it (contiguous slots from 0)
+    const int rb = q / rows_per_block;
+    const int fb = block_of_unit(units, G, (int64_t)rb * tiles);
+    const int lb = block_of_unit(units, G, (int64_t)(rb + 1) * tiles - 1);
+    const int NC = 2 * (lb - fb + 1) * 3;
+    const float* cs = cand_s + (int64_t)q * (2 * smax * 3);
+    const int* ci = cand_i + (int64_t)q * (2 * smax * 3);
 
     // Pass A: two smallest filter scores over all candidates, and tau = the smallest score any
     // discarded train can have (every stream discards only trains >= its 3rd best).
@@ -382,17 +418,25 @@ __global__ __launch_bounds__(256) void knn_refine_kernel(
 }
 
 // ---------------------------------------------------------------- exact fallback
-__global__ __launch_bounds__(256) void knn_fallback_kernel(
-    const float* __restrict__ Q, int64_t ldq, const float* __restrict__ T, int64_t ldt, int nt,
-    const int* __restrict__ flag_count, const int* __restrict__ flag_list, int* __restrict__ idx_out,
-    float* __restrict__ dist_out, int* __restrict__ stats, int S, int NS) {
+// Work item = (flagged query, chunk of trains).  A fixed grid strides over the items, so a single
+// flagged query is still spread over many CUs; a second small kernel merges the per-chunk top-2
+// (lexicographic (dist, idx) order is associative, so the result equals the sequential scan).
+struct Best2Rec {
+    float d0, q0, d1, q1;
+    int i0, i1;
+};
+
+constexpr int kFbScanBlocks = 1024;
+constexpr int kFbMergeBlocks = 128;
+
+__global__ __launch_bounds__(256) void knn_fallback_scan_kernel(
+    const float* __restrict__ Q, int64_t ldq, const float* __restrict__ T, int64_t ldt, int nt, int nch, int chunk,
+    const int* __restrict__ flag_count, const int* __restrict__ flag_list, Best2Rec* __restrict__ partial) {
     __shared__ __attribute__((aligned(16))) float qrow[kDim];
     __shared__ Best2 wbest[4];
-    const int nflag = *flag_count;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && stats) {
-        stats[0] = nflag; stats[1] = S; stats[2] = NS; stats[3] = 0;
-    }
-    for (int f = blockIdx.x; f < nflag; f += gridDim.x) {
+    const int64_t items = (int64_t)(*flag_count) * nch;
+    for (int64_t it = blockIdx.x; it < items; it += gridDim.x) {
+        const int f = (int)(it / nch), ch = (int)(it - (int64_t)f * nch);
         const int q = flag_list[f];
         __syncthreads();
         if (threadIdx.x < 32)
@@ -401,7 +445,8 @@ __global__ __launch_bounds__(256) void knn_fallback_kernel(
         __syncthreads();
         Best2 b;
         b.d[0] = b.d[1] = kInf; b.dsq[0] = b.dsq[1] = kInf; b.i[0] = b.i[1] = INT_MAX;
-        for (int t = threadIdx.x; t < nt; t += 256) {
+        const int t_end = min(nt, (ch + 1) * chunk);
+        for (int t = ch * chunk + threadIdx.x; t < t_end; t += 256) {
             const float dsq = exact_l2sq_128(qrow, T + (int64_t)t * ldt);
             best2_insert(b, sqrtf(dsq), dsq, t);
         }
@@ -414,10 +459,36 @@ __global__ __launch_bounds__(256) void knn_fallback_kernel(
                 best2_insert(r, wbest[w].d[0], wbest[w].dsq[0], wbest[w].i[0]);
                 best2_insert(r, wbest[w].d[1], wbest[w].dsq[1], wbest[w].i[1]);
             }
-            idx_out[2 * q + 0] = r.i[0] == INT_MAX ? -1 : r.i[0];
-            idx_out[2 * q + 1] = r.i[1] == INT_MAX ? -1 : r.i[1];
-            dist_out[2 * q + 0] = r.d[0];
-            dist_out[2 * q + 1] = r.d[1];
+            Best2Rec o{r.d[0], r.dsq[0], r.d[1], r.dsq[1], r.i[0], r.i[1]};
+            partial[it] = o;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void knn_fallback_merge_kernel(const Best2Rec* __restrict__ partial, int nch,
+                                                                const int* __restrict__ flag_count,
+                                                                const int* __restrict__ flag_list, int* __restrict__ idx_out,
+                                                                float* __restrict__ dist_out, int* __restrict__ stats, int S,
+                                                                int NS) {
+    const int nflag = *flag_count;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && stats) {
+        stats[0] = nflag; stats[1] = S; stats[2] = NS; stats[3] = nch;
+    }
+    for (int f = blockIdx.x; f < nflag; f += gridDim.x) {
+        Best2 b;
+        b.d[0] = b.d[1] = kInf; b.dsq[0] = b.dsq[1] = kInf; b.i[0] = b.i[1] = INT_MAX;
+        for (int c = threadIdx.x; c < nch; c += 64) {
+            const Best2Rec r = partial[(int64_t)f * nch + c];
+            best2_insert(b, r.d0, r.q0, r.i0);
+            best2_insert(b, r.d1, r.q1, r.i1);
+        }
+        best2_wave_reduce(b);
+        if (threadIdx.x == 0) {
+            const int q = flag_list[f];
+            idx_out[2 * q + 0] = b.i[0] == INT_MAX ? -1 : b.i[0];
+            idx_out[2 * q + 1] = b.i[1] == INT_MAX ? -1 : b.i[1];
+            dist_out[2 * q + 0] = b.d[0];
+            dist_out[2 * q + 1] = b.d[1];
         }
     }
 }
@@ -477,9 +548,21 @@ __global__ __launch_bounds__(256) void gather_matches_kernel(const float2* __res
     }
 }
 
+__global__ void knn_fill_empty_kernel(int* __restrict__ idx, float* __restrict__ dist, int64_t n2, int* __restrict__ stats) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n2) {
+        idx[i] = -1;
+        dist[i] = kInf;
+    }
+    if (i == 0 && stats) stats[0] = stats[1] = stats[2] = stats[3] = 0;
+}
+
+long long* g_trace = nullptr;   // dev diagnostics only
+
 struct KnnWs {
     float* tn;
-    unsigned* tmax;
+    float* bmax;
+    Best2Rec* fb_partial;
     int* flag_count;
     int* flag_list;
     float* cand_s;
@@ -490,17 +573,23 @@ struct KnnWs {
 KnnWs carve_ws(void* ws, int64_t nq, int64_t nt, const Plan& p) {
     sfm::Carver c(ws);
     KnnWs w;
-    w.tmax = c.take<unsigned>(1);
+    w.bmax = c.take<float>(kNormBlocks);
     w.flag_count = c.take<int>(1);
+    w.fb_partial = c.take<Best2Rec>((size_t)nq * p.fb_nch);
     w.tn = c.take<float>((size_t)p.tiles * kTileT);
     w.flag_list = c.take<int>((size_t)nq);
-    w.cand_s = c.take<float>((size_t)nq * p.NS * 3);
-    w.cand_i = c.take<int>((size_t)nq * p.NS * 3);
+    w.cand_s = c.take<float>((size_t)nq * 2 * p.smax * 3);
+    w.cand_i = c.take<int>((size_t)nq * 2 * p.smax * 3);
     w.bytes = c.used();
     return w;
 }
 
 }  // namespace
+
+extern "C" int sfm_debug_set_trace(void* dev_buf) {
+    g_trace = static_cast<long long*>(dev_buf);
+    return SFM_OK;
+}
 
 extern "C" size_t sfm_knn2_l2_f32_ws_bytes(int64_t nq, int64_t nt, int dim) {
     if (nq < 0 || nt < 0 || dim != kDim) return 0;
@@ -518,6 +607,12 @@ extern "C" int sfm_knn2_l2_f32(const float* q, int64_t nq, int64_t ldq, const fl
     SFM_CHECK_ARG(q && idx && dist && (t || nt == 0), "sfm_knn2_l2_f32: null pointer");
     SFM_CHECK_ARG(ldq >= dim && ldt >= dim && ldq % 4 == 0 && ldt % 4 == 0, "sfm_knn2_l2_f32: ldq/ldt must be >= dim and multiples of 4");
     SFM_CHECK_ARG(((uintptr_t)q & 15) == 0 && ((uintptr_t)t & 15) == 0, "sfm_knn2_l2_f32: q/t must be 16-byte aligned");
+    if (nt == 0) {   // no train rows: OpenCV leaves idx = -1 (and emits no DMatch)
+        hipLaunchKernelGGL(knn_fill_empty_kernel, dim3((unsigned)((2 * nq + 255) / 256)), dim3(256), 0, sfm::as_stream(stream_),
+                           idx, dist, 2 * nq, stats);
+        SFM_CHECK_LAUNCH();
+        return SFM_OK;
+    }
     const Plan p = make_plan(nq, nt);
     const size_t need = sfm_knn2_l2_f32_ws_bytes(nq, nt, dim);
     if (!ws || ws_bytes < need) {
@@ -529,29 +624,25 @@ extern "C" int sfm_knn2_l2_f32(const float* q, int64_t nq, int64_t ldq, const fl
     const KnnWs w = carve_ws(base, nq, nt, p);
     hipStream_t stream = sfm::as_stream(stream_);
 
-    SFM_CHECK_HIP(hipMemsetAsync(w.tmax, 0, 512, stream));   // tmax + flag_count (adjacent 256-B slots)
-    if (nt > 0) {
-        hipLaunchKernelGGL(knn_norms_kernel, dim3((unsigned)((nt + 7) / 8)), dim3(256), 0, stream, t, ldt, (int)nt, w.tn,
-                           w.tmax);
-        SFM_CHECK_LAUNCH();
-    }
-    const size_t lds = 2 * (size_t)kBufFloats * sizeof(float);
-    const dim3 grid((unsigned)(p.n_rb * p.S));
+    hipLaunchKernelGGL(knn_norms_kernel, dim3(kNormBlocks), dim3(256), 0, stream, t, ldt, (int)nt, w.tn, w.bmax,
+                       w.flag_count);
+    SFM_CHECK_LAUNCH();
+    const dim3 grid((unsigned)p.G);
     sfm::prof_begin(sfm::kProfKnnFilter, stream);
-    if (p.qg == 2)
-        hipLaunchKernelGGL(knn_filter_kernel<2>, grid, dim3(kThreads), lds, stream, q, ldq, (int)nq, t, ldt, (int)nt, w.tn,
-                           p.S, p.tiles, w.cand_s, w.cand_i);
-    else
-        hipLaunchKernelGGL(knn_filter_kernel<1>, grid, dim3(kThreads), lds, stream, q, ldq, (int)nq, t, ldt, (int)nt, w.tn,
-                           p.S, p.tiles, w.cand_s, w.cand_i);
+    hipLaunchKernelGGL(knn_filter_kernel, grid, dim3(kThreads), kLdsFloats * sizeof(float), stream, q, ldq, (int)nq, t, ldt,
+                       (int)nt, w.tn, p.tiles, p.units, p.smax, w.cand_s, w.cand_i, g_trace);
     sfm::prof_end(sfm::kProfKnnFilter, stream);
     SFM_CHECK_LAUNCH();
     sfm::prof_begin(sfm::kProfKnnRefine, stream);
     hipLaunchKernelGGL(knn_refine_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream, q, ldq, (int)nq, t, ldt,
-                       w.cand_s, w.cand_i, p.NS, w.tmax, idx, dist, w.flag_count, w.flag_list);
+                       w.cand_s, w.cand_i, p.rows_per_block, p.tiles, p.units, p.G, p.smax, w.bmax, idx, dist, w.flag_count,
+                       w.flag_list);
     SFM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(knn_fallback_kernel, dim3(256), dim3(256), 0, stream, q, ldq, t, ldt, (int)nt, w.flag_count,
-                       w.flag_list, idx, dist, stats, p.S, p.NS);
+    hipLaunchKernelGGL(knn_fallback_scan_kernel, dim3(kFbScanBlocks), dim3(256), 0, stream, q, ldq, t, ldt, (int)nt, p.fb_nch,
+                       p.fb_chunk, w.flag_count, w.flag_list, w.fb_partial);
+    SFM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(knn_fallback_merge_kernel, dim3(kFbMergeBlocks), dim3(64), 0, stream, w.fb_partial, p.fb_nch,
+                       w.flag_count, w.flag_list, idx, dist, stats, p.G, 2 * p.smax);
     sfm::prof_end(sfm::kProfKnnRefine, stream);
     SFM_CHECK_LAUNCH();
     return SFM_OK;

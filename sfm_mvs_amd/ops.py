@@ -238,3 +238,51 @@ def score_pnp(poses, K, X, obs, thr2=64.0, want_mask=False):
         check(_lib.lib().sfm_score_pnp(ptr(poses), h, k.ctypes.data_as(ctypes.c_void_p), ptr(X), ptr(obs), n,
                                        float(thr2), ptr(counts), ptr(mask), stream_ptr()), "sfm_score_pnp")
     return (counts, mask) if want_mask else counts
+
+
+class PairMatcher:
+    """Pre-planned KNN + Lowe-ratio for a fixed (nq, nt): all outputs and the workspace are allocated
+    once, so a call enqueues kernels only (no allocator traffic, no host sync).  This is the object the
+    pair-sharded matcher and bench.py drive."""
+
+    def __init__(self, nq, nt, device, ratio=0.70, dim=128):
+        self.nq, self.nt, self.dim, self.ratio = int(nq), int(nt), int(dim), float(ratio)
+        self.device = torch.device(device)
+        lib = _lib.lib()
+        need = lib.sfm_knn2_l2_f32_ws_bytes(self.nq, self.nt, self.dim)
+        if need == 0 and self.nq > 0:
+            raise SfmHipError(f"PairMatcher: unsupported shape nq={nq} nt={nt} dim={dim}")
+        self.ws = torch.empty(max(need, 256), dtype=torch.uint8, device=self.device)
+        self.idx = torch.empty((self.nq, 2), dtype=torch.int32, device=self.device)
+        self.dist = torch.empty((self.nq, 2), dtype=torch.float32, device=self.device)
+        self.stats = torch.zeros(4, dtype=torch.int32, device=self.device)
+        self.out_q = torch.empty(self.nq, dtype=torch.int32, device=self.device)
+        self.out_t = torch.empty(self.nq, dtype=torch.int32, device=self.device)
+        self.count = torch.zeros(1, dtype=torch.int32, device=self.device)
+
+    def run(self, des0, des1):
+        require_cuda(des0, des1)
+        if tuple(des0.shape) != (self.nq, self.dim) or tuple(des1.shape) != (self.nt, self.dim):
+            raise SfmHipError("PairMatcher.run: shape differs from the plan")
+        if des0.dtype != torch.float32 or des1.dtype != torch.float32 or des0.stride(1) != 1 or des1.stride(1) != 1:
+            raise SfmHipError("PairMatcher.run: float32 row-major descriptors required")
+        lib = _lib.lib()
+        s = stream_ptr()
+        check(lib.sfm_knn2_l2_f32(ptr(des0), self.nq, des0.stride(0), ptr(des1), self.nt, des1.stride(0), self.dim,
+                                  ptr(self.idx), ptr(self.dist), ptr(self.stats), ptr(self.ws), self.ws.numel(), s),
+              "sfm_knn2_l2_f32")
+        check(lib.sfm_ratio_compact(ptr(self.idx), ptr(self.dist), self.nq, self.ratio, ptr(self.out_q), ptr(self.out_t),
+                                    ptr(self.count), None, s), "sfm_ratio_compact")
+        return self.idx, self.dist, self.out_q, self.out_t, self.count
+
+
+def profile_enable(on=True):
+    check(_lib.lib().sfm_profile_enable(1 if on else 0), "sfm_profile_enable")
+
+
+def profile_read(slot):
+    """(total_ms, launches) of a profiling slot since the last read (synchronises)."""
+    ms = ctypes.c_double(0)
+    n = ctypes.c_int64(0)
+    check(_lib.lib().sfm_profile_read(int(slot), ctypes.byref(ms), ctypes.byref(n)), "sfm_profile_read")
+    return ms.value, n.value
