@@ -131,6 +131,8 @@ int sfm_triangulate_dlt(const double* P1_host, const double* P2_host,
  *   JtJ_cam_dev [ncam x 36], Jtr_cam_dev [ncam x 6] float64: Gauss-Newton normal
  *               equations per camera in (rvec, tvec), residual = proj - obs
  *   JtJ_pt_dev  [npt x 9],  Jtr_pt_dev [npt x 3] float64: same per 3D point
+ *   res2_dev    [1] float64  sum of ||proj - obs||^2 in fp64 (the squared error norm
+ *               OpenCV's Levenberg-Marquardt compares); accumulated (+=), caller zeroes
  *   cams_dev    [ncam x 6] float64 (rvec3, tvec3);  K_host 9 doubles row-major
  *   X_dev       [npt x 3] float32 with row stride ldx
  * ---------------------------------------------------------------------- */
@@ -142,7 +144,7 @@ int sfm_project_residual(const double* cams_dev, int64_t ncam, const double* K_h
                          float* proj_dev, double* sumsq_dev,
                          uint8_t* inlier_dev, float thr2,
                          double* JtJ_cam_dev, double* Jtr_cam_dev,
-                         double* JtJ_pt_dev, double* Jtr_pt_dev,
+                         double* JtJ_pt_dev, double* Jtr_pt_dev, double* res2_dev,
                          void* ws_dev, size_t ws_bytes, void* stream);
 
 /* Dense visibility variant (BASELINE config 4: every camera sees every point).
@@ -170,6 +172,14 @@ int sfm_ba_dense_sweep(const double* cams_dev, int64_t ncam, const double* K_hos
 int sfm_score_essential(const double* E_dev, int h, const double* x1n_dev,
                         const double* x2n_dev, int64_t n, float thr2,
                         int32_t* counts_dev, uint8_t* mask_dev, void* stream);
+
+/* cv2.recoverPose cheirality vote (sfm.py:311): for up to 4 candidate poses [R|t]
+ * (P_host: h x 12 doubles, row-major 3x4) triangulate every K-normalised pair
+ * against [I|0] in fp64 and count points with positive depth < dist_thresh in
+ * both views.  mask (optional) [h x n] uint8 is 255/0 like OpenCV's. */
+int sfm_recover_pose_score(const double* P_host, int h, const double* x1n_dev,
+                           const double* x2n_dev, int64_t n, double dist_thresh, int rows,
+                           int32_t* counts_dev, uint8_t* mask_dev, void* stream);
 
 /* PnP-RANSAC scoring for h hypotheses (rvec,tvec) over n 3D-2D pairs:
  * err = ||proj - obs||^2 as float32, inlier iff err <= thr2 (sfm.py:67 defaults:

@@ -136,14 +136,14 @@ def project_residual(cams, K, X, obs, cam_idx=None, pt_idx=None, thr2=64.0, want
     ncam, npt, nobs = cams.shape[0], X.shape[0], obs.shape[0]
     ci = None if cam_idx is None else np.ascontiguousarray(cam_idx, np.int32)
     pi = None if pt_idx is None else np.ascontiguousarray(pt_idx, np.int32)
-    out = dict(proj=np.empty((nobs, 2), np.float32), sumsq=np.zeros(1), inlier=np.empty(nobs, np.uint8))
+    out = dict(proj=np.empty((nobs, 2), np.float32), sumsq=np.zeros(1), inlier=np.empty(nobs, np.uint8), res2=np.zeros(1))
     if want_jac:
         out.update(JtJ_cam=np.zeros((ncam, 36)), Jtr_cam=np.zeros((ncam, 6)), JtJ_pt=np.zeros((npt, 9)),
                    Jtr_pt=np.zeros((npt, 3)))
     lib().orc_project_residual(_p(cams), C.c_int64(ncam), _p(_f64(K).reshape(9)), _p(X), C.c_int64(npt), C.c_int64(3),
                                _p(obs), _p(ci), _p(pi), C.c_int64(nobs), _p(out["proj"]), _p(out["sumsq"]),
                                _p(out["inlier"]), C.c_float(thr2), _p(out.get("JtJ_cam")), _p(out.get("Jtr_cam")),
-                               _p(out.get("JtJ_pt")), _p(out.get("Jtr_pt")), C.c_int(1))
+                               _p(out.get("JtJ_pt")), _p(out.get("Jtr_pt")), _p(out["res2"] if want_jac else None), C.c_int(1))
     return out
 
 
@@ -186,4 +186,15 @@ def score_pnp(poses, K, X, obs, thr2=64.0):
     mask = np.empty((h, n), np.uint8)
     lib().orc_score_pnp(_p(poses), C.c_int(h), _p(_f64(K).reshape(9)), _p(X), _p(obs), C.c_int64(n), C.c_float(thr2),
                         _p(counts), _p(mask))
+    return counts, mask
+
+
+def recover_pose_score(Ps, x1n, x2n, dist=50.0, rows=4):
+    Ps = _f64(Ps).reshape(-1, 12)
+    x1n, x2n = _f64(x1n).reshape(-1, 2), _f64(x2n).reshape(-1, 2)
+    h, n = Ps.shape[0], x1n.shape[0]
+    counts = np.empty(h, np.int32)
+    mask = np.empty((h, n), np.uint8)
+    lib().orc_recover_pose_score(_p(Ps), C.c_int(h), _p(x1n), _p(x2n), C.c_int64(n), C.c_double(dist), C.c_int(rows),
+                                 _p(counts), _p(mask))
     return counts, mask

@@ -281,6 +281,41 @@ void orc_triangulate_dlt(const double* P1, const double* P2, const float* x1, co
     }
 }
 
+ /* cv2.recoverPose cheirality vote (sfm.py:311): triangulate K-normalised double points against
+ * [I|0] / [R|t] (4 candidates from decomposeEssentialMat) and keep points with
+ * Q2*Q3 > 0, Q2/Q3 < dist, 0 < z' < dist.  Mask is 255/0 as OpenCV returns it. */
+void orc_recover_pose_score(const double* Ps, int h, const double* x1n, const double* x2n, int64_t n, double dist,
+                            int rows, int32_t* counts, uint8_t* mask) {
+    const double P0[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    const int per = rows / 2;
+    for (int m = 0; m < h; ++m) {
+        const double* P[2] = {P0, Ps + 12 * m};
+        int32_t cnt = 0;
+        for (int64_t i = 0; i < n; ++i) {
+            double A[6 * 4], w[4], Vt[16];
+            const double xs[2] = {x1n[2 * i], x2n[2 * i]}, ys[2] = {x1n[2 * i + 1], x2n[2 * i + 1]};
+            for (int v = 0; v < 2; ++v)
+                for (int k = 0; k < 4; ++k) {
+                    A[(v * per + 0) * 4 + k] = xs[v] * P[v][8 + k] - P[v][0 + k];
+                    A[(v * per + 1) * 4 + k] = ys[v] * P[v][8 + k] - P[v][4 + k];
+                    if (per == 3) A[(v * per + 2) * 4 + k] = xs[v] * P[v][4 + k] - ys[v] * P[v][0 + k];
+                }
+            orc_jacobi_svd(A, rows, 4, w, NULL, Vt);
+            const double* Q = Vt + 12;
+            int good = Q[2] * Q[3] > 0;
+            const double q0 = Q[0] / Q[3], q1 = Q[1] / Q[3], q2 = Q[2] / Q[3], q3 = Q[3] / Q[3];
+            good = (q2 < dist) && good;
+            const double* P1 = P[1];
+            const double z = ((P1[8] * q0 + P1[9] * q1) + P1[10] * q2) + P1[11] * q3;
+            good = (z > 0) && good;
+            good = (z < dist) && good;
+            if (mask) mask[(int64_t)m * n + i] = good ? 255 : 0;
+            cnt += good;
+        }
+        counts[m] = cnt;
+    }
+}
+
 /* ------------------------------------------------------------------------------------------
  * cv2.Rodrigues                                                            sfm.py:69,84,119
  * vec→mat: R = cos(th) I + (1-cos(th)) r r^T + sin(th) [r]x, th = |rvec|, r = rvec/th;
@@ -441,14 +476,14 @@ double orc_reprojection_error(const double* Rt, const double* K, const float* X,
 void orc_project_residual(const double* cams, int64_t ncam, const double* K, const float* X, int64_t npt,
                           int64_t ldx, const float* obs, const int32_t* cam_idx, const int32_t* pt_idx,
                           int64_t nobs, float* proj, double* sumsq, uint8_t* inlier, float thr2, double* JtJ_cam,
-                          double* Jtr_cam, double* JtJ_pt, double* Jtr_pt, int nthreads) {
+                          double* Jtr_cam, double* JtJ_pt, double* Jtr_pt, double* res2, int nthreads) {
     (void)nthreads;
     (void)npt;
     cam_t* cs = (cam_t*)malloc(sizeof(cam_t) * (size_t)ncam);
     double* dR = (double*)malloc(sizeof(double) * 27 * (size_t)ncam);
     for (int64_t c = 0; c < ncam; ++c) cam_init(&cs[c], cams + 6 * c, cams + 6 * c + 3, K, dR + 27 * c);
-    const int want_j = JtJ_cam || Jtr_cam || JtJ_pt || Jtr_pt;
-    double ss = 0;
+    const int want_j = JtJ_cam || Jtr_cam || JtJ_pt || Jtr_pt || res2;
+    double ss = 0, rr = 0;
     for (int64_t o = 0; o < nobs; ++o) {
         const int64_t ci = cam_idx ? cam_idx[o] : 0, pi = pt_idx ? pt_idx[o] : o;
         const cam_t* c = &cs[ci];
@@ -469,6 +504,7 @@ void orc_project_residual(const double* cams, int64_t ncam, const double* K, con
         if (want_j) {
             const double x = xyz[0], y = xyz[1], z = xyz[2];
             const double ru = u - (double)obs[2 * o], rv = v - (double)obs[2 * o + 1];
+            rr += ru * ru + rv * rv;
             double Jc[2][6], Jp[2][3];
             const double* dRdr = dR + 27 * ci;
             for (int j = 0; j < 3; ++j) {
@@ -497,6 +533,7 @@ void orc_project_residual(const double* cams, int64_t ncam, const double* K, con
         }
     }
     if (sumsq) *sumsq += ss;
+    if (res2) *res2 += rr;
     free(cs);
     free(dR);
 }

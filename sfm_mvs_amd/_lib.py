@@ -33,10 +33,11 @@ SIGNATURES = {
     "sfm_triangulate_dlt": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _int, _int, _vp, _vp]),
     "sfm_project_residual_ws_bytes": (_sz, [_i64, _i64, _i64]),
     "sfm_project_residual": (_int, [_vp, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _f32,
-                                    _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+                                    _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sfm_ba_dense_sweep_ws_bytes": (_sz, [_i64, _i64]),
     "sfm_ba_dense_sweep": (_int, [_vp, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sfm_score_essential": (_int, [_vp, _int, _vp, _vp, _i64, _f32, _vp, _vp, _vp]),
+    "sfm_recover_pose_score": (_int, [_vp, _int, _vp, _vp, _i64, _f64, _int, _vp, _vp, _vp]),
     "sfm_score_pnp": (_int, [_vp, _int, _vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp]),
     "sfm_profile_enable": (_int, [_int]),
     "sfm_debug_set_trace": (_int, [_vp]),

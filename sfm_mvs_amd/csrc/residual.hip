@@ -82,7 +82,7 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-constexpr int kNAcc = 28;   // 21 upper-triangular JtJ + 6 Jtr + 1 sumsq
+constexpr int kNAcc = 29;   // 21 upper-triangular JtJ + 6 Jtr + sumsq (f32 diff, the metric) + fp64 |proj-obs|^2
 
 // One lane per observation.  MODE 0: projection / residual / inliers only.  MODE 1: + Gauss-Newton blocks.
 // single_cam: every observation belongs to camera 0 → the 6x6 block is reduced in fixed order
@@ -123,6 +123,7 @@ __global__ __launch_bounds__(256) void residual_kernel(
         }
         if (MODE == 1) {
             const double ru = u - (double)ox, rv = v - (double)oy;
+            acc[28] = ru * ru + rv * rv;
             double Ju[6], Jv[6];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
@@ -175,13 +176,14 @@ __global__ __launch_bounds__(256) void residual_kernel(
     // fixed-order block reduction → one partial row per block
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int kFirst = (MODE == 1) ? 0 : 27;
+    constexpr int kLast = (MODE == 1) ? kNAcc : 28;
 #pragma unroll
-    for (int k = kFirst; k < kNAcc; ++k) {
+    for (int k = kFirst; k < kLast; ++k) {
         const double s = wave_sum(acc[k]);
         if (lane == 0) wacc[wave][k] = s;
     }
     __syncthreads();
-    if (threadIdx.x < kNAcc && threadIdx.x >= kFirst) {
+    if (threadIdx.x < kLast && threadIdx.x >= kFirst) {
         const int k = threadIdx.x;
         partials[(int64_t)blockIdx.x * kNAcc + k] = ((wacc[0][k] + wacc[1][k]) + wacc[2][k]) + wacc[3][k];
     }
@@ -189,13 +191,16 @@ __global__ __launch_bounds__(256) void residual_kernel(
 
 // Sums the per-block partial rows in block order (deterministic) and scatters into the outputs.
 __global__ void final_reduce_kernel(const double* __restrict__ partials, int nblocks, int with_jac,
-                                    double* __restrict__ sumsq, double* __restrict__ JtJ_cam, double* __restrict__ Jtr_cam) {
+                                    double* __restrict__ sumsq, double* __restrict__ JtJ_cam, double* __restrict__ Jtr_cam,
+                                    double* __restrict__ res2) {
     const int k = threadIdx.x;
     if (k >= kNAcc) return;
     if (!with_jac && k != 27) return;
     double s = 0;
     for (int b = 0; b < nblocks; ++b) s += partials[(int64_t)b * kNAcc + k];
-    if (k == 27) {
+    if (k == 28) {
+        if (res2) *res2 += s;
+    } else if (k == 27) {
         if (sumsq) *sumsq += s;
     } else if (k >= 21) {
         if (Jtr_cam) Jtr_cam[k - 21] += s;
@@ -275,8 +280,8 @@ extern "C" size_t sfm_project_residual_ws_bytes(int64_t nobs, int64_t ncam, int6
 extern "C" int sfm_project_residual(const double* cams, int64_t ncam, const double* K_host, const float* X, int64_t npt,
                                     int64_t ldx, const float* obs, const int32_t* cam_idx, const int32_t* pt_idx,
                                     int64_t nobs, float* proj, double* sumsq, uint8_t* inlier, float thr2,
-                                    double* JtJ_cam, double* Jtr_cam, double* JtJ_pt, double* Jtr_pt, void* ws,
-                                    size_t ws_bytes, void* stream_) {
+                                    double* JtJ_cam, double* Jtr_cam, double* JtJ_pt, double* Jtr_pt, double* res2,
+                                    void* ws, size_t ws_bytes, void* stream_) {
     SFM_CHECK_ARG(ncam >= 1 && npt >= 0 && nobs >= 0 && ldx >= 3, "sfm_project_residual: bad sizes");
     SFM_CHECK_ARG(cams && K_host, "sfm_project_residual: null camera/intrinsics");
     if (nobs == 0) return SFM_OK;
@@ -295,7 +300,7 @@ extern "C" int sfm_project_residual(const double* cams, int64_t ncam, const doub
 
     hipLaunchKernelGGL(cam_prepare_kernel, dim3((unsigned)((ncam + 63) / 64)), dim3(64), 0, stream, cams, ncam, table);
     SFM_CHECK_LAUNCH();
-    const bool jac = JtJ_cam || Jtr_cam || JtJ_pt || Jtr_pt;
+    const bool jac = JtJ_cam || Jtr_cam || JtJ_pt || Jtr_pt || res2;
     const int single = (cam_idx == nullptr) ? 1 : 0;
     const Intrin K = make_intrin(K_host);
     if (jac)
@@ -305,9 +310,9 @@ extern "C" int sfm_project_residual(const double* cams, int64_t ncam, const doub
         hipLaunchKernelGGL(residual_kernel<0>, dim3(blocks), dim3(256), 0, stream, table, K, X, ldx, obs, cam_idx, pt_idx,
                            nobs, proj, inlier, thr2, single, partials, JtJ_cam, Jtr_cam, JtJ_pt, Jtr_pt);
     SFM_CHECK_LAUNCH();
-    if (sumsq || (jac && single)) {
-        hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(64), 0, stream, partials, blocks, (jac && single) ? 1 : 0, sumsq,
-                           single ? JtJ_cam : nullptr, single ? Jtr_cam : nullptr);
+    if (sumsq || res2 || (jac && single)) {
+        hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(64), 0, stream, partials, blocks, jac ? 1 : 0, sumsq,
+                           single ? JtJ_cam : nullptr, single ? Jtr_cam : nullptr, res2);
         SFM_CHECK_LAUNCH();
     }
     return SFM_OK;

@@ -76,26 +76,9 @@ __device__ __forceinline__ void jacobi_pair(double (&At)[4][M], double (&V)[4][4
     }
 }
 
+// Right singular vector of the smallest singular value of the DLT system whose COLUMNS are At[k][*].
 template <int M>
-__global__ __launch_bounds__(256) void triangulate_kernel(ProjPair P, const float* __restrict__ x1,
-                                                          const float* __restrict__ x2, int64_t n, int64_t spt,
-                                                          int64_t sxy, int normalise_w, float* __restrict__ X4) {
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    constexpr int PER = M / 2;
-    double At[4][M];   // At[k][row]: column k of the DLT matrix
-#pragma unroll
-    for (int v = 0; v < 2; ++v) {
-        const float* xs = v == 0 ? x1 : x2;
-        const double x = (double)xs[i * spt];
-        const double y = (double)xs[i * spt + sxy];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            At[k][v * PER + 0] = x * P.p[v][8 + k] - P.p[v][k];
-            At[k][v * PER + 1] = y * P.p[v][8 + k] - P.p[v][4 + k];
-            if (PER == 3) At[k][v * PER + 2] = x * P.p[v][4 + k] - y * P.p[v][k];
-        }
-    }
+__device__ __forceinline__ void dlt_nullvec(double (&At)[4][M], double (&X)[4]) {
     double V[4][4], W[4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -140,12 +123,41 @@ __global__ __launch_bounds__(256) void triangulate_kernel(ProjPair P, const floa
                 const int ti = id[a]; id[a] = id[k]; id[k] = ti;
             }
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) X[k] = id[3] == 0 ? V[0][k] : id[3] == 1 ? V[1][k] : id[3] == 2 ? V[2][k] : V[3][k];
+}
+
+template <int M>
+__device__ __forceinline__ void dlt_build(double (&At)[4][M], const double* __restrict__ Pa, const double* __restrict__ Pb,
+                                          double xa, double ya, double xb, double yb) {
+    constexpr int PER = M / 2;
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+        const double* P = v == 0 ? Pa : Pb;
+        const double x = v == 0 ? xa : xb, y = v == 0 ? ya : yb;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            At[k][v * PER + 0] = x * P[8 + k] - P[k];
+            At[k][v * PER + 1] = y * P[8 + k] - P[4 + k];
+            if (PER == 3) At[k][v * PER + 2] = x * P[4 + k] - y * P[k];
+        }
+    }
+}
+
+template <int M>
+__global__ __launch_bounds__(256) void triangulate_kernel(ProjPair P, const float* __restrict__ x1,
+                                                          const float* __restrict__ x2, int64_t n, int64_t spt,
+                                                          int64_t sxy, int normalise_w, float* __restrict__ X4) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double At[4][M];   // At[k][row]: column k of the DLT matrix
+    dlt_build<M>(At, P.p[0], P.p[1], (double)x1[i * spt], (double)x1[i * spt + sxy], (double)x2[i * spt],
+                 (double)x2[i * spt + sxy]);
+    double Xd[4];
+    dlt_nullvec<M>(At, Xd);
     float X[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const double v = id[3] == 0 ? V[0][k] : id[3] == 1 ? V[1][k] : id[3] == 2 ? V[2][k] : V[3][k];
-        X[k] = (float)v;
-    }
+    for (int k = 0; k < 4; ++k) X[k] = (float)Xd[k];
     if (normalise_w) {
         const float w = X[3];
 #pragma unroll
@@ -153,6 +165,39 @@ __global__ __launch_bounds__(256) void triangulate_kernel(ProjPair P, const floa
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) X4[k * n + i] = X[k];
+}
+
+// cv2.recoverPose's cheirality vote (sfm.py:311): for pose candidate m = blockIdx.y triangulate every
+// K-normalised correspondence against [I|0] / [R|t] in fp64 (points are double there) and test
+//   Q2*Q3 > 0,  Q2/Q3 < dist,  0 < z' < dist  with z' = third row of [R|t] * (Q/Q3).
+struct PoseCands {
+    double p[4][12];
+};
+
+template <int M>
+__global__ __launch_bounds__(256) void recover_pose_kernel(PoseCands C, const double* __restrict__ x1n,
+                                                           const double* __restrict__ x2n, int64_t n, double dist,
+                                                           int* __restrict__ counts, unsigned char* __restrict__ mask) {
+    const int m = blockIdx.y;
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    bool good = false;
+    if (i < n) {
+        const double P0[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+        const double* P1 = C.p[m];
+        double At[4][M];
+        dlt_build<M>(At, P0, P1, x1n[2 * i], x1n[2 * i + 1], x2n[2 * i], x2n[2 * i + 1]);
+        double Q[4];
+        dlt_nullvec<M>(At, Q);
+        good = Q[2] * Q[3] > 0;
+        const double q0 = Q[0] / Q[3], q1 = Q[1] / Q[3], q2 = Q[2] / Q[3], q3 = Q[3] / Q[3];
+        good = (q2 < dist) && good;
+        const double z = ((P1[8] * q0 + P1[9] * q1) + P1[10] * q2) + P1[11] * q3;
+        good = (z > 0) && good;
+        good = (z < dist) && good;
+        if (mask) mask[(int64_t)m * n + i] = good ? 255 : 0;
+    }
+    const int cnt = __popcll(__ballot(good));
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&counts[m], cnt);
 }
 
 }  // namespace
@@ -178,6 +223,25 @@ extern "C" int sfm_triangulate_dlt(const double* P1, const double* P2, const flo
         hipLaunchKernelGGL(triangulate_kernel<6>, grid, dim3(256), 0, sfm::as_stream(stream_), P, x1, x2, n, stride_pt,
                            stride_xy, normalise_w, X4);
     sfm::prof_end(sfm::kProfTriangulate, sfm::as_stream(stream_));
+    SFM_CHECK_LAUNCH();
+    return SFM_OK;
+}
+
+extern "C" int sfm_recover_pose_score(const double* P_host, int h, const double* x1n, const double* x2n, int64_t n,
+                                      double dist_thresh, int rows, int32_t* counts, uint8_t* mask, void* stream_) {
+    SFM_CHECK_ARG(h >= 1 && h <= 4 && n >= 0 && (rows == 4 || rows == 6), "sfm_recover_pose_score: bad sizes");
+    SFM_CHECK_ARG(P_host && counts && (n == 0 || (x1n && x2n)), "sfm_recover_pose_score: null pointer");
+    hipStream_t stream = sfm::as_stream(stream_);
+    SFM_CHECK_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)h, stream));
+    if (n == 0) return SFM_OK;
+    PoseCands C;
+    for (int m = 0; m < 4; ++m)
+        for (int k = 0; k < 12; ++k) C.p[m][k] = m < h ? P_host[m * 12 + k] : 0.0;
+    const dim3 grid((unsigned)((n + 255) / 256), (unsigned)h);
+    if (rows == 4)
+        hipLaunchKernelGGL(recover_pose_kernel<4>, grid, dim3(256), 0, stream, C, x1n, x2n, n, dist_thresh, counts, mask);
+    else
+        hipLaunchKernelGGL(recover_pose_kernel<6>, grid, dim3(256), 0, stream, C, x1n, x2n, n, dist_thresh, counts, mask);
     SFM_CHECK_LAUNCH();
     return SFM_OK;
 }

@@ -1,0 +1,135 @@
+"""cv2-named facade over the HIP back-end: exactly the cv2 symbols sfm.py's hot path uses
+(SURVEY §2.2 ★ rows), with cv2's shapes, dtypes and return conventions, so that
+
+    from sfm_mvs_amd import cv2compat as cv2
+
+makes sfm.py's helper functions (Triangulation sfm.py:45, PnP :60, ReprojectionError :79, the matcher
+part of find_features :259-268, findEssentialMat/recoverPose :307-311) run on the MI355X unchanged.
+NumPy in, NumPy out; every call uploads, launches the kernels of libsfmhip.so and downloads.
+Not provided (out of scope): SIFT, cvtColor, pyrDown, imread, GUI.
+"""
+import numpy as np
+import torch
+
+from . import hostgeom as _hg
+from . import ops as _ops
+from . import ransac as _ransac
+
+RANSAC = 8
+NORM_L2 = 4
+SOLVEPNP_ITERATIVE = 0
+TRIANGULATE_ROWS = 4        # 4: current OpenCV DLT system; 6: legacy cvTriangulatePoints
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        raise _ops.SfmHipError("cv2compat needs a HIP device: there is no CPU fallback")
+    return torch.device("cuda")
+
+
+class DMatch:
+    __slots__ = ("queryIdx", "trainIdx", "imgIdx", "distance")
+
+    def __init__(self, queryIdx=-1, trainIdx=-1, imgIdx=0, distance=float("inf")):
+        self.queryIdx, self.trainIdx, self.imgIdx, self.distance = queryIdx, trainIdx, imgIdx, distance
+
+    def __repr__(self):
+        return f"DMatch(q={self.queryIdx}, t={self.trainIdx}, d={self.distance})"
+
+
+class BFMatcher:
+    """cv2.BFMatcher(normType=NORM_L2, crossCheck=False) — sfm.py:259, isfm.py:47."""
+
+    def __init__(self, normType=NORM_L2, crossCheck=False):
+        if normType != NORM_L2 or crossCheck:
+            raise NotImplementedError("only BFMatcher(NORM_L2, crossCheck=False) is on the reference's path")
+
+    def knnMatchArrays(self, queryDescriptors, trainDescriptors, k=2):
+        """Array form: (trainIdx (nq,2) int32, distance (nq,2) float32)."""
+        if k != 2:
+            raise NotImplementedError("k=2 only (sfm.py:260)")
+        d = _dev()
+        q = torch.as_tensor(np.ascontiguousarray(queryDescriptors, np.float32)).to(d)
+        t = torch.as_tensor(np.ascontiguousarray(trainDescriptors, np.float32)).to(d)
+        idx, dist = _ops.knn2(q, t)
+        return idx.cpu().numpy(), dist.cpu().numpy()
+
+    def knnMatch(self, queryDescriptors, trainDescriptors, k=2):
+        """list[nq] of [DMatch, DMatch] exactly as cv2 returns it (fewer entries when nt < k)."""
+        idx, dist = self.knnMatchArrays(queryDescriptors, trainDescriptors, k)
+        out = []
+        for qi in range(idx.shape[0]):
+            out.append([DMatch(qi, int(idx[qi, j]), 0, float(dist[qi, j])) for j in range(2) if idx[qi, j] >= 0])
+        return out
+
+
+def triangulatePoints(projMatr1, projMatr2, projPoints1, projPoints2):
+    """cv2.triangulatePoints: (2,N) points (any strides, float32/float64) → (4,N) float32 (sfm.py:53)."""
+    d = _dev()
+    a = torch.as_tensor(np.asarray(projPoints1, np.float32)).to(d)
+    b = torch.as_tensor(np.asarray(projPoints2, np.float32)).to(d)
+    if a.dim() != 2 or a.shape[0] != 2:
+        raise ValueError("triangulatePoints expects 2xN point arrays")
+    return _ops.triangulate(np.asarray(projMatr1, np.float64), np.asarray(projMatr2, np.float64), a, b,
+                            rows=TRIANGULATE_ROWS).cpu().numpy()
+
+
+def Rodrigues(src):
+    """cv2.Rodrigues: 3-vector → (3x3, jacobian=None) or 3x3 → ((3,1) vector, None)."""
+    src = np.asarray(src, np.float64)
+    if src.size == 9:
+        return _hg.rodrigues_mat2vec(src.reshape(3, 3)).reshape(3, 1), None
+    return _hg.rodrigues_vec2mat(src.reshape(3)), None
+
+
+def convertPointsFromHomogeneous(src):
+    """(N,4)/(N,3) → (N,1,3)/(N,1,2): divide by the last coordinate (w is already 1 at sfm.py:86,351)."""
+    src = np.asarray(src)
+    w = src[:, -1:]
+    scale = np.where(w != 0, 1.0 / np.where(w != 0, w, 1), 1.0).astype(src.dtype)
+    return (src[:, :-1] * scale).reshape(src.shape[0], 1, src.shape[1] - 1)
+
+
+def projectPoints(objectPoints, rvec, tvec, cameraMatrix, distCoeffs=None):
+    """cv2.projectPoints without distortion (sfm.py:88,121) → ((N,1,2) in the object points' dtype, None)."""
+    if distCoeffs is not None and np.any(np.asarray(distCoeffs) != 0):
+        raise NotImplementedError("the reference passes no distortion (sfm.py:88, :325)")
+    d = _dev()
+    X = np.asarray(objectPoints)
+    out_dtype = np.float32 if X.dtype == np.float32 else np.float64
+    Xf = torch.as_tensor(np.ascontiguousarray(X.reshape(-1, 3), np.float32)).to(d)
+    cams = torch.as_tensor(np.hstack([np.asarray(rvec, np.float64).ravel(), np.asarray(tvec, np.float64).ravel()])[None]).to(d)
+    obs = torch.zeros((Xf.shape[0], 2), dtype=torch.float32, device=d)
+    out = _ops.project_residual(cams, np.asarray(cameraMatrix, np.float64), Xf, obs, want_proj=True)
+    return out["proj"].cpu().numpy().astype(out_dtype).reshape(-1, 1, 2), None
+
+
+def norm(src1, src2=None, normType=NORM_L2):
+    """cv2.norm(a, b, NORM_L2): differences in the inputs' dtype, squares accumulated in double (sfm.py:93,95)."""
+    if normType != NORM_L2:
+        raise NotImplementedError("NORM_L2 only")
+    a = np.asarray(src1)
+    diff = a if src2 is None else a - np.asarray(src2)
+    d = _dev()
+    return float(torch.as_tensor(np.ascontiguousarray(diff)).to(d).to(torch.float64).square().sum().sqrt().item())
+
+
+def findEssentialMat(points1, points2, cameraMatrix, method=RANSAC, prob=0.999, threshold=1.0, mask=None):
+    if method != RANSAC:
+        raise NotImplementedError("method=cv2.RANSAC only (sfm.py:307)")
+    return _ransac.find_essential_mat(points1, points2, np.asarray(cameraMatrix, np.float64), prob, threshold)
+
+
+def recoverPose(E, points1, points2, cameraMatrix):
+    return _ransac.recover_pose(E, points1, points2, np.asarray(cameraMatrix, np.float64))
+
+
+def solvePnPRansac(objectPoints, imagePoints, cameraMatrix, distCoeffs, rvec=None, tvec=None, useExtrinsicGuess=False,
+                   iterationsCount=100, reprojectionError=8.0, confidence=0.99, inliers=None, flags=SOLVEPNP_ITERATIVE):
+    """The reference calls this with cv2.SOLVEPNP_ITERATIVE as the 5th POSITIONAL argument (sfm.py:67), which
+    is the `rvec` slot: it is ignored, exactly as OpenCV ignores it when useExtrinsicGuess is False."""
+    if useExtrinsicGuess or flags != SOLVEPNP_ITERATIVE:
+        raise NotImplementedError("defaults only (sfm.py:67)")
+    if distCoeffs is not None and np.any(np.asarray(distCoeffs) != 0):
+        raise NotImplementedError("zero distortion only (sfm.py:325,362)")
+    return _ransac.solve_pnp_ransac(objectPoints, imagePoints, cameraMatrix, iterationsCount, reprojectionError, confidence)

@@ -137,7 +137,7 @@ def triangulate(P1, P2, pts1, pts2, rows=4, normalise_w=False):
 
 
 def project_residual(cams, K, X, obs, cam_idx=None, pt_idx=None, thr2=64.0, want_proj=True, want_inlier=False,
-                     want_jac=False, want_pt_jac=False):
+                     want_jac=False, want_pt_jac=False, want_res2=False):
     """Reprojection sweep (sfm.py:79-100 / :67 scoring / :104-136 residual).
 
     cams [ncam,6] float64 CUDA (rvec, tvec); K 3x3 host; X [npt,3] float32 CUDA; obs [nobs,2] float32 CUDA.
@@ -164,6 +164,8 @@ def project_residual(cams, K, X, obs, cam_idx=None, pt_idx=None, thr2=64.0, want
     if want_pt_jac:
         out["JtJ_pt"] = torch.zeros((npt, 9), dtype=torch.float64, device=dev)
         out["Jtr_pt"] = torch.zeros((npt, 3), dtype=torch.float64, device=dev)
+    if want_res2:
+        out["res2"] = torch.zeros(1, dtype=torch.float64, device=dev)
     lib = _lib.lib()
     ws = _workspace(dev, lib.sfm_project_residual_ws_bytes(nobs, ncam, npt))
     ci = None if cam_idx is None else cam_idx.contiguous().to(torch.int32)
@@ -173,7 +175,7 @@ def project_residual(cams, K, X, obs, cam_idx=None, pt_idx=None, thr2=64.0, want
                                        X.stride(0) if npt > 1 else 3, ptr(obs), ptr(ci), ptr(pi), nobs,
                                        ptr(out.get("proj")), ptr(out["sumsq"]), ptr(out.get("inlier")), float(thr2),
                                        ptr(out.get("JtJ_cam")), ptr(out.get("Jtr_cam")), ptr(out.get("JtJ_pt")),
-                                       ptr(out.get("Jtr_pt")), ptr(ws), ws.numel(), stream_ptr()),
+                                       ptr(out.get("Jtr_pt")), ptr(out.get("res2")), ptr(ws), ws.numel(), stream_ptr()),
               "sfm_project_residual")
     return out
 

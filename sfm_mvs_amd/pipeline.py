@@ -1,0 +1,185 @@
+"""Host-side mirror of the reference's helper functions and driver (sfm.py), on top of the HIP back-end.
+
+Same names, argument meaning, shapes and quirks as the reference so that a user of sfm.py finds the same
+interface: `find_features` (sfm.py:242-270, matcher part), `Triangulation` (:45-56), `PnP`
+(:60-76), `ReprojectionError` (:79-100), `common_points` (:215-239), `to_ply` (:169-201) and the
+sliding-window driver (:274-423) as `run_sfm`.  SIFT itself is out of scope: an image is
+represented by its keypoint coordinates + 128-D descriptors ("features"), from any provider.
+
+Behavioural quirks that are load-bearing for parity are reproduced and marked `# quirk`.
+"""
+import numpy as np
+import torch
+
+from . import cv2compat as cv2
+from . import ops
+
+RATIO = 0.70          # sfm.py:264
+
+
+def find_features(feat0, feat1):
+    """Matcher half of sfm.py:242-270.  feat = (kp (n,2) float32 keypoint coordinates, des (n,128) float32).
+    Returns pts0, pts1 (M,2) float32 in ascending queryIdx order."""
+    kp0, des0 = feat0
+    kp1, des1 = feat1
+    dev = torch.device("cuda")
+    d0 = torch.as_tensor(np.ascontiguousarray(des0, np.float32)).to(dev)
+    d1 = torch.as_tensor(np.ascontiguousarray(des1, np.float32)).to(dev)
+    idx, dist = ops.knn2(d0, d1)                                   # bf.knnMatch(des0, des1, k=2)  sfm.py:260
+    out_q, out_t, count = ops.ratio_compact(idx, dist, RATIO)      # m.distance < 0.70*n.distance   sfm.py:262-265
+    p0, p1 = ops.gather_matches(torch.as_tensor(np.ascontiguousarray(kp0, np.float32)).to(dev),
+                                torch.as_tensor(np.ascontiguousarray(kp1, np.float32)).to(dev), out_q, out_t, count)
+    m = int(count.item())
+    return p0[:m].cpu().numpy(), p1[:m].cpu().numpy()              # sfm.py:267-268
+
+
+def Triangulation(P1, P2, pts1, pts2, K, repeat):
+    """sfm.py:45-56."""
+    if not repeat:
+        points1 = np.transpose(pts1)
+        points2 = np.transpose(pts2)
+    else:
+        points1, points2 = pts1, pts2
+    cloud = cv2.triangulatePoints(P1, P2, points1, points2)
+    cloud = cloud / cloud[3]                                       # float32 division, sfm.py:54
+    return points1, points2, cloud
+
+
+def PnP(X, p, K, d, p_0, initial):
+    """sfm.py:60-76."""
+    if initial == 1:
+        X = X[:, 0, :]
+        p = p.T
+        p_0 = p_0.T
+    ret, rvecs, t, inliers = cv2.solvePnPRansac(X, p, K, d, cv2.SOLVEPNP_ITERATIVE)   # quirk 1: 5th positional = rvec
+    R, _ = cv2.Rodrigues(rvecs)
+    if inliers is not None:
+        p = p[inliers[:, 0]]
+        X = X[inliers[:, 0]]
+        p_0 = p_0[inliers[:, 0]]
+    return R, t, p, X, p_0
+
+
+def ReprojectionError(X, pts, Rt, K, homogenity):
+    """sfm.py:79-100: ||float32(proj) - float32(pts)||_F / N in ONE fused sweep on the device."""
+    R = Rt[:3, :3]
+    t = Rt[:3, 3]
+    r, _ = cv2.Rodrigues(R)
+    if homogenity == 1:
+        X = cv2.convertPointsFromHomogeneous(X.T)
+    Xf = np.ascontiguousarray(np.asarray(X, np.float32).reshape(-1, 3))
+    obs = np.float32(pts.T if homogenity == 1 else pts)
+    dev = torch.device("cuda")
+    cams = torch.as_tensor(np.hstack([r.ravel(), np.asarray(t, np.float64).ravel()])[None]).to(dev)
+    out = ops.project_residual(cams, K, torch.as_tensor(Xf).to(dev), torch.as_tensor(np.ascontiguousarray(obs)).to(dev))
+    p = out["proj"].cpu().numpy()
+    tot_error = float(np.sqrt(out["sumsq"].item())) / len(p)       # quirk 3: Frobenius norm / N
+    return tot_error, X, p
+
+
+def common_points(pts1, pts2, pts3):
+    """sfm.py:215-239.  quirk 2: a row of pts2 "equals" pts1[i] when x OR y is bit-equal; first hit wins;
+    duplicates in indx2 allowed; the complement is mask-and-compress of pts2 / pts3."""
+    pts1 = np.asarray(pts1)
+    pts2 = np.asarray(pts2)
+    pts3 = np.asarray(pts3)
+    hit = (pts2[None, :, 0] == pts1[:, None, 0]) | (pts2[None, :, 1] == pts1[:, None, 1])
+    any_hit = hit.any(1)
+    indx1 = np.flatnonzero(any_hit)
+    indx2 = hit.argmax(1)[any_hit]
+    keep = np.ones(len(pts2), bool)
+    keep[indx2] = False
+    return indx1, indx2, pts2[keep].reshape(-1, 2), pts3[keep].reshape(-1, 2)
+
+
+def to_ply(path, point_cloud, colors, densify=False):
+    """sfm.py:169-201 byte-for-byte: x200, keep dist < mean(dist)+300 about the centroid, tab-indented header
+    whose last line also indents the first vertex (quirk 9), colour columns written as B G R."""
+    pts = point_cloud.reshape(-1, 3) * 200
+    verts = np.hstack([pts, colors.reshape(-1, 3)])
+    centred = verts[:, :3] - np.mean(verts[:, :3], axis=0)
+    dist = np.sqrt(centred[:, 0] ** 2 + centred[:, 1] ** 2 + centred[:, 2] ** 2)
+    verts = verts[np.where(dist < np.mean(dist) + 300)]
+    lines = ["format ascii 1.0", "element vertex %d" % len(verts), "property float x", "property float y",
+             "property float z", "property uchar blue", "property uchar green", "property uchar red", "end_header"]
+    name = "dense.ply" if densify else "sparse.ply"
+    with open(path + "/Point_Cloud/" + name, "w") as f:
+        f.write("ply\n" + "".join("\t\t" + ln + "\n" for ln in lines) + "\t\t")
+        np.savetxt(f, verts, "%f %f %f %d %d %d")
+    return len(verts)
+
+
+def run_sfm(features, K, images=None, log=None):
+    """The reference's driver, sfm.py:274-423 (bundle_adjustment=False, its default).
+    features: list of (kp (n,2) float32, des (n,128) float32) per image, in sequence order.
+    images:   optional list of HxWx3 uint8 arrays for the colour lookup (sfm.py:393-394).
+    Returns dict(posearr (9+12*n_cam,), Xtot (m,3), colorstot (m,3), errors [per-frame], first_error)."""
+    K = np.asarray(K, np.float64)
+    say = log or (lambda *a: None)
+    posearr = K.ravel()
+    R_t_0 = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0]], np.float64)
+    R_t_1 = np.empty((3, 4))
+    P1 = np.matmul(K, R_t_0)
+    Xtot = np.zeros((1, 3))               # quirk 8: leading zero row
+    colorstot = np.zeros((1, 3))
+
+    pts0, pts1 = find_features(features[0], features[1])
+    E, mask = cv2.findEssentialMat(pts0, pts1, K, method=cv2.RANSAC, prob=0.999, threshold=0.4, mask=None)
+    pts0 = pts0[mask.ravel() == 1]        # quirk 4: {0,1} mask
+    pts1 = pts1[mask.ravel() == 1]
+    _, R, t, mask = cv2.recoverPose(E, pts0, pts1, K)
+    pts0 = pts0[mask.ravel() > 0]         # quirk 4: {0,255} mask
+    pts1 = pts1[mask.ravel() > 0]
+    R_t_1[:3, :3] = np.matmul(R, R_t_0[:3, :3])
+    R_t_1[:3, 3] = R_t_0[:3, 3] + np.matmul(R_t_0[:3, :3], t.ravel())
+    P2 = np.matmul(K, R_t_1)
+
+    pts0, pts1, points_3d = Triangulation(P1, P2, pts0, pts1, K, repeat=False)
+    first_error, points_3d, _ = ReprojectionError(points_3d, pts1, R_t_1, K, homogenity=1)
+    say("REPROJECTION ERROR: ", first_error)
+    Rot, trans, pts1, points_3d, pts0t = PnP(points_3d, pts1, K, np.zeros((5, 1), dtype=np.float32), pts0, initial=1)
+    posearr = np.hstack((posearr, P1.ravel(), P2.ravel()))
+
+    errors = []
+    for i in range(len(features) - 2):
+        pts_, pts2 = find_features(features[i + 1], features[i + 2])
+        if i != 0:
+            pts0, pts1, points_3d = Triangulation(P1, P2, pts0, pts1, K, repeat=False)   # quirk 6: all ratio matches
+            pts1 = pts1.T
+            points_3d = cv2.convertPointsFromHomogeneous(points_3d.T)[:, 0, :]
+        indx1, indx2, temp1, temp2 = common_points(pts1, pts_, pts2)
+        com_pts2 = pts2[indx2]
+        com_pts_ = pts_[indx2]
+        com_pts0 = pts0.T[indx1]          # quirk 5: unused, mis-indexed at i == 0 in the reference too
+        del com_pts0
+        Rot, trans, com_pts2, points_3d, com_pts_ = PnP(points_3d[indx1], com_pts2, K,
+                                                        np.zeros((5, 1), dtype=np.float32), com_pts_, initial=0)
+        Rtnew = np.hstack((Rot, trans))
+        Pnew = np.matmul(K, Rtnew)
+        error, points_3d, _ = ReprojectionError(points_3d, com_pts2, Rtnew, K, homogenity=0)
+        temp1, temp2, points_3d = Triangulation(P2, Pnew, temp1, temp2, K, repeat=False)
+        error, points_3d, _ = ReprojectionError(points_3d, temp2, Rtnew, K, homogenity=1)
+        say("Reprojection Error: ", error)
+        errors.append(error)
+        posearr = np.hstack((posearr, Pnew.ravel()))
+
+        Xtot = np.vstack((Xtot, points_3d[:, 0, :]))
+        pts1_reg = np.array(temp2, dtype=np.int32)         # quirk 10: truncation toward zero
+        if images is not None:
+            img2 = images[i + 2]
+            colors = np.array([img2[l[1], l[0]] for l in pts1_reg.T]).reshape(-1, 3)
+        else:
+            colors = np.zeros((pts1_reg.shape[1], 3))
+        colorstot = np.vstack((colorstot, colors))
+
+        R_t_0 = np.copy(R_t_1)            # quirk 7: only the last two cameras are kept
+        P1 = np.copy(P2)
+        pts0 = np.copy(pts_)
+        pts1 = np.copy(pts2)
+        P2 = np.copy(Pnew)
+    return dict(posearr=posearr, Xtot=Xtot, colorstot=colorstot, errors=errors, first_error=first_error)
+
+
+def save_pose_csv(path, posearr):
+    """sfm.py:423: one value per line, numpy's default '%.18e'."""
+    np.savetxt(path, posearr, delimiter="\n")

