@@ -134,6 +134,10 @@ def bench_knn(args, world, rank, dev):
     elapsed = max_over_ranks(elapsed, world, dev)
     stats = pm.stats.cpu().tolist()
 
+    traffic = None          # HBM-side bytes per launch of the dominant kernel, from the committed PMC passes
+    tpath = os.path.join(ROOT, "profiles", "knn_traffic.json")
+    if os.path.exists(tpath) and (nq, nt) == (10000, 10000):
+        traffic = json.load(open(tpath)).get("bytes_per_launch")
     value = world * nq * nt * args.steps / elapsed
     filt_avg_ms = filt_ms / max(filt_n, 1)
     achieved = nq * nt * FLOP_PER_DISTANCE / (filt_avg_ms * 1e-3) / 1e12
@@ -145,7 +149,9 @@ def bench_knn(args, world, rank, dev):
                                "Lowe ratio 0.70, one image pair per GPU per step", "nq": nq, "nt": nt, "dim": 128,
                    "parallelism": f"pair-sharded x{world}" + (" + RCCL all-gather of match records" if world > 1 else "")},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                     "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                     "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/knn_traffic.json)",
+                     "algorithmic_bytes_per_launch": 4 * 128 * (nq + nt) + 16 * nq,
                      "kernel": "knn_filter_kernel", "avg_launch_ms": filt_avg_ms, "launches": filt_n,
                      "algorithmic_flop_per_launch": nq * nt * FLOP_PER_DISTANCE},
         "kernels_ms": {"knn_filter": filt_avg_ms, "knn_refine_plus_fallback": ref_ms / max(ref_n, 1)},

@@ -1,0 +1,26 @@
+#!/bin/bash
+# Round profile collection on the GPU box: kernel-trace stats of bench.py + PMC passes of the KNN step.
+# Usage (via gpurun): bash scripts/collect_profiles.sh rNN      → files under gpurun_out/profiles_rNN/
+TAG=${1:-r01}
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/profiles_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o knn -- python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-extras > $OUT/bench_under_rocprof.json 2> $OUT/trace.log
+cp $OUT/trace/knn_kernel_stats.csv $OUT/${TAG}_knn_kernel_stats.csv
+P1="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA"
+P2="FETCH_SIZE"
+P3="WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"
+P4="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_WAVES"
+i=1
+for P in "$P1" "$P2" "$P3" "$P4"; do
+  rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/pmc -o pass$i -- python $R/scripts/run_knn_steps.py 6 > $OUT/pmc_pass$i.log 2>&1
+  i=$((i+1))
+done
+python $R/scripts/summarize_pmc.py $OUT/pmc $TAG > $OUT/${TAG}_knn_pmc.md
+for wl in tri ba; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$wl -o $wl -- python $R/bench.py --workload $wl --steps 5 --warmup 1 > $OUT/bench_${wl}_under_rocprof.json 2>> $OUT/trace.log
+  cp $OUT/trace_$wl/${wl}_kernel_stats.csv $OUT/${TAG}_${wl}_kernel_stats.csv
+done
+rm -rf $OUT/trace $OUT/trace_tri $OUT/trace_ba
+ls $OUT

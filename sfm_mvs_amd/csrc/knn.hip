@@ -24,6 +24,7 @@
 #include "common.h"
 #include <cfloat>
 #include <climits>
+#include <cstdlib>
 
 namespace {
 
@@ -32,9 +33,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kDim = 128;
 constexpr int kTileT = 32;             // train rows per LDS tile (= MFMA M)
-constexpr int kWaves = 4;
-constexpr int kThreads = kWaves * 64;
-constexpr int kResidentBlocks = 1024;  // 256 CUs x 4 resident workgroups (launch_bounds(256, 4))
+
+
+constexpr int kResidentWaves = 4096;   // 256 CUs x 16 waves (4 per SIMD at <= 128 VGPRs)
 constexpr int kMaxSlots = 34;          // cap on filter blocks that may touch one query row block
 constexpr float kInf = __builtin_huge_valf();
 
@@ -43,12 +44,14 @@ constexpr float kInf = __builtin_huge_valf();
 // so all 2x256 resident workgroups finish together whatever nq, nt are; a block that crosses a
 // row-block boundary flushes its candidates and reloads the query fragment.
 struct Plan {
+    int waves;         // waves per filter workgroup (4, 8 or 16); 16 waves are resident per CU either way
     int rows_per_block;
     int n_rb;          // query row blocks
     int tiles;         // train tiles of 32
     int64_t units;     // n_rb * tiles
     int G;             // filter blocks
     int smax;          // candidate slots reserved per row block (>= blocks touching it)
+    int nsub;          // substreams (32 tiles each) per slot
     int fb_nch;        // fallback: train chunks per flagged query
     int fb_chunk;      // fallback: trains per chunk
 };
@@ -66,16 +69,21 @@ __host__ __device__ inline int block_of_unit(int64_t units, int G, int64_t u) {
 
 Plan make_plan(int64_t nq, int64_t nt) {
     Plan p;
-    p.rows_per_block = kWaves * 32;
+    static const int env_w = [] { const char* e = getenv("SFM_KNN_WAVES"); return e ? atoi(e) : 0; }();   // dev override
+    p.waves = (env_w == 4 || env_w == 8 || env_w == 16) ? env_w : 8;
+    p.rows_per_block = p.waves * 32;
     p.n_rb = (int)((nq + p.rows_per_block - 1) / p.rows_per_block);
     p.tiles = (int)((nt + kTileT - 1) / kTileT);
     p.units = (int64_t)p.n_rb * p.tiles;
-    int64_t g = kResidentBlocks;
+    int64_t g = kResidentWaves / p.waves;
     if (g > p.units) g = p.units;
     if (g > (int64_t)p.n_rb * (kMaxSlots - 2)) g = (int64_t)p.n_rb * (kMaxSlots - 2);
     if (g < 1) g = 1;
     p.G = (int)g;
     p.smax = p.n_rb > 0 ? p.G / p.n_rb + 2 : 1;
+    const int64_t maxseg = (p.units + p.G - 1) / p.G;                 // most tiles one workgroup can own
+    p.nsub = (int)((maxseg + 31) / 32);
+    if (p.nsub < 1) p.nsub = 1;
     // fallback chunks: 256 trains each when the worst-case partial buffer (every query flagged) stays small
     int64_t cap = nq > 0 ? (int64_t)(1 << 21) / nq : 1;
     if (cap < 2) cap = 2;
@@ -144,13 +152,15 @@ constexpr int kLdsFloats = 2 * kTileFloats + 2 * kTileT;
 // Train tile -> LDS: 4 buffer_load_dwordx4 ... lds per wave (1 KiB each).  Addressing through a buffer
 // descriptor keeps the per-lane state to ONE 32-bit offset register and makes rows past nt read as
 // zeros in hardware (their ||t||^2 is +inf, so they never become candidates).
+template <int W>
 __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t trs, int row_bytes, int lane_off, const float* __restrict__ tn,
-                                         int nt, int tile, float* __restrict__ tile_buf, float* __restrict__ tn_buf, int wave) {
+                                           int nt, int tile, float* __restrict__ tile_buf, float* __restrict__ tn_buf, int wave) {
+    constexpr int PIECES = 16 / W;                                  // 1 KiB LDS-DMA pieces per wave per tile
     const int soff = tile * kTileT * row_bytes;
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
-        float* dst = tile_buf + (wave * 4 + n) * 256;               // wave-uniform, 1 KiB per instruction
-        // row r = wave*8 + 2n + h holds source chunk p ^ (r & 15) = (p ^ (r0 & 15)) ^ 2n at position p
+    for (int n = 0; n < PIECES; ++n) {
+        float* dst = tile_buf + (wave * PIECES + n) * 256;          // wave-uniform, 1 KiB per instruction
+        // row r = 2*(wave*PIECES + n) + h holds source chunk p ^ (r & 15) = (p ^ (r0 & 15)) ^ 2n at position p
         __builtin_amdgcn_raw_ptr_buffer_load_lds(trs, (lptr_t)dst, 16, (lane_off ^ (32 * n)) + 2 * n * row_bytes, soff, 0, 0);
     }
     if (threadIdx.x < kTileT) {
@@ -159,9 +169,30 @@ __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t trs, int row_b
     }
 }
 
-__global__ __launch_bounds__(kThreads, 4) void knn_filter_kernel(
+constexpr int kKeyBits = 9;                       // 5 bits tile-in-substream + 4 bits accumulator register
+constexpr int kKeyMask = (1 << kKeyBits) - 1;
+constexpr int kSubTiles = 1 << (kKeyBits - 4);    // 32 tiles per substream
+constexpr int kKeyInf = 0x7F800000;               // +inf: larger than every finite non-negative score key
+
+// decode 3 packed keys into (truncated score, train index) records
+__device__ __forceinline__ void flush_keys(int k0, int k1, int k2, int sub_t0, int h, float* __restrict__ cs,
+                                           int* __restrict__ ci) {
+    const int ks[3] = {k0, k1, k2};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int seq = ks[r] & kKeyMask;
+        const bool empty = ks[r] == kKeyInf;
+        cs[r] = empty ? kInf : __int_as_float(ks[r] & ~kKeyMask);
+        ci[r] = empty ? -1 : (sub_t0 + (seq >> 4)) * kTileT + (seq & 3) + 8 * ((seq >> 2) & 3) + 4 * h;
+    }
+}
+
+// ABL != 0 are dev-only timing ablations (results are WRONG): bit0 skip the top-3 epilogue, bit1 skip the
+// per-tile barrier, bit2 skip re-staging, bit3 constant accumulator init, bit4 s_setprio around the MFMA run.
+template <int ABL, int W>
+__global__ __launch_bounds__(64 * W, 4) void knn_filter_kernel(
     const float* __restrict__ Q, int64_t ldq, int nq, const float* __restrict__ T, int64_t ldt, int nt,
-    const float* __restrict__ tn, int tiles, int64_t units, int smax, float* __restrict__ cand_s,
+    const float* __restrict__ tn, int tiles, int64_t units, int smax, int nsub, float* __restrict__ cand_s,
     int* __restrict__ cand_i, long long* __restrict__ trace) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if (trace && threadIdx.x == 0) {
@@ -182,18 +213,19 @@ __global__ __launch_bounds__(kThreads, 4) void knn_filter_kernel(
     const int row_bytes = (int)ldt * 4;
     const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc((void*)T, 0, nt * row_bytes, 0x00020000);
     // staging offset of this lane for n = 0: row r0 = wave*8 + h, byte position of chunk (p ^ (r0 & 15))
-    const int lane_off = (wave * 8 + h) * row_bytes + (((lane & 31) ^ ((wave * 8 + h) & 15)) << 4);
+    constexpr int PIECES = 16 / W;
+    const int lane_off = (wave * 2 * PIECES + h) * row_bytes + (((lane & 31) ^ ((wave * 2 * PIECES + h) & 15)) << 4);
 
     while (u < u_end) {
         const int rb = (int)(u / tiles);
         const int t_begin = (int)(u - (int64_t)rb * tiles);
         const int t_end = (int)min((int64_t)tiles, t_begin + (u_end - u));
         const int slot = blockIdx.x - block_of_unit(units, G, (int64_t)rb * tiles);
-        const int qrow = rb * (kWaves * 32) + wave * 32 + j;
+        const int qrow = rb * (W * 32) + wave * 32 + j;
         const bool qok = qrow < nq;
 
         __syncthreads();   // every wave is done with both buffers of the previous segment
-        stage_tile(trs, row_bytes, lane_off, tn, nt, t_begin, smem, tnb, wave);
+        stage_tile<W>(trs, row_bytes, lane_off, tn, nt, t_begin, smem, tnb, wave);
 
         float bq[64];
         {
@@ -208,16 +240,39 @@ __global__ __launch_bounds__(kThreads, 4) void knn_filter_kernel(
                 bq[4 * c + 3] = -2.f * v.w;
             }
         }
-        float bs[3] = {kInf, kInf, kInf};
-        int bi[3] = {-1, -1, -1};
+        // ||q||^2 of this lane's query (its own 64 k's + the other half-wave's), folded into the score by one
+        // extra MFMA step per tile (A = 1 on the h=0 half, B = ||q||^2 there) so that s ~ d^2 >= 0.
+        float qn = 0.f;
+#pragma unroll
+        for (int c = 0; c < 64; ++c) qn = fmaf(0.25f * bq[c], bq[c], qn);
+        qn += __shfl_xor(qn, 32, 64);
+        const float aug_a = h == 0 ? 1.f : 0.f;
+        const float aug_b = h == 0 ? qn : 0.f;
+
+        // Running top-3 as PACKED KEYS: (score bits & ~511) | (tile_in_substream << 4 | r).  Scores are
+        // non-negative up to rounding noise, so signed-integer order == float order and one insertion is
+        // v_and_or + v_min_i32 + 2 v_med3_i32 (4 VALU) instead of 13 compare/select ops; the 9 dropped
+        // mantissa bits (2^-14 relative) are covered by the refine kernel's slack.  A substream is 32 tiles.
+        int k0 = kKeyInf, k1 = kKeyInf, k2 = kKeyInf;
+        int sub = 0, sub_t0 = t_begin;
+        const int64_t obase = ((int64_t)qrow * (2 * smax * nsub) + (int64_t)slot * nsub * 2 + h) * 3;
         __syncthreads();   // tile t_begin landed (the barrier's release waits for the LDS-DMA: vmcnt(0))
 
         for (int t = t_begin; t < t_end; ++t) {
+            if (t - sub_t0 == kSubTiles) {
+                if (qok) flush_keys(k0, k1, k2, sub_t0, h, cand_s + obase + 6 * sub, cand_i + obase + 6 * sub);
+                k0 = k1 = k2 = kKeyInf;
+                ++sub;
+                sub_t0 = t;
+            }
             const int cur = (t - t_begin) & 1;
-            if (t + 1 < t_end) stage_tile(trs, row_bytes, lane_off, tn, nt, t + 1, smem + (cur ^ 1) * kTileFloats, tnb + (cur ^ 1) * kTileT, wave);
+            if (t + 1 < t_end && !(ABL & 4)) stage_tile<W>(trs, row_bytes, lane_off, tn, nt, t + 1, smem + (cur ^ 1) * kTileFloats, tnb + (cur ^ 1) * kTileT, wave);
 
             f32x16 acc;
-            {
+            if (ABL & 8) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 1.f;
+            } else {
                 const float* tnp = tnb + cur * kTileT + 4 * h;
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
@@ -232,8 +287,9 @@ __global__ __launch_bounds__(kThreads, 4) void knn_filter_kernel(
             // hipcc sinks such reads next to their consumer (and then blocks the in-order wave on the LDS
             // round trip every 4 MFMAs), so the reads and their counted waits are inline asm:
             //   issue r(c+2); s_waitcnt lgkmcnt(2) => r(c) has landed, r(c+1), r(c+2) stay in flight.
-            const unsigned abase = lds0 + (unsigned)(cur * kTileFloats + j * kDim) * 4u + ((unsigned)hm << 4);
+            const unsigned abase = lds0 + (unsigned)(((ABL & 4) ? 0 : cur) * kTileFloats + j * kDim) * 4u + ((unsigned)hm << 4);
             f32x4 af[3];
+            if (ABL & 16) __builtin_amdgcn_s_setprio(1);
             asm volatile("ds_read_b128 %0, %1" : "=v"(af[0]) : "v"(abase));
             asm volatile("ds_read_b128 %0, %1" : "=v"(af[1]) : "v"(abase ^ 32u));
 #pragma unroll
@@ -253,19 +309,33 @@ __global__ __launch_bounds__(kThreads, 4) void knn_filter_kernel(
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c % 3][2], bq[4 * c + 2], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c % 3][3], bq[4 * c + 3], acc, 0, 0, 0);
             }
-            const int id0 = t * kTileT + 4 * h;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aug_a, aug_b, acc, 0, 0, 0);
+            if (ABL & 16) __builtin_amdgcn_s_setprio(0);
+            const int seq0 = (t - sub_t0) << 4;
+            if (ABL & 1) {
+                k0 = min(k0, __float_as_int(acc[0]) + __float_as_int(acc[15]));
+            } else
 #pragma unroll
-            for (int r = 0; r < 16; ++r) top3_insert(acc[r], id0 + (r & 3) + 8 * (r >> 2), bs, bi);
-            __syncthreads();
+            for (int r = 0; r < 16; ++r) {
+                const int key = (__float_as_int(acc[r]) & ~kKeyMask) | (seq0 + r);
+                const int lo = min(key, k0), hi = max(key, k0);            // (lo, hi) = sorted (key, k0)
+                const int m1 = max(min(key, k1), min(max(key, k1), k0));   // med3(key, k0, k1)
+                k2 = max(min(key, k1), min(max(key, k1), k2));             // med3(key, k1, k2)
+                k1 = m1;
+                k0 = lo;
+                (void)hi;
+            }
+            if (!(ABL & 2)) __syncthreads();
         }
 
         if (qok) {
-            const int64_t o = ((int64_t)qrow * (2 * smax) + 2 * slot + h) * 3;
+            flush_keys(k0, k1, k2, sub_t0, h, cand_s + obase + 6 * sub, cand_i + obase + 6 * sub);
+            for (int e = sub + 1; e < nsub; ++e)       // unused substreams of this slot: empty
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                cand_s[o + r] = bs[r];
-                cand_i[o + r] = bi[r];
-            }
+                for (int r = 0; r < 3; ++r) {
+                    cand_s[obase + 6 * e + r] = kInf;
+                    cand_i[obase + 6 * e + r] = -1;
+                }
         }
         u += t_end - t_begin;
     }
@@ -334,7 +404,7 @@ __device__ __forceinline__ void best2_wave_reduce(Best2& b) {
 __global__ __launch_bounds__(256) void knn_refine_kernel(
     const float* __restrict__ Q, int64_t ldq, int nq, const float* __restrict__ T, int64_t ldt,
     const float* __restrict__ cand_s, const int* __restrict__ cand_i, int rows_per_block, int tiles, int64_t units,
-    int G, int smax, const float* __restrict__ bmax, int* __restrict__ idx_out, float* __restrict__ dist_out,
+    int G, int smax, int nsub, const float* __restrict__ bmax, int* __restrict__ idx_out, float* __restrict__ dist_out,
     int* __restrict__ flag_count, int* __restrict__ flag_list) {
     __shared__ __attribute__((aligned(16))) float qrows[4][kDim];
     const int lane = threadIdx.x & 63;
@@ -360,13 +430,14 @@ __global__ __launch_bounds__(256) void knn_refine_kernel(
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, m, 64));
     const float nsum = sqrtf(qq) + sqrtf(tmax);
-    const float eps = 600.f * 5.9604645e-8f * 1.01f * nsum * nsum;
+    // + 2^-14: the filter's packed keys drop the low 9 mantissa bits of the (non-negative) score
+    const float eps = (600.f * 5.9604645e-8f + 6.1035156e-5f) * 1.01f * nsum * nsum;
 
     // streams of this query's row block = filter blocks that touched it (contiguous slots from 0)
     const int rb = q / rows_per_block;
     const int fb = block_of_unit(units, G, (int64_t)rb * tiles);
     const int lb = block_of_unit(units, G, (int64_t)(rb + 1) * tiles - 1);
-    const int NC = 2 * (lb - fb + 1) * 3;
+    const int NC = 2 * (lb - fb + 1) * nsub * 3;
     const float* cs = cand_s + (int64_t)q * (2 * smax * 3);
     const int* ci = cand_i + (int64_t)q * (2 * smax * 3);
 
@@ -411,8 +482,9 @@ __global__ __launch_bounds__(256) void knn_refine_kernel(
         idx_out[2 * q + 1] = have2 ? b.i[1] : -1;
         dist_out[2 * q + 0] = b.d[0];
         dist_out[2 * q + 1] = b.d[1];
-        // Certificate: everything the filter discarded has exact d^2 >= tau + |q|^2 - eps.
-        const bool certified = (tau == kInf) || (have2 && (double)b.dsq[1] + (double)eps < (double)tau + (double)qq);
+        // Certificate: the filter score already includes |q|^2 (s ~ d^2), and everything the filter discarded
+        // has s >= tau, hence exact d^2 >= tau - eps.  (tau < 0 can only be rounding noise: never certifies.)
+        const bool certified = (tau == kInf) || (have2 && (double)b.dsq[1] + (double)eps < (double)tau);
         if (!certified) flag_list[atomicAdd(flag_count, 1)] = q;
     }
 }
@@ -578,8 +650,8 @@ KnnWs carve_ws(void* ws, int64_t nq, int64_t nt, const Plan& p) {
     w.fb_partial = c.take<Best2Rec>((size_t)nq * p.fb_nch);
     w.tn = c.take<float>((size_t)p.tiles * kTileT);
     w.flag_list = c.take<int>((size_t)nq);
-    w.cand_s = c.take<float>((size_t)nq * 2 * p.smax * 3);
-    w.cand_i = c.take<int>((size_t)nq * 2 * p.smax * 3);
+    w.cand_s = c.take<float>((size_t)nq * 2 * p.smax * p.nsub * 3);
+    w.cand_i = c.take<int>((size_t)nq * 2 * p.smax * p.nsub * 3);
     w.bytes = c.used();
     return w;
 }
@@ -629,20 +701,43 @@ extern "C" int sfm_knn2_l2_f32(const float* q, int64_t nq, int64_t ldq, const fl
     SFM_CHECK_LAUNCH();
     const dim3 grid((unsigned)p.G);
     sfm::prof_begin(sfm::kProfKnnFilter, stream);
-    hipLaunchKernelGGL(knn_filter_kernel, grid, dim3(kThreads), kLdsFloats * sizeof(float), stream, q, ldq, (int)nq, t, ldt,
-                       (int)nt, w.tn, p.tiles, p.units, p.smax, w.cand_s, w.cand_i, g_trace);
+    static const int abl = [] { const char* e = getenv("SFM_KNN_ABL"); return e ? atoi(e) : 0; }();   // dev only
+#define SFM_LAUNCH_FILTER(A, WV)                                                                                     \
+    hipLaunchKernelGGL((knn_filter_kernel<A, WV>), grid, dim3(64 * WV), kLdsFloats * sizeof(float), stream, q, ldq,    \
+                       (int)nq, t, ldt, (int)nt, w.tn, p.tiles, p.units, p.smax, p.nsub, w.cand_s, w.cand_i, g_trace)
+    if (p.waves == 4) {
+        switch (abl) {
+            case 1: SFM_LAUNCH_FILTER(1, 4); break;
+            case 7: SFM_LAUNCH_FILTER(7, 4); break;
+            default: SFM_LAUNCH_FILTER(0, 4); break;
+        }
+    } else if (p.waves == 8) {
+        switch (abl) {
+            case 1: SFM_LAUNCH_FILTER(1, 8); break;
+            case 7: SFM_LAUNCH_FILTER(7, 8); break;
+            default: SFM_LAUNCH_FILTER(0, 8); break;
+        }
+    } else {
+        switch (abl) {
+            case 1: SFM_LAUNCH_FILTER(1, 16); break;
+            case 7: SFM_LAUNCH_FILTER(7, 16); break;
+            default: SFM_LAUNCH_FILTER(0, 16); break;
+        }
+    }
+#undef SFM_LAUNCH_FILTER
     sfm::prof_end(sfm::kProfKnnFilter, stream);
     SFM_CHECK_LAUNCH();
     sfm::prof_begin(sfm::kProfKnnRefine, stream);
     hipLaunchKernelGGL(knn_refine_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream, q, ldq, (int)nq, t, ldt,
-                       w.cand_s, w.cand_i, p.rows_per_block, p.tiles, p.units, p.G, p.smax, w.bmax, idx, dist, w.flag_count,
+                       w.cand_s, w.cand_i, p.rows_per_block, p.tiles, p.units, p.G, p.smax * p.nsub, p.nsub, w.bmax, idx, dist,
+                       w.flag_count,
                        w.flag_list);
     SFM_CHECK_LAUNCH();
     hipLaunchKernelGGL(knn_fallback_scan_kernel, dim3(kFbScanBlocks), dim3(256), 0, stream, q, ldq, t, ldt, (int)nt, p.fb_nch,
                        p.fb_chunk, w.flag_count, w.flag_list, w.fb_partial);
     SFM_CHECK_LAUNCH();
     hipLaunchKernelGGL(knn_fallback_merge_kernel, dim3(kFbMergeBlocks), dim3(64), 0, stream, w.fb_partial, p.fb_nch,
-                       w.flag_count, w.flag_list, idx, dist, stats, p.G, 2 * p.smax);
+                       w.flag_count, w.flag_list, idx, dist, stats, p.G, 2 * p.smax * p.nsub);
     sfm::prof_end(sfm::kProfKnnRefine, stream);
     SFM_CHECK_LAUNCH();
     return SFM_OK;
