@@ -44,6 +44,8 @@ constexpr float kInf = __builtin_huge_valf();
 // so all 2x256 resident workgroups finish together whatever nq, nt are; a block that crosses a
 // row-block boundary flushes its candidates and reloads the query fragment.
 struct Plan {
+    int split;         // 1: split-bf16 filter (default), 0: fp32-MFMA filter
+    int nq_pad;        // query rows padded to whole row blocks
     int waves;         // waves per filter workgroup (4, 8 or 16); 16 waves are resident per CU either way
     int rows_per_block;
     int n_rb;          // query row blocks
@@ -71,8 +73,12 @@ Plan make_plan(int64_t nq, int64_t nt) {
     Plan p;
     static const int env_w = [] { const char* e = getenv("SFM_KNN_WAVES"); return e ? atoi(e) : 0; }();   // dev override
     p.waves = (env_w == 4 || env_w == 8 || env_w == 16) ? env_w : 8;
+    static const int env_f32 = [] { const char* e = getenv("SFM_KNN_FILTER"); return (e && e[0] == 'f') ? 1 : 0; }();   // "f32"
+    p.split = env_f32 ? 0 : 1;
+    if (p.split && !(env_w == 4 || env_w == 8 || env_w == 16)) p.waves = 16;
     p.rows_per_block = p.waves * 32;
     p.n_rb = (int)((nq + p.rows_per_block - 1) / p.rows_per_block);
+    p.nq_pad = p.n_rb * p.rows_per_block;
     p.tiles = (int)((nt + kTileT - 1) / kTileT);
     p.units = (int64_t)p.n_rb * p.tiles;
     int64_t g = kResidentWaves / p.waves;
@@ -342,6 +348,218 @@ __global__ __launch_bounds__(64 * W, 4) void knn_filter_kernel(
     if (trace && threadIdx.x == 0) trace[4 * blockIdx.x + 1] = wall_clock64();
 }
 
+// ---------------------------------------------------------------- split-bf16 filter
+// The filter only has to RANK (the refine kernel re-evaluates and certifies), so it need not run on
+// the 157 TFLOP/s fp32 MFMA: every float is split exactly into hi + mid + delta, hi = bf16(x),
+// mid = bf16(x - hi), |delta| <= 2^-16 |x|, and q.t ~ qh.th + qh.tm + qm.th on
+// v_mfma_f32_32x32x16_bf16 (2.5 PFLOP/s; products of bf16 are exact in the fp32 accumulator).
+// 25 MFMAs x 32 cycles per 32x32 tile instead of 65 x 64.  Neglected terms are bounded by
+// 3.05 * 2^-16 |q||t|; the refine kernel's slack accounts for it (kEpsSplit).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned bf16_rn_bits(float x) {
+    const unsigned u = __float_as_uint(x);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+
+// One pass over Q and T: split rows into (hi, mid) bf16 images (Q pre-scaled by -2, exact), fp32 squared norms,
+// per-block max of ||t||^2, zero the fallback counter.  Rows >= n of the padded images are zero-filled.
+__global__ __launch_bounds__(256) void knn_prep_kernel(const float* __restrict__ Q, int64_t ldq, int nq, int nq_pad,
+                                                       const float* __restrict__ T, int64_t ldt, int nt, int nt_pad,
+                                                       unsigned short* __restrict__ qsplit, float* __restrict__ qn,
+                                                       unsigned short* __restrict__ tsplit, float* __restrict__ tn,
+                                                       float* __restrict__ bmax, int* __restrict__ flag_count) {
+    __shared__ float wmax[4];
+    const int l = threadIdx.x & 31;
+    float mx = 0.f;
+    const int rows = nq_pad + nt_pad;
+    for (int row = blockIdx.x * 8 + (threadIdx.x >> 5); row < rows; row += gridDim.x * 8) {
+        const bool isq = row < nq_pad;
+        const int r = isq ? row : row - nq_pad;
+        const int n = isq ? nq : nt, npad = isq ? nq_pad : nt_pad;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < n) v = *reinterpret_cast<const float4*>((isq ? Q + (int64_t)r * ldq : T + (int64_t)r * ldt) + 4 * l);
+        float s = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+#pragma unroll
+        for (int m = 16; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+        const float sc = isq ? -2.f : 1.f;
+        const float e[4] = {sc * v.x, sc * v.y, sc * v.z, sc * v.w};
+        unsigned hb[4], mb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            hb[k] = bf16_rn_bits(e[k]);
+            mb[k] = bf16_rn_bits(e[k] - __uint_as_float(hb[k] << 16));   // x - hi is exact in fp32
+        }
+        unsigned short* img = isq ? qsplit : tsplit;
+        *reinterpret_cast<uint2*>(img + (int64_t)r * kDim + 4 * l) = make_uint2(hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16));
+        *reinterpret_cast<uint2*>(img + ((int64_t)npad + r) * kDim + 4 * l) = make_uint2(mb[0] | (mb[1] << 16), mb[2] | (mb[3] << 16));
+        if (l == 0) (isq ? qn : tn)[r] = s;
+        if (!isq) mx = fmaxf(mx, s);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        bmax[blockIdx.x] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+        if (blockIdx.x == 0) *flag_count = 0;
+    }
+}
+
+// LDS tile image: hi rows [32][256 B] at +0, mid rows at +8 KiB, 16-byte chunks XOR-swizzled with (row & 15).
+template <int W>
+__device__ __forceinline__ void stage_tile_split(__amdgpu_buffer_rsrc_t trs, int mid_off, int lane_off, const float* __restrict__ tn,
+                                                 int nt, int tile, float* __restrict__ tile_buf, float* __restrict__ tn_buf,
+                                                 int wave) {
+    constexpr int PIECES = 16 / W;                       // 1 KiB pieces (4 rows x 256 B) per wave per tile
+    const int p0 = wave * PIECES;
+    const int soff = tile * kTileT * 256 + (p0 >= 8 ? mid_off : 0);
+#pragma unroll
+    for (int n = 0; n < PIECES; ++n) {
+        float* dst = tile_buf + (p0 + n) * 256;
+        // row r = 4*((p0+n)&7) + (lane>>4) keeps source chunk pos ^ (r & 15) = (pos ^ (r0 & 15)) ^ 4n at position pos
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(trs, (lptr_t)dst, 16, (lane_off ^ (64 * n)) + 4 * n * 256, soff, 0, 0);
+    }
+    if (threadIdx.x < kTileT) {
+        const int row = tile * kTileT + threadIdx.x;
+        tn_buf[threadIdx.x] = row < nt ? tn[row] : kInf;
+    }
+}
+
+template <int ABL, int W>
+__global__ __launch_bounds__(64 * W, 4) void knn_filter_split_kernel(
+    const unsigned short* __restrict__ qsplit, const float* __restrict__ qnorm, int nq, int nq_pad,
+    const unsigned short* __restrict__ tsplit, int nt, int nt_pad, const float* __restrict__ tn, int tiles, int64_t units,
+    int smax, int nsub, float* __restrict__ cand_s, int* __restrict__ cand_i, long long* __restrict__ trace) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (trace && threadIdx.x == 0) {
+        trace[4 * blockIdx.x + 0] = wall_clock64();
+        trace[4 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg(0xF804);
+        trace[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg(0xF814);
+    }
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31;
+    const int h = lane >> 5;
+    const int hm = h ^ (j & 15);
+    const int G = gridDim.x;
+    const int64_t u_end = unit_begin(units, G, blockIdx.x + 1);
+    int64_t u = unit_begin(units, G, blockIdx.x);
+    float* const tnb = smem + 2 * kTileFloats;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
+    const int mid_off = nt_pad * 256;
+    const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc((void*)tsplit, 0, 2 * mid_off, 0x00020000);
+    constexpr int PIECES = 16 / W;
+    const int r0 = 4 * ((wave * PIECES) & 7) + (lane >> 4);
+    const int lane_off = r0 * 256 + (((lane & 15) ^ (r0 & 15)) << 4);
+
+    while (u < u_end) {
+        const int rb = (int)(u / tiles);
+        const int t_begin = (int)(u - (int64_t)rb * tiles);
+        const int t_end = (int)min((int64_t)tiles, t_begin + (u_end - u));
+        const int slot = blockIdx.x - block_of_unit(units, G, (int64_t)rb * tiles);
+        const int qrow = rb * (W * 32) + wave * 32 + j;
+        const bool qok = qrow < nq;
+
+        __syncthreads();
+        stage_tile_split<W>(trs, mid_off, lane_off, tn, nt, t_begin, smem, tnb, wave);
+
+        // query fragments (MFMA B operand): 8 k-steps x (hi, mid), already scaled by -2
+        uint4 bh[8], bm[8];
+        {
+            const int qr = qok ? qrow : 0;       // padded rows are zero in the image; invalid lanes are never written
+            const unsigned short* sh = qsplit + (int64_t)qr * kDim + 8 * h;
+            const unsigned short* sm = qsplit + ((int64_t)nq_pad + qr) * kDim + 8 * h;
+#pragma unroll
+            for (int st = 0; st < 8; ++st) {
+                bh[st] = *reinterpret_cast<const uint4*>(sh + 16 * st);
+                bm[st] = *reinterpret_cast<const uint4*>(sm + 16 * st);
+            }
+        }
+        const float qn = qok ? qnorm[qrow] : 0.f;   // folded into the accumulator init: s = (|t|^2 + |q|^2) - 2 q.t ~ d^2
+
+        int k0 = kKeyInf, k1 = kKeyInf, k2 = kKeyInf;
+        int sub = 0, sub_t0 = t_begin;
+        const int64_t obase = ((int64_t)qrow * (2 * smax * nsub) + (int64_t)slot * nsub * 2 + h) * 3;
+        __syncthreads();
+
+        for (int t = t_begin; t < t_end; ++t) {
+            if (t - sub_t0 == kSubTiles) {
+                if (qok) flush_keys(k0, k1, k2, sub_t0, h, cand_s + obase + 6 * sub, cand_i + obase + 6 * sub);
+                k0 = k1 = k2 = kKeyInf;
+                ++sub;
+                sub_t0 = t;
+            }
+            const int cur = (t - t_begin) & 1;
+            if (t + 1 < t_end && !(ABL & 4))
+                stage_tile_split<W>(trs, mid_off, lane_off, tn, nt, t + 1, smem + (cur ^ 1) * kTileFloats, tnb + (cur ^ 1) * kTileT, wave);
+
+            f32x16 acc;
+            {
+                const float* tnp = tnb + cur * kTileT + 4 * h;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const float4 v = *reinterpret_cast<const float4*>(tnp + 8 * b);
+                    acc[4 * b + 0] = v.x + qn;
+                    acc[4 * b + 1] = v.y + qn;
+                    acc[4 * b + 2] = v.z + qn;
+                    acc[4 * b + 3] = v.w + qn;
+                }
+            }
+            // fragment reads ONE k-step ahead (two register sets: 128 VGPRs leave no room for a third beside the
+            // 64-register query fragment): r(s+1) issued, lgkmcnt(2) => both reads of step s have landed.
+            const unsigned abase = lds0 + (unsigned)(((ABL & 4) ? 0 : cur) * kTileFloats) * 4u + (unsigned)j * 256u + ((unsigned)hm << 4);
+            u32x4 ah[2], am[2];
+            asm volatile("ds_read_b128 %0, %1" : "=v"(ah[0]) : "v"(abase));
+            asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(am[0]) : "v"(abase));
+#pragma unroll
+            for (int st = 0; st < 8; ++st) {
+                if (st + 1 < 8) {
+                    const unsigned ad = abase ^ (32u * (st + 1));
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(ah[(st + 1) & 1]) : "v"(ad));
+                    asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(am[(st + 1) & 1]) : "v"(ad));
+                    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ah[st & 1]), "+v"(am[st & 1]));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[st & 1]), "+v"(am[st & 1]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const bf16x8 Ah = __builtin_bit_cast(bf16x8, ah[st & 1]), Am = __builtin_bit_cast(bf16x8, am[st & 1]);
+                const bf16x8 Bh = __builtin_bit_cast(bf16x8, bh[st]), Bm = __builtin_bit_cast(bf16x8, bm[st]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, acc, 0, 0, 0);
+            }
+            const int seq0 = (t - sub_t0) << 4;
+            if (ABL & 1) {
+                k0 = min(k0, __float_as_int(acc[0]) + __float_as_int(acc[15]));
+            } else
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = (__float_as_int(acc[r]) & ~kKeyMask) | (seq0 + r);
+                const int lo = min(key, k0);
+                const int m1 = max(min(key, k1), min(max(key, k1), k0));
+                k2 = max(min(key, k1), min(max(key, k1), k2));
+                k1 = m1;
+                k0 = lo;
+            }
+            if (!(ABL & 2)) __syncthreads();
+        }
+
+        if (qok) {
+            flush_keys(k0, k1, k2, sub_t0, h, cand_s + obase + 6 * sub, cand_i + obase + 6 * sub);
+            for (int e = sub + 1; e < nsub; ++e)
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    cand_s[obase + 6 * e + r] = kInf;
+                    cand_i[obase + 6 * e + r] = -1;
+                }
+        }
+        u += t_end - t_begin;
+    }
+    if (trace && threadIdx.x == 0) trace[4 * blockIdx.x + 1] = wall_clock64();
+}
+
 // ---------------------------------------------------------------- exact direct-form distance
 // Reference arithmetic (OpenCV normL2Sqr_, SSE2 path): two 4-lane accumulators over blocks of 8,
 // mul and add separately rounded; lanes summed as (d0+d1) then ((s0+s1)+s2)+s3.
@@ -404,7 +622,8 @@ __device__ __forceinline__ void best2_wave_reduce(Best2& b) {
 __global__ __launch_bounds__(256) void knn_refine_kernel(
     const float* __restrict__ Q, int64_t ldq, int nq, const float* __restrict__ T, int64_t ldt,
     const float* __restrict__ cand_s, const int* __restrict__ cand_i, int rows_per_block, int tiles, int64_t units,
-    int G, int smax, int nsub, const float* __restrict__ bmax, int* __restrict__ idx_out, float* __restrict__ dist_out,
+    int G, int smax, int nsub, float eps_coef, const float* __restrict__ bmax, int* __restrict__ idx_out,
+    float* __restrict__ dist_out,
     int* __restrict__ flag_count, int* __restrict__ flag_list) {
     __shared__ __attribute__((aligned(16))) float qrows[4][kDim];
     const int lane = threadIdx.x & 63;
@@ -430,8 +649,8 @@ __global__ __launch_bounds__(256) void knn_refine_kernel(
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, m, 64));
     const float nsum = sqrtf(qq) + sqrtf(tmax);
-    // + 2^-14: the filter's packed keys drop the low 9 mantissa bits of the (non-negative) score
-    const float eps = (600.f * 5.9604645e-8f + 6.1035156e-5f) * 1.01f * nsum * nsum;
+    // eps_coef adds what the chosen filter loses on top (packed keys: 2^-14; split-bf16 products: see kEpsSplit)
+    const float eps = eps_coef * 1.01f * nsum * nsum;
 
     // streams of this query's row block = filter blocks that touched it (contiguous slots from 0)
     const int rb = q / rows_per_block;
@@ -631,7 +850,18 @@ __global__ void knn_fill_empty_kernel(int* __restrict__ idx, float* __restrict__
 
 long long* g_trace = nullptr;   // dev diagnostics only
 
+// Slack coefficients (relative to (|q|+|t|max)^2) handed to the refine kernel.
+//   common:   600u  fp32 rounding of norms / direct-form sums / sqrtf merge (+ GEMM-form chain for the f32 filter)
+//             2^-14 packed-key truncation of the score
+//   split:    2 * 3.05 * 2^-16 / 4  neglected (mid.mid, delta) product terms, |q||t| <= N^2/4
+//             400 * 2^-22           ~400 accumulations inside the bf16 MFMA chain, each assumed to lose <= 2^-22 relative
+constexpr float kEpsF32 = 600.f * 5.9604645e-8f + 6.1035156e-5f;
+constexpr float kEpsSplit = kEpsF32 + 2.33e-5f + 9.54e-5f;
+
 struct KnnWs {
+    unsigned short* qsplit;
+    unsigned short* tsplit;
+    float* qn;
     float* tn;
     float* bmax;
     Best2Rec* fb_partial;
@@ -649,6 +879,9 @@ KnnWs carve_ws(void* ws, int64_t nq, int64_t nt, const Plan& p) {
     w.flag_count = c.take<int>(1);
     w.fb_partial = c.take<Best2Rec>((size_t)nq * p.fb_nch);
     w.tn = c.take<float>((size_t)p.tiles * kTileT);
+    w.qn = c.take<float>((size_t)p.nq_pad);
+    w.qsplit = c.take<unsigned short>((size_t)p.nq_pad * kDim * 2);
+    w.tsplit = c.take<unsigned short>((size_t)p.tiles * kTileT * kDim * 2);
     w.flag_list = c.take<int>((size_t)nq);
     w.cand_s = c.take<float>((size_t)nq * 2 * p.smax * p.nsub * 3);
     w.cand_i = c.take<int>((size_t)nq * 2 * p.smax * p.nsub * 3);
@@ -696,12 +929,30 @@ extern "C" int sfm_knn2_l2_f32(const float* q, int64_t nq, int64_t ldq, const fl
     const KnnWs w = carve_ws(base, nq, nt, p);
     hipStream_t stream = sfm::as_stream(stream_);
 
+    const dim3 grid((unsigned)p.G);
+    static const int abl = [] { const char* e = getenv("SFM_KNN_ABL"); return e ? atoi(e) : 0; }();   // dev only
+    if (p.split) {
+        hipLaunchKernelGGL(knn_prep_kernel, dim3(kNormBlocks), dim3(256), 0, stream, q, ldq, (int)nq, p.nq_pad, t, ldt, (int)nt,
+                           p.tiles * kTileT, w.qsplit, w.qn, w.tsplit, w.tn, w.bmax, w.flag_count);
+        SFM_CHECK_LAUNCH();
+        sfm::prof_begin(sfm::kProfKnnFilter, stream);
+#define SFM_LAUNCH_SPLIT(A, WV)                                                                                        \
+    hipLaunchKernelGGL((knn_filter_split_kernel<A, WV>), grid, dim3(64 * WV), kLdsFloats * sizeof(float), stream,      \
+                       w.qsplit, w.qn, (int)nq, p.nq_pad, w.tsplit, (int)nt, p.tiles * kTileT, w.tn, p.tiles, p.units,  \
+                       p.smax, p.nsub, w.cand_s, w.cand_i, g_trace)
+        if (p.waves == 4) {
+            if (abl == 1) SFM_LAUNCH_SPLIT(1, 4); else if (abl == 7) SFM_LAUNCH_SPLIT(7, 4); else SFM_LAUNCH_SPLIT(0, 4);
+        } else if (p.waves == 8) {
+            if (abl == 1) SFM_LAUNCH_SPLIT(1, 8); else if (abl == 7) SFM_LAUNCH_SPLIT(7, 8); else SFM_LAUNCH_SPLIT(0, 8);
+        } else {
+            if (abl == 1) SFM_LAUNCH_SPLIT(1, 16); else if (abl == 7) SFM_LAUNCH_SPLIT(7, 16); else SFM_LAUNCH_SPLIT(0, 16);
+        }
+#undef SFM_LAUNCH_SPLIT
+    } else {
     hipLaunchKernelGGL(knn_norms_kernel, dim3(kNormBlocks), dim3(256), 0, stream, t, ldt, (int)nt, w.tn, w.bmax,
                        w.flag_count);
     SFM_CHECK_LAUNCH();
-    const dim3 grid((unsigned)p.G);
     sfm::prof_begin(sfm::kProfKnnFilter, stream);
-    static const int abl = [] { const char* e = getenv("SFM_KNN_ABL"); return e ? atoi(e) : 0; }();   // dev only
 #define SFM_LAUNCH_FILTER(A, WV)                                                                                     \
     hipLaunchKernelGGL((knn_filter_kernel<A, WV>), grid, dim3(64 * WV), kLdsFloats * sizeof(float), stream, q, ldq,    \
                        (int)nq, t, ldt, (int)nt, w.tn, p.tiles, p.units, p.smax, p.nsub, w.cand_s, w.cand_i, g_trace)
@@ -725,11 +976,13 @@ extern "C" int sfm_knn2_l2_f32(const float* q, int64_t nq, int64_t ldq, const fl
         }
     }
 #undef SFM_LAUNCH_FILTER
+    }
     sfm::prof_end(sfm::kProfKnnFilter, stream);
     SFM_CHECK_LAUNCH();
     sfm::prof_begin(sfm::kProfKnnRefine, stream);
     hipLaunchKernelGGL(knn_refine_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream, q, ldq, (int)nq, t, ldt,
-                       w.cand_s, w.cand_i, p.rows_per_block, p.tiles, p.units, p.G, p.smax * p.nsub, p.nsub, w.bmax, idx, dist,
+                       w.cand_s, w.cand_i, p.rows_per_block, p.tiles, p.units, p.G, p.smax * p.nsub, p.nsub,
+                       p.split ? kEpsSplit : kEpsF32, w.bmax, idx, dist,
                        w.flag_count,
                        w.flag_list);
     SFM_CHECK_LAUNCH();
