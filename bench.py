@@ -27,6 +27,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (no sparsity)
+SPLIT_MFMA_PER_TILE, F32_MFMA_PER_TILE = 24, 65
 FLOP_PER_DISTANCE = 256           # GEMM form 2*D
 HBM_PEAK_GBS = 8000.0
 FP64_VALU_PEAK_TFLOPS = 78.6
@@ -140,23 +142,51 @@ def bench_knn(args, world, rank, dev):
         traffic = json.load(open(tpath)).get("bytes_per_launch")
     value = world * nq * nt * args.steps / elapsed
     filt_avg_ms = filt_ms / max(filt_n, 1)
-    achieved = nq * nt * FLOP_PER_DISTANCE / (filt_avg_ms * 1e-3) / 1e12
+    algo_flop = nq * nt * FLOP_PER_DISTANCE
+    achieved = algo_flop / (filt_avg_ms * 1e-3) / 1e12
+    # MFMA work actually issued by the split filter: 3 bf16 products (hi.hi, hi.mid, mid.hi) per fp32 product
+    issued = (nq / 32.0) * (nt / 32.0) * SPLIT_MFMA_PER_TILE * 2 * 32 * 32 * 16 / (filt_avg_ms * 1e-3) / 1e12
     out = {
         "metric": "descriptor-pair distances/sec (BF-KNN k=2 + Lowe ratio)", "value": value, "unit": "distances/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 results (bit-identical to the direct-form f32 reference); filter arithmetic bf16 hi+mid split on MFMA, "
+                 "f32 exact refine",
+        "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: 10k x 10k uniform[0,1) float32 128-D descriptors, BF-KNN k=2 + "
                                "Lowe ratio 0.70, one image pair per GPU per step", "nq": nq, "nt": nt, "dim": 128,
                    "parallelism": f"pair-sharded x{world}" + (" + RCCL all-gather of match records" if world > 1 else "")},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": traffic,
                      "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/knn_traffic.json)",
                      "algorithmic_bytes_per_launch": 4 * 128 * (nq + nt) + 16 * nq,
-                     "kernel": "knn_filter_kernel", "avg_launch_ms": filt_avg_ms, "launches": filt_n,
-                     "algorithmic_flop_per_launch": nq * nt * FLOP_PER_DISTANCE},
+                     "kernel": "knn_filter_split_kernel", "avg_launch_ms": filt_avg_ms, "launches": filt_n,
+                     "algorithmic_flop_per_launch": algo_flop,
+                     "issued_mfma_tflops": issued, "issued_frac_of_peak": issued / BF16_MFMA_PEAK_TFLOPS,
+                     "note": "algorithmic = 256 FLOP per distance (SURVEY 8d); the kernel issues 3.07x that in bf16 MFMA flops"},
         "kernels_ms": {"knn_filter": filt_avg_ms, "knn_refine_plus_fallback": ref_ms / max(ref_n, 1)},
-        "knn_stats": {"fallback_queries": stats[0], "train_splits": stats[1], "streams_per_query": stats[2]},
+        "knn_stats": {"fallback_queries": stats[0], "filter_workgroups": stats[1], "streams_per_query": stats[2]},
     }
+    if world == 1 and not args.no_extras:
+        # the exact-f32-MFMA filter variant on the same inputs (identical results), for the fp32 roofline
+        ops.set_knn_filter("f32")
+        pm32 = ops.PairMatcher(nq, nt, dev, ratio=0.70)
+        for _ in range(5):
+            pm32.run(q, t)
+        torch.cuda.synchronize()
+        ops.profile_enable(True)
+        for _ in range(20):
+            pm32.run(q, t)
+        f32_ms, f32_n = ops.profile_read(0)
+        ops.profile_read(1)
+        ops.profile_enable(False)
+        ops.set_knn_filter("split")
+        same = bool(torch.equal(pm32.idx, pm.idx) and torch.equal(pm32.dist, pm.dist))
+        f32_avg = f32_ms / max(f32_n, 1)
+        out["fp32_filter_variant"] = {"kernel": "knn_filter_kernel (v_mfma_f32_32x32x2_f32)", "avg_launch_ms": f32_avg,
+                                      "achieved_tflops": algo_flop / (f32_avg * 1e-3) / 1e12, "peak_tflops": FP32_MFMA_PEAK_TFLOPS,
+                                      "frac": algo_flop / (f32_avg * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                                      "results_identical_to_default": same}
     return out
 
 

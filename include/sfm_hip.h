@@ -62,6 +62,10 @@ const char* sfm_last_error(void);
  * finite input (see DESIGN.md "certified filter + exact refine").
  * ---------------------------------------------------------------------- */
 size_t sfm_knn2_l2_f32_ws_bytes(int64_t nq, int64_t nt, int dim);
+/* Filter variant used by sfm_knn2_l2_f32 (results are bit-identical either way):
+ *   0  split-bf16 MFMA filter (default)      1  fp32 MFMA filter
+ * Call before sizing the workspace; the _ws_bytes twin follows the current mode. */
+int    sfm_knn_set_filter(int mode);
 int    sfm_knn2_l2_f32(const float* q_dev, int64_t nq, int64_t ldq,
                        const float* t_dev, int64_t nt, int64_t ldt, int dim,
                        int32_t* idx_dev, float* dist_dev, int32_t* stats_dev,
@@ -78,10 +82,13 @@ int    sfm_knn2_l2_f32(const float* q_dev, int64_t nq, int64_t ldq,
  *   out_q_dev, out_t_dev [nq] int32   queryIdx / trainIdx of survivors
  *   out_count_dev        [1]  int32   number of survivors M
  *   mask_dev (optional)  [nq] uint8   1 where the query passed
+ *   idx_dev / dist_dev must be 8-byte aligned (they are the outputs of sfm_knn2_l2_f32)
  * ---------------------------------------------------------------------- */
+size_t sfm_ratio_compact_ws_bytes(int64_t nq);
 int sfm_ratio_compact(const int32_t* idx_dev, const float* dist_dev, int64_t nq,
                       double ratio, int32_t* out_q_dev, int32_t* out_t_dev,
-                      int32_t* out_count_dev, uint8_t* mask_dev, void* stream);
+                      int32_t* out_count_dev, uint8_t* mask_dev,
+                      void* ws_dev, size_t ws_bytes, void* stream);
 
 /* Gather keypoint coordinates of the survivors: pts0 = kp0[out_q], pts1 = kp1[out_t]
  * (sfm.py:267-268).  kp*_dev are [n x 2] float32 (KeyPoint.pt); count_dev is the

@@ -28,7 +28,9 @@ SIGNATURES = {
     "sfm_last_error": (_c.c_char_p, []),
     "sfm_knn2_l2_f32_ws_bytes": (_sz, [_i64, _i64, _int]),
     "sfm_knn2_l2_f32": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _int, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "sfm_ratio_compact": (_int, [_vp, _vp, _i64, _f64, _vp, _vp, _vp, _vp, _vp]),
+    "sfm_knn_set_filter": (_int, [_int]),
+    "sfm_ratio_compact_ws_bytes": (_sz, [_i64]),
+    "sfm_ratio_compact": (_int, [_vp, _vp, _i64, _f64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sfm_gather_matches": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "sfm_triangulate_dlt": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _int, _int, _vp, _vp]),
     "sfm_project_residual_ws_bytes": (_sz, [_i64, _i64, _i64]),

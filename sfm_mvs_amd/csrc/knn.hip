@@ -69,19 +69,23 @@ __host__ __device__ inline int block_of_unit(int64_t units, int G, int64_t u) {
     return b;
 }
 
+// 0 = split-bf16 filter (default), 1 = fp32-MFMA filter.  Initialised from SFM_KNN_FILTER=f32, changed by
+// sfm_knn_set_filter().  Both give bit-identical results; they differ in speed only.
+int g_filter_mode = [] { const char* e = getenv("SFM_KNN_FILTER"); return (e && e[0] == 'f') ? 1 : 0; }();
+
 Plan make_plan(int64_t nq, int64_t nt) {
     Plan p;
     static const int env_w = [] { const char* e = getenv("SFM_KNN_WAVES"); return e ? atoi(e) : 0; }();   // dev override
     p.waves = (env_w == 4 || env_w == 8 || env_w == 16) ? env_w : 8;
-    static const int env_f32 = [] { const char* e = getenv("SFM_KNN_FILTER"); return (e && e[0] == 'f') ? 1 : 0; }();   // "f32"
-    p.split = env_f32 ? 0 : 1;
+    p.split = g_filter_mode == 1 ? 0 : 1;
     if (p.split && !(env_w == 4 || env_w == 8 || env_w == 16)) p.waves = 16;
     p.rows_per_block = p.waves * 32;
     p.n_rb = (int)((nq + p.rows_per_block - 1) / p.rows_per_block);
     p.nq_pad = p.n_rb * p.rows_per_block;
     p.tiles = (int)((nt + kTileT - 1) / kTileT);
     p.units = (int64_t)p.n_rb * p.tiles;
-    int64_t g = kResidentWaves / p.waves;
+    static const int env_res = [] { const char* e = getenv("SFM_KNN_RESIDENT"); return e ? atoi(e) : 0; }();   // dev override
+    int64_t g = (env_res > 0 ? env_res : kResidentWaves) / p.waves;
     if (g > p.units) g = p.units;
     if (g > (int64_t)p.n_rb * (kMaxSlots - 2)) g = (int64_t)p.n_rb * (kMaxSlots - 2);
     if (g < 1) g = 1;
@@ -496,7 +500,10 @@ __global__ __launch_bounds__(64 * W, 4) void knn_filter_split_kernel(
                 stage_tile_split<W>(trs, mid_off, lane_off, tn, nt, t + 1, smem + (cur ^ 1) * kTileFloats, tnb + (cur ^ 1) * kTileT, wave);
 
             f32x16 acc;
-            {
+            if (ABL & 8) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = qn;
+            } else {
                 const float* tnp = tnb + cur * kTileT + 4 * h;
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
@@ -515,7 +522,8 @@ __global__ __launch_bounds__(64 * W, 4) void knn_filter_split_kernel(
             asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(am[0]) : "v"(abase));
 #pragma unroll
             for (int st = 0; st < 8; ++st) {
-                if (st + 1 < 8) {
+                if (ABL & 32) {
+                } else if (st + 1 < 8) {
                     const unsigned ad = abase ^ (32u * (st + 1));
                     asm volatile("ds_read_b128 %0, %1" : "=v"(ah[(st + 1) & 1]) : "v"(ad));
                     asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(am[(st + 1) & 1]) : "v"(ad));
@@ -619,6 +627,25 @@ __device__ __forceinline__ void best2_wave_reduce(Best2& b) {
 }
 
 // ---------------------------------------------------------------- refine
+// Exact direct-form distances for a wave's short candidate list, EIGHT lanes per candidate: sub-lane l owns
+// accumulator lane l of the reference's 2x4-lane order (acc_l += (q[8i+l] - t[8i+l])^2, i = 0..15, mul and add
+// separately rounded), then s_l = acc_l + acc_{l+4}, d^2 = ((s0 + s1) + s2) + s3 — bit-identical to
+// exact_l2sq_128, with a 16-step dependent chain instead of 128.
+__device__ __forceinline__ float exact_l2sq_group8(const float* __restrict__ qrow /*LDS*/, const float* __restrict__ trow,
+                                                   int l) {
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float d = qrow[8 * i + l] - trow[8 * i + l];
+        acc = acc + d * d;
+    }
+    const float s = acc + __shfl_down(acc, 4, 8);        // valid on l < 4
+    const float s1 = __shfl_down(s, 1, 8), s2 = __shfl_down(s, 2, 8), s3 = __shfl_down(s, 3, 8);
+    return ((s + s1) + s2) + s3;                         // valid on l == 0
+}
+
+constexpr int kRefineMaxCand = 256;   // candidates kept in registers per wave (4 per lane); more → second sweep
+
 __global__ __launch_bounds__(256) void knn_refine_kernel(
     const float* __restrict__ Q, int64_t ldq, int nq, const float* __restrict__ T, int64_t ldt,
     const float* __restrict__ cand_s, const int* __restrict__ cand_i, int rows_per_block, int tiles, int64_t units,
@@ -626,6 +653,7 @@ __global__ __launch_bounds__(256) void knn_refine_kernel(
     float* __restrict__ dist_out,
     int* __restrict__ flag_count, int* __restrict__ flag_list) {
     __shared__ __attribute__((aligned(16))) float qrows[4][kDim];
+    __shared__ int qual[4][64];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int q = blockIdx.x * 4 + wave;
@@ -642,14 +670,13 @@ __global__ __launch_bounds__(256) void knn_refine_kernel(
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) qq += __shfl_xor(qq, m, 64);
 
-    // Slack that dominates: GEMM-form rounding of the filter (<= 2*gamma_130*(|q|+|t|)^2),
-    // rounding of the direct-form sums (<= 24u*d^2), of ||q||^2, ||t||^2 (gamma_128 each) and the
-    // final sqrtf merge (8u*d^2), u = 2^-24.  600u*(|q|+|t|max)^2 covers their sum with >1.5x room.
+    // Slack that dominates: rounding of the filter's dot-product chain, of ||q||^2, ||t||^2, of the direct-form
+    // sums (<= 24u*d^2) and the final sqrtf merge (8u*d^2) — 600u*(|q|+|t|max)^2, u = 2^-24 — plus what the chosen
+    // filter loses on top (packed keys; split-bf16 products): eps_coef, see kEpsF32 / kEpsSplit.
     float tmax = fmaxf(fmaxf(bmax[lane], bmax[lane + 64]), fmaxf(bmax[lane + 128], bmax[lane + 192]));
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, m, 64));
     const float nsum = sqrtf(qq) + sqrtf(tmax);
-    // eps_coef adds what the chosen filter loses on top (packed keys: 2^-14; split-bf16 products: see kEpsSplit)
     const float eps = eps_coef * 1.01f * nsum * nsum;
 
     // streams of this query's row block = filter blocks that touched it (contiguous slots from 0)
@@ -660,10 +687,20 @@ __global__ __launch_bounds__(256) void knn_refine_kernel(
     const float* cs = cand_s + (int64_t)q * (2 * smax * 3);
     const int* ci = cand_i + (int64_t)q * (2 * smax * 3);
 
-    // Pass A: two smallest filter scores over all candidates, and tau = the smallest score any
-    // discarded train can have (every stream discards only trains >= its 3rd best).
+    // Sweep 1 (registers for the first 256 candidates): two smallest filter scores, and tau = the smallest score
+    // any DISCARDED train can have (every stream discards only trains >= its 3rd best).
+    float rs[4];
+    int ri[4];
     float m1 = kInf, m2 = kInf, tau = kInf;
-    for (int c = lane; c < NC; c += 64) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = lane + 64 * k;
+        rs[k] = c < NC ? cs[c] : kInf;
+        ri[k] = c < NC ? ci[c] : -1;
+        if (c % 3 == 2) tau = fminf(tau, rs[k]);
+        if (rs[k] < m1) { m2 = m1; m1 = rs[k]; } else if (rs[k] < m2) { m2 = rs[k]; }
+    }
+    for (int c = lane + kRefineMaxCand; c < NC; c += 64) {
         const float s = cs[c];
         if (c % 3 == 2) tau = fminf(tau, s);
         if (s < m1) { m2 = m1; m1 = s; } else if (s < m2) { m2 = s; }
@@ -676,22 +713,39 @@ __global__ __launch_bounds__(256) void knn_refine_kernel(
         m1 = lo;
         tau = fminf(tau, __shfl_xor(tau, m, 64));
     }
-    // A candidate whose score exceeds the 2nd smallest score by more than 2*eps is strictly
+    // A candidate whose score exceeds the 2nd smallest score by more than 4*eps is strictly
     // farther (even after sqrtf) than two other candidates: it cannot be in the exact top-2.
     const float thr = m2 + 4.f * eps;
 
     Best2 b;
     b.d[0] = b.d[1] = kInf; b.dsq[0] = b.dsq[1] = kInf; b.i[0] = b.i[1] = INT_MAX;
-    for (int c0 = 0; c0 < NC; c0 += 64) {
-        const int c = c0 + lane;
-        if (c < NC) {
-            const float s = cs[c];
-            const int id = ci[c];
-            if (id >= 0 && s <= thr) {
-                const float dsq = exact_l2sq_128(qrows[wave], T + (int64_t)id * ldt);
-                best2_insert(b, sqrtf(dsq), dsq, id);
-            }
+    const int grp = lane >> 3, sl = lane & 7;
+    // Sweep 2: survivors are compacted into an LDS list (64 at a time) and evaluated 8 per pass, 8 lanes each.
+    for (int k0 = 0; k0 * 64 < NC; ++k0) {
+        float s;
+        int id;
+        if (k0 < 4) {
+            s = k0 == 0 ? rs[0] : k0 == 1 ? rs[1] : k0 == 2 ? rs[2] : rs[3];
+            id = k0 == 0 ? ri[0] : k0 == 1 ? ri[1] : k0 == 2 ? ri[2] : ri[3];
+        } else {
+            const int c = lane + 64 * k0;
+            s = c < NC ? cs[c] : kInf;
+            id = c < NC ? ci[c] : -1;
         }
+        const bool take = id >= 0 && s <= thr;
+        const unsigned long long mask = __ballot(take);
+        if (mask == 0) continue;
+        const int nsel = __popcll(mask);
+        if (take) qual[wave][__popcll(mask & ((1ull << lane) - 1ull))] = id;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int e0 = 0; e0 < nsel; e0 += 8) {
+            const int e = e0 + grp;
+            const int tid = e < nsel ? qual[wave][e] : qual[wave][0];
+            const float dsq = exact_l2sq_group8(qrows[wave], T + (int64_t)tid * ldt, sl);
+            if (sl == 0 && e < nsel) best2_insert(b, sqrtf(dsq), dsq, tid);
+        }
+        __builtin_amdgcn_wave_barrier();
     }
     best2_wave_reduce(b);
 
@@ -717,8 +771,8 @@ struct Best2Rec {
     int i0, i1;
 };
 
-constexpr int kFbScanBlocks = 1024;
-constexpr int kFbMergeBlocks = 128;
+constexpr int kFbScanBlocks = 512;
+constexpr int kFbMergeBlocks = 32;
 
 __global__ __launch_bounds__(256) void knn_fallback_scan_kernel(
     const float* __restrict__ Q, int64_t ldq, const float* __restrict__ T, int64_t ldt, int nt, int nch, int chunk,
@@ -786,45 +840,90 @@ __global__ __launch_bounds__(64) void knn_fallback_merge_kernel(const Best2Rec* 
 
 // ---------------------------------------------------------------- ratio test + ordered compaction
 // `m.distance < 0.70 * n.distance` (sfm.py:264): float32 distances promoted to double.
-__global__ __launch_bounds__(1024) void ratio_compact_kernel(const int* __restrict__ idx, const float* __restrict__ dist,
-                                                             int nq, double ratio, int* __restrict__ out_q,
-                                                             int* __restrict__ out_t, int* __restrict__ out_count,
-                                                             unsigned char* __restrict__ mask) {
-    __shared__ int wsum[16];
+// Two multi-workgroup passes (a single workgroup is limited by one CU's ~10 B/clk load path):
+//   count:   1024 queries per workgroup → pass bits (optionally the mask) + one count per workgroup
+//   scatter: every workgroup sums the counts of its predecessors (a few dozen ints), re-derives its bits and writes
+//            its survivors at the right offset → ascending queryIdx order, no atomics, deterministic.
+constexpr int kRatioBlock = 1024;   // queries per workgroup (256 threads x 4 consecutive queries)
+
+__device__ __forceinline__ unsigned ratio_bits(const int* __restrict__ idx, const float* __restrict__ dist, int nq, int qb,
+                                               double ratio, int (&ti)[4]) {
+    unsigned pass = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int q = qb + k;
+        ti[k] = -1;
+        if (q < nq) {
+            const int2 ii = *reinterpret_cast<const int2*>(idx + 2 * q);
+            const float2 dd = *reinterpret_cast<const float2*>(dist + 2 * q);
+            ti[k] = ii.x;
+            pass |= ((ii.y >= 0) && ((double)dd.x < ratio * (double)dd.y) ? 1u : 0u) << k;
+        }
+    }
+    return pass;
+}
+
+__global__ __launch_bounds__(256) void ratio_count_kernel(const int* __restrict__ idx, const float* __restrict__ dist, int nq,
+                                                          double ratio, int* __restrict__ block_count,
+                                                          unsigned char* __restrict__ mask) {
+    __shared__ int wsum[4];
+    const int qb = blockIdx.x * kRatioBlock + threadIdx.x * 4;
+    int ti[4];
+    const unsigned pass = ratio_bits(idx, dist, nq, qb, ratio, ti);
+    if (mask)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (qb + k < nq) mask[qb + k] = (pass >> k) & 1u;
+    int c = __popc(pass);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_count[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+__global__ __launch_bounds__(256) void ratio_scatter_kernel(const int* __restrict__ idx, const float* __restrict__ dist, int nq,
+                                                            double ratio, const int* __restrict__ block_count,
+                                                            int* __restrict__ out_q, int* __restrict__ out_t,
+                                                            int* __restrict__ out_count) {
+    __shared__ int wsum[4];
     __shared__ int base_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) base_s = 0;
+    // exclusive prefix of the preceding workgroups' counts
+    int part = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) part += block_count[b];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) part += __shfl_xor(part, m, 64);
+    if (lane == 0) wsum[wave] = part;
     __syncthreads();
-    for (int q0 = 0; q0 < nq; q0 += 1024) {
-        const int q = q0 + threadIdx.x;
-        bool pass = false;
-        int ti = -1;
-        if (q < nq) {
-            const float d1 = dist[2 * q], d2 = dist[2 * q + 1];
-            ti = idx[2 * q];
-            pass = (idx[2 * q + 1] >= 0) && ((double)d1 < ratio * (double)d2);
-            if (mask) mask[q] = pass ? 1 : 0;
-        }
-        const unsigned long long bal = __ballot(pass);
-        const int prefix = __popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) wsum[wave] = __popcll(bal);
-        __syncthreads();
-        int woff = 0, total = 0;
-        for (int w = 0; w < 16; ++w) {
-            const int c = wsum[w];
-            if (w < wave) woff += c;
-            total += c;
-        }
-        const int base = base_s;
-        if (pass) {
-            out_q[base + woff + prefix] = q;
-            out_t[base + woff + prefix] = ti;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) base_s = base + total;
-        __syncthreads();
+    if (threadIdx.x == 0) base_s = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+    const int base = base_s;
+    __syncthreads();
+
+    const int qb = blockIdx.x * kRatioBlock + threadIdx.x * 4;
+    int ti[4];
+    const unsigned pass = ratio_bits(idx, dist, nq, qb, ratio, ti);
+    const int mine = __popc(pass);
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
     }
-    if (threadIdx.x == 0) *out_count = base_s;
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    int pos = base + woff + incl - mine;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (pass & (1u << k)) {
+            out_q[pos] = qb + k;
+            out_t[pos] = ti[k];
+            ++pos;
+        }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) *out_count = pos;   // last thread of the last workgroup: total
 }
 
 __global__ __launch_bounds__(256) void gather_matches_kernel(const float2* __restrict__ kp0, const float2* __restrict__ kp1,
@@ -891,6 +990,12 @@ KnnWs carve_ws(void* ws, int64_t nq, int64_t nt, const Plan& p) {
 
 }  // namespace
 
+extern "C" int sfm_knn_set_filter(int mode) {
+    SFM_CHECK_ARG(mode == 0 || mode == 1, "sfm_knn_set_filter: mode must be 0 (split-bf16) or 1 (fp32 MFMA)");
+    g_filter_mode = mode;
+    return SFM_OK;
+}
+
 extern "C" int sfm_debug_set_trace(void* dev_buf) {
     g_trace = static_cast<long long*>(dev_buf);
     return SFM_OK;
@@ -945,7 +1050,8 @@ extern "C" int sfm_knn2_l2_f32(const float* q, int64_t nq, int64_t ldq, const fl
         } else if (p.waves == 8) {
             if (abl == 1) SFM_LAUNCH_SPLIT(1, 8); else if (abl == 7) SFM_LAUNCH_SPLIT(7, 8); else SFM_LAUNCH_SPLIT(0, 8);
         } else {
-            if (abl == 1) SFM_LAUNCH_SPLIT(1, 16); else if (abl == 7) SFM_LAUNCH_SPLIT(7, 16); else SFM_LAUNCH_SPLIT(0, 16);
+            if (abl == 1) SFM_LAUNCH_SPLIT(1, 16); else if (abl == 7) SFM_LAUNCH_SPLIT(7, 16); else if (abl == 15) SFM_LAUNCH_SPLIT(15, 16);
+            else if (abl == 47) SFM_LAUNCH_SPLIT(47, 16); else if (abl == 39) SFM_LAUNCH_SPLIT(39, 16); else SFM_LAUNCH_SPLIT(0, 16);
         }
 #undef SFM_LAUNCH_SPLIT
     } else {
@@ -996,12 +1102,32 @@ extern "C" int sfm_knn2_l2_f32(const float* q, int64_t nq, int64_t ldq, const fl
     return SFM_OK;
 }
 
+extern "C" size_t sfm_ratio_compact_ws_bytes(int64_t nq) {
+    if (nq < 0) return 0;
+    return sfm::align_up((size_t)((nq + kRatioBlock - 1) / kRatioBlock + 1) * sizeof(int), 256) + 256;
+}
+
 extern "C" int sfm_ratio_compact(const int32_t* idx, const float* dist, int64_t nq, double ratio, int32_t* out_q,
-                                 int32_t* out_t, int32_t* out_count, uint8_t* mask, void* stream_) {
+                                 int32_t* out_t, int32_t* out_count, uint8_t* mask, void* ws, size_t ws_bytes,
+                                 void* stream_) {
     SFM_CHECK_ARG(nq >= 0 && nq < INT_MAX, "sfm_ratio_compact: bad nq");
     SFM_CHECK_ARG(out_count && (nq == 0 || (idx && dist && out_q && out_t)), "sfm_ratio_compact: null pointer");
-    hipLaunchKernelGGL(ratio_compact_kernel, dim3(1), dim3(1024), 0, sfm::as_stream(stream_), idx, dist, (int)nq, ratio,
-                       out_q, out_t, out_count, mask);
+    SFM_CHECK_ARG(((uintptr_t)idx & 7) == 0 && ((uintptr_t)dist & 7) == 0, "sfm_ratio_compact: idx/dist must be 8-byte aligned");
+    hipStream_t stream = sfm::as_stream(stream_);
+    if (nq == 0) {
+        SFM_CHECK_HIP(hipMemsetAsync(out_count, 0, sizeof(int32_t), stream));
+        return SFM_OK;
+    }
+    if (!ws || ws_bytes < sfm_ratio_compact_ws_bytes(nq)) {
+        sfm::set_error("sfm_ratio_compact: workspace too small (%zu < %zu)", ws_bytes, sfm_ratio_compact_ws_bytes(nq));
+        return SFM_ERR_WORKSPACE;
+    }
+    int* counts = reinterpret_cast<int*>(sfm::align_up((size_t)(uintptr_t)ws, 256));
+    const unsigned blocks = (unsigned)((nq + kRatioBlock - 1) / kRatioBlock);
+    hipLaunchKernelGGL(ratio_count_kernel, dim3(blocks), dim3(256), 0, stream, idx, dist, (int)nq, ratio, counts, mask);
+    SFM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ratio_scatter_kernel, dim3(blocks), dim3(256), 0, stream, idx, dist, (int)nq, ratio, counts, out_q,
+                       out_t, out_count);
     SFM_CHECK_LAUNCH();
     return SFM_OK;
 }

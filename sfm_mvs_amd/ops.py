@@ -78,9 +78,11 @@ def ratio_compact(idx, dist, ratio=0.70, want_mask=False):
     out_t = torch.empty(nq, dtype=torch.int32, device=idx.device)
     count = torch.zeros(1, dtype=torch.int32, device=idx.device)
     mask = torch.empty(nq, dtype=torch.uint8, device=idx.device) if want_mask else None
+    lib = _lib.lib()
+    rws = torch.empty(max(lib.sfm_ratio_compact_ws_bytes(nq), 256), dtype=torch.uint8, device=idx.device)
     with torch.cuda.device(idx.device):
-        check(_lib.lib().sfm_ratio_compact(ptr(idx), ptr(dist), nq, float(ratio), ptr(out_q), ptr(out_t), ptr(count),
-                                           ptr(mask), stream_ptr()), "sfm_ratio_compact")
+        check(lib.sfm_ratio_compact(ptr(idx), ptr(dist), nq, float(ratio), ptr(out_q), ptr(out_t), ptr(count), ptr(mask),
+                                    ptr(rws), rws.numel(), stream_ptr()), "sfm_ratio_compact")
     return (out_q, out_t, count, mask) if want_mask else (out_q, out_t, count)
 
 
@@ -261,6 +263,7 @@ class PairMatcher:
         self.out_q = torch.empty(self.nq, dtype=torch.int32, device=self.device)
         self.out_t = torch.empty(self.nq, dtype=torch.int32, device=self.device)
         self.count = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.rws = torch.empty(max(lib.sfm_ratio_compact_ws_bytes(self.nq), 256), dtype=torch.uint8, device=self.device)
 
     def run(self, des0, des1):
         require_cuda(des0, des1)
@@ -274,8 +277,14 @@ class PairMatcher:
                                   ptr(self.idx), ptr(self.dist), ptr(self.stats), ptr(self.ws), self.ws.numel(), s),
               "sfm_knn2_l2_f32")
         check(lib.sfm_ratio_compact(ptr(self.idx), ptr(self.dist), self.nq, self.ratio, ptr(self.out_q), ptr(self.out_t),
-                                    ptr(self.count), None, s), "sfm_ratio_compact")
+                                    ptr(self.count), None, ptr(self.rws), self.rws.numel(), s), "sfm_ratio_compact")
         return self.idx, self.dist, self.out_q, self.out_t, self.count
+
+
+def set_knn_filter(mode):
+    """'split' (bf16 hi/mid MFMA filter, default) or 'f32' (fp32 MFMA filter); identical results."""
+    check(_lib.lib().sfm_knn_set_filter({"split": 0, "f32": 1}[mode]), "sfm_knn_set_filter")
+    _ws_cache.clear()
 
 
 def profile_enable(on=True):

@@ -67,6 +67,35 @@ def test_exact_ties_resolve_to_lower_index_via_fallback(hip, oracle):
     assert np.all(gd[::3, :] == 0) and np.all(gi[::3, 0] % 32 == 1) and np.all(gi[::3, 1] % 32 == 9)
 
 
+def test_near_ties_below_filter_resolution(hip, oracle):
+    """Trains that differ by ~1e-6 relative — far below what the split-bf16 / packed-key filter can rank.
+    The certificate must refuse and the exact paths (refine re-evaluation, full-scan fallback) must still
+    return the direct-form answer bit for bit."""
+    rng = np.random.default_rng(17)
+    base = rng.random((40, 128), dtype=np.float32)
+    t = np.repeat(base, 50, axis=0) + (rng.standard_normal((2000, 128)) * 1e-5).astype(np.float32)
+    t = t[rng.permutation(2000)]
+    q = np.vstack([rng.random((150, 128), dtype=np.float32), base + np.float32(1e-3)])
+    gi, gd, stats = run(hip, q, t, stats=True)
+    assert_bit_equal((gi, gd), oracle.knn2(q, t, nthreads=8))
+    assert stats[0] > 50                       # most queries cannot be certified
+    # same with SIFT-like integers where a third of the trains are exact duplicates of each other
+    t2 = sift_like(rng, 1500)
+    t2[500:1000] = t2[:500]
+    q2 = np.vstack([sift_like(rng, 100), t2[:100]])
+    assert_bit_equal(run(hip, q2, t2), oracle.knn2(q2, t2, nthreads=8))
+
+
+@pytest.mark.parametrize("scale", [1e-3, 1.0, 3e4])
+def test_dynamic_range(hip, oracle, scale):
+    """bf16 splitting keeps fp32's exponent range: tiny and huge descriptors must behave alike."""
+    rng = np.random.default_rng(int(scale * 1000) % 97)
+    q = (rng.standard_normal((400, 128)) * scale).astype(np.float32)
+    t = (rng.standard_normal((700, 128)) * scale).astype(np.float32)
+    t[::7] *= np.float32(1e-3)                  # mixed magnitudes inside one train set
+    assert_bit_equal(run(hip, q, t), oracle.knn2(q, t, nthreads=8))
+
+
 def test_duplicated_train_set(hip, oracle):
     rng = np.random.default_rng(8)
     base = rng.random((100, 128), dtype=np.float32)
