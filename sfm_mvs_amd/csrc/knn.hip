@@ -45,6 +45,7 @@ constexpr float kInf = __builtin_huge_valf();
 // row-block boundary flushes its candidates and reloads the query fragment.
 struct Plan {
     int split;         // 1: split-bf16 filter (default), 0: fp32-MFMA filter
+    int qg;            // 32-query groups per wave (2: knn_filter_split2_kernel at 2 waves/SIMD)
     int nq_pad;        // query rows padded to whole row blocks
     int waves;         // waves per filter workgroup (4, 8 or 16); 16 waves are resident per CU either way
     int rows_per_block;
@@ -78,14 +79,16 @@ Plan make_plan(int64_t nq, int64_t nt) {
     static const int env_w = [] { const char* e = getenv("SFM_KNN_WAVES"); return e ? atoi(e) : 0; }();   // dev override
     p.waves = (env_w == 4 || env_w == 8 || env_w == 16) ? env_w : 8;
     p.split = g_filter_mode == 1 ? 0 : 1;
-    if (p.split && !(env_w == 4 || env_w == 8 || env_w == 16)) p.waves = 16;
-    p.rows_per_block = p.waves * 32;
+    static const int env_qg = [] { const char* e = getenv("SFM_KNN_QG"); return e ? atoi(e) : 0; }();   // dev override
+    p.qg = (p.split && env_qg != 1) ? 2 : 1;
+    if (p.split && !(env_w == 4 || env_w == 8 || env_w == 16)) p.waves = p.qg == 2 ? 8 : 16;
+    p.rows_per_block = p.waves * 32 * p.qg;
     p.n_rb = (int)((nq + p.rows_per_block - 1) / p.rows_per_block);
     p.nq_pad = p.n_rb * p.rows_per_block;
     p.tiles = (int)((nt + kTileT - 1) / kTileT);
     p.units = (int64_t)p.n_rb * p.tiles;
     static const int env_res = [] { const char* e = getenv("SFM_KNN_RESIDENT"); return e ? atoi(e) : 0; }();   // dev override
-    int64_t g = (env_res > 0 ? env_res : kResidentWaves) / p.waves;
+    int64_t g = (env_res > 0 ? env_res : kResidentWaves / p.qg) / p.waves;
     if (g > p.units) g = p.units;
     if (g > (int64_t)p.n_rb * (kMaxSlots - 2)) g = (int64_t)p.n_rb * (kMaxSlots - 2);
     if (g < 1) g = 1;
@@ -568,6 +571,197 @@ __global__ __launch_bounds__(64 * W, 4) void knn_filter_split_kernel(
     if (trace && threadIdx.x == 0) trace[4 * blockIdx.x + 1] = wall_clock64();
 }
 
+// ---------------------------------------------------------------- split-bf16 filter, two query groups per wave
+// Same arithmetic and outputs as knn_filter_split_kernel, restructured for the matrix pipe's sweet spot of TWO waves
+// per SIMD (a pure bf16-MFMA chain sustains 2.1 PFLOP/s at <= 2 waves/SIMD but 1.5 at 4 — scripts/ubench):
+//   * a wave owns 64 queries (two 32-column groups, 128 VGPRs of query fragments), so every train fragment read
+//     from LDS feeds 6 MFMAs and the two groups' accumulators form two independent dependency chains;
+//   * software pipelining inside the wave: while tile t runs on the matrix pipe, the packed-key epilogue of
+//     tile t-1 (its accumulators are kept) is interleaved between the MFMAs on the vector pipe.
+template <int W>
+__device__ __forceinline__ void key_insert4(const f32x16& a, int r0, int seq0, int& k0, int& k1, int& k2) {
+#pragma unroll
+    for (int r = r0; r < r0 + W; ++r) {
+        const int key = (__float_as_int(a[r]) & ~kKeyMask) | (seq0 + r);
+        const int lo = min(key, k0);
+        const int m1 = max(min(key, k1), min(max(key, k1), k0));
+        k2 = max(min(key, k1), min(max(key, k1), k2));
+        k1 = m1;
+        k0 = lo;
+    }
+}
+
+template <int ABL, int W>
+__global__ __launch_bounds__(64 * W, 2) void knn_filter_split2_kernel(
+    const unsigned short* __restrict__ qsplit, const float* __restrict__ qnorm, int nq, int nq_pad,
+    const unsigned short* __restrict__ tsplit, int nt, int nt_pad, const float* __restrict__ tn, int tiles, int64_t units,
+    int smax, int nsub, float* __restrict__ cand_s, int* __restrict__ cand_i, long long* __restrict__ trace) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (trace && threadIdx.x == 0) {
+        trace[4 * blockIdx.x + 0] = wall_clock64();
+        trace[4 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg(0xF804);
+        trace[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg(0xF814);
+    }
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31;
+    const int h = lane >> 5;
+    const int hm = h ^ (j & 15);
+    const int G = gridDim.x;
+    const int64_t u_end = unit_begin(units, G, blockIdx.x + 1);
+    int64_t u = unit_begin(units, G, blockIdx.x);
+    float* const tnb = smem + 2 * kTileFloats;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
+    const int mid_off = nt_pad * 256;
+    const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc((void*)tsplit, 0, 2 * mid_off, 0x00020000);
+    constexpr int PIECES = 16 / W;
+    const int r0 = 4 * ((wave * PIECES) & 7) + (lane >> 4);
+    const int lane_off = r0 * 256 + (((lane & 15) ^ (r0 & 15)) << 4);
+
+    while (u < u_end) {
+        const int rb = (int)(u / tiles);
+        const int t_begin = (int)(u - (int64_t)rb * tiles);
+        const int t_end = (int)min((int64_t)tiles, t_begin + (u_end - u));
+        const int slot = blockIdx.x - block_of_unit(units, G, (int64_t)rb * tiles);
+        const int qrow0 = rb * (W * 64) + wave * 64 + j;          // group g adds 32*g
+        const bool qok[2] = {qrow0 < nq, qrow0 + 32 < nq};
+
+        __syncthreads();
+        stage_tile_split<W>(trs, mid_off, lane_off, tn, nt, t_begin, smem, tnb, wave);
+
+        uint4 bh[2][8], bm[2][8];
+        float qn[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int qr = qok[g] ? qrow0 + 32 * g : 0;
+            const unsigned short* sh = qsplit + (int64_t)qr * kDim + 8 * h;
+            const unsigned short* sm = qsplit + ((int64_t)nq_pad + qr) * kDim + 8 * h;
+#pragma unroll
+            for (int st = 0; st < 8; ++st) {
+                bh[g][st] = *reinterpret_cast<const uint4*>(sh + 16 * st);
+                bm[g][st] = *reinterpret_cast<const uint4*>(sm + 16 * st);
+            }
+            qn[g] = qok[g] ? qnorm[qrow0 + 32 * g] : 0.f;
+        }
+
+        int ka[2] = {kKeyInf, kKeyInf}, kb[2] = {kKeyInf, kKeyInf}, kc[2] = {kKeyInf, kKeyInf};
+        int sub = 0, sub_t0 = t_begin;
+        const int64_t ob0 = ((int64_t)qrow0 * (2 * smax * nsub) + (int64_t)slot * nsub * 2 + h) * 3;
+        const int64_t ob1 = ob0 + (int64_t)32 * (2 * smax * nsub) * 3;
+        __syncthreads();
+
+        f32x16 accA[2], accB[2];
+        // one tile: MFMAs of tile t into `cur`, packed-key inserts of tile t-1 from `prev` interleaved
+        auto tile = [&](f32x16(&cur)[2], f32x16(&prev)[2], int t, bool have_prev) {
+            if (have_prev && (t - 1) - sub_t0 == kSubTiles) {
+                if (qok[0]) flush_keys(ka[0], kb[0], kc[0], sub_t0, h, cand_s + ob0 + 6 * sub, cand_i + ob0 + 6 * sub);
+                if (qok[1]) flush_keys(ka[1], kb[1], kc[1], sub_t0, h, cand_s + ob1 + 6 * sub, cand_i + ob1 + 6 * sub);
+                ka[0] = kb[0] = kc[0] = ka[1] = kb[1] = kc[1] = kKeyInf;
+                ++sub;
+                sub_t0 = t - 1;
+            }
+            const int cur_buf = (t - t_begin) & 1;
+            if (t + 1 < t_end && !(ABL & 4))
+                stage_tile_split<W>(trs, mid_off, lane_off, tn, nt, t + 1, smem + (cur_buf ^ 1) * kTileFloats,
+                                    tnb + (cur_buf ^ 1) * kTileT, wave);
+            {
+                const float* tnp = tnb + cur_buf * kTileT + 4 * h;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const float4 v = *reinterpret_cast<const float4*>(tnp + 8 * b);
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {
+                        cur[g][4 * b + 0] = (ABL & 8) ? qn[g] : v.x + qn[g];
+                        cur[g][4 * b + 1] = (ABL & 8) ? qn[g] : v.y + qn[g];
+                        cur[g][4 * b + 2] = (ABL & 8) ? qn[g] : v.z + qn[g];
+                        cur[g][4 * b + 3] = (ABL & 8) ? qn[g] : v.w + qn[g];
+                    }
+                }
+            }
+            const unsigned abase = lds0 + (unsigned)(((ABL & 4) ? 0 : cur_buf) * kTileFloats) * 4u + (unsigned)j * 256u + ((unsigned)hm << 4);
+            const int seq0 = ((t - 1) - sub_t0) << 4;
+            u32x4 ah[2], am[2];
+            asm volatile("ds_read_b128 %0, %1" : "=v"(ah[0]) : "v"(abase));
+            asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(am[0]) : "v"(abase));
+#pragma unroll
+            for (int st = 0; st < 8; ++st) {
+                if (ABL & 32) {
+                } else if (st + 1 < 8) {
+                    const unsigned ad = abase ^ (32u * (st + 1));
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(ah[(st + 1) & 1]) : "v"(ad));
+                    asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(am[(st + 1) & 1]) : "v"(ad));
+                    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ah[st & 1]), "+v"(am[st & 1]));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[st & 1]), "+v"(am[st & 1]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const bf16x8 Ah = __builtin_bit_cast(bf16x8, ah[st & 1]), Am = __builtin_bit_cast(bf16x8, am[st & 1]);
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const bf16x8 Bh = __builtin_bit_cast(bf16x8, bh[g][st]), Bm = __builtin_bit_cast(bf16x8, bm[g][st]);
+                    cur[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, cur[g], 0, 0, 0);
+                    cur[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm, cur[g], 0, 0, 0);
+                    cur[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, cur[g], 0, 0, 0);
+                }
+                if (have_prev && (ABL & 1)) {    // dev ablation: keep the MFMAs alive with one op per k-step
+                    ka[0] = min(ka[0], __float_as_int(prev[0][2 * st]) + __float_as_int(prev[0][2 * st + 1]));
+                    ka[1] = min(ka[1], __float_as_int(prev[1][2 * st]) + __float_as_int(prev[1][2 * st + 1]));
+                } else if (have_prev) {          // 2 values of each group per k-step: 16 VALU beside 6 MFMAs
+                    key_insert4<2>(prev[0], 2 * st, seq0, ka[0], kb[0], kc[0]);
+                    key_insert4<2>(prev[1], 2 * st, seq0, ka[1], kb[1], kc[1]);
+                }
+            }
+            if (!(ABL & 2)) __syncthreads();
+        };
+
+        int t = t_begin;
+        bool have_prev = false;
+        for (; t + 1 < t_end; t += 2) {
+            tile(accA, accB, t, have_prev);
+            tile(accB, accA, t + 1, true);
+            have_prev = true;
+        }
+        if (t < t_end) {                                   // odd count: one more tile, then its own epilogue
+            tile(accA, accB, t, have_prev);
+            ++t;
+            if ((t - 1) - sub_t0 == kSubTiles) {
+                if (qok[0]) flush_keys(ka[0], kb[0], kc[0], sub_t0, h, cand_s + ob0 + 6 * sub, cand_i + ob0 + 6 * sub);
+                if (qok[1]) flush_keys(ka[1], kb[1], kc[1], sub_t0, h, cand_s + ob1 + 6 * sub, cand_i + ob1 + 6 * sub);
+                ka[0] = kb[0] = kc[0] = ka[1] = kb[1] = kc[1] = kKeyInf;
+                ++sub;
+                sub_t0 = t - 1;
+            }
+            key_insert4<16>(accA[0], 0, ((t - 1) - sub_t0) << 4, ka[0], kb[0], kc[0]);
+            key_insert4<16>(accA[1], 0, ((t - 1) - sub_t0) << 4, ka[1], kb[1], kc[1]);
+        } else if (have_prev || t_end - t_begin >= 2) {    // even count: the last tile's results are in accB
+            if ((t - 1) - sub_t0 == kSubTiles) {
+                if (qok[0]) flush_keys(ka[0], kb[0], kc[0], sub_t0, h, cand_s + ob0 + 6 * sub, cand_i + ob0 + 6 * sub);
+                if (qok[1]) flush_keys(ka[1], kb[1], kc[1], sub_t0, h, cand_s + ob1 + 6 * sub, cand_i + ob1 + 6 * sub);
+                ka[0] = kb[0] = kc[0] = ka[1] = kb[1] = kc[1] = kKeyInf;
+                ++sub;
+                sub_t0 = t - 1;
+            }
+            key_insert4<16>(accB[0], 0, ((t - 1) - sub_t0) << 4, ka[0], kb[0], kc[0]);
+            key_insert4<16>(accB[1], 0, ((t - 1) - sub_t0) << 4, ka[1], kb[1], kc[1]);
+        }
+
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+            if (qok[g]) {
+                const int64_t ob = g == 0 ? ob0 : ob1;
+                flush_keys(ka[g], kb[g], kc[g], sub_t0, h, cand_s + ob + 6 * sub, cand_i + ob + 6 * sub);
+                for (int e = sub + 1; e < nsub; ++e)
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        cand_s[ob + 6 * e + r] = kInf;
+                        cand_i[ob + 6 * e + r] = -1;
+                    }
+            }
+        u += t_end - t_begin;
+    }
+    if (trace && threadIdx.x == 0) trace[4 * blockIdx.x + 1] = wall_clock64();
+}
+
 // ---------------------------------------------------------------- exact direct-form distance
 // Reference arithmetic (OpenCV normL2Sqr_, SSE2 path): two 4-lane accumulators over blocks of 8,
 // mul and add separately rounded; lanes summed as (d0+d1) then ((s0+s1)+s2)+s3.
@@ -1045,7 +1239,20 @@ extern "C" int sfm_knn2_l2_f32(const float* q, int64_t nq, int64_t ldq, const fl
     hipLaunchKernelGGL((knn_filter_split_kernel<A, WV>), grid, dim3(64 * WV), kLdsFloats * sizeof(float), stream,      \
                        w.qsplit, w.qn, (int)nq, p.nq_pad, w.tsplit, (int)nt, p.tiles * kTileT, w.tn, p.tiles, p.units,  \
                        p.smax, p.nsub, w.cand_s, w.cand_i, g_trace)
-        if (p.waves == 4) {
+#define SFM_LAUNCH_SPLIT2(A, WV)                                                                                       \
+    hipLaunchKernelGGL((knn_filter_split2_kernel<A, WV>), grid, dim3(64 * WV), kLdsFloats * sizeof(float), stream,     \
+                       w.qsplit, w.qn, (int)nq, p.nq_pad, w.tsplit, (int)nt, p.tiles * kTileT, w.tn, p.tiles, p.units,  \
+                       p.smax, p.nsub, w.cand_s, w.cand_i, g_trace)
+        if (p.qg == 2) {
+            if (p.waves == 4) {
+                if (abl == 1) SFM_LAUNCH_SPLIT2(1, 4); else if (abl == 7) SFM_LAUNCH_SPLIT2(7, 4); else SFM_LAUNCH_SPLIT2(0, 4);
+            } else if (p.waves == 16) {
+                if (abl == 1) SFM_LAUNCH_SPLIT2(1, 16); else if (abl == 7) SFM_LAUNCH_SPLIT2(7, 16); else SFM_LAUNCH_SPLIT2(0, 16);
+            } else {
+                if (abl == 1) SFM_LAUNCH_SPLIT2(1, 8); else if (abl == 7) SFM_LAUNCH_SPLIT2(7, 8); else if (abl == 39) SFM_LAUNCH_SPLIT2(39, 8);
+                else if (abl == 47) SFM_LAUNCH_SPLIT2(47, 8); else SFM_LAUNCH_SPLIT2(0, 8);
+            }
+        } else if (p.waves == 4) {
             if (abl == 1) SFM_LAUNCH_SPLIT(1, 4); else if (abl == 7) SFM_LAUNCH_SPLIT(7, 4); else SFM_LAUNCH_SPLIT(0, 4);
         } else if (p.waves == 8) {
             if (abl == 1) SFM_LAUNCH_SPLIT(1, 8); else if (abl == 7) SFM_LAUNCH_SPLIT(7, 8); else SFM_LAUNCH_SPLIT(0, 8);
@@ -1054,6 +1261,7 @@ extern "C" int sfm_knn2_l2_f32(const float* q, int64_t nq, int64_t ldq, const fl
             else if (abl == 47) SFM_LAUNCH_SPLIT(47, 16); else if (abl == 39) SFM_LAUNCH_SPLIT(39, 16); else SFM_LAUNCH_SPLIT(0, 16);
         }
 #undef SFM_LAUNCH_SPLIT
+#undef SFM_LAUNCH_SPLIT2
     } else {
     hipLaunchKernelGGL(knn_norms_kernel, dim3(kNormBlocks), dim3(256), 0, stream, t, ldt, (int)nt, w.tn, w.bmax,
                        w.flag_count);
