@@ -36,7 +36,7 @@ constexpr int kTileT = 32;             // train rows per LDS tile (= MFMA M)
 
 
 constexpr int kResidentWaves = 4096;   // 256 CUs x 16 waves (4 per SIMD at <= 128 VGPRs)
-constexpr int kMaxSlots = 34;          // cap on filter blocks that may touch one query row block
+constexpr int kMaxSlots = 258;         // cap on filter blocks that may touch one query row block (all 256 CUs on one)
 constexpr float kInf = __builtin_huge_valf();
 
 // Work decomposition ("stream-K" over the flattened (query row block, train tile) unit space):

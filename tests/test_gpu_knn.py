@@ -28,6 +28,14 @@ def test_random_float_descriptors_bit_exact(hip, oracle, nq, nt):
     assert_bit_equal(run(hip, q, t), oracle.knn2(q, t, nthreads=8))
 
 
+@pytest.mark.parametrize("nq,nt", [(100, 20000), (3, 40000), (20000, 96)])
+def test_skewed_shapes(hip, oracle, nq, nt):
+    """Few queries x many trains (one query row block spread over every CU, many substreams) and the reverse."""
+    rng = np.random.default_rng(nq + nt)
+    q, t = rng.random((nq, 128), dtype=np.float32), rng.random((nt, 128), dtype=np.float32)
+    assert_bit_equal(run(hip, q, t), oracle.knn2(q, t, nthreads=8))
+
+
 def test_signed_and_scaled_floats(hip, oracle):
     rng = np.random.default_rng(5)
     q = (rng.standard_normal((500, 128)) * 37.5).astype(np.float32)
