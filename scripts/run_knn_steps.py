@@ -6,10 +6,24 @@ from sfm_mvs_amd import ops
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 nq = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
 nt = int(sys.argv[3]) if len(sys.argv) > 3 else 10000
-q = torch.rand((nq, 128), generator=torch.Generator().manual_seed(0)).cuda()
-t = torch.rand((nt, 128), generator=torch.Generator().manual_seed(1)).cuda()
+kind = sys.argv[4] if len(sys.argv) > 4 else "uniform"
+if kind == "sift":      # integer-valued 0..255 like cv2 SIFT output
+    q = torch.randint(0, 120, (nq, 128), generator=torch.Generator().manual_seed(0)).float().cuda()
+    t = torch.randint(0, 120, (nt, 128), generator=torch.Generator().manual_seed(1)).float().cuda()
+else:
+    q = torch.rand((nq, 128), generator=torch.Generator().manual_seed(0)).cuda()
+    t = torch.rand((nt, 128), generator=torch.Generator().manual_seed(1)).cuda()
 pm = ops.PairMatcher(nq, nt, q.device)
+import time
+for _ in range(3):
+    pm.run(q, t)
+torch.cuda.synchronize()
+ops.profile_enable(True)
+t0 = time.perf_counter()
 for _ in range(n):
     pm.run(q, t)
 torch.cuda.synchronize()
-print("done", pm.stats.cpu().tolist())
+dt = (time.perf_counter() - t0) / n
+f_ms, f_n = ops.profile_read(0)
+ops.profile_enable(False)
+print(f"done {kind} {nq}x{nt}: step {dt*1e3:.4f} ms  filter {f_ms/max(f_n,1):.4f} ms  {nq*nt/dt:.3e} dist/s  stats", pm.stats.cpu().tolist())

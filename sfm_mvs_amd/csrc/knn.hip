@@ -25,6 +25,7 @@
 #include <cfloat>
 #include <climits>
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -376,10 +377,13 @@ __global__ __launch_bounds__(256) void knn_prep_kernel(const float* __restrict__
                                                        const float* __restrict__ T, int64_t ldt, int nt, int nt_pad,
                                                        unsigned short* __restrict__ qsplit, float* __restrict__ qn,
                                                        unsigned short* __restrict__ tsplit, float* __restrict__ tn,
-                                                       float* __restrict__ bmax, int* __restrict__ flag_count) {
+                                                       float* __restrict__ bmax, int* __restrict__ midflag,
+                                                       int* __restrict__ flag_count) {
     __shared__ float wmax[4];
+    __shared__ int wmid[4];
     const int l = threadIdx.x & 31;
     float mx = 0.f;
+    unsigned anymid = 0;
     const int rows = nq_pad + nt_pad;
     for (int row = blockIdx.x * 8 + (threadIdx.x >> 5); row < rows; row += gridDim.x * 8) {
         const bool isq = row < nq_pad;
@@ -397,6 +401,7 @@ __global__ __launch_bounds__(256) void knn_prep_kernel(const float* __restrict__
         for (int k = 0; k < 4; ++k) {
             hb[k] = bf16_rn_bits(e[k]);
             mb[k] = bf16_rn_bits(e[k] - __uint_as_float(hb[k] << 16));   // x - hi is exact in fp32
+            anymid |= mb[k] & 0x7FFFu;
         }
         unsigned short* img = isq ? qsplit : tsplit;
         *reinterpret_cast<uint2*>(img + (int64_t)r * kDim + 4 * l) = make_uint2(hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16));
@@ -406,22 +411,30 @@ __global__ __launch_bounds__(256) void knn_prep_kernel(const float* __restrict__
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
-    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+    const int wany = __any(anymid != 0) ? 1 : 0;
+    if ((threadIdx.x & 63) == 0) {
+        wmax[threadIdx.x >> 6] = mx;
+        wmid[threadIdx.x >> 6] = wany;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         bmax[blockIdx.x] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+        // 0 for this block's rows when every value is exactly a bf16 (e.g. SIFT's integers 0..255): the filter
+        // then needs the hi.hi product only and its dot products are EXACT.
+        midflag[blockIdx.x] = wmid[0] | wmid[1] | wmid[2] | wmid[3];
         if (blockIdx.x == 0) *flag_count = 0;
     }
 }
 
 // LDS tile image: hi rows [32][256 B] at +0, mid rows at +8 KiB, 16-byte chunks XOR-swizzled with (row & 15).
-template <int W>
+template <int W, bool KMID = true>
 __device__ __forceinline__ void stage_tile_split(__amdgpu_buffer_rsrc_t trs, int mid_off, int lane_off, const float* __restrict__ tn,
                                                  int nt, int tile, float* __restrict__ tile_buf, float* __restrict__ tn_buf,
                                                  int wave) {
     constexpr int PIECES = 16 / W;                       // 1 KiB pieces (4 rows x 256 B) per wave per tile
     const int p0 = wave * PIECES;
     const int soff = tile * kTileT * 256 + (p0 >= 8 ? mid_off : 0);
+    if (KMID || p0 < 8)                                  // exact mode: the mid image is all zeros and never read
 #pragma unroll
     for (int n = 0; n < PIECES; ++n) {
         float* dst = tile_buf + (p0 + n) * 256;
@@ -591,11 +604,12 @@ __device__ __forceinline__ void key_insert4(const f32x16& a, int r0, int seq0, i
     }
 }
 
-template <int ABL, int W>
+template <int ABL, int W, bool KMID>
 __global__ __launch_bounds__(64 * W, 2) void knn_filter_split2_kernel(
     const unsigned short* __restrict__ qsplit, const float* __restrict__ qnorm, int nq, int nq_pad,
     const unsigned short* __restrict__ tsplit, int nt, int nt_pad, const float* __restrict__ tn, int tiles, int64_t units,
-    int smax, int nsub, float* __restrict__ cand_s, int* __restrict__ cand_i, long long* __restrict__ trace) {
+    int smax, int nsub, const int* __restrict__ midflag, float* __restrict__ cand_s, int* __restrict__ cand_i,
+    long long* __restrict__ trace) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if (trace && threadIdx.x == 0) {
         trace[4 * blockIdx.x + 0] = wall_clock64();
@@ -617,6 +631,10 @@ __global__ __launch_bounds__(64 * W, 2) void knn_filter_split2_kernel(
     constexpr int PIECES = 16 / W;
     const int r0 = 4 * ((wave * PIECES) & 7) + (lane >> 4);
     const int lane_off = r0 * 256 + (((lane & 15) ^ (r0 & 15)) << 4);
+    // Both instantiations are launched; the one that does not match the data exits here.  KMID = false: every input
+    // is exactly a bf16 (real SIFT descriptors, integers 0..255) → one exact product instead of three.
+    const bool need_mid = __any((midflag[lane] | midflag[lane + 64] | midflag[lane + 128] | midflag[lane + 192]) != 0);
+    if (need_mid != KMID) return;
 
     while (u < u_end) {
         const int rb = (int)(u / tiles);
@@ -627,7 +645,7 @@ __global__ __launch_bounds__(64 * W, 2) void knn_filter_split2_kernel(
         const bool qok[2] = {qrow0 < nq, qrow0 + 32 < nq};
 
         __syncthreads();
-        stage_tile_split<W>(trs, mid_off, lane_off, tn, nt, t_begin, smem, tnb, wave);
+        stage_tile_split<W, KMID>(trs, mid_off, lane_off, tn, nt, t_begin, smem, tnb, wave);
 
         uint4 bh[2][8], bm[2][8];
         float qn[2];
@@ -639,7 +657,7 @@ __global__ __launch_bounds__(64 * W, 2) void knn_filter_split2_kernel(
 #pragma unroll
             for (int st = 0; st < 8; ++st) {
                 bh[g][st] = *reinterpret_cast<const uint4*>(sh + 16 * st);
-                bm[g][st] = *reinterpret_cast<const uint4*>(sm + 16 * st);
+                if (KMID) bm[g][st] = *reinterpret_cast<const uint4*>(sm + 16 * st);
             }
             qn[g] = qok[g] ? qnorm[qrow0 + 32 * g] : 0.f;
         }
@@ -653,6 +671,7 @@ __global__ __launch_bounds__(64 * W, 2) void knn_filter_split2_kernel(
         f32x16 accA[2], accB[2];
         // one tile: MFMAs of tile t into `cur`, packed-key inserts of tile t-1 from `prev` interleaved
         auto tile = [&](f32x16(&cur)[2], f32x16(&prev)[2], int t, bool have_prev) {
+            constexpr bool kMid = KMID;
             if (have_prev && (t - 1) - sub_t0 == kSubTiles) {
                 if (qok[0]) flush_keys(ka[0], kb[0], kc[0], sub_t0, h, cand_s + ob0 + 6 * sub, cand_i + ob0 + 6 * sub);
                 if (qok[1]) flush_keys(ka[1], kb[1], kc[1], sub_t0, h, cand_s + ob1 + 6 * sub, cand_i + ob1 + 6 * sub);
@@ -662,7 +681,7 @@ __global__ __launch_bounds__(64 * W, 2) void knn_filter_split2_kernel(
             }
             const int cur_buf = (t - t_begin) & 1;
             if (t + 1 < t_end && !(ABL & 4))
-                stage_tile_split<W>(trs, mid_off, lane_off, tn, nt, t + 1, smem + (cur_buf ^ 1) * kTileFloats,
+                stage_tile_split<W, KMID>(trs, mid_off, lane_off, tn, nt, t + 1, smem + (cur_buf ^ 1) * kTileFloats,
                                     tnb + (cur_buf ^ 1) * kTileT, wave);
             {
                 const float* tnp = tnb + cur_buf * kTileT + 4 * h;
@@ -682,26 +701,35 @@ __global__ __launch_bounds__(64 * W, 2) void knn_filter_split2_kernel(
             const int seq0 = ((t - 1) - sub_t0) << 4;
             u32x4 ah[2], am[2];
             asm volatile("ds_read_b128 %0, %1" : "=v"(ah[0]) : "v"(abase));
-            asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(am[0]) : "v"(abase));
+            if (KMID) asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(am[0]) : "v"(abase));
 #pragma unroll
             for (int st = 0; st < 8; ++st) {
                 if (ABL & 32) {
                 } else if (st + 1 < 8) {
                     const unsigned ad = abase ^ (32u * (st + 1));
                     asm volatile("ds_read_b128 %0, %1" : "=v"(ah[(st + 1) & 1]) : "v"(ad));
-                    asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(am[(st + 1) & 1]) : "v"(ad));
-                    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ah[st & 1]), "+v"(am[st & 1]));
-                } else {
+                    if (KMID) {
+                        asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(am[(st + 1) & 1]) : "v"(ad));
+                        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ah[st & 1]), "+v"(am[st & 1]));
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(ah[st & 1]));
+                    }
+                } else if (KMID) {
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[st & 1]), "+v"(am[st & 1]));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[st & 1]));
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                const bf16x8 Ah = __builtin_bit_cast(bf16x8, ah[st & 1]), Am = __builtin_bit_cast(bf16x8, am[st & 1]);
+                const bf16x8 Ah = __builtin_bit_cast(bf16x8, ah[st & 1]);
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
-                    const bf16x8 Bh = __builtin_bit_cast(bf16x8, bh[g][st]), Bm = __builtin_bit_cast(bf16x8, bm[g][st]);
+                    const bf16x8 Bh = __builtin_bit_cast(bf16x8, bh[g][st]);
                     cur[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, cur[g], 0, 0, 0);
-                    cur[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm, cur[g], 0, 0, 0);
-                    cur[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, cur[g], 0, 0, 0);
+                    if (kMid) {
+                        const bf16x8 Am = __builtin_bit_cast(bf16x8, am[st & 1]), Bm = __builtin_bit_cast(bf16x8, bm[g][st]);
+                        cur[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm, cur[g], 0, 0, 0);
+                        cur[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, cur[g], 0, 0, 0);
+                    }
                 }
                 if (have_prev && (ABL & 1)) {    // dev ablation: keep the MFMAs alive with one op per k-step
                     ka[0] = min(ka[0], __float_as_int(prev[0][2 * st]) + __float_as_int(prev[0][2 * st + 1]));
@@ -714,35 +742,26 @@ __global__ __launch_bounds__(64 * W, 2) void knn_filter_split2_kernel(
             if (!(ABL & 2)) __syncthreads();
         };
 
-        int t = t_begin;
+        // accA = tile being computed, accB = previous tile (its epilogue runs inside tile()); 32 v_mov per tile
+        // instead of a second copy of the ~1k-instruction body (instruction-cache footprint).
         bool have_prev = false;
-        for (; t + 1 < t_end; t += 2) {
+        for (int t = t_begin; t < t_end; ++t) {
             tile(accA, accB, t, have_prev);
-            tile(accB, accA, t + 1, true);
+            accB[0] = accA[0];
+            accB[1] = accA[1];
             have_prev = true;
         }
-        if (t < t_end) {                                   // odd count: one more tile, then its own epilogue
-            tile(accA, accB, t, have_prev);
-            ++t;
-            if ((t - 1) - sub_t0 == kSubTiles) {
+        if (t_end > t_begin) {                             // epilogue of the last tile
+            const int tl = t_end - 1;
+            if (tl - sub_t0 == kSubTiles) {
                 if (qok[0]) flush_keys(ka[0], kb[0], kc[0], sub_t0, h, cand_s + ob0 + 6 * sub, cand_i + ob0 + 6 * sub);
                 if (qok[1]) flush_keys(ka[1], kb[1], kc[1], sub_t0, h, cand_s + ob1 + 6 * sub, cand_i + ob1 + 6 * sub);
                 ka[0] = kb[0] = kc[0] = ka[1] = kb[1] = kc[1] = kKeyInf;
                 ++sub;
-                sub_t0 = t - 1;
+                sub_t0 = tl;
             }
-            key_insert4<16>(accA[0], 0, ((t - 1) - sub_t0) << 4, ka[0], kb[0], kc[0]);
-            key_insert4<16>(accA[1], 0, ((t - 1) - sub_t0) << 4, ka[1], kb[1], kc[1]);
-        } else if (have_prev || t_end - t_begin >= 2) {    // even count: the last tile's results are in accB
-            if ((t - 1) - sub_t0 == kSubTiles) {
-                if (qok[0]) flush_keys(ka[0], kb[0], kc[0], sub_t0, h, cand_s + ob0 + 6 * sub, cand_i + ob0 + 6 * sub);
-                if (qok[1]) flush_keys(ka[1], kb[1], kc[1], sub_t0, h, cand_s + ob1 + 6 * sub, cand_i + ob1 + 6 * sub);
-                ka[0] = kb[0] = kc[0] = ka[1] = kb[1] = kc[1] = kKeyInf;
-                ++sub;
-                sub_t0 = t - 1;
-            }
-            key_insert4<16>(accB[0], 0, ((t - 1) - sub_t0) << 4, ka[0], kb[0], kc[0]);
-            key_insert4<16>(accB[1], 0, ((t - 1) - sub_t0) << 4, ka[1], kb[1], kc[1]);
+            key_insert4<16>(accB[0], 0, (tl - sub_t0) << 4, ka[0], kb[0], kc[0]);
+            key_insert4<16>(accB[1], 0, (tl - sub_t0) << 4, ka[1], kb[1], kc[1]);
         }
 
 #pragma unroll
@@ -1157,6 +1176,7 @@ struct KnnWs {
     float* qn;
     float* tn;
     float* bmax;
+    int* midflag;
     Best2Rec* fb_partial;
     int* flag_count;
     int* flag_list;
@@ -1169,6 +1189,7 @@ KnnWs carve_ws(void* ws, int64_t nq, int64_t nt, const Plan& p) {
     sfm::Carver c(ws);
     KnnWs w;
     w.bmax = c.take<float>(kNormBlocks);
+    w.midflag = c.take<int>(kNormBlocks);
     w.flag_count = c.take<int>(1);
     w.fb_partial = c.take<Best2Rec>((size_t)nq * p.fb_nch);
     w.tn = c.take<float>((size_t)p.tiles * kTileT);
@@ -1232,17 +1253,22 @@ extern "C" int sfm_knn2_l2_f32(const float* q, int64_t nq, int64_t ldq, const fl
     static const int abl = [] { const char* e = getenv("SFM_KNN_ABL"); return e ? atoi(e) : 0; }();   // dev only
     if (p.split) {
         hipLaunchKernelGGL(knn_prep_kernel, dim3(kNormBlocks), dim3(256), 0, stream, q, ldq, (int)nq, p.nq_pad, t, ldt, (int)nt,
-                           p.tiles * kTileT, w.qsplit, w.qn, w.tsplit, w.tn, w.bmax, w.flag_count);
+                           p.tiles * kTileT, w.qsplit, w.qn, w.tsplit, w.tn, w.bmax, w.midflag, w.flag_count);
         SFM_CHECK_LAUNCH();
         sfm::prof_begin(sfm::kProfKnnFilter, stream);
 #define SFM_LAUNCH_SPLIT(A, WV)                                                                                        \
     hipLaunchKernelGGL((knn_filter_split_kernel<A, WV>), grid, dim3(64 * WV), kLdsFloats * sizeof(float), stream,      \
                        w.qsplit, w.qn, (int)nq, p.nq_pad, w.tsplit, (int)nt, p.tiles * kTileT, w.tn, p.tiles, p.units,  \
                        p.smax, p.nsub, w.cand_s, w.cand_i, g_trace)
-#define SFM_LAUNCH_SPLIT2(A, WV)                                                                                       \
-    hipLaunchKernelGGL((knn_filter_split2_kernel<A, WV>), grid, dim3(64 * WV), kLdsFloats * sizeof(float), stream,     \
-                       w.qsplit, w.qn, (int)nq, p.nq_pad, w.tsplit, (int)nt, p.tiles * kTileT, w.tn, p.tiles, p.units,  \
-                       p.smax, p.nsub, w.cand_s, w.cand_i, g_trace)
+#define SFM_LAUNCH_SPLIT2(A, WV)                                                                                        \
+    do {                                                                                                                 \
+    hipLaunchKernelGGL((knn_filter_split2_kernel<A, WV, true>), grid, dim3(64 * WV), kLdsFloats * sizeof(float), stream, \
+                       w.qsplit, w.qn, (int)nq, p.nq_pad, w.tsplit, (int)nt, p.tiles * kTileT, w.tn, p.tiles, p.units,   \
+                       p.smax, p.nsub, w.midflag, w.cand_s, w.cand_i, g_trace);                                          \
+    hipLaunchKernelGGL((knn_filter_split2_kernel<A, WV, false>), grid, dim3(64 * WV), kLdsFloats * sizeof(float), stream, \
+                       w.qsplit, w.qn, (int)nq, p.nq_pad, w.tsplit, (int)nt, p.tiles * kTileT, w.tn, p.tiles, p.units,   \
+                       p.smax, p.nsub, w.midflag, w.cand_s, w.cand_i, g_trace);                                          \
+    } while (0)
         if (p.qg == 2) {
             if (p.waves == 4) {
                 if (abl == 1) SFM_LAUNCH_SPLIT2(1, 4); else if (abl == 7) SFM_LAUNCH_SPLIT2(7, 4); else SFM_LAUNCH_SPLIT2(0, 4);
