@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="knn", choices=["knn", "tri", "ba"])
+    ap.add_argument("--workload", default="knn", choices=["knn", "tri", "ba", "sfm"])
     ap.add_argument("--nq", type=int, default=10000)
     ap.add_argument("--nt", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -160,7 +160,7 @@ def bench_knn(args, world, rank, dev):
                      "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": traffic,
                      "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/knn_traffic.json)",
                      "algorithmic_bytes_per_launch": 4 * 128 * (nq + nt) + 16 * nq,
-                     "kernel": "knn_filter_split_kernel", "avg_launch_ms": filt_avg_ms, "launches": filt_n,
+                     "kernel": "knn_filter_split2_kernel<0, 8, true>", "avg_launch_ms": filt_avg_ms, "launches": filt_n,
                      "algorithmic_flop_per_launch": algo_flop,
                      "issued_mfma_tflops": issued, "issued_frac_of_peak": issued / BF16_MFMA_PEAK_TFLOPS,
                      "note": "algorithmic = 256 FLOP per distance (SURVEY 8d); the kernel issues 3.07x that in bf16 MFMA flops"},
@@ -299,6 +299,35 @@ def bench_ba(args, world, rank, dev):
                          "fp64_valu_peak_TFLOPs": FP64_VALU_PEAK_TFLOPS}}
 
 
+def bench_sfm(args, world, rank, dev):
+    """BASELINE configs[2] on Gustav GEOMETRY (the images are not available): the incremental driver over the 57
+    cameras of the reference's pose.csv, features rendered from the reference's own cloud."""
+    from sfm_mvs_amd import pipeline as pl
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from datagen import decompose_P, gustav_scene
+    K, P, feats, ids = gustav_scene(57, seed=3)
+    pl.run_sfm(feats[:4], K)                      # warm-up (allocator, first launches)
+    barrier_sync(world)
+    times = []
+    for _ in range(max(1, min(args.steps, 5))):
+        t0 = time.perf_counter()
+        out = pl.run_sfm(feats, K)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    got = out["posearr"][9:].reshape(-1, 3, 4)
+    dR = max(np.abs(decompose_P(K, got[k])[0] - decompose_P(K, P[k])[0]).max() for k in range(57))
+    dt = max(np.linalg.norm(decompose_P(K, got[k])[1] - decompose_P(K, P[k])[1]) / max(1.0, np.linalg.norm(decompose_P(K, P[k])[1]))
+             for k in range(57))
+    sec = float(np.median(times))
+    return {"metric": "end-to-end incremental SfM, 57 cameras (s)", "value": sec, "unit": "s", "n_gpus": world,
+            "steps": len(times), "warmup": 1, "ms_per_step": sec * 1e3, "higher_is_better": False, "scaling": "replicas",
+            "vs_baseline": None, "dtype": "f32/f64", "data": "synthetic (Gustav geometry: pose.csv cameras x sparse.ply points)",
+            "config": {"workload": "BASELINE configs[2] on synthetic Gustav geometry", "images": 57,
+                       "features_per_image": int(np.mean([len(f[0]) for f in feats]))},
+            "parity": {"max_abs_dR_vs_pose_csv": float(dR), "max_rel_dt_vs_pose_csv": float(dt),
+                       "max_frame_reproj_error": float(max(out["errors"])), "cloud_points": int(len(out["Xtot"]))}}
+
+
 def main():
     args = parse()
     world, rank, local = init_dist(args)
@@ -314,6 +343,8 @@ def main():
                 out["cpu_baseline"] = cpu_knn_baseline(args.nq, args.nt, 0, 1)
     elif args.workload == "tri":
         out = bench_tri(args, world, rank, dev)
+    elif args.workload == "sfm":
+        out = bench_sfm(args, world, rank, dev)
     else:
         out = bench_ba(args, world, rank, dev)
     if rank == 0:

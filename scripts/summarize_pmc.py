@@ -10,7 +10,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob(os.path.join(d, "pass*_counter_collection.csv"))):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        k = k[k.find("knn_"):].split("(")[0].split("<")[0] if "knn_" in k else (k.split("(")[0][-40:])
+        k = k[k.find("knn_"):].split("(")[0] if "knn_" in k else (k.split("(")[0][-40:])   # keep template arguments
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 print(f"# {tag}: PMC counters of the KNN step (10k x 10k, config 2), mean per launch over 6 launches\n")
 print("Collected with `rocprofv3 --kernel-trace --pmc <group>` in four separate passes (scripts/collect_profiles.sh).")
@@ -26,7 +26,9 @@ for k, v in agg.items():
         print(f"| {c} | {m[c]:.4g} |")
     if "SQ_VALU_MFMA_BUSY_CYCLES" in m and m.get("SQ_INSTS_MFMA", 0) > 0:
         print(f"\nMFMA busy cycles / MFMA instruction = {m['SQ_VALU_MFMA_BUSY_CYCLES'] / m['SQ_INSTS_MFMA']:.1f} "
-              f"(64 = one v_mfma_f32_32x32x2_f32); per-SIMD busy = {m['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024:.0f} cycles")
+              f"(32 = v_mfma_f32_32x32x16_bf16, 64 = v_mfma_f32_32x32x2_f32); per-SIMD busy = "
+              f"{m['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024:.0f} cycles; matrix-pipe busy fraction of CU-busy time = "
+              f"{m['SQ_VALU_MFMA_BUSY_CYCLES'] / (4 * m['SQ_BUSY_CU_CYCLES']):.2f}")
     if "FETCH_SIZE" in m:
         print(f"\nHBM-side read traffic ~= {2 * m['FETCH_SIZE'] * 1024 / 1e6:.1f} MB (2 x FETCH_SIZE), "
               f"write ~= {m.get('WRITE_SIZE', 0) * 1024 / 1e6:.1f} MB per launch")

@@ -255,7 +255,7 @@ struct DensePlan {
 
 DensePlan dense_plan(int64_t ncam, int64_t npt) {
     DensePlan d;
-    d.pp = npt >= 256 * 1024 ? 4 : 2;
+    d.pp = npt >= 64 * 1024 ? 4 : 2;
     d.tiles = (int)((npt + 256 * d.pp - 1) / (256 * d.pp));
     int nch = d.tiles > 0 ? (1024 + d.tiles - 1) / d.tiles : 1;
     if (nch > ncam / 16) nch = (int)(ncam / 16);

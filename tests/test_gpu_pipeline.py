@@ -100,3 +100,18 @@ def test_driver_reproduces_pose_csv_on_gustav_geometry(hip):
         assert np.linalg.norm(tg - tw) < 2e-2 * max(1.0, np.linalg.norm(tw)), k
     assert out["first_error"] < 0.05 and max(out["errors"]) < 0.05
     assert len(out["Xtot"]) > 100 and np.all(out["Xtot"][0] == 0)              # quirk 8: leading zero row
+
+
+def test_full_57_camera_sequence_matches_pose_csv(hip):
+    """BASELINE config 3 at full length on Gustav geometry: all 57 cameras of the reference's pose.csv are
+    re-registered by the incremental driver (match -> E/RANSAC -> triangulate -> PnP per frame)."""
+    from sfm_mvs_amd import pipeline as pl
+    K, P, feats, ids = gustav_scene(57, seed=3)
+    out = pl.run_sfm(feats, K)
+    got = out["posearr"][9:].reshape(-1, 3, 4)
+    assert got.shape == (57, 3, 4) and out["posearr"].shape == (9 + 57 * 12,)      # = pose.csv's 693 values
+    for k in range(57):
+        Rg, tg = decompose_P(K, got[k])
+        Rw, tw = decompose_P(K, P[k])
+        assert np.abs(Rg - Rw).max() < 1e-3 and np.linalg.norm(tg - tw) < 5e-3 * max(1.0, np.linalg.norm(tw)), k
+    assert max(out["errors"]) < 0.01                      # the reference's metric ||dp||_F / N per frame
