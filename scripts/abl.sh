@@ -1,1 +1,1 @@
-for a in 0 7 39 47; do echo -n "split2 W=8 ABL=$a "; SFM_KNN_ABL=$a python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-extras | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('filter_ms', round(d['kernels_ms']['knn_filter'],4))"; done
+for a in 0 1 2 4 6 7; do echo -n "split2 ring ABL=$a "; SFM_KNN_ABL=$a python scripts/run_knn_steps.py 50 10000 10000 uniform | cut -c1-80; done

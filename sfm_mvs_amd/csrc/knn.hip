@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) void knn_prep_kernel(const float* __restrict__
         unsigned short* img = isq ? qsplit : tsplit;
         *reinterpret_cast<uint2*>(img + (int64_t)r * kDim + 4 * l) = make_uint2(hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16));
         *reinterpret_cast<uint2*>(img + ((int64_t)npad + r) * kDim + 4 * l) = make_uint2(mb[0] | (mb[1] << 16), mb[2] | (mb[3] << 16));
-        if (l == 0) (isq ? qn : tn)[r] = s;
+        if (l == 0) (isq ? qn : tn)[r] = (isq || r < n) ? s : kInf;   // padded train rows can never be candidates
         if (!isq) mx = fmaxf(mx, s);
     }
 #pragma unroll
@@ -433,13 +433,14 @@ __device__ __forceinline__ void stage_tile_split(__amdgpu_buffer_rsrc_t trs, int
                                                  int wave) {
     constexpr int PIECES = 16 / W;                       // 1 KiB pieces (4 rows x 256 B) per wave per tile
     const int p0 = wave * PIECES;
-    const int soff = tile * kTileT * 256 + (p0 >= 8 ? mid_off : 0);
+    // soffset and the LDS destination (M0) must be PROVABLY wave-uniform or hipcc wraps every DMA in a waterfall loop
+    const int soff = __builtin_amdgcn_readfirstlane(tile * kTileT * 256 + (p0 >= 8 ? mid_off : 0));
+    const unsigned dst0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)tile_buf + p0 * 1024);
     if (KMID || p0 < 8)                                  // exact mode: the mid image is all zeros and never read
 #pragma unroll
     for (int n = 0; n < PIECES; ++n) {
-        float* dst = tile_buf + (p0 + n) * 256;
         // row r = 4*((p0+n)&7) + (lane>>4) keeps source chunk pos ^ (r & 15) = (pos ^ (r0 & 15)) ^ 4n at position pos
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(trs, (lptr_t)dst, 16, (lane_off ^ (64 * n)) + 4 * n * 256, soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(trs, (lptr_t)(size_t)(dst0 + n * 1024), 16, (lane_off ^ (64 * n)) + 4 * n * 256, soff, 0, 0);
     }
     if (threadIdx.x < kTileT) {
         const int row = tile * kTileT + threadIdx.x;
@@ -604,6 +605,27 @@ __device__ __forceinline__ void key_insert4(const f32x16& a, int r0, int seq0, i
     }
 }
 
+// LDS ring of the pipelined filter: 3 tile images (16 KiB each) + 3 x 64 floats of ||t||^2.
+constexpr int kRing = 3;
+constexpr int kRingLdsBytes = kRing * kTileFloats * 4 + kRing * 256;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Wait until at most `keep` of this wave's vector-memory operations are still in flight (keep is wave-uniform).
+__device__ __forceinline__ void wait_vm_keep(int keep) {
+    switch (keep) {
+        case 0: wait_vmcnt<0>(); break;
+        case 1: wait_vmcnt<1>(); break;
+        case 2: wait_vmcnt<2>(); break;
+        case 3: wait_vmcnt<3>(); break;
+        case 4: wait_vmcnt<4>(); break;
+        default: wait_vmcnt<5>(); break;
+    }
+}
+
 template <int ABL, int W, bool KMID>
 __global__ __launch_bounds__(64 * W, 2) void knn_filter_split2_kernel(
     const unsigned short* __restrict__ qsplit, const float* __restrict__ qnorm, int nq, int nq_pad,
@@ -624,17 +646,38 @@ __global__ __launch_bounds__(64 * W, 2) void knn_filter_split2_kernel(
     const int G = gridDim.x;
     const int64_t u_end = unit_begin(units, G, blockIdx.x + 1);
     int64_t u = unit_begin(units, G, blockIdx.x);
-    float* const tnb = smem + 2 * kTileFloats;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
+    const unsigned lds_tn = lds0 + kRing * kTileFloats * 4;
     const int mid_off = nt_pad * 256;
     const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc((void*)tsplit, 0, 2 * mid_off, 0x00020000);
+    const __amdgpu_buffer_rsrc_t tnrs = __builtin_amdgcn_make_buffer_rsrc((void*)tn, 0, nt_pad * 4, 0x00020000);
     constexpr int PIECES = 16 / W;
-    const int r0 = 4 * ((wave * PIECES) & 7) + (lane >> 4);
+    const int p0 = wave * PIECES;
+    const int r0 = 4 * (p0 & 7) + (lane >> 4);
     const int lane_off = r0 * 256 + (((lane & 15) ^ (r0 & 15)) << 4);
+    const bool stage_pieces = KMID || p0 < 8;                    // exact mode never reads the (all-zero) mid image
+    const int my_vm = (stage_pieces ? PIECES : 0) + (wave == 0 ? 1 : 0);   // VMEM ops this wave issues per staged tile
     // Both instantiations are launched; the one that does not match the data exits here.  KMID = false: every input
     // is exactly a bf16 (real SIFT descriptors, integers 0..255) → one exact product instead of three.
     const bool need_mid = __any((midflag[lane] | midflag[lane + 64] | midflag[lane + 128] | midflag[lane + 192]) != 0);
     if (need_mid != KMID) return;
+
+    // Train tile `tile` → ring slot `buf`, entirely by LDS-DMA (hi/mid images 1 KiB per piece; ||t||^2 as one dword
+    // piece from wave 0: padded rows hold +inf).  No VGPR destinations, so nothing here makes hipcc wait.
+    auto stage = [&](int tile, int buf) {
+        const int soff = __builtin_amdgcn_readfirstlane(tile * kTileT * 256 + (p0 >= 8 ? mid_off : 0));
+        const unsigned dst0 = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)buf * (kTileFloats * 4) + (unsigned)p0 * 1024u);
+        if (stage_pieces)
+#pragma unroll
+            for (int n = 0; n < PIECES; ++n)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(trs, (lptr_t)(size_t)(dst0 + n * 1024), 16,
+                                                         (lane_off ^ (64 * n)) + 4 * n * 256, soff, 0, 0);
+        if (wave == 0) {
+            const unsigned dtn = __builtin_amdgcn_readfirstlane(lds_tn + (unsigned)buf * 256u);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(tnrs, (lptr_t)(size_t)dtn, 4, lane * 4,
+                                                     __builtin_amdgcn_readfirstlane(tile * kTileT * 4), 0, 0);
+        }
+    };
 
     while (u < u_end) {
         const int rb = (int)(u / tiles);
@@ -644,8 +687,9 @@ __global__ __launch_bounds__(64 * W, 2) void knn_filter_split2_kernel(
         const int qrow0 = rb * (W * 64) + wave * 64 + j;          // group g adds 32*g
         const bool qok[2] = {qrow0 < nq, qrow0 + 32 < nq};
 
-        __syncthreads();
-        stage_tile_split<W, KMID>(trs, mid_off, lane_off, tn, nt, t_begin, smem, tnb, wave);
+        __syncthreads();                                           // previous segment fully consumed, nothing in flight
+        stage(t_begin, 0);
+        if (t_begin + 1 < t_end && !(ABL & 4)) stage(t_begin + 1, 1);
 
         uint4 bh[2][8], bm[2][8];
         float qn[2];
@@ -664,48 +708,54 @@ __global__ __launch_bounds__(64 * W, 2) void knn_filter_split2_kernel(
 
         int ka[2] = {kKeyInf, kKeyInf}, kb[2] = {kKeyInf, kKeyInf}, kc[2] = {kKeyInf, kKeyInf};
         int sub = 0, sub_t0 = t_begin;
-        const int64_t ob0 = ((int64_t)qrow0 * (2 * smax * nsub) + (int64_t)slot * nsub * 2 + h) * 3;
-        const int64_t ob1 = ob0 + (int64_t)32 * (2 * smax * nsub) * 3;
-        __syncthreads();
+        auto flush = [&](int sb, int st0) {                        // candidate records of both query groups
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+                if (qok[g]) {
+                    const int64_t ob = ((int64_t)(qrow0 + 32 * g) * (2 * smax * nsub) + (int64_t)slot * nsub * 2 + h) * 3 + 6 * sb;
+                    flush_keys(ka[g], kb[g], kc[g], st0, h, cand_s + ob, cand_i + ob);
+                }
+            ka[0] = kb[0] = kc[0] = ka[1] = kb[1] = kc[1] = kKeyInf;
+        };
+        wait_vmcnt<0>();                                           // first tile(s) + query fragments landed
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
 
         f32x16 accA[2], accB[2];
-        // one tile: MFMAs of tile t into `cur`, packed-key inserts of tile t-1 from `prev` interleaved
+        // one tile: MFMAs of tile t into `cur`, packed-key inserts of tile t-1 from `prev` interleaved.
+        // Every LDS access in here is inline asm: an ordinary load would make hipcc drain the in-flight LDS-DMA.
         auto tile = [&](f32x16(&cur)[2], f32x16(&prev)[2], int t, bool have_prev) {
-            constexpr bool kMid = KMID;
             if (have_prev && (t - 1) - sub_t0 == kSubTiles) {
-                if (qok[0]) flush_keys(ka[0], kb[0], kc[0], sub_t0, h, cand_s + ob0 + 6 * sub, cand_i + ob0 + 6 * sub);
-                if (qok[1]) flush_keys(ka[1], kb[1], kc[1], sub_t0, h, cand_s + ob1 + 6 * sub, cand_i + ob1 + 6 * sub);
-                ka[0] = kb[0] = kc[0] = ka[1] = kb[1] = kc[1] = kKeyInf;
+                flush(sub, sub_t0);
+                wait_vmcnt<0>();                                   // stores are counted in vmcnt too: restart the count
                 ++sub;
                 sub_t0 = t - 1;
             }
-            const int cur_buf = (t - t_begin) & 1;
-            if (t + 1 < t_end && !(ABL & 4))
-                stage_tile_split<W, KMID>(trs, mid_off, lane_off, tn, nt, t + 1, smem + (cur_buf ^ 1) * kTileFloats,
-                                    tnb + (cur_buf ^ 1) * kTileT, wave);
-            {
-                const float* tnp = tnb + cur_buf * kTileT + 4 * h;
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const float4 v = *reinterpret_cast<const float4*>(tnp + 8 * b);
-#pragma unroll
-                    for (int g = 0; g < 2; ++g) {
-                        cur[g][4 * b + 0] = (ABL & 8) ? qn[g] : v.x + qn[g];
-                        cur[g][4 * b + 1] = (ABL & 8) ? qn[g] : v.y + qn[g];
-                        cur[g][4 * b + 2] = (ABL & 8) ? qn[g] : v.z + qn[g];
-                        cur[g][4 * b + 3] = (ABL & 8) ? qn[g] : v.w + qn[g];
-                    }
-                }
-            }
-            const unsigned abase = lds0 + (unsigned)(((ABL & 4) ? 0 : cur_buf) * kTileFloats) * 4u + (unsigned)j * 256u + ((unsigned)hm << 4);
-            const int seq0 = ((t - 1) - sub_t0) << 4;
+            const int buf = (t - t_begin) % kRing;
+            if (t + 2 < t_end && !(ABL & 4)) stage(t + 2, (buf + 2) % kRing);
+            const unsigned abase = lds0 + (unsigned)(((ABL & 4) ? 0 : buf) * kTileFloats) * 4u + (unsigned)j * 256u + ((unsigned)hm << 4);
+            const unsigned tnad = lds_tn + (unsigned)((ABL & 4) ? 0 : buf) * 256u + 16u * h;
+            f32x4 tv[4];
             u32x4 ah[2], am[2];
+            asm volatile("ds_read_b128 %0, %1" : "=v"(tv[0]) : "v"(tnad));
+            asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(tv[1]) : "v"(tnad));
+            asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(tv[2]) : "v"(tnad));
+            asm volatile("ds_read_b128 %0, %1 offset:96" : "=v"(tv[3]) : "v"(tnad));
             asm volatile("ds_read_b128 %0, %1" : "=v"(ah[0]) : "v"(abase));
             if (KMID) asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(am[0]) : "v"(abase));
+            if (KMID) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]), "+v"(tv[3]));
+            else asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]), "+v"(tv[3]));
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) cur[g][4 * b + e] = tv[b][e] + qn[g];
+            const int seq0 = ((t - 1) - sub_t0) << 4;
 #pragma unroll
             for (int st = 0; st < 8; ++st) {
-                if (ABL & 32) {
-                } else if (st + 1 < 8) {
+                if (st + 1 < 8) {
                     const unsigned ad = abase ^ (32u * (st + 1));
                     asm volatile("ds_read_b128 %0, %1" : "=v"(ah[(st + 1) & 1]) : "v"(ad));
                     if (KMID) {
@@ -725,7 +775,7 @@ __global__ __launch_bounds__(64 * W, 2) void knn_filter_split2_kernel(
                 for (int g = 0; g < 2; ++g) {
                     const bf16x8 Bh = __builtin_bit_cast(bf16x8, bh[g][st]);
                     cur[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, cur[g], 0, 0, 0);
-                    if (kMid) {
+                    if (KMID) {
                         const bf16x8 Am = __builtin_bit_cast(bf16x8, am[st & 1]), Bm = __builtin_bit_cast(bf16x8, bm[g][st]);
                         cur[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm, cur[g], 0, 0, 0);
                         cur[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, cur[g], 0, 0, 0);
@@ -734,12 +784,20 @@ __global__ __launch_bounds__(64 * W, 2) void knn_filter_split2_kernel(
                 if (have_prev && (ABL & 1)) {    // dev ablation: keep the MFMAs alive with one op per k-step
                     ka[0] = min(ka[0], __float_as_int(prev[0][2 * st]) + __float_as_int(prev[0][2 * st + 1]));
                     ka[1] = min(ka[1], __float_as_int(prev[1][2 * st]) + __float_as_int(prev[1][2 * st + 1]));
-                } else if (have_prev) {          // 2 values of each group per k-step: 16 VALU beside 6 MFMAs
+                } else if (have_prev) {          // 2 values of each group per k-step: 16 VALU beside the MFMAs
                     key_insert4<2>(prev[0], 2 * st, seq0, ka[0], kb[0], kc[0]);
                     key_insert4<2>(prev[1], 2 * st, seq0, ka[1], kb[1], kc[1]);
                 }
             }
-            if (!(ABL & 2)) __syncthreads();
+            // Tile t+1 must have landed for every wave before anyone reads it; tile t+2 (just issued) stays in flight
+            // across the barrier: counted vmcnt + raw s_barrier (a __syncthreads() would drain the DMA queue).
+            if (t + 1 < t_end && !(ABL & 2)) {
+                if (t + 2 < t_end) wait_vm_keep(my_vm);
+                else wait_vmcnt<0>();
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
         };
 
         // accA = tile being computed, accB = previous tile (its epilogue runs inside tile()); 32 v_mov per tile
@@ -754,21 +812,18 @@ __global__ __launch_bounds__(64 * W, 2) void knn_filter_split2_kernel(
         if (t_end > t_begin) {                             // epilogue of the last tile
             const int tl = t_end - 1;
             if (tl - sub_t0 == kSubTiles) {
-                if (qok[0]) flush_keys(ka[0], kb[0], kc[0], sub_t0, h, cand_s + ob0 + 6 * sub, cand_i + ob0 + 6 * sub);
-                if (qok[1]) flush_keys(ka[1], kb[1], kc[1], sub_t0, h, cand_s + ob1 + 6 * sub, cand_i + ob1 + 6 * sub);
-                ka[0] = kb[0] = kc[0] = ka[1] = kb[1] = kc[1] = kKeyInf;
+                flush(sub, sub_t0);
                 ++sub;
                 sub_t0 = tl;
             }
             key_insert4<16>(accB[0], 0, (tl - sub_t0) << 4, ka[0], kb[0], kc[0]);
             key_insert4<16>(accB[1], 0, (tl - sub_t0) << 4, ka[1], kb[1], kc[1]);
         }
-
+        flush(sub, sub_t0);
 #pragma unroll
         for (int g = 0; g < 2; ++g)
             if (qok[g]) {
-                const int64_t ob = g == 0 ? ob0 : ob1;
-                flush_keys(ka[g], kb[g], kc[g], sub_t0, h, cand_s + ob + 6 * sub, cand_i + ob + 6 * sub);
+                const int64_t ob = ((int64_t)(qrow0 + 32 * g) * (2 * smax * nsub) + (int64_t)slot * nsub * 2 + h) * 3;
                 for (int e = sub + 1; e < nsub; ++e)
 #pragma unroll
                     for (int r = 0; r < 3; ++r) {
@@ -776,6 +831,7 @@ __global__ __launch_bounds__(64 * W, 2) void knn_filter_split2_kernel(
                         cand_i[ob + 6 * e + r] = -1;
                     }
             }
+        wait_vmcnt<0>();
         u += t_end - t_begin;
     }
     if (trace && threadIdx.x == 0) trace[4 * blockIdx.x + 1] = wall_clock64();
@@ -1262,10 +1318,10 @@ extern "C" int sfm_knn2_l2_f32(const float* q, int64_t nq, int64_t ldq, const fl
                        p.smax, p.nsub, w.cand_s, w.cand_i, g_trace)
 #define SFM_LAUNCH_SPLIT2(A, WV)                                                                                        \
     do {                                                                                                                 \
-    hipLaunchKernelGGL((knn_filter_split2_kernel<A, WV, true>), grid, dim3(64 * WV), kLdsFloats * sizeof(float), stream, \
+    hipLaunchKernelGGL((knn_filter_split2_kernel<A, WV, true>), grid, dim3(64 * WV), kRingLdsBytes, stream,             \
                        w.qsplit, w.qn, (int)nq, p.nq_pad, w.tsplit, (int)nt, p.tiles * kTileT, w.tn, p.tiles, p.units,   \
                        p.smax, p.nsub, w.midflag, w.cand_s, w.cand_i, g_trace);                                          \
-    hipLaunchKernelGGL((knn_filter_split2_kernel<A, WV, false>), grid, dim3(64 * WV), kLdsFloats * sizeof(float), stream, \
+    hipLaunchKernelGGL((knn_filter_split2_kernel<A, WV, false>), grid, dim3(64 * WV), kRingLdsBytes, stream,            \
                        w.qsplit, w.qn, (int)nq, p.nq_pad, w.tsplit, (int)nt, p.tiles * kTileT, w.tn, p.tiles, p.units,   \
                        p.smax, p.nsub, w.midflag, w.cand_s, w.cand_i, g_trace);                                          \
     } while (0)
@@ -1275,8 +1331,8 @@ extern "C" int sfm_knn2_l2_f32(const float* q, int64_t nq, int64_t ldq, const fl
             } else if (p.waves == 16) {
                 if (abl == 1) SFM_LAUNCH_SPLIT2(1, 16); else if (abl == 7) SFM_LAUNCH_SPLIT2(7, 16); else SFM_LAUNCH_SPLIT2(0, 16);
             } else {
-                if (abl == 1) SFM_LAUNCH_SPLIT2(1, 8); else if (abl == 7) SFM_LAUNCH_SPLIT2(7, 8); else if (abl == 39) SFM_LAUNCH_SPLIT2(39, 8);
-                else if (abl == 47) SFM_LAUNCH_SPLIT2(47, 8); else SFM_LAUNCH_SPLIT2(0, 8);
+                if (abl == 1) SFM_LAUNCH_SPLIT2(1, 8); else if (abl == 7) SFM_LAUNCH_SPLIT2(7, 8); else if (abl == 2) SFM_LAUNCH_SPLIT2(2, 8);
+                else if (abl == 4) SFM_LAUNCH_SPLIT2(4, 8); else if (abl == 6) SFM_LAUNCH_SPLIT2(6, 8); else SFM_LAUNCH_SPLIT2(0, 8);
             }
         } else if (p.waves == 4) {
             if (abl == 1) SFM_LAUNCH_SPLIT(1, 4); else if (abl == 7) SFM_LAUNCH_SPLIT(7, 4); else SFM_LAUNCH_SPLIT(0, 4);

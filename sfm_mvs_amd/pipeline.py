@@ -17,9 +17,29 @@ from . import ops
 RATIO = 0.70          # sfm.py:264
 
 
-def find_features(feat0, feat1):
-    """Matcher half of sfm.py:242-270.  feat = (kp (n,2) float32 keypoint coordinates, des (n,128) float32).
-    Returns pts0, pts1 (M,2) float32 in ascending queryIdx order."""
+class Backend:
+    """What the helper functions run on: the cv2-named facade `cv` plus the fused device operators.  The default
+    is the HIP back-end; tests substitute a CPU twin built on the oracle to diff the whole driver."""
+
+    def __init__(self, cv=None, match=None, reproj=None):
+        self.cv = cv or cv2
+        self.match = match or _match_hip
+        self.reproj = reproj or _reproj_hip
+
+
+_default = None
+
+
+def _be(be):
+    global _default
+    if be is not None:
+        return be
+    if _default is None:
+        _default = Backend()
+    return _default
+
+
+def _match_hip(feat0, feat1):
     kp0, des0 = feat0
     kp1, des1 = feat1
     dev = torch.device("cuda")
@@ -33,8 +53,15 @@ def find_features(feat0, feat1):
     return p0[:m].cpu().numpy(), p1[:m].cpu().numpy()              # sfm.py:267-268
 
 
-def Triangulation(P1, P2, pts1, pts2, K, repeat):
+def find_features(feat0, feat1, be=None):
+    """Matcher half of sfm.py:242-270.  feat = (kp (n,2) float32 keypoint coordinates, des (n,128) float32).
+    Returns pts0, pts1 (M,2) float32 in ascending queryIdx order."""
+    return _be(be).match(feat0, feat1)
+
+
+def Triangulation(P1, P2, pts1, pts2, K, repeat, be=None):
     """sfm.py:45-56."""
+    cv2 = _be(be).cv
     if not repeat:
         points1 = np.transpose(pts1)
         points2 = np.transpose(pts2)
@@ -45,8 +72,9 @@ def Triangulation(P1, P2, pts1, pts2, K, repeat):
     return points1, points2, cloud
 
 
-def PnP(X, p, K, d, p_0, initial):
+def PnP(X, p, K, d, p_0, initial, be=None):
     """sfm.py:60-76."""
+    cv2 = _be(be).cv
     if initial == 1:
         X = X[:, 0, :]
         p = p.T
@@ -60,8 +88,18 @@ def PnP(X, p, K, d, p_0, initial):
     return R, t, p, X, p_0
 
 
-def ReprojectionError(X, pts, Rt, K, homogenity):
+def _reproj_hip(r, t, K, Xf, obs):
+    """Fused projection + squared-error sum on the device → (sumsq, projected float32 (N,2))."""
+    dev = torch.device("cuda")
+    cams = torch.as_tensor(np.hstack([r.ravel(), np.asarray(t, np.float64).ravel()])[None]).to(dev)
+    out = ops.project_residual(cams, K, torch.as_tensor(Xf).to(dev), torch.as_tensor(np.ascontiguousarray(obs)).to(dev))
+    return float(out["sumsq"].item()), out["proj"].cpu().numpy()
+
+
+def ReprojectionError(X, pts, Rt, K, homogenity, be=None):
     """sfm.py:79-100: ||float32(proj) - float32(pts)||_F / N in ONE fused sweep on the device."""
+    b = _be(be)
+    cv2 = b.cv
     R = Rt[:3, :3]
     t = Rt[:3, 3]
     r, _ = cv2.Rodrigues(R)
@@ -69,11 +107,8 @@ def ReprojectionError(X, pts, Rt, K, homogenity):
         X = cv2.convertPointsFromHomogeneous(X.T)
     Xf = np.ascontiguousarray(np.asarray(X, np.float32).reshape(-1, 3))
     obs = np.float32(pts.T if homogenity == 1 else pts)
-    dev = torch.device("cuda")
-    cams = torch.as_tensor(np.hstack([r.ravel(), np.asarray(t, np.float64).ravel()])[None]).to(dev)
-    out = ops.project_residual(cams, K, torch.as_tensor(Xf).to(dev), torch.as_tensor(np.ascontiguousarray(obs)).to(dev))
-    p = out["proj"].cpu().numpy()
-    tot_error = float(np.sqrt(out["sumsq"].item())) / len(p)       # quirk 3: Frobenius norm / N
+    sumsq, p = b.reproj(r, t, K, Xf, obs)
+    tot_error = float(np.sqrt(sumsq)) / len(p)                     # quirk 3: Frobenius norm / N
     return tot_error, X, p
 
 
@@ -109,12 +144,14 @@ def to_ply(path, point_cloud, colors, densify=False):
     return len(verts)
 
 
-def run_sfm(features, K, images=None, log=None):
+def run_sfm(features, K, images=None, log=None, be=None):
     """The reference's driver, sfm.py:274-423 (bundle_adjustment=False, its default).
     features: list of (kp (n,2) float32, des (n,128) float32) per image, in sequence order.
     images:   optional list of HxWx3 uint8 arrays for the colour lookup (sfm.py:393-394).
     Returns dict(posearr (9+12*n_cam,), Xtot (m,3), colorstot (m,3), errors [per-frame], first_error)."""
     K = np.asarray(K, np.float64)
+    be = _be(be)
+    cv2 = be.cv
     say = log or (lambda *a: None)
     posearr = K.ravel()
     R_t_0 = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0]], np.float64)
@@ -123,7 +160,7 @@ def run_sfm(features, K, images=None, log=None):
     Xtot = np.zeros((1, 3))               # quirk 8: leading zero row
     colorstot = np.zeros((1, 3))
 
-    pts0, pts1 = find_features(features[0], features[1])
+    pts0, pts1 = find_features(features[0], features[1], be)
     E, mask = cv2.findEssentialMat(pts0, pts1, K, method=cv2.RANSAC, prob=0.999, threshold=0.4, mask=None)
     pts0 = pts0[mask.ravel() == 1]        # quirk 4: {0,1} mask
     pts1 = pts1[mask.ravel() == 1]
@@ -134,17 +171,17 @@ def run_sfm(features, K, images=None, log=None):
     R_t_1[:3, 3] = R_t_0[:3, 3] + np.matmul(R_t_0[:3, :3], t.ravel())
     P2 = np.matmul(K, R_t_1)
 
-    pts0, pts1, points_3d = Triangulation(P1, P2, pts0, pts1, K, repeat=False)
-    first_error, points_3d, _ = ReprojectionError(points_3d, pts1, R_t_1, K, homogenity=1)
+    pts0, pts1, points_3d = Triangulation(P1, P2, pts0, pts1, K, repeat=False, be=be)
+    first_error, points_3d, _ = ReprojectionError(points_3d, pts1, R_t_1, K, homogenity=1, be=be)
     say("REPROJECTION ERROR: ", first_error)
-    Rot, trans, pts1, points_3d, pts0t = PnP(points_3d, pts1, K, np.zeros((5, 1), dtype=np.float32), pts0, initial=1)
+    Rot, trans, pts1, points_3d, pts0t = PnP(points_3d, pts1, K, np.zeros((5, 1), dtype=np.float32), pts0, initial=1, be=be)
     posearr = np.hstack((posearr, P1.ravel(), P2.ravel()))
 
     errors = []
     for i in range(len(features) - 2):
-        pts_, pts2 = find_features(features[i + 1], features[i + 2])
+        pts_, pts2 = find_features(features[i + 1], features[i + 2], be)
         if i != 0:
-            pts0, pts1, points_3d = Triangulation(P1, P2, pts0, pts1, K, repeat=False)   # quirk 6: all ratio matches
+            pts0, pts1, points_3d = Triangulation(P1, P2, pts0, pts1, K, repeat=False, be=be)   # quirk 6: all ratio matches
             pts1 = pts1.T
             points_3d = cv2.convertPointsFromHomogeneous(points_3d.T)[:, 0, :]
         indx1, indx2, temp1, temp2 = common_points(pts1, pts_, pts2)
@@ -153,12 +190,12 @@ def run_sfm(features, K, images=None, log=None):
         com_pts0 = pts0.T[indx1]          # quirk 5: unused, mis-indexed at i == 0 in the reference too
         del com_pts0
         Rot, trans, com_pts2, points_3d, com_pts_ = PnP(points_3d[indx1], com_pts2, K,
-                                                        np.zeros((5, 1), dtype=np.float32), com_pts_, initial=0)
+                                                        np.zeros((5, 1), dtype=np.float32), com_pts_, initial=0, be=be)
         Rtnew = np.hstack((Rot, trans))
         Pnew = np.matmul(K, Rtnew)
-        error, points_3d, _ = ReprojectionError(points_3d, com_pts2, Rtnew, K, homogenity=0)
-        temp1, temp2, points_3d = Triangulation(P2, Pnew, temp1, temp2, K, repeat=False)
-        error, points_3d, _ = ReprojectionError(points_3d, temp2, Rtnew, K, homogenity=1)
+        error, points_3d, _ = ReprojectionError(points_3d, com_pts2, Rtnew, K, homogenity=0, be=be)
+        temp1, temp2, points_3d = Triangulation(P2, Pnew, temp1, temp2, K, repeat=False, be=be)
+        error, points_3d, _ = ReprojectionError(points_3d, temp2, Rtnew, K, homogenity=1, be=be)
         say("Reprojection Error: ", error)
         errors.append(error)
         posearr = np.hstack((posearr, Pnew.ravel()))

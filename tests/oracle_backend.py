@@ -28,3 +28,51 @@ class OracleBackend:
         if want_jac:
             return out["JtJ_cam"][0].reshape(6, 6), out["Jtr_cam"][0], err
         return None, None, err
+
+
+class OracleCv2:
+    """cv2-named facade over the CPU oracle (the CPU twin of sfm_mvs_amd.cv2compat) — tests only."""
+    RANSAC, NORM_L2, SOLVEPNP_ITERATIVE = 8, 4, 0
+
+    def __init__(self, oracle, rows=4):
+        from sfm_mvs_amd import hostgeom, ransac
+        self.O, self.hg, self.ransac, self.rows = oracle, hostgeom, ransac, rows
+        self.be = OracleBackend(oracle, rows)
+
+    def triangulatePoints(self, P1, P2, a, b):
+        return self.O.triangulate(P1, P2, np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32), rows=self.rows)
+
+    def Rodrigues(self, src):
+        src = np.asarray(src, np.float64)
+        if src.size == 9:
+            return self.hg.rodrigues_mat2vec(src.reshape(3, 3)).reshape(3, 1), None
+        return self.hg.rodrigues_vec2mat(src.reshape(3)), None
+
+    def convertPointsFromHomogeneous(self, src):
+        from sfm_mvs_amd import cv2compat
+        return cv2compat.convertPointsFromHomogeneous(src)
+
+    def findEssentialMat(self, p1, p2, K, method=8, prob=0.999, threshold=1.0, mask=None):
+        return self.ransac.find_essential_mat(p1, p2, np.asarray(K, np.float64), prob, threshold, backend=self.be)
+
+    def recoverPose(self, E, p1, p2, K):
+        return self.ransac.recover_pose(E, p1, p2, np.asarray(K, np.float64), backend=self.be)
+
+    def solvePnPRansac(self, X, p, K, d, *a, **k):
+        return self.ransac.solve_pnp_ransac(X, p, K, backend=self.be)
+
+
+def oracle_pipeline_backend(oracle):
+    """sfm_mvs_amd.pipeline.Backend whose every numeric operator is the CPU oracle."""
+    from sfm_mvs_amd.pipeline import Backend
+
+    def match(feat0, feat1):
+        idx, dist = oracle.knn2(feat0[1], feat1[1], nthreads=8)
+        q, t, _ = oracle.ratio_filter(idx, dist, 0.70)
+        return np.float32(feat0[0])[q], np.float32(feat1[0])[t]
+
+    def reproj(r, t, K, Xf, obs):
+        out = oracle.project_residual(np.hstack([np.ravel(r), np.ravel(t)])[None], K, Xf, obs, want_jac=False)
+        return float(out["sumsq"][0]), out["proj"]
+
+    return Backend(cv=OracleCv2(oracle), match=match, reproj=reproj)

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from datagen import decompose_P, gustav_pair, gustav_scene, planted_pair
-from oracle_backend import OracleBackend
+from oracle_backend import OracleBackend, oracle_pipeline_backend
 
 pytestmark = pytest.mark.gpu
 
@@ -115,3 +115,18 @@ def test_full_57_camera_sequence_matches_pose_csv(hip):
         Rw, tw = decompose_P(K, P[k])
         assert np.abs(Rg - Rw).max() < 1e-3 and np.linalg.norm(tg - tw) < 5e-3 * max(1.0, np.linalg.norm(tw)), k
     assert max(out["errors"]) < 0.01                      # the reference's metric ||dp||_F / N per frame
+
+
+def test_driver_parity_hip_vs_cpu_oracle_twin(hip, oracle):
+    """The whole incremental driver twice on the same 12-frame sequence: once on the HIP back-end, once with every
+    numeric operator replaced by the CPU oracle.  north_star bar: reprojection errors and point cloud within 1e-4
+    relative, integer decisions (match lists, RANSAC masks → array shapes) identical."""
+    from sfm_mvs_amd import pipeline as pl
+    K, P, feats, ids = gustav_scene(12, seed=7, pix_noise=0.2)
+    got = pl.run_sfm(feats, K)
+    want = pl.run_sfm(feats, K, be=oracle_pipeline_backend(oracle))
+    assert got["posearr"].shape == want["posearr"].shape and got["Xtot"].shape == want["Xtot"].shape
+    assert np.allclose(got["posearr"], want["posearr"], rtol=1e-6, atol=1e-9)
+    assert np.allclose(got["Xtot"], want["Xtot"], rtol=1e-4, atol=1e-6)
+    assert got["first_error"] == pytest.approx(want["first_error"], rel=1e-4)
+    assert np.allclose(got["errors"], want["errors"], rtol=1e-4, atol=0)
