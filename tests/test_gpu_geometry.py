@@ -133,3 +133,25 @@ def test_ransac_scoring_masks_bit_exact(hip, oracle):
     gc, gm = hip.score_essential(cu(Es), cu(x1), cu(x2), thr2, want_mask=True)
     assert np.array_equal(gc.cpu().numpy(), wc) and np.array_equal(gm.cpu().numpy(), wm)
     assert wc[0] > wc[-1]
+
+
+def test_empty_and_degenerate_inputs(hip, oracle):
+    """Edge cases the reference can hit: no correspondences, a single one, points behind the camera."""
+    K, P1, P2, X, x1, x2 = gustav_pair(1, 4, 0.0, seed=1)
+    e = torch.empty((2, 0), dtype=torch.float32, device="cuda")
+    assert hip.triangulate(P1, P2, e, e).shape == (4, 0)
+    one = hip.triangulate(P1, P2, cu(x1[:1]).t(), cu(x2[:1]).t(), normalise_w=True).cpu().numpy()
+    assert np.allclose(one, oracle.triangulate(P1, P2, x1[:1].T, x2[:1].T, normalise_w=True), rtol=1e-6)
+    R, t = decompose_P(K, P2)
+    cams = cu(np.hstack([oracle.rodrigues_mat2vec(R), t])[None])
+    out = hip.project_residual(cams, K, torch.empty((0, 3), dtype=torch.float32, device="cuda"),
+                               torch.empty((0, 2), dtype=torch.float32, device="cuda"))
+    assert out["sumsq"].item() == 0.0 and out["proj"].shape == (0, 2)
+    # a point exactly in the camera plane (Z' = 0): OpenCV's `z ? 1/z : 1` branch, same on both sides
+    Xw = np.float32(R.T @ (np.array([0.3, -0.2, 0.0]) - t))[None]
+    pz = hip.project_residual(cams, K, cu(Xw), cu(np.zeros((1, 2), np.float32)))["proj"].cpu().numpy()
+    _, wz = oracle.project_points(oracle.rodrigues_mat2vec(R), t, K, Xw)
+    assert np.all(np.isfinite(pz)) and np.allclose(pz, wz, rtol=1e-3, atol=0.5)
+    counts = hip.score_pnp(cams, K, torch.empty((0, 3), dtype=torch.float32, device="cuda"),
+                           torch.empty((0, 2), dtype=torch.float32, device="cuda"))
+    assert counts.cpu().tolist() == [0]

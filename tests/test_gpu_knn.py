@@ -119,6 +119,10 @@ def test_single_train_row_and_empty_query(hip, oracle):
     assert gi.tolist() == [[0, -1]] * 40 and np.all(np.isinf(gd[:, 1])) and np.all(gd[:, 0] == np.float32(np.sqrt(128.0)))
     gi, gd = run(hip, np.zeros((0, 128), np.float32), t)
     assert gi.shape == (0, 2)
+    gi, gd = run(hip, q, np.zeros((0, 128), np.float32))          # no train rows: OpenCV emits no DMatch
+    assert np.all(gi == -1) and np.all(np.isinf(gd))
+    _, _, cnt = hip.ratio_compact(torch.from_numpy(gi).cuda(), torch.from_numpy(gd).cuda(), 0.70)
+    assert int(cnt.item()) == 0
 
 
 def test_strided_rows(hip, oracle):
