@@ -118,8 +118,9 @@ constexpr int kNormBlocks = 256;
 
 __global__ __launch_bounds__(256) void knn_norms_kernel(const float* __restrict__ T, int64_t ldt, int nt,
                                                         float* __restrict__ tn, float* __restrict__ bmax,
-                                                        int* __restrict__ flag_count) {
+                                                        int* __restrict__ flag_count, int* __restrict__ tickets, int nq) {
     __shared__ float wmax[4];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nq; i += gridDim.x * 256) tickets[i] = 0;   // fallback tickets
     const int l = threadIdx.x & 31;
     float mx = 0.f;
     for (int row = blockIdx.x * 8 + (threadIdx.x >> 5); row < nt; row += gridDim.x * 8) {
@@ -373,19 +374,20 @@ __device__ __forceinline__ unsigned bf16_rn_bits(float x) {
 
 // One pass over Q and T: split rows into (hi, mid) bf16 images (Q pre-scaled by -2, exact), fp32 squared norms,
 // per-block max of ||t||^2, zero the fallback counter.  Rows >= n of the padded images are zero-filled.
-__global__ __launch_bounds__(256) void knn_prep_kernel(const float* __restrict__ Q, int64_t ldq, int nq, int nq_pad,
+__global__ __launch_bounds__(1024) void knn_prep_kernel(const float* __restrict__ Q, int64_t ldq, int nq, int nq_pad,
                                                        const float* __restrict__ T, int64_t ldt, int nt, int nt_pad,
                                                        unsigned short* __restrict__ qsplit, float* __restrict__ qn,
                                                        unsigned short* __restrict__ tsplit, float* __restrict__ tn,
                                                        float* __restrict__ bmax, int* __restrict__ midflag,
-                                                       int* __restrict__ flag_count) {
-    __shared__ float wmax[4];
-    __shared__ int wmid[4];
+                                                       int* __restrict__ flag_count, int* __restrict__ tickets) {
+    __shared__ float wmax[16];
+    __shared__ int wmid[16];
     const int l = threadIdx.x & 31;
     float mx = 0.f;
     unsigned anymid = 0;
     const int rows = nq_pad + nt_pad;
-    for (int row = blockIdx.x * 8 + (threadIdx.x >> 5); row < rows; row += gridDim.x * 8) {
+    for (int i = blockIdx.x * 1024 + threadIdx.x; i < nq; i += gridDim.x * 1024) tickets[i] = 0;   // fallback tickets
+    for (int row = blockIdx.x * 32 + (threadIdx.x >> 5); row < rows; row += gridDim.x * 32) {   // 32 rows in flight per block
         const bool isq = row < nq_pad;
         const int r = isq ? row : row - nq_pad;
         const int n = isq ? nq : nt, npad = isq ? nq_pad : nt_pad;
@@ -418,10 +420,16 @@ __global__ __launch_bounds__(256) void knn_prep_kernel(const float* __restrict__
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        bmax[blockIdx.x] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+        float bm = wmax[0];
+        int fl = wmid[0];
+        for (int w = 1; w < 16; ++w) {
+            bm = fmaxf(bm, wmax[w]);
+            fl |= wmid[w];
+        }
+        bmax[blockIdx.x] = bm;
         // 0 for this block's rows when every value is exactly a bf16 (e.g. SIFT's integers 0..255): the filter
         // then needs the hi.hi product only and its dot products are EXACT.
-        midflag[blockIdx.x] = wmid[0] | wmid[1] | wmid[2] | wmid[3];
+        midflag[blockIdx.x] = fl;
         if (blockIdx.x == 0) *flag_count = 0;
     }
 }
@@ -627,17 +635,10 @@ __device__ __forceinline__ void wait_vm_keep(int keep) {
 }
 
 template <int ABL, int W, bool KMID>
-__global__ __launch_bounds__(64 * W, 2) void knn_filter_split2_kernel(
-    const unsigned short* __restrict__ qsplit, const float* __restrict__ qnorm, int nq, int nq_pad,
-    const unsigned short* __restrict__ tsplit, int nt, int nt_pad, const float* __restrict__ tn, int tiles, int64_t units,
-    int smax, int nsub, const int* __restrict__ midflag, float* __restrict__ cand_s, int* __restrict__ cand_i,
-    long long* __restrict__ trace) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    if (trace && threadIdx.x == 0) {
-        trace[4 * blockIdx.x + 0] = wall_clock64();
-        trace[4 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg(0xF804);
-        trace[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg(0xF814);
-    }
+__device__ __forceinline__ void filter_split2_body(
+    float* smem, const unsigned short* __restrict__ qsplit, const float* __restrict__ qnorm, int nq, int nq_pad,
+    const unsigned short* __restrict__ tsplit, int nt_pad, const float* __restrict__ tn, int tiles, int64_t units,
+    int smax, int nsub, float* __restrict__ cand_s, int* __restrict__ cand_i) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31;
@@ -657,10 +658,6 @@ __global__ __launch_bounds__(64 * W, 2) void knn_filter_split2_kernel(
     const int lane_off = r0 * 256 + (((lane & 15) ^ (r0 & 15)) << 4);
     const bool stage_pieces = KMID || p0 < 8;                    // exact mode never reads the (all-zero) mid image
     const int my_vm = (stage_pieces ? PIECES : 0) + (wave == 0 ? 1 : 0);   // VMEM ops this wave issues per staged tile
-    // Both instantiations are launched; the one that does not match the data exits here.  KMID = false: every input
-    // is exactly a bf16 (real SIFT descriptors, integers 0..255) → one exact product instead of three.
-    const bool need_mid = __any((midflag[lane] | midflag[lane + 64] | midflag[lane + 128] | midflag[lane + 192]) != 0);
-    if (need_mid != KMID) return;
 
     // Train tile `tile` → ring slot `buf`, entirely by LDS-DMA (hi/mid images 1 KiB per piece; ||t||^2 as one dword
     // piece from wave 0: padded rows hold +inf).  No VGPR destinations, so nothing here makes hipcc wait.
@@ -834,6 +831,29 @@ __global__ __launch_bounds__(64 * W, 2) void knn_filter_split2_kernel(
         wait_vmcnt<0>();
         u += t_end - t_begin;
     }
+}
+
+// One launch, two bodies: KMID = false when every input is exactly a bf16 (real SIFT descriptors are integers 0..255;
+// knn_prep_kernel reports it) → one exact product instead of three and no mid-image traffic.  The branch is taken once
+// per workgroup, so only the chosen body's instructions are ever fetched.
+template <int ABL, int W>
+__global__ __launch_bounds__(64 * W, 2) void knn_filter_split2_kernel(
+    const unsigned short* __restrict__ qsplit, const float* __restrict__ qnorm, int nq, int nq_pad,
+    const unsigned short* __restrict__ tsplit, int nt, int nt_pad, const float* __restrict__ tn, int tiles, int64_t units,
+    int smax, int nsub, const int* __restrict__ midflag, float* __restrict__ cand_s, int* __restrict__ cand_i,
+    long long* __restrict__ trace) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (trace && threadIdx.x == 0) {
+        trace[4 * blockIdx.x + 0] = wall_clock64();
+        trace[4 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg(0xF804);
+        trace[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg(0xF814);
+    }
+    const int lane = threadIdx.x & 63;
+    const bool need_mid = __any((midflag[lane] | midflag[lane + 64] | midflag[lane + 128] | midflag[lane + 192]) != 0);
+    if (need_mid)
+        filter_split2_body<ABL, W, true>(smem, qsplit, qnorm, nq, nq_pad, tsplit, nt_pad, tn, tiles, units, smax, nsub, cand_s, cand_i);
+    else
+        filter_split2_body<ABL, W, false>(smem, qsplit, qnorm, nq, nq_pad, tsplit, nt_pad, tn, tiles, units, smax, nsub, cand_s, cand_i);
     if (trace && threadIdx.x == 0) trace[4 * blockIdx.x + 1] = wall_clock64();
 }
 
@@ -1041,14 +1061,24 @@ struct Best2Rec {
 };
 
 constexpr int kFbScanBlocks = 512;
-constexpr int kFbMergeBlocks = 32;
 
-__global__ __launch_bounds__(256) void knn_fallback_scan_kernel(
+// One launch: every (flagged query, train chunk) item writes its partial top-2, publishes it with an agent-scope
+// release and takes a ticket; the workgroup that draws the LAST ticket of a query acquires and merges that query's
+// partials (cdna guide G16: release -> relaxed atomic -> acquire, placement independent).  Tickets are zeroed by the
+// prep / norms kernel of the same call.
+__global__ __launch_bounds__(256) void knn_fallback_kernel(
     const float* __restrict__ Q, int64_t ldq, const float* __restrict__ T, int64_t ldt, int nt, int nch, int chunk,
-    const int* __restrict__ flag_count, const int* __restrict__ flag_list, Best2Rec* __restrict__ partial) {
+    const int* __restrict__ flag_count, const int* __restrict__ flag_list, Best2Rec* __restrict__ partial,
+    int* __restrict__ tickets, int* __restrict__ idx_out, float* __restrict__ dist_out, int* __restrict__ stats, int G,
+    int NS) {
     __shared__ __attribute__((aligned(16))) float qrow[kDim];
     __shared__ Best2 wbest[4];
-    const int64_t items = (int64_t)(*flag_count) * nch;
+    __shared__ int last_s;
+    const int nflag = *flag_count;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && stats) {
+        stats[0] = nflag; stats[1] = G; stats[2] = NS; stats[3] = nch;
+    }
+    const int64_t items = (int64_t)nflag * nch;
     for (int64_t it = blockIdx.x; it < items; it += gridDim.x) {
         const int f = (int)(it / nch), ch = (int)(it - (int64_t)f * nch);
         const int q = flag_list[f];
@@ -1075,34 +1105,28 @@ __global__ __launch_bounds__(256) void knn_fallback_scan_kernel(
             }
             Best2Rec o{r.d[0], r.dsq[0], r.d[1], r.dsq[1], r.i[0], r.i[1]};
             partial[it] = o;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int ticket = __hip_atomic_fetch_add(&tickets[f], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last_s = (ticket == nch - 1) ? 1 : 0;
+            if (last_s) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
-    }
-}
-
-__global__ __launch_bounds__(64) void knn_fallback_merge_kernel(const Best2Rec* __restrict__ partial, int nch,
-                                                                const int* __restrict__ flag_count,
-                                                                const int* __restrict__ flag_list, int* __restrict__ idx_out,
-                                                                float* __restrict__ dist_out, int* __restrict__ stats, int S,
-                                                                int NS) {
-    const int nflag = *flag_count;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && stats) {
-        stats[0] = nflag; stats[1] = S; stats[2] = NS; stats[3] = nch;
-    }
-    for (int f = blockIdx.x; f < nflag; f += gridDim.x) {
-        Best2 b;
-        b.d[0] = b.d[1] = kInf; b.dsq[0] = b.dsq[1] = kInf; b.i[0] = b.i[1] = INT_MAX;
-        for (int c = threadIdx.x; c < nch; c += 64) {
-            const Best2Rec r = partial[(int64_t)f * nch + c];
-            best2_insert(b, r.d0, r.q0, r.i0);
-            best2_insert(b, r.d1, r.q1, r.i1);
-        }
-        best2_wave_reduce(b);
-        if (threadIdx.x == 0) {
-            const int q = flag_list[f];
-            idx_out[2 * q + 0] = b.i[0] == INT_MAX ? -1 : b.i[0];
-            idx_out[2 * q + 1] = b.i[1] == INT_MAX ? -1 : b.i[1];
-            dist_out[2 * q + 0] = b.d[0];
-            dist_out[2 * q + 1] = b.d[1];
+        __syncthreads();
+        if (last_s && threadIdx.x < 64) {          // one wave merges this query's nch partials
+            Best2 m;
+            m.d[0] = m.d[1] = kInf; m.dsq[0] = m.dsq[1] = kInf; m.i[0] = m.i[1] = INT_MAX;
+            for (int c = threadIdx.x; c < nch; c += 64) {
+                const Best2Rec r = partial[(int64_t)f * nch + c];
+                best2_insert(m, r.d0, r.q0, r.i0);
+                best2_insert(m, r.d1, r.q1, r.i1);
+            }
+            best2_wave_reduce(m);
+            if (threadIdx.x == 0) {
+                idx_out[2 * q + 0] = m.i[0] == INT_MAX ? -1 : m.i[0];
+                idx_out[2 * q + 1] = m.i[1] == INT_MAX ? -1 : m.i[1];
+                dist_out[2 * q + 0] = m.d[0];
+                dist_out[2 * q + 1] = m.d[1];
+            }
         }
     }
 }
@@ -1236,6 +1260,7 @@ struct KnnWs {
     Best2Rec* fb_partial;
     int* flag_count;
     int* flag_list;
+    int* tickets;
     float* cand_s;
     int* cand_i;
     size_t bytes;
@@ -1253,6 +1278,7 @@ KnnWs carve_ws(void* ws, int64_t nq, int64_t nt, const Plan& p) {
     w.qsplit = c.take<unsigned short>((size_t)p.nq_pad * kDim * 2);
     w.tsplit = c.take<unsigned short>((size_t)p.tiles * kTileT * kDim * 2);
     w.flag_list = c.take<int>((size_t)nq);
+    w.tickets = c.take<int>((size_t)nq);
     w.cand_s = c.take<float>((size_t)nq * 2 * p.smax * p.nsub * 3);
     w.cand_i = c.take<int>((size_t)nq * 2 * p.smax * p.nsub * 3);
     w.bytes = c.used();
@@ -1308,8 +1334,8 @@ extern "C" int sfm_knn2_l2_f32(const float* q, int64_t nq, int64_t ldq, const fl
     const dim3 grid((unsigned)p.G);
     static const int abl = [] { const char* e = getenv("SFM_KNN_ABL"); return e ? atoi(e) : 0; }();   // dev only
     if (p.split) {
-        hipLaunchKernelGGL(knn_prep_kernel, dim3(kNormBlocks), dim3(256), 0, stream, q, ldq, (int)nq, p.nq_pad, t, ldt, (int)nt,
-                           p.tiles * kTileT, w.qsplit, w.qn, w.tsplit, w.tn, w.bmax, w.midflag, w.flag_count);
+        hipLaunchKernelGGL(knn_prep_kernel, dim3(kNormBlocks), dim3(1024), 0, stream, q, ldq, (int)nq, p.nq_pad, t, ldt, (int)nt,
+                           p.tiles * kTileT, w.qsplit, w.qn, w.tsplit, w.tn, w.bmax, w.midflag, w.flag_count, w.tickets);
         SFM_CHECK_LAUNCH();
         sfm::prof_begin(sfm::kProfKnnFilter, stream);
 #define SFM_LAUNCH_SPLIT(A, WV)                                                                                        \
@@ -1317,14 +1343,9 @@ extern "C" int sfm_knn2_l2_f32(const float* q, int64_t nq, int64_t ldq, const fl
                        w.qsplit, w.qn, (int)nq, p.nq_pad, w.tsplit, (int)nt, p.tiles * kTileT, w.tn, p.tiles, p.units,  \
                        p.smax, p.nsub, w.cand_s, w.cand_i, g_trace)
 #define SFM_LAUNCH_SPLIT2(A, WV)                                                                                        \
-    do {                                                                                                                 \
-    hipLaunchKernelGGL((knn_filter_split2_kernel<A, WV, true>), grid, dim3(64 * WV), kRingLdsBytes, stream,             \
-                       w.qsplit, w.qn, (int)nq, p.nq_pad, w.tsplit, (int)nt, p.tiles * kTileT, w.tn, p.tiles, p.units,   \
-                       p.smax, p.nsub, w.midflag, w.cand_s, w.cand_i, g_trace);                                          \
-    hipLaunchKernelGGL((knn_filter_split2_kernel<A, WV, false>), grid, dim3(64 * WV), kRingLdsBytes, stream,            \
-                       w.qsplit, w.qn, (int)nq, p.nq_pad, w.tsplit, (int)nt, p.tiles * kTileT, w.tn, p.tiles, p.units,   \
-                       p.smax, p.nsub, w.midflag, w.cand_s, w.cand_i, g_trace);                                          \
-    } while (0)
+    hipLaunchKernelGGL((knn_filter_split2_kernel<A, WV>), grid, dim3(64 * WV), kRingLdsBytes, stream, w.qsplit, w.qn,    \
+                       (int)nq, p.nq_pad, w.tsplit, (int)nt, p.tiles * kTileT, w.tn, p.tiles, p.units, p.smax, p.nsub,    \
+                       w.midflag, w.cand_s, w.cand_i, g_trace)
         if (p.qg == 2) {
             if (p.waves == 4) {
                 if (abl == 1) SFM_LAUNCH_SPLIT2(1, 4); else if (abl == 7) SFM_LAUNCH_SPLIT2(7, 4); else SFM_LAUNCH_SPLIT2(0, 4);
@@ -1346,7 +1367,7 @@ extern "C" int sfm_knn2_l2_f32(const float* q, int64_t nq, int64_t ldq, const fl
 #undef SFM_LAUNCH_SPLIT2
     } else {
     hipLaunchKernelGGL(knn_norms_kernel, dim3(kNormBlocks), dim3(256), 0, stream, t, ldt, (int)nt, w.tn, w.bmax,
-                       w.flag_count);
+                       w.flag_count, w.tickets, (int)nq);
     SFM_CHECK_LAUNCH();
     sfm::prof_begin(sfm::kProfKnnFilter, stream);
 #define SFM_LAUNCH_FILTER(A, WV)                                                                                     \
@@ -1382,11 +1403,9 @@ extern "C" int sfm_knn2_l2_f32(const float* q, int64_t nq, int64_t ldq, const fl
                        w.flag_count,
                        w.flag_list);
     SFM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(knn_fallback_scan_kernel, dim3(kFbScanBlocks), dim3(256), 0, stream, q, ldq, t, ldt, (int)nt, p.fb_nch,
-                       p.fb_chunk, w.flag_count, w.flag_list, w.fb_partial);
-    SFM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(knn_fallback_merge_kernel, dim3(kFbMergeBlocks), dim3(64), 0, stream, w.fb_partial, p.fb_nch,
-                       w.flag_count, w.flag_list, idx, dist, stats, p.G, 2 * p.smax * p.nsub);
+    hipLaunchKernelGGL(knn_fallback_kernel, dim3(kFbScanBlocks), dim3(256), 0, stream, q, ldq, t, ldt, (int)nt, p.fb_nch,
+                       p.fb_chunk, w.flag_count, w.flag_list, w.fb_partial, w.tickets, idx, dist, stats, p.G,
+                       2 * p.smax * p.nsub);
     sfm::prof_end(sfm::kProfKnnRefine, stream);
     SFM_CHECK_LAUNCH();
     return SFM_OK;
