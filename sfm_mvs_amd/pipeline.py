@@ -112,6 +112,41 @@ def ReprojectionError(X, pts, Rt, K, homogenity, be=None):
     return tot_error, X, p
 
 
+def OptimReprojectionError(x, be=None):
+    """sfm.py:104-136: residual vector of the reference's bundle adjustment.  x = [Rt 12 | K 9 | p 2N | X 3N], the 2-D
+    block is found with the reference's `int(rest * 0.4)` split, the residual is (p - proj)^2 / N flattened (2N,).
+    The projection runs on the device; the print() of sfm.py:132 is dropped."""
+    b = _be(be)
+    cv2 = b.cv
+    x = np.asarray(x, np.float64)
+    Rt = x[0:12].reshape((3, 4))
+    K = x[12:21].reshape((3, 3))
+    rest = int(len(x[21:]) * 0.4)
+    p = x[21:21 + rest].reshape((2, int(rest / 2))).T
+    X = x[21 + rest:].reshape((int(len(x[21 + rest:]) / 3), 3))
+    r, _ = cv2.Rodrigues(Rt[:3, :3])
+    _, p2d = b.reproj(r, Rt[:3, 3], K, np.ascontiguousarray(X, np.float32), np.ascontiguousarray(p, np.float32))
+    num_pts = len(p)
+    return (((p - p2d.astype(np.float64)) ** 2).ravel()) / num_pts
+
+
+def BundleAdjustment(points_3d, temp2, Rtnew, K, r_error, be=None):
+    """sfm.py:138-157 (disabled by default in the reference, sfm.py:33): SciPy's trust-region least squares with its
+    default 2-point finite-difference Jacobian over [Rt | K | 2-D points | 3-D points], residuals from the device.
+    Returns X (N,3), p (N,2), Rt (3,4) exactly as the reference unpacks them."""
+    from scipy.optimize import least_squares
+    opt_variables = np.hstack((np.asarray(Rtnew, np.float64).ravel(), np.asarray(K, np.float64).ravel()))
+    opt_variables = np.hstack((opt_variables, np.asarray(temp2, np.float64).ravel()))
+    opt_variables = np.hstack((opt_variables, np.asarray(points_3d, np.float64).ravel()))
+    res = least_squares(fun=lambda v: OptimReprojectionError(v, be), x0=opt_variables, gtol=r_error)
+    cv = res.x
+    Rt = cv[0:12].reshape((3, 4))
+    rest = int(len(cv[21:]) * 0.4)
+    p = cv[21:21 + rest].reshape((2, int(rest / 2))).T
+    X = cv[21 + rest:].reshape((int(len(cv[21 + rest:]) / 3), 3))
+    return X, p, Rt
+
+
 def common_points(pts1, pts2, pts3):
     """sfm.py:215-239.  quirk 2: a row of pts2 "equals" pts1[i] when x OR y is bit-equal; first hit wins;
     duplicates in indx2 allowed; the complement is mask-and-compress of pts2 / pts3."""

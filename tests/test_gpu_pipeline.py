@@ -130,3 +130,21 @@ def test_driver_parity_hip_vs_cpu_oracle_twin(hip, oracle):
     assert np.allclose(got["Xtot"], want["Xtot"], rtol=1e-4, atol=1e-6)
     assert got["first_error"] == pytest.approx(want["first_error"], rel=1e-4)
     assert np.allclose(got["errors"], want["errors"], rtol=1e-4, atol=0)
+
+
+def test_bundle_adjustment_mirror(hip, oracle):
+    """sfm.py:104-157 (off by default in the reference): the residual vector matches the CPU twin and SciPy's TRF on it
+    does not increase the cost.  Small N: every Jacobian costs 5N+22 residual evaluations, as in the reference."""
+    from sfm_mvs_amd import pipeline as pl
+    K, P1, P2, X, x1, x2 = gustav_pair(2, 12, 0.5, seed=4)
+    R, t = decompose_P(K, P2)
+    Rt = np.hstack([R, t[:, None]])
+    Xn = X + np.random.default_rng(0).normal(0, 0.01, X.shape)
+    x0 = np.hstack([Rt.ravel(), K.ravel(), x2.T.astype(np.float64).ravel(), Xn.ravel()])
+    r_hip = pl.OptimReprojectionError(x0)
+    r_cpu = pl.OptimReprojectionError(x0, be=oracle_pipeline_backend(oracle))
+    assert r_hip.shape == (24,) and np.allclose(r_hip, r_cpu, rtol=1e-4, atol=1e-9)
+    Xo, po, Rto = pl.BundleAdjustment(Xn, x2.T, Rt, K, 0.5)
+    assert Xo.shape == (12, 3) and po.shape == (12, 2) and Rto.shape == (3, 4)
+    x1v = np.hstack([Rto.ravel(), K.ravel(), po.T.ravel(), Xo.ravel()])
+    assert pl.OptimReprojectionError(x1v).sum() <= r_hip.sum() * 1.0001
