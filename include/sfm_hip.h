@@ -99,6 +99,21 @@ int sfm_gather_matches(const float* kp0_dev, const float* kp1_dev,
                        float* pts0_dev, float* pts1_dev, void* stream);
 
 /* ------------------------------------------------------------------------
+ * A9  common_points(pts1, pts2, pts3)                       sfm.py:215-239
+ *
+ * For every row i of pts1 ([n1 x 2] float32) the FIRST row of pts2 ([n2 x 2])
+ * whose x OR y is bit-equal (the reference's broadcast `pts2 == pts1[i,:]`,
+ * SURVEY 3.6-2).  Matches are written in ascending i:
+ *   idx1_dev, idx2_dev [n1] int32   (indx1, indx2), first *count_dev entries valid
+ *   keep2_dev [n2] uint8            0 for rows of pts2 (and pts3) named in indx2 —
+ *                                   the complement the reference mask-compresses
+ *   first_ws_dev [n1] int32         scratch
+ * ---------------------------------------------------------------------- */
+int sfm_common_points(const float* pts1_dev, int64_t n1, const float* pts2_dev, int64_t n2,
+                      int32_t* first_ws_dev, int32_t* idx1_dev, int32_t* idx2_dev,
+                      int32_t* count_dev, uint8_t* keep2_dev, void* stream);
+
+/* ------------------------------------------------------------------------
  * A4  cv2.triangulatePoints(P1, P2, points1, points2)    sfm.py:53
  *     + `cloud = cloud / cloud[3]`                        sfm.py:54
  *

@@ -32,6 +32,7 @@ SIGNATURES = {
     "sfm_ratio_compact_ws_bytes": (_sz, [_i64]),
     "sfm_ratio_compact": (_int, [_vp, _vp, _i64, _f64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sfm_gather_matches": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "sfm_common_points": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sfm_triangulate_dlt": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _int, _int, _vp, _vp]),
     "sfm_project_residual_ws_bytes": (_sz, [_i64, _i64, _i64]),
     "sfm_project_residual": (_int, [_vp, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _f32,

@@ -1,0 +1,101 @@
+// Data association between consecutive pairs — common_points (sfm.py:215-239).
+//
+// For every row i of pts1 the reference takes `np.where(pts2 == pts1[i, :])[0][0]`: the FIRST row of pts2 whose x OR
+// whose y is bit-equal (element-wise broadcast), appends (i, row) to (indx1, indx2) — duplicates in
+// indx2 allowed — and then drops the matched rows of pts2 / pts3 by mask-and-compress.  n1 * n2 ~ 1e6-1e7 exact
+// float compares per frame: one lane per row of pts1 scanning pts2 through LDS tiles (coalesced, early exit per
+// wave), then an ordered ballot compaction.  Integer outputs, bit-exact by construction.
+#include "common.h"
+
+namespace {
+
+constexpr int kTile = 1024;   // rows of pts2 staged per iteration (8 KiB)
+
+__global__ __launch_bounds__(256) void first_match_kernel(const float2* __restrict__ p1, int n1, const float2* __restrict__ p2,
+                                                          int n2, int* __restrict__ first, unsigned char* __restrict__ keep2) {
+    __shared__ float2 tile[kTile];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const float2 a = i < n1 ? p1[i] : make_float2(0.f, 0.f);
+    int found = i < n1 ? -1 : 0;          // lanes past n1 are "done"
+    for (int base = 0; base < n2; base += kTile) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < kTile && base + k < n2; k += 256) tile[k] = p2[base + k];
+        __syncthreads();
+        if (__syncthreads_and(found >= 0)) break;
+        if (found < 0) {
+            const int m = min(kTile, n2 - base);
+            for (int k = 0; k < m; ++k) {
+                const float2 b = tile[k];
+                if (b.x == a.x || b.y == a.y) {     // x OR y, exact float equality (NaN never matches, like NumPy)
+                    found = base + k;
+                    break;
+                }
+            }
+        }
+    }
+    if (i < n1) {
+        first[i] = found;
+        if (found >= 0) keep2[found] = 0;           // all writers store the same value
+    }
+}
+
+__global__ __launch_bounds__(256) void keep_init_kernel(unsigned char* __restrict__ keep2, int n2) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r < n2) keep2[r] = 1;
+}
+
+// single workgroup ordered compaction of (i, first[i]) pairs with first[i] >= 0
+__global__ __launch_bounds__(1024) void assoc_compact_kernel(const int* __restrict__ first, int n1, int* __restrict__ idx1,
+                                                             int* __restrict__ idx2, int* __restrict__ count) {
+    __shared__ int wsum[16];
+    __shared__ int base_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) base_s = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n1; i0 += 1024) {
+        const int i = i0 + threadIdx.x;
+        const int f = i < n1 ? first[i] : -1;
+        const unsigned long long bal = __ballot(f >= 0);
+        if (lane == 0) wsum[wave] = __popcll(bal);
+        __syncthreads();
+        int woff = 0, total = 0;
+        for (int w = 0; w < 16; ++w) {
+            if (w < wave) woff += wsum[w];
+            total += wsum[w];
+        }
+        if (f >= 0) {
+            const int pos = base_s + woff + __popcll(bal & ((1ull << lane) - 1ull));
+            idx1[pos] = i;
+            idx2[pos] = f;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) base_s += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *count = base_s;
+}
+
+}  // namespace
+
+extern "C" int sfm_common_points(const float* pts1, int64_t n1, const float* pts2, int64_t n2, int32_t* first_ws,
+                                 int32_t* idx1, int32_t* idx2, int32_t* count, uint8_t* keep2, void* stream_) {
+    SFM_CHECK_ARG(n1 >= 0 && n2 >= 0 && n1 < (1 << 30) && n2 < (1 << 30), "sfm_common_points: bad sizes");
+    SFM_CHECK_ARG(count && (n1 == 0 || (pts1 && first_ws && idx1 && idx2)) && (n2 == 0 || (pts2 && keep2)),
+                  "sfm_common_points: null pointer");
+    hipStream_t stream = sfm::as_stream(stream_);
+    if (n2 > 0) {
+        hipLaunchKernelGGL(keep_init_kernel, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, stream, keep2, (int)n2);
+        SFM_CHECK_LAUNCH();
+    }
+    if (n1 == 0) {
+        SFM_CHECK_HIP(hipMemsetAsync(count, 0, sizeof(int32_t), stream));
+        return SFM_OK;
+    }
+    hipLaunchKernelGGL(first_match_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, stream,
+                       reinterpret_cast<const float2*>(pts1), (int)n1, reinterpret_cast<const float2*>(pts2), (int)n2, first_ws,
+                       keep2);
+    SFM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(assoc_compact_kernel, dim3(1), dim3(1024), 0, stream, first_ws, (int)n1, idx1, idx2, count);
+    SFM_CHECK_LAUNCH();
+    return SFM_OK;
+}

@@ -100,6 +100,26 @@ def gather_matches(kp0, kp1, out_q, out_t, count):
     return pts0, pts1
 
 
+def common_points(pts1, pts2):
+    """sfm.py:215-239 association on device: (indx1 int32[m], indx2 int32[m], keep2 bool[n2]) — x OR y bit-equality,
+    first hit, ascending order."""
+    require_cuda(pts1, pts2)
+    pts1 = pts1.contiguous().float().reshape(-1, 2)
+    pts2 = pts2.contiguous().float().reshape(-1, 2)
+    n1, n2 = pts1.shape[0], pts2.shape[0]
+    dev = pts1.device
+    first = torch.empty(max(n1, 1), dtype=torch.int32, device=dev)
+    idx1 = torch.empty(max(n1, 1), dtype=torch.int32, device=dev)
+    idx2 = torch.empty(max(n1, 1), dtype=torch.int32, device=dev)
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    keep2 = torch.empty(max(n2, 1), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(_lib.lib().sfm_common_points(ptr(pts1), n1, ptr(pts2), n2, ptr(first), ptr(idx1), ptr(idx2), ptr(count),
+                                           ptr(keep2), stream_ptr()), "sfm_common_points")
+    m = int(count.item())
+    return idx1[:m], idx2[:m], keep2[:n2].bool()
+
+
 def match_pair(des0, des1, ratio=0.70):
     """KNN + ratio for one image pair; returns (query_idx, train_idx, dist1) trimmed to the survivors.
 

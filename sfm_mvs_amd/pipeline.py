@@ -149,10 +149,18 @@ def BundleAdjustment(points_3d, temp2, Rtnew, K, r_error, be=None):
 
 def common_points(pts1, pts2, pts3):
     """sfm.py:215-239.  quirk 2: a row of pts2 "equals" pts1[i] when x OR y is bit-equal; first hit wins;
-    duplicates in indx2 allowed; the complement is mask-and-compress of pts2 / pts3."""
+    duplicates in indx2 allowed; the complement is mask-and-compress of pts2 / pts3.  Runs on the device
+    (sfm_common_points) when a GPU is present; the NumPy form below is the same definition for host-only use."""
     pts1 = np.asarray(pts1)
     pts2 = np.asarray(pts2)
     pts3 = np.asarray(pts3)
+    if torch.cuda.is_available() and pts1.dtype == np.float32 and pts2.dtype == np.float32 and len(pts1) and len(pts2):
+        dev = torch.device("cuda")
+        i1, i2, keep = ops.common_points(torch.from_numpy(np.ascontiguousarray(pts1)).to(dev),
+                                         torch.from_numpy(np.ascontiguousarray(pts2)).to(dev))
+        keep = keep.cpu().numpy()
+        return (i1.cpu().numpy().astype(np.int64), i2.cpu().numpy().astype(np.int64), pts2[keep].reshape(-1, 2),
+                pts3[keep].reshape(-1, 2))
     hit = (pts2[None, :, 0] == pts1[:, None, 0]) | (pts2[None, :, 1] == pts1[:, None, 1])
     any_hit = hit.any(1)
     indx1 = np.flatnonzero(any_hit)

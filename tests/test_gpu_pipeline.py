@@ -148,3 +148,30 @@ def test_bundle_adjustment_mirror(hip, oracle):
     assert Xo.shape == (12, 3) and po.shape == (12, 2) and Rto.shape == (3, 4)
     x1v = np.hstack([Rto.ravel(), K.ravel(), po.T.ravel(), Xo.ravel()])
     assert pl.OptimReprojectionError(x1v).sum() <= r_hip.sum() * 1.0001
+
+
+def test_common_points_kernel_vs_reference_golden_vectors(hip, oracle):
+    """sfm_common_points against the vectors produced by executing the reference's own common_points (x-OR-y quirk,
+    duplicates, empty intersections) and against the oracle on a frame-sized random case."""
+    import os
+    from datagen import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "common_points.npz"))
+    for name in "abcd":
+        i1, i2, keep = hip.common_points(cu32(z[f"{name}_pts1"]), cu32(z[f"{name}_pts2"]))
+        assert np.array_equal(i1.cpu().numpy(), z[f"{name}_indx1"]) and np.array_equal(i2.cpu().numpy(), z[f"{name}_indx2"]), name
+        k = keep.cpu().numpy()
+        assert np.array_equal(z[f"{name}_pts2"][k], z[f"{name}_temp1"].reshape(-1, 2))
+        assert np.array_equal(z[f"{name}_pts3"][k], z[f"{name}_temp2"].reshape(-1, 2))
+    rng = np.random.default_rng(3)
+    p2 = np.round(rng.uniform(0, 900, (3100, 2)), 1).astype(np.float32)       # coarse grid: many x-only / y-only hits
+    p1 = np.round(rng.uniform(0, 900, (2900, 2)), 1).astype(np.float32)
+    p1[::3] = p2[rng.permutation(3100)[:967]]
+    wi1, wi2, wt1, _ = oracle.common_points(p1, p2, p2)
+    i1, i2, keep = hip.common_points(cu32(p1), cu32(p2))
+    assert np.array_equal(i1.cpu().numpy(), wi1) and np.array_equal(i2.cpu().numpy(), wi2)
+    assert np.array_equal(p2[keep.cpu().numpy()], wt1)
+
+
+def cu32(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
