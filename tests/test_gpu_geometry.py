@@ -155,3 +155,19 @@ def test_empty_and_degenerate_inputs(hip, oracle):
     counts = hip.score_pnp(cams, K, torch.empty((0, 3), dtype=torch.float32, device="cuda"),
                            torch.empty((0, 2), dtype=torch.float32, device="cuda"))
     assert counts.cpu().tolist() == [0]
+
+
+def test_block_bundle_adjustment_reduces_cost_to_the_noise_floor(hip):
+    """an optimiser on top of the sweep.  Perturbed cameras/points of a dense problem are pulled back: the
+    fp64 cost must fall monotonically towards its noise floor, in the dense and the indexed form alike."""
+    from sfm_mvs_amd import ba
+    K, cams, X, obs = ba_problem(6, 800, 0.3, seed=8, perturb=0.01)
+    c0, x0 = cu(cams), cu(X)
+    cams1, X1, hist = ba.bundle_adjust(c0, K, x0, cu(obs), iters=12)
+    assert all(b <= a * (1 + 1e-12) for a, b in zip(hist, hist[1:])) and hist[-1] < 0.1 * hist[0]
+    noise_floor = 2 * 6 * 800 * 0.3 ** 2          # E[sum of squared residuals] at the true parameters
+    assert hist[-1] < noise_floor
+    ci = np.repeat(np.arange(6), 800).astype(np.int32)
+    pi = np.tile(np.arange(800), 6).astype(np.int32)
+    _, _, hist2 = ba.bundle_adjust(c0, K, x0, cu(obs.reshape(-1, 2)), cu(ci), cu(pi), iters=12)
+    assert hist2[-1] == pytest.approx(hist[-1], rel=1e-6)
