@@ -87,14 +87,17 @@ def _sample_subsets(rng, count, model_points, iters):
     return out
 
 
-def _ransac(count, model_points, max_iters, confidence, make_models, score, chunk=32):
-    """Sequential-semantics RANSAC with chunked hypothesis generation and batched scoring."""
+def _ransac(count, model_points, max_iters, confidence, make_models, score, chunk=4, max_chunk=64):
+    """Sequential-semantics RANSAC with chunked hypothesis generation and batched scoring.  Chunks start small and
+    double: with a high inlier ratio `niters` collapses after the first good model, and hypotheses generated beyond it
+    would be wasted host work (the drawn subsets, and therefore the result, do not depend on the chunking)."""
     rng = hg.CvRNG()
     niters = max_iters
     best_count, best_model, best_mask = 0, None, None
     it = 0
     while it < niters:
         m = min(chunk, niters - it)
+        chunk = min(2 * chunk, max_chunk)
         subsets = _sample_subsets(rng, count, model_points, m)
         models, owner = [], []
         for k in range(m):
