@@ -160,7 +160,7 @@ def bench_knn(args, world, rank, dev):
                      "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": traffic,
                      "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/knn_traffic.json)",
                      "algorithmic_bytes_per_launch": 4 * 128 * (nq + nt) + 16 * nq,
-                     "kernel": "knn_filter_split2_kernel<0, 8, true>", "avg_launch_ms": filt_avg_ms, "launches": filt_n,
+                     "kernel": "knn_filter_split2_kernel<0, 8>", "avg_launch_ms": filt_avg_ms, "launches": filt_n,
                      "algorithmic_flop_per_launch": algo_flop,
                      "issued_mfma_tflops": issued, "issued_frac_of_peak": issued / BF16_MFMA_PEAK_TFLOPS,
                      "note": "algorithmic = 256 FLOP per distance (SURVEY 8d); the kernel issues 3.07x that in bf16 MFMA flops"},
@@ -168,6 +168,23 @@ def bench_knn(args, world, rank, dev):
         "knn_stats": {"fallback_queries": stats[0], "filter_workgroups": stats[1], "streams_per_query": stats[2]},
     }
     if world == 1 and not args.no_extras:
+        # boundary handing over HOST buffers: pinned H2D of both descriptor sets + the step + D2H of the results
+        qh, th = q.cpu().pin_memory(), t.cpu().pin_memory()
+        qd, td = torch.empty_like(q), torch.empty_like(t)
+        ih, dh = torch.empty((nq, 2), dtype=torch.int32).pin_memory(), torch.empty((nq, 2), dtype=torch.float32).pin_memory()
+        for _ in range(3):
+            qd.copy_(qh, non_blocking=True); td.copy_(th, non_blocking=True)
+            pm.run(qd, td)
+            ih.copy_(pm.idx, non_blocking=True); dh.copy_(pm.dist, non_blocking=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            qd.copy_(qh, non_blocking=True); td.copy_(th, non_blocking=True)
+            pm.run(qd, td)
+            ih.copy_(pm.idx, non_blocking=True); dh.copy_(pm.dist, non_blocking=True)
+        torch.cuda.synchronize()
+        out["pcie_inclusive"] = {"distances_per_sec": nq * nt * 20 / (time.perf_counter() - t0),
+                                 "note": "pinned-host descriptors in, results out, same stream (not the headline value)"}
         # the exact-f32-MFMA filter variant on the same inputs (identical results), for the fp32 roofline
         ops.set_knn_filter("f32")
         pm32 = ops.PairMatcher(nq, nt, dev, ratio=0.70)
