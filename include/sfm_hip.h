@@ -55,15 +55,19 @@ const char* sfm_last_error(void);
  *   stats_dev (optional, may be NULL) int32[4]:
  *       [0] queries resolved by the exact full-scan fallback
  *       [1] filter workgroups launched   [2] candidate streams reserved per query
- *       [3] train chunks per fallback query
+ *       [3] filter arithmetic that ran: 0 fp16 single product, exact inputs; 1 fp16 single product;
+ *           2 bf16 hi/mid split; 3 fp32 MFMA
  *
  * dim must be 128 (SIFT); q_dev/t_dev 16-byte aligned; ldq, ldt multiples of 4.
  * The result is bit-identical to the direct-form float32 evaluation for ANY
  * finite input (see DESIGN.md "certified filter + exact refine").
  * ---------------------------------------------------------------------- */
 size_t sfm_knn2_l2_f32_ws_bytes(int64_t nq, int64_t nt, int dim);
-/* Filter variant used by sfm_knn2_l2_f32 (results are bit-identical either way):
- *   0  split-bf16 MFMA filter (default)      1  fp32 MFMA filter
+/* Filter variant used by sfm_knn2_l2_f32 (results are bit-identical whichever runs):
+ *   0  16-bit MFMA filter (default); its arithmetic is chosen on the device from the data:
+ *      one fp16 product when the values fit fp16's range (exact for integer descriptors),
+ *      else the three-product bf16 hi/mid split
+ *   1  fp32 MFMA filter                       2  as 0 but pinned to the bf16 split
  * Call before sizing the workspace; the _ws_bytes twin follows the current mode. */
 int    sfm_knn_set_filter(int mode);
 int    sfm_knn2_l2_f32(const float* q_dev, int64_t nq, int64_t ldq,

@@ -365,6 +365,7 @@ __global__ __launch_bounds__(64 * W, 4) void knn_filter_kernel(
 // 25 MFMAs x 32 cycles per 32x32 tile instead of 65 x 64.  Neglected terms are bounded by
 // 3.05 * 2^-16 |q||t|; the refine kernel's slack accounts for it (kEpsSplit).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ unsigned bf16_rn_bits(float x) {
@@ -372,8 +373,32 @@ __device__ __forceinline__ unsigned bf16_rn_bits(float x) {
     return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
 }
 
-// One pass over Q and T: split rows into (hi, mid) bf16 images (Q pre-scaled by -2, exact), fp32 squared norms,
-// per-block max of ||t||^2, zero the fallback counter.  Rows >= n of the padded images are zero-filled.
+// Filter arithmetic modes, decided ON THE DEVICE from what knn_prep_kernel saw (no host round trip):
+//   kModeHalfExact  every value (Q pre-scaled by -2) is exactly a normal fp16 or zero (real SIFT descriptors are
+//                   integers 0..255): ONE v_mfma_f32_32x32x16_f16 product, dot products exact.
+//   kModeHalf       values within fp16 range and ||t||max >= 1/2: one fp16 product; rounding each operand to 11 bits
+//                   perturbs the score by <= 2^-11 (|q|+|t|)^2 (+ an absolute term for values below the fp16 normal
+//                   range, which the matrix pipe may flush) — the refine kernel's slack (kEpsHalf*) covers it.
+//   kModeSplit      anything else (huge / tiny magnitudes): bf16 hi+mid split, three products, full fp32 range.
+constexpr int kModeHalfExact = 0, kModeHalf = 1, kModeSplit = 2;
+constexpr int kFlagBf16Inexact = 1, kFlagHalfInexact = 2, kFlagRangeBad = 4;
+
+// Wave-uniform mode from the per-block flags and per-block max ||t||^2 (256 entries each).
+__device__ __forceinline__ int knn_filter_mode(const int* __restrict__ flags, const float* __restrict__ bmax, int lane,
+                                               float* tmax_out = nullptr) {
+    const int fl = flags[lane] | flags[lane + 64] | flags[lane + 128] | flags[lane + 192];
+    float tmax = fmaxf(fmaxf(bmax[lane], bmax[lane + 64]), fmaxf(bmax[lane + 128], bmax[lane + 192]));
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, m, 64));
+    if (tmax_out) *tmax_out = tmax;
+    if (__any((fl & kFlagRangeBad) != 0)) return kModeSplit;
+    if (!__any((fl & kFlagHalfInexact) != 0)) return kModeHalfExact;
+    return tmax >= 0.25f ? kModeHalf : kModeSplit;
+}
+
+// One pass over Q and T: rows → (hi, mid) bf16 images and an fp16 image (Q pre-scaled by -2, exact), fp32 squared
+// norms, per-block max of ||t||^2 and exactness / range flags, zero the fallback counter.  Rows >= n of the padded
+// images are zero-filled.  Image layout: [3][n_pad][128] 16-bit: bf16 hi, bf16 mid, fp16.
 __global__ __launch_bounds__(1024) void knn_prep_kernel(const float* __restrict__ Q, int64_t ldq, int nq, int nq_pad,
                                                        const float* __restrict__ T, int64_t ldt, int nt, int nt_pad,
                                                        unsigned short* __restrict__ qsplit, float* __restrict__ qn,
@@ -384,7 +409,7 @@ __global__ __launch_bounds__(1024) void knn_prep_kernel(const float* __restrict_
     __shared__ int wmid[16];
     const int l = threadIdx.x & 31;
     float mx = 0.f;
-    unsigned anymid = 0;
+    unsigned flags = 0;
     const int rows = nq_pad + nt_pad;
     for (int i = blockIdx.x * 1024 + threadIdx.x; i < nq; i += gridDim.x * 1024) tickets[i] = 0;   // fallback tickets
     for (int row = blockIdx.x * 32 + (threadIdx.x >> 5); row < rows; row += gridDim.x * 32) {   // 32 rows in flight per block
@@ -398,25 +423,33 @@ __global__ __launch_bounds__(1024) void knn_prep_kernel(const float* __restrict_
         for (int m = 16; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
         const float sc = isq ? -2.f : 1.f;
         const float e[4] = {sc * v.x, sc * v.y, sc * v.z, sc * v.w};
-        unsigned hb[4], mb[4];
+        unsigned hb[4], mb[4], fb[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             hb[k] = bf16_rn_bits(e[k]);
             mb[k] = bf16_rn_bits(e[k] - __uint_as_float(hb[k] << 16));   // x - hi is exact in fp32
-            anymid |= mb[k] & 0x7FFFu;
+            if (mb[k] & 0x7FFFu) flags |= kFlagBf16Inexact;
+            const float ae = fabsf(e[k]);
+            const _Float16 hv = (_Float16)e[k];                          // round to nearest even
+            fb[k] = (unsigned)__builtin_bit_cast(unsigned short, hv);
+            if (!(ae <= 60000.f)) flags |= kFlagRangeBad;                // also catches NaN / inf
+            if ((float)hv != e[k] || (ae != 0.f && ae < 6.103515625e-5f)) flags |= kFlagHalfInexact;
         }
         unsigned short* img = isq ? qsplit : tsplit;
         *reinterpret_cast<uint2*>(img + (int64_t)r * kDim + 4 * l) = make_uint2(hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16));
         *reinterpret_cast<uint2*>(img + ((int64_t)npad + r) * kDim + 4 * l) = make_uint2(mb[0] | (mb[1] << 16), mb[2] | (mb[3] << 16));
+        *reinterpret_cast<uint2*>(img + (2 * (int64_t)npad + r) * kDim + 4 * l) = make_uint2(fb[0] | (fb[1] << 16), fb[2] | (fb[3] << 16));
         if (l == 0) (isq ? qn : tn)[r] = (isq || r < n) ? s : kInf;   // padded train rows can never be candidates
         if (!isq) mx = fmaxf(mx, s);
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
-    const int wany = __any(anymid != 0) ? 1 : 0;
+    int wfl = 0;
+#pragma unroll
+    for (int b = 1; b <= 4; b <<= 1) wfl |= __any((flags & b) != 0) ? b : 0;
     if ((threadIdx.x & 63) == 0) {
         wmax[threadIdx.x >> 6] = mx;
-        wmid[threadIdx.x >> 6] = wany;
+        wmid[threadIdx.x >> 6] = wfl;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -427,8 +460,6 @@ __global__ __launch_bounds__(1024) void knn_prep_kernel(const float* __restrict_
             fl |= wmid[w];
         }
         bmax[blockIdx.x] = bm;
-        // 0 for this block's rows when every value is exactly a bf16 (e.g. SIFT's integers 0..255): the filter
-        // then needs the hi.hi product only and its dot products are EXACT.
         midflag[blockIdx.x] = fl;
         if (blockIdx.x == 0) *flag_count = 0;
     }
@@ -650,7 +681,8 @@ __device__ __forceinline__ void filter_split2_body(
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
     const unsigned lds_tn = lds0 + kRing * kTileFloats * 4;
     const int mid_off = nt_pad * 256;
-    const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc((void*)tsplit, 0, 2 * mid_off, 0x00020000);
+    const int img_off = KMID ? 0 : 2 * mid_off;                 // single-product modes read the fp16 image
+    const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc((void*)tsplit, 0, 3 * mid_off, 0x00020000);
     const __amdgpu_buffer_rsrc_t tnrs = __builtin_amdgcn_make_buffer_rsrc((void*)tn, 0, nt_pad * 4, 0x00020000);
     constexpr int PIECES = 16 / W;
     const int p0 = wave * PIECES;
@@ -662,7 +694,7 @@ __device__ __forceinline__ void filter_split2_body(
     // Train tile `tile` → ring slot `buf`, entirely by LDS-DMA (hi/mid images 1 KiB per piece; ||t||^2 as one dword
     // piece from wave 0: padded rows hold +inf).  No VGPR destinations, so nothing here makes hipcc wait.
     auto stage = [&](int tile, int buf) {
-        const int soff = __builtin_amdgcn_readfirstlane(tile * kTileT * 256 + (p0 >= 8 ? mid_off : 0));
+        const int soff = __builtin_amdgcn_readfirstlane(tile * kTileT * 256 + (p0 >= 8 ? mid_off : img_off));
         const unsigned dst0 = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)buf * (kTileFloats * 4) + (unsigned)p0 * 1024u);
         if (stage_pieces)
 #pragma unroll
@@ -693,7 +725,7 @@ __device__ __forceinline__ void filter_split2_body(
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             const int qr = qok[g] ? qrow0 + 32 * g : 0;
-            const unsigned short* sh = qsplit + (int64_t)qr * kDim + 8 * h;
+            const unsigned short* sh = qsplit + ((KMID ? 0 : 2 * (int64_t)nq_pad) + qr) * kDim + 8 * h;
             const unsigned short* sm = qsplit + ((int64_t)nq_pad + qr) * kDim + 8 * h;
 #pragma unroll
             for (int st = 0; st < 8; ++st) {
@@ -771,11 +803,14 @@ __device__ __forceinline__ void filter_split2_body(
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
                     const bf16x8 Bh = __builtin_bit_cast(bf16x8, bh[g][st]);
-                    cur[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, cur[g], 0, 0, 0);
                     if (KMID) {
+                        cur[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, cur[g], 0, 0, 0);
                         const bf16x8 Am = __builtin_bit_cast(bf16x8, am[st & 1]), Bm = __builtin_bit_cast(bf16x8, bm[g][st]);
                         cur[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm, cur[g], 0, 0, 0);
                         cur[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, cur[g], 0, 0, 0);
+                    } else {
+                        cur[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[st & 1]),
+                                                                       __builtin_bit_cast(f16x8, bh[g][st]), cur[g], 0, 0, 0);
                     }
                 }
                 if (have_prev && (ABL & 1)) {    // dev ablation: keep the MFMAs alive with one op per k-step
@@ -833,14 +868,15 @@ __device__ __forceinline__ void filter_split2_body(
     }
 }
 
-// One launch, two bodies: KMID = false when every input is exactly a bf16 (real SIFT descriptors are integers 0..255;
-// knn_prep_kernel reports it) → one exact product instead of three and no mid-image traffic.  The branch is taken once
-// per workgroup, so only the chosen body's instructions are ever fetched.
+// One launch, two bodies: KMID = false is the single-product fp16 body (kModeHalfExact / kModeHalf, chosen on the
+// device by knn_filter_mode), KMID = true the three-product bf16 split.  The branch is taken once per workgroup, so
+// only the chosen body's instructions are ever fetched.
 template <int ABL, int W>
 __global__ __launch_bounds__(64 * W, 2) void knn_filter_split2_kernel(
     const unsigned short* __restrict__ qsplit, const float* __restrict__ qnorm, int nq, int nq_pad,
     const unsigned short* __restrict__ tsplit, int nt, int nt_pad, const float* __restrict__ tn, int tiles, int64_t units,
-    int smax, int nsub, const int* __restrict__ midflag, float* __restrict__ cand_s, int* __restrict__ cand_i,
+    int smax, int nsub, const int* __restrict__ midflag, const float* __restrict__ bmax, int force_mode,
+    float* __restrict__ cand_s, int* __restrict__ cand_i,
     long long* __restrict__ trace) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if (trace && threadIdx.x == 0) {
@@ -849,7 +885,7 @@ __global__ __launch_bounds__(64 * W, 2) void knn_filter_split2_kernel(
         trace[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg(0xF814);
     }
     const int lane = threadIdx.x & 63;
-    const bool need_mid = __any((midflag[lane] | midflag[lane + 64] | midflag[lane + 128] | midflag[lane + 192]) != 0);
+    const bool need_mid = (force_mode >= 0 ? force_mode : knn_filter_mode(midflag, bmax, lane)) == kModeSplit;
     if (need_mid)
         filter_split2_body<ABL, W, true>(smem, qsplit, qnorm, nq, nq_pad, tsplit, nt_pad, tn, tiles, units, smax, nsub, cand_s, cand_i);
     else
@@ -933,13 +969,28 @@ __device__ __forceinline__ float exact_l2sq_group8(const float* __restrict__ qro
     return ((s + s1) + s2) + s3;                         // valid on l == 0
 }
 
+// Slack coefficients of the refine kernel's certificate, relative to (|q|+|t|max)^2:
+//   common:   600u  fp32 rounding of norms / direct-form sums / sqrtf merge (+ GEMM-form chain for the f32 filter)
+//             2^-14 packed-key truncation of the score
+//   MFMA:     400 * 2^-22  ~400 accumulations inside the 16-bit MFMA chain, each assumed to lose <= 2^-22 relative
+//   split:    2 * 3.05 * 2^-16 / 4  neglected (mid.mid, delta) product terms, |q||t| <= N^2/4
+//   half:     2 * (2^-10 + 2^-22) / 4  both operands rounded to 11 bits: |q^.t^ - q.t| <= (2^-10 + 2^-22)|q||t|;
+//             plus, ABSOLUTE, 2 * 2^-14 * sqrt(128) * (|q|+|t|max) for elements below the fp16 normal range
+//             (each perturbed by at most 2^-14 even if the matrix pipe flushes them)
+constexpr float kEpsF32 = 600.f * 5.9604645e-8f + 6.1035156e-5f;
+constexpr float kEpsExact = kEpsF32 + 9.54e-5f;
+constexpr float kEpsSplit = kEpsExact + 2.33e-5f;
+constexpr float kEpsHalf = kEpsExact + 4.8840e-4f;
+constexpr float kEpsHalfAbs = 1.3811e-3f;
+constexpr int kModeF32 = 3;   // fp32-MFMA filter (host-selected)
+
 constexpr int kRefineMaxCand = 256;   // candidates kept in registers per wave (4 per lane); more → second sweep
 
 __global__ __launch_bounds__(256) void knn_refine_kernel(
     const float* __restrict__ Q, int64_t ldq, int nq, const float* __restrict__ T, int64_t ldt,
     const float* __restrict__ cand_s, const int* __restrict__ cand_i, int rows_per_block, int tiles, int64_t units,
-    int G, int smax, int nsub, float eps_coef, const float* __restrict__ bmax, int* __restrict__ idx_out,
-    float* __restrict__ dist_out,
+    int G, int smax, int nsub, int force_mode, const int* __restrict__ midflag, const float* __restrict__ bmax,
+    int* __restrict__ idx_out, float* __restrict__ dist_out,
     int* __restrict__ flag_count, int* __restrict__ flag_list) {
     __shared__ __attribute__((aligned(16))) float qrows[4][kDim];
     __shared__ int qual[4][64];
@@ -962,11 +1013,12 @@ __global__ __launch_bounds__(256) void knn_refine_kernel(
     // Slack that dominates: rounding of the filter's dot-product chain, of ||q||^2, ||t||^2, of the direct-form
     // sums (<= 24u*d^2) and the final sqrtf merge (8u*d^2) — 600u*(|q|+|t|max)^2, u = 2^-24 — plus what the chosen
     // filter loses on top (packed keys; split-bf16 products): eps_coef, see kEpsF32 / kEpsSplit.
-    float tmax = fmaxf(fmaxf(bmax[lane], bmax[lane + 64]), fmaxf(bmax[lane + 128], bmax[lane + 192]));
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, m, 64));
+    float tmax;
+    int mode = knn_filter_mode(midflag, bmax, lane, &tmax);
+    if (force_mode >= 0) mode = force_mode;
     const float nsum = sqrtf(qq) + sqrtf(tmax);
-    const float eps = eps_coef * 1.01f * nsum * nsum;
+    const float eps_coef = mode == kModeHalfExact ? kEpsExact : mode == kModeHalf ? kEpsHalf : mode == kModeSplit ? kEpsSplit : kEpsF32;
+    const float eps = 1.01f * (eps_coef * nsum * nsum + (mode == kModeHalf ? kEpsHalfAbs * nsum : 0.f));
 
     // streams of this query's row block = filter blocks that touched it (contiguous slots from 0)
     const int rb = q / rows_per_block;
@@ -1070,13 +1122,16 @@ __global__ __launch_bounds__(256) void knn_fallback_kernel(
     const float* __restrict__ Q, int64_t ldq, const float* __restrict__ T, int64_t ldt, int nt, int nch, int chunk,
     const int* __restrict__ flag_count, const int* __restrict__ flag_list, Best2Rec* __restrict__ partial,
     int* __restrict__ tickets, int* __restrict__ idx_out, float* __restrict__ dist_out, int* __restrict__ stats, int G,
-    int NS) {
+    int NS, int force_mode, const int* __restrict__ midflag, const float* __restrict__ bmax) {
     __shared__ __attribute__((aligned(16))) float qrow[kDim];
     __shared__ Best2 wbest[4];
     __shared__ int last_s;
     const int nflag = *flag_count;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && stats) {
-        stats[0] = nflag; stats[1] = G; stats[2] = NS; stats[3] = nch;
+    if (blockIdx.x == 0 && threadIdx.x < 64 && stats) {
+        const int mode = force_mode >= 0 ? force_mode : knn_filter_mode(midflag, bmax, threadIdx.x);
+        if (threadIdx.x == 0) {
+            stats[0] = nflag; stats[1] = G; stats[2] = NS; stats[3] = mode;
+        }
     }
     const int64_t items = (int64_t)nflag * nch;
     for (int64_t it = blockIdx.x; it < items; it += gridDim.x) {
@@ -1241,14 +1296,8 @@ __global__ void knn_fill_empty_kernel(int* __restrict__ idx, float* __restrict__
 }
 
 long long* g_trace = nullptr;   // dev diagnostics only
-
-// Slack coefficients (relative to (|q|+|t|max)^2) handed to the refine kernel.
-//   common:   600u  fp32 rounding of norms / direct-form sums / sqrtf merge (+ GEMM-form chain for the f32 filter)
-//             2^-14 packed-key truncation of the score
-//   split:    2 * 3.05 * 2^-16 / 4  neglected (mid.mid, delta) product terms, |q||t| <= N^2/4
-//             400 * 2^-22           ~400 accumulations inside the bf16 MFMA chain, each assumed to lose <= 2^-22 relative
-constexpr float kEpsF32 = 600.f * 5.9604645e-8f + 6.1035156e-5f;
-constexpr float kEpsSplit = kEpsF32 + 2.33e-5f + 9.54e-5f;
+// dev/test only: SFM_KNN_MODE=split|half pins the 16-bit filter's arithmetic mode (default: decided on the device)
+int g_force_mode = [] { const char* e = getenv("SFM_KNN_MODE"); return !e ? -1 : e[0] == 's' ? kModeSplit : e[0] == 'h' ? kModeHalf : -1; }();
 
 struct KnnWs {
     unsigned short* qsplit;
@@ -1275,8 +1324,8 @@ KnnWs carve_ws(void* ws, int64_t nq, int64_t nt, const Plan& p) {
     w.fb_partial = c.take<Best2Rec>((size_t)nq * p.fb_nch);
     w.tn = c.take<float>((size_t)p.tiles * kTileT);
     w.qn = c.take<float>((size_t)p.nq_pad);
-    w.qsplit = c.take<unsigned short>((size_t)p.nq_pad * kDim * 2);
-    w.tsplit = c.take<unsigned short>((size_t)p.tiles * kTileT * kDim * 2);
+    w.qsplit = c.take<unsigned short>((size_t)p.nq_pad * kDim * 3);
+    w.tsplit = c.take<unsigned short>((size_t)p.tiles * kTileT * kDim * 3);
     w.flag_list = c.take<int>((size_t)nq);
     w.tickets = c.take<int>((size_t)nq);
     w.cand_s = c.take<float>((size_t)nq * 2 * p.smax * p.nsub * 3);
@@ -1288,8 +1337,9 @@ KnnWs carve_ws(void* ws, int64_t nq, int64_t nt, const Plan& p) {
 }  // namespace
 
 extern "C" int sfm_knn_set_filter(int mode) {
-    SFM_CHECK_ARG(mode == 0 || mode == 1, "sfm_knn_set_filter: mode must be 0 (split-bf16) or 1 (fp32 MFMA)");
-    g_filter_mode = mode;
+    SFM_CHECK_ARG(mode >= 0 && mode <= 2, "sfm_knn_set_filter: mode must be 0 (16-bit MFMA, auto), 1 (fp32 MFMA) or 2 (bf16 split pinned)");
+    g_filter_mode = mode == 1 ? 1 : 0;
+    g_force_mode = mode == 2 ? kModeSplit : -1;
     return SFM_OK;
 }
 
@@ -1345,7 +1395,7 @@ extern "C" int sfm_knn2_l2_f32(const float* q, int64_t nq, int64_t ldq, const fl
 #define SFM_LAUNCH_SPLIT2(A, WV)                                                                                        \
     hipLaunchKernelGGL((knn_filter_split2_kernel<A, WV>), grid, dim3(64 * WV), kRingLdsBytes, stream, w.qsplit, w.qn,    \
                        (int)nq, p.nq_pad, w.tsplit, (int)nt, p.tiles * kTileT, w.tn, p.tiles, p.units, p.smax, p.nsub,    \
-                       w.midflag, w.cand_s, w.cand_i, g_trace)
+                       w.midflag, w.bmax, g_force_mode, w.cand_s, w.cand_i, g_trace)
         if (p.qg == 2) {
             if (p.waves == 4) {
                 if (abl == 1) SFM_LAUNCH_SPLIT2(1, 4); else if (abl == 7) SFM_LAUNCH_SPLIT2(7, 4); else SFM_LAUNCH_SPLIT2(0, 4);
@@ -1396,16 +1446,17 @@ extern "C" int sfm_knn2_l2_f32(const float* q, int64_t nq, int64_t ldq, const fl
     }
     sfm::prof_end(sfm::kProfKnnFilter, stream);
     SFM_CHECK_LAUNCH();
+    const int force_mode = !p.split ? kModeF32 : p.qg == 2 ? g_force_mode : kModeSplit;
     sfm::prof_begin(sfm::kProfKnnRefine, stream);
     hipLaunchKernelGGL(knn_refine_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream, q, ldq, (int)nq, t, ldt,
                        w.cand_s, w.cand_i, p.rows_per_block, p.tiles, p.units, p.G, p.smax * p.nsub, p.nsub,
-                       p.split ? kEpsSplit : kEpsF32, w.bmax, idx, dist,
+                       force_mode, w.midflag, w.bmax, idx, dist,
                        w.flag_count,
                        w.flag_list);
     SFM_CHECK_LAUNCH();
     hipLaunchKernelGGL(knn_fallback_kernel, dim3(kFbScanBlocks), dim3(256), 0, stream, q, ldq, t, ldt, (int)nt, p.fb_nch,
                        p.fb_chunk, w.flag_count, w.flag_list, w.fb_partial, w.tickets, idx, dist, stats, p.G,
-                       2 * p.smax * p.nsub);
+                       2 * p.smax * p.nsub, force_mode, w.midflag, w.bmax);
     sfm::prof_end(sfm::kProfKnnRefine, stream);
     SFM_CHECK_LAUNCH();
     return SFM_OK;

@@ -302,8 +302,9 @@ class PairMatcher:
 
 
 def set_knn_filter(mode):
-    """'split' (bf16 hi/mid MFMA filter, default) or 'f32' (fp32 MFMA filter); identical results."""
-    check(_lib.lib().sfm_knn_set_filter({"split": 0, "f32": 1}[mode]), "sfm_knn_set_filter")
+    """'auto' (16-bit MFMA filter, fp16 single product or bf16 split chosen on the device; default), 'f32'
+    (fp32 MFMA filter) or 'split' (bf16 split pinned); identical results."""
+    check(_lib.lib().sfm_knn_set_filter({"auto": 0, "f32": 1, "split": 2}[mode]), "sfm_knn_set_filter")
     _ws_cache.clear()
 
 

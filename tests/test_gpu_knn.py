@@ -155,3 +155,55 @@ def test_config2_size_properties_and_parity(hip, oracle):
     # purely random data: nothing passes the 0.7 ratio test
     _, _, cnt = hip.ratio_compact(torch.from_numpy(gi).cuda(), torch.from_numpy(gd).cuda(), 0.70)
     assert int(cnt.item()) == 0
+
+
+# ---------------------------------------------------------------- filter arithmetic modes
+# The 16-bit MFMA filter picks its arithmetic on the device (stats[3]: 0 fp16 exact, 1 fp16, 2 bf16 split); the
+# fp32-MFMA filter is host-selected (3).  Whatever ranks, the returned indices / distances must not change.
+def _mode_cases():
+    rng = np.random.default_rng(77)
+    cases = {}
+    q, t, _ = planted_pair(rng, 900, 1500, 0.3)
+    cases["sift_integers"] = (q, t, 0)
+    cases["uniform_floats"] = (rng.random((700, 128), dtype=np.float32), rng.random((1300, 128), dtype=np.float32), 1)
+    u = rng.standard_normal((800, 128)).astype(np.float32)
+    v = rng.standard_normal((1100, 128)).astype(np.float32)
+    cases["unit_norm_signed"] = (u / np.linalg.norm(u, axis=1, keepdims=True), v / np.linalg.norm(v, axis=1, keepdims=True), 1)
+    cases["tiny_norms"] = ((u * np.float32(1e-3)), (v * np.float32(1e-3)), 2)
+    cases["beyond_fp16_range"] = ((u * np.float32(3e4)), (v * np.float32(3e4)), 2)
+    w = rng.random((600, 128), dtype=np.float32)
+    w[:, ::3] *= np.float32(1e-6)                                     # a third of the elements below fp16's normal range
+    x = rng.random((900, 128), dtype=np.float32)
+    x[:, 1::5] *= np.float32(3e-7)
+    cases["fp16_subnormal_elements"] = (w, x, 1)
+    h = (rng.integers(-2048, 2049, (500, 128)) / 8.0).astype(np.float32)   # exactly representable in fp16, not in bf16
+    g = (rng.integers(-2048, 2049, (800, 128)) / 8.0).astype(np.float32)
+    cases["fp16_exact_not_bf16_exact"] = (h, g, 0)
+    return cases
+
+
+@pytest.mark.parametrize("name", ["sift_integers", "uniform_floats", "unit_norm_signed", "tiny_norms", "beyond_fp16_range",
+                                  "fp16_subnormal_elements", "fp16_exact_not_bf16_exact"])
+def test_filter_modes_all_agree_with_oracle(hip, oracle, name):
+    q, t, expect_mode = _mode_cases()[name]
+    want = oracle.knn2(q, t, nthreads=8)
+    try:
+        for variant, mode in (("auto", expect_mode), ("split", 2), ("f32", 3)):
+            hip.set_knn_filter(variant)
+            gi, gd, stats = run(hip, q, t, stats=True)
+            assert stats[3] == mode, f"{name}/{variant}: filter mode {stats[3]}, expected {mode}"
+            assert_bit_equal((gi, gd), want)
+            assert stats[0] < len(q) // 4, f"{name}/{variant}: {stats[0]} of {len(q)} queries fell back"
+    finally:
+        hip.set_knn_filter("auto")
+
+
+def test_fp16_mode_near_ties_and_duplicates(hip, oracle):
+    """fp16 rounding merges trains that differ by < 2^-11 relative: the certificate must send them to the exact paths."""
+    rng = np.random.default_rng(78)
+    base = rng.random((64, 128), dtype=np.float32)
+    t = np.repeat(base, 8, axis=0) * (1 + np.float32(2e-5) * rng.standard_normal((512, 1)).astype(np.float32))
+    q = base[:40] + np.float32(1e-3) * rng.standard_normal((40, 128)).astype(np.float32)
+    gi, gd, stats = run(hip, q.astype(np.float32), t.astype(np.float32), stats=True)
+    assert stats[3] == 1
+    assert_bit_equal((gi, gd), oracle.knn2(q.astype(np.float32), t.astype(np.float32), nthreads=4))
