@@ -1,23 +1,22 @@
 // Brute-force 128-D L2 2-NN (cv2.BFMatcher().knnMatch(des0, des1, k=2), sfm.py:259-260)
 // for gfx950 — "certified filter + exact refine":
 //
-//   1. knn_norms_kernel   ||t||^2 per train row (+ global max), fp32.
-//   2. knn_filter_kernel  s(q,t) = ||t||^2 - 2 q.t on v_mfma_f32_32x32x2_f32 with the
-//                         OPERANDS SWAPPED (A = train tile from LDS, B = query fragment
-//                         resident in VGPRs) so that a lane owns ONE query column and the
-//                         running top-3 per lane needs no cross-lane traffic.  Train tiles
-//                         stream HBM/L2 -> LDS by buffer_load ... lds (XOR-swizzled image);
-//                         32 queries per wave, 4 workgroups per CU, stream-K work split.
-//                         Every (workgroup segment, half-wave) pair is an independent
-//                         "stream" that emits its 3 best (s, idx).
-//   3. knn_refine_kernel  one wave per query: re-evaluates the few candidates that can
-//                         still be in the top-2 with the reference's direct-form float32
-//                         arithmetic (sub, mul, add — no FMA — in OpenCV's 2x4-lane
-//                         accumulation order, then sqrtf), orders them by (dist, idx) and
-//                         CERTIFIES the answer against the lower bound of everything the
-//                         filter discarded.  Uncertifiable queries are queued …
-//   4. knn_fallback_*      … and resolved by an exact direct-form scan of all trains (chunked over
-//                         the whole chip, then merged).
+//   1. knn_prep_kernel    one pass over Q and T: 16-bit operand images (bf16 hi/mid split and fp16), fp32
+//                         ||.||^2, exactness / range flags.  (knn_norms_kernel for the fp32-MFMA variant.)
+//   2. knn_filter_*       s(q,t) = ||t||^2 + ||q||^2 - 2 q.t on the matrix pipe with the OPERANDS SWAPPED
+//                         (A = train tile from LDS, B = query fragments resident in VGPRs) so that a lane
+//                         owns ONE query column and the running top-3 per lane needs no cross-lane traffic.
+//                         Default: knn_filter_split2_kernel — v_mfma_f32_32x32x16_{f16,bf16}, one fp16 product
+//                         or three bf16 hi/mid products, chosen on the device from the data; train tiles stream
+//                         L2 -> LDS by buffer_load ... lds into a 3-slot ring (XOR-swizzled image); 2 x 32 queries
+//                         per wave, one 8-wave workgroup per CU, stream-K work split.  Every (workgroup segment,
+//                         32-tile substream, half-wave) triple is an independent "stream" that emits its 3 best.
+//   3. knn_refine_kernel  one wave per query: re-evaluates the few candidates that can still be in the top-2
+//                         with the reference's direct-form float32 arithmetic (sub, mul, add — no FMA — in
+//                         OpenCV's 2x4-lane accumulation order, then sqrtf), orders them by (dist, idx) and
+//                         CERTIFIES the answer stream by stream against the lower bound of what each stream
+//                         discarded.  Streams that cannot be certified are queued …
+//   4. knn_rescan_kernel  … and their <= 512 trains evaluated exactly and merged (64-bit atomic top-2).
 //
 // The GEMM-form value is therefore never returned: indices and distances are bit-identical
 // to the direct-form oracle (oracle/sfm_oracle.c: orc_knn2_l2_f32) for any finite input.
@@ -56,8 +55,6 @@ struct Plan {
     int G;             // filter blocks
     int smax;          // candidate slots reserved per row block (>= blocks touching it)
     int nsub;          // substreams (32 tiles each) per slot
-    int fb_nch;        // fallback: train chunks per flagged query
-    int fb_chunk;      // fallback: trains per chunk
 };
 
 __host__ __device__ inline int64_t unit_begin(int64_t units, int G, int b) { return units * b / G; }
@@ -98,15 +95,6 @@ Plan make_plan(int64_t nq, int64_t nt) {
     const int64_t maxseg = (p.units + p.G - 1) / p.G;                 // most tiles one workgroup can own
     p.nsub = (int)((maxseg + 31) / 32);
     if (p.nsub < 1) p.nsub = 1;
-    // fallback chunks: 256 trains each when the worst-case partial buffer (every query flagged) stays small
-    int64_t cap = nq > 0 ? (int64_t)(1 << 21) / nq : 1;
-    if (cap < 2) cap = 2;
-    int64_t nch = (nt + 255) / 256;
-    if (nch > cap) nch = cap;
-    if (nch < 1) nch = 1;
-    p.fb_nch = (int)nch;
-    p.fb_chunk = (int)((nt + nch - 1) / nch);
-    if (p.fb_chunk < 1) p.fb_chunk = 1;
     return p;
 }
 
@@ -137,7 +125,7 @@ __global__ __launch_bounds__(256) void knn_norms_kernel(const float* __restrict_
     __syncthreads();
     if (threadIdx.x == 0) {
         bmax[blockIdx.x] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-        if (blockIdx.x == 0) *flag_count = 0;
+        if (blockIdx.x == 0) flag_count[0] = flag_count[1] = 0;
     }
 }
 
@@ -461,7 +449,7 @@ __global__ __launch_bounds__(1024) void knn_prep_kernel(const float* __restrict_
         }
         bmax[blockIdx.x] = bm;
         midflag[blockIdx.x] = fl;
-        if (blockIdx.x == 0) *flag_count = 0;
+        if (blockIdx.x == 0) flag_count[0] = flag_count[1] = 0;
     }
 }
 
@@ -991,7 +979,8 @@ __global__ __launch_bounds__(256) void knn_refine_kernel(
     const float* __restrict__ cand_s, const int* __restrict__ cand_i, int rows_per_block, int tiles, int64_t units,
     int G, int smax, int nsub, int force_mode, const int* __restrict__ midflag, const float* __restrict__ bmax,
     int* __restrict__ idx_out, float* __restrict__ dist_out,
-    int* __restrict__ flag_count, int* __restrict__ flag_list) {
+    int* __restrict__ flag_count /*[0] flagged queries, [1] rescan items*/, int2* __restrict__ items,
+    int* __restrict__ fb_n, unsigned long long* __restrict__ fb_best) {
     __shared__ __attribute__((aligned(16))) float qrows[4][kDim];
     __shared__ int qual[4][64];
     const int lane = threadIdx.x & 63;
@@ -1090,53 +1079,82 @@ __global__ __launch_bounds__(256) void knn_refine_kernel(
     }
     best2_wave_reduce(b);
 
+    const bool have2 = b.i[1] != INT_MAX;
     if (lane == 0) {
-        const bool have2 = b.i[1] != INT_MAX;
         idx_out[2 * q + 0] = b.i[0] == INT_MAX ? -1 : b.i[0];
         idx_out[2 * q + 1] = have2 ? b.i[1] : -1;
         dist_out[2 * q + 0] = b.d[0];
         dist_out[2 * q + 1] = b.d[1];
-        // Certificate: the filter score already includes |q|^2 (s ~ d^2), and everything the filter discarded
-        // has s >= tau, hence exact d^2 >= tau - eps.  (tau < 0 can only be rounding noise: never certifies.)
-        const bool certified = (tau == kInf) || (have2 && (double)b.dsq[1] + (double)eps < (double)tau);
-        if (!certified) flag_list[atomicAdd(flag_count, 1)] = q;
+    }
+    // Certificate, per stream: the filter score already includes |q|^2 (s ~ d^2) and a stream discards only trains
+    // with s >= its 3rd best s3, hence exact d^2 >= s3 - eps.  A stream with d2^2 + eps < s3 provably hides nothing;
+    // every other FULL stream (s3 finite) is "suspicious" and becomes a rescan item: its <= 512 trains are evaluated
+    // exactly by knn_rescan_kernel and merged into this query's answer.  (s3 < 0 can only be rounding noise: never
+    // certifies.)  Typically 0 streams; a handful for ~0.1 % of the queries; all of them for degenerate train sets.
+    if (tau == kInf) return;                                           // no stream discarded anything
+    const double lim = have2 ? (double)b.dsq[1] + (double)eps : (double)kInf;
+    if (lim < (double)tau) return;                                     // wave-uniform: certified
+    int nsusp = 0;
+    for (int k0 = 0; k0 * 64 < NC; ++k0) {
+        const int c = lane + 64 * k0;
+        const float s3 = (c < NC && c % 3 == 2) ? (k0 == 0 ? rs[0] : k0 == 1 ? rs[1] : k0 == 2 ? rs[2] : k0 == 3 ? rs[3] : cs[c]) : kInf;
+        const unsigned long long m = __ballot(s3 < kInf && !(lim < (double)s3));
+        nsusp += __popcll(m);
+    }
+    int base = 0;
+    if (lane == 0) {
+        base = atomicAdd(flag_count + 1, nsusp);
+        atomicAdd(flag_count, 1);
+        fb_n[q] = nsusp;
+        // the answer so far, as (distance bits, index) keys for the rescan's atomic top-2 merge
+        fb_best[2 * q + 0] = b.i[0] == INT_MAX ? ~0ull : ((unsigned long long)__float_as_uint(b.d[0]) << 32) | (unsigned)b.i[0];
+        fb_best[2 * q + 1] = !have2 ? ~0ull : ((unsigned long long)__float_as_uint(b.d[1]) << 32) | (unsigned)b.i[1];
+    }
+    base = __shfl(base, 0, 64);
+    for (int k0 = 0; k0 * 64 < NC; ++k0) {
+        const int c = lane + 64 * k0;
+        const float s3 = (c < NC && c % 3 == 2) ? (k0 == 0 ? rs[0] : k0 == 1 ? rs[1] : k0 == 2 ? rs[2] : k0 == 3 ? rs[3] : cs[c]) : kInf;
+        const bool susp = s3 < kInf && !(lim < (double)s3);
+        const unsigned long long m = __ballot(susp);
+        if (susp) items[base + __popcll(m & ((1ull << lane) - 1ull))] = make_int2(q, c / 3);
+        base += __popcll(m);
     }
 }
 
-// ---------------------------------------------------------------- exact fallback
-// Work item = (flagged query, chunk of trains).  A fixed grid strides over the items, so a single
-// flagged query is still spread over many CUs; a second small kernel merges the per-chunk top-2
-// (lexicographic (dist, idx) order is associative, so the result equals the sequential scan).
-struct Best2Rec {
-    float d0, q0, d1, q1;
-    int i0, i1;
-};
+// ---------------------------------------------------------------- exact rescan of suspicious streams
+// One work item = (query, stream): the <= 32 tiles x 16 rows a filter stream covered are evaluated with the reference
+// arithmetic, one train per thread, and the item's two best (distance, index) keys are merged into the query's
+// answer with 64-bit atomic minima: `old = atomicMin(best0, key); if (old != key) atomicMin(best1, max(old, key))`
+// keeps the two smallest DISTINCT keys whatever the arrival order (a key equal to the current minimum is the same
+// train seen twice — the stream's own top-3 were already evaluated by the refine kernel — and is dropped).
+// The item that draws a query's last ticket publishes the answer (release -> relaxed ticket -> acquire; tickets are
+// zeroed by the prep / norms kernel of the same call).
+constexpr int kRescanBlocks = 1024;
 
-constexpr int kFbScanBlocks = 512;
-
-// One launch: every (flagged query, train chunk) item writes its partial top-2, publishes it with an agent-scope
-// release and takes a ticket; the workgroup that draws the LAST ticket of a query acquires and merges that query's
-// partials (cdna guide G16: release -> relaxed atomic -> acquire, placement independent).  Tickets are zeroed by the
-// prep / norms kernel of the same call.
-__global__ __launch_bounds__(256) void knn_fallback_kernel(
-    const float* __restrict__ Q, int64_t ldq, const float* __restrict__ T, int64_t ldt, int nt, int nch, int chunk,
-    const int* __restrict__ flag_count, const int* __restrict__ flag_list, Best2Rec* __restrict__ partial,
-    int* __restrict__ tickets, int* __restrict__ idx_out, float* __restrict__ dist_out, int* __restrict__ stats, int G,
-    int NS, int force_mode, const int* __restrict__ midflag, const float* __restrict__ bmax) {
+__global__ __launch_bounds__(256) void knn_rescan_kernel(
+    const float* __restrict__ Q, int64_t ldq, const float* __restrict__ T, int64_t ldt, int nt, int rows_per_block,
+    int tiles, int64_t units, int G, int nsub, const int* __restrict__ flag_count, const int2* __restrict__ items,
+    const int* __restrict__ fb_n, unsigned long long* __restrict__ fb_best, int* __restrict__ tickets,
+    int* __restrict__ idx_out, float* __restrict__ dist_out, int* __restrict__ stats, int NS, int force_mode,
+    const int* __restrict__ midflag, const float* __restrict__ bmax) {
     __shared__ __attribute__((aligned(16))) float qrow[kDim];
     __shared__ Best2 wbest[4];
-    __shared__ int last_s;
-    const int nflag = *flag_count;
+    const int nitems = flag_count[1];
     if (blockIdx.x == 0 && threadIdx.x < 64 && stats) {
         const int mode = force_mode >= 0 ? force_mode : knn_filter_mode(midflag, bmax, threadIdx.x);
         if (threadIdx.x == 0) {
-            stats[0] = nflag; stats[1] = G; stats[2] = NS; stats[3] = mode;
+            stats[0] = flag_count[0]; stats[1] = G; stats[2] = NS; stats[3] = mode;
         }
     }
-    const int64_t items = (int64_t)nflag * nch;
-    for (int64_t it = blockIdx.x; it < items; it += gridDim.x) {
-        const int f = (int)(it / nch), ch = (int)(it - (int64_t)f * nch);
-        const int q = flag_list[f];
+    for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
+        const int2 item = items[it];
+        const int q = item.x, sid = item.y;
+        const int slot = sid / (2 * nsub), sb = (sid % (2 * nsub)) >> 1, h = sid & 1;
+        const int rb = q / rows_per_block;
+        const int wg = block_of_unit(units, G, (int64_t)rb * tiles) + slot;
+        const int64_t u0 = max(unit_begin(units, G, wg), (int64_t)rb * tiles), u1 = min(unit_begin(units, G, wg + 1), (int64_t)(rb + 1) * tiles);
+        const int t_begin = (int)(u0 - (int64_t)rb * tiles) + kSubTiles * sb;
+        const int t_end = min((int)(u1 - (int64_t)rb * tiles), t_begin + kSubTiles);
         __syncthreads();
         if (threadIdx.x < 32)
             *reinterpret_cast<float4*>(&qrow[4 * threadIdx.x]) =
@@ -1144,10 +1162,13 @@ __global__ __launch_bounds__(256) void knn_fallback_kernel(
         __syncthreads();
         Best2 b;
         b.d[0] = b.d[1] = kInf; b.dsq[0] = b.dsq[1] = kInf; b.i[0] = b.i[1] = INT_MAX;
-        const int t_end = min(nt, (ch + 1) * chunk);
-        for (int t = ch * chunk + threadIdx.x; t < t_end; t += 256) {
-            const float dsq = exact_l2sq_128(qrow, T + (int64_t)t * ldt);
-            best2_insert(b, sqrtf(dsq), dsq, t);
+        for (int i = threadIdx.x; i < (t_end - t_begin) * 16; i += 256) {
+            const int r = i & 15;
+            const int t = (t_begin + (i >> 4)) * kTileT + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (t < nt) {
+                const float dsq = exact_l2sq_128(qrow, T + (int64_t)t * ldt);
+                best2_insert(b, sqrtf(dsq), dsq, t);
+            }
         }
         best2_wave_reduce(b);
         if ((threadIdx.x & 63) == 0) wbest[threadIdx.x >> 6] = b;
@@ -1158,29 +1179,25 @@ __global__ __launch_bounds__(256) void knn_fallback_kernel(
                 best2_insert(r, wbest[w].d[0], wbest[w].dsq[0], wbest[w].i[0]);
                 best2_insert(r, wbest[w].d[1], wbest[w].dsq[1], wbest[w].i[1]);
             }
-            Best2Rec o{r.d[0], r.dsq[0], r.d[1], r.dsq[1], r.i[0], r.i[1]};
-            partial[it] = o;
+            unsigned long long* best = fb_best + 2 * (int64_t)q;
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+                if (r.i[e] != INT_MAX) {
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(r.d[e]) << 32) | (unsigned)r.i[e];
+                    const unsigned long long old = __hip_atomic_fetch_min(best, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (old != key)
+                        __hip_atomic_fetch_min(best + 1, old > key ? old : key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const int ticket = __hip_atomic_fetch_add(&tickets[f], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            last_s = (ticket == nch - 1) ? 1 : 0;
-            if (last_s) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        __syncthreads();
-        if (last_s && threadIdx.x < 64) {          // one wave merges this query's nch partials
-            Best2 m;
-            m.d[0] = m.d[1] = kInf; m.dsq[0] = m.dsq[1] = kInf; m.i[0] = m.i[1] = INT_MAX;
-            for (int c = threadIdx.x; c < nch; c += 64) {
-                const Best2Rec r = partial[(int64_t)f * nch + c];
-                best2_insert(m, r.d0, r.q0, r.i0);
-                best2_insert(m, r.d1, r.q1, r.i1);
-            }
-            best2_wave_reduce(m);
-            if (threadIdx.x == 0) {
-                idx_out[2 * q + 0] = m.i[0] == INT_MAX ? -1 : m.i[0];
-                idx_out[2 * q + 1] = m.i[1] == INT_MAX ? -1 : m.i[1];
-                dist_out[2 * q + 0] = m.d[0];
-                dist_out[2 * q + 1] = m.d[1];
+            const int ticket = __hip_atomic_fetch_add(&tickets[q], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ticket == fb_n[q] - 1) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                const unsigned long long k0 = __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long k1 = __hip_atomic_load(best + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                idx_out[2 * q + 0] = k0 == ~0ull ? -1 : (int)(unsigned)k0;
+                idx_out[2 * q + 1] = k1 == ~0ull ? -1 : (int)(unsigned)k1;
+                dist_out[2 * q + 0] = k0 == ~0ull ? kInf : __uint_as_float((unsigned)(k0 >> 32));
+                dist_out[2 * q + 1] = k1 == ~0ull ? kInf : __uint_as_float((unsigned)(k1 >> 32));
             }
         }
     }
@@ -1306,9 +1323,10 @@ struct KnnWs {
     float* tn;
     float* bmax;
     int* midflag;
-    Best2Rec* fb_partial;
-    int* flag_count;
-    int* flag_list;
+    int* flag_count;              // [0] queries with rescan items, [1] rescan items
+    int2* items;                  // (query, stream) rescan work list, worst case every stream of every query
+    int* fb_n;                    // items per flagged query
+    unsigned long long* fb_best;  // [nq][2] (distance bits << 32 | index) keys of flagged queries
     int* tickets;
     float* cand_s;
     int* cand_i;
@@ -1320,13 +1338,14 @@ KnnWs carve_ws(void* ws, int64_t nq, int64_t nt, const Plan& p) {
     KnnWs w;
     w.bmax = c.take<float>(kNormBlocks);
     w.midflag = c.take<int>(kNormBlocks);
-    w.flag_count = c.take<int>(1);
-    w.fb_partial = c.take<Best2Rec>((size_t)nq * p.fb_nch);
+    w.flag_count = c.take<int>(2);
+    w.fb_best = c.take<unsigned long long>((size_t)nq * 2);
+    w.fb_n = c.take<int>((size_t)nq);
     w.tn = c.take<float>((size_t)p.tiles * kTileT);
     w.qn = c.take<float>((size_t)p.nq_pad);
     w.qsplit = c.take<unsigned short>((size_t)p.nq_pad * kDim * 3);
     w.tsplit = c.take<unsigned short>((size_t)p.tiles * kTileT * kDim * 3);
-    w.flag_list = c.take<int>((size_t)nq);
+    w.items = c.take<int2>((size_t)nq * 2 * p.smax * p.nsub);
     w.tickets = c.take<int>((size_t)nq);
     w.cand_s = c.take<float>((size_t)nq * 2 * p.smax * p.nsub * 3);
     w.cand_i = c.take<int>((size_t)nq * 2 * p.smax * p.nsub * 3);
@@ -1451,12 +1470,11 @@ extern "C" int sfm_knn2_l2_f32(const float* q, int64_t nq, int64_t ldq, const fl
     hipLaunchKernelGGL(knn_refine_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream, q, ldq, (int)nq, t, ldt,
                        w.cand_s, w.cand_i, p.rows_per_block, p.tiles, p.units, p.G, p.smax * p.nsub, p.nsub,
                        force_mode, w.midflag, w.bmax, idx, dist,
-                       w.flag_count,
-                       w.flag_list);
+                       w.flag_count, w.items, w.fb_n, w.fb_best);
     SFM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(knn_fallback_kernel, dim3(kFbScanBlocks), dim3(256), 0, stream, q, ldq, t, ldt, (int)nt, p.fb_nch,
-                       p.fb_chunk, w.flag_count, w.flag_list, w.fb_partial, w.tickets, idx, dist, stats, p.G,
-                       2 * p.smax * p.nsub, force_mode, w.midflag, w.bmax);
+    hipLaunchKernelGGL(knn_rescan_kernel, dim3(kRescanBlocks), dim3(256), 0, stream, q, ldq, t, ldt, (int)nt,
+                       p.rows_per_block, p.tiles, p.units, p.G, p.nsub, w.flag_count, w.items, w.fb_n, w.fb_best, w.tickets,
+                       idx, dist, stats, 2 * p.smax * p.nsub, force_mode, w.midflag, w.bmax);
     sfm::prof_end(sfm::kProfKnnRefine, stream);
     SFM_CHECK_LAUNCH();
     return SFM_OK;
