@@ -53,7 +53,7 @@ const char* sfm_last_error(void);
  *   idx_dev [nq x 2]   int32   trainIdx of 1st / 2nd neighbour (-1 if nt < k)
  *   dist_dev[nq x 2]   float32 DMatch.distance            (+inf if nt < k)
  *   stats_dev (optional, may be NULL) int32[4]:
- *       [0] queries resolved by the exact full-scan fallback
+ *       [0] queries for which at least one filter stream had to be rescanned exactly
  *       [1] filter workgroups launched   [2] candidate streams reserved per query
  *       [3] filter arithmetic that ran: 0 fp16 single product, exact inputs; 1 fp16 single product;
  *           2 bf16 hi/mid split; 3 fp32 MFMA

@@ -100,15 +100,14 @@ Plan make_plan(int64_t nq, int64_t nt) {
 
 // ---------------------------------------------------------------- norms
 // ||t||^2 per train row (32 lanes per row, one float4 each) + one max per block (no atomics: a
-// single hot atomicMax address costs ~12 ns per arrival).  Block 0 also zeroes the fallback counter,
+// single hot atomicMax address costs ~12 ns per arrival).  Block 0 also zeroes the rescan counter,
 // so the pipeline needs no memset launch.
 constexpr int kNormBlocks = 256;
 
 __global__ __launch_bounds__(256) void knn_norms_kernel(const float* __restrict__ T, int64_t ldt, int nt,
                                                         float* __restrict__ tn, float* __restrict__ bmax,
-                                                        int* __restrict__ flag_count, int* __restrict__ tickets, int nq) {
+                                                        int* __restrict__ stats) {
     __shared__ float wmax[4];
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < nq; i += gridDim.x * 256) tickets[i] = 0;   // fallback tickets
     const int l = threadIdx.x & 31;
     float mx = 0.f;
     for (int row = blockIdx.x * 8 + (threadIdx.x >> 5); row < nt; row += gridDim.x * 8) {
@@ -125,7 +124,7 @@ __global__ __launch_bounds__(256) void knn_norms_kernel(const float* __restrict_
     __syncthreads();
     if (threadIdx.x == 0) {
         bmax[blockIdx.x] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-        if (blockIdx.x == 0) flag_count[0] = flag_count[1] = 0;
+        if (blockIdx.x == 0 && stats) stats[0] = 0;   // rescanned-query counter (refine kernel)
     }
 }
 
@@ -385,21 +384,20 @@ __device__ __forceinline__ int knn_filter_mode(const int* __restrict__ flags, co
 }
 
 // One pass over Q and T: rows → (hi, mid) bf16 images and an fp16 image (Q pre-scaled by -2, exact), fp32 squared
-// norms, per-block max of ||t||^2 and exactness / range flags, zero the fallback counter.  Rows >= n of the padded
+// norms, per-block max of ||t||^2 and exactness / range flags, zero the rescan counter.  Rows >= n of the padded
 // images are zero-filled.  Image layout: [3][n_pad][128] 16-bit: bf16 hi, bf16 mid, fp16.
 __global__ __launch_bounds__(1024) void knn_prep_kernel(const float* __restrict__ Q, int64_t ldq, int nq, int nq_pad,
                                                        const float* __restrict__ T, int64_t ldt, int nt, int nt_pad,
                                                        unsigned short* __restrict__ qsplit, float* __restrict__ qn,
                                                        unsigned short* __restrict__ tsplit, float* __restrict__ tn,
                                                        float* __restrict__ bmax, int* __restrict__ midflag,
-                                                       int* __restrict__ flag_count, int* __restrict__ tickets) {
+                                                       int* __restrict__ stats) {
     __shared__ float wmax[16];
     __shared__ int wmid[16];
     const int l = threadIdx.x & 31;
     float mx = 0.f;
     unsigned flags = 0;
     const int rows = nq_pad + nt_pad;
-    for (int i = blockIdx.x * 1024 + threadIdx.x; i < nq; i += gridDim.x * 1024) tickets[i] = 0;   // fallback tickets
     for (int row = blockIdx.x * 32 + (threadIdx.x >> 5); row < rows; row += gridDim.x * 32) {   // 32 rows in flight per block
         const bool isq = row < nq_pad;
         const int r = isq ? row : row - nq_pad;
@@ -449,7 +447,7 @@ __global__ __launch_bounds__(1024) void knn_prep_kernel(const float* __restrict_
         }
         bmax[blockIdx.x] = bm;
         midflag[blockIdx.x] = fl;
-        if (blockIdx.x == 0) flag_count[0] = flag_count[1] = 0;
+        if (blockIdx.x == 0 && stats) stats[0] = 0;   // rescanned-query counter (refine kernel)
     }
 }
 
@@ -909,6 +907,22 @@ __device__ __forceinline__ float exact_l2sq_128(const float* __restrict__ qrow /
     return ((s0 + s1) + s2) + s3;
 }
 
+// Lane exchanges without an address register: lane ^ M by DPP quad_perm (M = 1, 2) or ds_swizzle bit mode
+// (M = 4, 8, 16); __shfl_xor compiles to ds_bpermute and keeps one address VGPR alive per distinct pattern.
+template <int M>
+__device__ __forceinline__ int lane_xor(int v) {
+    if constexpr (M == 1) return __builtin_amdgcn_update_dpp(0, v, 0xB1 /*quad_perm [1,0,3,2]*/, 0xF, 0xF, false);
+    else if constexpr (M == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4E /*quad_perm [2,3,0,1]*/, 0xF, 0xF, false);
+    else if constexpr (M == 4 || M == 8 || M == 16) return __builtin_amdgcn_ds_swizzle(v, 0x1F | (M << 10));
+    else return __shfl_xor(v, M, 64);
+}
+template <int M>
+__device__ __forceinline__ float lane_xor(float v) { return __int_as_float(lane_xor<M>(__float_as_int(v))); }
+// value of the next lane inside an aligned pair (valid on even lanes) / of lane 3 on lane 2 of a quad
+__device__ __forceinline__ float lane_odd_neighbour(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xF5 /*quad_perm [1,1,3,3]*/, 0xF, 0xF, false));
+}
+
 struct Best2 {
     float d[2];     // sqrtf distance
     float dsq[2];   // its square (certificate)
@@ -972,234 +986,427 @@ constexpr float kEpsHalf = kEpsExact + 4.8840e-4f;
 constexpr float kEpsHalfAbs = 1.3811e-3f;
 constexpr int kModeF32 = 3;   // fp32-MFMA filter (host-selected)
 
-constexpr int kRefineMaxCand = 256;   // candidates kept in registers per wave (4 per lane); more → second sweep
+__device__ __forceinline__ void best2_insert_unique(Best2& b, float d, float dsq, int i) {
+    if (i == b.i[0] || i == b.i[1]) return;          // the same train seen twice (a stream's own top-3 are rescanned)
+    best2_insert(b, d, dsq, i);
+}
 
-__global__ __launch_bounds__(256) void knn_refine_kernel(
-    const float* __restrict__ Q, int64_t ldq, int nq, const float* __restrict__ T, int64_t ldt,
-    const float* __restrict__ cand_s, const int* __restrict__ cand_i, int rows_per_block, int tiles, int64_t units,
-    int G, int smax, int nsub, int force_mode, const int* __restrict__ midflag, const float* __restrict__ bmax,
-    int* __restrict__ idx_out, float* __restrict__ dist_out,
-    int* __restrict__ flag_count /*[0] flagged queries, [1] rescan items*/, int2* __restrict__ items,
-    int* __restrict__ fb_n, unsigned long long* __restrict__ fb_best) {
-    __shared__ __attribute__((aligned(16))) float qrows[4][kDim];
-    __shared__ int qual[4][64];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int q = blockIdx.x * 4 + wave;
-    const bool valid = q < nq;
+template <int M>
+__device__ __forceinline__ void best2_exchange_step(Best2& b) {
+    Best2 o;
+    o.d[0] = lane_xor<M>(b.d[0]); o.dsq[0] = lane_xor<M>(b.dsq[0]); o.i[0] = lane_xor<M>(b.i[0]);
+    o.d[1] = lane_xor<M>(b.d[1]); o.dsq[1] = lane_xor<M>(b.dsq[1]); o.i[1] = lane_xor<M>(b.i[1]);
+    best2_insert_unique(b, o.d[0], o.dsq[0], o.i[0]);
+    best2_insert_unique(b, o.d[1], o.dsq[1], o.i[1]);
+}
 
-    float qq = 0.f;
-    if (valid && lane < 32) {
-        const float4 v = *reinterpret_cast<const float4*>(Q + (int64_t)q * ldq + 4 * lane);
-        *reinterpret_cast<float4*>(&qrows[wave][4 * lane]) = v;
-        qq = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-    }
-    __syncthreads();
-    if (!valid) return;
+template <int WIDTH>
+__device__ __forceinline__ void best2_group_reduce(Best2& b) {      // all lanes of a WIDTH-lane group end up equal
+    if constexpr (WIDTH >= 64) best2_exchange_step<32>(b);
+    if constexpr (WIDTH >= 32) best2_exchange_step<16>(b);
+    if constexpr (WIDTH >= 16) best2_exchange_step<8>(b);
+    if constexpr (WIDTH >= 8) best2_exchange_step<4>(b);
+    best2_exchange_step<2>(b);
+    best2_exchange_step<1>(b);
+}
+
+// Exact d^2 with FOUR lanes per train (a quad).  Lane j loads the float4 at elements 16n + 4j (n = 0..7), so a quad
+// reads 64 contiguous bytes per instruction (a lane-per-row or 8-lane layout touches 2-4x as many cache lines per
+// instruction, and the L1 tag rate is what bounds these kernels).  Element 16n + 4j + c belongs to accumulator lane
+// a = 4(j&1) + c of the reference's 2x4-lane order at step i = 2n + (j>>1): the running sums alternate between the
+// quad's lower and upper lane pair, acc <- swap_pairs(acc) + x, 16 steps, each add rounded exactly as the
+// reference's.  All four lanes execute every step; a pair's "off" steps produce values that are overwritten before
+// anyone reads them.  Result valid on lane j == 2.
+__device__ __forceinline__ float quad_swap(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E /*quad_perm [2,3,0,1]*/, 0xF, 0xF, false));
+}
+
+__device__ __forceinline__ float exact_l2sq_quad(const float* __restrict__ qrow /*LDS*/, const float* __restrict__ trow, int j) {
+    float4 t[8];
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) qq += __shfl_xor(qq, m, 64);
-
-    // Slack that dominates: rounding of the filter's dot-product chain, of ||q||^2, ||t||^2, of the direct-form
-    // sums (<= 24u*d^2) and the final sqrtf merge (8u*d^2) — 600u*(|q|+|t|max)^2, u = 2^-24 — plus what the chosen
-    // filter loses on top (packed keys; split-bf16 products): eps_coef, see kEpsF32 / kEpsSplit.
-    float tmax;
-    int mode = knn_filter_mode(midflag, bmax, lane, &tmax);
-    if (force_mode >= 0) mode = force_mode;
-    const float nsum = sqrtf(qq) + sqrtf(tmax);
-    const float eps_coef = mode == kModeHalfExact ? kEpsExact : mode == kModeHalf ? kEpsHalf : mode == kModeSplit ? kEpsSplit : kEpsF32;
-    const float eps = 1.01f * (eps_coef * nsum * nsum + (mode == kModeHalf ? kEpsHalfAbs * nsum : 0.f));
-
-    // streams of this query's row block = filter blocks that touched it (contiguous slots from 0)
-    const int rb = q / rows_per_block;
-    const int fb = block_of_unit(units, G, (int64_t)rb * tiles);
-    const int lb = block_of_unit(units, G, (int64_t)(rb + 1) * tiles - 1);
-    const int NC = 2 * (lb - fb + 1) * nsub * 3;
-    const float* cs = cand_s + (int64_t)q * (2 * smax * 3);
-    const int* ci = cand_i + (int64_t)q * (2 * smax * 3);
-
-    // Sweep 1 (registers for the first 256 candidates): two smallest filter scores, and tau = the smallest score
-    // any DISCARDED train can have (every stream discards only trains >= its 3rd best).
-    float rs[4];
-    int ri[4];
-    float m1 = kInf, m2 = kInf, tau = kInf;
+    for (int n = 0; n < 8; ++n) t[n] = *reinterpret_cast<const float4*>(trow + 16 * n + 4 * j);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int c = lane + 64 * k;
-        rs[k] = c < NC ? cs[c] : kInf;
-        ri[k] = c < NC ? ci[c] : -1;
-        if (c % 3 == 2) tau = fminf(tau, rs[k]);
-        if (rs[k] < m1) { m2 = m1; m1 = rs[k]; } else if (rs[k] < m2) { m2 = rs[k]; }
-    }
-    for (int c = lane + kRefineMaxCand; c < NC; c += 64) {
-        const float s = cs[c];
-        if (c % 3 == 2) tau = fminf(tau, s);
-        if (s < m1) { m2 = m1; m1 = s; } else if (s < m2) { m2 = s; }
-    }
+    for (int n = 0; n < 8; ++n) {
+        const float4 qv = *reinterpret_cast<const float4*>(qrow + 16 * n + 4 * j);
+        float4 x;
+        float d;
+        d = qv.x - t[n].x; x.x = d * d;
+        d = qv.y - t[n].y; x.y = d * d;
+        d = qv.z - t[n].z; x.z = d * d;
+        d = qv.w - t[n].w; x.w = d * d;
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const float o1 = __shfl_xor(m1, m, 64), o2 = __shfl_xor(m2, m, 64);
-        const float lo = fminf(m1, o1), hi = fmaxf(m1, o1);
-        m2 = fminf(hi, fminf(m2, o2));
-        m1 = lo;
-        tau = fminf(tau, __shfl_xor(tau, m, 64));
-    }
-    // A candidate whose score exceeds the 2nd smallest score by more than 4*eps is strictly
-    // farther (even after sqrtf) than two other candidates: it cannot be in the exact top-2.
-    const float thr = m2 + 4.f * eps;
-
-    Best2 b;
-    b.d[0] = b.d[1] = kInf; b.dsq[0] = b.dsq[1] = kInf; b.i[0] = b.i[1] = INT_MAX;
-    const int grp = lane >> 3, sl = lane & 7;
-    // Sweep 2: survivors are compacted into an LDS list (64 at a time) and evaluated 8 per pass, 8 lanes each.
-    for (int k0 = 0; k0 * 64 < NC; ++k0) {
-        float s;
-        int id;
-        if (k0 < 4) {
-            s = k0 == 0 ? rs[0] : k0 == 1 ? rs[1] : k0 == 2 ? rs[2] : rs[3];
-            id = k0 == 0 ? ri[0] : k0 == 1 ? ri[1] : k0 == 2 ? ri[2] : ri[3];
-        } else {
-            const int c = lane + 64 * k0;
-            s = c < NC ? cs[c] : kInf;
-            id = c < NC ? ci[c] : -1;
+        for (int half = 0; half < 2; ++half) {            // step 2n: lower pair live; step 2n+1: upper pair live
+            acc.x = quad_swap(acc.x) + x.x;
+            acc.y = quad_swap(acc.y) + x.y;
+            acc.z = quad_swap(acc.z) + x.z;
+            acc.w = quad_swap(acc.w) + x.w;
         }
-        const bool take = id >= 0 && s <= thr;
-        const unsigned long long mask = __ballot(take);
-        if (mask == 0) continue;
-        const int nsel = __popcll(mask);
-        if (take) qual[wave][__popcll(mask & ((1ull << lane) - 1ull))] = id;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        for (int e0 = 0; e0 < nsel; e0 += 8) {
-            const int e = e0 + grp;
-            const int tid = e < nsel ? qual[wave][e] : qual[wave][0];
-            const float dsq = exact_l2sq_group8(qrows[wave], T + (int64_t)tid * ldt, sl);
-            if (sl == 0 && e < nsel) best2_insert(b, sqrtf(dsq), dsq, tid);
-        }
-        __builtin_amdgcn_wave_barrier();
     }
-    best2_wave_reduce(b);
+    // lane 2 holds accumulator lanes 0..3, lane 3 holds 4..7:  s_c = acc_c + acc_{c+4},  d^2 = ((s0 + s1) + s2) + s3
+    const float s0 = acc.x + lane_odd_neighbour(acc.x), s1 = acc.y + lane_odd_neighbour(acc.y);
+    const float s2 = acc.z + lane_odd_neighbour(acc.z), s3 = acc.w + lane_odd_neighbour(acc.w);
+    return ((s0 + s1) + s2) + s3;
+}
 
-    const bool have2 = b.i[1] != INT_MAX;
-    if (lane == 0) {
-        idx_out[2 * q + 0] = b.i[0] == INT_MAX ? -1 : b.i[0];
-        idx_out[2 * q + 1] = have2 ? b.i[1] : -1;
-        dist_out[2 * q + 0] = b.d[0];
-        dist_out[2 * q + 1] = b.d[1];
+// Exact d^2 with TWO lanes per train: lane p owns accumulator lanes 4p..4p+3 of the reference order for all 16
+// steps (float4 at elements 8i + 4p), so there is no cross-lane chain and 8 candidates of a 16-lane query group are
+// evaluated in ONE pass — the latency-optimal layout for the refine kernel's short candidate lists.
+// Result valid on the even lane.
+__device__ __forceinline__ float exact_l2sq_pair(const float* __restrict__ qrow /*LDS*/, const float* __restrict__ trow, int p) {
+    float4 t[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t[i] = *reinterpret_cast<const float4*>(trow + 8 * i + 4 * p);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    __builtin_amdgcn_sched_barrier(0);                   // all 16 row fetches first ...
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        // ... and the query reads / products at most 4 steps ahead of the adds (hipcc otherwise hoists all of them:
+        // 190 VGPRs, 2 waves per SIMD, and the refine kernel needs 3 for a single resident round at 10^4 queries)
+        if (i % 4 == 0) __builtin_amdgcn_sched_barrier(0);
+        const float4 qv = *reinterpret_cast<const float4*>(qrow + 8 * i + 4 * p);
+        float d;
+        d = qv.x - t[i].x; acc.x = acc.x + d * d;
+        d = qv.y - t[i].y; acc.y = acc.y + d * d;
+        d = qv.z - t[i].z; acc.z = acc.z + d * d;
+        d = qv.w - t[i].w; acc.w = acc.w + d * d;
     }
-    // Certificate, per stream: the filter score already includes |q|^2 (s ~ d^2) and a stream discards only trains
-    // with s >= its 3rd best s3, hence exact d^2 >= s3 - eps.  A stream with d2^2 + eps < s3 provably hides nothing;
-    // every other FULL stream (s3 finite) is "suspicious" and becomes a rescan item: its <= 512 trains are evaluated
-    // exactly by knn_rescan_kernel and merged into this query's answer.  (s3 < 0 can only be rounding noise: never
-    // certifies.)  Typically 0 streams; a handful for ~0.1 % of the queries; all of them for degenerate train sets.
-    if (tau == kInf) return;                                           // no stream discarded anything
-    const double lim = have2 ? (double)b.dsq[1] + (double)eps : (double)kInf;
-    if (lim < (double)tau) return;                                     // wave-uniform: certified
-    int nsusp = 0;
-    for (int k0 = 0; k0 * 64 < NC; ++k0) {
-        const int c = lane + 64 * k0;
-        const float s3 = (c < NC && c % 3 == 2) ? (k0 == 0 ? rs[0] : k0 == 1 ? rs[1] : k0 == 2 ? rs[2] : k0 == 3 ? rs[3] : cs[c]) : kInf;
-        const unsigned long long m = __ballot(s3 < kInf && !(lim < (double)s3));
-        nsusp += __popcll(m);
+    const float s0 = acc.x + lane_odd_neighbour(acc.x), s1 = acc.y + lane_odd_neighbour(acc.y);
+    const float s2 = acc.z + lane_odd_neighbour(acc.z), s3 = acc.w + lane_odd_neighbour(acc.w);
+    return ((s0 + s1) + s2) + s3;
+}
+
+// exact_l2sq_quad for R trains at once: all 8R row fetches are issued before the first add (the rescan is bound by
+// memory round trips, not arithmetic).  trow[r] == nullptr skips row r.
+template <int R>
+__device__ __forceinline__ void exact_l2sq_quad_rows(const float* __restrict__ qrow /*LDS*/, const float* const (&trow)[R], int j,
+                                                     float (&out)[R]) {
+    float4 t[R][8];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int n = 0; n < 8; ++n)
+            t[r][n] = trow[r] ? *reinterpret_cast<const float4*>(trow[r] + 16 * n + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        const float4 qv = *reinterpret_cast<const float4*>(qrow + 16 * n + 4 * j);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float4 x;
+            float d;
+            d = qv.x - t[r][n].x; x.x = d * d;
+            d = qv.y - t[r][n].y; x.y = d * d;
+            d = qv.z - t[r][n].z; x.z = d * d;
+            d = qv.w - t[r][n].w; x.w = d * d;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                acc[r].x = quad_swap(acc[r].x) + x.x;
+                acc[r].y = quad_swap(acc[r].y) + x.y;
+                acc[r].z = quad_swap(acc[r].z) + x.z;
+                acc[r].w = quad_swap(acc[r].w) + x.w;
+            }
+        }
     }
-    int base = 0;
-    if (lane == 0) {
-        base = atomicAdd(flag_count + 1, nsusp);
-        atomicAdd(flag_count, 1);
-        fb_n[q] = nsusp;
-        // the answer so far, as (distance bits, index) keys for the rescan's atomic top-2 merge
-        fb_best[2 * q + 0] = b.i[0] == INT_MAX ? ~0ull : ((unsigned long long)__float_as_uint(b.d[0]) << 32) | (unsigned)b.i[0];
-        fb_best[2 * q + 1] = !have2 ? ~0ull : ((unsigned long long)__float_as_uint(b.d[1]) << 32) | (unsigned)b.i[1];
-    }
-    base = __shfl(base, 0, 64);
-    for (int k0 = 0; k0 * 64 < NC; ++k0) {
-        const int c = lane + 64 * k0;
-        const float s3 = (c < NC && c % 3 == 2) ? (k0 == 0 ? rs[0] : k0 == 1 ? rs[1] : k0 == 2 ? rs[2] : k0 == 3 ? rs[3] : cs[c]) : kInf;
-        const bool susp = s3 < kInf && !(lim < (double)s3);
-        const unsigned long long m = __ballot(susp);
-        if (susp) items[base + __popcll(m & ((1ull << lane) - 1ull))] = make_int2(q, c / 3);
-        base += __popcll(m);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float s0 = acc[r].x + lane_odd_neighbour(acc[r].x), s1 = acc[r].y + lane_odd_neighbour(acc[r].y);
+        const float s2 = acc[r].z + lane_odd_neighbour(acc[r].z), s3 = acc[r].w + lane_odd_neighbour(acc[r].w);
+        out[r] = ((s0 + s1) + s2) + s3;
     }
 }
 
-// ---------------------------------------------------------------- exact rescan of suspicious streams
-// One work item = (query, stream): the <= 32 tiles x 16 rows a filter stream covered are evaluated with the reference
-// arithmetic, one train per thread, and the item's two best (distance, index) keys are merged into the query's
-// answer with 64-bit atomic minima: `old = atomicMin(best0, key); if (old != key) atomicMin(best1, max(old, key))`
-// keeps the two smallest DISTINCT keys whatever the arrival order (a key equal to the current minimum is the same
-// train seen twice — the stream's own top-3 were already evaluated by the refine kernel — and is dropped).
-// The item that draws a query's last ticket publishes the answer (release -> relaxed ticket -> acquire; tickets are
-// zeroed by the prep / norms kernel of the same call).
-constexpr int kRescanBlocks = 1024;
+constexpr int kRefQ = 16;        // queries per refine workgroup: 16 lanes each
+constexpr int kRefRegs = 6;      // candidates per lane kept in registers (96 per query); more are re-read
+constexpr int kRescanRows = 2;   // trains a quad has in flight during a rescan (32 VGPRs each)
+constexpr int kRefItems = 128;   // rescan items one round can hold (16 queries x at most 6 streams per 16 candidates)
 
-__global__ __launch_bounds__(256) void knn_rescan_kernel(
-    const float* __restrict__ Q, int64_t ldq, const float* __restrict__ T, int64_t ldt, int nt, int rows_per_block,
-    int tiles, int64_t units, int G, int nsub, const int* __restrict__ flag_count, const int2* __restrict__ items,
-    const int* __restrict__ fb_n, unsigned long long* __restrict__ fb_best, int* __restrict__ tickets,
-    int* __restrict__ idx_out, float* __restrict__ dist_out, int* __restrict__ stats, int NS, int force_mode,
-    const int* __restrict__ midflag, const float* __restrict__ bmax) {
-    __shared__ __attribute__((aligned(16))) float qrow[kDim];
+// Sixteen lanes per query, sixteen queries per workgroup (one resident round for 10^4 queries).
+//   sweep 1  two smallest filter scores over the query's candidate records and each stream's 3rd best
+//   sweep 2  candidates within 4*eps of the 2nd smallest score are compacted and evaluated exactly → (d1, d2)
+//   certify  per stream: the filter score includes |q|^2 (s ~ d^2) and a stream discards only trains with s >= its
+//            3rd best s3, hence exact d^2 >= s3 - eps; a stream with d2^2 + eps < s3 provably hides nothing.
+//   rescan   every other FULL stream (typically none; a handful for ~0.1 % of the queries; all of them for degenerate
+//            train sets) has its <= 512 trains evaluated exactly by the whole workgroup and merged into the query's
+//            answer.  After that the answer equals a full direct-form scan.
+__global__ __launch_bounds__(256, 3) void knn_refine_kernel(
+    const float* __restrict__ Q, int64_t ldq, int nq, const float* __restrict__ T, int64_t ldt, int nt,
+    const float* __restrict__ cand_s, const int* __restrict__ cand_i, int rows_per_block, int tiles, int64_t units,
+    int G, int smax, int nsub, int force_mode, const int* __restrict__ midflag, const float* __restrict__ bmax,
+    const unsigned short* __restrict__ thalf /*fp16 image of T, or null*/, const float* __restrict__ tn,
+    int* __restrict__ idx_out, float* __restrict__ dist_out, int* __restrict__ stats, long long* __restrict__ trace) {
+    __shared__ __attribute__((aligned(16))) float qrows[kRefQ][kDim];
+    __shared__ int qual[kRefQ][32];
+    __shared__ int item_q[kRefItems], item_sid[kRefItems];
+    __shared__ double item_lim[kRefItems];
+    __shared__ float item_qq[kRefItems];
+    __shared__ int surv[kSubTiles * 16];
+    __shared__ int nitem, nsurv;
     __shared__ Best2 wbest[4];
-    const int nitems = flag_count[1];
-    if (blockIdx.x == 0 && threadIdx.x < 64 && stats) {
-        const int mode = force_mode >= 0 ? force_mode : knn_filter_mode(midflag, bmax, threadIdx.x);
-        if (threadIdx.x == 0) {
-            stats[0] = flag_count[0]; stats[1] = G; stats[2] = NS; stats[3] = mode;
+    if (trace && threadIdx.x == 0) trace[16 * blockIdx.x + 0] = wall_clock64();   // dev diagnostics
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int sub = lane >> 4, sl = lane & 15;           // query slot inside the wave, lane inside the query
+    const int ql = wave * 4 + sub;                       // query slot inside the workgroup
+    const int q = blockIdx.x * kRefQ + ql;
+    const bool valid = q < nq;
+
+    for (int e = threadIdx.x; e < kRefQ * 32; e += 256) {
+        const int row = blockIdx.x * kRefQ + (e >> 5);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < nq) v = *reinterpret_cast<const float4*>(Q + (int64_t)row * ldq + 4 * (e & 31));
+        *reinterpret_cast<float4*>(&qrows[e >> 5][4 * (e & 31)]) = v;
+    }
+    if (threadIdx.x == 0) nitem = nsurv = 0;
+
+    // Slack that dominates: rounding of the filter's dot-product chain, of ||q||^2, ||t||^2, of the direct-form
+    // sums (<= 24u*d^2) and the final sqrtf merge (8u*d^2) — 600u*(|q|+|t|max)^2, u = 2^-24 — plus what the
+    // filter arithmetic that ran loses on top (packed keys; 16-bit operands): see kEps*.
+    float tmax;
+    int mode = knn_filter_mode(midflag, bmax, lane, &tmax);
+    if (force_mode >= 0) mode = force_mode;
+    const float eps_coef = mode == kModeHalfExact ? kEpsExact : mode == kModeHalf ? kEpsHalf : mode == kModeSplit ? kEpsSplit : kEpsF32;
+
+    // streams of this workgroup's query row block = filter blocks that touched it (contiguous slots from 0);
+    // the queries of a workgroup share the row block (rows_per_block is a multiple of 16)
+    const int rb = (blockIdx.x * kRefQ) / rows_per_block;
+    const int fb = block_of_unit(units, G, (int64_t)rb * tiles);
+    const int lb = block_of_unit(units, G, (int64_t)(rb + 1) * tiles - 1);
+    const int NC = 2 * (lb - fb + 1) * nsub * 3;
+    const float* cs = cand_s + (int64_t)(valid ? q : 0) * (2 * smax * 3);
+    const int* ci = cand_i + (int64_t)(valid ? q : 0) * (2 * smax * 3);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && stats) {
+        stats[1] = G; stats[2] = 2 * smax; stats[3] = mode;
+    }
+
+    // Sweep 1
+    float rs[kRefRegs];
+    int ri[kRefRegs];
+    float m1 = kInf, m2 = kInf, tau = kInf;
+#pragma unroll
+    for (int k = 0; k < kRefRegs; ++k) {
+        const int c = sl + 16 * k;
+        rs[k] = (valid && c < NC) ? cs[c] : kInf;
+        ri[k] = (valid && c < NC) ? ci[c] : -1;
+    }
+    __syncthreads();                                     // query rows in LDS
+    if (trace && threadIdx.x == 0) trace[16 * blockIdx.x + 1] = wall_clock64();
+    float qq;
+    {
+        const float4 a = *reinterpret_cast<const float4*>(&qrows[ql][8 * sl]), c4 = *reinterpret_cast<const float4*>(&qrows[ql][8 * sl + 4]);
+        qq = a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w + c4.x * c4.x + c4.y * c4.y + c4.z * c4.z + c4.w * c4.w;
+    }
+    qq += lane_xor<8>(qq); qq += lane_xor<4>(qq); qq += lane_xor<2>(qq); qq += lane_xor<1>(qq);
+    const float nsum = sqrtf(qq) + sqrtf(tmax);
+    const float eps = 1.01f * (eps_coef * nsum * nsum + (mode == kModeHalf ? kEpsHalfAbs * nsum : 0.f));
+#pragma unroll
+    for (int k = 0; k < kRefRegs; ++k) {
+        if ((sl + 16 * k) % 3 == 2) tau = fminf(tau, rs[k]);
+        if (rs[k] < m1) { m2 = m1; m1 = rs[k]; } else if (rs[k] < m2) { m2 = rs[k]; }
+    }
+    if (valid)
+        for (int c = sl + 16 * kRefRegs; c < NC; c += 16) {
+            const float s = cs[c];
+            if (c % 3 == 2) tau = fminf(tau, s);
+            if (s < m1) { m2 = m1; m1 = s; } else if (s < m2) { m2 = s; }
+        }
+    auto fold = [&](float o1, float o2, float ot) {
+        const float lo = fminf(m1, o1), hi = fmaxf(m1, o1);
+        m2 = fminf(hi, fminf(m2, o2));
+        m1 = lo;
+        tau = fminf(tau, ot);
+    };
+    fold(lane_xor<8>(m1), lane_xor<8>(m2), lane_xor<8>(tau));
+    fold(lane_xor<4>(m1), lane_xor<4>(m2), lane_xor<4>(tau));
+    fold(lane_xor<2>(m1), lane_xor<2>(m2), lane_xor<2>(tau));
+    fold(lane_xor<1>(m1), lane_xor<1>(m2), lane_xor<1>(tau));
+    // A candidate whose score exceeds the 2nd smallest score by more than 4*eps is strictly
+    // farther (even after sqrtf) than two other candidates: it cannot be in the exact top-2.
+    const float thr = m2 + 4.f * eps;
+    if (trace && threadIdx.x == 0) trace[16 * blockIdx.x + 2] = wall_clock64();
+
+    // Sweep 2: the survivors of ALL candidate chunks are compacted in LDS first, then evaluated 8 per pass (a lane
+    // pair each), so the dependent train-row fetches of a query overlap instead of costing one round trip per chunk.
+    Best2 b;
+    b.d[0] = b.d[1] = kInf; b.dsq[0] = b.dsq[1] = kInf; b.i[0] = b.i[1] = INT_MAX;
+    const int pr = sl >> 1, pp = sl & 1;                  // candidate pair inside the query's 16 lanes
+    int cnt = 0;                                          // survivors listed so far (uniform inside a query's 16 lanes)
+    auto evaluate = [&]() {
+        int nmax = cnt;
+        nmax = max(nmax, lane_xor<16>(nmax));
+        nmax = max(nmax, lane_xor<32>(nmax));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+        for (int e0 = 0; e0 < nmax; e0 += 8) {
+            const int e = e0 + pr;
+            const int tid = e < cnt ? qual[ql][e] : 0;    // idle pairs re-read train 0 (nt >= 1 here)
+            const float dsq = exact_l2sq_pair(qrows[ql], T + (int64_t)tid * ldt, pp);
+            if (pp == 0 && e < cnt) best2_insert(b, sqrtf(dsq), dsq, tid);
+        }
+        __builtin_amdgcn_wave_barrier();
+        cnt = 0;
+    };
+    for (int k0 = 0; k0 * 16 < NC; ++k0) {
+        float s = kInf;
+        int id = -1;
+        if (k0 < kRefRegs) {
+#pragma unroll
+            for (int k = 0; k < kRefRegs; ++k)
+                if (k == k0) { s = rs[k]; id = ri[k]; }
+        } else if (valid && sl + 16 * k0 < NC) {
+            s = cs[sl + 16 * k0];
+            id = ci[sl + 16 * k0];
+        }
+        const bool take = id >= 0 && s <= thr;
+        const unsigned long long mask = __ballot(take);
+        if (mask == 0) continue;                          // wave-uniform
+        const unsigned mine = (unsigned)(mask >> (16 * sub)) & 0xFFFFu;
+        if (take) qual[ql][cnt + __popc(mine & ((1u << sl) - 1u))] = id;
+        cnt += __popc(mine);
+        if (__any(cnt > 16)) evaluate();                  // the next chunk could overflow the 32-entry list
+    }
+    evaluate();
+    best2_group_reduce<16>(b);
+    if (trace && threadIdx.x == 0) trace[16 * blockIdx.x + 3] = wall_clock64();
+    // (s3 < 0 can only be rounding noise: such a stream never certifies.)
+    const double lim = b.i[1] != INT_MAX ? (double)b.dsq[1] + (double)eps : (double)kInf;
+    const bool open = valid && tau < kInf && !(lim < (double)tau);    // some stream could not be certified
+
+    // Rescan of the streams that could not be certified.
+    bool rescanned = false;
+    const bool use_half = thalf && (mode == kModeHalf || mode == kModeHalfExact);
+    if (__syncthreads_or(open ? 1 : 0)) {
+        for (int k0 = 0; k0 * 16 < NC; ++k0) {
+            const int c = sl + 16 * k0;
+            float s3 = kInf;
+            if (open && c < NC && c % 3 == 2) {
+                s3 = cs[c];
+#pragma unroll
+                for (int k = 0; k < kRefRegs; ++k)
+                    if (k == k0) s3 = rs[k];
+            }
+            if (s3 < kInf && !(lim < (double)s3)) {
+                const int p = atomicAdd(&nitem, 1);
+                item_q[p] = ql;
+                item_sid[p] = c / 3;
+                item_lim[p] = lim;
+                item_qq[p] = qq;
+            }
+            __syncthreads();
+            const int n_items = nitem;
+            for (int it = 0; it < n_items; ++it) {
+                const int w = item_q[it], sid = item_sid[it];
+                const int slot = sid / (2 * nsub), sb = (sid % (2 * nsub)) >> 1, h = sid & 1;
+                const int wg = fb + slot;
+                const int64_t u0 = max(unit_begin(units, G, wg), (int64_t)rb * tiles);
+                const int64_t u1 = min(unit_begin(units, G, wg + 1), (int64_t)(rb + 1) * tiles);
+                const int t_begin = (int)(u0 - (int64_t)rb * tiles) + kSubTiles * sb;
+                const int t_end = min((int)(u1 - (int64_t)rb * tiles), t_begin + kSubTiles);
+                const int ntr = (t_end - t_begin) * 16;
+                if (trace && threadIdx.x == 0 && !trace[16 * blockIdx.x + 6]) trace[16 * blockIdx.x + 6] = wall_clock64();
+                auto train_of = [&](int i) { return (t_begin + (i >> 4)) * kTileT + (i & 3) + 8 * ((i >> 2) & 3) + 4 * h; };
+                // Phase A: which of the stream's trains need the exact arithmetic?  In the fp16 modes the fp16 image
+                // (L2-resident: the filter just streamed it; half the bytes of the fp32 rows in HBM) gives
+                // s' = ||t||^2 + ||q||^2 - 2 q.t^ with |s' - d^2| <= eps (only t is rounded here, the filter rounds
+                // both operands), so only trains with s' <= d2^2 + eps can enter the top-2.  Otherwise: all of them.
+                if (use_half) {
+                    const double lim_w = item_lim[it];
+                    const float qq_w = item_qq[it];
+                    const int jq = threadIdx.x & 3;
+                    for (int i0 = threadIdx.x >> 2; i0 < ntr; i0 += 64 * 4) {      // a quad per train, 4 trains in flight
+                        uint4 hv[4][4];
+                        int tr[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int i = i0 + 64 * r;
+                            tr[r] = i < ntr ? train_of(i) : nt;
+#pragma unroll
+                            for (int n = 0; n < 4; ++n)
+                                hv[r][n] = tr[r] < nt ? *reinterpret_cast<const uint4*>(thalf + (int64_t)tr[r] * kDim + 32 * n + 8 * jq)
+                                                      : make_uint4(0u, 0u, 0u, 0u);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float dot = 0.f;
+#pragma unroll
+                            for (int n = 0; n < 4; ++n) {
+                                const f16x8 hx = __builtin_bit_cast(f16x8, hv[r][n]);
+                                const float4 qa = *reinterpret_cast<const float4*>(&qrows[w][32 * n + 8 * jq]);
+                                const float4 qb = *reinterpret_cast<const float4*>(&qrows[w][32 * n + 8 * jq + 4]);
+                                dot = fmaf(qa.x, (float)hx[0], dot); dot = fmaf(qa.y, (float)hx[1], dot);
+                                dot = fmaf(qa.z, (float)hx[2], dot); dot = fmaf(qa.w, (float)hx[3], dot);
+                                dot = fmaf(qb.x, (float)hx[4], dot); dot = fmaf(qb.y, (float)hx[5], dot);
+                                dot = fmaf(qb.z, (float)hx[6], dot); dot = fmaf(qb.w, (float)hx[7], dot);
+                            }
+                            dot += lane_xor<2>(dot);
+                            dot += lane_xor<1>(dot);
+                            if (jq == 0 && tr[r] < nt) {
+                                const float sp = (tn[tr[r]] + qq_w) - 2.f * dot;
+                                if (!(lim_w < (double)sp)) surv[atomicAdd(&nsurv, 1)] = tr[r];
+                            }
+                        }
+                    }
+                } else {
+                    for (int i = threadIdx.x; i < ntr; i += 256) {
+                        const int t = train_of(i);
+                        if (t < nt) surv[atomicAdd(&nsurv, 1)] = t;
+                    }
+                }
+                __syncthreads();
+                // Phase B: exact direct-form distances of the listed trains, a quad per train.
+                const int ns = nsurv;
+                if (trace && threadIdx.x == 0 && !trace[16 * blockIdx.x + 7]) { trace[16 * blockIdx.x + 7] = wall_clock64(); trace[16 * blockIdx.x + 10] = ns; }
+                Best2 pb;
+                pb.d[0] = pb.d[1] = kInf; pb.dsq[0] = pb.dsq[1] = kInf; pb.i[0] = pb.i[1] = INT_MAX;
+                for (int i0 = threadIdx.x >> 2; i0 < ns; i0 += 64 * kRescanRows) {
+                    const float* rows[kRescanRows];
+                    int tr[kRescanRows];
+#pragma unroll
+                    for (int r = 0; r < kRescanRows; ++r) {
+                        const int i = i0 + 64 * r;
+                        tr[r] = i < ns ? surv[i] : -1;
+                        rows[r] = tr[r] >= 0 ? T + (int64_t)tr[r] * ldt : nullptr;
+                    }
+                    float dsq[kRescanRows];
+                    exact_l2sq_quad_rows<kRescanRows>(qrows[w], rows, threadIdx.x & 3, dsq);
+#pragma unroll
+                    for (int r = 0; r < kRescanRows; ++r)
+                        if ((threadIdx.x & 3) == 2 && rows[r]) best2_insert(pb, sqrtf(dsq[r]), dsq[r], tr[r]);
+                }
+                if (trace && threadIdx.x == 0 && !trace[16 * blockIdx.x + 8]) trace[16 * blockIdx.x + 8] = wall_clock64();
+                best2_group_reduce<64>(pb);
+                if (lane == 0) wbest[wave] = pb;
+                __syncthreads();
+                if (ql == w) {
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) {
+                        best2_insert_unique(b, wbest[x].d[0], wbest[x].dsq[0], wbest[x].i[0]);
+                        best2_insert_unique(b, wbest[x].d[1], wbest[x].dsq[1], wbest[x].i[1]);
+                    }
+                    rescanned = true;
+                }
+                if (threadIdx.x == 0) nsurv = 0;
+                __syncthreads();
+                if (trace && threadIdx.x == 0) { trace[16 * blockIdx.x + 9] = wall_clock64(); trace[16 * blockIdx.x + 11] += 1; }
+            }
+            if (threadIdx.x == 0) nitem = 0;
+            __syncthreads();
         }
     }
-    for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
-        const int2 item = items[it];
-        const int q = item.x, sid = item.y;
-        const int slot = sid / (2 * nsub), sb = (sid % (2 * nsub)) >> 1, h = sid & 1;
-        const int rb = q / rows_per_block;
-        const int wg = block_of_unit(units, G, (int64_t)rb * tiles) + slot;
-        const int64_t u0 = max(unit_begin(units, G, wg), (int64_t)rb * tiles), u1 = min(unit_begin(units, G, wg + 1), (int64_t)(rb + 1) * tiles);
-        const int t_begin = (int)(u0 - (int64_t)rb * tiles) + kSubTiles * sb;
-        const int t_end = min((int)(u1 - (int64_t)rb * tiles), t_begin + kSubTiles);
-        __syncthreads();
-        if (threadIdx.x < 32)
-            *reinterpret_cast<float4*>(&qrow[4 * threadIdx.x]) =
-                *reinterpret_cast<const float4*>(Q + (int64_t)q * ldq + 4 * threadIdx.x);
-        __syncthreads();
-        Best2 b;
-        b.d[0] = b.d[1] = kInf; b.dsq[0] = b.dsq[1] = kInf; b.i[0] = b.i[1] = INT_MAX;
-        for (int i = threadIdx.x; i < (t_end - t_begin) * 16; i += 256) {
-            const int r = i & 15;
-            const int t = (t_begin + (i >> 4)) * kTileT + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (t < nt) {
-                const float dsq = exact_l2sq_128(qrow, T + (int64_t)t * ldt);
-                best2_insert(b, sqrtf(dsq), dsq, t);
-            }
-        }
-        best2_wave_reduce(b);
-        if ((threadIdx.x & 63) == 0) wbest[threadIdx.x >> 6] = b;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            Best2 r = wbest[0];
-            for (int w = 1; w < 4; ++w) {
-                best2_insert(r, wbest[w].d[0], wbest[w].dsq[0], wbest[w].i[0]);
-                best2_insert(r, wbest[w].d[1], wbest[w].dsq[1], wbest[w].i[1]);
-            }
-            unsigned long long* best = fb_best + 2 * (int64_t)q;
-#pragma unroll
-            for (int e = 0; e < 2; ++e)
-                if (r.i[e] != INT_MAX) {
-                    const unsigned long long key = ((unsigned long long)__float_as_uint(r.d[e]) << 32) | (unsigned)r.i[e];
-                    const unsigned long long old = __hip_atomic_fetch_min(best, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (old != key)
-                        __hip_atomic_fetch_min(best + 1, old > key ? old : key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            const int ticket = __hip_atomic_fetch_add(&tickets[q], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (ticket == fb_n[q] - 1) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                const unsigned long long k0 = __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned long long k1 = __hip_atomic_load(best + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                idx_out[2 * q + 0] = k0 == ~0ull ? -1 : (int)(unsigned)k0;
-                idx_out[2 * q + 1] = k1 == ~0ull ? -1 : (int)(unsigned)k1;
-                dist_out[2 * q + 0] = k0 == ~0ull ? kInf : __uint_as_float((unsigned)(k0 >> 32));
-                dist_out[2 * q + 1] = k1 == ~0ull ? kInf : __uint_as_float((unsigned)(k1 >> 32));
-            }
-        }
+
+    if (valid && sl == 0) {
+        idx_out[2 * q + 0] = b.i[0] == INT_MAX ? -1 : b.i[0];
+        idx_out[2 * q + 1] = b.i[1] == INT_MAX ? -1 : b.i[1];
+        dist_out[2 * q + 0] = b.d[0];
+        dist_out[2 * q + 1] = b.d[1];
+        if (rescanned && stats) atomicAdd(stats, 1);
+    }
+    if (trace && threadIdx.x == 0) {
+        trace[16 * blockIdx.x + 4] = wall_clock64();
+        trace[16 * blockIdx.x + 5] = __builtin_amdgcn_s_getreg(0xF804);
     }
 }
 
@@ -1323,11 +1530,6 @@ struct KnnWs {
     float* tn;
     float* bmax;
     int* midflag;
-    int* flag_count;              // [0] queries with rescan items, [1] rescan items
-    int2* items;                  // (query, stream) rescan work list, worst case every stream of every query
-    int* fb_n;                    // items per flagged query
-    unsigned long long* fb_best;  // [nq][2] (distance bits << 32 | index) keys of flagged queries
-    int* tickets;
     float* cand_s;
     int* cand_i;
     size_t bytes;
@@ -1338,15 +1540,10 @@ KnnWs carve_ws(void* ws, int64_t nq, int64_t nt, const Plan& p) {
     KnnWs w;
     w.bmax = c.take<float>(kNormBlocks);
     w.midflag = c.take<int>(kNormBlocks);
-    w.flag_count = c.take<int>(2);
-    w.fb_best = c.take<unsigned long long>((size_t)nq * 2);
-    w.fb_n = c.take<int>((size_t)nq);
     w.tn = c.take<float>((size_t)p.tiles * kTileT);
     w.qn = c.take<float>((size_t)p.nq_pad);
     w.qsplit = c.take<unsigned short>((size_t)p.nq_pad * kDim * 3);
     w.tsplit = c.take<unsigned short>((size_t)p.tiles * kTileT * kDim * 3);
-    w.items = c.take<int2>((size_t)nq * 2 * p.smax * p.nsub);
-    w.tickets = c.take<int>((size_t)nq);
     w.cand_s = c.take<float>((size_t)nq * 2 * p.smax * p.nsub * 3);
     w.cand_i = c.take<int>((size_t)nq * 2 * p.smax * p.nsub * 3);
     w.bytes = c.used();
@@ -1404,7 +1601,7 @@ extern "C" int sfm_knn2_l2_f32(const float* q, int64_t nq, int64_t ldq, const fl
     static const int abl = [] { const char* e = getenv("SFM_KNN_ABL"); return e ? atoi(e) : 0; }();   // dev only
     if (p.split) {
         hipLaunchKernelGGL(knn_prep_kernel, dim3(kNormBlocks), dim3(1024), 0, stream, q, ldq, (int)nq, p.nq_pad, t, ldt, (int)nt,
-                           p.tiles * kTileT, w.qsplit, w.qn, w.tsplit, w.tn, w.bmax, w.midflag, w.flag_count, w.tickets);
+                           p.tiles * kTileT, w.qsplit, w.qn, w.tsplit, w.tn, w.bmax, w.midflag, stats);
         SFM_CHECK_LAUNCH();
         sfm::prof_begin(sfm::kProfKnnFilter, stream);
 #define SFM_LAUNCH_SPLIT(A, WV)                                                                                        \
@@ -1436,7 +1633,7 @@ extern "C" int sfm_knn2_l2_f32(const float* q, int64_t nq, int64_t ldq, const fl
 #undef SFM_LAUNCH_SPLIT2
     } else {
     hipLaunchKernelGGL(knn_norms_kernel, dim3(kNormBlocks), dim3(256), 0, stream, t, ldt, (int)nt, w.tn, w.bmax,
-                       w.flag_count, w.tickets, (int)nq);
+                       stats);
     SFM_CHECK_LAUNCH();
     sfm::prof_begin(sfm::kProfKnnFilter, stream);
 #define SFM_LAUNCH_FILTER(A, WV)                                                                                     \
@@ -1467,14 +1664,10 @@ extern "C" int sfm_knn2_l2_f32(const float* q, int64_t nq, int64_t ldq, const fl
     SFM_CHECK_LAUNCH();
     const int force_mode = !p.split ? kModeF32 : p.qg == 2 ? g_force_mode : kModeSplit;
     sfm::prof_begin(sfm::kProfKnnRefine, stream);
-    hipLaunchKernelGGL(knn_refine_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, stream, q, ldq, (int)nq, t, ldt,
-                       w.cand_s, w.cand_i, p.rows_per_block, p.tiles, p.units, p.G, p.smax * p.nsub, p.nsub,
-                       force_mode, w.midflag, w.bmax, idx, dist,
-                       w.flag_count, w.items, w.fb_n, w.fb_best);
-    SFM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(knn_rescan_kernel, dim3(kRescanBlocks), dim3(256), 0, stream, q, ldq, t, ldt, (int)nt,
-                       p.rows_per_block, p.tiles, p.units, p.G, p.nsub, w.flag_count, w.items, w.fb_n, w.fb_best, w.tickets,
-                       idx, dist, stats, 2 * p.smax * p.nsub, force_mode, w.midflag, w.bmax);
+    hipLaunchKernelGGL(knn_refine_kernel, dim3((unsigned)((nq + kRefQ - 1) / kRefQ)), dim3(256), 0, stream, q, ldq, (int)nq, t, ldt,
+                       (int)nt, w.cand_s, w.cand_i, p.rows_per_block, p.tiles, p.units, p.G, p.smax * p.nsub, p.nsub,
+                       force_mode, w.midflag, w.bmax, p.split ? w.tsplit + (size_t)2 * p.tiles * kTileT * kDim : nullptr, w.tn, idx, dist,
+                       stats, g_trace ? g_trace + 16384 : nullptr);
     sfm::prof_end(sfm::kProfKnnRefine, stream);
     SFM_CHECK_LAUNCH();
     return SFM_OK;
