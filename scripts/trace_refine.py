@@ -34,4 +34,4 @@ for w in late:
     print(f"   WG {w}: start {st[w]:.1f} q {e1[w]-st[w]:.1f} s1 {e2[w]-e1[w]:.1f} s2 {e3[w]-e2[w]:.1f} tail {en[w]-e3[w]:.1f} end {en[w]:.1f}")
     if a[w, 6]:
         r = [us(a[w, k]) for k in (6, 7, 8, 9)]
-        print(f"      rescan: first item setup done +{r[0]-e3[w]:.1f}, phase A +{r[1]-r[0]:.1f} (survivors {a[w,10]}), phase B +{r[2]-r[1]:.1f}, last item merged at +{r[3]-r[2]:.1f}; items {a[w,11]}")
+        print(f"      rescan: first item setup done +{r[0]-e3[w]:.1f}, prefilter +{r[1]-r[0]:.1f} (survivors {a[w,10]}), items done +{r[2]-r[1]:.1f}, final evaluate+store +{en[w]-r[2]:.1f}")

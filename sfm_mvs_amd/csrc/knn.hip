@@ -1119,9 +1119,11 @@ __device__ __forceinline__ void exact_l2sq_quad_rows(const float* __restrict__ q
 }
 
 constexpr int kRefQ = 16;        // queries per refine workgroup: 16 lanes each
-constexpr int kRefRegs = 6;      // candidates per lane kept in registers (96 per query); more are re-read
-constexpr int kRescanRows = 2;   // trains a quad has in flight during a rescan (32 VGPRs each)
-constexpr int kRefItems = 128;   // rescan items one round can hold (16 queries x at most 6 streams per 16 candidates)
+constexpr int kS1 = 6;           // candidate records per lane fetched up front by sweep 1 (96 per query)
+constexpr int kRescanRows = 1;   // trains a quad has in flight during a rescan (32 VGPRs each)
+constexpr int kRefItems = 512;   // rescan work list (query, stream); more → 16 candidate slots per query at a time (<= 96)
+constexpr int kPreRows = 2;      // trains a quad has in flight during the rescan's fp16 prefilter (16 VGPRs each)
+constexpr int kQualCap = 48;     // exact-evaluation list per query
 
 // Sixteen lanes per query, sixteen queries per workgroup (one resident round for 10^4 queries).
 //   sweep 1  two smallest filter scores over the query's candidate records and each stream's 3rd best
@@ -1138,10 +1140,11 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
     const unsigned short* __restrict__ thalf /*fp16 image of T, or null*/, const float* __restrict__ tn,
     int* __restrict__ idx_out, float* __restrict__ dist_out, int* __restrict__ stats, long long* __restrict__ trace) {
     __shared__ __attribute__((aligned(16))) float qrows[kRefQ][kDim];
-    __shared__ int qual[kRefQ][32];
-    __shared__ int item_q[kRefItems], item_sid[kRefItems];
-    __shared__ double item_lim[kRefItems];
-    __shared__ float item_qq[kRefItems];
+    __shared__ int qual[kRefQ][kQualCap];
+    __shared__ int items[kRefItems];                     // (query slot << 20) | stream
+    __shared__ double q_lim[kRefQ];
+    __shared__ float q_qq[kRefQ];
+    __shared__ int cnt_lds[kRefQ];
     __shared__ int surv[kSubTiles * 16];
     __shared__ int nitem, nsurv;
     __shared__ Best2 wbest[4];
@@ -1181,15 +1184,14 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
         stats[1] = G; stats[2] = 2 * smax; stats[3] = mode;
     }
 
-    // Sweep 1
-    float rs[kRefRegs];
-    int ri[kRefRegs];
+    // Sweep 1: two smallest scores and the smallest 3rd-best.  (The records are re-read from L1/L2 by the later
+    // sweeps instead of being held in registers: the kernel needs <= 168 VGPRs for a single resident round.)
     float m1 = kInf, m2 = kInf, tau = kInf;
+    float s1v[kS1];
 #pragma unroll
-    for (int k = 0; k < kRefRegs; ++k) {
+    for (int k = 0; k < kS1; ++k) {
         const int c = sl + 16 * k;
-        rs[k] = (valid && c < NC) ? cs[c] : kInf;
-        ri[k] = (valid && c < NC) ? ci[c] : -1;
+        s1v[k] = (valid && c < NC) ? cs[c] : kInf;
     }
     __syncthreads();                                     // query rows in LDS
     if (trace && threadIdx.x == 0) trace[16 * blockIdx.x + 1] = wall_clock64();
@@ -1202,12 +1204,12 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
     const float nsum = sqrtf(qq) + sqrtf(tmax);
     const float eps = 1.01f * (eps_coef * nsum * nsum + (mode == kModeHalf ? kEpsHalfAbs * nsum : 0.f));
 #pragma unroll
-    for (int k = 0; k < kRefRegs; ++k) {
-        if ((sl + 16 * k) % 3 == 2) tau = fminf(tau, rs[k]);
-        if (rs[k] < m1) { m2 = m1; m1 = rs[k]; } else if (rs[k] < m2) { m2 = rs[k]; }
+    for (int k = 0; k < kS1; ++k) {
+        if ((sl + 16 * k) % 3 == 2) tau = fminf(tau, s1v[k]);
+        if (s1v[k] < m1) { m2 = m1; m1 = s1v[k]; } else if (s1v[k] < m2) { m2 = s1v[k]; }
     }
     if (valid)
-        for (int c = sl + 16 * kRefRegs; c < NC; c += 16) {
+        for (int c = sl + 16 * kS1; c < NC; c += 16) {
             const float s = cs[c];
             if (c % 3 == 2) tau = fminf(tau, s);
             if (s < m1) { m2 = m1; m1 = s; } else if (s < m2) { m2 = s; }
@@ -1222,9 +1224,10 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
     fold(lane_xor<4>(m1), lane_xor<4>(m2), lane_xor<4>(tau));
     fold(lane_xor<2>(m1), lane_xor<2>(m2), lane_xor<2>(tau));
     fold(lane_xor<1>(m1), lane_xor<1>(m2), lane_xor<1>(tau));
-    // A candidate whose score exceeds the 2nd smallest score by more than 4*eps is strictly
-    // farther (even after sqrtf) than two other candidates: it cannot be in the exact top-2.
-    const float thr = m2 + 4.f * eps;
+    // The two best-scored candidates have d^2 <= m2 + eps.  A candidate with s > m2 + 2.5*eps has d^2 >= s - eps >
+    // m2 + 1.5*eps: farther than both by > eps/2 >= 300u*(|q|+|t|)^2, which also separates the float32 square roots
+    // (one ulp of sqrtf is < 2^-22 relative in d^2) — it cannot be in the exact top-2, ties included.
+    const float thr = m2 + 2.5f * eps;
     if (trace && threadIdx.x == 0) trace[16 * blockIdx.x + 2] = wall_clock64();
 
     // Sweep 2: the survivors of ALL candidate chunks are compacted in LDS first, then evaluated 8 per pass (a lane
@@ -1232,7 +1235,8 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
     Best2 b;
     b.d[0] = b.d[1] = kInf; b.dsq[0] = b.dsq[1] = kInf; b.i[0] = b.i[1] = INT_MAX;
     const int pr = sl >> 1, pp = sl & 1;                  // candidate pair inside the query's 16 lanes
-    int cnt = 0;                                          // survivors listed so far (uniform inside a query's 16 lanes)
+    int cnt = 0;                                          // entries of qual[ql] (uniform inside a query's 16 lanes)
+    // Exact evaluation of the listed trains (two sites: the candidates' and, rarely, the rescan survivors').
     auto evaluate = [&]() {
         int nmax = cnt;
         nmax = max(nmax, lane_xor<16>(nmax));
@@ -1244,61 +1248,76 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
             const int e = e0 + pr;
             const int tid = e < cnt ? qual[ql][e] : 0;    // idle pairs re-read train 0 (nt >= 1 here)
             const float dsq = exact_l2sq_pair(qrows[ql], T + (int64_t)tid * ldt, pp);
-            if (pp == 0 && e < cnt) best2_insert(b, sqrtf(dsq), dsq, tid);
+            if (pp == 0 && e < cnt) best2_insert_unique(b, sqrtf(dsq), dsq, tid);
         }
         __builtin_amdgcn_wave_barrier();
         cnt = 0;
     };
-    for (int k0 = 0; k0 * 16 < NC; ++k0) {
-        float s = kInf;
-        int id = -1;
-        if (k0 < kRefRegs) {
-#pragma unroll
-            for (int k = 0; k < kRefRegs; ++k)
-                if (k == k0) { s = rs[k]; id = ri[k]; }
-        } else if (valid && sl + 16 * k0 < NC) {
-            s = cs[sl + 16 * k0];
-            id = ci[sl + 16 * k0];
-        }
-        const bool take = id >= 0 && s <= thr;
-        const unsigned long long mask = __ballot(take);
-        if (mask == 0) continue;                          // wave-uniform
-        const unsigned mine = (unsigned)(mask >> (16 * sub)) & 0xFFFFu;
-        if (take) qual[ql][cnt + __popc(mine & ((1u << sl) - 1u))] = id;
-        cnt += __popc(mine);
-        if (__any(cnt > 16)) evaluate();                  // the next chunk could overflow the 32-entry list
-    }
-    evaluate();
-    best2_group_reduce<16>(b);
-    if (trace && threadIdx.x == 0) trace[16 * blockIdx.x + 3] = wall_clock64();
-    // (s3 < 0 can only be rounding noise: such a stream never certifies.)
-    const double lim = b.i[1] != INT_MAX ? (double)b.dsq[1] + (double)eps : (double)kInf;
-    const bool open = valid && tau < kInf && !(lim < (double)tau);    // some stream could not be certified
 
-    // Rescan of the streams that could not be certified.
+    double lim = 0.0;
     bool rescanned = false;
     const bool use_half = thalf && (mode == kModeHalf || mode == kModeHalfExact);
-    if (__syncthreads_or(open ? 1 : 0)) {
-        for (int k0 = 0; k0 * 16 < NC; ++k0) {
+    for (int k0 = 0; k0 * 16 < NC;) {                     // (wave-uniform)
+        for (; k0 * 16 < NC; ++k0) {
+            if (__any(cnt > kQualCap - 16)) break;        // the list might not take another chunk: evaluate first
             const int c = sl + 16 * k0;
-            float s3 = kInf;
-            if (open && c < NC && c % 3 == 2) {
-                s3 = cs[c];
-#pragma unroll
-                for (int k = 0; k < kRefRegs; ++k)
-                    if (k == k0) s3 = rs[k];
+            const float s = (valid && c < NC) ? cs[c] : kInf;
+            const int id = (valid && c < NC) ? ci[c] : -1;                // (empty records: s = +inf, id = -1)
+            const bool take = id >= 0 && s <= thr;
+            const unsigned long long mask = __ballot(take);
+            if (mask == 0) continue;                      // wave-uniform
+            const unsigned mine = (unsigned)(mask >> (16 * sub)) & 0xFFFFu;
+            if (take) qual[ql][cnt + __popc(mine & ((1u << sl) - 1u))] = id;
+            cnt += __popc(mine);
+        }
+        evaluate();                                       // the hot site
+    }
+    for (int round = 0;; ++round) {
+        if (round == 1) evaluate();                       // rescan survivors (cold site)
+        best2_group_reduce<16>(b);
+        if (trace && threadIdx.x == 0 && round == 0) trace[16 * blockIdx.x + 3] = wall_clock64();
+        if (round == 1) break;
+        // Certificate.  (s3 < 0 can only be rounding noise: such a stream never certifies.)
+        lim = b.i[1] != INT_MAX ? (double)b.dsq[1] + (double)eps : (double)kInf;
+        const bool open = valid && tau < kInf && !(lim < (double)tau);    // some stream could not be certified
+        if (!__syncthreads_or(open ? 1 : 0)) break;
+
+        // ---- rescan of the streams that could not be certified (rare; everything below is cold code) ----
+        if (open) {
+            if (sl == 0) {
+                q_lim[ql] = lim;
+                q_qq[ql] = qq;
+                cnt_lds[ql] = 0;
             }
-            if (s3 < kInf && !(lim < (double)s3)) {
-                const int p = atomicAdd(&nitem, 1);
-                item_q[p] = ql;
-                item_sid[p] = c / 3;
-                item_lim[p] = lim;
-                item_qq[p] = qq;
+            for (int c = sl; c < NC; c += 16)
+                if (c % 3 == 2) {
+                    const float s3 = cs[c];
+                    if (s3 < kInf && !(lim < (double)s3)) {
+                        const int p = atomicAdd(&nitem, 1);
+                        if (p < kRefItems) items[p] = (ql << 20) | (c / 3);
+                    }
+                }
+            rescanned = true;
+        }
+        __syncthreads();
+        const int n_items = nitem;
+        // more uncertified streams than the list holds (degenerate train sets): 16 candidate slots per query at a time
+        const int n_rounds = n_items <= kRefItems ? 1 : (NC + 15) / 16;
+        for (int k0 = 0; k0 < n_rounds; ++k0) {
+            if (n_items > kRefItems) {
+                __syncthreads();
+                if (threadIdx.x == 0) nitem = 0;
+                __syncthreads();
+                const int c = sl + 16 * k0;
+                if (open && c < NC && c % 3 == 2) {
+                    const float s3 = cs[c];
+                    if (s3 < kInf && !(lim < (double)s3)) items[atomicAdd(&nitem, 1)] = (ql << 20) | (c / 3);   // <= 96 per round
+                }
+                __syncthreads();
             }
-            __syncthreads();
-            const int n_items = nitem;
-            for (int it = 0; it < n_items; ++it) {
-                const int w = item_q[it], sid = item_sid[it];
+            const int n_it = min(nitem, kRefItems);
+            for (int it = 0; it < n_it; ++it) {
+                const int w = items[it] >> 20, sid = items[it] & 0xFFFFF;
                 const int slot = sid / (2 * nsub), sb = (sid % (2 * nsub)) >> 1, h = sid & 1;
                 const int wg = fb + slot;
                 const int64_t u0 = max(unit_begin(units, G, wg), (int64_t)rb * tiles);
@@ -1306,21 +1325,21 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
                 const int t_begin = (int)(u0 - (int64_t)rb * tiles) + kSubTiles * sb;
                 const int t_end = min((int)(u1 - (int64_t)rb * tiles), t_begin + kSubTiles);
                 const int ntr = (t_end - t_begin) * 16;
-                if (trace && threadIdx.x == 0 && !trace[16 * blockIdx.x + 6]) trace[16 * blockIdx.x + 6] = wall_clock64();
                 auto train_of = [&](int i) { return (t_begin + (i >> 4)) * kTileT + (i & 3) + 8 * ((i >> 2) & 3) + 4 * h; };
-                // Phase A: which of the stream's trains need the exact arithmetic?  In the fp16 modes the fp16 image
-                // (L2-resident: the filter just streamed it; half the bytes of the fp32 rows in HBM) gives
-                // s' = ||t||^2 + ||q||^2 - 2 q.t^ with |s' - d^2| <= eps (only t is rounded here, the filter rounds
-                // both operands), so only trains with s' <= d2^2 + eps can enter the top-2.  Otherwise: all of them.
+                if (trace && threadIdx.x == 0 && !trace[16 * blockIdx.x + 6]) trace[16 * blockIdx.x + 6] = wall_clock64();
+                // Which of the stream's trains need the exact arithmetic?  In the fp16 modes the fp16 image (L2-resident:
+                // the filter just streamed it; half the bytes of the fp32 rows in HBM) gives s' = ||t||^2 + ||q||^2 - 2 q.t^
+                // with |s' - d^2| <= eps (only t is rounded here, the filter rounds both operands), so only trains with
+                // s' <= d2^2 + eps can enter the top-2.  Otherwise: all of them.
                 if (use_half) {
-                    const double lim_w = item_lim[it];
-                    const float qq_w = item_qq[it];
+                    const double lim_w = q_lim[w];
+                    const float qq_w = q_qq[w];
                     const int jq = threadIdx.x & 3;
-                    for (int i0 = threadIdx.x >> 2; i0 < ntr; i0 += 64 * 4) {      // a quad per train, 4 trains in flight
-                        uint4 hv[4][4];
-                        int tr[4];
+                    for (int i0 = threadIdx.x >> 2; i0 < ntr; i0 += 64 * kPreRows) {   // a quad per train
+                        uint4 hv[kPreRows][4];
+                        int tr[kPreRows];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
+                        for (int r = 0; r < kPreRows; ++r) {
                             const int i = i0 + 64 * r;
                             tr[r] = i < ntr ? train_of(i) : nt;
 #pragma unroll
@@ -1329,7 +1348,7 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
                                                       : make_uint4(0u, 0u, 0u, 0u);
                         }
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
+                        for (int r = 0; r < kPreRows; ++r) {
                             float dot = 0.f;
 #pragma unroll
                             for (int n = 0; n < 4; ++n) {
@@ -1356,45 +1375,53 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
                     }
                 }
                 __syncthreads();
-                // Phase B: exact direct-form distances of the listed trains, a quad per train.
                 const int ns = nsurv;
                 if (trace && threadIdx.x == 0 && !trace[16 * blockIdx.x + 7]) { trace[16 * blockIdx.x + 7] = wall_clock64(); trace[16 * blockIdx.x + 10] = ns; }
-                Best2 pb;
-                pb.d[0] = pb.d[1] = kInf; pb.dsq[0] = pb.dsq[1] = kInf; pb.i[0] = pb.i[1] = INT_MAX;
-                for (int i0 = threadIdx.x >> 2; i0 < ns; i0 += 64 * kRescanRows) {
-                    const float* rows[kRescanRows];
-                    int tr[kRescanRows];
-#pragma unroll
-                    for (int r = 0; r < kRescanRows; ++r) {
-                        const int i = i0 + 64 * r;
-                        tr[r] = i < ns ? surv[i] : -1;
-                        rows[r] = tr[r] >= 0 ? T + (int64_t)tr[r] * ldt : nullptr;
+                const int have = cnt_lds[w];
+                if (have + ns <= kQualCap) {
+                    // the usual case, a few survivors: queue them for the owning query's next (hot) evaluation
+                    if (threadIdx.x < ns) qual[w][have + threadIdx.x] = surv[threadIdx.x];
+                    __syncthreads();
+                    if (threadIdx.x == 0) {
+                        cnt_lds[w] = have + ns;
+                        nsurv = 0;
                     }
-                    float dsq[kRescanRows];
-                    exact_l2sq_quad_rows<kRescanRows>(qrows[w], rows, threadIdx.x & 3, dsq);
+                } else {
+                    // many survivors: evaluate them here with the whole workgroup, a quad per train
+                    Best2 pb;
+                    pb.d[0] = pb.d[1] = kInf; pb.dsq[0] = pb.dsq[1] = kInf; pb.i[0] = pb.i[1] = INT_MAX;
+                    for (int i0 = threadIdx.x >> 2; i0 < ns; i0 += 64 * kRescanRows) {
+                        const float* rows[kRescanRows];
+                        int tr[kRescanRows];
 #pragma unroll
-                    for (int r = 0; r < kRescanRows; ++r)
-                        if ((threadIdx.x & 3) == 2 && rows[r]) best2_insert(pb, sqrtf(dsq[r]), dsq[r], tr[r]);
-                }
-                if (trace && threadIdx.x == 0 && !trace[16 * blockIdx.x + 8]) trace[16 * blockIdx.x + 8] = wall_clock64();
-                best2_group_reduce<64>(pb);
-                if (lane == 0) wbest[wave] = pb;
-                __syncthreads();
-                if (ql == w) {
+                        for (int r = 0; r < kRescanRows; ++r) {
+                            const int i = i0 + 64 * r;
+                            tr[r] = i < ns ? surv[i] : -1;
+                            rows[r] = tr[r] >= 0 ? T + (int64_t)tr[r] * ldt : nullptr;
+                        }
+                        float dsq[kRescanRows];
+                        exact_l2sq_quad_rows<kRescanRows>(qrows[w], rows, threadIdx.x & 3, dsq);
 #pragma unroll
-                    for (int x = 0; x < 4; ++x) {
-                        best2_insert_unique(b, wbest[x].d[0], wbest[x].dsq[0], wbest[x].i[0]);
-                        best2_insert_unique(b, wbest[x].d[1], wbest[x].dsq[1], wbest[x].i[1]);
+                        for (int r = 0; r < kRescanRows; ++r)
+                            if ((threadIdx.x & 3) == 2 && rows[r]) best2_insert(pb, sqrtf(dsq[r]), dsq[r], tr[r]);
                     }
-                    rescanned = true;
+                    best2_group_reduce<64>(pb);
+                    if (lane == 0) wbest[wave] = pb;
+                    __syncthreads();
+                    if (ql == w) {
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) {
+                            best2_insert_unique(b, wbest[x].d[0], wbest[x].dsq[0], wbest[x].i[0]);
+                            best2_insert_unique(b, wbest[x].d[1], wbest[x].dsq[1], wbest[x].i[1]);
+                        }
+                    }
+                    if (threadIdx.x == 0) nsurv = 0;
                 }
-                if (threadIdx.x == 0) nsurv = 0;
                 __syncthreads();
-                if (trace && threadIdx.x == 0) { trace[16 * blockIdx.x + 9] = wall_clock64(); trace[16 * blockIdx.x + 11] += 1; }
             }
-            if (threadIdx.x == 0) nitem = 0;
-            __syncthreads();
         }
+        if (open) cnt = cnt_lds[ql];                       // survivors queued for this query → round 1
+        if (trace && threadIdx.x == 0) trace[16 * blockIdx.x + 8] = wall_clock64();
     }
 
     if (valid && sl == 0) {
