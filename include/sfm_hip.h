@@ -94,6 +94,17 @@ int sfm_ratio_compact(const int32_t* idx_dev, const float* dist_dev, int64_t nq,
                       int32_t* out_count_dev, uint8_t* mask_dev,
                       void* ws_dev, size_t ws_bytes, void* stream);
 
+/* A2 + A3 in one call: the matcher part of find_features (sfm.py:259-266).  Same outputs as
+ * sfm_knn2_l2_f32 followed by sfm_ratio_compact, bit for bit; the Lowe test is folded into the
+ * last KNN kernel, which saves one launch per image pair.  Workspace: sfm_match_l2_f32_ws_bytes. */
+size_t sfm_match_l2_f32_ws_bytes(int64_t nq, int64_t nt, int dim);
+int sfm_match_l2_f32(const float* q_dev, int64_t nq, int64_t ldq,
+                     const float* t_dev, int64_t nt, int64_t ldt, int dim, double ratio,
+                     int32_t* idx_dev, float* dist_dev,
+                     int32_t* out_q_dev, int32_t* out_t_dev, int32_t* out_count_dev,
+                     uint8_t* mask_dev /*optional*/, int32_t* stats_dev /*optional*/,
+                     void* ws_dev, size_t ws_bytes, void* stream);
+
 /* Gather keypoint coordinates of the survivors: pts0 = kp0[out_q], pts1 = kp1[out_t]
  * (sfm.py:267-268).  kp*_dev are [n x 2] float32 (KeyPoint.pt); count_dev is the
  * device scalar written by sfm_ratio_compact; capacity = rows available in pts*_dev. */

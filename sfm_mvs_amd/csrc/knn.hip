@@ -106,7 +106,7 @@ constexpr int kNormBlocks = 256;
 
 __global__ __launch_bounds__(256) void knn_norms_kernel(const float* __restrict__ T, int64_t ldt, int nt,
                                                         float* __restrict__ tn, float* __restrict__ bmax,
-                                                        int* __restrict__ stats) {
+                                                        int* __restrict__ stats, int* __restrict__ zero, int nzero) {
     __shared__ float wmax[4];
     const int l = threadIdx.x & 31;
     float mx = 0.f;
@@ -125,6 +125,8 @@ __global__ __launch_bounds__(256) void knn_norms_kernel(const float* __restrict_
     if (threadIdx.x == 0) {
         bmax[blockIdx.x] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
         if (blockIdx.x == 0 && stats) stats[0] = 0;   // rescanned-query counter (refine kernel)
+        if (blockIdx.x == 1 || gridDim.x == 1)
+            for (int i = 0; i < nzero; ++i) zero[i] = 0;   // Lowe-ratio survivor counters of the fused match call
     }
 }
 
@@ -391,7 +393,7 @@ __global__ __launch_bounds__(1024) void knn_prep_kernel(const float* __restrict_
                                                        unsigned short* __restrict__ qsplit, float* __restrict__ qn,
                                                        unsigned short* __restrict__ tsplit, float* __restrict__ tn,
                                                        float* __restrict__ bmax, int* __restrict__ midflag,
-                                                       int* __restrict__ stats) {
+                                                       int* __restrict__ stats, int* __restrict__ zero, int nzero) {
     __shared__ float wmax[16];
     __shared__ int wmid[16];
     const int l = threadIdx.x & 31;
@@ -448,6 +450,8 @@ __global__ __launch_bounds__(1024) void knn_prep_kernel(const float* __restrict_
         bmax[blockIdx.x] = bm;
         midflag[blockIdx.x] = fl;
         if (blockIdx.x == 0 && stats) stats[0] = 0;   // rescanned-query counter (refine kernel)
+        if (blockIdx.x == 1 || gridDim.x == 1)
+            for (int i = 0; i < nzero; ++i) zero[i] = 0;   // Lowe-ratio survivor counters of the fused match call
     }
 }
 
@@ -1118,6 +1122,7 @@ __device__ __forceinline__ void exact_l2sq_quad_rows(const float* __restrict__ q
     }
 }
 
+constexpr int kRatioBlock = 1024; // queries per ratio workgroup (256 threads x 4 consecutive queries)
 constexpr int kRefQ = 16;        // queries per refine workgroup: 16 lanes each
 constexpr int kS1 = 6;           // candidate records per lane fetched up front by sweep 1 (96 per query)
 constexpr int kRescanRows = 1;   // trains a quad has in flight during a rescan (32 VGPRs each)
@@ -1138,7 +1143,9 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
     const float* __restrict__ cand_s, const int* __restrict__ cand_i, int rows_per_block, int tiles, int64_t units,
     int G, int smax, int nsub, int force_mode, const int* __restrict__ midflag, const float* __restrict__ bmax,
     const unsigned short* __restrict__ thalf /*fp16 image of T, or null*/, const float* __restrict__ tn,
-    int* __restrict__ idx_out, float* __restrict__ dist_out, int* __restrict__ stats, long long* __restrict__ trace) {
+    int* __restrict__ idx_out, float* __restrict__ dist_out, int* __restrict__ stats, double ratio,
+    int* __restrict__ ratio_counts /*null unless fused with the Lowe ratio*/, unsigned char* __restrict__ ratio_mask,
+    long long* __restrict__ trace) {
     __shared__ __attribute__((aligned(16))) float qrows[kRefQ][kDim];
     __shared__ int qual[kRefQ][kQualCap];
     __shared__ int items[kRefItems];                     // (query slot << 20) | stream
@@ -1431,6 +1438,14 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
         dist_out[2 * q + 1] = b.d[1];
         if (rescanned && stats) atomicAdd(stats, 1);
     }
+    if (ratio_counts) {
+        // fused sfm_match_l2_f32: the Lowe test of sfm.py:264 here, survivors counted per 1024-query block (integer
+        // atomics: order-independent), so the match list needs the ordered scatter pass only
+        const bool pass = valid && sl == 0 && b.i[1] != INT_MAX && (double)b.d[0] < ratio * (double)b.d[1];
+        if (ratio_mask && valid && sl == 0) ratio_mask[q] = pass ? 1 : 0;
+        const int n = __popcll(__ballot(pass));
+        if (lane == 0 && n) atomicAdd(ratio_counts + (blockIdx.x * kRefQ) / kRatioBlock, n);
+    }
     if (trace && threadIdx.x == 0) {
         trace[16 * blockIdx.x + 4] = wall_clock64();
         trace[16 * blockIdx.x + 5] = __builtin_amdgcn_s_getreg(0xF804);
@@ -1443,7 +1458,6 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
 //   count:   1024 queries per workgroup → pass bits (optionally the mask) + one count per workgroup
 //   scatter: every workgroup sums the counts of its predecessors (a few dozen ints), re-derives its bits and writes
 //            its survivors at the right offset → ascending queryIdx order, no atomics, deterministic.
-constexpr int kRatioBlock = 1024;   // queries per workgroup (256 threads x 4 consecutive queries)
 
 __device__ __forceinline__ unsigned ratio_bits(const int* __restrict__ idx, const float* __restrict__ dist, int nq, int qb,
                                                double ratio, int (&ti)[4]) {
@@ -1597,9 +1611,12 @@ extern "C" size_t sfm_knn2_l2_f32_ws_bytes(int64_t nq, int64_t nt, int dim) {
     return carve_ws(nullptr, nq, nt, p).bytes + 256;
 }
 
-extern "C" int sfm_knn2_l2_f32(const float* q, int64_t nq, int64_t ldq, const float* t, int64_t nt, int64_t ldt,
-                               int dim, int32_t* idx, float* dist, int32_t* stats, void* ws, size_t ws_bytes,
-                               void* stream_) {
+namespace {
+// KNN, optionally fused with the Lowe-ratio survivor count (ratio_counts != null: one int per 1024 queries).
+int knn2_impl(const float* q, int64_t nq, int64_t ldq, const float* t, int64_t nt, int64_t ldt, int dim, int32_t* idx,
+              float* dist, int32_t* stats, void* ws, size_t ws_bytes, void* stream_, double ratio, int* ratio_counts,
+              unsigned char* ratio_mask) {
+    const int ratio_blocks = ratio_counts ? (int)((nq + kRatioBlock - 1) / kRatioBlock) : 0;
     SFM_CHECK_ARG(dim == kDim, "sfm_knn2_l2_f32: dim must be 128 (got %d)", dim);
     SFM_CHECK_ARG(nq >= 0 && nt >= 0 && nq < INT_MAX / 256 && nt < INT_MAX / 2, "sfm_knn2_l2_f32: bad sizes nq=%lld nt=%lld",
                   (long long)nq, (long long)nt);
@@ -1628,7 +1645,7 @@ extern "C" int sfm_knn2_l2_f32(const float* q, int64_t nq, int64_t ldq, const fl
     static const int abl = [] { const char* e = getenv("SFM_KNN_ABL"); return e ? atoi(e) : 0; }();   // dev only
     if (p.split) {
         hipLaunchKernelGGL(knn_prep_kernel, dim3(kNormBlocks), dim3(1024), 0, stream, q, ldq, (int)nq, p.nq_pad, t, ldt, (int)nt,
-                           p.tiles * kTileT, w.qsplit, w.qn, w.tsplit, w.tn, w.bmax, w.midflag, stats);
+                           p.tiles * kTileT, w.qsplit, w.qn, w.tsplit, w.tn, w.bmax, w.midflag, stats, ratio_counts, ratio_blocks);
         SFM_CHECK_LAUNCH();
         sfm::prof_begin(sfm::kProfKnnFilter, stream);
 #define SFM_LAUNCH_SPLIT(A, WV)                                                                                        \
@@ -1660,7 +1677,7 @@ extern "C" int sfm_knn2_l2_f32(const float* q, int64_t nq, int64_t ldq, const fl
 #undef SFM_LAUNCH_SPLIT2
     } else {
     hipLaunchKernelGGL(knn_norms_kernel, dim3(kNormBlocks), dim3(256), 0, stream, t, ldt, (int)nt, w.tn, w.bmax,
-                       stats);
+                       stats, ratio_counts, ratio_blocks);
     SFM_CHECK_LAUNCH();
     sfm::prof_begin(sfm::kProfKnnFilter, stream);
 #define SFM_LAUNCH_FILTER(A, WV)                                                                                     \
@@ -1694,10 +1711,17 @@ extern "C" int sfm_knn2_l2_f32(const float* q, int64_t nq, int64_t ldq, const fl
     hipLaunchKernelGGL(knn_refine_kernel, dim3((unsigned)((nq + kRefQ - 1) / kRefQ)), dim3(256), 0, stream, q, ldq, (int)nq, t, ldt,
                        (int)nt, w.cand_s, w.cand_i, p.rows_per_block, p.tiles, p.units, p.G, p.smax * p.nsub, p.nsub,
                        force_mode, w.midflag, w.bmax, p.split ? w.tsplit + (size_t)2 * p.tiles * kTileT * kDim : nullptr, w.tn, idx, dist,
-                       stats, g_trace ? g_trace + 16384 : nullptr);
+                       stats, ratio, ratio_counts, ratio_mask, g_trace ? g_trace + 16384 : nullptr);
     sfm::prof_end(sfm::kProfKnnRefine, stream);
     SFM_CHECK_LAUNCH();
     return SFM_OK;
+}
+}  // namespace
+
+extern "C" int sfm_knn2_l2_f32(const float* q, int64_t nq, int64_t ldq, const float* t, int64_t nt, int64_t ldt,
+                               int dim, int32_t* idx, float* dist, int32_t* stats, void* ws, size_t ws_bytes,
+                               void* stream_) {
+    return knn2_impl(q, nq, ldq, t, nt, ldt, dim, idx, dist, stats, ws, ws_bytes, stream_, 0.0, nullptr, nullptr);
 }
 
 extern "C" size_t sfm_ratio_compact_ws_bytes(int64_t nq) {
@@ -1724,6 +1748,41 @@ extern "C" int sfm_ratio_compact(const int32_t* idx, const float* dist, int64_t 
     const unsigned blocks = (unsigned)((nq + kRatioBlock - 1) / kRatioBlock);
     hipLaunchKernelGGL(ratio_count_kernel, dim3(blocks), dim3(256), 0, stream, idx, dist, (int)nq, ratio, counts, mask);
     SFM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(ratio_scatter_kernel, dim3(blocks), dim3(256), 0, stream, idx, dist, (int)nq, ratio, counts, out_q,
+                       out_t, out_count);
+    SFM_CHECK_LAUNCH();
+    return SFM_OK;
+}
+
+extern "C" size_t sfm_match_l2_f32_ws_bytes(int64_t nq, int64_t nt, int dim) {
+    const size_t k = sfm_knn2_l2_f32_ws_bytes(nq, nt, dim);
+    return k ? k + sfm_ratio_compact_ws_bytes(nq) : 0;
+}
+
+extern "C" int sfm_match_l2_f32(const float* q, int64_t nq, int64_t ldq, const float* t, int64_t nt, int64_t ldt, int dim,
+                                double ratio, int32_t* idx, float* dist, int32_t* out_q, int32_t* out_t,
+                                int32_t* out_count, uint8_t* mask, int32_t* stats, void* ws, size_t ws_bytes,
+                                void* stream_) {
+    SFM_CHECK_ARG(out_count && (nq == 0 || (out_q && out_t)), "sfm_match_l2_f32: null pointer");
+    SFM_CHECK_ARG(nq >= 0 && nq < INT_MAX / 256, "sfm_match_l2_f32: bad nq");
+    hipStream_t stream = sfm::as_stream(stream_);
+    if (nq == 0 || nt == 0) {   // no neighbours, no matches
+        SFM_CHECK_HIP(hipMemsetAsync(out_count, 0, sizeof(int32_t), stream));
+        if (mask && nq > 0) SFM_CHECK_HIP(hipMemsetAsync(mask, 0, (size_t)nq, stream));
+        return knn2_impl(q, nq, ldq, t, nt, ldt, dim, idx, dist, stats, ws, ws_bytes, stream_, 0.0, nullptr, nullptr);
+    }
+    const size_t rbytes = sfm_ratio_compact_ws_bytes(nq);
+    const size_t need = sfm_match_l2_f32_ws_bytes(nq, nt, dim);
+    if (!ws || ws_bytes < need || need == 0) {
+        SFM_CHECK_ARG(dim == kDim, "sfm_match_l2_f32: dim must be 128 (got %d)", dim);
+        sfm::set_error("sfm_match_l2_f32: workspace too small (%zu < %zu)", ws_bytes, need);
+        return SFM_ERR_WORKSPACE;
+    }
+    int* counts = reinterpret_cast<int*>(sfm::align_up((size_t)(uintptr_t)ws, 256));
+    const int rc = knn2_impl(q, nq, ldq, t, nt, ldt, dim, idx, dist, stats, static_cast<char*>(ws) + rbytes, ws_bytes - rbytes,
+                             stream_, ratio, counts, mask);
+    if (rc != SFM_OK) return rc;
+    const unsigned blocks = (unsigned)((nq + kRatioBlock - 1) / kRatioBlock);
     hipLaunchKernelGGL(ratio_scatter_kernel, dim3(blocks), dim3(256), 0, stream, idx, dist, (int)nq, ratio, counts, out_q,
                        out_t, out_count);
     SFM_CHECK_LAUNCH();

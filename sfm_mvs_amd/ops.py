@@ -125,8 +125,14 @@ def match_pair(des0, des1, ratio=0.70):
 
     One host sync (reading the survivor count) — this is the find_features() boundary.
     """
-    idx, dist = knn2(des0, des1)
-    out_q, out_t, count = ratio_compact(idx, dist, ratio)
+    require_cuda(des0, des1)
+    if des0.dim() != 2 or des1.dim() != 2 or des0.shape[1] != 128 or des1.shape[1] != 128:
+        raise SfmHipError("match_pair: descriptors must be [n,128]")
+    if des0.dtype != torch.float32 or des1.dtype != torch.float32:
+        raise SfmHipError("match_pair: descriptors must be float32 (cv2 SIFT output)")
+    pm = PairMatcher(des0.shape[0], des1.shape[0], des0.device, ratio)
+    idx, dist, out_q, out_t, count = pm.run(des0 if des0.stride(1) == 1 else des0.contiguous(),
+                                            des1 if des1.stride(1) == 1 else des1.contiguous())
     m = int(count.item())
     return out_q[:m], out_t[:m], idx, dist
 
@@ -273,7 +279,7 @@ class PairMatcher:
         self.nq, self.nt, self.dim, self.ratio = int(nq), int(nt), int(dim), float(ratio)
         self.device = torch.device(device)
         lib = _lib.lib()
-        need = lib.sfm_knn2_l2_f32_ws_bytes(self.nq, self.nt, self.dim)
+        need = lib.sfm_match_l2_f32_ws_bytes(self.nq, self.nt, self.dim)
         if need == 0 and self.nq > 0:
             raise SfmHipError(f"PairMatcher: unsupported shape nq={nq} nt={nt} dim={dim}")
         self.ws = torch.empty(max(need, 256), dtype=torch.uint8, device=self.device)
@@ -283,7 +289,6 @@ class PairMatcher:
         self.out_q = torch.empty(self.nq, dtype=torch.int32, device=self.device)
         self.out_t = torch.empty(self.nq, dtype=torch.int32, device=self.device)
         self.count = torch.zeros(1, dtype=torch.int32, device=self.device)
-        self.rws = torch.empty(max(lib.sfm_ratio_compact_ws_bytes(self.nq), 256), dtype=torch.uint8, device=self.device)
 
     def run(self, des0, des1):
         require_cuda(des0, des1)
@@ -291,13 +296,10 @@ class PairMatcher:
             raise SfmHipError("PairMatcher.run: shape differs from the plan")
         if des0.dtype != torch.float32 or des1.dtype != torch.float32 or des0.stride(1) != 1 or des1.stride(1) != 1:
             raise SfmHipError("PairMatcher.run: float32 row-major descriptors required")
-        lib = _lib.lib()
-        s = stream_ptr()
-        check(lib.sfm_knn2_l2_f32(ptr(des0), self.nq, des0.stride(0), ptr(des1), self.nt, des1.stride(0), self.dim,
-                                  ptr(self.idx), ptr(self.dist), ptr(self.stats), ptr(self.ws), self.ws.numel(), s),
-              "sfm_knn2_l2_f32")
-        check(lib.sfm_ratio_compact(ptr(self.idx), ptr(self.dist), self.nq, self.ratio, ptr(self.out_q), ptr(self.out_t),
-                                    ptr(self.count), None, ptr(self.rws), self.rws.numel(), s), "sfm_ratio_compact")
+        check(_lib.lib().sfm_match_l2_f32(ptr(des0), self.nq, des0.stride(0), ptr(des1), self.nt, des1.stride(0), self.dim,
+                                          self.ratio, ptr(self.idx), ptr(self.dist), ptr(self.out_q), ptr(self.out_t),
+                                          ptr(self.count), None, ptr(self.stats), ptr(self.ws), self.ws.numel(), stream_ptr()),
+              "sfm_match_l2_f32")
         return self.idx, self.dist, self.out_q, self.out_t, self.count
 
 

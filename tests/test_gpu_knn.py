@@ -207,3 +207,40 @@ def test_fp16_mode_near_ties_and_duplicates(hip, oracle):
     gi, gd, stats = run(hip, q.astype(np.float32), t.astype(np.float32), stats=True)
     assert stats[3] == 1
     assert_bit_equal((gi, gd), oracle.knn2(q.astype(np.float32), t.astype(np.float32), nthreads=4))
+
+
+@pytest.mark.parametrize("nq", [1, 255, 1024, 1025, 9999, 16384, 16385, 50000])
+def test_ratio_compact_all_sizes(hip, oracle, nq):
+    """Count + ordered scatter over 1..49 workgroups: ascending queryIdx order, exact mask, exact count."""
+    rng = np.random.default_rng(nq)
+    d2 = rng.random(nq, dtype=np.float32) + np.float32(0.5)
+    d1 = (d2 * rng.random(nq, dtype=np.float32)).astype(np.float32)
+    d1[::17] = np.float32(0.7) * d2[::17]                      # products that round right at the threshold
+    dist = np.stack([d1, d2], 1)
+    idx = rng.integers(0, 1000, (nq, 2)).astype(np.int32)
+    idx[::29, 1] = -1                                          # a query with a single neighbour never passes
+    dist[::29, 1] = np.inf
+    oq, ot, cnt, mask = hip.ratio_compact(torch.from_numpy(idx).cuda(), torch.from_numpy(dist).cuda(), 0.70, want_mask=True)
+    wq, wt, wmask = oracle.ratio_filter(idx, dist, 0.70)
+    m = int(cnt.item())
+    assert m == len(wq)
+    assert np.array_equal(oq[:m].cpu().numpy(), wq) and np.array_equal(ot[:m].cpu().numpy(), wt)
+    assert np.array_equal(mask.cpu().numpy(), wmask)
+
+
+@pytest.mark.parametrize("nq,nt", [(2000, 3001), (17, 40), (5000, 1), (1025, 2048)])
+def test_fused_match_equals_knn_then_ratio(hip, oracle, nq, nt):
+    """sfm_match_l2_f32 (PairMatcher / match_pair) = sfm_knn2_l2_f32 + sfm_ratio_compact, bit for bit, = the oracle."""
+    rng = np.random.default_rng(nq + nt)
+    q, t, _ = planted_pair(rng, nq, nt, 0.3) if nt > 1 else (sift_like(rng, nq), sift_like(rng, nt), None)
+    qd, td = torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda()
+    pm = hip.PairMatcher(nq, nt, qd.device, ratio=0.70)
+    for _ in range(2):                                      # second run: the survivor counters are re-zeroed by the call
+        idx, dist, out_q, out_t, count = pm.run(qd, td)
+    m = int(count.item())
+    wi, wd = oracle.knn2(q, t, nthreads=8)
+    wq, wt, _ = oracle.ratio_filter(wi, wd, 0.70)
+    assert_bit_equal((idx.cpu().numpy(), dist.cpu().numpy()), (wi, wd))
+    assert m == len(wq) and np.array_equal(out_q[:m].cpu().numpy(), wq) and np.array_equal(out_t[:m].cpu().numpy(), wt)
+    mq, mt, _, _ = hip.match_pair(qd, td, 0.70)
+    assert np.array_equal(mq.cpu().numpy(), wq) and np.array_equal(mt.cpu().numpy(), wt)
