@@ -229,13 +229,14 @@ int sfm_score_pnp(const double* poses_dev, int h, const double* K_host,
  * Measurement hook (no reference counterpart): when enabled, the library brackets
  * its dominant kernels with hipEvents recorded on the launch stream.
  * sfm_profile_read synchronises those events, returns the summed device time
- * and launch count of one slot, and resets the slot.
- *   slot 0 knn filter (MFMA)   1 knn refine+fallback   2 triangulate
+ * and launch count of one slot, and resets the slot (toggling the switch does not).
+ *   slot 0 knn filter (MFMA)   1 knn refine (+ rescans)   2 triangulate
  *        3 dense BA sweep       4 indexed residual sweep
  * ---------------------------------------------------------------------- */
 int sfm_profile_enable(int on);
 /* Dev diagnostics: when non-NULL, every knn filter workgroup b writes int64[4] =
- * {start tick, end tick (100 MHz), HW_ID, XCC_ID} at dev_buf[4*b..]; NULL disables. */
+ * {start tick, end tick (100 MHz), HW_ID, XCC_ID} at dev_buf[4*b..] and every refine workgroup w
+ * int64[16] phase ticks at dev_buf[16384 + 16*w..]; NULL disables. */
 int sfm_debug_set_trace(void* dev_buf);
 int sfm_profile_read(int slot, double* total_ms_host, int64_t* launches_host);
 

@@ -18,7 +18,8 @@ import time
 for _ in range(3):
     pm.run(q, t)
 torch.cuda.synchronize()
-ops.profile_enable(True)
+prof = os.environ.get('SFM_NO_PROF') is None
+ops.profile_enable(prof)
 t0 = time.perf_counter()
 for _ in range(n):
     pm.run(q, t)

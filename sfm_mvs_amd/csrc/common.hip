@@ -51,8 +51,7 @@ void prof_end(int slot, hipStream_t s) {
 
 extern "C" int sfm_profile_enable(int on) {
     std::lock_guard<std::mutex> lk(sfm::g_prof_mu);
-    sfm::g_prof.on = on != 0;
-    for (int k = 0; k < sfm::kProfSlots; ++k) sfm::g_prof.used[k] = 0;
+    sfm::g_prof.on = on != 0;          // slots keep accumulating across on/off toggles; sfm_profile_read resets one
     return SFM_OK;
 }
 
