@@ -8,7 +8,7 @@ nt = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
 q = torch.rand((nq, 128)).cuda(); t = torch.rand((nt, 128)).cuda()
 pm = ops.PairMatcher(nq, nt, q.device)
 for _ in range(3): pm.run(q, t)
-tr = torch.zeros((4096, 4), dtype=torch.int64, device="cuda")
+tr = torch.zeros((8192, 4), dtype=torch.int64, device="cuda")
 _lib.lib().sfm_debug_set_trace(ctypes.c_void_p(tr.data_ptr()))
 pm.run(q, t); torch.cuda.synchronize()
 _lib.lib().sfm_debug_set_trace(None)
@@ -17,6 +17,10 @@ t0 = a[:, 0].min(); st = (a[:, 0] - t0) / 100.0; en = (a[:, 1] - t0) / 100.0   #
 hw = a[:, 2]; xcc = a[:, 3] & 0xF
 cu = (hw >> 8) & 0xF; sh = (hw >> 12) & 1; se = (hw >> 13) & 0x7
 key = xcc * 10000 + se * 100 + sh * 16 + cu
+b = tr.view(-1)[8192:8192 + 4 * G].view(G, 4).cpu().numpy()
+print("prologue (first segment) us: med %.1f max %.1f | last loop end -> WG end us: med %.1f max %.1f" % (np.median(b[:, 0]) / 100.0, b[:, 0].max() / 100.0, np.median(a[:, 1] - b[:, 1]) / 100.0, (a[:, 1] - b[:, 1]).max() / 100.0))
+mhz = (b[:, 3] - b[:, 2]) / ((a[:, 1] - a[:, 0]) / 100.0)
+print("shader clock during the kernel (clock64 ticks per us): min %.0f med %.0f max %.0f" % (mhz.min(), np.median(mhz), mhz.max()))
 print("G", G, "start us: min %.1f max %.1f | end us: min %.1f max %.1f | dur: min %.1f med %.1f max %.1f" % (st.min(), st.max(), en.min(), en.max(), (en-st).min(), np.median(en-st), (en-st).max()))
 u, c = np.unique(key, return_counts=True)
 print("distinct CUs used:", len(u), "blocks/CU histogram:", dict(zip(*np.unique(c, return_counts=True))))

@@ -621,11 +621,15 @@ __global__ __launch_bounds__(64 * W, 4) void knn_filter_split_kernel(
 //     from LDS feeds 6 MFMAs and the two groups' accumulators form two independent dependency chains;
 //   * software pipelining inside the wave: while tile t runs on the matrix pipe, the packed-key epilogue of
 //     tile t-1 (its accumulators are kept) is interleaved between the MFMAs on the vector pipe.
+// The pack is ONE v_and_or_b32 only if the mask sits in a VGPR and the sequence number in an SGPR (gfx9 VOP3 takes a
+// single scalar operand and no literal; left alone hipcc keeps both scalar and emits v_and + v_or).
 template <int W>
-__device__ __forceinline__ void key_insert4(const f32x16& a, int r0, int seq0, int& k0, int& k1, int& k2) {
+__device__ __forceinline__ void key_insert4(const f32x16& a, int r0, int seq0 /*wave-uniform*/, int vmask /*VGPR holding ~kKeyMask*/,
+                                            int& k0, int& k1, int& k2) {
 #pragma unroll
     for (int r = r0; r < r0 + W; ++r) {
-        const int key = (__float_as_int(a[r]) & ~kKeyMask) | (seq0 + r);
+        int key;
+        asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(key) : "v"(a[r]), "v"(vmask), "s"(seq0 + r));
         const int lo = min(key, k0);
         const int m1 = max(min(key, k1), min(max(key, k1), k0));
         k2 = max(min(key, k1), min(max(key, k1), k2));
@@ -659,7 +663,7 @@ template <int ABL, int W, bool KMID>
 __device__ __forceinline__ void filter_split2_body(
     float* smem, const unsigned short* __restrict__ qsplit, const float* __restrict__ qnorm, int nq, int nq_pad,
     const unsigned short* __restrict__ tsplit, int nt_pad, const float* __restrict__ tn, int tiles, int64_t units,
-    int smax, int nsub, float* __restrict__ cand_s, int* __restrict__ cand_i) {
+    int smax, int nsub, float* __restrict__ cand_s, int* __restrict__ cand_i, long long* __restrict__ trace) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31;
@@ -724,6 +728,9 @@ __device__ __forceinline__ void filter_split2_body(
             }
             qn[g] = qok[g] ? qnorm[qrow0 + 32 * g] : 0.f;
         }
+        const float b_aug[2] = {h ? qn[0] : 1.f, h ? qn[1] : 1.f};
+        int vmask;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(vmask) : "s"(~kKeyMask));
 
         int ka[2] = {kKeyInf, kKeyInf}, kb[2] = {kKeyInf, kKeyInf}, kc[2] = {kKeyInf, kKeyInf};
         int sub = 0, sub_t0 = t_begin;
@@ -740,6 +747,7 @@ __device__ __forceinline__ void filter_split2_body(
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if (trace && threadIdx.x == 0) trace[8192 + 4 * blockIdx.x + 0] += wall_clock64() - trace[4 * blockIdx.x];   // dev: prologue(s)
 
         f32x16 accA[2], accB[2];
         // one tile: MFMAs of tile t into `cur`, packed-key inserts of tile t-1 from `prev` interleaved.
@@ -754,61 +762,74 @@ __device__ __forceinline__ void filter_split2_body(
             const int buf = (t - t_begin) % kRing;
             if (t + 2 < t_end && !(ABL & 4)) stage(t + 2, (buf + 2) % kRing);
             const unsigned abase = lds0 + (unsigned)(((ABL & 4) ? 0 : buf) * kTileFloats) * 4u + (unsigned)j * 256u + ((unsigned)hm << 4);
-            const unsigned tnad = lds_tn + (unsigned)((ABL & 4) ? 0 : buf) * 256u + 16u * h;
-            f32x4 tv[4];
-            u32x4 ah[2], am[2];
-            asm volatile("ds_read_b128 %0, %1" : "=v"(tv[0]) : "v"(tnad));
-            asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(tv[1]) : "v"(tnad));
-            asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(tv[2]) : "v"(tnad));
-            asm volatile("ds_read_b128 %0, %1 offset:96" : "=v"(tv[3]) : "v"(tnad));
-            asm volatile("ds_read_b128 %0, %1" : "=v"(ah[0]) : "v"(abase));
-            if (KMID) asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(am[0]) : "v"(abase));
-            if (KMID) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]), "+v"(tv[3]));
-            else asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(tv[0]), "+v"(tv[1]), "+v"(tv[2]), "+v"(tv[3]));
+            const unsigned tnad = lds_tn + (unsigned)((ABL & 4) ? 0 : buf) * 256u + 4u * j;
+            float tnj;
+            u32x4 ah[KMID ? 2 : 8], am[2];
+            asm volatile("ds_read_b32 %0, %1" : "=v"(tnj) : "v"(tnad));
+            if (KMID) {
+                asm volatile("ds_read_b128 %0, %1" : "=v"(ah[0]) : "v"(abase));
+                asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(am[0]) : "v"(abase));
+                asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(tnj));
+            } else {
+                // single-product body: a k-step is only 2 MFMAs (64 pipe cycles), less than the LDS latency, so the
+                // whole A fragment of the tile (8 x 16 B per lane) is requested up front; LDS returns in order
 #pragma unroll
-            for (int b = 0; b < 4; ++b)
+                for (int st = 0; st < 8; ++st) asm volatile("ds_read_b128 %0, %1" : "=v"(ah[st]) : "v"(abase ^ (32u * st)));
+                asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(tnj));
+            }
+            // accumulator init ||t||^2 + ||q||^2 as one fp32 MFMA (A = [||t||^2, 1], B = [1; ||q||^2], C = 0): the loop is
+            // bound by VALU issue (the matrix pipe idles more than half the time), so 32 v_add per tile cost more
+            // than 2 x 64 matrix-pipe cycles
+            {
+                const float a_aug = h ? 1.f : tnj;
+                const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int g = 0; g < 2; ++g) cur[g][4 * b + e] = tv[b][e] + qn[g];
-            const int seq0 = ((t - 1) - sub_t0) << 4;
+                for (int g = 0; g < 2; ++g) cur[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_aug, b_aug[g], zero, 0, 0, 0);
+            }
+            const int seq0 = __builtin_amdgcn_readfirstlane(((t - 1) - sub_t0) << 4);
 #pragma unroll
             for (int st = 0; st < 8; ++st) {
-                if (st + 1 < 8) {
-                    const unsigned ad = abase ^ (32u * (st + 1));
-                    asm volatile("ds_read_b128 %0, %1" : "=v"(ah[(st + 1) & 1]) : "v"(ad));
-                    if (KMID) {
+                if constexpr (KMID) {
+                    if (st + 1 < 8) {
+                        const unsigned ad = abase ^ (32u * (st + 1));
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(ah[(st + 1) & 1]) : "v"(ad));
                         asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(am[(st + 1) & 1]) : "v"(ad));
                         asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ah[st & 1]), "+v"(am[st & 1]));
                     } else {
-                        asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(ah[st & 1]));
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[st & 1]), "+v"(am[st & 1]));
                     }
-                } else if (KMID) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[st & 1]), "+v"(am[st & 1]));
-                } else {
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[st & 1]));
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                const bf16x8 Ah = __builtin_bit_cast(bf16x8, ah[st & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const bf16x8 Ah = __builtin_bit_cast(bf16x8, ah[st & 1]), Am = __builtin_bit_cast(bf16x8, am[st & 1]);
 #pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    const bf16x8 Bh = __builtin_bit_cast(bf16x8, bh[g][st]);
-                    if (KMID) {
+                    for (int g = 0; g < 2; ++g) {
+                        const bf16x8 Bh = __builtin_bit_cast(bf16x8, bh[g][st]), Bm = __builtin_bit_cast(bf16x8, bm[g][st]);
                         cur[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, cur[g], 0, 0, 0);
-                        const bf16x8 Am = __builtin_bit_cast(bf16x8, am[st & 1]), Bm = __builtin_bit_cast(bf16x8, bm[g][st]);
                         cur[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm, cur[g], 0, 0, 0);
                         cur[g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, cur[g], 0, 0, 0);
-                    } else {
-                        cur[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[st & 1]),
-                                                                       __builtin_bit_cast(f16x8, bh[g][st]), cur[g], 0, 0, 0);
                     }
+                } else {
+                    switch (st) {                        // wait for fragment st only: 7 - st later ones stay in flight
+                        case 0: asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(ah[0])); break;
+                        case 1: asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(ah[1 % (KMID ? 2 : 8)])); break;
+                        case 2: asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(ah[2 % (KMID ? 2 : 8)])); break;
+                        case 3: asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ah[3 % (KMID ? 2 : 8)])); break;
+                        case 4: asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(ah[4 % (KMID ? 2 : 8)])); break;
+                        case 5: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ah[5 % (KMID ? 2 : 8)])); break;
+                        case 6: asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(ah[6 % (KMID ? 2 : 8)])); break;
+                        default: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[7 % (KMID ? 2 : 8)])); break;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int g = 0; g < 2; ++g)
+                        cur[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[st % (KMID ? 2 : 8)]),
+                                                                       __builtin_bit_cast(f16x8, bh[g][st]), cur[g], 0, 0, 0);
                 }
                 if (have_prev && (ABL & 1)) {    // dev ablation: keep the MFMAs alive with one op per k-step
                     ka[0] = min(ka[0], __float_as_int(prev[0][2 * st]) + __float_as_int(prev[0][2 * st + 1]));
                     ka[1] = min(ka[1], __float_as_int(prev[1][2 * st]) + __float_as_int(prev[1][2 * st + 1]));
                 } else if (have_prev) {          // 2 values of each group per k-step: 16 VALU beside the MFMAs
-                    key_insert4<2>(prev[0], 2 * st, seq0, ka[0], kb[0], kc[0]);
-                    key_insert4<2>(prev[1], 2 * st, seq0, ka[1], kb[1], kc[1]);
+                    key_insert4<2>(prev[0], 2 * st, seq0, vmask, ka[0], kb[0], kc[0]);
+                    key_insert4<2>(prev[1], 2 * st, seq0, vmask, ka[1], kb[1], kc[1]);
                 }
             }
             // Tile t+1 must have landed for every wave before anyone reads it; tile t+2 (just issued) stays in flight
@@ -822,15 +843,13 @@ __device__ __forceinline__ void filter_split2_body(
             }
         };
 
-        // accA = tile being computed, accB = previous tile (its epilogue runs inside tile()); 32 v_mov per tile
-        // instead of a second copy of the ~1k-instruction body (instruction-cache footprint).
-        bool have_prev = false;
-        for (int t = t_begin; t < t_end; ++t) {
-            tile(accA, accB, t, have_prev);
-            accB[0] = accA[0];
-            accB[1] = accA[1];
-            have_prev = true;
+        // Two copies of the tile body with the accumulator sets swapping roles (tile being computed / previous tile,
+        // whose epilogue runs inside tile()): the loop is VALU-issue bound and a rotating copy would cost 32 v_mov per tile.
+        for (int t = t_begin; t < t_end; t += 2) {
+            tile(accA, accB, t, t > t_begin);
+            if (t + 1 < t_end) tile(accB, accA, t + 1, true);
         }
+        if (trace && threadIdx.x == 0) trace[8192 + 4 * blockIdx.x + 1] = wall_clock64();   // dev: tile loop done
         if (t_end > t_begin) {                             // epilogue of the last tile
             const int tl = t_end - 1;
             if (tl - sub_t0 == kSubTiles) {
@@ -838,8 +857,13 @@ __device__ __forceinline__ void filter_split2_body(
                 ++sub;
                 sub_t0 = tl;
             }
-            key_insert4<16>(accB[0], 0, (tl - sub_t0) << 4, ka[0], kb[0], kc[0]);
-            key_insert4<16>(accB[1], 0, (tl - sub_t0) << 4, ka[1], kb[1], kc[1]);
+            if ((t_end - t_begin) & 1) {
+                key_insert4<16>(accA[0], 0, __builtin_amdgcn_readfirstlane((tl - sub_t0) << 4), vmask, ka[0], kb[0], kc[0]);
+                key_insert4<16>(accA[1], 0, __builtin_amdgcn_readfirstlane((tl - sub_t0) << 4), vmask, ka[1], kb[1], kc[1]);
+            } else {
+                key_insert4<16>(accB[0], 0, __builtin_amdgcn_readfirstlane((tl - sub_t0) << 4), vmask, ka[0], kb[0], kc[0]);
+                key_insert4<16>(accB[1], 0, __builtin_amdgcn_readfirstlane((tl - sub_t0) << 4), vmask, ka[1], kb[1], kc[1]);
+            }
         }
         flush(sub, sub_t0);
 #pragma unroll
@@ -873,14 +897,18 @@ __global__ __launch_bounds__(64 * W, 2) void knn_filter_split2_kernel(
         trace[4 * blockIdx.x + 0] = wall_clock64();
         trace[4 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg(0xF804);
         trace[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg(0xF814);
+        trace[8192 + 4 * blockIdx.x + 2] = clock64();
     }
     const int lane = threadIdx.x & 63;
     const bool need_mid = (force_mode >= 0 ? force_mode : knn_filter_mode(midflag, bmax, lane)) == kModeSplit;
     if (need_mid)
-        filter_split2_body<ABL, W, true>(smem, qsplit, qnorm, nq, nq_pad, tsplit, nt_pad, tn, tiles, units, smax, nsub, cand_s, cand_i);
+        filter_split2_body<ABL, W, true>(smem, qsplit, qnorm, nq, nq_pad, tsplit, nt_pad, tn, tiles, units, smax, nsub, cand_s, cand_i, trace);
     else
-        filter_split2_body<ABL, W, false>(smem, qsplit, qnorm, nq, nq_pad, tsplit, nt_pad, tn, tiles, units, smax, nsub, cand_s, cand_i);
-    if (trace && threadIdx.x == 0) trace[4 * blockIdx.x + 1] = wall_clock64();
+        filter_split2_body<ABL, W, false>(smem, qsplit, qnorm, nq, nq_pad, tsplit, nt_pad, tn, tiles, units, smax, nsub, cand_s, cand_i, trace);
+    if (trace && threadIdx.x == 0) {
+        trace[4 * blockIdx.x + 1] = wall_clock64();
+        trace[8192 + 4 * blockIdx.x + 3] = clock64();
+    }
 }
 
 // ---------------------------------------------------------------- exact direct-form distance
