@@ -28,7 +28,43 @@ def extract(names):
     return ns
 
 
+def helper_goldens():
+    """The reference's OWN helper functions (Triangulation sfm.py:45, PnP :60, ReprojectionError :79), AST-extracted and
+    executed with `cv2` bound to the CPU oracle's cv2-named facade: pins the helpers' data flow (transposed views,
+    homogeneous division, (N,1,3) layouts, the stray positional argument, inlier gathers) — everything of the
+    reference that is not inside OpenCV.  Inputs + outputs are stored; the GPU tests replay them on the HIP path."""
+    import sys
+    root = os.path.dirname(os.path.dirname(OUT))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    from oracle import oracle as O
+    from oracle_backend import OracleCv2
+    from datagen import decompose_P, gustav_pair
+    ns = extract({"Triangulation", "PnP", "ReprojectionError"})
+    ns["cv2"] = OracleCv2(O)
+    out = {}
+    for tag, k, n, sigma in (("a", 1, 400, 0.3), ("b", 30, 250, 1.0)):
+        K, P1, P2, X, x1, x2 = gustav_pair(k, n, sigma, seed=100 + k)
+        x2[::23] += np.float32(25.0)                                # a few gross outliers for the PnP inlier set
+        # sfm.py:313-317: first call with (M,2) arrays, repeat=False
+        pts1, pts2, cloud = ns["Triangulation"](P1, P2, x1, x2, K, False)
+        R, t = decompose_P(K, P2)
+        Rt = np.hstack([R, t.reshape(3, 1)])
+        err1, X3, proj1 = ns["ReprojectionError"](cloud, pts2, Rt, K, 1)
+        # sfm.py:325: PnP on the bootstrap cloud, initial = 1
+        Rp, tp, p_in, X_in, p0_in = ns["PnP"](X3, pts2, K, np.zeros((5, 1), np.float32), pts1, 1)
+        # sfm.py:362-366: later frames, initial = 0, then the homogenity = 0 error
+        Rq, tq, q_in, Xq_in, q0_in = ns["PnP"](X3[:, 0, :], x2, K, np.zeros((5, 1), np.float32), x1, 0)
+        err0, X0, proj0 = ns["ReprojectionError"](Xq_in, q_in, np.hstack([Rq, tq]), K, 0)
+        for name, v in dict(K=K, P1=P1, P2=P2, x1=x1, x2=x2, Rt=Rt, pts1=np.ascontiguousarray(pts1), pts2=np.ascontiguousarray(pts2),
+                            cloud=cloud, err1=err1, X3=X3, proj1=proj1, Rp=Rp, tp=tp, p_in=p_in, X_in=X_in, p0_in=p0_in,
+                            Rq=Rq, tq=tq, q_in=q_in, Xq_in=Xq_in, q0_in=q0_in, err0=err0, proj0=proj0).items():
+            out[f"{tag}_{name}"] = np.asarray(v)
+    np.savez_compressed(os.path.join(OUT, "helpers.npz"), **out)
+
+
 def main():
+    helper_goldens()
     ns = extract({"common_points", "to_ply"})
     rng = np.random.default_rng(20260928)
 

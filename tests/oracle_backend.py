@@ -52,6 +52,15 @@ class OracleCv2:
         from sfm_mvs_amd import cv2compat
         return cv2compat.convertPointsFromHomogeneous(src)
 
+    def projectPoints(self, objectPoints, rvec, tvec, cameraMatrix, distCoeffs=None):
+        X = np.asarray(objectPoints)
+        p64, p32 = self.O.project_points(np.ravel(rvec), np.ravel(tvec), cameraMatrix, np.float32(X).reshape(-1, 3))
+        return (p32 if X.dtype == np.float32 else p64).reshape(-1, 1, 2), None
+
+    def norm(self, a, b=None, normType=4):
+        d = np.asarray(a) if b is None else np.asarray(a) - np.asarray(b)      # difference in the inputs' dtype
+        return float(np.sqrt(np.sum(np.float64(d) ** 2)))                        # squares accumulated in double
+
     def findEssentialMat(self, p1, p2, K, method=8, prob=0.999, threshold=1.0, mask=None):
         return self.ransac.find_essential_mat(p1, p2, np.asarray(K, np.float64), prob, threshold, backend=self.be)
 

@@ -175,3 +175,24 @@ def test_common_points_kernel_vs_reference_golden_vectors(hip, oracle):
 def cu32(a):
     import torch
     return torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+
+
+def test_hip_helpers_against_the_references_own_helpers(hip, oracle):
+    """Same replay as tests/test_oracle_golden.py, on the HIP back-end, against the golden outputs of the reference's
+    helper source: index sets identical, floating-point outputs within north_star's 1e-4."""
+    import os
+    from datagen import GOLDEN
+    from test_oracle_golden import _replay_helpers
+    from sfm_mvs_amd import pipeline as pl
+    g = np.load(os.path.join(GOLDEN, "helpers.npz"))
+    for tag in ("a", "b"):
+        got = _replay_helpers(pl, None, g, tag)
+        for k, v in got.items():
+            want = g[f"{tag}_{k}"]
+            v = np.asarray(v)
+            assert v.shape == want.shape, (tag, k, v.shape, want.shape)       # same inlier COUNT for the gathered arrays
+            if k in ("pts1", "pts2", "p_in", "p0_in", "q_in", "q0_in"):         # pure gathers of inputs: the inlier sets
+                assert np.array_equal(v, want), (tag, k)
+            else:
+                scale = max(np.abs(want).max(), 1e-30)
+                assert np.abs(v - want).max() <= 1e-4 * scale, (tag, k, np.abs(v - want).max(), scale)

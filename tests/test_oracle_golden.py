@@ -31,3 +31,33 @@ def test_to_ply_filter_golden(oracle):
     cols = z["colors"][keep]
     assert np.array_equal(np.array([[int(v) for v in r[3:]] for r in body]), cols.astype(int))
     assert keep.sum() < len(keep)                              # the far outliers were dropped
+
+
+def _replay_helpers(pl, be, g, tag):
+    """Replays the call sequence of tests/golden/make_golden.py::helper_goldens on `be`; returns the same outputs."""
+    K, P1, P2, x1, x2, Rt = (g[f"{tag}_{k}"] for k in ("K", "P1", "P2", "x1", "x2", "Rt"))
+    pts1, pts2, cloud = pl.Triangulation(P1, P2, x1, x2, K, False, be=be)
+    err1, X3, proj1 = pl.ReprojectionError(cloud, pts2, Rt, K, 1, be=be)
+    Rp, tp, p_in, X_in, p0_in = pl.PnP(X3, pts2, K, np.zeros((5, 1), np.float32), pts1, 1, be=be)
+    Rq, tq, q_in, Xq_in, q0_in = pl.PnP(X3[:, 0, :], x2, K, np.zeros((5, 1), np.float32), x1, 0, be=be)
+    err0, X0, proj0 = pl.ReprojectionError(Xq_in, q_in, np.hstack([Rq, tq]), K, 0, be=be)
+    return dict(pts1=np.ascontiguousarray(pts1), pts2=np.ascontiguousarray(pts2), cloud=cloud, err1=err1, X3=X3, proj1=proj1,
+                Rp=Rp, tp=tp, p_in=p_in, X_in=X_in, p0_in=p0_in, Rq=Rq, tq=tq, q_in=q_in, Xq_in=Xq_in, q0_in=q0_in,
+                err0=err0, proj0=proj0)
+
+
+def test_pipeline_helpers_equal_the_references_own_helpers(oracle):
+    """helpers.npz = outputs of the REFERENCE's Triangulation / PnP / ReprojectionError source (AST-executed over the
+    oracle's cv2 facade).  The package's same-named helpers over the same operators must agree bit for bit: shapes,
+    transposed views, float32 homogeneous division, inlier gathers, the error's `/ len(p)`."""
+    from oracle_backend import oracle_pipeline_backend
+    from sfm_mvs_amd import pipeline as pl
+    g = np.load(os.path.join(GOLDEN, "helpers.npz"))
+    be = oracle_pipeline_backend(oracle)
+    for tag in ("a", "b"):
+        got = _replay_helpers(pl, be, g, tag)
+        for k, v in got.items():
+            want = g[f"{tag}_{k}"]
+            assert np.shape(v) == want.shape, (tag, k, np.shape(v), want.shape)
+            assert np.array_equal(np.asarray(v), want), (tag, k)
+        assert len(got["p_in"]) < len(g[f"{tag}_x1"])              # the planted outliers were rejected
