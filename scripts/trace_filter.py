@@ -30,3 +30,9 @@ print("late starters:", late.sum(), "their start range", (st[late].min() if late
 for k in u[c == c.max()][:3]:
     sel = key == k; print(" CU", k, "blocks", np.flatnonzero(sel), "start", st[sel].round(1), "end", en[sel].round(1))
 
+# do the slow workgroups coincide with the ones that cross a query-row-block boundary (second prologue)?
+tiles = (nt + 31) // 32; n_rb = (nq + 511) // 512; units = n_rb * tiles
+ub = np.array([units * b // G for b in range(G + 1)])
+cross = (ub[:-1] // tiles) != ((ub[1:] - 1) // tiles)
+d = en - st
+print("crossing WGs: %d, their duration med %.1f us; others med %.1f us (max %.1f)" % (cross.sum(), np.median(d[cross]), np.median(d[~cross]), d[~cross].max()))

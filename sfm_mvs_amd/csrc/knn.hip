@@ -25,6 +25,9 @@
 #include <climits>
 #include <cstdlib>
 #include <type_traits>
+#include <algorithm>
+#include <mutex>
+#include <vector>
 
 namespace {
 
@@ -38,6 +41,7 @@ constexpr int kTileT = 32;             // train rows per LDS tile (= MFMA M)
 constexpr int kResidentWaves = 4096;   // 256 CUs x 16 waves (4 per SIMD at <= 128 VGPRs)
 constexpr int kMaxSlots = 258;         // cap on filter blocks that may touch one query row block (all 256 CUs on one)
 constexpr float kInf = __builtin_huge_valf();
+constexpr int kSubTilesHost = 32;      // = kSubTiles (tiles per substream), needed by make_plan before its definition
 
 // Work decomposition ("stream-K" over the flattened (query row block, train tile) unit space):
 // block b owns units [units*b/G, units*(b+1)/G).  Every block gets the same number of units (+-1),
@@ -55,6 +59,7 @@ struct Plan {
     int G;             // filter blocks
     int smax;          // candidate slots reserved per row block (>= blocks touching it)
     int nsub;          // substreams (32 tiles each) per slot
+    int seg_cost;      // partition weight of a segment in tile-steps (0: plain equal-units split)
 };
 
 __host__ __device__ inline int64_t unit_begin(int64_t units, int G, int b) { return units * b / G; }
@@ -68,11 +73,83 @@ __host__ __device__ inline int block_of_unit(int64_t units, int G, int64_t u) {
     return b;
 }
 
+// The partition as a function: block b owns units [part_begin(b), part_begin(b+1)).  seg_cost = 0 is unit_begin().
+// seg_cost > 0 (pipelined split2 filter) equalises COST instead of units: every segment — the part of a block's range
+// inside one query row block — pays seg_cost tile-steps for its prologue (query fragments, ring start) and flush, so
+// a block that crosses a row-block boundary gets correspondingly fewer tiles (measured at 10k x 10k: crossing blocks
+// ran 5 us = 4 tile-steps longer than the rest and set the kernel's duration).  In "cost space" a row block is
+// tiles + seg_cost long and every block gets the same length (+-1); mapping back drops the seg_cost gaps.
+struct Partition {
+    int64_t units;
+    int tiles, G, seg_cost;
+    int64_t total;     // cost-space length of the whole problem: units + seg_cost per row block
+};
+
+__host__ __device__ inline Partition make_partition(int64_t units, int tiles, int G, int seg_cost) {
+    Partition pt{units, tiles, G, seg_cost, 0};
+    if (seg_cost > 0) {
+        const int64_t n_rb = units / tiles;
+        pt.total = units + (int64_t)seg_cost * n_rb;
+    }
+    return pt;
+}
+
+__host__ __device__ inline int64_t part_begin(const Partition& pt, int b) {
+    if (pt.seg_cost == 0) return unit_begin(pt.units, pt.G, b);
+    const int64_t y = pt.total * b / pt.G, period = pt.tiles + pt.seg_cost;
+    const int64_t rb = y / period, rem = y - rb * period;
+    const int64_t x = rb * pt.tiles + (rem < pt.tiles ? rem : pt.tiles);
+    return x < pt.units ? x : pt.units;
+}
+constexpr int kSegCostTiles = 5;
+int g_seg_cost = [] { const char* e = getenv("SFM_KNN_SEGCOST"); return e ? atoi(e) : kSegCostTiles; }();   // dev override
+
+// One workgroup fills the partition tables the filter / refine kernels read: begin[G+1], and per query row block the
+// first and last block that touches it.
+__device__ inline void fill_partition_tables(const Partition pt, int n_rb, int64_t* __restrict__ begin, int* __restrict__ rb_first,
+                                             int* __restrict__ rb_last) {
+    const int G = pt.G, tiles = pt.tiles;
+    for (int b = threadIdx.x; b <= G; b += blockDim.x) begin[b] = b == G ? pt.units : part_begin(pt, b);
+    __threadfence_block();
+    __syncthreads();
+    for (int rb = threadIdx.x; rb < n_rb; rb += blockDim.x) {
+        const int64_t u0 = (int64_t)rb * tiles, u1 = (int64_t)(rb + 1) * tiles - 1;
+        int lo = 0, hi = G - 1;                                // smallest b with begin[b+1] > u0
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (begin[mid + 1] > u0) hi = mid; else lo = mid + 1;
+        }
+        rb_first[rb] = lo;
+        lo = 0, hi = G - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (begin[mid + 1] > u1) hi = mid; else lo = mid + 1;
+        }
+        rb_last[rb] = lo;
+    }
+}
+
 // 0 = split-bf16 filter (default), 1 = fp32-MFMA filter.  Initialised from SFM_KNN_FILTER=f32, changed by
 // sfm_knn_set_filter().  Both give bit-identical results; they differ in speed only.
 int g_filter_mode = [] { const char* e = getenv("SFM_KNN_FILTER"); return (e && e[0] == 'f') ? 1 : 0; }();
 
+Plan make_plan_uncached(int64_t nq, int64_t nt);
+
+// Planning walks the partition (O(G + row blocks)): keep the last plan.
 Plan make_plan(int64_t nq, int64_t nt) {
+    static std::mutex mu;
+    static int64_t k_nq = -1, k_nt = -1;
+    static int k_mode = -1, k_seg = -1;
+    static Plan cached;
+    std::lock_guard<std::mutex> lk(mu);
+    if (nq != k_nq || nt != k_nt || g_filter_mode != k_mode || g_seg_cost != k_seg) {
+        cached = make_plan_uncached(nq, nt);
+        k_nq = nq; k_nt = nt; k_mode = g_filter_mode; k_seg = g_seg_cost;
+    }
+    return cached;
+}
+
+Plan make_plan_uncached(int64_t nq, int64_t nt) {
     Plan p;
     static const int env_w = [] { const char* e = getenv("SFM_KNN_WAVES"); return e ? atoi(e) : 0; }();   // dev override
     p.waves = (env_w == 4 || env_w == 8 || env_w == 16) ? env_w : 8;
@@ -91,10 +168,25 @@ Plan make_plan(int64_t nq, int64_t nt) {
     if (g > (int64_t)p.n_rb * (kMaxSlots - 2)) g = (int64_t)p.n_rb * (kMaxSlots - 2);
     if (g < 1) g = 1;
     p.G = (int)g;
-    p.smax = p.n_rb > 0 ? p.G / p.n_rb + 2 : 1;
-    const int64_t maxseg = (p.units + p.G - 1) / p.G;                 // most tiles one workgroup can own
-    p.nsub = (int)((maxseg + 31) / 32);
-    if (p.nsub < 1) p.nsub = 1;
+    p.seg_cost = (p.split && p.qg == 2) ? g_seg_cost : 0;
+    {   // candidate slots per row block / substreams per slot from the actual partition
+        std::vector<int64_t> begin((size_t)p.G + 1);
+        const Partition pt = make_partition(p.units, p.tiles, p.G, p.seg_cost);
+        for (int b = 0; b <= p.G; ++b) begin[b] = b == p.G ? p.units : part_begin(pt, b);
+        int64_t maxseg = 1;
+        for (int b = 0; b < p.G; ++b) maxseg = std::max(maxseg, begin[b + 1] - begin[b]);
+        int touch = 1, b0 = 0, b1 = 0;
+        for (int rb = 0; rb < p.n_rb; ++rb) {
+            const int64_t u0 = (int64_t)rb * p.tiles, u1 = (int64_t)(rb + 1) * p.tiles - 1;
+            while (b0 + 1 < p.G && begin[b0 + 1] <= u0) ++b0;
+            while (b1 + 1 < p.G && begin[b1 + 1] <= u1) ++b1;
+            touch = std::max(touch, b1 - b0 + 1);
+        }
+        p.smax = touch;
+        if (maxseg > p.tiles) maxseg = p.tiles;
+        p.nsub = (int)((maxseg + kSubTilesHost - 1) / kSubTilesHost);
+        if (p.nsub < 1) p.nsub = 1;
+    }
     return p;
 }
 
@@ -106,11 +198,19 @@ constexpr int kNormBlocks = 256;
 
 __global__ __launch_bounds__(256) void knn_norms_kernel(const float* __restrict__ T, int64_t ldt, int nt,
                                                         float* __restrict__ tn, float* __restrict__ bmax,
-                                                        int* __restrict__ stats, int* __restrict__ zero, int nzero) {
+                                                        int* __restrict__ stats, int* __restrict__ zero, int nzero,
+                                                        int64_t units, int tiles, int G, int seg_cost, int n_rb,
+                                                        int64_t* __restrict__ wg_begin, int* __restrict__ rb_first,
+                                                        int* __restrict__ rb_last) {
     __shared__ float wmax[4];
+    if (blockIdx.x == gridDim.x - 1) {                     // the extra workgroup: partition tables, nothing else
+        fill_partition_tables(make_partition(units, tiles, G, seg_cost), n_rb, wg_begin, rb_first, rb_last);
+        return;
+    }
+    const int nblk = gridDim.x - 1;
     const int l = threadIdx.x & 31;
     float mx = 0.f;
-    for (int row = blockIdx.x * 8 + (threadIdx.x >> 5); row < nt; row += gridDim.x * 8) {
+    for (int row = blockIdx.x * 8 + (threadIdx.x >> 5); row < nt; row += nblk * 8) {
         const float4 v = *reinterpret_cast<const float4*>(T + (int64_t)row * ldt + 4 * l);
         float s = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
 #pragma unroll
@@ -125,7 +225,7 @@ __global__ __launch_bounds__(256) void knn_norms_kernel(const float* __restrict_
     if (threadIdx.x == 0) {
         bmax[blockIdx.x] = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
         if (blockIdx.x == 0 && stats) stats[0] = 0;   // rescanned-query counter (refine kernel)
-        if (blockIdx.x == 1 || gridDim.x == 1)
+        if (blockIdx.x == 1 || nblk == 1)
             for (int i = 0; i < nzero; ++i) zero[i] = 0;   // Lowe-ratio survivor counters of the fused match call
     }
 }
@@ -393,14 +493,22 @@ __global__ __launch_bounds__(1024) void knn_prep_kernel(const float* __restrict_
                                                        unsigned short* __restrict__ qsplit, float* __restrict__ qn,
                                                        unsigned short* __restrict__ tsplit, float* __restrict__ tn,
                                                        float* __restrict__ bmax, int* __restrict__ midflag,
-                                                       int* __restrict__ stats, int* __restrict__ zero, int nzero) {
+                                                       int* __restrict__ stats, int* __restrict__ zero, int nzero,
+                                                       int64_t units, int tiles, int G, int seg_cost, int n_rb,
+                                                       int64_t* __restrict__ wg_begin, int* __restrict__ rb_first,
+                                                       int* __restrict__ rb_last) {
     __shared__ float wmax[16];
+    if (blockIdx.x == gridDim.x - 1) {                     // the extra workgroup: partition tables, nothing else
+        fill_partition_tables(make_partition(units, tiles, G, seg_cost), n_rb, wg_begin, rb_first, rb_last);
+        return;
+    }
+    const int nblk = gridDim.x - 1;
     __shared__ int wmid[16];
     const int l = threadIdx.x & 31;
     float mx = 0.f;
     unsigned flags = 0;
     const int rows = nq_pad + nt_pad;
-    for (int row = blockIdx.x * 32 + (threadIdx.x >> 5); row < rows; row += gridDim.x * 32) {   // 32 rows in flight per block
+    for (int row = blockIdx.x * 32 + (threadIdx.x >> 5); row < rows; row += nblk * 32) {   // 32 rows in flight per block
         const bool isq = row < nq_pad;
         const int r = isq ? row : row - nq_pad;
         const int n = isq ? nq : nt, npad = isq ? nq_pad : nt_pad;
@@ -450,7 +558,7 @@ __global__ __launch_bounds__(1024) void knn_prep_kernel(const float* __restrict_
         bmax[blockIdx.x] = bm;
         midflag[blockIdx.x] = fl;
         if (blockIdx.x == 0 && stats) stats[0] = 0;   // rescanned-query counter (refine kernel)
-        if (blockIdx.x == 1 || gridDim.x == 1)
+        if (blockIdx.x == 1 || nblk == 1)
             for (int i = 0; i < nzero; ++i) zero[i] = 0;   // Lowe-ratio survivor counters of the fused match call
     }
 }
@@ -663,15 +771,15 @@ template <int ABL, int W, bool KMID>
 __device__ __forceinline__ void filter_split2_body(
     float* smem, const unsigned short* __restrict__ qsplit, const float* __restrict__ qnorm, int nq, int nq_pad,
     const unsigned short* __restrict__ tsplit, int nt_pad, const float* __restrict__ tn, int tiles, int64_t units,
-    int smax, int nsub, float* __restrict__ cand_s, int* __restrict__ cand_i, long long* __restrict__ trace) {
+    int smax, int nsub, float* __restrict__ cand_s, int* __restrict__ cand_i, const int64_t* __restrict__ wg_begin,
+    const int* __restrict__ rb_first, long long* __restrict__ trace) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31;
     const int h = lane >> 5;
     const int hm = h ^ (j & 15);
-    const int G = gridDim.x;
-    const int64_t u_end = unit_begin(units, G, blockIdx.x + 1);
-    int64_t u = unit_begin(units, G, blockIdx.x);
+    const int64_t u_end = wg_begin[blockIdx.x + 1];
+    int64_t u = wg_begin[blockIdx.x];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
     const unsigned lds_tn = lds0 + kRing * kTileFloats * 4;
     const int mid_off = nt_pad * 256;
@@ -706,7 +814,7 @@ __device__ __forceinline__ void filter_split2_body(
         const int rb = (int)(u / tiles);
         const int t_begin = (int)(u - (int64_t)rb * tiles);
         const int t_end = (int)min((int64_t)tiles, t_begin + (u_end - u));
-        const int slot = blockIdx.x - block_of_unit(units, G, (int64_t)rb * tiles);
+        const int slot = blockIdx.x - rb_first[rb];
         const int qrow0 = rb * (W * 64) + wave * 64 + j;          // group g adds 32*g
         const bool qok[2] = {qrow0 < nq, qrow0 + 32 < nq};
 
@@ -890,7 +998,7 @@ __global__ __launch_bounds__(64 * W, 2) void knn_filter_split2_kernel(
     const unsigned short* __restrict__ qsplit, const float* __restrict__ qnorm, int nq, int nq_pad,
     const unsigned short* __restrict__ tsplit, int nt, int nt_pad, const float* __restrict__ tn, int tiles, int64_t units,
     int smax, int nsub, const int* __restrict__ midflag, const float* __restrict__ bmax, int force_mode,
-    float* __restrict__ cand_s, int* __restrict__ cand_i,
+    float* __restrict__ cand_s, int* __restrict__ cand_i, const int64_t* __restrict__ wg_begin, const int* __restrict__ rb_first,
     long long* __restrict__ trace) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if (trace && threadIdx.x == 0) {
@@ -902,9 +1010,9 @@ __global__ __launch_bounds__(64 * W, 2) void knn_filter_split2_kernel(
     const int lane = threadIdx.x & 63;
     const bool need_mid = (force_mode >= 0 ? force_mode : knn_filter_mode(midflag, bmax, lane)) == kModeSplit;
     if (need_mid)
-        filter_split2_body<ABL, W, true>(smem, qsplit, qnorm, nq, nq_pad, tsplit, nt_pad, tn, tiles, units, smax, nsub, cand_s, cand_i, trace);
+        filter_split2_body<ABL, W, true>(smem, qsplit, qnorm, nq, nq_pad, tsplit, nt_pad, tn, tiles, units, smax, nsub, cand_s, cand_i, wg_begin, rb_first, trace);
     else
-        filter_split2_body<ABL, W, false>(smem, qsplit, qnorm, nq, nq_pad, tsplit, nt_pad, tn, tiles, units, smax, nsub, cand_s, cand_i, trace);
+        filter_split2_body<ABL, W, false>(smem, qsplit, qnorm, nq, nq_pad, tsplit, nt_pad, tn, tiles, units, smax, nsub, cand_s, cand_i, wg_begin, rb_first, trace);
     if (trace && threadIdx.x == 0) {
         trace[4 * blockIdx.x + 1] = wall_clock64();
         trace[8192 + 4 * blockIdx.x + 3] = clock64();
@@ -1171,6 +1279,7 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
     const float* __restrict__ cand_s, const int* __restrict__ cand_i, int rows_per_block, int tiles, int64_t units,
     int G, int smax, int nsub, int force_mode, const int* __restrict__ midflag, const float* __restrict__ bmax,
     const unsigned short* __restrict__ thalf /*fp16 image of T, or null*/, const float* __restrict__ tn,
+    const int64_t* __restrict__ wg_begin, const int* __restrict__ rb_first, const int* __restrict__ rb_last,
     int* __restrict__ idx_out, float* __restrict__ dist_out, int* __restrict__ stats, double ratio,
     int* __restrict__ ratio_counts /*null unless fused with the Lowe ratio*/, unsigned char* __restrict__ ratio_mask,
     long long* __restrict__ trace) {
@@ -1210,8 +1319,8 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
     // streams of this workgroup's query row block = filter blocks that touched it (contiguous slots from 0);
     // the queries of a workgroup share the row block (rows_per_block is a multiple of 16)
     const int rb = (blockIdx.x * kRefQ) / rows_per_block;
-    const int fb = block_of_unit(units, G, (int64_t)rb * tiles);
-    const int lb = block_of_unit(units, G, (int64_t)(rb + 1) * tiles - 1);
+    const int fb = rb_first[rb];
+    const int lb = rb_last[rb];
     const int NC = 2 * (lb - fb + 1) * nsub * 3;
     const float* cs = cand_s + (int64_t)(valid ? q : 0) * (2 * smax * 3);
     const int* ci = cand_i + (int64_t)(valid ? q : 0) * (2 * smax * 3);
@@ -1355,8 +1464,8 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
                 const int w = items[it] >> 20, sid = items[it] & 0xFFFFF;
                 const int slot = sid / (2 * nsub), sb = (sid % (2 * nsub)) >> 1, h = sid & 1;
                 const int wg = fb + slot;
-                const int64_t u0 = max(unit_begin(units, G, wg), (int64_t)rb * tiles);
-                const int64_t u1 = min(unit_begin(units, G, wg + 1), (int64_t)(rb + 1) * tiles);
+                const int64_t u0 = max(wg_begin[wg], (int64_t)rb * tiles);
+                const int64_t u1 = min(wg_begin[wg + 1], (int64_t)(rb + 1) * tiles);
                 const int t_begin = (int)(u0 - (int64_t)rb * tiles) + kSubTiles * sb;
                 const int t_end = min((int)(u1 - (int64_t)rb * tiles), t_begin + kSubTiles);
                 const int ntr = (t_end - t_begin) * 16;
@@ -1599,6 +1708,9 @@ struct KnnWs {
     float* tn;
     float* bmax;
     int* midflag;
+    int64_t* wg_begin;            // partition tables (filled by the prep / norms launch)
+    int* rb_first;
+    int* rb_last;
     float* cand_s;
     int* cand_i;
     size_t bytes;
@@ -1609,6 +1721,9 @@ KnnWs carve_ws(void* ws, int64_t nq, int64_t nt, const Plan& p) {
     KnnWs w;
     w.bmax = c.take<float>(kNormBlocks);
     w.midflag = c.take<int>(kNormBlocks);
+    w.wg_begin = c.take<int64_t>((size_t)p.G + 1);
+    w.rb_first = c.take<int>((size_t)p.n_rb);
+    w.rb_last = c.take<int>((size_t)p.n_rb);
     w.tn = c.take<float>((size_t)p.tiles * kTileT);
     w.qn = c.take<float>((size_t)p.nq_pad);
     w.qsplit = c.take<unsigned short>((size_t)p.nq_pad * kDim * 3);
@@ -1672,8 +1787,9 @@ int knn2_impl(const float* q, int64_t nq, int64_t ldq, const float* t, int64_t n
     const dim3 grid((unsigned)p.G);
     static const int abl = [] { const char* e = getenv("SFM_KNN_ABL"); return e ? atoi(e) : 0; }();   // dev only
     if (p.split) {
-        hipLaunchKernelGGL(knn_prep_kernel, dim3(kNormBlocks), dim3(1024), 0, stream, q, ldq, (int)nq, p.nq_pad, t, ldt, (int)nt,
-                           p.tiles * kTileT, w.qsplit, w.qn, w.tsplit, w.tn, w.bmax, w.midflag, stats, ratio_counts, ratio_blocks);
+        hipLaunchKernelGGL(knn_prep_kernel, dim3(kNormBlocks + 1), dim3(1024), 0, stream, q, ldq, (int)nq, p.nq_pad, t, ldt, (int)nt,
+                           p.tiles * kTileT, w.qsplit, w.qn, w.tsplit, w.tn, w.bmax, w.midflag, stats, ratio_counts, ratio_blocks,
+                           p.units, p.tiles, p.G, p.seg_cost, p.n_rb, w.wg_begin, w.rb_first, w.rb_last);
         SFM_CHECK_LAUNCH();
         sfm::prof_begin(sfm::kProfKnnFilter, stream);
 #define SFM_LAUNCH_SPLIT(A, WV)                                                                                        \
@@ -1683,7 +1799,7 @@ int knn2_impl(const float* q, int64_t nq, int64_t ldq, const float* t, int64_t n
 #define SFM_LAUNCH_SPLIT2(A, WV)                                                                                        \
     hipLaunchKernelGGL((knn_filter_split2_kernel<A, WV>), grid, dim3(64 * WV), kRingLdsBytes, stream, w.qsplit, w.qn,    \
                        (int)nq, p.nq_pad, w.tsplit, (int)nt, p.tiles * kTileT, w.tn, p.tiles, p.units, p.smax, p.nsub,    \
-                       w.midflag, w.bmax, g_force_mode, w.cand_s, w.cand_i, g_trace)
+                       w.midflag, w.bmax, g_force_mode, w.cand_s, w.cand_i, w.wg_begin, w.rb_first, g_trace)
         if (p.qg == 2) {
             if (p.waves == 4) {
                 if (abl == 1) SFM_LAUNCH_SPLIT2(1, 4); else if (abl == 7) SFM_LAUNCH_SPLIT2(7, 4); else SFM_LAUNCH_SPLIT2(0, 4);
@@ -1704,8 +1820,8 @@ int knn2_impl(const float* q, int64_t nq, int64_t ldq, const float* t, int64_t n
 #undef SFM_LAUNCH_SPLIT
 #undef SFM_LAUNCH_SPLIT2
     } else {
-    hipLaunchKernelGGL(knn_norms_kernel, dim3(kNormBlocks), dim3(256), 0, stream, t, ldt, (int)nt, w.tn, w.bmax,
-                       stats, ratio_counts, ratio_blocks);
+    hipLaunchKernelGGL(knn_norms_kernel, dim3(kNormBlocks + 1), dim3(256), 0, stream, t, ldt, (int)nt, w.tn, w.bmax,
+                       stats, ratio_counts, ratio_blocks, p.units, p.tiles, p.G, p.seg_cost, p.n_rb, w.wg_begin, w.rb_first, w.rb_last);
     SFM_CHECK_LAUNCH();
     sfm::prof_begin(sfm::kProfKnnFilter, stream);
 #define SFM_LAUNCH_FILTER(A, WV)                                                                                     \
@@ -1738,7 +1854,7 @@ int knn2_impl(const float* q, int64_t nq, int64_t ldq, const float* t, int64_t n
     sfm::prof_begin(sfm::kProfKnnRefine, stream);
     hipLaunchKernelGGL(knn_refine_kernel, dim3((unsigned)((nq + kRefQ - 1) / kRefQ)), dim3(256), 0, stream, q, ldq, (int)nq, t, ldt,
                        (int)nt, w.cand_s, w.cand_i, p.rows_per_block, p.tiles, p.units, p.G, p.smax * p.nsub, p.nsub,
-                       force_mode, w.midflag, w.bmax, p.split ? w.tsplit + (size_t)2 * p.tiles * kTileT * kDim : nullptr, w.tn, idx, dist,
+                       force_mode, w.midflag, w.bmax, p.split ? w.tsplit + (size_t)2 * p.tiles * kTileT * kDim : nullptr, w.tn, w.wg_begin, w.rb_first, w.rb_last, idx, dist,
                        stats, ratio, ratio_counts, ratio_mask, g_trace ? g_trace + 16384 : nullptr);
     sfm::prof_end(sfm::kProfKnnRefine, stream);
     SFM_CHECK_LAUNCH();
