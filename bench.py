@@ -29,6 +29,8 @@ sys.path.insert(0, ROOT)
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (no sparsity)
 PROF_EVERY = 8                     # steps between profiled launches in the timed region
+PIPE_DEPTH = 3                     # independent pairs in flight (one stream + workspace each)
+PROF_EVERY_PIPELINED = 40          # ... when pairs are pipelined (a profiled launch drains the pipeline)
 SPLIT_MFMA_PER_TILE, F32_MFMA_PER_TILE = 24, 65
 FLOP_PER_DISTANCE = 256           # GEMM form 2*D
 HBM_PEAK_GBS = 8000.0
@@ -45,6 +47,7 @@ def parse():
     ap.add_argument("--nt", type=int, default=10000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--pipe-depth", type=int, default=PIPE_DEPTH, help="independent pairs in flight per GPU (1 = one stream)")
     return ap.parse_args()
 
 
@@ -108,33 +111,47 @@ def bench_knn(args, world, rank, dev):
     nq, nt = args.nq, args.nt
     q = torch.rand((nq, 128), generator=torch.Generator().manual_seed(2 * rank)).to(dev)
     t = torch.rand((nt, 128), generator=torch.Generator().manual_seed(2 * rank + 1)).to(dev)
-    pm = ops.PairMatcher(nq, nt, dev, ratio=0.70)
+    # Pairs are independent units: consecutive steps are pipelined over PIPE_DEPTH streams so that the
+    # low-occupancy tail of one pair (rescans, ordered scatter) and the prep pass of the next overlap a filter kernel.
+    depth = max(1, args.pipe_depth)
+    pipe = ops.PairPipeline(nq, nt, dev, ratio=0.70, depth=depth)
+    pm = pipe.matchers[0]
     if world > 1:
         import torch.distributed as dist
-        rec = torch.empty((nq, 4), dtype=torch.int32, device=dev)          # {q, t, d1, d2} 16-byte records
-        gathered = torch.empty((world * nq, 4), dtype=torch.int32, device=dev)
+        recs = [torch.empty((nq, 4), dtype=torch.int32, device=dev) for _ in range(depth)]   # {q, t, d1, d2} 16-byte records
+        gathered = [torch.empty((world * nq, 4), dtype=torch.int32, device=dev) for _ in range(depth)]
+        qidx = torch.arange(nq, device=dev, dtype=torch.int32)
 
     def step():
-        idx, d, oq, ot, cnt = pm.run(q, t)
+        k, st, (idx, d, oq, ot, cnt) = pipe.submit(q, t)
         if world > 1:
-            rec[:, 0] = torch.arange(nq, device=dev, dtype=torch.int32)
-            rec[:, 1] = idx[:, 0]
-            rec[:, 2:] = d.view(torch.int32)
-            dist.all_gather_into_tensor(gathered, rec)
+            with torch.cuda.stream(st):
+                rec = recs[k]
+                rec[:, 0] = qidx
+                rec[:, 1] = idx[:, 0]
+                rec[:, 2:] = d.view(torch.int32)
+                dist.all_gather_into_tensor(gathered[k], rec)
 
     for _ in range(args.warmup):
         step()
     barrier_sync(world)
     # The library brackets its kernels with HIP events on the launch stream when profiling is on.  An event pair costs
-    # ~3.5 us of stream time (measured: 14 us per step for the two pairs), so only every PROF_EVERY-th step of the
-    # timed region carries them; the roofline's launch duration is the average over those launches.
+    # ~3.5 us of stream time, and with several pairs in flight a kernel's event-to-event time also contains the
+    # neighbours' kernels it shares the chip with — so every prof_every-th step of the timed region is run ALONE
+    # (pipeline drained before and after) with the events on; the roofline's launch duration is the average over
+    # those launches.  The drains are inside the timed region and cost `value` a few percent.
+    prof_every = PROF_EVERY if depth == 1 else PROF_EVERY_PIPELINED
     ops.profile_read(0), ops.profile_read(1)               # clear the slots
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if i % PROF_EVERY == 0:
+        if i % prof_every == 0:
+            if depth > 1:
+                pipe.synchronize()
             ops.profile_enable(True)
             step()
             ops.profile_enable(False)
+            if depth > 1:
+                pipe.synchronize()
         else:
             step()
     barrier_sync(world)
@@ -168,20 +185,28 @@ def bench_knn(args, world, rank, dev):
         "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: 10k x 10k uniform[0,1) float32 128-D descriptors, BF-KNN k=2 + "
                                "Lowe ratio 0.70, one image pair per GPU per step", "nq": nq, "nt": nt, "dim": 128,
-                   "parallelism": f"pair-sharded x{world}" + (" + RCCL all-gather of match records" if world > 1 else "")},
+                   "parallelism": f"pair-sharded x{world}" + (" + RCCL all-gather of match records" if world > 1 else "")
+                                  + f"; {depth} independent pairs in flight per GPU (one HIP stream each)"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": traffic,
                      "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/knn_traffic.json)",
                      "algorithmic_bytes_per_launch": 4 * 128 * (nq + nt) + 16 * nq,
-                     "kernel": "knn_filter_split2_kernel<0, 8>", "avg_launch_ms": filt_avg_ms, "launches": filt_n,
+                     "kernel": "knn_filter_split2_kernel<0, 4>", "avg_launch_ms": filt_avg_ms, "launches": filt_n,
                      "algorithmic_flop_per_launch": algo_flop,
                      "issued_mfma_tflops": issued, "issued_frac_of_peak": issued / BF16_MFMA_PEAK_TFLOPS,
-                     "launch_sampling": f"HIP events on every {PROF_EVERY}th step of the timed region",
+                     "launch_sampling": f"HIP events on every {prof_every}th step of the timed region" + (", run alone (pipeline drained)" if depth > 1 else ""),
                      "note": "algorithmic = 256 FLOP per distance (SURVEY 8d); issued = MFMA flops of the arithmetic mode that ran"},
         "kernels_ms": {"knn_filter": filt_avg_ms, "knn_refine": ref_ms / max(ref_n, 1)},
         "knn_stats": {"rescanned_queries": stats[0], "filter_workgroups": stats[1], "streams_per_query": stats[2],
                       "filter_mode": mode_name},
     }
+    # latency of ONE pair on one stream (no overlap with neighbouring pairs), outside the timed region
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        pm.run(q, t)
+    torch.cuda.synchronize()
+    out["pair_latency_ms_single_stream"] = (time.perf_counter() - t0) / 50 * 1e3
     if world == 1 and not args.no_extras:
         # boundary handing over HOST buffers: pinned H2D of both descriptor sets + the step + D2H of the results
         qh, th = q.cpu().pin_memory(), t.cpu().pin_memory()
@@ -233,7 +258,7 @@ def bench_knn(args, world, rank, dev):
         ops.profile_enable(False)
         ops.set_knn_filter("auto")
         sp_avg = sp_ms / max(sp_n, 1)
-        out["bf16_split_variant"] = {"kernel": "knn_filter_split2_kernel<0, 8> (3 x v_mfma_f32_32x32x16_bf16 per product)",
+        out["bf16_split_variant"] = {"kernel": "knn_filter_split2_kernel<0, 4> (3 x v_mfma_f32_32x32x16_bf16 per product)",
                                      "avg_launch_ms": sp_avg, "achieved_tflops": algo_flop / (sp_avg * 1e-3) / 1e12,
                                      "issued_mfma_tflops": 3 * algo_flop / (sp_avg * 1e-3) / 1e12,
                                      "results_identical_to_default": bool(torch.equal(pms.idx, pm.idx) and torch.equal(pms.dist, pm.dist))}

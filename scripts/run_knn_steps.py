@@ -18,6 +18,22 @@ import time
 for _ in range(3):
     pm.run(q, t)
 torch.cuda.synchronize()
+ns = int(os.environ.get("SFM_STREAMS", "1"))
+if ns > 1:      # independent pairs pipelined over ns streams (one PairMatcher = one workspace per stream)
+    pms = [pm] + [ops.PairMatcher(nq, nt, q.device) for _ in range(ns - 1)]
+    streams = [torch.cuda.Stream() for _ in range(ns)]
+    for i in range(2 * ns):
+        with torch.cuda.stream(streams[i % ns]):
+            pms[i % ns].run(q, t)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n):
+        with torch.cuda.stream(streams[i % ns]):
+            pms[i % ns].run(q, t)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    print(f"done {kind} {nq}x{nt}: {ns} streams: step {dt*1e3:.4f} ms  {nq*nt/dt:.3e} dist/s")
+    sys.exit(0)
 prof = os.environ.get('SFM_NO_PROF') is None
 ops.profile_enable(prof)
 t0 = time.perf_counter()

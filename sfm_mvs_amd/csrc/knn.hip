@@ -156,7 +156,7 @@ Plan make_plan_uncached(int64_t nq, int64_t nt) {
     p.split = g_filter_mode == 1 ? 0 : 1;
     static const int env_qg = [] { const char* e = getenv("SFM_KNN_QG"); return e ? atoi(e) : 0; }();   // dev override
     p.qg = (p.split && env_qg != 1) ? 2 : 1;
-    if (p.split && !(env_w == 4 || env_w == 8 || env_w == 16)) p.waves = p.qg == 2 ? 8 : 16;
+    if (p.split && !(env_w == 4 || env_w == 8 || env_w == 16)) p.waves = p.qg == 2 ? 4 : 16;   // split2: two 4-wave workgroups per CU (their barrier stalls interleave; ~3 % over one 8-wave group)
     p.rows_per_block = p.waves * 32 * p.qg;
     p.n_rb = (int)((nq + p.rows_per_block - 1) / p.rows_per_block);
     p.nq_pad = p.n_rb * p.rows_per_block;

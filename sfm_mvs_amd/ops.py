@@ -303,6 +303,35 @@ class PairMatcher:
         return self.idx, self.dist, self.out_q, self.out_t, self.count
 
 
+class PairPipeline:
+    """Independent image pairs pipelined over `depth` HIP streams (one PairMatcher = one workspace + output set per
+    stream).  A pair's step ends with low-occupancy phases — the refine kernel's few rescanning workgroups, the
+    10-workgroup ordered scatter, the next pair's prep pass — that a single stream serialises; on separate streams
+    they overlap the neighbouring pairs' filter kernels (measured at 10k x 10k: 0.072 -> 0.052 ms per pair at depth 3).
+    Results of submit() number i live in slot i % depth until submit() number i + depth reuses it."""
+
+    def __init__(self, nq, nt, device, ratio=0.70, depth=3):
+        self.depth = int(depth)
+        self.matchers = [PairMatcher(nq, nt, device, ratio) for _ in range(self.depth)]
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(self.depth)]
+        self.n = 0
+
+    def submit(self, des0, des1):
+        """Enqueue one pair on the next stream (after everything already enqueued on the caller's current stream);
+        returns (slot, stream, (idx, dist, out_q, out_t, count)) — the tensors are valid once `stream` reaches here."""
+        k = self.n % self.depth
+        self.n += 1
+        st = self.streams[k]
+        st.wait_stream(torch.cuda.current_stream(st.device))
+        with torch.cuda.stream(st):
+            out = self.matchers[k].run(des0, des1)
+        return k, st, out
+
+    def synchronize(self):
+        for st in self.streams:
+            st.synchronize()
+
+
 def set_knn_filter(mode):
     """'auto' (16-bit MFMA filter, fp16 single product or bf16 split chosen on the device; default), 'f32'
     (fp32 MFMA filter) or 'split' (bf16 split pinned); identical results."""

@@ -244,3 +244,24 @@ def test_fused_match_equals_knn_then_ratio(hip, oracle, nq, nt):
     assert m == len(wq) and np.array_equal(out_q[:m].cpu().numpy(), wq) and np.array_equal(out_t[:m].cpu().numpy(), wt)
     mq, mt, _, _ = hip.match_pair(qd, td, 0.70)
     assert np.array_equal(mq.cpu().numpy(), wq) and np.array_equal(mt.cpu().numpy(), wt)
+
+
+def test_pair_pipeline_keeps_pairs_apart(hip, oracle):
+    """Three different pairs in flight on three streams: every slot must hold its own pair's result."""
+    rng = np.random.default_rng(99)
+    pairs = [planted_pair(rng, 1500, 2100, 0.3)[:2] for _ in range(5)]
+    dev = [(torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda()) for q, t in pairs]
+    pipe = hip.PairPipeline(1500, 2100, dev[0][0].device, ratio=0.70, depth=3)
+    got = []
+    for i, (q, t) in enumerate(dev):
+        k, st, (idx, dist, oq, ot, cnt) = pipe.submit(q, t)
+        got.append((k, st, idx, dist, oq, ot, cnt))
+    pipe.synchronize()
+    # slots 0,1 were reused by pairs 3,4; slots hold pairs 3, 4, 2
+    for i in (2, 3, 4):
+        k, st, idx, dist, oq, ot, cnt = got[i]
+        wi, wd = oracle.knn2(*pairs[i], nthreads=8)
+        wq, wt, _ = oracle.ratio_filter(wi, wd, 0.70)
+        assert_bit_equal((idx.cpu().numpy(), dist.cpu().numpy()), (wi, wd))
+        m = int(cnt.item())
+        assert m == len(wq) and np.array_equal(oq[:m].cpu().numpy(), wq) and np.array_equal(ot[:m].cpu().numpy(), wt)
