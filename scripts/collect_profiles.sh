@@ -8,6 +8,9 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o knn -- python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-extras > $OUT/bench_under_rocprof.json 2> $OUT/trace.log
 cp $OUT/trace/knn_kernel_stats.csv $OUT/${TAG}_knn_kernel_stats.csv
+# the same bench with ONE pair in flight: kernel durations without the neighbouring pairs' kernels sharing the chip
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace1 -o knn1 -- python $R/bench.py --steps 100 --warmup 10 --pipe-depth 1 --no-cpu-baseline --no-extras > $OUT/bench_depth1_under_rocprof.json 2>> $OUT/trace.log
+cp $OUT/trace1/knn1_kernel_stats.csv $OUT/${TAG}_knn_depth1_kernel_stats.csv
 P1="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA"
 P2="FETCH_SIZE"
 P3="WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"
@@ -22,5 +25,5 @@ for wl in tri ba; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$wl -o $wl -- python $R/bench.py --workload $wl --steps 5 --warmup 1 > $OUT/bench_${wl}_under_rocprof.json 2>> $OUT/trace.log
   cp $OUT/trace_$wl/${wl}_kernel_stats.csv $OUT/${TAG}_${wl}_kernel_stats.csv
 done
-rm -rf $OUT/trace $OUT/trace_tri $OUT/trace_ba
+rm -rf $OUT/trace $OUT/trace1 $OUT/trace_tri $OUT/trace_ba
 ls $OUT
