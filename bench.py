@@ -30,6 +30,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32,
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (no sparsity)
 PROF_EVERY = 8                     # steps between profiled launches in the timed region
 PIPE_DEPTH = 3                     # independent pairs in flight (one stream + workspace each)
+EXCH_BATCH = 8                     # pairs per RCCL all-gather at N > 1
 PROF_EVERY_PIPELINED = 40          # ... when pairs are pipelined (a profiled launch drains the pipeline)
 SPLIT_MFMA_PER_TILE, F32_MFMA_PER_TILE = 24, 65
 FLOP_PER_DISTANCE = 256           # GEMM form 2*D
@@ -55,11 +56,12 @@ def init_dist(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or os.environ.get("SFM_BENCH_EXCHANGE"):     # (the env switch runs the N > 1 code path on one rank: dev/test)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local), world_size=world, rank=rank)
     else:
         torch.cuda.set_device(0)
         local = 0
@@ -116,24 +118,45 @@ def bench_knn(args, world, rank, dev):
     depth = max(1, args.pipe_depth)
     pipe = ops.PairPipeline(nq, nt, dev, ratio=0.70, depth=depth)
     pm = pipe.matchers[0]
-    if world > 1:
-        import torch.distributed as dist
-        recs = [torch.empty((nq, 4), dtype=torch.int32, device=dev) for _ in range(depth)]   # {q, t, d1, d2} 16-byte records
-        gathered = [torch.empty((world * nq, 4), dtype=torch.int32, device=dev) for _ in range(depth)]
-        qidx = torch.arange(nq, device=dev, dtype=torch.int32)
+    import torch.distributed as dist
+    exchange = dist.is_available() and dist.is_initialized()
+    if exchange:
+        # The exchange: every rank ends up with every pair's {trainIdx x2, distance x2} block (16 B per query).
+        # EXCH_BATCH pairs are written straight into one batch buffer and exchanged by ONE RCCL all-gather (fewer, larger
+        # collectives: a 160 KB all-gather per pair costs more in launch + ring latency than the pair itself), issued from
+        # one stream in the same order on every rank; two batch buffers alternate.
+        batch = [torch.empty((EXCH_BATCH, 2, nq, 2), dtype=torch.int32, device=dev) for _ in range(2)]
+        gathered = [torch.empty((world, EXCH_BATCH, 2, nq, 2), dtype=torch.int32, device=dev) for _ in range(2)]
+        free = [None, None]                                  # per batch buffer: "its previous all-gather has read it"
+        state = {"cur": 0, "fill": 0}
+
+    def flush():
+        """All-gather the pairs accumulated in the current batch buffer (a partial batch is sent whole)."""
+        if not exchange or state["fill"] == 0:
+            return
+        cur = state["cur"]
+        main = torch.cuda.current_stream()
+        for st in pipe.streams:
+            main.wait_stream(st)
+        dist.all_gather_into_tensor(gathered[cur], batch[cur])
+        ev = torch.cuda.Event()
+        ev.record(main)                                      # (the collective is complete on `main` here: async_op=False)
+        free[cur] = ev
+        state["cur"], state["fill"] = cur ^ 1, 0
 
     def step():
-        k, st, (idx, d, oq, ot, cnt) = pipe.submit(q, t)
-        if world > 1:
-            with torch.cuda.stream(st):
-                rec = recs[k]
-                rec[:, 0] = qidx
-                rec[:, 1] = idx[:, 0]
-                rec[:, 2:] = d.view(torch.int32)
-                dist.all_gather_into_tensor(gathered[k], rec)
+        if not exchange:
+            pipe.submit(q, t, after=False)                   # static inputs, nothing to wait for
+            return
+        cur, b = state["cur"], state["fill"]
+        pipe.submit(q, t, after=free[cur] if (b < depth and free[cur] is not None) else False, result=batch[cur][b])
+        state["fill"] = b + 1
+        if state["fill"] == EXCH_BATCH:
+            flush()
 
     for _ in range(args.warmup):
         step()
+    flush()
     barrier_sync(world)
     # The library brackets its kernels with HIP events on the launch stream when profiling is on.  An event pair costs
     # ~3.5 us of stream time, and with several pairs in flight a kernel's event-to-event time also contains the
@@ -154,6 +177,7 @@ def bench_knn(args, world, rank, dev):
                 pipe.synchronize()
         else:
             step()
+    flush()
     barrier_sync(world)
     elapsed = time.perf_counter() - t0
     filt_ms, filt_n = ops.profile_read(0)
@@ -185,7 +209,7 @@ def bench_knn(args, world, rank, dev):
         "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: 10k x 10k uniform[0,1) float32 128-D descriptors, BF-KNN k=2 + "
                                "Lowe ratio 0.70, one image pair per GPU per step", "nq": nq, "nt": nt, "dim": 128,
-                   "parallelism": f"pair-sharded x{world}" + (" + RCCL all-gather of match records" if world > 1 else "")
+                   "parallelism": f"pair-sharded x{world}" + (f" + one RCCL all-gather of the match records per {EXCH_BATCH} pairs" if world > 1 else "")
                                   + f"; {depth} independent pairs in flight per GPU (one HIP stream each)"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": traffic,
@@ -424,8 +448,8 @@ def main():
         out = bench_ba(args, world, rank, dev)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
 
 

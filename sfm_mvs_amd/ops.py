@@ -283,24 +283,34 @@ class PairMatcher:
         if need == 0 and self.nq > 0:
             raise SfmHipError(f"PairMatcher: unsupported shape nq={nq} nt={nt} dim={dim}")
         self.ws = torch.empty(max(need, 256), dtype=torch.uint8, device=self.device)
-        self.idx = torch.empty((self.nq, 2), dtype=torch.int32, device=self.device)
-        self.dist = torch.empty((self.nq, 2), dtype=torch.float32, device=self.device)
+        # idx and dist share one allocation ([2][nq][2] x 4 bytes): the pair-sharded exchange all-gathers `result` as is
+        self.result = torch.empty((2, self.nq, 2), dtype=torch.int32, device=self.device)
+        self.idx = self.result[0]
+        self.dist = self.result[1].view(torch.float32)
         self.stats = torch.zeros(4, dtype=torch.int32, device=self.device)
         self.out_q = torch.empty(self.nq, dtype=torch.int32, device=self.device)
         self.out_t = torch.empty(self.nq, dtype=torch.int32, device=self.device)
         self.count = torch.zeros(1, dtype=torch.int32, device=self.device)
 
-    def run(self, des0, des1):
+    def run(self, des0, des1, result=None):
+        """result: optional int32 [2][nq][2] CUDA tensor to receive (trainIdx, distance bits) instead of self.result —
+        e.g. a slot of the batch buffer the pair-sharded exchange all-gathers."""
         require_cuda(des0, des1)
         if tuple(des0.shape) != (self.nq, self.dim) or tuple(des1.shape) != (self.nt, self.dim):
             raise SfmHipError("PairMatcher.run: shape differs from the plan")
+        idx, dist = self.idx, self.dist
+        if result is not None:
+            require_cuda(result)
+            if tuple(result.shape) != (2, self.nq, 2) or result.dtype != torch.int32 or not result.is_contiguous():
+                raise SfmHipError("PairMatcher.run: result must be a contiguous int32 [2][nq][2] tensor")
+            idx, dist = result[0], result[1].view(torch.float32)
         if des0.dtype != torch.float32 or des1.dtype != torch.float32 or des0.stride(1) != 1 or des1.stride(1) != 1:
             raise SfmHipError("PairMatcher.run: float32 row-major descriptors required")
         check(_lib.lib().sfm_match_l2_f32(ptr(des0), self.nq, des0.stride(0), ptr(des1), self.nt, des1.stride(0), self.dim,
-                                          self.ratio, ptr(self.idx), ptr(self.dist), ptr(self.out_q), ptr(self.out_t),
+                                          self.ratio, ptr(idx), ptr(dist), ptr(self.out_q), ptr(self.out_t),
                                           ptr(self.count), None, ptr(self.stats), ptr(self.ws), self.ws.numel(), stream_ptr()),
               "sfm_match_l2_f32")
-        return self.idx, self.dist, self.out_q, self.out_t, self.count
+        return idx, dist, self.out_q, self.out_t, self.count
 
 
 class PairPipeline:
@@ -316,15 +326,21 @@ class PairPipeline:
         self.streams = [torch.cuda.Stream(device=device) for _ in range(self.depth)]
         self.n = 0
 
-    def submit(self, des0, des1):
-        """Enqueue one pair on the next stream (after everything already enqueued on the caller's current stream);
-        returns (slot, stream, (idx, dist, out_q, out_t, count)) — the tensors are valid once `stream` reaches here."""
+    def submit(self, des0, des1, after=None, result=None):
+        """Enqueue one pair on the next stream; returns (slot, stream, (idx, dist, out_q, out_t, count)) — the tensors
+        are valid once `stream` reaches here, and are overwritten by submit() number i + depth.
+        `after`: None → the pair waits for everything already enqueued on the caller's current stream (inputs produced
+        there are safe); an Event → it waits for that event only (e.g. "the consumer has read this slot's previous
+        result"); False → no wait (inputs must already be complete)."""
         k = self.n % self.depth
         self.n += 1
         st = self.streams[k]
-        st.wait_stream(torch.cuda.current_stream(st.device))
+        if after is None:
+            st.wait_stream(torch.cuda.current_stream(st.device))
+        elif after is not False:
+            st.wait_event(after)
         with torch.cuda.stream(st):
-            out = self.matchers[k].run(des0, des1)
+            out = self.matchers[k].run(des0, des1, result)
         return k, st, out
 
     def synchronize(self):
