@@ -197,6 +197,25 @@ int sfm_ba_dense_sweep(const double* cams_dev, int64_t ncam, const double* K_hos
                        double* JtJ_pt_dev, double* Jtr_pt_dev,
                        void* ws_dev, size_t ws_bytes, void* stream);
 
+/* Matrix-free products with the camera-point coupling W of the dense normal equations
+ *     [ B   W ] [dc]   [g_c]       W_ij = Jc_ij^T Jp_ij  (6x3),  B, C, g_c, g_p from sfm_ba_dense_sweep
+ *     [ W^T C ] [dp] = [g_p]
+ * for a Schur-complement solver (replaces scipy least_squares + finite differences,
+ * sfm.py:138-157): S = B - W C^-1 W^T is applied as  S x = B x - W (C^-1 (W^T x)).
+ *   sfm_ba_schur_wt:  u_pt_dev  [npt x 3]  = W^T x,   x_cam_dev [ncam x 6]
+ *   sfm_ba_schur_w :  w_cam_dev [ncam x 6] = W v,     v_pt_dev  [npt x 3]
+ * The W blocks are never stored: both Jacobians are re-derived from (cams, X) in registers, so a
+ * product reads no observation data.  Fixed-order reductions: deterministic.  fp64 throughout. */
+size_t sfm_ba_schur_ws_bytes(int64_t ncam, int64_t npt);
+int sfm_ba_schur_wt(const double* cams_dev, int64_t ncam, const double* K_host,
+                    const float* X_dev, int64_t npt, int64_t ldx,
+                    const double* x_cam_dev, double* u_pt_dev,
+                    void* ws_dev, size_t ws_bytes, void* stream);
+int sfm_ba_schur_w(const double* cams_dev, int64_t ncam, const double* K_host,
+                   const float* X_dev, int64_t npt, int64_t ldx,
+                   const double* v_pt_dev, double* w_cam_dev,
+                   void* ws_dev, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------
  * A7  cv2.findEssentialMat RANSAC scoring                sfm.py:307
  *
@@ -231,7 +250,7 @@ int sfm_score_pnp(const double* poses_dev, int h, const double* K_host,
  * sfm_profile_read synchronises those events, returns the summed device time
  * and launch count of one slot, and resets the slot (toggling the switch does not).
  *   slot 0 knn filter (MFMA)   1 knn refine (+ rescans)   2 triangulate
- *        3 dense BA sweep       4 indexed residual sweep
+ *        3 dense BA sweep       4 indexed residual sweep    5 Schur products (W^T x, W v)
  * ---------------------------------------------------------------------- */
 int sfm_profile_enable(int on);
 /* Dev diagnostics: when non-NULL, every knn filter workgroup b writes int64[4] =

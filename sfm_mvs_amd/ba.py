@@ -79,3 +79,107 @@ def bundle_adjust(cams, K, X, obs, cam_idx=None, pt_idx=None, iters=10, lam=1e-3
         if not step_done:
             break
     return cams, X, hist
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Schur-complement Levenberg-Marquardt (dense visibility): the joint step instead of alternating block updates.
+# ---------------------------------------------------------------------------------------------------------------
+def _inv3_sym(A):
+    """Batched inverse of symmetric 3x3 blocks on the device: A [n,9] → [n,9]."""
+    a, b, c, d, e, f = A[:, 0], A[:, 1], A[:, 2], A[:, 4], A[:, 5], A[:, 8]
+    c00, c01, c02 = d * f - e * e, c * e - b * f, b * e - c * d
+    c11, c12, c22 = a * f - c * c, b * c - a * e, a * d - b * b
+    det = a * c00 + b * c01 + c * c02
+    inv = 1.0 / torch.where(det.abs() > 1e-300, det, torch.ones_like(det))
+    return torch.stack([c00, c01, c02, c01, c11, c12, c02, c12, c22], 1) * inv[:, None]
+
+
+def _bmv(A, x, n):
+    """Batched (n x n blocks, row-major [m, n*n]) times [m, n] on the device."""
+    return torch.bmm(A.view(-1, n, n), x.unsqueeze(2)).squeeze(2)
+
+
+def schur_step(cams, K, X, blocks, lam, fix_first_camera=True, cg_tol=1e-10, cg_iters=200):
+    """One damped Gauss-Newton step of the dense problem through the reduced camera system.
+
+        [ B+lam*diag(B)    W           ] [dc]   [g_c]        S dc = g_c - W Cd^-1 g_p,    S = Bd - W Cd^-1 W^T
+        [ W^T              C+lam*diag(C)] [dp] = [g_p]       dp   = Cd^-1 (g_p - W^T dc)
+
+    S is never formed: preconditioned conjugate gradients with S x = Bd x - W (Cd^-1 (W^T x)) (two device sweeps per
+    iteration, ops.ba_schur_wt / ops.ba_schur_w), block-Jacobi preconditioner Bd^-1.  `blocks` = the dict returned by
+    ops.ba_dense_sweep at (cams, X).  Returns (dc [ncam,6], dp [npt,3], number of CG iterations); the update is
+    params - step (the sweep's gradient is J^T r)."""
+    dev = X.device
+    B = blocks["JtJ_cam"].clone().view(-1, 6, 6)
+    C = blocks["JtJ_pt"].clone()
+    gc, gp = blocks["Jtr_cam"], blocks["Jtr_pt"]
+    ncam = B.shape[0]
+    di = torch.arange(6, device=dev)
+    B[:, di, di] *= 1.0 + lam
+    C[:, 0] *= 1.0 + lam
+    C[:, 4] *= 1.0 + lam
+    C[:, 8] *= 1.0 + lam
+    Cinv = _inv3_sym(C)
+    free = torch.ones((ncam, 1), dtype=torch.float64, device=dev)
+    if fix_first_camera:
+        free[0] = 0                                                        # gauge: camera 0 does not move
+    Minv = torch.linalg.inv(B)                                             # block-Jacobi preconditioner
+
+    def S(x):
+        x = x * free
+        u = ops.ba_schur_wt(cams, K, X, x)
+        w = ops.ba_schur_w(cams, K, X, _bmv(Cinv, u, 3))
+        return (torch.bmm(B, x.unsqueeze(2)).squeeze(2) - w) * free
+
+    rhs = (gc - ops.ba_schur_w(cams, K, X, _bmv(Cinv, gp, 3))) * free
+    x = torch.zeros_like(rhs)
+    r = rhs.clone()
+    z = torch.bmm(Minv, r.unsqueeze(2)).squeeze(2) * free
+    p = z.clone()
+    rz = float((r * z).sum())
+    r0 = float(rhs.norm())
+    it = 0
+    while it < cg_iters and r0 > 0 and float(r.norm()) > cg_tol * r0:
+        Sp = S(p)
+        alpha = rz / float((p * Sp).sum())
+        x += alpha * p
+        r -= alpha * Sp
+        z = torch.bmm(Minv, r.unsqueeze(2)).squeeze(2) * free
+        rz_new = float((r * z).sum())
+        p = z + (rz_new / rz) * p
+        rz = rz_new
+        it += 1
+    dp = _bmv(Cinv, gp - ops.ba_schur_wt(cams, K, X, x), 3)
+    return x, dp, it
+
+
+def bundle_adjust_schur(cams, K, X, obs, iters=10, lam=1e-3, fix_first_camera=True, log=None):
+    """Levenberg-Marquardt on the dense problem (obs [ncam,npt,2]) with the joint Schur-complement step.
+    Returns (cams, X, history of fp64 costs)."""
+    if obs.dim() != 3:
+        raise ops.SfmHipError("bundle_adjust_schur: dense visibility only (obs [ncam,npt,2])")
+    cams = cams.clone().to(torch.float64)
+    X = X.clone().to(torch.float32)
+    say = log or (lambda *a: None)
+    blocks = ops.ba_dense_sweep(cams, K, X, obs)
+    cost = float(blocks["sumsq"].item())
+    hist = [cost]
+    for it in range(iters):
+        accepted = False
+        for _ in range(8):
+            dc, dp, ncg = schur_step(cams, K, X, blocks, lam, fix_first_camera)
+            c_new = cams - dc
+            x_new = (X.to(torch.float64) - dp).to(torch.float32)
+            b_new = ops.ba_dense_sweep(c_new, K, x_new, obs)
+            cost_new = float(b_new["sumsq"].item())
+            if cost_new < cost:
+                cams, X, blocks, accepted = c_new, x_new, b_new, True
+                gain = (cost - cost_new) / cost
+                cost, lam = cost_new, max(lam / 3.0, 1e-12)
+                say(f"schur-lm iter {it}: cost {cost:.6g} lambda {lam:.2g} cg {ncg}")
+                break
+            lam *= 4.0
+        hist.append(cost)
+        if not accepted or gain < 1e-9:
+            break
+    return cams, X, hist

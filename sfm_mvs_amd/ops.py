@@ -237,6 +237,44 @@ def ba_dense_sweep(cams, K, X, obs, want_cam=True, want_pt=True):
     return out
 
 
+def _schur_args(cams, K, X):
+    require_cuda(cams, X)
+    cams = cams.contiguous().to(torch.float64).reshape(-1, 6)
+    if X.dtype != torch.float32 or X.dim() != 2 or X.shape[1] < 3:
+        raise SfmHipError("schur product: X must be float32 [npt,>=3]")
+    if X.stride(-1) != 1:
+        X = X.contiguous()
+    return cams, _f64_host(K, 9, "K"), X
+
+
+def ba_schur_wt(cams, K, X, x_cam):
+    """u = W^T x for dense visibility: x_cam [ncam,6] float64 → u [npt,3] float64 (no observation data is read)."""
+    cams, k, X = _schur_args(cams, K, X)
+    ncam, npt, dev = cams.shape[0], X.shape[0], X.device
+    x_cam = x_cam.contiguous().to(torch.float64).reshape(ncam, 6)
+    u = torch.empty((npt, 3), dtype=torch.float64, device=dev)
+    lib = _lib.lib()
+    ws = _workspace(dev, lib.sfm_ba_schur_ws_bytes(ncam, npt))
+    with torch.cuda.device(dev):
+        check(lib.sfm_ba_schur_wt(ptr(cams), ncam, k.ctypes.data_as(ctypes.c_void_p), ptr(X), npt, X.stride(0), ptr(x_cam), ptr(u),
+                                  ptr(ws), ws.numel(), stream_ptr()), "sfm_ba_schur_wt")
+    return u
+
+
+def ba_schur_w(cams, K, X, v_pt):
+    """w = W v for dense visibility: v_pt [npt,3] float64 → w [ncam,6] float64."""
+    cams, k, X = _schur_args(cams, K, X)
+    ncam, npt, dev = cams.shape[0], X.shape[0], X.device
+    v_pt = v_pt.contiguous().to(torch.float64).reshape(npt, 3)
+    w = torch.empty((ncam, 6), dtype=torch.float64, device=dev)
+    lib = _lib.lib()
+    ws = _workspace(dev, lib.sfm_ba_schur_ws_bytes(ncam, npt))
+    with torch.cuda.device(dev):
+        check(lib.sfm_ba_schur_w(ptr(cams), ncam, k.ctypes.data_as(ctypes.c_void_p), ptr(X), npt, X.stride(0), ptr(v_pt), ptr(w),
+                                 ptr(ws), ws.numel(), stream_ptr()), "sfm_ba_schur_w")
+    return w
+
+
 def score_essential(E, x1n, x2n, thr2, want_mask=False):
     """Sampson-distance inlier counts for h candidate essential matrices (sfm.py:307 RANSAC scoring)."""
     require_cuda(E, x1n, x2n)

@@ -171,3 +171,88 @@ def test_block_bundle_adjustment_reduces_cost_to_the_noise_floor(hip):
     pi = np.tile(np.arange(800), 6).astype(np.int32)
     _, _, hist2 = ba.bundle_adjust(c0, K, x0, cu(obs.reshape(-1, 2)), cu(ci), cu(pi), iters=12)
     assert hist2[-1] == pytest.approx(hist[-1], rel=1e-6)
+
+
+# ---------------------------------------------------------------- Schur-complement products and solver
+def _numpy_pair_jacobians(cams, K, X):
+    """Central-difference Jacobians of the float64 projection: Jc [ncam,npt,2,6], Jp [ncam,npt,2,3]."""
+    from scipy.spatial.transform import Rotation
+
+    def proj(c, Xs):
+        R = Rotation.from_rotvec(c[:3]).as_matrix()
+        Xc = Xs @ R.T + c[3:]
+        return np.stack([K[0, 0] * Xc[:, 0] / Xc[:, 2] + K[0, 2], K[1, 1] * Xc[:, 1] / Xc[:, 2] + K[1, 2]], 1)
+
+    ncam, npt = len(cams), len(X)
+    X = X.astype(np.float64)
+    Jc, Jp = np.empty((ncam, npt, 2, 6)), np.empty((ncam, npt, 2, 3))
+    for i, c in enumerate(cams):
+        for a in range(6):
+            h = 1e-6 * max(1.0, abs(c[a]))
+            d = np.zeros(6); d[a] = h
+            Jc[i, :, :, a] = (proj(c + d, X) - proj(c - d, X)) / (2 * h)
+        for a in range(3):
+            h = 1e-6
+            d = np.zeros(3); d[a] = h
+            Jp[i, :, :, a] = (proj(c, X + d) - proj(c, X - d)) / (2 * h)
+    return Jc, Jp
+
+
+def test_schur_products_match_finite_difference_jacobians(hip):
+    K, cams, X, obs = ba_problem(9, 700, 0.5, seed=31)
+    Jc, Jp = _numpy_pair_jacobians(cams, K, X)
+    rng = np.random.default_rng(1)
+    x, v = rng.standard_normal((9, 6)), rng.standard_normal((700, 3))
+    want_u = np.einsum("ijkb,ijk->jb", Jp, np.einsum("ijka,ia->ijk", Jc, x))        # W^T x
+    want_w = np.einsum("ijka,ijk->ia", Jc, np.einsum("ijkb,jb->ijk", Jp, v))        # W v
+    u = hip.ba_schur_wt(cu(cams), K, cu(X), cu(x))
+    w = hip.ba_schur_w(cu(cams), K, cu(X), cu(v))
+    assert np.abs(u.cpu().numpy() - want_u).max() <= 1e-6 * np.abs(want_u).max()
+    assert np.abs(w.cpu().numpy() - want_w).max() <= 1e-6 * np.abs(want_w).max()
+    # adjointness  <v, W^T x> = <x, W v>  to rounding, and reproducibility of the fixed-order reductions
+    assert float((u.cpu() * torch.from_numpy(v)).sum()) == pytest.approx(float((w.cpu() * torch.from_numpy(x)).sum()), rel=1e-11)
+    assert torch.equal(u, hip.ba_schur_wt(cu(cams), K, cu(X), cu(x))) and torch.equal(w, hip.ba_schur_w(cu(cams), K, cu(X), cu(v)))
+
+
+def test_schur_step_equals_dense_normal_equation_solve(hip):
+    """The PCG solution of the reduced camera system + back-substitution = the solve of the full damped normal
+    equations assembled (on the host, from the sweep's own blocks and finite-difference W) for a small problem."""
+    from sfm_mvs_amd import ba
+    ncam, npt, lam = 5, 80, 1e-2
+    K, cams, X, obs = ba_problem(ncam, npt, 0.5, seed=32)
+    blocks = hip.ba_dense_sweep(cu(cams), K, cu(X), cu(obs))
+    dc, dp, ncg = ba.schur_step(cu(cams), K, cu(X), blocks, lam, fix_first_camera=False, cg_tol=1e-13)
+    Jc, Jp = _numpy_pair_jacobians(cams, K, X)
+    n = 6 * ncam + 3 * npt
+    H = np.zeros((n, n))
+    B = blocks["JtJ_cam"].cpu().numpy().reshape(ncam, 6, 6)
+    C = blocks["JtJ_pt"].cpu().numpy().reshape(npt, 3, 3)
+    for i in range(ncam):
+        H[6 * i:6 * i + 6, 6 * i:6 * i + 6] = B[i] + lam * np.diag(np.diag(B[i]))
+    for j in range(npt):
+        o = 6 * ncam + 3 * j
+        H[o:o + 3, o:o + 3] = C[j] + lam * np.diag(np.diag(C[j]))
+    W = np.einsum("ijka,ijkb->ijab", Jc, Jp)
+    for i in range(ncam):
+        for j in range(npt):
+            o = 6 * ncam + 3 * j
+            H[6 * i:6 * i + 6, o:o + 3] = W[i, j]
+            H[o:o + 3, 6 * i:6 * i + 6] = W[i, j].T
+    g = np.hstack([blocks["Jtr_cam"].cpu().numpy().ravel(), blocks["Jtr_pt"].cpu().numpy().ravel()])
+    sol = np.linalg.solve(H, g)
+    assert ncg <= 6 * ncam + 2
+    assert np.abs(dc.cpu().numpy().ravel() - sol[:6 * ncam]).max() <= 2e-5 * np.abs(sol[:6 * ncam]).max()
+    assert np.abs(dp.cpu().numpy().ravel() - sol[6 * ncam:]).max() <= 2e-5 * np.abs(sol[6 * ncam:]).max()
+
+
+def test_schur_lm_converges_to_the_noise_floor(hip):
+    """Joint Schur-complement LM vs the alternating block updates on the same problem and iteration budget."""
+    from sfm_mvs_amd import ba
+    ncam, npt, sigma = 12, 3000, 0.5
+    K, cams, X, obs = ba_problem(ncam, npt, sigma, seed=33, perturb=0.01)
+    c1, x1, h1 = ba.bundle_adjust_schur(cu(cams), K, cu(X), cu(obs), iters=8)
+    c2, x2, h2 = ba.bundle_adjust(cu(cams), K, cu(X), cu(obs), iters=8)
+    floor = 2 * ncam * npt * sigma ** 2                               # E[sum of squared noise]
+    assert all(b <= a for a, b in zip(h1, h1[1:]))
+    assert h1[-1] < 1.05 * floor and h1[-1] < 0.3 * h1[0]
+    assert h1[-1] <= h2[-1] * 1.0001                                   # the joint step is at least as good
