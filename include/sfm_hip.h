@@ -136,7 +136,13 @@ int sfm_common_points(const float* pts1_dev, int64_t n1, const float* pts2_dev, 
  * smallest singular value (one-sided Jacobi as in OpenCV's SVD), cast to
  * float32.  rows = 4 → modern 4x4 system (x*P3-P1, y*P3-P2 per view);
  * rows = 6 → legacy cvTriangulatePoints 6x4 system (adds x*P2-y*P1).
- * normalise_w != 0 additionally performs the reference's float32 division by w.
+ * normalise_w = 1 additionally performs the reference's float32 division by w.
+ * normalise_w = 2 (rows = 4 only) is the same normalised result by a ~20x cheaper route:
+ *   the smallest eigenvector of A^T A by inverse iteration (LDL^T, fp64), unit-normalised,
+ *   cast and divided exactly like the faithful path — bit-identical to it on > 99.9 % of
+ *   points, within 1 float32 ulp otherwise; lanes that do not converge (degenerate geometry)
+ *   run the Jacobi sweeps.  The un-normalised vector (normalise_w = 0) has OpenCV's sign and
+ *   is only offered by the faithful path.
  *
  *   P1, P2        HOST pointers, 12 doubles each, row-major 3x4
  *   x1_dev,x2_dev float32; point i has x at [i*stride_pt] and y at
