@@ -31,7 +31,6 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf1
 PROF_EVERY = 8                     # steps between profiled launches in the timed region
 PIPE_DEPTH = 3                     # independent pairs in flight (one stream + workspace each)
 EXCH_BATCH = 8                     # pairs per RCCL all-gather at N > 1
-PROF_EVERY_PIPELINED = 40          # ... when pairs are pipelined (a profiled launch drains the pipeline)
 SPLIT_MFMA_PER_TILE, F32_MFMA_PER_TILE = 24, 65
 FLOP_PER_DISTANCE = 256           # GEMM form 2*D
 HBM_PEAK_GBS = 8000.0
@@ -160,14 +159,19 @@ def bench_knn(args, world, rank, dev):
     barrier_sync(world)
     # The library brackets its kernels with HIP events on the launch stream when profiling is on.  An event pair costs
     # ~3.5 us of stream time, and with several pairs in flight a kernel's event-to-event time also contains the
-    # neighbours' kernels it shares the chip with — so every prof_every-th step of the timed region is run ALONE
-    # (pipeline drained before and after) with the events on; the roofline's launch duration is the average over
-    # those launches.  The drains are inside the timed region and cost `value` a few percent.
-    prof_every = PROF_EVERY if depth == 1 else PROF_EVERY_PIPELINED
+    # neighbours' kernels it shares the chip with — so a few steps of the timed region are run ALONE (pipeline drained
+    # before and after) with the events on; the roofline's launch duration is the average over those launches.
+    # The drains are inside the timed region and cost `value` 2-3 percent.
+    # Pipelined: the first, the middle and the last step of the timed region (at the two ends the pipeline is empty
+    # anyway, so only the middle one costs a full drain + refill).
+    if depth == 1:
+        profiled = set(range(0, args.steps, PROF_EVERY))
+    else:
+        profiled = {0, args.steps // 2, args.steps - 1}
     ops.profile_read(0), ops.profile_read(1)               # clear the slots
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if i % prof_every == 0:
+        if i in profiled:
             if depth > 1:
                 pipe.synchronize()
             ops.profile_enable(True)
@@ -218,7 +222,8 @@ def bench_knn(args, world, rank, dev):
                      "kernel": "knn_filter_split2_kernel<0, 4>", "avg_launch_ms": filt_avg_ms, "launches": filt_n,
                      "algorithmic_flop_per_launch": algo_flop,
                      "issued_mfma_tflops": issued, "issued_frac_of_peak": issued / BF16_MFMA_PEAK_TFLOPS,
-                     "launch_sampling": f"HIP events on every {prof_every}th step of the timed region" + (", run alone (pipeline drained)" if depth > 1 else ""),
+                     "launch_sampling": (f"HIP events on every {PROF_EVERY}th step of the timed region" if depth == 1 else
+                                         "HIP events on the first, middle and last step of the timed region, each run alone (pipeline drained)"),
                      "note": "algorithmic = 256 FLOP per distance (SURVEY 8d); issued = MFMA flops of the arithmetic mode that ran"},
         "kernels_ms": {"knn_filter": filt_avg_ms, "knn_refine": ref_ms / max(ref_n, 1)},
         "knn_stats": {"rescanned_queries": stats[0], "filter_workgroups": stats[1], "streams_per_query": stats[2],
