@@ -790,13 +790,16 @@ __device__ __forceinline__ void filter_split2_body(
     const int p0 = wave * PIECES;
     const int r0 = 4 * (p0 & 7) + (lane >> 4);
     const int lane_off = r0 * 256 + (((lane & 15) ^ (r0 & 15)) << 4);
-    const bool stage_pieces = KMID || p0 < 8;                    // exact mode never reads the (all-zero) mid image
+    const bool stage_pieces = true;
     const int my_vm = (stage_pieces ? PIECES : 0) + (wave == 0 ? 1 : 0);   // VMEM ops this wave issues per staged tile
 
     // Train tile `tile` → ring slot `buf`, entirely by LDS-DMA (hi/mid images 1 KiB per piece; ||t||^2 as one dword
     // piece from wave 0: padded rows hold +inf).  No VGPR destinations, so nothing here makes hipcc wait.
+    // Single-product body: a ring slot holds TWO consecutive tiles of the fp16 image (the second where the split body
+    // keeps its mid rows), `tile` is the first of the pair, and there is one barrier per PAIR of tiles.
     auto stage = [&](int tile, int buf) {
-        const int soff = __builtin_amdgcn_readfirstlane(tile * kTileT * 256 + (p0 >= 8 ? mid_off : img_off));
+        const int soff = __builtin_amdgcn_readfirstlane(KMID ? tile * kTileT * 256 + (p0 >= 8 ? mid_off : 0)
+                                                             : (tile + (p0 >= 8 ? 1 : 0)) * kTileT * 256 + img_off);
         const unsigned dst0 = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)buf * (kTileFloats * 4) + (unsigned)p0 * 1024u);
         if (stage_pieces)
 #pragma unroll
@@ -819,8 +822,9 @@ __device__ __forceinline__ void filter_split2_body(
         const bool qok[2] = {qrow0 < nq, qrow0 + 32 < nq};
 
         __syncthreads();                                           // previous segment fully consumed, nothing in flight
+        constexpr int kPerSlot = KMID ? 1 : 2;                      // tiles per ring slot
         stage(t_begin, 0);
-        if (t_begin + 1 < t_end && !(ABL & 4)) stage(t_begin + 1, 1);
+        if (t_begin + kPerSlot < t_end && !(ABL & 4)) stage(t_begin + kPerSlot, 1);
 
         uint4 bh[2][8], bm[2][8];
         float qn[2];
@@ -867,10 +871,13 @@ __device__ __forceinline__ void filter_split2_body(
                 ++sub;
                 sub_t0 = t - 1;
             }
-            const int buf = (t - t_begin) % kRing;
-            if (t + 2 < t_end && !(ABL & 4)) stage(t + 2, (buf + 2) % kRing);
-            const unsigned abase = lds0 + (unsigned)(((ABL & 4) ? 0 : buf) * kTileFloats) * 4u + (unsigned)j * 256u + ((unsigned)hm << 4);
-            const unsigned tnad = lds_tn + (unsigned)((ABL & 4) ? 0 : buf) * 256u + 4u * j;
+            const int rel = t - t_begin;
+            const int buf = (KMID ? rel : rel >> 1) % kRing;
+            const int half = KMID ? 0 : (rel & 1);                  // which tile of the slot's pair
+            if (half == 0 && t + 2 * kPerSlot < t_end && !(ABL & 4)) stage(t + 2 * kPerSlot, (buf + 2) % kRing);
+            const unsigned abase = lds0 + (unsigned)(((ABL & 4) ? 0 : buf) * kTileFloats) * 4u + (unsigned)half * 8192u +
+                                   (unsigned)j * 256u + ((unsigned)hm << 4);
+            const unsigned tnad = lds_tn + (unsigned)((ABL & 4) ? 0 : buf) * 256u + (unsigned)half * 128u + 4u * j;
             float tnj;
             u32x4 ah[KMID ? 2 : 8], am[2];
             asm volatile("ds_read_b32 %0, %1" : "=v"(tnj) : "v"(tnad));
@@ -942,8 +949,10 @@ __device__ __forceinline__ void filter_split2_body(
             }
             // Tile t+1 must have landed for every wave before anyone reads it; tile t+2 (just issued) stays in flight
             // across the barrier: counted vmcnt + raw s_barrier (a __syncthreads() would drain the DMA queue).
-            if (t + 1 < t_end && !(ABL & 2)) {
-                if (t + 2 < t_end) wait_vm_keep(my_vm);
+            // (single-product body: only after the second tile of a pair; then the next PAIR must have landed and the
+            // one after it, issued while this pair's first tile ran, stays in flight)
+            if (t + 1 < t_end && (KMID || half == 1) && !(ABL & 2)) {
+                if (t + 1 + kPerSlot < t_end) wait_vm_keep(my_vm);
                 else wait_vmcnt<0>();
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_s_barrier();
