@@ -102,9 +102,32 @@ def cpu_knn_baseline(nq, nt, seed_q, seed_t):
     for _ in range(passes):
         O.knn2(q[:rows], t, nthreads=cores)
     dt = time.perf_counter() - t0
-    return {"value": passes * rows * nt / dt, "unit": "distances/s", "cores": cores, "kind": "port",
-            "sample": f"{passes} pass(es) over the first {rows} of {nq} query rows x {nt} train rows of the same synthetic "
-                      f"set, oracle orc_knn2_l2_f32 (direct-form f32, OpenMP over query rows, {cores} threads), {dt:.1f} s"}
+    out = {"value": passes * rows * nt / dt, "unit": "distances/s", "cores": cores, "kind": "port",
+           "sample": f"{passes} pass(es) over the first {rows} of {nq} query rows x {nt} train rows of the same synthetic "
+                     f"set, oracle orc_knn2_l2_f32 (direct-form f32, OpenMP over query rows, {cores} threads), {dt:.1f} s"}
+    # also one thread, and torch.cdist + topk on the CPU as an independent sanity point (a few seconds each)
+    r1 = min(nq, 256)
+    t0 = time.perf_counter()
+    O.knn2(q[:r1], t, nthreads=1)
+    out["one_thread_distances_per_sec"] = r1 * nt / (time.perf_counter() - t0)
+    try:
+        r2 = min(nq, 2000)
+        qt, tt = torch.from_numpy(q[:r2]), torch.from_numpy(t)
+        t0 = time.perf_counter()
+        d = torch.cdist(qt, tt)
+        vals, idx = torch.topk(d, 2, dim=1, largest=False)
+        out["torch_cdist_topk_distances_per_sec"] = r2 * nt / (time.perf_counter() - t0)
+        out["torch_threads"] = torch.get_num_threads()
+        wi, _ = O.knn2(q[:r2], t, nthreads=cores)
+        out["torch_topk_first_neighbour_agreement"] = float((idx[:, 0].numpy() == wi[:, 0]).mean())
+    except Exception as e:                                    # a sanity point only
+        out["torch_cdist_topk_error"] = str(e)
+    try:
+        model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")]
+        out["cpu_model"] = model[0] if model else None
+    except OSError:
+        pass
+    return out
 
 
 def bench_knn(args, world, rank, dev):
