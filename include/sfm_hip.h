@@ -221,6 +221,14 @@ int sfm_ba_schur_w(const double* cams_dev, int64_t ncam, const double* K_host,
                    const float* X_dev, int64_t npt, int64_t ldx,
                    const double* v_pt_dev, double* w_cam_dev,
                    void* ws_dev, size_t ws_bytes, void* stream);
+/* Sparse visibility (observation o = camera cam_idx[o] sees point pt_idx[o]): mode 0 → out = W^T in,
+ * mode 1 → out = W in.  One lane per observation, fp64 atomics (order-dependent in the last bits). */
+size_t sfm_ba_schur_indexed_ws_bytes(int64_t ncam);
+int sfm_ba_schur_indexed(const double* cams_dev, int64_t ncam, const double* K_host,
+                         const float* X_dev, int64_t npt, int64_t ldx,
+                         const int32_t* cam_idx_dev, const int32_t* pt_idx_dev, int64_t nobs, int mode,
+                         const double* in_dev, double* out_dev,
+                         void* ws_dev, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * A7  cv2.findEssentialMat RANSAC scoring                sfm.py:307

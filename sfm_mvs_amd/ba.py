@@ -99,7 +99,7 @@ def _bmv(A, x, n):
     return torch.bmm(A.view(-1, n, n), x.unsqueeze(2)).squeeze(2)
 
 
-def schur_step(cams, K, X, blocks, lam, fix_first_camera=True, cg_tol=1e-10, cg_iters=200):
+def schur_step(cams, K, X, blocks, lam, fix_first_camera=True, cg_tol=1e-10, cg_iters=200, cam_idx=None, pt_idx=None):
     """One damped Gauss-Newton step of the dense problem through the reduced camera system.
 
         [ B+lam*diag(B)    W           ] [dc]   [g_c]        S dc = g_c - W Cd^-1 g_p,    S = Bd - W Cd^-1 W^T
@@ -127,11 +127,11 @@ def schur_step(cams, K, X, blocks, lam, fix_first_camera=True, cg_tol=1e-10, cg_
 
     def S(x):
         x = x * free
-        u = ops.ba_schur_wt(cams, K, X, x)
-        w = ops.ba_schur_w(cams, K, X, _bmv(Cinv, u, 3))
+        u = ops.ba_schur_wt(cams, K, X, x, cam_idx, pt_idx)
+        w = ops.ba_schur_w(cams, K, X, _bmv(Cinv, u, 3), cam_idx, pt_idx)
         return (torch.bmm(B, x.unsqueeze(2)).squeeze(2) - w) * free
 
-    rhs = (gc - ops.ba_schur_w(cams, K, X, _bmv(Cinv, gp, 3))) * free
+    rhs = (gc - ops.ba_schur_w(cams, K, X, _bmv(Cinv, gp, 3), cam_idx, pt_idx)) * free
     x = torch.zeros_like(rhs)
     r = rhs.clone()
     z = torch.bmm(Minv, r.unsqueeze(2)).squeeze(2) * free
@@ -149,29 +149,37 @@ def schur_step(cams, K, X, blocks, lam, fix_first_camera=True, cg_tol=1e-10, cg_
         p = z + (rz_new / rz) * p
         rz = rz_new
         it += 1
-    dp = _bmv(Cinv, gp - ops.ba_schur_wt(cams, K, X, x), 3)
+    dp = _bmv(Cinv, gp - ops.ba_schur_wt(cams, K, X, x, cam_idx, pt_idx), 3)
     return x, dp, it
 
 
-def bundle_adjust_schur(cams, K, X, obs, iters=10, lam=1e-3, fix_first_camera=True, log=None):
-    """Levenberg-Marquardt on the dense problem (obs [ncam,npt,2]) with the joint Schur-complement step.
-    Returns (cams, X, history of fp64 costs)."""
-    if obs.dim() != 3:
-        raise ops.SfmHipError("bundle_adjust_schur: dense visibility only (obs [ncam,npt,2])")
+def bundle_adjust_schur(cams, K, X, obs, cam_idx=None, pt_idx=None, iters=10, lam=1e-3, fix_first_camera=True, log=None):
+    """Levenberg-Marquardt with the joint Schur-complement step.  obs [ncam,npt,2] (dense visibility) or [nobs,2] with
+    cam_idx / pt_idx (sparse: windows of an incremental reconstruction).  Returns (cams, X, history of fp64 costs)."""
+    dense = obs.dim() == 3
+    if not dense and (cam_idx is None or pt_idx is None):
+        raise ops.SfmHipError("bundle_adjust_schur: sparse observations need cam_idx and pt_idx")
     cams = cams.clone().to(torch.float64)
     X = X.clone().to(torch.float32)
     say = log or (lambda *a: None)
-    blocks = ops.ba_dense_sweep(cams, K, X, obs)
-    cost = float(blocks["sumsq"].item())
+
+    def sweep(c, x):
+        if dense:
+            out = ops.ba_dense_sweep(c, K, x, obs)
+            return out, float(out["sumsq"].item())
+        out = ops.project_residual(c, K, x, obs, cam_idx, pt_idx, want_proj=False, want_jac=True, want_pt_jac=True, want_res2=True)
+        return out, float(out["res2"].item())
+
+    blocks, cost = sweep(cams, X)
     hist = [cost]
     for it in range(iters):
         accepted = False
         for _ in range(8):
-            dc, dp, ncg = schur_step(cams, K, X, blocks, lam, fix_first_camera)
+            dc, dp, ncg = schur_step(cams, K, X, blocks, lam, fix_first_camera, cam_idx=None if dense else cam_idx,
+                                     pt_idx=None if dense else pt_idx)
             c_new = cams - dc
             x_new = (X.to(torch.float64) - dp).to(torch.float32)
-            b_new = ops.ba_dense_sweep(c_new, K, x_new, obs)
-            cost_new = float(b_new["sumsq"].item())
+            b_new, cost_new = sweep(c_new, x_new)
             if cost_new < cost:
                 cams, X, blocks, accepted = c_new, x_new, b_new, True
                 gain = (cost - cost_new) / cost

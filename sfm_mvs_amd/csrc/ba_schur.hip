@@ -224,6 +224,38 @@ __global__ void schur_cam_fold_kernel(const double* __restrict__ cam_part, int t
     w[c * 6 + k] = s;
 }
 
+// Indexed (sparse-visibility) variants: one lane per observation (cam_idx[o], pt_idx[o]); sums by fp64 hardware atomics
+// (order-dependent in the last bits, like the indexed residual sweep).  MODE 0: u[pt] += Jp^T (Jc x[cam]);
+// MODE 1: w[cam] += Jc^T (Jp v[pt]).  Outputs must be zeroed by the caller (the entry points do it).
+template <int MODE>
+__global__ __launch_bounds__(256) void schur_indexed_kernel(const double* __restrict__ table, Intrin K, const float* __restrict__ X,
+                                                           int64_t ldx, const int* __restrict__ cam_idx,
+                                                           const int* __restrict__ pt_idx, int64_t nobs,
+                                                           const double* __restrict__ in, double* __restrict__ out) {
+    const int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (o >= nobs) return;
+    const int64_t ci = cam_idx[o], pi = pt_idx[o];
+    double Ju[6], Jv[6], Pu[3], Pv[3];
+    pair_jacobians(table + ci * kCamStride, K, X[pi * ldx], X[pi * ldx + 1], X[pi * ldx + 2], Ju, Jv, Pu, Pv);
+    if (MODE == 0) {
+        const double* xi = in + ci * 6;
+        double tu = 0, tv = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            tu += Ju[a] * xi[a];
+            tv += Jv[a] * xi[a];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) unsafeAtomicAdd(&out[pi * 3 + k], Pu[k] * tu + Pv[k] * tv);
+    } else {
+        const double* vj = in + pi * 3;
+        const double su = Pu[0] * vj[0] + Pu[1] * vj[1] + Pu[2] * vj[2];
+        const double sv = Pv[0] * vj[0] + Pv[1] * vj[1] + Pv[2] * vj[2];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) unsafeAtomicAdd(&out[ci * 6 + a], Ju[a] * su + Jv[a] * sv);
+    }
+}
+
 struct SchurPlan {
     int pp, tiles, nch;
 };
@@ -318,6 +350,37 @@ extern "C" int sfm_ba_schur_w(const double* cams, int64_t ncam, const double* K_
     sfm::prof_end(sfm::kProfBaSchur, stream);
     SFM_CHECK_LAUNCH();
     hipLaunchKernelGGL(schur_cam_fold_kernel, dim3((unsigned)ncam), dim3(64), 0, stream, w.part, d.tiles, (int)ncam, w_cam);
+    SFM_CHECK_LAUNCH();
+    return SFM_OK;
+}
+
+// Sparse visibility: observation o sees point pt_idx[o] from camera cam_idx[o].  mode 0: out = W^T in (in [ncam x 6],
+// out [npt x 3]); mode 1: out = W in (in [npt x 3], out [ncam x 6]).  ws_dev: ncam * 40 doubles (+256 B).
+extern "C" size_t sfm_ba_schur_indexed_ws_bytes(int64_t ncam) {
+    return ncam < 1 ? 0 : (size_t)ncam * kCamStride * sizeof(double) + 512;
+}
+
+extern "C" int sfm_ba_schur_indexed(const double* cams, int64_t ncam, const double* K_host, const float* X, int64_t npt,
+                                    int64_t ldx, const int32_t* cam_idx, const int32_t* pt_idx, int64_t nobs, int mode,
+                                    const double* in, double* out, void* ws, size_t ws_bytes, void* stream_) {
+    SFM_CHECK_ARG(ncam >= 1 && npt >= 1 && ldx >= 3 && nobs >= 0 && (mode == 0 || mode == 1), "sfm_ba_schur_indexed: bad sizes / mode");
+    SFM_CHECK_ARG(cams && K_host && X && in && out && (nobs == 0 || (cam_idx && pt_idx)), "sfm_ba_schur_indexed: null pointer");
+    if (!ws || ws_bytes < sfm_ba_schur_indexed_ws_bytes(ncam)) {
+        sfm::set_error("sfm_ba_schur_indexed: workspace too small (%zu < %zu)", ws_bytes, sfm_ba_schur_indexed_ws_bytes(ncam));
+        return SFM_ERR_WORKSPACE;
+    }
+    hipStream_t stream = sfm::as_stream(stream_);
+    double* table = reinterpret_cast<double*>(sfm::align_up((size_t)(uintptr_t)ws, 256));
+    const Intrin K{K_host[0], K_host[4], K_host[2], K_host[5]};
+    SFM_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(double) * (size_t)(mode == 0 ? npt * 3 : ncam * 6), stream));
+    if (nobs == 0) return SFM_OK;
+    hipLaunchKernelGGL(schur_cam_prepare_kernel, dim3((unsigned)((ncam + 63) / 64)), dim3(64), 0, stream, cams, ncam, table);
+    SFM_CHECK_LAUNCH();
+    const dim3 grid((unsigned)((nobs + 255) / 256));
+    if (mode == 0)
+        hipLaunchKernelGGL(schur_indexed_kernel<0>, grid, dim3(256), 0, stream, table, K, X, ldx, cam_idx, pt_idx, nobs, in, out);
+    else
+        hipLaunchKernelGGL(schur_indexed_kernel<1>, grid, dim3(256), 0, stream, table, K, X, ldx, cam_idx, pt_idx, nobs, in, out);
     SFM_CHECK_LAUNCH();
     return SFM_OK;
 }

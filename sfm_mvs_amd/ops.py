@@ -251,11 +251,29 @@ def _schur_args(cams, K, X):
     return cams, _f64_host(K, 9, "K"), X
 
 
-def ba_schur_wt(cams, K, X, x_cam):
-    """u = W^T x for dense visibility: x_cam [ncam,6] float64 → u [npt,3] float64 (no observation data is read)."""
+def _schur_indexed(cams, k, X, cam_idx, pt_idx, mode, vec):
+    require_cuda(cam_idx, pt_idx)
+    ncam, npt, dev = cams.shape[0], X.shape[0], X.device
+    cam_idx = cam_idx.contiguous().to(torch.int32)
+    pt_idx = pt_idx.contiguous().to(torch.int32)
+    out = torch.empty((npt, 3) if mode == 0 else (ncam, 6), dtype=torch.float64, device=dev)
+    lib = _lib.lib()
+    ws = _workspace(dev, lib.sfm_ba_schur_indexed_ws_bytes(ncam))
+    with torch.cuda.device(dev):
+        check(lib.sfm_ba_schur_indexed(ptr(cams), ncam, k.ctypes.data_as(ctypes.c_void_p), ptr(X), npt, X.stride(0), ptr(cam_idx),
+                                       ptr(pt_idx), cam_idx.numel(), mode, ptr(vec), ptr(out), ptr(ws), ws.numel(), stream_ptr()),
+              "sfm_ba_schur_indexed")
+    return out
+
+
+def ba_schur_wt(cams, K, X, x_cam, cam_idx=None, pt_idx=None):
+    """u = W^T x: x_cam [ncam,6] float64 → u [npt,3] float64.  Dense visibility unless cam_idx / pt_idx (one entry per
+    observation) are given.  No observation data is read."""
     cams, k, X = _schur_args(cams, K, X)
     ncam, npt, dev = cams.shape[0], X.shape[0], X.device
     x_cam = x_cam.contiguous().to(torch.float64).reshape(ncam, 6)
+    if cam_idx is not None:
+        return _schur_indexed(cams, k, X, cam_idx, pt_idx, 0, x_cam)
     u = torch.empty((npt, 3), dtype=torch.float64, device=dev)
     lib = _lib.lib()
     ws = _workspace(dev, lib.sfm_ba_schur_ws_bytes(ncam, npt))
@@ -265,11 +283,13 @@ def ba_schur_wt(cams, K, X, x_cam):
     return u
 
 
-def ba_schur_w(cams, K, X, v_pt):
-    """w = W v for dense visibility: v_pt [npt,3] float64 → w [ncam,6] float64."""
+def ba_schur_w(cams, K, X, v_pt, cam_idx=None, pt_idx=None):
+    """w = W v: v_pt [npt,3] float64 → w [ncam,6] float64 (dense visibility unless cam_idx / pt_idx are given)."""
     cams, k, X = _schur_args(cams, K, X)
     ncam, npt, dev = cams.shape[0], X.shape[0], X.device
     v_pt = v_pt.contiguous().to(torch.float64).reshape(npt, 3)
+    if cam_idx is not None:
+        return _schur_indexed(cams, k, X, cam_idx, pt_idx, 1, v_pt)
     w = torch.empty((ncam, 6), dtype=torch.float64, device=dev)
     lib = _lib.lib()
     ws = _workspace(dev, lib.sfm_ba_schur_ws_bytes(ncam, npt))

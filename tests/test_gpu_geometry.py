@@ -282,3 +282,30 @@ def test_schur_lm_converges_to_the_noise_floor(hip):
     assert all(b <= a for a, b in zip(h1, h1[1:]))
     assert h1[-1] < 1.05 * floor and h1[-1] < 0.3 * h1[0]
     assert h1[-1] <= h2[-1] * 1.0001                                   # the joint step is at least as good
+
+
+def test_sparse_schur_products_and_solver(hip):
+    """Indexed visibility (each observation names its camera and point): products against the finite-difference
+    Jacobians restricted to the visible pairs; the LM solver reaches the noise floor of the visible observations."""
+    from sfm_mvs_amd import ba
+    ncam, npt, sigma = 8, 900, 0.5
+    K, cams, X, obs = ba_problem(ncam, npt, sigma, seed=41, perturb=0.01)
+    rng = np.random.default_rng(2)
+    vis = rng.random((ncam, npt)) < 0.45
+    vis[:3] = True                                                    # every point is seen at least three times
+    ci, pi = np.nonzero(vis)
+    ci, pi = ci.astype(np.int32), pi.astype(np.int32)
+    o = obs[ci, pi]
+    Jc, Jp = _numpy_pair_jacobians(cams, K, X)
+    x, v = rng.standard_normal((ncam, 6)), rng.standard_normal((npt, 3))
+    tu = np.einsum("oka,oa->ok", Jc[ci, pi], x[ci])
+    want_u = np.zeros((npt, 3)); np.add.at(want_u, pi, np.einsum("okb,ok->ob", Jp[ci, pi], tu))
+    sv = np.einsum("okb,ob->ok", Jp[ci, pi], v[pi])
+    want_w = np.zeros((ncam, 6)); np.add.at(want_w, ci, np.einsum("oka,ok->oa", Jc[ci, pi], sv))
+    u = hip.ba_schur_wt(cu(cams), K, cu(X), cu(x), cu(ci), cu(pi)).cpu().numpy()
+    w = hip.ba_schur_w(cu(cams), K, cu(X), cu(v), cu(ci), cu(pi)).cpu().numpy()
+    assert np.abs(u - want_u).max() <= 1e-6 * np.abs(want_u).max()
+    assert np.abs(w - want_w).max() <= 1e-6 * np.abs(want_w).max()
+    c1, x1, h1 = ba.bundle_adjust_schur(cu(cams), K, cu(X), cu(o), cu(ci), cu(pi), iters=8)
+    floor = 2 * len(ci) * sigma ** 2
+    assert all(b <= a for a, b in zip(h1, h1[1:])) and h1[-1] < 1.05 * floor and h1[-1] < 0.3 * h1[0]
