@@ -154,8 +154,7 @@ Plan make_plan_uncached(int64_t nq, int64_t nt) {
     static const int env_w = [] { const char* e = getenv("SFM_KNN_WAVES"); return e ? atoi(e) : 0; }();   // dev override
     p.waves = (env_w == 4 || env_w == 8 || env_w == 16) ? env_w : 8;
     p.split = g_filter_mode == 1 ? 0 : 1;
-    static const int env_qg = [] { const char* e = getenv("SFM_KNN_QG"); return e ? atoi(e) : 0; }();   // dev override
-    p.qg = (p.split && env_qg != 1) ? 2 : 1;
+    p.qg = p.split ? 2 : 1;
     if (p.split && !(env_w == 4 || env_w == 8 || env_w == 16)) p.waves = p.qg == 2 ? 4 : 16;   // split2: two 4-wave workgroups per CU (their barrier stalls interleave; ~3 % over one 8-wave group)
     p.rows_per_block = p.waves * 32 * p.qg;
     p.n_rb = (int)((nq + p.rows_per_block - 1) / p.rows_per_block);
@@ -563,168 +562,10 @@ __global__ __launch_bounds__(1024) void knn_prep_kernel(const float* __restrict_
     }
 }
 
-// LDS tile image: hi rows [32][256 B] at +0, mid rows at +8 KiB, 16-byte chunks XOR-swizzled with (row & 15).
-template <int W, bool KMID = true>
-__device__ __forceinline__ void stage_tile_split(__amdgpu_buffer_rsrc_t trs, int mid_off, int lane_off, const float* __restrict__ tn,
-                                                 int nt, int tile, float* __restrict__ tile_buf, float* __restrict__ tn_buf,
-                                                 int wave) {
-    constexpr int PIECES = 16 / W;                       // 1 KiB pieces (4 rows x 256 B) per wave per tile
-    const int p0 = wave * PIECES;
-    // soffset and the LDS destination (M0) must be PROVABLY wave-uniform or hipcc wraps every DMA in a waterfall loop
-    const int soff = __builtin_amdgcn_readfirstlane(tile * kTileT * 256 + (p0 >= 8 ? mid_off : 0));
-    const unsigned dst0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)tile_buf + p0 * 1024);
-    if (KMID || p0 < 8)                                  // exact mode: the mid image is all zeros and never read
-#pragma unroll
-    for (int n = 0; n < PIECES; ++n) {
-        // row r = 4*((p0+n)&7) + (lane>>4) keeps source chunk pos ^ (r & 15) = (pos ^ (r0 & 15)) ^ 4n at position pos
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(trs, (lptr_t)(size_t)(dst0 + n * 1024), 16, (lane_off ^ (64 * n)) + 4 * n * 256, soff, 0, 0);
-    }
-    if (threadIdx.x < kTileT) {
-        const int row = tile * kTileT + threadIdx.x;
-        tn_buf[threadIdx.x] = row < nt ? tn[row] : kInf;
-    }
-}
-
-template <int ABL, int W>
-__global__ __launch_bounds__(64 * W, 4) void knn_filter_split_kernel(
-    const unsigned short* __restrict__ qsplit, const float* __restrict__ qnorm, int nq, int nq_pad,
-    const unsigned short* __restrict__ tsplit, int nt, int nt_pad, const float* __restrict__ tn, int tiles, int64_t units,
-    int smax, int nsub, float* __restrict__ cand_s, int* __restrict__ cand_i, long long* __restrict__ trace) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    if (trace && threadIdx.x == 0) {
-        trace[4 * blockIdx.x + 0] = wall_clock64();
-        trace[4 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg(0xF804);
-        trace[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg(0xF814);
-    }
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int j = lane & 31;
-    const int h = lane >> 5;
-    const int hm = h ^ (j & 15);
-    const int G = gridDim.x;
-    const int64_t u_end = unit_begin(units, G, blockIdx.x + 1);
-    int64_t u = unit_begin(units, G, blockIdx.x);
-    float* const tnb = smem + 2 * kTileFloats;
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
-    const int mid_off = nt_pad * 256;
-    const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc((void*)tsplit, 0, 2 * mid_off, 0x00020000);
-    constexpr int PIECES = 16 / W;
-    const int r0 = 4 * ((wave * PIECES) & 7) + (lane >> 4);
-    const int lane_off = r0 * 256 + (((lane & 15) ^ (r0 & 15)) << 4);
-
-    while (u < u_end) {
-        const int rb = (int)(u / tiles);
-        const int t_begin = (int)(u - (int64_t)rb * tiles);
-        const int t_end = (int)min((int64_t)tiles, t_begin + (u_end - u));
-        const int slot = blockIdx.x - block_of_unit(units, G, (int64_t)rb * tiles);
-        const int qrow = rb * (W * 32) + wave * 32 + j;
-        const bool qok = qrow < nq;
-
-        __syncthreads();
-        stage_tile_split<W>(trs, mid_off, lane_off, tn, nt, t_begin, smem, tnb, wave);
-
-        // query fragments (MFMA B operand): 8 k-steps x (hi, mid), already scaled by -2
-        uint4 bh[8], bm[8];
-        {
-            const int qr = qok ? qrow : 0;       // padded rows are zero in the image; invalid lanes are never written
-            const unsigned short* sh = qsplit + (int64_t)qr * kDim + 8 * h;
-            const unsigned short* sm = qsplit + ((int64_t)nq_pad + qr) * kDim + 8 * h;
-#pragma unroll
-            for (int st = 0; st < 8; ++st) {
-                bh[st] = *reinterpret_cast<const uint4*>(sh + 16 * st);
-                bm[st] = *reinterpret_cast<const uint4*>(sm + 16 * st);
-            }
-        }
-        const float qn = qok ? qnorm[qrow] : 0.f;   // folded into the accumulator init: s = (|t|^2 + |q|^2) - 2 q.t ~ d^2
-
-        int k0 = kKeyInf, k1 = kKeyInf, k2 = kKeyInf;
-        int sub = 0, sub_t0 = t_begin;
-        const int64_t obase = ((int64_t)qrow * (2 * smax * nsub) + (int64_t)slot * nsub * 2 + h) * 3;
-        __syncthreads();
-
-        for (int t = t_begin; t < t_end; ++t) {
-            if (t - sub_t0 == kSubTiles) {
-                if (qok) flush_keys(k0, k1, k2, sub_t0, h, cand_s + obase + 6 * sub, cand_i + obase + 6 * sub);
-                k0 = k1 = k2 = kKeyInf;
-                ++sub;
-                sub_t0 = t;
-            }
-            const int cur = (t - t_begin) & 1;
-            if (t + 1 < t_end && !(ABL & 4))
-                stage_tile_split<W>(trs, mid_off, lane_off, tn, nt, t + 1, smem + (cur ^ 1) * kTileFloats, tnb + (cur ^ 1) * kTileT, wave);
-
-            f32x16 acc;
-            if (ABL & 8) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = qn;
-            } else {
-                const float* tnp = tnb + cur * kTileT + 4 * h;
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    const float4 v = *reinterpret_cast<const float4*>(tnp + 8 * b);
-                    acc[4 * b + 0] = v.x + qn;
-                    acc[4 * b + 1] = v.y + qn;
-                    acc[4 * b + 2] = v.z + qn;
-                    acc[4 * b + 3] = v.w + qn;
-                }
-            }
-            // fragment reads ONE k-step ahead (two register sets: 128 VGPRs leave no room for a third beside the
-            // 64-register query fragment): r(s+1) issued, lgkmcnt(2) => both reads of step s have landed.
-            const unsigned abase = lds0 + (unsigned)(((ABL & 4) ? 0 : cur) * kTileFloats) * 4u + (unsigned)j * 256u + ((unsigned)hm << 4);
-            u32x4 ah[2], am[2];
-            asm volatile("ds_read_b128 %0, %1" : "=v"(ah[0]) : "v"(abase));
-            asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(am[0]) : "v"(abase));
-#pragma unroll
-            for (int st = 0; st < 8; ++st) {
-                if (ABL & 32) {
-                } else if (st + 1 < 8) {
-                    const unsigned ad = abase ^ (32u * (st + 1));
-                    asm volatile("ds_read_b128 %0, %1" : "=v"(ah[(st + 1) & 1]) : "v"(ad));
-                    asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(am[(st + 1) & 1]) : "v"(ad));
-                    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ah[st & 1]), "+v"(am[st & 1]));
-                } else {
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah[st & 1]), "+v"(am[st & 1]));
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                const bf16x8 Ah = __builtin_bit_cast(bf16x8, ah[st & 1]), Am = __builtin_bit_cast(bf16x8, am[st & 1]);
-                const bf16x8 Bh = __builtin_bit_cast(bf16x8, bh[st]), Bm = __builtin_bit_cast(bf16x8, bm[st]);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, acc, 0, 0, 0);
-            }
-            const int seq0 = (t - sub_t0) << 4;
-            if (ABL & 1) {
-                k0 = min(k0, __float_as_int(acc[0]) + __float_as_int(acc[15]));
-            } else
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = (__float_as_int(acc[r]) & ~kKeyMask) | (seq0 + r);
-                const int lo = min(key, k0);
-                const int m1 = max(min(key, k1), min(max(key, k1), k0));
-                k2 = max(min(key, k1), min(max(key, k1), k2));
-                k1 = m1;
-                k0 = lo;
-            }
-            if (!(ABL & 2)) __syncthreads();
-        }
-
-        if (qok) {
-            flush_keys(k0, k1, k2, sub_t0, h, cand_s + obase + 6 * sub, cand_i + obase + 6 * sub);
-            for (int e = sub + 1; e < nsub; ++e)
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    cand_s[obase + 6 * e + r] = kInf;
-                    cand_i[obase + 6 * e + r] = -1;
-                }
-        }
-        u += t_end - t_begin;
-    }
-    if (trace && threadIdx.x == 0) trace[4 * blockIdx.x + 1] = wall_clock64();
-}
-
-// ---------------------------------------------------------------- split-bf16 filter, two query groups per wave
-// Same arithmetic and outputs as knn_filter_split_kernel, restructured for the matrix pipe's sweet spot of TWO waves
-// per SIMD (a pure bf16-MFMA chain sustains 2.1 PFLOP/s at <= 2 waves/SIMD but 1.5 at 4 — scripts/ubench):
+// ---------------------------------------------------------------- 16-bit filter, two query groups per wave
+// LDS tile image: hi rows [32][256 B] at +0, mid rows (split) / the next tile's rows (fp16) at +8 KiB, 16-byte chunks
+// XOR-swizzled with (row & 15).  Structured for the matrix pipe's sweet spot of TWO waves per SIMD (a pure 16-bit MFMA
+// chain sustains 2.1 PFLOP/s at <= 2 waves/SIMD but 1.5 at 4 — scripts/ubench):
 //   * a wave owns 64 queries (two 32-column groups, 128 VGPRs of query fragments), so every train fragment read
 //     from LDS feeds 6 MFMAs and the two groups' accumulators form two independent dependency chains;
 //   * software pipelining inside the wave: while tile t runs on the matrix pipe, the packed-key epilogue of
@@ -1801,32 +1642,18 @@ int knn2_impl(const float* q, int64_t nq, int64_t ldq, const float* t, int64_t n
                            p.units, p.tiles, p.G, p.seg_cost, p.n_rb, w.wg_begin, w.rb_first, w.rb_last);
         SFM_CHECK_LAUNCH();
         sfm::prof_begin(sfm::kProfKnnFilter, stream);
-#define SFM_LAUNCH_SPLIT(A, WV)                                                                                        \
-    hipLaunchKernelGGL((knn_filter_split_kernel<A, WV>), grid, dim3(64 * WV), kLdsFloats * sizeof(float), stream,      \
-                       w.qsplit, w.qn, (int)nq, p.nq_pad, w.tsplit, (int)nt, p.tiles * kTileT, w.tn, p.tiles, p.units,  \
-                       p.smax, p.nsub, w.cand_s, w.cand_i, g_trace)
 #define SFM_LAUNCH_SPLIT2(A, WV)                                                                                        \
     hipLaunchKernelGGL((knn_filter_split2_kernel<A, WV>), grid, dim3(64 * WV), kRingLdsBytes, stream, w.qsplit, w.qn,    \
                        (int)nq, p.nq_pad, w.tsplit, (int)nt, p.tiles * kTileT, w.tn, p.tiles, p.units, p.smax, p.nsub,    \
                        w.midflag, w.bmax, g_force_mode, w.cand_s, w.cand_i, w.wg_begin, w.rb_first, g_trace)
-        if (p.qg == 2) {
-            if (p.waves == 4) {
-                if (abl == 1) SFM_LAUNCH_SPLIT2(1, 4); else if (abl == 7) SFM_LAUNCH_SPLIT2(7, 4); else SFM_LAUNCH_SPLIT2(0, 4);
-            } else if (p.waves == 16) {
-                if (abl == 1) SFM_LAUNCH_SPLIT2(1, 16); else if (abl == 7) SFM_LAUNCH_SPLIT2(7, 16); else SFM_LAUNCH_SPLIT2(0, 16);
-            } else {
-                if (abl == 1) SFM_LAUNCH_SPLIT2(1, 8); else if (abl == 7) SFM_LAUNCH_SPLIT2(7, 8); else if (abl == 2) SFM_LAUNCH_SPLIT2(2, 8);
-                else if (abl == 4) SFM_LAUNCH_SPLIT2(4, 8); else if (abl == 6) SFM_LAUNCH_SPLIT2(6, 8); else SFM_LAUNCH_SPLIT2(0, 8);
-            }
-        } else if (p.waves == 4) {
-            if (abl == 1) SFM_LAUNCH_SPLIT(1, 4); else if (abl == 7) SFM_LAUNCH_SPLIT(7, 4); else SFM_LAUNCH_SPLIT(0, 4);
-        } else if (p.waves == 8) {
-            if (abl == 1) SFM_LAUNCH_SPLIT(1, 8); else if (abl == 7) SFM_LAUNCH_SPLIT(7, 8); else SFM_LAUNCH_SPLIT(0, 8);
+        if (p.waves == 4) {
+            if (abl == 1) SFM_LAUNCH_SPLIT2(1, 4); else if (abl == 2) SFM_LAUNCH_SPLIT2(2, 4); else if (abl == 4) SFM_LAUNCH_SPLIT2(4, 4);
+            else if (abl == 6) SFM_LAUNCH_SPLIT2(6, 4); else if (abl == 7) SFM_LAUNCH_SPLIT2(7, 4); else SFM_LAUNCH_SPLIT2(0, 4);
+        } else if (p.waves == 16) {
+            if (abl == 1) SFM_LAUNCH_SPLIT2(1, 16); else if (abl == 7) SFM_LAUNCH_SPLIT2(7, 16); else SFM_LAUNCH_SPLIT2(0, 16);
         } else {
-            if (abl == 1) SFM_LAUNCH_SPLIT(1, 16); else if (abl == 7) SFM_LAUNCH_SPLIT(7, 16); else if (abl == 15) SFM_LAUNCH_SPLIT(15, 16);
-            else if (abl == 47) SFM_LAUNCH_SPLIT(47, 16); else if (abl == 39) SFM_LAUNCH_SPLIT(39, 16); else SFM_LAUNCH_SPLIT(0, 16);
+            if (abl == 1) SFM_LAUNCH_SPLIT2(1, 8); else if (abl == 7) SFM_LAUNCH_SPLIT2(7, 8); else SFM_LAUNCH_SPLIT2(0, 8);
         }
-#undef SFM_LAUNCH_SPLIT
 #undef SFM_LAUNCH_SPLIT2
     } else {
     hipLaunchKernelGGL(knn_norms_kernel, dim3(kNormBlocks + 1), dim3(256), 0, stream, t, ldt, (int)nt, w.tn, w.bmax,
@@ -1859,7 +1686,7 @@ int knn2_impl(const float* q, int64_t nq, int64_t ldq, const float* t, int64_t n
     }
     sfm::prof_end(sfm::kProfKnnFilter, stream);
     SFM_CHECK_LAUNCH();
-    const int force_mode = !p.split ? kModeF32 : p.qg == 2 ? g_force_mode : kModeSplit;
+    const int force_mode = !p.split ? kModeF32 : g_force_mode;
     sfm::prof_begin(sfm::kProfKnnRefine, stream);
     hipLaunchKernelGGL(knn_refine_kernel, dim3((unsigned)((nq + kRefQ - 1) / kRefQ)), dim3(256), 0, stream, q, ldq, (int)nq, t, ldt,
                        (int)nt, w.cand_s, w.cand_i, p.rows_per_block, p.tiles, p.units, p.G, p.smax * p.nsub, p.nsub,
