@@ -1,0 +1,75 @@
+"""Randomised parity sweep: sfm_match_l2_f32 (through PairMatcher) against the CPU oracle on random shapes and data
+families, including the degenerate ones that force rescans.  Usage: python scripts/fuzz_knn.py [seconds] [seed]"""
+import os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from sfm_mvs_amd import ops
+from oracle import oracle as O
+from datagen import planted_pair, sift_like
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = np.random.default_rng(seed)
+
+
+def make(kind, nq, nt):
+    if kind == "uniform":
+        return rng.random((nq, 128), dtype=np.float32), rng.random((nt, 128), dtype=np.float32)
+    if kind == "normal_scaled":
+        s = np.float32(10.0 ** rng.uniform(-4, 4))
+        return (rng.standard_normal((nq, 128)) * s).astype(np.float32), (rng.standard_normal((nt, 128)) * s + s).astype(np.float32)
+    if kind == "sift":
+        return sift_like(rng, nq), sift_like(rng, nt)
+    if kind == "planted":
+        q, t, _ = planted_pair(rng, nq, max(nt, 2), 0.3)
+        return q, t
+    if kind == "duplicates":
+        base = rng.random((max(1, nt // 7), 128), dtype=np.float32)
+        t = np.tile(base, (8, 1))[:nt]
+        q = base[rng.integers(0, len(base), nq)] + np.float32(1e-3) * rng.standard_normal((nq, 128)).astype(np.float32)
+        return q.astype(np.float32), t
+    if kind == "near_ties":
+        base = rng.random((1, 128), dtype=np.float32)
+        t = (base * (1 + np.float32(1e-6) * rng.standard_normal((nt, 1)).astype(np.float32))).astype(np.float32)
+        return rng.random((nq, 128), dtype=np.float32), t
+    if kind == "unit":
+        q = rng.standard_normal((nq, 128)); t = rng.standard_normal((nt, 128))
+        return (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32), (t / np.linalg.norm(t, axis=1, keepdims=True)).astype(np.float32)
+    if kind == "mixed_magnitude":
+        q = rng.random((nq, 128), dtype=np.float32); t = rng.random((nt, 128), dtype=np.float32)
+        t[:: max(1, nt // 9)] *= np.float32(1e-4); q[::3] *= np.float32(100.0)
+        return q, t
+    raise ValueError(kind)
+
+
+kinds = ["uniform", "normal_scaled", "sift", "planted", "duplicates", "near_ties", "unit", "mixed_magnitude"]
+t_end = time.time() + budget
+cases = fails = 0
+modes = {}
+while time.time() < t_end:
+    kind = kinds[cases % len(kinds)]
+    nq = int(rng.choice([1, 3, 17, 64, 255, 257, 1000, 2049, 5000]) if rng.random() < 0.5 else rng.integers(1, 6000))
+    nt = int(rng.choice([1, 2, 31, 33, 512, 1023, 4097, 9000]) if rng.random() < 0.5 else rng.integers(1, 12000))
+    if kind in ("duplicates", "near_ties"):
+        nq, nt = min(nq, 600), min(nt, 3000)             # every stream is rescanned: keep the exact work bounded
+    q, t = make(kind, nq, nt)
+    nq, nt = len(q), len(t)
+    variant = ["auto", "auto", "auto", "split", "f32"][cases % 5]
+    ops.set_knn_filter(variant)
+    pm = ops.PairMatcher(nq, nt, "cuda", ratio=0.70)
+    idx, dist, oq, ot, cnt = pm.run(torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda())
+    gi, gd, m = idx.cpu().numpy(), dist.cpu().numpy(), int(cnt.item())
+    wi, wd = O.knn2(q, t, nthreads=os.cpu_count() or 8)
+    wq, wt, _ = O.ratio_filter(wi, wd, 0.70)
+    ok = np.array_equal(gi, wi) and np.array_equal(gd.view(np.uint32), wd.view(np.uint32)) and m == len(wq) \
+        and np.array_equal(oq[:m].cpu().numpy(), wq) and np.array_equal(ot[:m].cpu().numpy(), wt)
+    st = pm.stats.cpu().tolist()
+    modes[st[3]] = modes.get(st[3], 0) + 1
+    cases += 1
+    if not ok:
+        fails += 1
+        print(f"MISMATCH case {cases}: kind={kind} nq={nq} nt={nt} variant={variant} stats={st} rows differing={(gi != wi).any(1).sum()}", flush=True)
+ops.set_knn_filter("auto")
+print(f"fuzz: {cases} cases, {fails} mismatches, filter modes used {modes} (seed {seed})")
+sys.exit(1 if fails else 0)

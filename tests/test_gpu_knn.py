@@ -265,3 +265,13 @@ def test_pair_pipeline_keeps_pairs_apart(hip, oracle):
         assert_bit_equal((idx.cpu().numpy(), dist.cpu().numpy()), (wi, wd))
         m = int(cnt.item())
         assert m == len(wq) and np.array_equal(oq[:m].cpu().numpy(), wq) and np.array_equal(ot[:m].cpu().numpy(), wt)
+
+
+def test_randomised_parity_sweep(hip):
+    """A few seconds of scripts/fuzz_knn.py: random shapes x data families (incl. duplicates / near-ties that force
+    rescans) x filter variants, each compared bit for bit with the oracle (the script exits non-zero on a mismatch)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_knn.py"), "6", "7"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " 0 mismatches" in r.stdout
