@@ -259,6 +259,16 @@ int sfm_score_pnp(const double* poses_dev, int h, const double* K_host,
                   int32_t* counts_dev, uint8_t* mask_dev, void* stream);
 
 /* ------------------------------------------------------------------------
+ * A6  host-side minimal solver of solvePnPRansac (sfm.py:67): EPnP on a sample of 4..64
+ *     correspondences — the hypothesis generator between two device scoring launches
+ *     (sfm_score_pnp).  Pure host code, HOST pointers:
+ *   K_host 9 doubles (row-major 3x3), Xw_host [n x 3] doubles, uv_host [n x 2] doubles (pixels)
+ *   R_host 9 doubles (row-major), t_host 3 doubles
+ * ---------------------------------------------------------------------- */
+int sfm_host_epnp(const double* K_host, const double* Xw_host, const double* uv_host, int n,
+                  double* R_host, double* t_host);
+
+/* ------------------------------------------------------------------------
  * Measurement hook (no reference counterpart): when enabled, the library brackets
  * its dominant kernels with hipEvents recorded on the launch stream.
  * sfm_profile_read synchronises those events, returns the summed device time

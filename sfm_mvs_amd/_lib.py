@@ -46,6 +46,7 @@ SIGNATURES = {
     "sfm_ba_schur_w": (_int, [_vp, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
     "sfm_ba_schur_indexed_ws_bytes": (_sz, [_i64]),
     "sfm_ba_schur_indexed": (_int, [_vp, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _int, _vp, _vp, _vp, _sz, _vp]),
+    "sfm_host_epnp": (_int, [_vp, _vp, _vp, _int, _vp, _vp]),
     "sfm_score_essential": (_int, [_vp, _int, _vp, _vp, _i64, _f32, _vp, _vp, _vp]),
     "sfm_recover_pose_score": (_int, [_vp, _int, _vp, _vp, _i64, _f64, _int, _vp, _vp, _vp]),
     "sfm_score_pnp": (_int, [_vp, _int, _vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp]),

@@ -180,8 +180,25 @@ def _epnp_betas(L, rho, cols):
 
 
 def epnp(K, Xw, uv):
-    """EPnP (Lepetit, Moreno-Noguer, Fua 2009) as used for the 5-point minimal samples of
-    solvePnPRansac.  Xw (n,3), uv (n,2) pixels.  Returns R (3,3), t (3,)."""
+    """EPnP (Lepetit, Moreno-Noguer, Fua 2009) as used for the 5-point minimal samples of solvePnPRansac.
+    Xw (n,3), uv (n,2) pixels.  Returns R (3,3), t (3,).  Runs the library's host solver (sfm_host_epnp, C++: the
+    NumPy restatement below took 1.2 ms per call and 60 % of a 57-camera run); samples larger than 64 points use NumPy."""
+    Xw = np.ascontiguousarray(Xw, np.float64).reshape(-1, 3)
+    uv = np.ascontiguousarray(uv, np.float64).reshape(-1, 2)
+    if 4 <= len(Xw) <= 64:
+        import ctypes
+        from . import _lib
+        Kc = np.ascontiguousarray(K, np.float64).reshape(9)
+        R, t = np.empty(9), np.empty(3)
+        vp = ctypes.c_void_p
+        _lib.check(_lib.lib().sfm_host_epnp(Kc.ctypes.data_as(vp), Xw.ctypes.data_as(vp), uv.ctypes.data_as(vp), len(Xw),
+                                            R.ctypes.data_as(vp), t.ctypes.data_as(vp)), "sfm_host_epnp")
+        return R.reshape(3, 3), t
+    return epnp_numpy(K, Xw, uv)
+
+
+def epnp_numpy(K, Xw, uv):
+    """The same algorithm in NumPy (reference for the C++ solver's tests; large samples)."""
     Xw = np.asarray(Xw, np.float64)
     uv = np.asarray(uv, np.float64)
     n = len(Xw)

@@ -114,3 +114,31 @@ def test_scene_generator_is_consistent():
     assert len(feats) == 4 and all(f[0].dtype == np.float32 and f[1].shape[1] == 128 for f in feats)
     common = np.intersect1d(ids[1][ids[1] >= 0], ids[2][ids[2] >= 0])
     assert len(common) > 100
+
+
+def test_cpp_epnp_agrees_with_the_numpy_restatement():
+    """sfm_host_epnp (C++) vs hostgeom.epnp_numpy.  On exact correspondences both return the same pose; on noisy minimal
+    samples EPnP's three beta approximations + 5 Gauss-Newton steps can settle on different, equally good solutions
+    (eigenvector bases of near-equal eigenvalues differ between the two eigen-solvers), so there the two are compared
+    against the ground truth instead of against each other."""
+    K, P1, P2, X, x1, x2 = gustav_pair(3, 400, 0.0, seed=11)
+    R, t = decompose_P(K, P2)
+    rng = np.random.default_rng(0)
+    for trial in range(100):
+        n = 5 if trial < 70 else int(rng.integers(6, 40))
+        sel = rng.choice(len(X), n, replace=False)
+        Rc, tc = hg.epnp(K, X[sel], x2[sel].astype(np.float64))
+        Rn, tn = hg.epnp_numpy(K, X[sel], x2[sel].astype(np.float64))
+        assert abs(np.linalg.det(Rc) - 1) < 1e-9 and np.allclose(Rc @ Rc.T, np.eye(3), atol=1e-9)
+        assert np.abs(Rc - Rn).max() < 1e-6 and np.abs(tc - tn).max() < 1e-5 * max(1.0, np.abs(tn).max()), trial
+    K, P1, P2, X, x1, x2 = gustav_pair(3, 400, 0.3, seed=11)
+    ec, en = [], []
+    for trial in range(200):
+        n = 5 if trial < 150 else int(rng.integers(6, 40))
+        sel = rng.choice(len(X), n, replace=False)
+        Rc, tc = hg.epnp(K, X[sel], x2[sel].astype(np.float64))
+        Rn, tn = hg.epnp_numpy(K, X[sel], x2[sel].astype(np.float64))
+        assert np.isfinite(Rc).all() and abs(np.linalg.det(Rc) - 1) < 1e-9
+        ec.append(np.abs(Rc - R).max())
+        en.append(np.abs(Rn - R).max())
+    assert 0.7 < np.median(ec) / np.median(en) < 1.4 and np.percentile(ec, 90) < 1.5 * np.percentile(en, 90)
