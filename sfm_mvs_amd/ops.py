@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import SfmHipError, check, ptr, require_cuda, stream_ptr
+from ._lib import SfmHipError, check, on_device, ptr, require_cuda, stream_ptr
 
 _ws_cache = {}
 
@@ -58,7 +58,7 @@ def knn2(des0, des1, return_stats=False):
     ws = _workspace(des0.device, need)
     ldq = des0.stride(0) if nq > 1 else dim
     ldt = des1.stride(0) if nt > 1 else dim
-    with torch.cuda.device(des0.device):
+    with on_device(des0.device):
         check(lib.sfm_knn2_l2_f32(ptr(des0), nq, ldq, ptr(des1), nt, ldt, dim, ptr(idx), ptr(dist), ptr(stats),
                                   ptr(ws), ws.numel(), stream_ptr()), "sfm_knn2_l2_f32")
     return (idx, dist, stats) if return_stats else (idx, dist)
@@ -80,7 +80,7 @@ def ratio_compact(idx, dist, ratio=0.70, want_mask=False):
     mask = torch.empty(nq, dtype=torch.uint8, device=idx.device) if want_mask else None
     lib = _lib.lib()
     rws = torch.empty(max(lib.sfm_ratio_compact_ws_bytes(nq), 256), dtype=torch.uint8, device=idx.device)
-    with torch.cuda.device(idx.device):
+    with on_device(idx.device):
         check(lib.sfm_ratio_compact(ptr(idx), ptr(dist), nq, float(ratio), ptr(out_q), ptr(out_t), ptr(count), ptr(mask),
                                     ptr(rws), rws.numel(), stream_ptr()), "sfm_ratio_compact")
     return (out_q, out_t, count, mask) if want_mask else (out_q, out_t, count)
@@ -94,7 +94,7 @@ def gather_matches(kp0, kp1, out_q, out_t, count):
     cap = out_q.shape[0]
     pts0 = torch.empty((cap, 2), dtype=torch.float32, device=kp0.device)
     pts1 = torch.empty((cap, 2), dtype=torch.float32, device=kp0.device)
-    with torch.cuda.device(kp0.device):
+    with on_device(kp0.device):
         check(_lib.lib().sfm_gather_matches(ptr(kp0), ptr(kp1), ptr(out_q), ptr(out_t), ptr(count), cap, ptr(pts0),
                                             ptr(pts1), stream_ptr()), "sfm_gather_matches")
     return pts0, pts1
@@ -113,7 +113,7 @@ def common_points(pts1, pts2):
     idx2 = torch.empty(max(n1, 1), dtype=torch.int32, device=dev)
     count = torch.zeros(1, dtype=torch.int32, device=dev)
     keep2 = torch.empty(max(n2, 1), dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with on_device(dev):
         check(_lib.lib().sfm_common_points(ptr(pts1), n1, ptr(pts2), n2, ptr(first), ptr(idx1), ptr(idx2), ptr(count),
                                            ptr(keep2), stream_ptr()), "sfm_common_points")
     m = int(count.item())
@@ -161,7 +161,7 @@ def triangulate(P1, P2, pts1, pts2, rows=4, normalise_w=False):
     p2 = _f64_host(P2, 12, "P2")
     X4 = torch.empty((4, n), dtype=torch.float32, device=pts1.device)
     spt, sxy = (pts1.stride(1), pts1.stride(0)) if n > 0 else (1, 1)
-    with torch.cuda.device(pts1.device):
+    with on_device(pts1.device):
         check(_lib.lib().sfm_triangulate_dlt(p1.ctypes.data_as(ctypes.c_void_p), p2.ctypes.data_as(ctypes.c_void_p),
                                              ptr(pts1), ptr(pts2), n, spt, sxy, int(rows), int(normalise_w),
                                              ptr(X4), stream_ptr()), "sfm_triangulate_dlt")
@@ -202,7 +202,7 @@ def project_residual(cams, K, X, obs, cam_idx=None, pt_idx=None, thr2=64.0, want
     ws = _workspace(dev, lib.sfm_project_residual_ws_bytes(nobs, ncam, npt))
     ci = None if cam_idx is None else cam_idx.contiguous().to(torch.int32)
     pi = None if pt_idx is None else pt_idx.contiguous().to(torch.int32)
-    with torch.cuda.device(dev):
+    with on_device(dev):
         check(lib.sfm_project_residual(ptr(cams), ncam, k.ctypes.data_as(ctypes.c_void_p), ptr(X), npt,
                                        X.stride(0) if npt > 1 else 3, ptr(obs), ptr(ci), ptr(pi), nobs,
                                        ptr(out.get("proj")), ptr(out["sumsq"]), ptr(out.get("inlier")), float(thr2),
@@ -233,7 +233,7 @@ def ba_dense_sweep(cams, K, X, obs, want_cam=True, want_pt=True):
         out["Jtr_pt"] = torch.empty((npt, 3), dtype=torch.float64, device=dev)
     lib = _lib.lib()
     ws = _workspace(dev, lib.sfm_ba_dense_sweep_ws_bytes(ncam, npt))
-    with torch.cuda.device(dev):
+    with on_device(dev):
         check(lib.sfm_ba_dense_sweep(ptr(cams), ncam, k.ctypes.data_as(ctypes.c_void_p), ptr(X), npt, X.stride(0),
                                      ptr(obs), ptr(out["sumsq"]), ptr(out.get("JtJ_cam")), ptr(out.get("Jtr_cam")),
                                      ptr(out.get("JtJ_pt")), ptr(out.get("Jtr_pt")), ptr(ws), ws.numel(), stream_ptr()),
@@ -259,7 +259,7 @@ def _schur_indexed(cams, k, X, cam_idx, pt_idx, mode, vec):
     out = torch.empty((npt, 3) if mode == 0 else (ncam, 6), dtype=torch.float64, device=dev)
     lib = _lib.lib()
     ws = _workspace(dev, lib.sfm_ba_schur_indexed_ws_bytes(ncam))
-    with torch.cuda.device(dev):
+    with on_device(dev):
         check(lib.sfm_ba_schur_indexed(ptr(cams), ncam, k.ctypes.data_as(ctypes.c_void_p), ptr(X), npt, X.stride(0), ptr(cam_idx),
                                        ptr(pt_idx), cam_idx.numel(), mode, ptr(vec), ptr(out), ptr(ws), ws.numel(), stream_ptr()),
               "sfm_ba_schur_indexed")
@@ -277,7 +277,7 @@ def ba_schur_wt(cams, K, X, x_cam, cam_idx=None, pt_idx=None):
     u = torch.empty((npt, 3), dtype=torch.float64, device=dev)
     lib = _lib.lib()
     ws = _workspace(dev, lib.sfm_ba_schur_ws_bytes(ncam, npt))
-    with torch.cuda.device(dev):
+    with on_device(dev):
         check(lib.sfm_ba_schur_wt(ptr(cams), ncam, k.ctypes.data_as(ctypes.c_void_p), ptr(X), npt, X.stride(0), ptr(x_cam), ptr(u),
                                   ptr(ws), ws.numel(), stream_ptr()), "sfm_ba_schur_wt")
     return u
@@ -293,7 +293,7 @@ def ba_schur_w(cams, K, X, v_pt, cam_idx=None, pt_idx=None):
     w = torch.empty((ncam, 6), dtype=torch.float64, device=dev)
     lib = _lib.lib()
     ws = _workspace(dev, lib.sfm_ba_schur_ws_bytes(ncam, npt))
-    with torch.cuda.device(dev):
+    with on_device(dev):
         check(lib.sfm_ba_schur_w(ptr(cams), ncam, k.ctypes.data_as(ctypes.c_void_p), ptr(X), npt, X.stride(0), ptr(v_pt), ptr(w),
                                  ptr(ws), ws.numel(), stream_ptr()), "sfm_ba_schur_w")
     return w
@@ -308,7 +308,7 @@ def score_essential(E, x1n, x2n, thr2, want_mask=False):
     h, n = E.shape[0], x1n.shape[0]
     counts = torch.empty(h, dtype=torch.int32, device=E.device)
     mask = torch.empty((h, n), dtype=torch.uint8, device=E.device) if want_mask else None
-    with torch.cuda.device(E.device):
+    with on_device(E.device):
         check(_lib.lib().sfm_score_essential(ptr(E), h, ptr(x1n), ptr(x2n), n, float(thr2), ptr(counts), ptr(mask),
                                              stream_ptr()), "sfm_score_essential")
     return (counts, mask) if want_mask else counts
@@ -326,7 +326,7 @@ def score_pnp(poses, K, X, obs, thr2=64.0, want_mask=False):
     k = _f64_host(K, 9, "K")
     counts = torch.empty(h, dtype=torch.int32, device=X.device)
     mask = torch.empty((h, n), dtype=torch.uint8, device=X.device) if want_mask else None
-    with torch.cuda.device(X.device):
+    with on_device(X.device):
         check(_lib.lib().sfm_score_pnp(ptr(poses), h, k.ctypes.data_as(ctypes.c_void_p), ptr(X), ptr(obs), n,
                                        float(thr2), ptr(counts), ptr(mask), stream_ptr()), "sfm_score_pnp")
     return (counts, mask) if want_mask else counts

@@ -16,6 +16,7 @@ import torch
 
 from . import hostgeom as hg
 from . import ops
+from ._lib import on_device
 
 
 class HipBackend:
@@ -42,7 +43,7 @@ class HipBackend:
         h, n = P.shape[0], prep[0].shape[0]
         counts = torch.empty(h, dtype=torch.int32, device=self.device)
         mask = torch.empty((h, n), dtype=torch.uint8, device=self.device)
-        with torch.cuda.device(self.device):
+        with on_device(self.device):
             _lib.check(_lib.lib().sfm_recover_pose_score(P.ctypes.data_as(ctypes.c_void_p), h, _lib.ptr(prep[0]),
                                                          _lib.ptr(prep[1]), n, float(dist), self.dlt_rows, _lib.ptr(counts),
                                                          _lib.ptr(mask), _lib.stream_ptr()), "sfm_recover_pose_score")
