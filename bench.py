@@ -185,12 +185,12 @@ def bench_knn(args, world, rank, dev):
     # neighbours' kernels it shares the chip with — so a few steps of the timed region are run ALONE (pipeline drained
     # before and after) with the events on; the roofline's launch duration is the average over those launches.
     # The drains are inside the timed region and cost `value` 2-3 percent.
-    # Pipelined: the first, the middle and the last step of the timed region (at the two ends the pipeline is empty
-    # anyway, so only the middle one costs a full drain + refill).
+    # Pipelined: the first and the last step of the timed region (the pipeline is empty there anyway) and three
+    # evenly spaced ones in between (each costs a drain + refill).
     if depth == 1:
         profiled = set(range(0, args.steps, PROF_EVERY))
     else:
-        profiled = {0, args.steps // 2, args.steps - 1}
+        profiled = {0, args.steps // 4, args.steps // 2, 3 * args.steps // 4, args.steps - 1}
     ops.profile_read(0), ops.profile_read(1)               # clear the slots
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -246,7 +246,7 @@ def bench_knn(args, world, rank, dev):
                      "algorithmic_flop_per_launch": algo_flop,
                      "issued_mfma_tflops": issued, "issued_frac_of_peak": issued / BF16_MFMA_PEAK_TFLOPS,
                      "launch_sampling": (f"HIP events on every {PROF_EVERY}th step of the timed region" if depth == 1 else
-                                         "HIP events on the first, middle and last step of the timed region, each run alone (pipeline drained)"),
+                                         "HIP events on 5 evenly spaced steps of the timed region (first and last included), each run alone (pipeline drained)"),
                      "note": "algorithmic = 256 FLOP per distance (SURVEY 8d); issued = MFMA flops of the arithmetic mode that ran"},
         "kernels_ms": {"knn_filter": filt_avg_ms, "knn_refine": ref_ms / max(ref_n, 1)},
         "knn_stats": {"rescanned_queries": stats[0], "filter_workgroups": stats[1], "streams_per_query": stats[2],
