@@ -872,30 +872,8 @@ __global__ __launch_bounds__(64 * W, 2) void knn_filter_split2_kernel(
 // ---------------------------------------------------------------- exact direct-form distance
 // Reference arithmetic (OpenCV normL2Sqr_, SSE2 path): two 4-lane accumulators over blocks of 8,
 // mul and add separately rounded; lanes summed as (d0+d1) then ((s0+s1)+s2)+s3.
-// Compiled with -ffp-contract=off so none of this fuses.
-__device__ __forceinline__ float exact_l2sq_128(const float* __restrict__ qrow /*LDS*/, const float* __restrict__ trow) {
-    float acc[8];
-#pragma unroll
-    for (int l = 0; l < 8; ++l) acc[l] = 0.f;
-#pragma unroll 4
-    for (int i = 0; i < 16; ++i) {
-        const float4 t0 = *reinterpret_cast<const float4*>(trow + 8 * i);
-        const float4 t1 = *reinterpret_cast<const float4*>(trow + 8 * i + 4);
-        const float4 q0 = *reinterpret_cast<const float4*>(qrow + 8 * i);
-        const float4 q1 = *reinterpret_cast<const float4*>(qrow + 8 * i + 4);
-        float d;
-        d = q0.x - t0.x; acc[0] = acc[0] + d * d;
-        d = q0.y - t0.y; acc[1] = acc[1] + d * d;
-        d = q0.z - t0.z; acc[2] = acc[2] + d * d;
-        d = q0.w - t0.w; acc[3] = acc[3] + d * d;
-        d = q1.x - t1.x; acc[4] = acc[4] + d * d;
-        d = q1.y - t1.y; acc[5] = acc[5] + d * d;
-        d = q1.z - t1.z; acc[6] = acc[6] + d * d;
-        d = q1.w - t1.w; acc[7] = acc[7] + d * d;
-    }
-    const float s0 = acc[0] + acc[4], s1 = acc[1] + acc[5], s2 = acc[2] + acc[6], s3 = acc[3] + acc[7];
-    return ((s0 + s1) + s2) + s3;
-}
+// Compiled with -ffp-contract=off so none of this fuses.  The evaluators below (lane pair / quad per train) keep that
+// order: which hardware lane owns which accumulator lane is free, the order of the 16 adds per accumulator is not.
 
 // Lane exchanges without an address register: lane ^ M by DPP quad_perm (M = 1, 2) or ds_swizzle bit mode
 // (M = 4, 8, 16); __shfl_xor compiles to ds_bpermute and keeps one address VGPR alive per distinct pattern.
@@ -932,35 +910,7 @@ __device__ __forceinline__ void best2_insert(Best2& b, float d, float dsq, int i
     }
 }
 
-__device__ __forceinline__ void best2_wave_reduce(Best2& b) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        Best2 o;
-        o.d[0] = __shfl_xor(b.d[0], m, 64); o.dsq[0] = __shfl_xor(b.dsq[0], m, 64); o.i[0] = __shfl_xor(b.i[0], m, 64);
-        o.d[1] = __shfl_xor(b.d[1], m, 64); o.dsq[1] = __shfl_xor(b.dsq[1], m, 64); o.i[1] = __shfl_xor(b.i[1], m, 64);
-        best2_insert(b, o.d[0], o.dsq[0], o.i[0]);
-        best2_insert(b, o.d[1], o.dsq[1], o.i[1]);
-    }
-}
-
 // ---------------------------------------------------------------- refine
-// Exact direct-form distances for a wave's short candidate list, EIGHT lanes per candidate: sub-lane l owns
-// accumulator lane l of the reference's 2x4-lane order (acc_l += (q[8i+l] - t[8i+l])^2, i = 0..15, mul and add
-// separately rounded), then s_l = acc_l + acc_{l+4}, d^2 = ((s0 + s1) + s2) + s3 — bit-identical to
-// exact_l2sq_128, with a 16-step dependent chain instead of 128.
-__device__ __forceinline__ float exact_l2sq_group8(const float* __restrict__ qrow /*LDS*/, const float* __restrict__ trow,
-                                                   int l) {
-    float acc = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const float d = qrow[8 * i + l] - trow[8 * i + l];
-        acc = acc + d * d;
-    }
-    const float s = acc + __shfl_down(acc, 4, 8);        // valid on l < 4
-    const float s1 = __shfl_down(s, 1, 8), s2 = __shfl_down(s, 2, 8), s3 = __shfl_down(s, 3, 8);
-    return ((s + s1) + s2) + s3;                         // valid on l == 0
-}
-
 // Slack coefficients of the refine kernel's certificate, relative to (|q|+|t|max)^2:
 //   common:   600u  fp32 rounding of norms / direct-form sums / sqrtf merge (+ GEMM-form chain for the f32 filter)
 //             2^-14 packed-key truncation of the score
@@ -1011,34 +961,6 @@ __device__ __forceinline__ float quad_swap(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E /*quad_perm [2,3,0,1]*/, 0xF, 0xF, false));
 }
 
-__device__ __forceinline__ float exact_l2sq_quad(const float* __restrict__ qrow /*LDS*/, const float* __restrict__ trow, int j) {
-    float4 t[8];
-#pragma unroll
-    for (int n = 0; n < 8; ++n) t[n] = *reinterpret_cast<const float4*>(trow + 16 * n + 4 * j);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int n = 0; n < 8; ++n) {
-        const float4 qv = *reinterpret_cast<const float4*>(qrow + 16 * n + 4 * j);
-        float4 x;
-        float d;
-        d = qv.x - t[n].x; x.x = d * d;
-        d = qv.y - t[n].y; x.y = d * d;
-        d = qv.z - t[n].z; x.z = d * d;
-        d = qv.w - t[n].w; x.w = d * d;
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {            // step 2n: lower pair live; step 2n+1: upper pair live
-            acc.x = quad_swap(acc.x) + x.x;
-            acc.y = quad_swap(acc.y) + x.y;
-            acc.z = quad_swap(acc.z) + x.z;
-            acc.w = quad_swap(acc.w) + x.w;
-        }
-    }
-    // lane 2 holds accumulator lanes 0..3, lane 3 holds 4..7:  s_c = acc_c + acc_{c+4},  d^2 = ((s0 + s1) + s2) + s3
-    const float s0 = acc.x + lane_odd_neighbour(acc.x), s1 = acc.y + lane_odd_neighbour(acc.y);
-    const float s2 = acc.z + lane_odd_neighbour(acc.z), s3 = acc.w + lane_odd_neighbour(acc.w);
-    return ((s0 + s1) + s2) + s3;
-}
-
 // Exact d^2 with TWO lanes per train: lane p owns accumulator lanes 4p..4p+3 of the reference order for all 16
 // steps (float4 at elements 8i + 4p), so there is no cross-lane chain and 8 candidates of a 16-lane query group are
 // evaluated in ONE pass — the latency-optimal layout for the refine kernel's short candidate lists.
@@ -1066,8 +988,8 @@ __device__ __forceinline__ float exact_l2sq_pair(const float* __restrict__ qrow 
     return ((s0 + s1) + s2) + s3;
 }
 
-// exact_l2sq_quad for R trains at once: all 8R row fetches are issued before the first add (the rescan is bound by
-// memory round trips, not arithmetic).  trow[r] == nullptr skips row r.
+// The quad evaluation for R trains at once: all 8R row fetches are issued before the first add (the rescan is bound
+// by memory round trips, not arithmetic).  trow[r] == nullptr skips row r.
 template <int R>
 __device__ __forceinline__ void exact_l2sq_quad_rows(const float* __restrict__ qrow /*LDS*/, const float* const (&trow)[R], int j,
                                                      float (&out)[R]) {
