@@ -10,6 +10,7 @@ from datagen import planted_pair, sift_like
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+big = len(sys.argv) > 3 and sys.argv[3] == "big"       # also long train sets (many substreams / candidate records per query)
 rng = np.random.default_rng(seed)
 
 
@@ -51,6 +52,8 @@ while time.time() < t_end:
     kind = kinds[cases % len(kinds)]
     nq = int(rng.choice([1, 3, 17, 64, 255, 257, 1000, 2049, 5000]) if rng.random() < 0.5 else rng.integers(1, 6000))
     nt = int(rng.choice([1, 2, 31, 33, 512, 1023, 4097, 9000]) if rng.random() < 0.5 else rng.integers(1, 12000))
+    if big and cases % 3 == 0:
+        nq, nt = int(rng.integers(1, 700)), int(rng.integers(20000, 70000))
     if kind in ("duplicates", "near_ties"):
         nq, nt = min(nq, 600), min(nt, 3000)             # every stream is rescanned: keep the exact work bounded
     q, t = make(kind, nq, nt)
