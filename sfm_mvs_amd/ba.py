@@ -136,16 +136,18 @@ def schur_step(cams, K, X, blocks, lam, fix_first_camera=True, cg_tol=1e-10, cg_
     r = rhs.clone()
     z = torch.bmm(Minv, r.unsqueeze(2)).squeeze(2) * free
     p = z.clone()
-    rz = float((r * z).sum())
-    r0 = float(rhs.norm())
+    rz = (r * z).sum()                                   # CG scalars stay on the device: one host sync per 5 iterations
+    stop2 = (cg_tol * cg_tol) * (rhs * rhs).sum()
     it = 0
-    while it < cg_iters and r0 > 0 and float(r.norm()) > cg_tol * r0:
+    while it < cg_iters:
+        if it % 5 == 0 and bool(((r * r).sum() <= stop2).item()):
+            break
         Sp = S(p)
-        alpha = rz / float((p * Sp).sum())
+        alpha = rz / (p * Sp).sum()
         x += alpha * p
         r -= alpha * Sp
         z = torch.bmm(Minv, r.unsqueeze(2)).squeeze(2) * free
-        rz_new = float((r * z).sum())
+        rz_new = (r * z).sum()
         p = z + (rz_new / rz) * p
         rz = rz_new
         it += 1
