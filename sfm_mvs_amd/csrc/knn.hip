@@ -33,6 +33,8 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+typedef int i32x3 __attribute__((ext_vector_type(3)));
 
 constexpr int kDim = 128;
 constexpr int kTileT = 32;             // train rows per LDS tile (= MFMA M)
@@ -281,13 +283,19 @@ constexpr int kKeyInf = 0x7F800000;               // +inf: larger than every fin
 __device__ __forceinline__ void flush_keys(int k0, int k1, int k2, int sub_t0, int h, float* __restrict__ cs,
                                            int* __restrict__ ci) {
     const int ks[3] = {k0, k1, k2};
+    float sc[3];
+    int id[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         const int seq = ks[r] & kKeyMask;
         const bool empty = ks[r] == kKeyInf;
-        cs[r] = empty ? kInf : __int_as_float(ks[r] & ~kKeyMask);
-        ci[r] = empty ? -1 : (sub_t0 + (seq >> 4)) * kTileT + (seq & 3) + 8 * ((seq >> 2) & 3) + 4 * h;
+        sc[r] = empty ? kInf : __int_as_float(ks[r] & ~kKeyMask);
+        id[r] = empty ? -1 : (sub_t0 + (seq >> 4)) * kTileT + (seq & 3) + 8 * ((seq >> 2) & 3) + 4 * h;
     }
+    // one 12-byte store per array: a lane's record is private and the lanes of a wave are 336+ B apart, so every
+    // store instruction is 64 separate requests — three dword stores cost three times as much
+    asm volatile("global_store_dwordx3 %0, %1, off" ::"v"(cs), "v"(f32x3{sc[0], sc[1], sc[2]}) : "memory");
+    asm volatile("global_store_dwordx3 %0, %1, off" ::"v"(ci), "v"(i32x3{id[0], id[1], id[2]}) : "memory");
 }
 
 // ABL != 0 are dev-only timing ablations (results are WRONG): bit0 skip the top-3 epilogue, bit1 skip the
@@ -696,7 +704,9 @@ __device__ __forceinline__ void filter_split2_body(
                 }
             ka[0] = kb[0] = kc[0] = ka[1] = kb[1] = kc[1] = kKeyInf;
         };
+        if (trace && threadIdx.x == 0 && !trace[14336 + 4 * blockIdx.x + 1]) trace[14336 + 4 * blockIdx.x + 1] = wall_clock64();   // dev: loads issued
         wait_vmcnt<0>();                                           // first tile(s) + query fragments landed
+        if (trace && threadIdx.x == 0 && !trace[14336 + 4 * blockIdx.x + 2]) trace[14336 + 4 * blockIdx.x + 2] = wall_clock64();   // dev: landed
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -859,6 +869,7 @@ __global__ __launch_bounds__(64 * W, 2) void knn_filter_split2_kernel(
     }
     const int lane = threadIdx.x & 63;
     const bool need_mid = (force_mode >= 0 ? force_mode : knn_filter_mode(midflag, bmax, lane)) == kModeSplit;
+    if (trace && threadIdx.x == 0) trace[14336 + 4 * blockIdx.x + 0] = wall_clock64();   // dev: mode known
     if (need_mid)
         filter_split2_body<ABL, W, true>(smem, qsplit, qnorm, nq, nq_pad, tsplit, nt_pad, tn, tiles, units, smax, nsub, cand_s, cand_i, wg_begin, rb_first, trace);
     else
