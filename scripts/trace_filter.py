@@ -21,8 +21,6 @@ b = tr.view(-1)[8192:8192 + 4 * G].view(G, 4).cpu().numpy()
 print("prologue (first segment) us: med %.1f max %.1f | last loop end -> WG end us: med %.1f max %.1f" % (np.median(b[:, 0]) / 100.0, b[:, 0].max() / 100.0, np.median(a[:, 1] - b[:, 1]) / 100.0, (a[:, 1] - b[:, 1]).max() / 100.0))
 mhz = (b[:, 3] - b[:, 2]) / ((a[:, 1] - a[:, 0]) / 100.0)
 print("shader clock during the kernel (clock64 ticks per us): min %.0f med %.0f max %.0f" % (mhz.min(), np.median(mhz), mhz.max()))
-d = tr.view(-1)[14336:14336 + 4 * G].view(G, 4).cpu().numpy()
-print("prologue split (us, medians): start->mode %.1f, mode->loads issued %.1f, issued->landed %.1f" % (np.median(d[:, 0] - a[:, 0]) / 100.0, np.median(d[:, 1] - d[:, 0]) / 100.0, np.median(d[:, 2] - d[:, 1]) / 100.0))
 print("G", G, "start us: min %.1f max %.1f | end us: min %.1f max %.1f | dur: min %.1f med %.1f max %.1f" % (st.min(), st.max(), en.min(), en.max(), (en-st).min(), np.median(en-st), (en-st).max()))
 u, c = np.unique(key, return_counts=True)
 print("distinct CUs used:", len(u), "blocks/CU histogram:", dict(zip(*np.unique(c, return_counts=True))))

@@ -33,8 +33,8 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x3 __attribute__((ext_vector_type(3)));
-typedef int i32x3 __attribute__((ext_vector_type(3)));
+typedef float f32x3 __attribute__((ext_vector_type(3), aligned(4)));
+typedef int i32x3 __attribute__((ext_vector_type(3), aligned(4)));
 
 constexpr int kDim = 128;
 constexpr int kTileT = 32;             // train rows per LDS tile (= MFMA M)
@@ -280,22 +280,34 @@ constexpr int kSubTiles = 1 << (kKeyBits - 4);    // 32 tiles per substream
 constexpr int kKeyInf = 0x7F800000;               // +inf: larger than every finite non-negative score key
 
 // decode 3 packed keys into (truncated score, train index) records
+template <bool WIDE = false>
 __device__ __forceinline__ void flush_keys(int k0, int k1, int k2, int sub_t0, int h, float* __restrict__ cs,
                                            int* __restrict__ ci) {
     const int ks[3] = {k0, k1, k2};
-    float sc[3];
-    int id[3];
+    if constexpr (WIDE) {
+        // one 12-byte store per array (4-byte aligned vector types: global_store_dwordx3): a lane's record is private
+        // and the lanes of a wave are 336+ B apart, so every store instruction is 64 separate requests — three dword
+        // stores cost three times as much.  (Only where registers are plentiful: the 96-bit register tuples tipped the
+        // split body, which sits at the 256-VGPR limit, into 49 spills.)
+        f32x3 sc;
+        i32x3 id;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const int seq = ks[r] & kKeyMask;
-        const bool empty = ks[r] == kKeyInf;
-        sc[r] = empty ? kInf : __int_as_float(ks[r] & ~kKeyMask);
-        id[r] = empty ? -1 : (sub_t0 + (seq >> 4)) * kTileT + (seq & 3) + 8 * ((seq >> 2) & 3) + 4 * h;
+        for (int r = 0; r < 3; ++r) {
+            const int seq = ks[r] & kKeyMask;
+            sc[r] = ks[r] == kKeyInf ? kInf : __int_as_float(ks[r] & ~kKeyMask);
+            id[r] = ks[r] == kKeyInf ? -1 : (sub_t0 + (seq >> 4)) * kTileT + (seq & 3) + 8 * ((seq >> 2) & 3) + 4 * h;
+        }
+        *reinterpret_cast<f32x3*>(cs) = sc;
+        *reinterpret_cast<i32x3*>(ci) = id;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int seq = ks[r] & kKeyMask;
+            const bool empty = ks[r] == kKeyInf;
+            cs[r] = empty ? kInf : __int_as_float(ks[r] & ~kKeyMask);
+            ci[r] = empty ? -1 : (sub_t0 + (seq >> 4)) * kTileT + (seq & 3) + 8 * ((seq >> 2) & 3) + 4 * h;
+        }
     }
-    // one 12-byte store per array: a lane's record is private and the lanes of a wave are 336+ B apart, so every
-    // store instruction is 64 separate requests — three dword stores cost three times as much
-    asm volatile("global_store_dwordx3 %0, %1, off" ::"v"(cs), "v"(f32x3{sc[0], sc[1], sc[2]}) : "memory");
-    asm volatile("global_store_dwordx3 %0, %1, off" ::"v"(ci), "v"(i32x3{id[0], id[1], id[2]}) : "memory");
 }
 
 // ABL != 0 are dev-only timing ablations (results are WRONG): bit0 skip the top-3 epilogue, bit1 skip the
@@ -672,22 +684,62 @@ __device__ __forceinline__ void filter_split2_body(
 
         __syncthreads();                                           // previous segment fully consumed, nothing in flight
         constexpr int kPerSlot = KMID ? 1 : 2;                      // tiles per ring slot
-        stage(t_begin, 0);
-        if (t_begin + kPerSlot < t_end && !(ABL & 4)) stage(t_begin + kPerSlot, 1);
+        // Query fragments.  A lane needs 16 x 16 B of ITS query row (B operand: column j, k-chunk 2st+h), i.e. a
+        // wave-level load touches 32 rows x 32 B — 64 separate requests per instruction, and issuing the 16 of them
+        // took 4 us of a 6.6 us prologue.  Single-product body with 4-wave workgroups: load the wave's rows COALESCED
+        // (1 KiB = 4 whole rows per instruction) and transpose through the still-unused ring (8 KiB per wave, same
+        // XOR swizzle as the tile image), then stage the first tiles.
+        constexpr bool kCoalescedQ = !KMID && W == 4;
+        if (!kCoalescedQ) {
+            stage(t_begin, 0);
+            if (t_begin + kPerSlot < t_end && !(ABL & 4)) stage(t_begin + kPerSlot, 1);
+        }
 
         uint4 bh[2][8], bm[2][8];
         float qn[2];
+        if constexpr (kCoalescedQ) {
+            const unsigned short* img = qsplit + (2 * (int64_t)nq_pad + rb * (W * 64) + wave * 64) * kDim;   // fp16 image, this wave's 64 rows
+            const int lr = lane >> 4, lc = lane & 15;                // row within a 4-row load, 16-byte chunk
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const int qr = qok[g] ? qrow0 + 32 * g : 0;
-            const unsigned short* sh = qsplit + ((KMID ? 0 : 2 * (int64_t)nq_pad) + qr) * kDim + 8 * h;
-            const unsigned short* sm = qsplit + ((int64_t)nq_pad + qr) * kDim + 8 * h;
+            for (int g = 0; g < 2; ++g)
 #pragma unroll
-            for (int st = 0; st < 8; ++st) {
-                bh[g][st] = *reinterpret_cast<const uint4*>(sh + 16 * st);
-                if (KMID) bm[g][st] = *reinterpret_cast<const uint4*>(sm + 16 * st);
+                for (int n = 0; n < 8; ++n)
+                    bh[g][n] = *reinterpret_cast<const uint4*>(img + (int64_t)(32 * g + 4 * n + lr) * kDim + 8 * lc);
+            char* const scratch = reinterpret_cast<char*>(smem) + wave * 8192;    // (no LDS-DMA is in flight yet: plain accesses)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+#pragma unroll
+                for (int n = 0; n < 8; ++n) {
+                    const int r = 4 * n + lr;
+                    *reinterpret_cast<uint4*>(scratch + r * 256 + ((lc ^ (r & 15)) << 4)) = bh[g][n];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int st = 0; st < 8; ++st)
+                    bh[g][st] = *reinterpret_cast<const uint4*>(scratch + j * 256 + ((((2 * st + h) ^ (j & 15))) << 4));
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                qn[g] = qok[g] ? qnorm[qrow0 + 32 * g] : 0.f;
             }
-            qn[g] = qok[g] ? qnorm[qrow0 + 32 * g] : 0.f;
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();                           // every wave is done with its scratch: the ring is free
+            asm volatile("" ::: "memory");
+            stage(t_begin, 0);
+            if (t_begin + kPerSlot < t_end && !(ABL & 4)) stage(t_begin + kPerSlot, 1);
+        } else {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int qr = qok[g] ? qrow0 + 32 * g : 0;
+                const unsigned short* sh = qsplit + ((KMID ? 0 : 2 * (int64_t)nq_pad) + qr) * kDim + 8 * h;
+                const unsigned short* sm = qsplit + ((int64_t)nq_pad + qr) * kDim + 8 * h;
+#pragma unroll
+                for (int st = 0; st < 8; ++st) {
+                    bh[g][st] = *reinterpret_cast<const uint4*>(sh + 16 * st);
+                    if (KMID) bm[g][st] = *reinterpret_cast<const uint4*>(sm + 16 * st);
+                }
+                qn[g] = qok[g] ? qnorm[qrow0 + 32 * g] : 0.f;
+            }
         }
         const float b_aug[2] = {h ? qn[0] : 1.f, h ? qn[1] : 1.f};
         int vmask;
@@ -700,13 +752,11 @@ __device__ __forceinline__ void filter_split2_body(
             for (int g = 0; g < 2; ++g)
                 if (qok[g]) {
                     const int64_t ob = ((int64_t)(qrow0 + 32 * g) * (2 * smax * nsub) + (int64_t)slot * nsub * 2 + h) * 3 + 6 * sb;
-                    flush_keys(ka[g], kb[g], kc[g], st0, h, cand_s + ob, cand_i + ob);
+                    flush_keys<!KMID>(ka[g], kb[g], kc[g], st0, h, cand_s + ob, cand_i + ob);
                 }
             ka[0] = kb[0] = kc[0] = ka[1] = kb[1] = kc[1] = kKeyInf;
         };
-        if (trace && threadIdx.x == 0 && !trace[14336 + 4 * blockIdx.x + 1]) trace[14336 + 4 * blockIdx.x + 1] = wall_clock64();   // dev: loads issued
         wait_vmcnt<0>();                                           // first tile(s) + query fragments landed
-        if (trace && threadIdx.x == 0 && !trace[14336 + 4 * blockIdx.x + 2]) trace[14336 + 4 * blockIdx.x + 2] = wall_clock64();   // dev: landed
         asm volatile("" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -869,7 +919,6 @@ __global__ __launch_bounds__(64 * W, 2) void knn_filter_split2_kernel(
     }
     const int lane = threadIdx.x & 63;
     const bool need_mid = (force_mode >= 0 ? force_mode : knn_filter_mode(midflag, bmax, lane)) == kModeSplit;
-    if (trace && threadIdx.x == 0) trace[14336 + 4 * blockIdx.x + 0] = wall_clock64();   // dev: mode known
     if (need_mid)
         filter_split2_body<ABL, W, true>(smem, qsplit, qnorm, nq, nq_pad, tsplit, nt_pad, tn, tiles, units, smax, nsub, cand_s, cand_i, wg_begin, rb_first, trace);
     else
