@@ -610,6 +610,7 @@ __device__ __forceinline__ void key_insert4(const f32x16& a, int r0, int seq0 /*
 // LDS ring of the pipelined filter: 3 tile images (16 KiB each) + 3 x 64 floats of ||t||^2.
 constexpr int kRing = 3;
 constexpr int kRingLdsBytes = kRing * kTileFloats * 4 + kRing * 256;
+constexpr int kQScratchBytes = 4 * 4096;            // per-wave transposition slabs of the 4-wave filter's query-fragment prologue
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -687,13 +688,11 @@ __device__ __forceinline__ void filter_split2_body(
         // Query fragments.  A lane needs 16 x 16 B of ITS query row (B operand: column j, k-chunk 2st+h), i.e. a
         // wave-level load touches 32 rows x 32 B — 64 separate requests per instruction, and issuing the 16 of them
         // took 4 us of a 6.6 us prologue.  Single-product body with 4-wave workgroups: load the wave's rows COALESCED
-        // (1 KiB = 4 whole rows per instruction) and transpose through the still-unused ring (8 KiB per wave, same
-        // XOR swizzle as the tile image), then stage the first tiles.
+        // (1 KiB = 4 whole rows per instruction) and transpose through a 4 KiB per-wave LDS slab behind the ring (16 rows
+        // at a time, same XOR swizzle as the tile image) while the first tiles' DMA — issued first — is in flight.
         constexpr bool kCoalescedQ = !KMID && W == 4;
-        if (!kCoalescedQ) {
-            stage(t_begin, 0);
-            if (t_begin + kPerSlot < t_end && !(ABL & 4)) stage(t_begin + kPerSlot, 1);
-        }
+        stage(t_begin, 0);
+        if (t_begin + kPerSlot < t_end && !(ABL & 4)) stage(t_begin + kPerSlot, 1);
 
         uint4 bh[2][8], bm[2][8];
         float qn[2];
@@ -705,28 +704,31 @@ __device__ __forceinline__ void filter_split2_body(
 #pragma unroll
                 for (int n = 0; n < 8; ++n)
                     bh[g][n] = *reinterpret_cast<const uint4*>(img + (int64_t)(32 * g + 4 * n + lr) * kDim + 8 * lc);
-            char* const scratch = reinterpret_cast<char*>(smem) + wave * 8192;    // (no LDS-DMA is in flight yet: plain accesses)
+            // (plain LDS accesses: the wait they imply covers the tile DMA issued above, which has to land anyway)
+            char* const scratch = reinterpret_cast<char*>(smem) + kRingLdsBytes + wave * 4096;
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
+                uint4 got[8];
 #pragma unroll
-                for (int n = 0; n < 8; ++n) {
-                    const int r = 4 * n + lr;
-                    *reinterpret_cast<uint4*>(scratch + r * 256 + ((lc ^ (r & 15)) << 4)) = bh[g][n];
+                for (int s16 = 0; s16 < 2; ++s16) {                  // rows 16*s16 .. +16 of the group
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        const int r = 4 * n + lr;                    // row inside the slab
+                        *reinterpret_cast<uint4*>(scratch + r * 256 + ((lc ^ r) << 4)) = bh[g][4 * s16 + n];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if ((j >> 4) == s16)                             // the 32 lanes whose query row is in this slab
+#pragma unroll
+                        for (int st = 0; st < 8; ++st)
+                            got[st] = *reinterpret_cast<const uint4*>(scratch + (j & 15) * 256 + ((((2 * st + h) ^ (j & 15))) << 4));
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int st = 0; st < 8; ++st)
-                    bh[g][st] = *reinterpret_cast<const uint4*>(scratch + j * 256 + ((((2 * st + h) ^ (j & 15))) << 4));
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
+                for (int st = 0; st < 8; ++st) bh[g][st] = got[st];
                 qn[g] = qok[g] ? qnorm[qrow0 + 32 * g] : 0.f;
             }
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_s_barrier();                           // every wave is done with its scratch: the ring is free
-            asm volatile("" ::: "memory");
-            stage(t_begin, 0);
-            if (t_begin + kPerSlot < t_end && !(ABL & 4)) stage(t_begin + kPerSlot, 1);
         } else {
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
@@ -1625,7 +1627,7 @@ int knn2_impl(const float* q, int64_t nq, int64_t ldq, const float* t, int64_t n
         SFM_CHECK_LAUNCH();
         sfm::prof_begin(sfm::kProfKnnFilter, stream);
 #define SFM_LAUNCH_SPLIT2(A, WV)                                                                                        \
-    hipLaunchKernelGGL((knn_filter_split2_kernel<A, WV>), grid, dim3(64 * WV), kRingLdsBytes, stream, w.qsplit, w.qn,    \
+    hipLaunchKernelGGL((knn_filter_split2_kernel<A, WV>), grid, dim3(64 * WV), kRingLdsBytes + (WV == 4 ? kQScratchBytes : 0), stream, w.qsplit, w.qn,    \
                        (int)nq, p.nq_pad, w.tsplit, (int)nt, p.tiles * kTileT, w.tn, p.tiles, p.units, p.smax, p.nsub,    \
                        w.midflag, w.bmax, g_force_mode, w.cand_s, w.cand_i, w.wg_begin, w.rb_first, g_trace)
         if (p.waves == 4) {
