@@ -30,6 +30,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32,
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (no sparsity)
 PROF_EVERY = 8                     # steps between profiled launches in the timed region
 PIPE_DEPTH = 3                     # independent pairs in flight (one stream + workspace each)
+PROF_REPEAT = 3                    # filter launches per HIP-event pair on a profiled step (an event pair adds ~7 us to one)
 EXCH_BATCH = 8                     # pairs per RCCL all-gather at N > 1
 SPLIT_MFMA_PER_TILE, F32_MFMA_PER_TILE = 24, 65
 FLOP_PER_DISTANCE = 256           # GEMM form 2*D
@@ -185,19 +186,19 @@ def bench_knn(args, world, rank, dev):
     # neighbours' kernels it shares the chip with — so a few steps of the timed region are run ALONE (pipeline drained
     # before and after) with the events on; the roofline's launch duration is the average over those launches.
     # The drains are inside the timed region and cost `value` 2-3 percent.
-    # Pipelined: the first and the last step of the timed region (the pipeline is empty there anyway) and three
-    # evenly spaced ones in between (each costs a drain + refill).
+    # Pipelined: the first and the last step of the timed region (the pipeline is empty there anyway) and the middle
+    # one (which costs a drain + refill).
     if depth == 1:
         profiled = set(range(0, args.steps, PROF_EVERY))
     else:
-        profiled = {0, args.steps // 4, args.steps // 2, 3 * args.steps // 4, args.steps - 1}
+        profiled = {0, args.steps // 2, args.steps - 1}
     ops.profile_read(0), ops.profile_read(1)               # clear the slots
     t0 = time.perf_counter()
     for i in range(args.steps):
         if i in profiled:
             if depth > 1:
                 pipe.synchronize()
-            ops.profile_enable(True)
+            ops.profile_enable(PROF_REPEAT)
             step()
             ops.profile_enable(False)
             if depth > 1:
@@ -246,7 +247,9 @@ def bench_knn(args, world, rank, dev):
                      "algorithmic_flop_per_launch": algo_flop,
                      "issued_mfma_tflops": issued, "issued_frac_of_peak": issued / BF16_MFMA_PEAK_TFLOPS,
                      "launch_sampling": (f"HIP events on every {PROF_EVERY}th step of the timed region" if depth == 1 else
-                                         "HIP events on 5 evenly spaced steps of the timed region (first and last included), each run alone (pipeline drained)"),
+                                         "HIP events on the first, middle and last step of the timed region, each run alone (pipeline drained)")
+                                        + f"; on those steps the filter kernel is launched {PROF_REPEAT}x back-to-back inside the event pair "
+                                          "(idempotent) so that the event overhead (~7 us per pair) is amortised",
                      "note": "algorithmic = 256 FLOP per distance (SURVEY 8d); issued = MFMA flops of the arithmetic mode that ran"},
         "kernels_ms": {"knn_filter": filt_avg_ms, "knn_refine": ref_ms / max(ref_n, 1)},
         "knn_stats": {"rescanned_queries": stats[0], "filter_workgroups": stats[1], "streams_per_query": stats[2],

@@ -275,6 +275,9 @@ int sfm_host_epnp(const double* K_host, const double* Xw_host, const double* uv_
  * and launch count of one slot, and resets the slot (toggling the switch does not).
  *   slot 0 knn filter (MFMA)   1 knn refine (+ rescans)   2 triangulate
  *        3 dense BA sweep       4 indexed residual sweep    5 Schur products (W^T x, W v)
+ * sfm_profile_enable(n) with n > 1: as 1, and the knn filter kernel is launched n times back-to-back
+ * inside one event pair (idempotent), so the few microseconds an event pair adds to a single short
+ * launch are amortised; sfm_profile_read then reports n launches per bracket.
  * ---------------------------------------------------------------------- */
 int sfm_profile_enable(int on);
 /* Dev diagnostics: when non-NULL, every knn filter workgroup b writes int64[4] =

@@ -19,6 +19,8 @@ void set_error(const char* fmt, ...) {
 namespace {
 struct ProfState {
     bool on = false;
+    int repeat = 1;                      // launches per event pair for kernels that support it (sfm_profile_enable(n > 1))
+    size_t launches[kProfSlots] = {0};
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[kProfSlots];
     size_t used[kProfSlots] = {0};
     hipEvent_t pending[kProfSlots] = {nullptr};
@@ -39,19 +41,23 @@ void prof_begin(int slot, hipStream_t s) {
     (void)hipEventRecord(v[g_prof.used[slot]].first, s);
 }
 
-void prof_end(int slot, hipStream_t s) {
+void prof_end(int slot, hipStream_t s, int launches) {
     if (!g_prof.on) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     auto& v = g_prof.ev[slot];
     if (g_prof.used[slot] >= v.size()) return;
     (void)hipEventRecord(v[g_prof.used[slot]].second, s);
     ++g_prof.used[slot];
+    g_prof.launches[slot] += (size_t)launches;
 }
+
+int prof_repeat() { return g_prof.on ? g_prof.repeat : 1; }
 }  // namespace sfm
 
 extern "C" int sfm_profile_enable(int on) {
     std::lock_guard<std::mutex> lk(sfm::g_prof_mu);
     sfm::g_prof.on = on != 0;          // slots keep accumulating across on/off toggles; sfm_profile_read resets one
+    sfm::g_prof.repeat = on > 1 ? on : 1;
     return SFM_OK;
 }
 
@@ -68,8 +74,9 @@ extern "C" int sfm_profile_read(int slot, double* total_ms, int64_t* launches) {
         tot += ms;
     }
     *total_ms = tot;
-    *launches = (int64_t)n;
+    *launches = (int64_t)sfm::g_prof.launches[slot];
     sfm::g_prof.used[slot] = 0;
+    sfm::g_prof.launches[slot] = 0;
     return SFM_OK;
 }
 

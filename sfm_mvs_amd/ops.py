@@ -418,7 +418,8 @@ def set_knn_filter(mode):
 
 
 def profile_enable(on=True):
-    check(_lib.lib().sfm_profile_enable(1 if on else 0), "sfm_profile_enable")
+    """False / True, or an int n > 1: the knn filter kernel is launched n times inside each event pair."""
+    check(_lib.lib().sfm_profile_enable(int(on)), "sfm_profile_enable")
 
 
 def profile_read(slot):
