@@ -108,24 +108,34 @@ int g_seg_cost = [] { const char* e = getenv("SFM_KNN_SEGCOST"); return e ? atoi
 
 // One workgroup fills the partition tables the filter / refine kernels read: begin[G+1], and per query row block the
 // first and last block that touches it.
+constexpr int kPartLds = 1025;                                  // blocks whose table fits the LDS copy used for the searches
 __device__ inline void fill_partition_tables(const Partition pt, int n_rb, int64_t* __restrict__ begin, int* __restrict__ rb_first,
                                              int* __restrict__ rb_last) {
+    // the binary searches below are 9-10 DEPENDENT reads each: from global memory that was 6-7 us and made this one
+    // workgroup the critical path of the whole prep launch, so they run on an LDS copy of the table
+    __shared__ int64_t tab[kPartLds];
     const int G = pt.G, tiles = pt.tiles;
-    for (int b = threadIdx.x; b <= G; b += blockDim.x) begin[b] = b == G ? pt.units : part_begin(pt, b);
+    const bool in_lds = G + 1 <= kPartLds;
+    for (int b = threadIdx.x; b <= G; b += blockDim.x) {
+        const int64_t v = b == G ? pt.units : part_begin(pt, b);
+        begin[b] = v;
+        if (in_lds) tab[b] = v;
+    }
     __threadfence_block();
     __syncthreads();
+    const int64_t* look = in_lds ? tab : begin;
     for (int rb = threadIdx.x; rb < n_rb; rb += blockDim.x) {
         const int64_t u0 = (int64_t)rb * tiles, u1 = (int64_t)(rb + 1) * tiles - 1;
         int lo = 0, hi = G - 1;                                // smallest b with begin[b+1] > u0
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
-            if (begin[mid + 1] > u0) hi = mid; else lo = mid + 1;
+            if (look[mid + 1] > u0) hi = mid; else lo = mid + 1;
         }
         rb_first[rb] = lo;
         lo = 0, hi = G - 1;
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
-            if (begin[mid + 1] > u1) hi = mid; else lo = mid + 1;
+            if (look[mid + 1] > u1) hi = mid; else lo = mid + 1;
         }
         rb_last[rb] = lo;
     }
