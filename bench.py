@@ -43,9 +43,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="knn", choices=["knn", "tri", "ba", "sfm"])
+    ap.add_argument("--workload", default="knn", choices=["knn", "tri", "ba", "sfm", "c5"])
     ap.add_argument("--nq", type=int, default=10000)
     ap.add_argument("--nt", type=int, default=10000)
+    ap.add_argument("--images", type=int, default=32, help="workload c5: images in the sequence (BASELINE config 5 has 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--pipe-depth", type=int, default=PIPE_DEPTH, help="independent pairs in flight per GPU (1 = one stream)")
@@ -478,6 +479,58 @@ def bench_ba(args, world, rank, dev):
                          "fp64_valu_peak_TFLOPs": FP64_VALU_PEAK_TFLOPS}}
 
 
+def bench_c5(args, world, rank, dev):
+    """BASELINE configs[4] shape on this rank's share: a sequence of images with 50 000 SIFT-like descriptors each,
+    image k+1 containing 30 % planted matches of image k; sequential pairs (k, k+1) as in sfm.py:347, all descriptors
+    resident in HBM, pairs pipelined over streams.  Checks that the planted matches are what survives the ratio test."""
+    from sfm_mvs_amd import ops
+    n_img, n_desc = max(2, args.images), 50_000
+    g = torch.Generator(device=dev).manual_seed(100 + rank)
+
+    def sift_like(n):
+        d = torch.randn((n, 128), generator=g, device=dev).abs_().square_()
+        d /= d.norm(dim=1, keepdim=True)
+        d = torch.minimum(d, torch.tensor(0.2, device=dev))
+        d /= d.norm(dim=1, keepdim=True)
+        return (d * 512).round_().clamp_(0, 255)
+
+    imgs, planted = [sift_like(n_desc)], []
+    for k in range(1, n_img):
+        nxt = sift_like(n_desc)
+        src = torch.randperm(n_desc, generator=g, device=dev)[: int(0.3 * n_desc)]
+        dst = torch.randperm(n_desc, generator=g, device=dev)[: int(0.3 * n_desc)]
+        nxt[dst] = (imgs[-1][src] + torch.randn((len(src), 128), generator=g, device=dev).mul_(2).round_()).clamp_(0, 255)
+        imgs.append(nxt)
+        planted.append((2 * src, dst.to(torch.int32)))            # position of trainIdx[src][0] in the flat [nq][2] result
+    pipe = ops.PairPipeline(n_desc, n_desc, dev, ratio=0.70, depth=PIPE_DEPTH)
+    for k in range(min(3, n_img - 1)):                       # warm-up
+        pipe.submit(imgs[k], imgs[k + 1], after=False)
+    barrier_sync(world)
+    pairs = n_img - 1
+    counts = torch.zeros(pairs, dtype=torch.int32, device=dev)
+    nn1 = torch.empty((pairs, n_desc, 2), dtype=torch.int32, device=dev)     # every pair's trainIdx block, kept for the check
+    t0 = time.perf_counter()
+    for k in range(pairs):
+        slot, st, (idx, dist, oq, ot, cnt) = pipe.submit(imgs[k], imgs[k + 1], after=False)
+        with torch.cuda.stream(st):                          # consume the result on the pair's own stream, before the slot is
+            counts[k].copy_(cnt[0], non_blocking=True)       # reused (plain copies into preallocated buffers: no allocator traffic)
+            nn1[k].copy_(idx, non_blocking=True)
+    barrier_sync(world)
+    elapsed = max_over_ranks(time.perf_counter() - t0, world, dev)
+    hits = sum(int((nn1[k].reshape(-1).index_select(0, planted[k][0]) == planted[k][1]).sum().item()) for k in range(pairs))
+    frac_hit = hits / (pairs * int(0.3 * n_desc))
+    return {"metric": "descriptor-pair distances/sec over an image sequence (BF-KNN k=2 + Lowe ratio)",
+            "value": world * pairs * n_desc * n_desc / elapsed, "unit": "distances/s", "n_gpus": world, "steps": pairs, "warmup": 3,
+            "ms_per_step": elapsed / pairs * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 results; filter arithmetic fp16 single product (exact for integer descriptors)", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[4] shape: {n_img} images x 50k SIFT-like descriptors per GPU, sequential pairs, "
+                                   "30 % planted matches", "images": n_img, "descriptors": n_desc,
+                       "parallelism": f"pair-sharded x{world}; {PIPE_DEPTH} pairs in flight per GPU"},
+            "planted_matches_recovered_as_nearest_neighbour": frac_hit,
+            "ratio_survivors_per_pair_mean": float(counts.float().mean().item()),
+            "seconds_for_256_images_at_this_rate": 255 * n_desc * n_desc / (world * pairs * n_desc * n_desc / elapsed)}
+
+
 def bench_sfm(args, world, rank, dev):
     """BASELINE configs[2] on Gustav GEOMETRY (the images are not available): the incremental driver over the 57
     cameras of the reference's pose.csv, features rendered from the reference's own cloud."""
@@ -524,6 +577,8 @@ def main():
         out = bench_tri(args, world, rank, dev)
     elif args.workload == "sfm":
         out = bench_sfm(args, world, rank, dev)
+    elif args.workload == "c5":
+        out = bench_c5(args, world, rank, dev)
     else:
         out = bench_ba(args, world, rank, dev)
     if rank == 0:
