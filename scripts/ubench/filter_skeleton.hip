@@ -56,7 +56,7 @@ __global__ __launch_bounds__(512, 2) void k(const unsigned* __restrict__ T, int 
             for (int g = 0; g < 2; ++g)
                 cur[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, V >= 1 ? ah[s] : areg[s]),
                                                                __builtin_bit_cast(f16x8, bh[g][s]), cur[g], 0, 0, 0);
-            if (V >= 2) {
+            if (V == 2) {
 #pragma unroll
                 for (int g = 0; g < 2; ++g)
 #pragma unroll
@@ -69,6 +69,18 @@ __global__ __launch_bounds__(512, 2) void k(const unsigned* __restrict__ T, int 
                         k1[g] = m1;
                         k0[g] = lo;
                     }
+            } else if (V == 3) {       // pair-min: one insertion per two adjacent scores (candidates would be row pairs)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const int m = min(__float_as_int(prev[g][2 * s]), __float_as_int(prev[g][2 * s + 1]));
+                    int key;
+                    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(key) : "v"(m), "v"(vmask), "s"(seq0 + s));
+                    const int lo = min(key, k0[g]);
+                    const int m1 = max(min(key, k1[g]), min(max(key, k1[g]), k0[g]));
+                    k2[g] = max(min(key, k1[g]), min(max(key, k1[g]), k2[g]));
+                    k1[g] = m1;
+                    k0[g] = lo;
+                }
             } else {
                 k0[0] = min(k0[0], __float_as_int(prev[0][2 * s]) + __float_as_int(prev[0][2 * s + 1]));
                 k0[1] = min(k0[1], __float_as_int(prev[1][2 * s]) + __float_as_int(prev[1][2 * s + 1]));
@@ -106,6 +118,7 @@ int main() {
         run<0, false>(T, out, tiles); run<0, true>(T, out, tiles);
         run<1, false>(T, out, tiles); run<1, true>(T, out, tiles);
         run<2, false>(T, out, tiles); run<2, true>(T, out, tiles);
+        run<3, true>(T, out, tiles);
     }
     return 0;
 }
