@@ -43,7 +43,7 @@ constexpr int kTileT = 32;             // train rows per LDS tile (= MFMA M)
 constexpr int kResidentWaves = 4096;   // 256 CUs x 16 waves (4 per SIMD at <= 128 VGPRs)
 constexpr int kMaxSlots = 258;         // cap on filter blocks that may touch one query row block (all 256 CUs on one)
 constexpr float kInf = __builtin_huge_valf();
-constexpr int kSubTilesHost = 32;      // = kSubTiles (tiles per substream), needed by make_plan before its definition
+constexpr int kSubTilesHost = 64;      // = kSubTiles (tiles per substream), needed by make_plan before its definition
 
 // Work decomposition ("stream-K" over the flattened (query row block, train tile) unit space):
 // block b owns units [units*b/G, units*(b+1)/G).  Every block gets the same number of units (+-1),
@@ -284,9 +284,10 @@ __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t trs, int row_b
     }
 }
 
-constexpr int kKeyBits = 9;                       // 5 bits tile-in-substream + 4 bits accumulator register
+constexpr int kKeyBits = 9;                       // 6 bits tile-in-substream + 3 bits accumulator-register PAIR
 constexpr int kKeyMask = (1 << kKeyBits) - 1;
-constexpr int kSubTiles = 1 << (kKeyBits - 4);    // 32 tiles per substream
+constexpr int kSubTiles = 1 << (kKeyBits - 3);    // 64 tiles per substream
+static_assert(kSubTiles == kSubTilesHost, "make_plan's copy");
 constexpr int kKeyInf = 0x7F800000;               // +inf: larger than every finite non-negative score key
 
 // decode 3 packed keys into (truncated score, train index) records
@@ -305,7 +306,7 @@ __device__ __forceinline__ void flush_keys(int k0, int k1, int k2, int sub_t0, i
         for (int r = 0; r < 3; ++r) {
             const int seq = ks[r] & kKeyMask;
             sc[r] = ks[r] == kKeyInf ? kInf : __int_as_float(ks[r] & ~kKeyMask);
-            id[r] = ks[r] == kKeyInf ? -1 : (sub_t0 + (seq >> 4)) * kTileT + (seq & 3) + 8 * ((seq >> 2) & 3) + 4 * h;
+            id[r] = ks[r] == kKeyInf ? -1 : (sub_t0 + (seq >> 3)) * kTileT + 2 * (seq & 1) + 8 * ((seq >> 1) & 3) + 4 * h;
         }
         *reinterpret_cast<f32x3*>(cs) = sc;
         *reinterpret_cast<i32x3*>(ci) = id;
@@ -315,7 +316,7 @@ __device__ __forceinline__ void flush_keys(int k0, int k1, int k2, int sub_t0, i
             const int seq = ks[r] & kKeyMask;
             const bool empty = ks[r] == kKeyInf;
             cs[r] = empty ? kInf : __int_as_float(ks[r] & ~kKeyMask);
-            ci[r] = empty ? -1 : (sub_t0 + (seq >> 4)) * kTileT + (seq & 3) + 8 * ((seq >> 2) & 3) + 4 * h;
+            ci[r] = empty ? -1 : (sub_t0 + (seq >> 3)) * kTileT + 2 * (seq & 1) + 8 * ((seq >> 1) & 3) + 4 * h;
         }
     }
 }
@@ -382,10 +383,11 @@ __global__ __launch_bounds__(64 * W, 4) void knn_filter_kernel(
         const float aug_a = h == 0 ? 1.f : 0.f;
         const float aug_b = h == 0 ? qn : 0.f;
 
-        // Running top-3 as PACKED KEYS: (score bits & ~511) | (tile_in_substream << 4 | r).  Scores are
-        // non-negative up to rounding noise, so signed-integer order == float order and one insertion is
-        // v_and_or + v_min_i32 + 2 v_med3_i32 (4 VALU) instead of 13 compare/select ops; the 9 dropped
-        // mantissa bits (2^-14 relative) are covered by the refine kernel's slack.  A substream is 32 tiles.
+        // Running top-3 as PACKED KEYS, one per PAIR of adjacent trains: (min(score_r, score_r+1) bits & ~511) |
+        // (tile_in_substream << 3 | r/2).  Scores are non-negative up to rounding noise, so signed-integer order ==
+        // float order and one insertion is v_min_f32 + v_and_or + v_min_i32 + 2 v_med3_i32 (5 VALU per two scores)
+        // instead of 13 compare/select ops per score; the 9 dropped mantissa bits (2^-14 relative) are covered by the
+        // refine kernel's slack.  A substream is 64 tiles.
         int k0 = kKeyInf, k1 = kKeyInf, k2 = kKeyInf;
         int sub = 0, sub_t0 = t_begin;
         const int64_t obase = ((int64_t)qrow * (2 * smax * nsub) + (int64_t)slot * nsub * 2 + h) * 3;
@@ -444,13 +446,13 @@ __global__ __launch_bounds__(64 * W, 4) void knn_filter_kernel(
             }
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aug_a, aug_b, acc, 0, 0, 0);
             if (ABL & 16) __builtin_amdgcn_s_setprio(0);
-            const int seq0 = (t - sub_t0) << 4;
+            const int seq0 = (t - sub_t0) << 3;
             if (ABL & 1) {
                 k0 = min(k0, __float_as_int(acc[0]) + __float_as_int(acc[15]));
             } else
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = (__float_as_int(acc[r]) & ~kKeyMask) | (seq0 + r);
+            for (int r = 0; r < 16; r += 2) {                              // one key per PAIR of adjacent trains (see key_insert4)
+                const int key = (__float_as_int(fminf(acc[r], acc[r + 1])) & ~kKeyMask) | (seq0 + (r >> 1));
                 const int lo = min(key, k0), hi = max(key, k0);            // (lo, hi) = sorted (key, k0)
                 const int m1 = max(min(key, k1), min(max(key, k1), k0));   // med3(key, k0, k1)
                 k2 = max(min(key, k1), min(max(key, k1), k2));             // med3(key, k1, k2)
@@ -602,13 +604,17 @@ __global__ __launch_bounds__(1024) void knn_prep_kernel(const float* __restrict_
 //     tile t-1 (its accumulators are kept) is interleaved between the MFMAs on the vector pipe.
 // The pack is ONE v_and_or_b32 only if the mask sits in a VGPR and the sequence number in an SGPR (gfx9 VOP3 takes a
 // single scalar operand and no literal; left alone hipcc keeps both scalar and emits v_and + v_or).
+// One key per PAIR of adjacent trains (accumulator registers r, r+1 = rows 2m, 2m+1): min first, then one insertion —
+// 5 VALU per two scores instead of 8 (the packed-key epilogue was 31 % of a 50k x 50k launch).  A candidate record is
+// therefore a row pair; the refine kernel evaluates both rows exactly, and a discarded pair has BOTH scores >= the
+// stream's 3rd-best pair minimum, so the certificate is unchanged.
 template <int W>
 __device__ __forceinline__ void key_insert4(const f32x16& a, int r0, int seq0 /*wave-uniform*/, int vmask /*VGPR holding ~kKeyMask*/,
                                             int& k0, int& k1, int& k2) {
 #pragma unroll
-    for (int r = r0; r < r0 + W; ++r) {
+    for (int r = r0; r < r0 + W; r += 2) {
         int key;
-        asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(key) : "v"(a[r]), "v"(vmask), "s"(seq0 + r));
+        asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(key) : "v"(fminf(a[r], a[r + 1])), "v"(vmask), "s"(seq0 + (r >> 1)));
         const int lo = min(key, k0);
         const int m1 = max(min(key, k1), min(max(key, k1), k0));
         k2 = max(min(key, k1), min(max(key, k1), k2));
@@ -814,7 +820,7 @@ __device__ __forceinline__ void filter_split2_body(
 #pragma unroll
                 for (int g = 0; g < 2; ++g) cur[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_aug, b_aug[g], zero, 0, 0, 0);
             }
-            const int seq0 = __builtin_amdgcn_readfirstlane(((t - 1) - sub_t0) << 4);
+            const int seq0 = __builtin_amdgcn_readfirstlane(((t - 1) - sub_t0) << 3);
 #pragma unroll
             for (int st = 0; st < 8; ++st) {
                 if constexpr (KMID) {
@@ -888,11 +894,11 @@ __device__ __forceinline__ void filter_split2_body(
                 sub_t0 = tl;
             }
             if ((t_end - t_begin) & 1) {
-                key_insert4<16>(accA[0], 0, __builtin_amdgcn_readfirstlane((tl - sub_t0) << 4), vmask, ka[0], kb[0], kc[0]);
-                key_insert4<16>(accA[1], 0, __builtin_amdgcn_readfirstlane((tl - sub_t0) << 4), vmask, ka[1], kb[1], kc[1]);
+                key_insert4<16>(accA[0], 0, __builtin_amdgcn_readfirstlane((tl - sub_t0) << 3), vmask, ka[0], kb[0], kc[0]);
+                key_insert4<16>(accA[1], 0, __builtin_amdgcn_readfirstlane((tl - sub_t0) << 3), vmask, ka[1], kb[1], kc[1]);
             } else {
-                key_insert4<16>(accB[0], 0, __builtin_amdgcn_readfirstlane((tl - sub_t0) << 4), vmask, ka[0], kb[0], kc[0]);
-                key_insert4<16>(accB[1], 0, __builtin_amdgcn_readfirstlane((tl - sub_t0) << 4), vmask, ka[1], kb[1], kc[1]);
+                key_insert4<16>(accB[0], 0, __builtin_amdgcn_readfirstlane((tl - sub_t0) << 3), vmask, ka[0], kb[0], kc[0]);
+                key_insert4<16>(accB[1], 0, __builtin_amdgcn_readfirstlane((tl - sub_t0) << 3), vmask, ka[1], kb[1], kc[1]);
             }
         }
         flush(sub, sub_t0);
@@ -1108,7 +1114,7 @@ constexpr int kS1 = 6;           // candidate records per lane fetched up front 
 constexpr int kRescanRows = 1;   // trains a quad has in flight during a rescan (32 VGPRs each)
 constexpr int kRefItems = 512;   // rescan work list (query, stream); more → 16 candidate slots per query at a time (<= 96)
 constexpr int kPreRows = 2;      // trains a quad has in flight during the rescan's fp16 prefilter (16 VGPRs each)
-constexpr int kQualCap = 48;     // exact-evaluation list per query
+constexpr int kQualCap = 80;     // exact-evaluation list per query (a chunk of 16 records adds up to 32 rows)
 
 // Sixteen lanes per query, sixteen queries per workgroup (one resident round for 10^4 queries).
 //   sweep 1  two smallest filter scores over the query's candidate records and each stream's 3rd best
@@ -1247,7 +1253,7 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
     const bool use_half = thalf && (mode == kModeHalf || mode == kModeHalfExact);
     for (int k0 = 0; k0 * 16 < NC;) {                     // (wave-uniform)
         for (; k0 * 16 < NC; ++k0) {
-            if (__any(cnt > kQualCap - 16)) break;        // the list might not take another chunk: evaluate first
+            if (__any(cnt > kQualCap - 32)) break;        // the list might not take another chunk: evaluate first
             const int c = sl + 16 * k0;
             const float s = (valid && c < NC) ? cs[c] : kInf;
             const int id = (valid && c < NC) ? ci[c] : -1;                // (empty records: s = +inf, id = -1)
@@ -1255,8 +1261,12 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
             const unsigned long long mask = __ballot(take);
             if (mask == 0) continue;                      // wave-uniform
             const unsigned mine = (unsigned)(mask >> (16 * sub)) & 0xFFFFu;
-            if (take) qual[ql][cnt + __popc(mine & ((1u << sl) - 1u))] = id;
-            cnt += __popc(mine);
+            if (take) {                                   // a record names a row PAIR (id, id + 1): both are evaluated
+                const int at = cnt + 2 * __popc(mine & ((1u << sl) - 1u));
+                qual[ql][at] = id;
+                qual[ql][at + 1] = id + 1 < nt ? id + 1 : id;
+            }
+            cnt += 2 * __popc(mine);
         }
         evaluate();                                       // the hot site
     }
