@@ -269,6 +269,40 @@ int sfm_host_epnp(const double* K_host, const double* Xw_host, const double* uv_
                   double* R_host, double* t_host);
 
 /* ------------------------------------------------------------------------
+ * Next row f-1: image preprocessing + SIFT
+ *   cv2.pyrDown(img)                                  sfm.py:40
+ *   cv2.cvtColor(img, cv2.COLOR_BGR2GRAY)             sfm.py:243-244
+ *   cv2.xfeatures2d.SIFT_create().detectAndCompute(gray, None)   sfm.py:246-252
+ *
+ * sfm_bgr2gray_u8 / sfm_pyrdown_u8: OpenCV's uint8 fixed-point programs
+ * ((1868 B + 9617 G + 4899 R + 8192) >> 14; 5x5 binomial, (sum + 128) >> 8,
+ * BORDER_REFLECT_101, output ((w+1)/2, (h+1)/2)).  All pointers are device memory.
+ *
+ * sfm_sift_detect_and_compute: the whole of detectAndCompute (nfeatures = 0), stream
+ * ordered, no host round trip: 2x bilinear base image, Gaussian / DoG pyramid,
+ * 26-neighbour extrema with sub-pixel refinement, contrast and edge tests,
+ * orientation histograms (one keypoint per peak >= 0.8 max), OpenCV's keypoint
+ * ordering + duplicate removal, 4x4x8 descriptors (clip 0.2, x512, u8-valued float32).
+ *   gray_dev        [h x stride] uint8
+ *   keypoints_dev   [max_keypoints x 8] float32: x, y, size, angle (degrees), response,
+ *                   octave (int32 bits, OpenCV packing), class_id (int32 bits, -1), 0
+ *   descriptors_dev [max_keypoints x 128] float32 (NULL: detect only)
+ *   count_dev       int32[4]: [0] keypoints written (ordered), [1] keypoints before
+ *                   duplicate removal, [2] refined extrema; [1] or [2] > max_keypoints
+ *                   means the capacity was exceeded and the output is truncated
+ * Filter kernels longer than 31 taps (sigma * 2^(1+2/n_octave_layers) > ~3.7) are
+ * rejected with SFM_ERR_ARG; the defaults (3, 0.04, 10, 1.6) need 27.
+ * ---------------------------------------------------------------------- */
+int sfm_bgr2gray_u8(const uint8_t* bgr_dev, int64_t w, int64_t h, int64_t stride_bytes, uint8_t* gray_dev, void* stream);
+int sfm_pyrdown_u8(const uint8_t* src_dev, int64_t w, int64_t h, int channels, uint8_t* dst_dev, void* stream);
+size_t sfm_sift_ws_bytes(int64_t w, int64_t h, int n_octave_layers, int64_t max_keypoints);
+int sfm_sift_detect_and_compute(const uint8_t* gray_dev, int64_t w, int64_t h, int64_t stride_bytes,
+                                int n_octave_layers, double contrast_threshold, double edge_threshold,
+                                double sigma, int64_t max_keypoints, float* keypoints_dev,
+                                float* descriptors_dev, int32_t* count_dev, void* ws, size_t ws_bytes,
+                                void* stream);
+
+/* ------------------------------------------------------------------------
  * Measurement hook (no reference counterpart): when enabled, the library brackets
  * its dominant kernels with hipEvents recorded on the launch stream.
  * sfm_profile_read synchronises those events, returns the summed device time

@@ -30,6 +30,7 @@ def lib():
         _lib.orc_common_points.restype = C.c_int64
         _lib.orc_to_ply_filter.restype = C.c_int64
         _lib.orc_reprojection_error.restype = C.c_double
+        _lib.orc_sift_detect_and_compute.restype = C.c_int64
     return _lib
 
 
@@ -198,3 +199,40 @@ def recover_pose_score(Ps, x1n, x2n, dist=50.0, rows=4):
     lib().orc_recover_pose_score(_p(Ps), C.c_int(h), _p(x1n), _p(x2n), C.c_int64(n), C.c_double(dist), C.c_int(rows),
                                  _p(counts), _p(mask))
     return counts, mask
+
+
+def bgr2gray(bgr):
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    h, w, _ = bgr.shape
+    out = np.empty((h, w), np.uint8)
+    lib().orc_bgr2gray_u8(_p(bgr), C.c_int64(w), C.c_int64(h), C.c_int64(3 * w), _p(out))
+    return out
+
+
+def pyrdown(img):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape[:2]
+    ch = 1 if img.ndim == 2 else img.shape[2]
+    out = np.empty(((h + 1) // 2, (w + 1) // 2) + img.shape[2:], np.uint8)
+    lib().orc_pyrdown_u8(_p(img), C.c_int64(w), C.c_int64(h), C.c_int(ch), _p(out))
+    return out
+
+
+def sift_gauss_kernel(sigma):
+    k = np.zeros(128, np.float32)
+    n = lib().orc_sift_gauss_kernel(C.c_double(sigma), _p(k))
+    return k[:n].copy()
+
+
+def sift(gray, n_octave_layers=3, contrast=0.04, edge=10.0, sigma=1.6, cap=200000, want_pyramid=False):
+    """detectAndCompute: (kp (n,8) f32 {x,y,size,angle,response,octave bits,class_id bits,0}, desc (n,128) f32[, pyr])."""
+    gray = np.ascontiguousarray(gray, np.uint8)
+    h, w = gray.shape
+    kp = np.zeros((cap, 8), np.float32)
+    desc = np.zeros((cap, 128), np.float32)
+    pyr = np.zeros((n_octave_layers + 3, 2 * h, 2 * w), np.float32) if want_pyramid else None
+    n = lib().orc_sift_detect_and_compute(_p(gray), C.c_int64(w), C.c_int64(h), C.c_int64(w), C.c_int(n_octave_layers),
+                                          C.c_double(contrast), C.c_double(edge), C.c_double(sigma), C.c_int64(cap),
+                                          _p(kp), _p(desc), _p(pyr))
+    n = min(int(n), cap)
+    return (kp[:n].copy(), desc[:n].copy(), pyr) if want_pyramid else (kp[:n].copy(), desc[:n].copy())

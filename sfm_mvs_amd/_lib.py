@@ -47,6 +47,10 @@ SIGNATURES = {
     "sfm_ba_schur_indexed_ws_bytes": (_sz, [_i64]),
     "sfm_ba_schur_indexed": (_int, [_vp, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _int, _vp, _vp, _vp, _sz, _vp]),
     "sfm_host_epnp": (_int, [_vp, _vp, _vp, _int, _vp, _vp]),
+    "sfm_bgr2gray_u8": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
+    "sfm_pyrdown_u8": (_int, [_vp, _i64, _i64, _int, _vp, _vp]),
+    "sfm_sift_ws_bytes": (_sz, [_i64, _i64, _int, _i64]),
+    "sfm_sift_detect_and_compute": (_int, [_vp, _i64, _i64, _i64, _int, _f64, _f64, _f64, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sfm_score_essential": (_int, [_vp, _int, _vp, _vp, _i64, _f32, _vp, _vp, _vp]),
     "sfm_recover_pose_score": (_int, [_vp, _int, _vp, _vp, _i64, _f64, _int, _vp, _vp, _vp]),
     "sfm_score_pnp": (_int, [_vp, _int, _vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp]),

@@ -1,0 +1,724 @@
+// SIFT detectAndCompute and the two preprocessing calls in front of it, for gfx950.
+//
+// Replaces  cv2.pyrDown (sfm.py:40), cv2.cvtColor(BGR2GRAY) (sfm.py:243-244) and
+// cv2.xfeatures2d.SIFT_create().detectAndCompute(gray, None) (sfm.py:246-252).
+//
+// Everything is stream-ordered device work; nothing is copied to the host:
+//   upsample 2x (u8 -> f32, bilinear) -> per octave { fused separable Gaussian (LDS tile, rows then columns) that also
+//   emits the DoG plane; nearest 2x decimation } -> per octave extrema + sub-pixel refinement (one lane per pixel,
+//   refined candidates appended) -> orientation histograms (one wave per candidate) -> counting-rank sort in OpenCV's
+//   keypoint order + duplicate removal (ordered compaction) -> descriptors (one wave per keypoint).
+//
+// Arithmetic contract: float32 operations in the order of the sequential algorithm (oracle/sift_oracle.c restates
+// it), no contraction (-ffp-contract=off), IEEE divide/sqrt, and fixed polynomial programs for exp / sincos / atan2,
+// so keypoints and descriptors are reproducible bit for bit.  Histogram sums, which are order-sensitive, are
+// accumulated by an owner lane per bin that walks the samples in raster order.
+//
+// Memory: one workspace holds the whole scale space: for a W x H input the doubled base is 2W x 2H floats and the
+// pyramid (6 Gaussian + 5 DoG planes per octave at the defaults) takes 11 * 4/3 * 16 WH bytes (147 MB for the
+// reference's 968 x 648 frames) — resident in HBM from the first blur to the last descriptor.
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include "common.h"
+
+namespace {
+
+constexpr int kImgBorder = 5, kMaxInterpSteps = 5, kOriBins = 36, kDescWidth = 4, kDescBins = 8;
+constexpr float kOriSigFctr = 1.5f, kOriRadius = 4.5f, kOriPeakRatio = 0.8f, kDescSclFctr = 3.f, kDescMagThr = 0.2f, kIntDescrFctr = 512.f;
+constexpr int kMaxTaps = 31, kMaxR = kMaxTaps / 2;
+constexpr int kTileW = 64, kTileH = 32;
+constexpr int kMaxOctaves = 16;
+
+struct Taps { float k[kMaxTaps + 1]; int n; };
+
+// Scale-space geometry (octave o of a doubled base W0 x H0): planes are W0>>o by H0>>o; Gaussian planes of all
+// octaves are packed back to back, (nL+3) per octave, DoG planes (nL+2) per octave in a second region.
+struct Geom {
+    float* g; float* d; int W0, H0, nL, nOct;
+    __device__ __host__ int w(int o) const { return W0 >> o; }
+    __device__ __host__ int h(int o) const { return H0 >> o; }
+    __device__ __host__ size_t plane(int o) const { return (size_t)w(o) * h(o); }
+    __device__ __host__ size_t goff(int o) const { size_t s = 0; for (int p = 0; p < o; ++p) s += plane(p) * (nL + 3); return s; }
+    __device__ __host__ size_t doff(int o) const { size_t s = 0; for (int p = 0; p < o; ++p) s += plane(p) * (nL + 2); return s; }
+    __device__ __host__ float* G(int o, int i) const { return g + goff(o) + plane(o) * i; }
+    __device__ __host__ float* D(int o, int i) const { return d + doff(o) + plane(o) * i; }
+};
+
+__device__ inline int reflect101(int p, int len) {
+    if (len == 1) return 0;
+    while ((unsigned)p >= (unsigned)len) p = p < 0 ? -p : 2 * len - p - 2;
+    return p;
+}
+__device__ inline int cv_round(float v) { return __float2int_rn(v); }
+__device__ inline int cv_floor(float v) { return (int)floorf(v); }
+
+__device__ inline float sift_expf(float x) {   // Cephes expf, fixed operation order (see the oracle)
+    if (x < -80.f) x = -80.f;
+    if (x > 80.f) x = 80.f;
+    const float n = rintf(x * 1.44269504f);
+    float r = x - n * 0.693359375f;
+    r = r - n * -2.12194440e-4f;
+    float p = 1.9875691500e-4f;
+    p = p * r + 1.3981999507e-3f;
+    p = p * r + 8.3334519073e-3f;
+    p = p * r + 4.1665795894e-2f;
+    p = p * r + 1.6666665459e-1f;
+    p = p * r + 5.0000001201e-1f;
+    const float y = p * (r * r) + r + 1.0f;
+    return y * __uint_as_float((unsigned)((int)n + 127) << 23);
+}
+
+__device__ inline void sift_sincos(float xf, float* s, float* c) {
+    const double x = (double)xf;
+    const double kq = rint(x * 0.63661977236758134308);
+    const double r = (x - kq * 1.57079632679489655800) - kq * 6.123233995736766e-17;
+    const double r2 = r * r;
+    double sp = -7.6471637318198164759e-13;
+    sp = sp * r2 + 1.6059043836821614599e-10;
+    sp = sp * r2 - 2.5052108385441718775e-8;
+    sp = sp * r2 + 2.7557319223985890653e-6;
+    sp = sp * r2 - 1.9841269841269841270e-4;
+    sp = sp * r2 + 8.3333333333333333333e-3;
+    sp = sp * r2 - 1.6666666666666666667e-1;
+    const double sn = r + r * r2 * sp;
+    double cp = 4.7794773323873852974e-14;
+    cp = cp * r2 - 1.1470745597729724714e-11;
+    cp = cp * r2 + 2.0876756987868098979e-9;
+    cp = cp * r2 - 2.7557319223985890653e-7;
+    cp = cp * r2 + 2.4801587301587301587e-5;
+    cp = cp * r2 - 1.3888888888888888889e-3;
+    cp = cp * r2 + 4.1666666666666666667e-2;
+    const double cs = 1.0 - 0.5 * r2 + r2 * r2 * cp;
+    const int q = (int)((long long)kq & 3);
+    *s = (float)(q == 0 ? sn : q == 1 ? cs : q == 2 ? -sn : -cs);
+    *c = (float)(q == 0 ? cs : q == 1 ? -sn : q == 2 ? -cs : sn);
+}
+
+__device__ inline float fast_atan2_deg(float y, float x) {
+    const float p1 = 0.9997878412794807f * 57.29577951308232f, p3 = -0.3258083974640975f * 57.29577951308232f,
+                p5 = 0.1555786518463281f * 57.29577951308232f, p7 = -0.04432655554792128f * 57.29577951308232f;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) { c = ay / (ax + (float)DBL_EPSILON); c2 = c * c; a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
+    else          { c = ax / (ay + (float)DBL_EPSILON); c2 = c * c; a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+// ------------------------------------------------------------------------------------------------ preprocessing
+
+__global__ __launch_bounds__(256) void bgr2gray_kernel(const unsigned char* __restrict__ bgr, int w, int h, long stride, unsigned char* __restrict__ gray) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const unsigned char* p = bgr + (size_t)y * stride + 3 * x;
+    gray[(size_t)y * w + x] = (unsigned char)((p[0] * 1868 + p[1] * 9617 + p[2] * 4899 + (1 << 13)) >> 14);
+}
+
+__global__ __launch_bounds__(256) void pyrdown_kernel(const unsigned char* __restrict__ src, int w, int h, int ch, unsigned char* __restrict__ dst) {
+    const int dw = (w + 1) / 2, dh = (h + 1) / 2;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= dw || y >= dh) return;
+    for (int c = 0; c < ch; ++c) {
+        int s = 0;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int sy = reflect101(2 * y + i - 2, h);
+            int r = 0;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int kj = j == 0 || j == 4 ? 1 : j == 2 ? 6 : 4;
+                r += kj * src[((size_t)sy * w + reflect101(2 * x + j - 2, w)) * ch + c];
+            }
+            s += (i == 0 || i == 4 ? 1 : i == 2 ? 6 : 4) * r;
+        }
+        dst[((size_t)y * dw + x) * ch + c] = (unsigned char)((s + 128) >> 8);
+    }
+}
+
+// resize(float(gray), 2x, INTER_LINEAR): horizontal taps first, then vertical, indices clamped at the border
+__global__ __launch_bounds__(256) void upsample2_kernel(const unsigned char* __restrict__ gray, int w, int h, long stride, float* __restrict__ out) {
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= 2 * w || dy >= 2 * h) return;
+    float fx = (float)((dx + 0.5) * 0.5 - 0.5);
+    int sx = cv_floor(fx); fx -= sx;
+    if (sx < 0) { sx = 0; fx = 0; }
+    if (sx >= w - 1) { sx = w - 1; fx = 0; }
+    const int sx1 = sx + 1 < w ? sx + 1 : w - 1;
+    float fy = (float)((dy + 0.5) * 0.5 - 0.5);
+    int sy = cv_floor(fy); fy -= sy;
+    if (sy < 0) { sy = 0; fy = 0; }
+    if (sy >= h - 1) { sy = h - 1; fy = 0; }
+    const int sy1 = sy + 1 < h ? sy + 1 : h - 1;
+    const unsigned char *r0 = gray + (size_t)sy * stride, *r1 = gray + (size_t)sy1 * stride;
+    const float a = (float)r0[sx] * (1.f - fx) + (float)r0[sx1] * fx;
+    const float b = (float)r1[sx] * (1.f - fx) + (float)r1[sx1] * fx;
+    out[(size_t)dy * 2 * w + dx] = a * (1.f - fy) + b * fy;
+}
+
+__global__ __launch_bounds__(256) void decimate2_kernel(const float* __restrict__ src, int sw, float* __restrict__ dst, int dw, int dh) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x < dw && y < dh) dst[(size_t)y * dw + x] = src[(size_t)(2 * y) * sw + 2 * x];
+}
+
+// ------------------------------------------------------------------------------------------------ Gaussian + DoG
+// One 64 x 32 output tile per workgroup.  The (32+2R) x (64+2R) input window (BORDER_REFLECT_101) goes to LDS once,
+// the row pass writes (32+2R) x 64 partial results back to LDS, the column pass reads them: each input pixel is
+// fetched from HBM/L2 about (1+2R/64)(1+2R/32) times instead of 2(2R+1) times.  `dog` (optional) = dst - src.
+__global__ __launch_bounds__(256) void gauss_blur_kernel(const float* __restrict__ src, float* __restrict__ dst, float* __restrict__ dog,
+                                                         int w, int h, Taps taps) {
+    __shared__ float tin[(kTileH + 2 * kMaxR) * (kTileW + 2 * kMaxR)];
+    __shared__ float th[(kTileH + 2 * kMaxR) * kTileW];
+    __shared__ float tk[kMaxTaps + 1];
+    const int n = taps.n, R = n >> 1;
+    const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
+    const int pitch = kTileW + 2 * R, rows = kTileH + 2 * R;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < kMaxTaps; ++i) tk[i] = taps.k[i];
+    }
+    for (int e = threadIdx.x; e < rows * pitch; e += 256) {
+        const int ry = e / pitch, rx = e - ry * pitch;
+        tin[e] = src[(size_t)reflect101(y0 - R + ry, h) * w + reflect101(x0 - R + rx, w)];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < rows * kTileW; e += 256) {
+        const int ry = e >> 6, cx = e & 63;
+        const float* p = tin + ry * pitch + cx;
+        float s = p[0] * tk[0];
+        for (int j = 1; j < n; ++j) s += p[j] * tk[j];
+        th[e] = s;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < kTileH * kTileW; e += 256) {
+        const int ty = e >> 6, tx = e & 63;
+        const int x = x0 + tx, y = y0 + ty;
+        if (x >= w || y >= h) continue;
+        const float* p = th + (ty + R) * kTileW + tx;
+        float s = tk[R] * p[0];
+        for (int j = 1; j <= R; ++j) s += tk[R + j] * (p[j * kTileW] + p[-j * kTileW]);
+        dst[(size_t)y * w + x] = s;
+        if (dog) dog[(size_t)y * w + x] = s - tin[(ty + R) * pitch + tx + R];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ extrema
+struct Cand { int o, layer, r, c; float x, y, size, response; int octave; };
+
+__device__ inline void solve3(const float (&a)[3][3], const float (&b)[3], float (&x)[3]) {   // Matx33f::solve: Cramer
+    float d = a[0][0] * (a[1][1] * a[2][2] - a[2][1] * a[1][2]) - a[0][1] * (a[1][0] * a[2][2] - a[2][0] * a[1][2]) +
+              a[0][2] * (a[1][0] * a[2][1] - a[2][0] * a[1][1]);
+    if (d == 0) { x[0] = x[1] = x[2] = 0; return; }
+    d = 1 / d;
+    x[0] = d * (b[0] * (a[1][1] * a[2][2] - a[1][2] * a[2][1]) - a[0][1] * (b[1] * a[2][2] - a[1][2] * b[2]) +
+                a[0][2] * (b[1] * a[2][1] - a[1][1] * b[2]));
+    x[1] = d * (a[0][0] * (b[1] * a[2][2] - a[1][2] * b[2]) - b[0] * (a[1][0] * a[2][2] - a[1][2] * a[2][0]) +
+                a[0][2] * (a[1][0] * b[2] - b[1] * a[2][0]));
+    x[2] = d * (a[0][0] * (a[1][1] * b[2] - b[1] * a[2][1]) - a[0][1] * (a[1][0] * b[2] - b[1] * a[2][0]) +
+                b[0] * (a[1][0] * a[2][1] - a[1][1] * a[2][0]));
+}
+
+__device__ bool adjust_local_extrema(const float* __restrict__ dog, int w, int h, size_t plane, int octv, int layer, int r, int c, int nL,
+                                     float contrastThreshold, float edgeThreshold, float sigma, Cand* out) {
+    const float img_scale = 1.f / 255, deriv_scale = img_scale * 0.5f, second_deriv_scale = img_scale, cross_deriv_scale = img_scale * 0.25f;
+    float xi = 0, xr = 0, xc = 0;
+    int i = 0;
+#define PXI(l, rr, cc) dog[(size_t)(l) * plane + (size_t)(rr) * w + (cc)]
+    for (; i < kMaxInterpSteps; ++i) {
+        const float dD[3] = {(PXI(layer, r, c + 1) - PXI(layer, r, c - 1)) * deriv_scale, (PXI(layer, r + 1, c) - PXI(layer, r - 1, c)) * deriv_scale,
+                             (PXI(layer + 1, r, c) - PXI(layer - 1, r, c)) * deriv_scale};
+        const float v2 = PXI(layer, r, c) * 2;
+        const float dxx = (PXI(layer, r, c + 1) + PXI(layer, r, c - 1) - v2) * second_deriv_scale;
+        const float dyy = (PXI(layer, r + 1, c) + PXI(layer, r - 1, c) - v2) * second_deriv_scale;
+        const float dss = (PXI(layer + 1, r, c) + PXI(layer - 1, r, c) - v2) * second_deriv_scale;
+        const float dxy = (PXI(layer, r + 1, c + 1) - PXI(layer, r + 1, c - 1) - PXI(layer, r - 1, c + 1) + PXI(layer, r - 1, c - 1)) * cross_deriv_scale;
+        const float dxs = (PXI(layer + 1, r, c + 1) - PXI(layer + 1, r, c - 1) - PXI(layer - 1, r, c + 1) + PXI(layer - 1, r, c - 1)) * cross_deriv_scale;
+        const float dys = (PXI(layer + 1, r + 1, c) - PXI(layer + 1, r - 1, c) - PXI(layer - 1, r + 1, c) + PXI(layer - 1, r - 1, c)) * cross_deriv_scale;
+        const float H[3][3] = {{dxx, dxy, dxs}, {dxy, dyy, dys}, {dxs, dys, dss}};
+        float X[3];
+        solve3(H, dD, X);
+        xi = -X[2]; xr = -X[1]; xc = -X[0];
+        if (fabsf(xi) < 0.5f && fabsf(xr) < 0.5f && fabsf(xc) < 0.5f) break;
+        if (fabsf(xi) > (float)(INT32_MAX / 3) || fabsf(xr) > (float)(INT32_MAX / 3) || fabsf(xc) > (float)(INT32_MAX / 3)) return false;
+        c += cv_round(xc); r += cv_round(xr); layer += cv_round(xi);
+        if (layer < 1 || layer > nL || c < kImgBorder || c >= w - kImgBorder || r < kImgBorder || r >= h - kImgBorder) return false;
+    }
+    if (i >= kMaxInterpSteps) return false;
+    const float dD[3] = {(PXI(layer, r, c + 1) - PXI(layer, r, c - 1)) * deriv_scale, (PXI(layer, r + 1, c) - PXI(layer, r - 1, c)) * deriv_scale,
+                         (PXI(layer + 1, r, c) - PXI(layer - 1, r, c)) * deriv_scale};
+    const float t = dD[0] * xc + dD[1] * xr + dD[2] * xi;
+    const float contr = PXI(layer, r, c) * img_scale + t * 0.5f;
+    if (fabsf(contr) * nL < contrastThreshold) return false;
+    const float v2 = PXI(layer, r, c) * 2.f;
+    const float dxx = (PXI(layer, r, c + 1) + PXI(layer, r, c - 1) - v2) * second_deriv_scale;
+    const float dyy = (PXI(layer, r + 1, c) + PXI(layer, r - 1, c) - v2) * second_deriv_scale;
+    const float dxy = (PXI(layer, r + 1, c + 1) - PXI(layer, r + 1, c - 1) - PXI(layer, r - 1, c + 1) + PXI(layer, r - 1, c - 1)) * cross_deriv_scale;
+#undef PXI
+    const float tr = dxx + dyy, det = dxx * dyy - dxy * dxy;
+    if (det <= 0 || tr * tr * edgeThreshold >= (edgeThreshold + 1) * (edgeThreshold + 1) * det) return false;
+    out->o = octv; out->layer = layer; out->r = r; out->c = c;
+    out->x = (c + xc) * (1 << octv);
+    out->y = (r + xr) * (1 << octv);
+    out->octave = octv + (layer << 8) + (cv_round((xi + 0.5f) * 255) << 16);
+    out->size = sigma * sift_expf(((layer + xi) / nL) * 0.69314718f) * (1 << octv) * 2;
+    out->response = fabsf(contr);
+    return true;
+}
+
+// one lane per pixel of DoG layers 1..nL of one octave (blockIdx.z = layer - 1)
+__global__ __launch_bounds__(256) void extrema_kernel(Geom geo, int o, int threshold, float contrastThreshold, float edgeThreshold, float sigma,
+                                                      Cand* __restrict__ cand, int* __restrict__ counters, int cap) {
+    const int w = geo.w(o), h = geo.h(o);
+    const int c = kImgBorder + blockIdx.x * 64 + (threadIdx.x & 63), r = kImgBorder + blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int layer = 1 + blockIdx.z;
+    if (c >= w - kImgBorder || r >= h - kImgBorder) return;
+    const size_t plane = geo.plane(o);
+    const float* dog = geo.D(o, 0);
+    const float* img = dog + plane * layer + (size_t)r * w + c;
+    const float val = img[0];
+    if (!(fabsf(val) > (float)threshold)) return;
+    bool is_max = val > 0, is_min = val < 0;
+#pragma unroll
+    for (int dl = -1; dl <= 1; ++dl)
+#pragma unroll
+        for (int dr = -1; dr <= 1; ++dr)
+#pragma unroll
+            for (int dc = -1; dc <= 1; ++dc) {
+                const float v = img[(long)dl * (long)plane + dr * w + dc];
+                is_max = is_max && val >= v;
+                is_min = is_min && val <= v;
+            }
+    if (!is_max && !is_min) return;
+    Cand k;
+    if (!adjust_local_extrema(dog, w, h, plane, o, layer, r, c, geo.nL, contrastThreshold, edgeThreshold, sigma, &k)) return;
+    const int slot = atomicAdd(&counters[0], 1);
+    if (slot < cap) cand[slot] = k;
+}
+
+// ------------------------------------------------------------------------------------------------ orientation
+constexpr int kOriChunk = 1024;
+// One wave per refined candidate.  Samples of the (2r+1)^2 window are evaluated 64 at a time into LDS (bin, weight *
+// magnitude); lane b < 36 then owns histogram bin b and adds its samples in raster order (float sums are order
+// sensitive; this is the order of the sequential algorithm).  Keypoints (one per histogram peak >= 0.8 max) are
+// appended unordered; the sort below fixes the order.
+__global__ __launch_bounds__(256) void orientation_kernel(Geom geo, const Cand* __restrict__ cand, int* __restrict__ counters, int cap,
+                                                          float* __restrict__ kp_raw) {
+    __shared__ float sval[4][kOriChunk];
+    __shared__ signed char sbin[4][kOriChunk];
+    __shared__ float shist[4][kOriBins + 4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int id = blockIdx.x * 4 + wave;
+    const int ncand = min(counters[0], cap);
+    if (id >= ncand) return;
+    const Cand k = cand[id];
+    const int w = geo.w(k.o), h = geo.h(k.o);
+    const float* img = geo.G(k.o, k.layer);
+    const float scl_octv = k.size * 0.5f / (1 << k.o);
+    const int radius = cv_round(kOriRadius * scl_octv);
+    const float sigma = kOriSigFctr * scl_octv;
+    const float expf_scale = -1.f / (2.f * sigma * sigma);
+    const int side = 2 * radius + 1, total = side * side;
+    const int n = kOriBins;
+    float acc = 0.f;   // lane b: temphist[b]
+    for (int base = 0; base < total; base += kOriChunk) {
+        const int m = min(kOriChunk, total - base);
+        for (int e = lane; e < m; e += 64) {
+            const int idx = base + e;
+            const int i = idx / side - radius, j = idx % side - radius;
+            const int y = k.r + i, x = k.c + j;
+            int bin = -1; float v = 0.f;
+            if (!(y <= 0 || y >= h - 1 || x <= 0 || x >= w - 1)) {
+                const float dx = img[(size_t)y * w + x + 1] - img[(size_t)y * w + x - 1];
+                const float dy = img[(size_t)(y - 1) * w + x] - img[(size_t)(y + 1) * w + x];
+                const float W = sift_expf((i * i + j * j) * expf_scale);
+                const float ori = fast_atan2_deg(dy, dx), mag = sqrtf(dx * dx + dy * dy);
+                bin = cv_round((n / 360.f) * ori);
+                if (bin >= n) bin -= n;
+                if (bin < 0) bin += n;
+                v = W * mag;
+            }
+            sbin[wave][e] = (signed char)bin; sval[wave][e] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes are visible
+        for (int e = 0; e < m; ++e)
+            if (sbin[wave][e] == lane) acc += sval[wave][e];
+        __builtin_amdgcn_wave_barrier();
+    }
+    float* th = &shist[wave][2];
+    if (lane < n) th[lane] = acc;
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    if (lane == 0) { th[-1] = th[n - 1]; th[-2] = th[n - 2]; th[n] = th[0]; th[n + 1] = th[1]; }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    float hv = -FLT_MAX;
+    if (lane < n) hv = (th[lane - 2] + th[lane + 2]) * (1.f / 16.f) + (th[lane - 1] + th[lane + 1]) * (4.f / 16.f) + th[lane] * (6.f / 16.f);
+    float omax = hv;
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) omax = fmaxf(omax, __shfl_xor(omax, s));
+    const float mag_thr = omax * kOriPeakRatio;
+    const int l = lane > 0 ? lane - 1 : n - 1, r2 = lane < n - 1 ? lane + 1 : 0;
+    const float hl = __shfl(hv, l), hr = __shfl(hv, r2);
+    const bool peak = lane < n && hv > hl && hv > hr && hv >= mag_thr;
+    const unsigned long long bal = __ballot(peak);
+    int slot0 = 0;
+    if (lane == 0) slot0 = atomicAdd(&counters[1], __popcll(bal));
+    slot0 = __shfl(slot0, 0);
+    if (peak) {
+        float bin = lane + 0.5f * (hl - hr) / (hl - 2 * hv + hr);
+        bin = bin < 0 ? n + bin : bin >= n ? bin - n : bin;
+        float angle = 360.f - (360.f / n) * bin;
+        if (fabsf(angle - 360.f) < FLT_EPSILON) angle = 0.f;
+        const int slot = slot0 + __popcll(bal & ((1ull << lane) - 1ull));
+        if (slot < cap) {
+            float* q = kp_raw + (size_t)slot * 8;
+            q[0] = k.x; q[1] = k.y; q[2] = k.size; q[3] = angle; q[4] = k.response; q[5] = __int_as_float(k.octave); q[6] = __int_as_float(-1); q[7] = 0.f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ ordering
+// KeyPointsFilter::removeDuplicatedSorted order: x, y ascending, size descending, angle ascending, response, octave
+// descending.  rank[i] = number of keypoints ordered before i (all-pairs counting through LDS tiles: n is ~1e4, the
+// n^2 compares are a few tens of microseconds and need no multi-pass sort); keypoints equal in every field are
+// interchangeable, the index breaks the tie.
+struct Key { float x, y, size, angle, response; int octave; };
+__device__ inline bool key_before(const Key& a, int ia, const Key& b, int ib) {
+    if (a.x != b.x) return a.x < b.x;
+    if (a.y != b.y) return a.y < b.y;
+    if (a.size != b.size) return a.size > b.size;
+    if (a.angle != b.angle) return a.angle < b.angle;
+    if (a.response != b.response) return a.response > b.response;
+    if (a.octave != b.octave) return a.octave > b.octave;
+    return ia < ib;
+}
+
+__global__ __launch_bounds__(256) void rank_scatter_kernel(const float* __restrict__ kp_raw, const int* __restrict__ counters, int cap,
+                                                           float* __restrict__ kp_sorted) {
+    __shared__ Key tile[256];
+    const int n = min(counters[1], cap);
+    if ((int)(blockIdx.x * 256) >= n) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    Key me = {0, 0, 0, 0, 0, 0};
+    if (i < n) { const float* q = kp_raw + (size_t)i * 8; me = {q[0], q[1], q[2], q[3], q[4], __float_as_int(q[5])}; }
+    int rank = 0;
+    for (int base = 0; base < n; base += 256) {
+        __syncthreads();
+        if (base + (int)threadIdx.x < n) { const float* q = kp_raw + (size_t)(base + threadIdx.x) * 8; tile[threadIdx.x] = {q[0], q[1], q[2], q[3], q[4], __float_as_int(q[5])}; }
+        __syncthreads();
+        const int m = min(256, n - base);
+        if (i < n)
+            for (int j = 0; j < m; ++j) rank += key_before(tile[j], base + j, me, i) ? 1 : 0;
+    }
+    if (i < n) {
+        const float4* s = reinterpret_cast<const float4*>(kp_raw + (size_t)i * 8);
+        float4* d = reinterpret_cast<float4*>(kp_sorted + (size_t)rank * 8);
+        d[0] = s[0]; d[1] = s[1];
+    }
+}
+
+// single workgroup: drop keypoints equal to their predecessor in (x, y, size, angle), keep the order, undo the 2x
+// base (firstOctave = -1): pt and size halve, the octave byte decrements.
+__global__ __launch_bounds__(1024) void dedupe_kernel(const float* __restrict__ kp_sorted, int* __restrict__ counters, int cap, float* __restrict__ kp_out,
+                                                      int* __restrict__ count_out) {
+    __shared__ int wsum[16];
+    __shared__ int base_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = min(counters[1], cap);
+    if (threadIdx.x == 0) base_s = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += 1024) {
+        const int i = i0 + threadIdx.x;
+        bool keep = false;
+        float4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
+        if (i < n) {
+            a = reinterpret_cast<const float4*>(kp_sorted + (size_t)i * 8)[0];
+            b = reinterpret_cast<const float4*>(kp_sorted + (size_t)i * 8)[1];
+            keep = true;
+            if (i > 0) {
+                const float4 p = reinterpret_cast<const float4*>(kp_sorted + (size_t)(i - 1) * 8)[0];
+                keep = !(p.x == a.x && p.y == a.y && p.z == a.z && p.w == a.w);
+            }
+        }
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) wsum[wave] = __popcll(bal);
+        __syncthreads();
+        int woff = 0, total = 0;
+        for (int w = 0; w < 16; ++w) { if (w < wave) woff += wsum[w]; total += wsum[w]; }
+        if (keep) {
+            const int pos = base_s + woff + __popcll(bal & ((1ull << lane) - 1ull));
+            int oct = __float_as_int(b.y);
+            oct = (oct & ~255) | ((oct - 1) & 255);
+            float4* d = reinterpret_cast<float4*>(kp_out + (size_t)pos * 8);
+            d[0] = make_float4(a.x * 0.5f, a.y * 0.5f, a.z * 0.5f, a.w);
+            d[1] = make_float4(b.x, __int_as_float(oct), b.z, 0.f);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) base_s += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { counters[2] = base_s; count_out[0] = base_s; count_out[1] = counters[1]; count_out[2] = counters[0]; }
+}
+
+// ------------------------------------------------------------------------------------------------ descriptors
+constexpr int kDescChunk = 512;
+constexpr int kHistCells = (kDescWidth + 2) * (kDescWidth + 2), kHistBins = kDescBins + 2;
+// One wave per keypoint.  The rotated (2r+1)^2 window is walked in raster order, 512 samples at a time: all lanes
+// evaluate samples (gradient, Gaussian weight, the three fractional bin coordinates) into LDS, then lane c < 36 owns
+// the 10 orientation bins of spatial cell c of the 6 x 6 x 10 trilinear histogram and adds the samples that touch its
+// cell, in order.  Normalisation, the 0.2 clip and the 512 / u8 quantisation follow; output is float32 holding integers.
+__global__ __launch_bounds__(256) void descriptor_kernel(Geom geo, const float* __restrict__ kp, const int* __restrict__ counters, int cap,
+                                                         float* __restrict__ desc) {
+    __shared__ float4 sfrac[4][kDescChunk];      // rbin, cbin, obin fractions, magnitude
+    __shared__ int scode[4][kDescChunk];         // -1 invalid, else (r0+1) | (c0+1) << 4 | o0 << 8
+    __shared__ float shist[4][kHistCells * kHistBins];
+    __shared__ float sdst[4][128];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int id = blockIdx.x * 4 + wave;
+    const int nkp = min(counters[2], cap);
+    if (id >= nkp) return;
+    const float* q = kp + (size_t)id * 8;
+    const int packed = __float_as_int(q[5]);
+    int octave = packed & 255; const int layer = (packed >> 8) & 255;
+    octave = octave < 128 ? octave : (-128 | octave);
+    const float scale = octave >= 0 ? 1.f / (1 << octave) : (float)(1 << -octave);
+    const float size = q[2] * scale;
+    float ori = 360.f - q[3];
+    if (fabsf(ori - 360.f) < FLT_EPSILON) ori = 0.f;
+    const int o = octave + 1;
+    const int w = geo.w(o), h = geo.h(o);
+    const float* img = geo.G(o, layer);
+    const int d = kDescWidth, n = kDescBins;
+    const int px = cv_round(q[0] * scale), py = cv_round(q[1] * scale);
+    const float scl = size * 0.5f;
+    float cos_t, sin_t;
+    sift_sincos(ori * (float)(3.14159265358979323846 / 180), &sin_t, &cos_t);
+    const float bins_per_rad = n / 360.f, exp_scale = -1.f / (d * d * 0.5f), hist_width = kDescSclFctr * scl;
+    int radius = cv_round(hist_width * 1.4142135623730951f * (d + 1) * 0.5f);
+    radius = min(radius, (int)sqrt((double)w * w + (double)h * h));
+    cos_t /= hist_width; sin_t /= hist_width;
+    float* hist = shist[wave];
+    for (int e = lane; e < kHistCells * kHistBins; e += 64) hist[e] = 0.f;
+    const int side = 2 * radius + 1;
+    const long total = (long)side * side;
+    const int cell_r = lane / (d + 2), cell_c = lane % (d + 2);
+    float* mine = hist + lane * kHistBins;       // lanes >= 36 never touch it
+    for (long base = 0; base < total; base += kDescChunk) {
+        const int m = (int)min((long)kDescChunk, total - base);
+        for (int e = lane; e < m; e += 64) {
+            const long idx = base + e;
+            const int i = (int)(idx / side) - radius, j = (int)(idx % side) - radius;
+            const float c_rot = j * cos_t - i * sin_t, r_rot = j * sin_t + i * cos_t;
+            float rbin = r_rot + d / 2 - 0.5f, cbin = c_rot + d / 2 - 0.5f;
+            const int r = py + i, c = px + j;
+            int code = -1; float4 f = {0, 0, 0, 0};
+            if (rbin > -1 && rbin < d && cbin > -1 && cbin < d && r > 0 && r < h - 1 && c > 0 && c < w - 1) {
+                const float dx = img[(size_t)r * w + c + 1] - img[(size_t)r * w + c - 1];
+                const float dy = img[(size_t)(r - 1) * w + c] - img[(size_t)(r + 1) * w + c];
+                const float W = sift_expf((c_rot * c_rot + r_rot * r_rot) * exp_scale);
+                float obin = (fast_atan2_deg(dy, dx) - ori) * bins_per_rad;
+                const float mag = sqrtf(dx * dx + dy * dy) * W;
+                const int r0 = cv_floor(rbin), c0 = cv_floor(cbin);
+                int o0 = cv_floor(obin);
+                rbin -= r0; cbin -= c0; obin -= o0;
+                if (o0 < 0) o0 += n;
+                if (o0 >= n) o0 -= n;
+                code = (r0 + 1) | ((c0 + 1) << 4) | (o0 << 8);
+                f = make_float4(rbin, cbin, obin, mag);
+            }
+            scode[wave][e] = code; sfrac[wave][e] = f;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        for (int e = 0; e < m; ++e) {
+            const int code = scode[wave][e];
+            if (code < 0) continue;                       // wave-uniform
+            const int dr = cell_r - (code & 15), dc = cell_c - ((code >> 4) & 15);
+            if (lane < kHistCells && (unsigned)dr <= 1u && (unsigned)dc <= 1u) {
+                const float4 f = sfrac[wave][e];
+                const int o0 = code >> 8;
+                const float vr1 = f.w * f.x;
+                const float vr = dr ? vr1 : f.w - vr1;
+                const float vrc1 = vr * f.y;
+                const float vrc = dc ? vrc1 : vr - vrc1;
+                const float vo1 = vrc * f.z, vo0 = vrc - vo1;
+                mine[o0] += vo0;
+                mine[o0 + 1] += vo1;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+    }
+    // circular orientation bins: bin n folds onto 0, n+1 onto 1; then the d x d interior cells are the descriptor
+    float* dst = sdst[wave];
+    if (lane < d * d) {
+        const int ci = lane / d, cj = lane % d;
+        float* hc = hist + ((ci + 1) * (d + 2) + (cj + 1)) * kHistBins;
+        hc[0] += hc[n]; hc[1] += hc[n + 1];
+        for (int k = 0; k < n; ++k) dst[lane * n + k] = hc[k];
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    const int len = d * d * n;
+    float nrm2 = 0.f;
+    for (int k = 0; k < len; ++k) nrm2 += dst[k] * dst[k];     // sequential on every lane: the order is part of the result
+    const float thr = sqrtf(nrm2) * kDescMagThr;
+    nrm2 = 0.f;
+    for (int k = 0; k < len; ++k) { const float v = fminf(dst[k], thr); nrm2 += v * v; }
+    const float s = sqrtf(nrm2);
+    const float mul = kIntDescrFctr / fmaxf(s, FLT_EPSILON);
+    for (int k = lane; k < len; k += 64) {
+        const float v = fminf(dst[k], thr);
+        const int iv = cv_round(v * mul);
+        desc[(size_t)id * 128 + k] = (float)(iv < 0 ? 0 : iv > 255 ? 255 : iv);
+    }
+}
+
+int gauss_taps(double sigma, Taps* t) {   // getGaussianKernel(cvRound(sigma*8+1)|1, sigma, CV_32F)
+    const int n = (int)lrint(sigma * 4 * 2 + 1) | 1;
+    if (n > kMaxTaps) return -1;
+    const double s2 = -0.5 / (sigma * sigma);
+    double sum = 0;
+    for (int i = 0; i < n; ++i) { const double x = i - (n - 1) * 0.5; t->k[i] = (float)std::exp(s2 * x * x); sum += t->k[i]; }
+    sum = 1. / sum;
+    for (int i = 0; i < n; ++i) t->k[i] = (float)(t->k[i] * sum);
+    for (int i = n; i <= kMaxTaps; ++i) t->k[i] = 0.f;
+    t->n = n;
+    return n;
+}
+
+int num_octaves(int64_t w, int64_t h) {
+    const double m = (double)std::min(2 * w, 2 * h);
+    return (int)lrint(std::log(m) / std::log(2.) - 2) + 1;
+}
+
+struct Layout { size_t g_floats, d_floats, up_floats; int nOct; };
+Layout layout(int64_t w, int64_t h, int nL) {
+    Layout L{};
+    L.nOct = num_octaves(w, h);
+    for (int o = 0; o < L.nOct; ++o) {
+        const size_t p = (size_t)((2 * w) >> o) * (size_t)((2 * h) >> o);
+        L.g_floats += p * (nL + 3);
+        L.d_floats += p * (nL + 2);
+    }
+    L.up_floats = (size_t)4 * w * h;
+    return L;
+}
+
+}  // namespace
+
+extern "C" int sfm_bgr2gray_u8(const uint8_t* bgr, int64_t w, int64_t h, int64_t stride, uint8_t* gray, void* stream) {
+    SFM_CHECK_ARG(bgr && gray && w > 0 && h > 0 && stride >= 3 * w && w < (1 << 20) && h < (1 << 20), "sfm_bgr2gray_u8: bad arguments");
+    hipLaunchKernelGGL(bgr2gray_kernel, dim3((unsigned)((w + 63) / 64), (unsigned)((h + 3) / 4)), dim3(256), 0, sfm::as_stream(stream), bgr, (int)w,
+                       (int)h, (long)stride, gray);
+    SFM_CHECK_LAUNCH();
+    return SFM_OK;
+}
+
+extern "C" int sfm_pyrdown_u8(const uint8_t* src, int64_t w, int64_t h, int channels, uint8_t* dst, void* stream) {
+    SFM_CHECK_ARG(src && dst && w > 0 && h > 0 && channels >= 1 && channels <= 4 && w < (1 << 20) && h < (1 << 20), "sfm_pyrdown_u8: bad arguments");
+    const int64_t dw = (w + 1) / 2, dh = (h + 1) / 2;
+    hipLaunchKernelGGL(pyrdown_kernel, dim3((unsigned)((dw + 63) / 64), (unsigned)((dh + 3) / 4)), dim3(256), 0, sfm::as_stream(stream), src, (int)w,
+                       (int)h, channels, dst);
+    SFM_CHECK_LAUNCH();
+    return SFM_OK;
+}
+
+extern "C" size_t sfm_sift_ws_bytes(int64_t w, int64_t h, int n_octave_layers, int64_t max_keypoints) {
+    if (w <= 0 || h <= 0 || n_octave_layers < 1 || max_keypoints < 0) return 0;
+    const Layout L = layout(w, h, n_octave_layers);
+    sfm::Carver c(nullptr);
+    c.take<float>(L.up_floats);
+    c.take<float>(L.g_floats);
+    c.take<float>(L.d_floats);
+    c.take<Cand>((size_t)max_keypoints);
+    c.take<float>((size_t)max_keypoints * 8);
+    c.take<float>((size_t)max_keypoints * 8);
+    c.take<int>(64);
+    return c.used();
+}
+
+extern "C" int sfm_sift_detect_and_compute(const uint8_t* gray, int64_t w, int64_t h, int64_t stride, int n_octave_layers, double contrast_threshold,
+                                           double edge_threshold, double sigma, int64_t max_keypoints, float* keypoints, float* descriptors,
+                                           int32_t* count, void* ws, size_t ws_bytes, void* stream_) {
+    SFM_CHECK_ARG(gray && keypoints && count && ws, "sfm_sift_detect_and_compute: null pointer");
+    SFM_CHECK_ARG(w >= 8 && h >= 8 && w <= 16384 && h <= 16384 && stride >= w, "sfm_sift_detect_and_compute: image must be 8..16384 pixels a side");
+    SFM_CHECK_ARG(n_octave_layers >= 1 && n_octave_layers <= 8 && sigma > 0 && max_keypoints > 0 && max_keypoints < (1 << 24),
+                  "sfm_sift_detect_and_compute: bad parameters");
+    if (ws_bytes < sfm_sift_ws_bytes(w, h, n_octave_layers, max_keypoints)) {
+        sfm::set_error("sfm_sift_detect_and_compute: workspace too small");
+        return SFM_ERR_WORKSPACE;
+    }
+    hipStream_t stream = sfm::as_stream(stream_);
+    const int nL = n_octave_layers, cap = (int)max_keypoints;
+    const Layout L = layout(w, h, nL);
+    SFM_CHECK_ARG(L.nOct >= 1 && L.nOct <= kMaxOctaves, "sfm_sift_detect_and_compute: octave count out of range");
+    sfm::Carver c(ws);
+    float* up = c.take<float>(L.up_floats);
+    Geom geo;
+    geo.g = c.take<float>(L.g_floats);
+    geo.d = c.take<float>(L.d_floats);
+    geo.W0 = (int)(2 * w); geo.H0 = (int)(2 * h); geo.nL = nL; geo.nOct = L.nOct;
+    Cand* cand = c.take<Cand>((size_t)cap);
+    float* kp_raw = c.take<float>((size_t)cap * 8);
+    float* kp_sorted = c.take<float>((size_t)cap * 8);
+    int* counters = c.take<int>(64);
+
+    // per-layer blur taps: sig[i]^2 = (sigma k^i)^2 - (sigma k^(i-1))^2, k = 2^(1/nL); the base blur lifts the assumed
+    // 0.5 px camera blur (1.0 after doubling) to sigma
+    Taps taps[16];
+    {
+        const float sf = (float)sigma;
+        float sd = sf * sf - 0.5f * 0.5f * 4;
+        sd = std::sqrt(sd > 0.01f ? sd : 0.01f);
+        SFM_CHECK_ARG(gauss_taps((double)sd, &taps[0]) > 0, "sfm_sift_detect_and_compute: sigma needs more than %d filter taps", kMaxTaps);
+        const double k = std::pow(2., 1. / nL);
+        for (int i = 1; i < nL + 3; ++i) {
+            const double sp = std::pow(k, (double)(i - 1)) * sigma, st = sp * k;
+            SFM_CHECK_ARG(gauss_taps(std::sqrt(st * st - sp * sp), &taps[i]) > 0, "sfm_sift_detect_and_compute: sigma needs more than %d filter taps",
+                          kMaxTaps);
+        }
+    }
+    SFM_CHECK_HIP(hipMemsetAsync(counters, 0, 64 * sizeof(int), stream));
+    auto grid2 = [](int ww, int hh) { return dim3((unsigned)((ww + 63) / 64), (unsigned)((hh + 3) / 4)); };
+    auto tiles = [](int ww, int hh) { return dim3((unsigned)((ww + kTileW - 1) / kTileW), (unsigned)((hh + kTileH - 1) / kTileH)); };
+    hipLaunchKernelGGL(upsample2_kernel, grid2(geo.W0, geo.H0), dim3(256), 0, stream, gray, (int)w, (int)h, (long)stride, up);
+    SFM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gauss_blur_kernel, tiles(geo.W0, geo.H0), dim3(256), 0, stream, (const float*)up, geo.G(0, 0), (float*)nullptr, geo.W0, geo.H0,
+                       taps[0]);
+    SFM_CHECK_LAUNCH();
+    for (int o = 0; o < geo.nOct; ++o) {
+        const int ow = geo.w(o), oh = geo.h(o);
+        if (o > 0) {
+            hipLaunchKernelGGL(decimate2_kernel, grid2(ow, oh), dim3(256), 0, stream, (const float*)geo.G(o - 1, nL), geo.w(o - 1), geo.G(o, 0), ow, oh);
+            SFM_CHECK_LAUNCH();
+        }
+        for (int i = 1; i < nL + 3; ++i) {
+            hipLaunchKernelGGL(gauss_blur_kernel, tiles(ow, oh), dim3(256), 0, stream, (const float*)geo.G(o, i - 1), geo.G(o, i), geo.D(o, i - 1), ow, oh,
+                               taps[i]);
+            SFM_CHECK_LAUNCH();
+        }
+        if (ow > 2 * kImgBorder && oh > 2 * kImgBorder) {
+            const int threshold = (int)std::floor(0.5 * contrast_threshold / nL * 255);
+            const dim3 g((unsigned)((ow - 2 * kImgBorder + 63) / 64), (unsigned)((oh - 2 * kImgBorder + 3) / 4), (unsigned)nL);
+            hipLaunchKernelGGL(extrema_kernel, g, dim3(256), 0, stream, geo, o, threshold, (float)contrast_threshold, (float)edge_threshold, (float)sigma,
+                               cand, counters, cap);
+            SFM_CHECK_LAUNCH();
+        }
+    }
+    const unsigned wave_blocks = (unsigned)((cap + 3) / 4);
+    hipLaunchKernelGGL(orientation_kernel, dim3(wave_blocks), dim3(256), 0, stream, geo, (const Cand*)cand, counters, cap, kp_raw);
+    SFM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(rank_scatter_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, stream, (const float*)kp_raw, (const int*)counters, cap,
+                       kp_sorted);
+    SFM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(dedupe_kernel, dim3(1), dim3(1024), 0, stream, (const float*)kp_sorted, counters, cap, keypoints, count);
+    SFM_CHECK_LAUNCH();
+    if (descriptors) {
+        hipLaunchKernelGGL(descriptor_kernel, dim3(wave_blocks), dim3(256), 0, stream, geo, (const float*)keypoints, (const int*)counters, cap, descriptors);
+        SFM_CHECK_LAUNCH();
+    }
+    return SFM_OK;
+}

@@ -6,7 +6,8 @@
 makes sfm.py's helper functions (Triangulation sfm.py:45, PnP :60, ReprojectionError :79, the matcher
 part of find_features :259-268, findEssentialMat/recoverPose :307-311) run on the MI355X unchanged.
 NumPy in, NumPy out; every call uploads, launches the kernels of libsfmhip.so and downloads.
-Not provided (out of scope): SIFT, cvtColor, pyrDown, imread, GUI.
+Also provided: `SIFT_create` / `xfeatures2d.SIFT_create` (`detectAndCompute`), `cvtColor(BGR2GRAY)`,
+`pyrDown`, `KeyPoint`.  Not provided (out of scope): imread, GUI.
 """
 import numpy as np
 import torch
@@ -14,10 +15,12 @@ import torch
 from . import hostgeom as _hg
 from . import ops as _ops
 from . import ransac as _ransac
+from . import sift as _sift
 
 RANSAC = 8
 NORM_L2 = 4
 SOLVEPNP_ITERATIVE = 0
+COLOR_BGR2GRAY = 6
 TRIANGULATE_ROWS = 4        # 4: current OpenCV DLT system; 6: legacy cvTriangulatePoints
 
 
@@ -133,3 +136,66 @@ def solvePnPRansac(objectPoints, imagePoints, cameraMatrix, distCoeffs, rvec=Non
     if distCoeffs is not None and np.any(np.asarray(distCoeffs) != 0):
         raise NotImplementedError("zero distortion only (sfm.py:325,362)")
     return _ransac.solve_pnp_ransac(objectPoints, imagePoints, cameraMatrix, iterationsCount, reprojectionError, confidence)
+
+
+class KeyPoint:
+    """cv2.KeyPoint: .pt (x, y), .size, .angle, .response, .octave, .class_id — sfm.py:267-268 reads `.pt`."""
+    __slots__ = ("pt", "size", "angle", "response", "octave", "class_id")
+
+    def __init__(self, x=0.0, y=0.0, size=0.0, angle=-1.0, response=0.0, octave=0, class_id=-1):
+        self.pt, self.size, self.angle, self.response, self.octave, self.class_id = (x, y), size, angle, response, octave, class_id
+
+    def __repr__(self):
+        return f"KeyPoint(pt={self.pt}, size={self.size}, angle={self.angle})"
+
+
+def cvtColor(src, code):
+    """cv2.cvtColor(img, cv2.COLOR_BGR2GRAY) on uint8 — sfm.py:243-244."""
+    if code != COLOR_BGR2GRAY:
+        raise NotImplementedError("only COLOR_BGR2GRAY is on the reference's path")
+    return _sift.bgr2gray(torch.as_tensor(np.ascontiguousarray(src, np.uint8)).to(_dev())).cpu().numpy()
+
+
+def pyrDown(src):
+    """cv2.pyrDown(img) on uint8 — sfm.py:40 (`img_downscale`)."""
+    return _sift.pyrdown(torch.as_tensor(np.ascontiguousarray(src, np.uint8)).to(_dev())).cpu().numpy()
+
+
+class _Sift:
+    """cv2.xfeatures2d.SIFT_create() / cv2.SIFT_create() — sfm.py:246."""
+
+    def __init__(self, nfeatures=0, nOctaveLayers=3, contrastThreshold=0.04, edgeThreshold=10, sigma=1.6):
+        if nfeatures != 0:
+            raise NotImplementedError("nfeatures=0 only (sfm.py:246 uses the defaults)")
+        self._params = (nOctaveLayers, contrastThreshold, edgeThreshold, sigma)
+        self._engines = {}
+
+    def detectAndComputeArrays(self, image):
+        """Array form: (keypoints (n, 8) float32 {x, y, size, angle, response, octave bits, class_id bits, 0}, descriptors (n, 128) float32)."""
+        img = np.ascontiguousarray(image)
+        if img.dtype != np.uint8 or img.ndim != 2:
+            raise _ops.SfmHipError("detectAndCompute expects a single-channel uint8 image (sfm.py:243-244 converts first)")
+        h, w = img.shape
+        eng = self._engines.get((w, h))
+        if eng is None:
+            nl, ct, et, sg = self._params
+            eng = self._engines[(w, h)] = _sift.Sift(w, h, _dev(), nl, ct, et, sg)
+        kp, des = eng.run(torch.as_tensor(img).to(_dev()))
+        return kp.cpu().numpy(), des.cpu().numpy()
+
+    def detectAndCompute(self, image, mask=None):
+        """-> (list of KeyPoint, descriptors (n, 128) float32) — sfm.py:247,252."""
+        if mask is not None:
+            raise NotImplementedError("mask=None only (sfm.py:247)")
+        kp, des = self.detectAndComputeArrays(image)
+        octv, cid = kp[:, 5].view(np.int32), kp[:, 6].view(np.int32)
+        kps = [KeyPoint(float(k[0]), float(k[1]), float(k[2]), float(k[3]), float(k[4]), int(o), int(c)) for k, o, c in zip(kp, octv, cid)]
+        return kps, des
+
+
+def SIFT_create(*args, **kwargs):
+    return _Sift(*args, **kwargs)
+
+
+class xfeatures2d:      # namespace, as in opencv-contrib (sfm.py:246)
+    SIFT_create = staticmethod(SIFT_create)

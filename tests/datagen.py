@@ -132,3 +132,38 @@ def gustav_scene(n_images, seed=0, clutter=200, desc_noise=1.5, pix_noise=0.0):
         feats.append((np.vstack([kp, ckp])[order], np.vstack([des, cdes])[order]))
         ids.append(np.hstack([vis, -np.ones(clutter, int)])[order])
     return K, P[:n_images], feats, ids
+
+
+def scene_image(w, h, seed, shift=(0.0, 0.0)):
+    """Procedural grayscale uint8 test image (no dataset on the box): overlapping soft blobs, hard-edged rectangles,
+    oriented gratings and low-pass noise, so SIFT finds corners, blobs and textured regions over several octaves.
+    `shift` translates the content (in pixels) to build overlapping view pairs."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    xx = xx + shift[0]
+    yy = yy + shift[1]
+    span = max(w, h)
+    img = np.full((h, w), 90.0)
+    for _ in range(int(60 * w * h / (256 * 192)) + 8):
+        cx, cy = rng.uniform(-0.2, 1.2) * w, rng.uniform(-0.2, 1.2) * h
+        s = np.exp(rng.uniform(np.log(1.5), np.log(span / 12)))
+        ang, ecc = rng.uniform(0, np.pi), rng.uniform(0.5, 1.0)
+        u = (xx - cx) * np.cos(ang) + (yy - cy) * np.sin(ang)
+        v = -(xx - cx) * np.sin(ang) + (yy - cy) * np.cos(ang)
+        img += rng.uniform(-70, 70) * np.exp(-(u * u + (v / ecc) ** 2) / (2 * s * s))
+    for _ in range(int(14 * w * h / (256 * 192)) + 3):
+        cx, cy = rng.uniform(0, w), rng.uniform(0, h)
+        a, b = rng.uniform(3, span / 8), rng.uniform(3, span / 8)
+        ang = rng.uniform(0, np.pi)
+        u = (xx - cx) * np.cos(ang) + (yy - cy) * np.sin(ang)
+        v = -(xx - cx) * np.sin(ang) + (yy - cy) * np.cos(ang)
+        img += rng.uniform(-50, 50) * ((np.abs(u) < a) & (np.abs(v) < b))
+    for _ in range(3):
+        ang, f, ph = rng.uniform(0, np.pi), rng.uniform(0.05, 0.4), rng.uniform(0, 6.28)
+        cx, cy, s = rng.uniform(0, w), rng.uniform(0, h), span / 6
+        img += 15 * np.sin((xx * np.cos(ang) + yy * np.sin(ang)) * f + ph) * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * s * s))
+    # band-limited texture that translates with the content: a sum of random plane waves
+    for _ in range(40):
+        ang, f, ph, a = rng.uniform(0, np.pi), rng.uniform(0.2, 1.2), rng.uniform(0, 6.28), rng.uniform(1, 5)
+        img += a * np.sin((xx * np.cos(ang) + yy * np.sin(ang)) * f + ph)
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
