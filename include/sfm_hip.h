@@ -290,8 +290,8 @@ int sfm_host_epnp(const double* K_host, const double* Xw_host, const double* uv_
  *   count_dev       int32[4]: [0] keypoints written (ordered), [1] keypoints before
  *                   duplicate removal, [2] refined extrema; [1] or [2] > max_keypoints
  *                   means the capacity was exceeded and the output is truncated
- * Filter kernels longer than 31 taps (sigma * 2^(1+2/n_octave_layers) > ~3.7) are
- * rejected with SFM_ERR_ARG; the defaults (3, 0.04, 10, 1.6) need 27.
+ * Blur kernels longer than 55 taps (a per-layer sigma above 6.8) are rejected with
+ * SFM_ERR_ARG; the defaults (3, 0.04, 10, 1.6) need 27.
  * ---------------------------------------------------------------------- */
 int sfm_bgr2gray_u8(const uint8_t* bgr_dev, int64_t w, int64_t h, int64_t stride_bytes, uint8_t* gray_dev, void* stream);
 int sfm_pyrdown_u8(const uint8_t* src_dev, int64_t w, int64_t h, int channels, uint8_t* dst_dev, void* stream);

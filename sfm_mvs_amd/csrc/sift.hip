@@ -26,7 +26,7 @@ namespace {
 
 constexpr int kImgBorder = 5, kMaxInterpSteps = 5, kOriBins = 36, kDescWidth = 4, kDescBins = 8;
 constexpr float kOriSigFctr = 1.5f, kOriRadius = 4.5f, kOriPeakRatio = 0.8f, kDescSclFctr = 3.f, kDescMagThr = 0.2f, kIntDescrFctr = 512.f;
-constexpr int kMaxTaps = 31, kMaxR = kMaxTaps / 2;
+constexpr int kMaxTaps = 55;   // filter length limit (LDS tile of the blur kernel stays under 64 KB): sigma <= 6.8 per blur
 constexpr int kTileW = 64, kTileH = 32;
 constexpr int kMaxOctaves = 16;
 
@@ -168,12 +168,13 @@ __global__ __launch_bounds__(256) void decimate2_kernel(const float* __restrict_
 // fetched from HBM/L2 about (1+2R/64)(1+2R/32) times instead of 2(2R+1) times.  `dog` (optional) = dst - src.
 __global__ __launch_bounds__(256) void gauss_blur_kernel(const float* __restrict__ src, float* __restrict__ dst, float* __restrict__ dog,
                                                          int w, int h, Taps taps) {
-    __shared__ float tin[(kTileH + 2 * kMaxR) * (kTileW + 2 * kMaxR)];
-    __shared__ float th[(kTileH + 2 * kMaxR) * kTileW];
-    __shared__ float tk[kMaxTaps + 1];
+    extern __shared__ float blur_lds[];      // tk[kMaxTaps+1] | th[rows x 64] | tin[rows x pitch]
     const int n = taps.n, R = n >> 1;
     const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
     const int pitch = kTileW + 2 * R, rows = kTileH + 2 * R;
+    float* tk = blur_lds;
+    float* th = tk + kMaxTaps + 1;
+    float* tin = th + rows * kTileW;
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int i = 0; i < kMaxTaps; ++i) tk[i] = taps.k[i];
@@ -684,9 +685,13 @@ extern "C" int sfm_sift_detect_and_compute(const uint8_t* gray, int64_t w, int64
     SFM_CHECK_HIP(hipMemsetAsync(counters, 0, 64 * sizeof(int), stream));
     auto grid2 = [](int ww, int hh) { return dim3((unsigned)((ww + 63) / 64), (unsigned)((hh + 3) / 4)); };
     auto tiles = [](int ww, int hh) { return dim3((unsigned)((ww + kTileW - 1) / kTileW), (unsigned)((hh + kTileH - 1) / kTileH)); };
+    auto blur_lds = [](const Taps& t) {
+        const int R = t.n / 2, rows = kTileH + 2 * R;
+        return (size_t)(kMaxTaps + 1 + rows * kTileW + rows * (kTileW + 2 * R)) * sizeof(float);
+    };
     hipLaunchKernelGGL(upsample2_kernel, grid2(geo.W0, geo.H0), dim3(256), 0, stream, gray, (int)w, (int)h, (long)stride, up);
     SFM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gauss_blur_kernel, tiles(geo.W0, geo.H0), dim3(256), 0, stream, (const float*)up, geo.G(0, 0), (float*)nullptr, geo.W0, geo.H0,
+    hipLaunchKernelGGL(gauss_blur_kernel, tiles(geo.W0, geo.H0), dim3(256), blur_lds(taps[0]), stream, (const float*)up, geo.G(0, 0), (float*)nullptr, geo.W0, geo.H0,
                        taps[0]);
     SFM_CHECK_LAUNCH();
     for (int o = 0; o < geo.nOct; ++o) {
@@ -696,7 +701,7 @@ extern "C" int sfm_sift_detect_and_compute(const uint8_t* gray, int64_t w, int64
             SFM_CHECK_LAUNCH();
         }
         for (int i = 1; i < nL + 3; ++i) {
-            hipLaunchKernelGGL(gauss_blur_kernel, tiles(ow, oh), dim3(256), 0, stream, (const float*)geo.G(o, i - 1), geo.G(o, i), geo.D(o, i - 1), ow, oh,
+            hipLaunchKernelGGL(gauss_blur_kernel, tiles(ow, oh), dim3(256), blur_lds(taps[i]), stream, (const float*)geo.G(o, i - 1), geo.G(o, i), geo.D(o, i - 1), ow, oh,
                                taps[i]);
             SFM_CHECK_LAUNCH();
         }

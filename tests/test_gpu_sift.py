@@ -1,0 +1,128 @@
+"""SIFT + preprocessing on the MI355X: libsfmhip.so through its C-ABI against the CPU oracle on the same
+images — keypoints and descriptors bit for bit (the kernels keep the sequential algorithm's float32 operation order) —
+plus an images -> keypoints -> matches round trip through the KNN path."""
+import numpy as np
+import pytest
+import torch
+
+from datagen import scene_image
+
+pytestmark = pytest.mark.gpu
+
+
+def _sift_hip(g, **kw):
+    from sfm_mvs_amd import sift
+    h, w = g.shape
+    eng = sift.Sift(w, h, "cuda", **kw)
+    kp, des = eng.run(torch.as_tensor(g).cuda())
+    return kp.cpu().numpy(), des.cpu().numpy(), eng
+
+
+def _same(a, b):
+    return a.shape == b.shape and np.array_equal(a.view(np.int32), b.view(np.int32))
+
+
+def test_bgr2gray_and_pyrdown_bit_exact(hip, oracle):
+    from sfm_mvs_amd import sift
+    rng = np.random.default_rng(0)
+    for (h, w) in [(1, 1), (7, 5), (64, 64), (217, 333), (648, 968)]:
+        bgr = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        d = torch.as_tensor(bgr).cuda()
+        assert np.array_equal(sift.bgr2gray(d).cpu().numpy(), oracle.bgr2gray(bgr))
+        assert np.array_equal(sift.pyrdown(d).cpu().numpy(), oracle.pyrdown(bgr))
+        gray = np.ascontiguousarray(bgr[..., 1])
+        assert np.array_equal(sift.pyrdown(torch.as_tensor(gray).cuda()).cpu().numpy(), oracle.pyrdown(gray))
+
+
+@pytest.mark.parametrize("w,h,seed", [(160, 120, 0), (256, 192, 1), (333, 217, 2), (97, 301, 5), (640, 480, 7)])
+def test_sift_bit_exact_vs_oracle(hip, oracle, w, h, seed):
+    g = scene_image(w, h, seed)
+    kpo, deso = oracle.sift(g)
+    kp, des, eng = _sift_hip(g)
+    assert len(kpo) > 100
+    assert _same(kp, kpo) and _same(des, deso)
+    n, raw, cand, _ = eng.count.tolist()
+    assert n == len(kpo) and raw >= n and cand <= raw
+
+
+def test_sift_small_flat_and_strided(hip, oracle):
+    from sfm_mvs_amd import sift
+    flat = np.full((40, 56), 93, np.uint8)
+    kp, des, _ = _sift_hip(flat)
+    assert kp.shape == (0, 8) and des.shape == (0, 128)
+    tiny = scene_image(24, 17, 3)
+    kpo, deso = oracle.sift(tiny)
+    kp, des, _ = _sift_hip(tiny)
+    assert _same(kp, kpo) and _same(des, deso)
+    # a view with a row stride larger than its width (a crop of a bigger frame), no copy
+    big = torch.as_tensor(scene_image(300, 200, 9)).cuda()
+    crop = big[20:180, 50:250]
+    eng = sift.Sift(200, 160, "cuda")
+    kp, des = eng.run(crop)
+    kpo, deso = oracle.sift(crop.cpu().numpy())
+    assert _same(kp.cpu().numpy(), kpo) and _same(des.cpu().numpy(), deso)
+
+
+def test_sift_other_parameters(hip, oracle):
+    g = scene_image(240, 180, 12)
+    for kw, okw in [(dict(n_octave_layers=4, contrast_threshold=0.03), dict(n_octave_layers=4, contrast=0.03)),
+                    (dict(edge_threshold=6.0, sigma=1.4), dict(edge=6.0, sigma=1.4)),
+                    (dict(n_octave_layers=2), dict(n_octave_layers=2))]:
+        kpo, deso = oracle.sift(g, **okw)
+        kp, des, _ = _sift_hip(g, **kw)
+        assert len(kpo) > 50 and _same(kp, kpo) and _same(des, deso)
+
+
+def test_sift_errors_are_loud(hip):
+    from sfm_mvs_amd import SfmHipError, sift
+    g = torch.as_tensor(scene_image(160, 120, 0)).cuda()
+    with pytest.raises(SfmHipError):
+        sift.Sift(160, 120, "cuda", max_keypoints=64).run(g)          # capacity exceeded: reported, not truncated silently
+    with pytest.raises(SfmHipError):
+        sift.Sift(160, 120, "cuda").run(g.cpu())                       # host memory
+    with pytest.raises(SfmHipError):
+        sift.Sift(160, 120, "cuda").run(g[:, :100])                    # wrong size
+    with pytest.raises(SfmHipError):
+        sift.Sift(160, 120, "cuda", sigma=8.0).run(g)                  # needs more than 55 taps
+
+
+def test_sift_repeatable_and_reusable(hip):
+    from sfm_mvs_amd import sift
+    eng = sift.Sift(256, 192, "cuda")
+    a = torch.as_tensor(scene_image(256, 192, 1)).cuda()
+    b = torch.as_tensor(scene_image(256, 192, 2)).cuda()
+    kpa, dea = (t.clone() for t in eng.run(a))
+    kpb, _ = eng.run(b)
+    assert len(kpb) != len(kpa) or not torch.equal(kpa, kpb)
+    kpa2, dea2 = eng.run(a)
+    assert torch.equal(kpa.view(torch.int32), kpa2.view(torch.int32)) and torch.equal(dea, dea2)
+
+
+def test_images_to_matches_round_trip(hip):
+    """find_features (sfm.py:242-270) from pixels: SIFT on two overlapping views of one scene, BF-KNN k=2 + Lowe 0.70 on
+    the descriptors, gather of the keypoint coordinates; the matches must reproduce the known translation."""
+    from sfm_mvs_amd import cv2compat as cv2
+    dx, dy = 23.0, -11.0
+    g0 = scene_image(320, 240, 21)
+    g1 = scene_image(320, 240, 21, shift=(dx, dy))          # content moves by (-dx, -dy)
+    s = cv2.xfeatures2d.SIFT_create()
+    kp0, des0 = s.detectAndCompute(g0, None)
+    kp1, des1 = s.detectAndCompute(g1, None)
+    assert len(kp0) > 500 and des0.shape == (len(kp0), 128) and isinstance(kp0[0].pt, tuple)
+    matches = cv2.BFMatcher().knnMatch(des0, des1, k=2)
+    good = [m for m, n in matches if m.distance < 0.70 * n.distance]
+    assert len(good) > 150
+    p0 = np.float32([kp0[m.queryIdx].pt for m in good])
+    p1 = np.float32([kp1[m.trainIdx].pt for m in good])
+    d = p0 - p1
+    ok = (np.abs(d[:, 0] - dx) < 0.5) & (np.abs(d[:, 1] - dy) < 0.5)
+    assert ok.mean() > 0.95
+
+
+def test_cv2compat_preprocessing(hip, oracle):
+    from sfm_mvs_amd import cv2compat as cv2
+    bgr = np.random.default_rng(3).integers(0, 256, (90, 130, 3), dtype=np.uint8)
+    small = cv2.pyrDown(bgr)
+    assert small.shape == (45, 65, 3) and np.array_equal(small, oracle.pyrdown(bgr))
+    gray = cv2.cvtColor(small, cv2.COLOR_BGR2GRAY)
+    assert gray.shape == (45, 65) and np.array_equal(gray, oracle.bgr2gray(small))

@@ -1,0 +1,121 @@
+"""Known-answer and property tests that pin the SIFT / preprocessing oracle (oracle/sift_oracle.c) on the CPU.
+
+cv2 is not installable here and the reference holds no keypoint vectors ("parity unpinned", see the oracle header),
+so the restatement is pinned by OpenCV's documented constants and by the invariances the algorithm must have."""
+import numpy as np
+
+from datagen import scene_image
+
+
+def test_bgr2gray_known_values(oracle):
+    px = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255], [0, 0, 0], [10, 200, 90]]], np.uint8)
+    g = oracle.bgr2gray(px)[0]
+    # OpenCV's documented results for pure B, G, R, white, black; last: (10*1868 + 200*9617 + 90*4899 + 8192) >> 14
+    assert g.tolist() == [29, 150, 76, 255, 0, (10 * 1868 + 200 * 9617 + 90 * 4899 + 8192) >> 14]
+
+
+def test_pyrdown_shape_constant_and_impulse(oracle):
+    img = np.full((13, 18), 77, np.uint8)
+    out = oracle.pyrdown(img)
+    assert out.shape == (7, 9) and (out == 77).all()
+    imp = np.zeros((16, 16), np.uint8)
+    imp[8, 8] = 255
+    out = oracle.pyrdown(imp)
+    k = np.array([1, 4, 6, 4, 1])
+    want = (np.outer(k, k)[::2, ::2] * 255 + 128) >> 8          # taps that land on even source coordinates
+    assert np.array_equal(out[3:6, 3:6], want) and out.sum() == want.sum()
+    rgb = np.random.default_rng(0).integers(0, 256, (9, 11, 3), dtype=np.uint8)
+    out3 = oracle.pyrdown(rgb)
+    assert out3.shape == (5, 6, 3)
+    for c in range(3):
+        assert np.array_equal(out3[..., c], oracle.pyrdown(rgb[..., c].copy()))
+
+
+def test_gaussian_taps(oracle):
+    k = oracle.sift_gauss_kernel(1.6)
+    assert len(k) == 15 and abs(k.sum() - 1) < 1e-6 and np.array_equal(k, k[::-1]) and k.argmax() == 7
+    assert len(oracle.sift_gauss_kernel(1.2262735)) == 11            # first in-octave blur at the defaults
+    x = np.arange(15) - 7
+    ref = np.exp(-x * x / (2 * 1.6 ** 2))
+    assert np.allclose(k, ref / ref.sum(), atol=1e-7)
+
+
+def _blobs(w, h, blobs):
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.full((h, w), 60.0)
+    for cx, cy, s in blobs:
+        img += 150 * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * s * s))
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def test_sift_finds_blobs_at_their_scale(oracle):
+    blobs = [(60, 50, 4.0), (150, 100, 7.0), (200, 40, 3.0), (100, 150, 5.0)]
+    kp, des = oracle.sift(_blobs(256, 192, blobs))
+    assert len(kp) >= 4 and des.shape == (len(kp), 128)
+    for cx, cy, s in blobs:
+        d = np.hypot(kp[:, 0] - cx, kp[:, 1] - cy)
+        near = kp[d < 1.0]
+        assert len(near) >= 1
+        # DoG of a Gaussian blob of std s peaks near sigma = s / sqrt(k), k = 2^(1/3); keypoint size = 2 sigma;
+        # the bilinear 2x base shifts coordinates by +0.25 px (OpenCV halves base coordinates without the offset)
+        assert abs(near[0, 2] / (2 * s) - 2 ** (-1 / 6)) < 0.06
+        assert abs(near[0, 0] - cx - 0.25) < 0.15 and abs(near[0, 1] - cy - 0.25) < 0.15
+    octave = kp[:, 5].view(np.int32)
+    assert set(octave & 255) <= {255, 0, 1, 2} and ((octave >> 8) & 255).min() >= 1 and ((octave >> 8) & 255).max() <= 3
+    assert (kp[:, 6].view(np.int32) == -1).all()
+
+
+def test_sift_output_contract(oracle):
+    g = scene_image(200, 150, 4)
+    kp, des = oracle.sift(g)
+    assert 300 < len(kp) < 5000
+    # descriptors: integer-valued 0..255 float32 with norm about 512 (sfm.py:260 feeds them to BFMatcher as they are)
+    assert des.dtype == np.float32 and np.array_equal(des, np.rint(des)) and des.min() >= 0 and des.max() <= 255
+    nrm = np.linalg.norm(des, axis=1)
+    assert np.all(np.abs(nrm - 512) < 12)
+    # KeyPointsFilter::removeDuplicatedSorted order: x, then y ascending; size descending; angle ascending; no duplicates
+    key = np.stack([kp[:, 0], kp[:, 1], -kp[:, 2], kp[:, 3]], 1).astype(np.float64)
+    order = np.lexsort(key.T[::-1])
+    assert np.array_equal(order, np.arange(len(kp)))
+    assert len(np.unique(kp[:, :4].view(np.int32), axis=0)) == len(kp)
+    assert (kp[:, 3] >= 0).all() and (kp[:, 3] < 360).all() and (kp[:, 4] * 3 >= 0.04 - 1e-7).all()
+    # inside the border the detector keeps (5 px of the octave's grid)
+    assert kp[:, 0].min() > 2 and kp[:, 0].max() < 198 and kp[:, 1].min() > 2 and kp[:, 1].max() < 148
+    # flat image: no keypoints
+    kp0, des0 = oracle.sift(np.full((64, 80), 128, np.uint8))
+    assert len(kp0) == 0 and des0.shape == (0, 128)
+
+
+def test_sift_rotation_covariance(oracle):
+    """A 90-degree rotation of the image rotates the keypoints and shifts the angles; descriptors of corresponding
+    keypoints stay close (the pipeline is not bit-symmetric: rows and columns are filtered in a different order)."""
+    g = scene_image(180, 140, 6)
+    kp, des = oracle.sift(g)
+    g2 = np.ascontiguousarray(np.rot90(g))          # (x, y) -> (y, w - 1 - x)
+    kp2, des2 = oracle.sift(g2)
+    w = g.shape[1]
+    # the +0.25 px base offset stays along +x/+y in both frames
+    ex, ey = kp[:, 1] - 0.25 + 0.25, (w - 1) - (kp[:, 0] - 0.25) + 0.25
+    hit = 0
+    close = 0
+    for i in range(len(kp)):
+        d = np.hypot(kp2[:, 0] - ex[i], kp2[:, 1] - ey[i])
+        da = np.abs((kp2[:, 3] - kp[i, 3] + 90 + 180) % 360 - 180)   # cv2 angles run clockwise
+        ok = np.flatnonzero((d < 0.75) & (da < 8) & (np.abs(kp2[:, 2] / kp[i, 2] - 1) < 0.1))
+        if len(ok):
+            hit += 1
+            close += np.linalg.norm(des2[ok] - des[i], axis=1).min() < 120
+    assert hit > 0.8 * len(kp) and close > 0.9 * hit
+
+
+def test_sift_scale_covariance(oracle):
+    """The same blobs rendered at twice the size reappear one octave up with twice the keypoint size."""
+    g = _blobs(128, 96, [(40, 30, 3.0), (90, 60, 4.5), (60, 70, 3.5)])
+    g2 = _blobs(256, 192, [(80.5, 60.5, 6.0), (180.5, 120.5, 9.0), (120.5, 140.5, 7.0)])
+    kp, _ = oracle.sift(g)
+    kp2, _ = oracle.sift(g2)
+    for cx, cy in [(40, 30), (90, 60), (60, 70)]:
+        a = kp[np.hypot(kp[:, 0] - cx, kp[:, 1] - cy) < 1.0][0]
+        b = kp2[np.hypot(kp2[:, 0] - 2 * cx - 0.5, kp2[:, 1] - 2 * cy - 0.5) < 1.5][0]
+        assert abs(b[2] / a[2] - 2) < 0.12
+        assert ((b[5:6].view(np.int32)[0] + 1) & 255) - ((a[5:6].view(np.int32)[0] + 1) & 255) == 1
