@@ -35,7 +35,7 @@ struct Taps { float k[kMaxTaps + 1]; int n; };
 // Scale-space geometry (octave o of a doubled base W0 x H0): planes are W0>>o by H0>>o; Gaussian planes of all
 // octaves are packed back to back, (nL+3) per octave, DoG planes (nL+2) per octave in a second region.
 struct Geom {
-    float* g; float* d; int W0, H0, nL, nOct;
+    float* g; float* d; float* mag; float* ori; int W0, H0, nL, nOct;
     __device__ __host__ int w(int o) const { return W0 >> o; }
     __device__ __host__ int h(int o) const { return H0 >> o; }
     __device__ __host__ size_t plane(int o) const { return (size_t)w(o) * h(o); }
@@ -43,6 +43,8 @@ struct Geom {
     __device__ __host__ size_t doff(int o) const { size_t s = 0; for (int p = 0; p < o; ++p) s += plane(p) * (nL + 2); return s; }
     __device__ __host__ float* G(int o, int i) const { return g + goff(o) + plane(o) * i; }
     __device__ __host__ float* D(int o, int i) const { return d + doff(o) + plane(o) * i; }
+    // gradient magnitude / orientation of Gaussian layers 1..nL (the layers keypoints live in), nL planes per octave
+    __device__ __host__ size_t moff(int o, int layer) const { size_t s = 0; for (int p = 0; p < o; ++p) s += plane(p) * nL; return s + plane(o) * (layer - 1); }
 };
 
 __device__ inline int reflect101(int p, int len) {
@@ -267,12 +269,21 @@ __device__ bool adjust_local_extrema(const float* __restrict__ dog, int w, int h
     return true;
 }
 
-// one lane per pixel of DoG layers 1..nL of one octave (blockIdx.z = layer - 1)
-__global__ __launch_bounds__(256) void extrema_kernel(Geom geo, int o, int threshold, float contrastThreshold, float edgeThreshold, float sigma,
+// tiles of 64 x 4 pixels of the bordered interior, nL layers per octave, all octaves in one launch
+__device__ __host__ inline int extrema_tiles(const Geom& g, int o) {
+    const int iw = g.w(o) - 2 * kImgBorder, ih = g.h(o) - 2 * kImgBorder;
+    return iw > 0 && ih > 0 ? ((iw + 63) / 64) * ((ih + 3) / 4) * g.nL : 0;
+}
+
+__global__ __launch_bounds__(256) void extrema_kernel(Geom geo, int threshold, float contrastThreshold, float edgeThreshold, float sigma,
                                                       Cand* __restrict__ cand, int* __restrict__ counters, int cap) {
+    int o = 0, t = blockIdx.x;
+    for (;; ++o) { const int k = extrema_tiles(geo, o); if (t < k) break; t -= k; }
     const int w = geo.w(o), h = geo.h(o);
-    const int c = kImgBorder + blockIdx.x * 64 + (threadIdx.x & 63), r = kImgBorder + blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int layer = 1 + blockIdx.z;
+    const int tx = (w - 2 * kImgBorder + 63) / 64, ty = (h - 2 * kImgBorder + 3) / 4;
+    const int layer = 1 + t / (tx * ty);
+    t -= (layer - 1) * tx * ty;
+    const int c = kImgBorder + (t % tx) * 64 + (threadIdx.x & 63), r = kImgBorder + (t / tx) * 4 + (threadIdx.x >> 6);
     if (c >= w - kImgBorder || r >= h - kImgBorder) return;
     const size_t plane = geo.plane(o);
     const float* dog = geo.D(o, 0);
@@ -297,6 +308,27 @@ __global__ __launch_bounds__(256) void extrema_kernel(Geom geo, int o, int thres
     if (slot < cap) cand[slot] = k;
 }
 
+// Gradient magnitude and orientation (degrees, OpenCV's fastAtan2) of every interior pixel of Gaussian layers
+// 1..nL, all octaves in one launch: the orientation and descriptor kernels visit each pixel many times.
+__global__ __launch_bounds__(256) void gradient_kernel(Geom geo) {
+    int o = 0;
+    size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; o < geo.nOct; ++o) { const size_t k = geo.plane(o) * geo.nL; if (p < k) break; p -= k; }
+    if (o >= geo.nOct) return;
+    const size_t plane = geo.plane(o);
+    const int w = geo.w(o), h = geo.h(o);
+    const int layer = 1 + (int)(p / plane);
+    const int rem = (int)(p - (size_t)(layer - 1) * plane);
+    const int y = rem / w, x = rem - y * w;
+    if (x <= 0 || x >= w - 1 || y <= 0 || y >= h - 1) return;
+    const float* img = geo.G(o, layer);
+    const float dx = img[(size_t)y * w + x + 1] - img[(size_t)y * w + x - 1];
+    const float dy = img[(size_t)(y - 1) * w + x] - img[(size_t)(y + 1) * w + x];
+    const size_t at = geo.moff(o, layer) + (size_t)y * w + x;
+    geo.mag[at] = sqrtf(dx * dx + dy * dy);
+    geo.ori[at] = fast_atan2_deg(dy, dx);
+}
+
 // ------------------------------------------------------------------------------------------------ orientation
 constexpr int kOriChunk = 1024;
 // One wave per refined candidate.  Samples of the (2r+1)^2 window are evaluated 64 at a time into LDS (bin, weight *
@@ -314,7 +346,8 @@ __global__ __launch_bounds__(256) void orientation_kernel(Geom geo, const Cand* 
     if (id >= ncand) return;
     const Cand k = cand[id];
     const int w = geo.w(k.o), h = geo.h(k.o);
-    const float* img = geo.G(k.o, k.layer);
+    const float* gmag = geo.mag + geo.moff(k.o, k.layer);
+    const float* gori = geo.ori + geo.moff(k.o, k.layer);
     const float scl_octv = k.size * 0.5f / (1 << k.o);
     const int radius = cv_round(kOriRadius * scl_octv);
     const float sigma = kOriSigFctr * scl_octv;
@@ -330,10 +363,8 @@ __global__ __launch_bounds__(256) void orientation_kernel(Geom geo, const Cand* 
             const int y = k.r + i, x = k.c + j;
             int bin = -1; float v = 0.f;
             if (!(y <= 0 || y >= h - 1 || x <= 0 || x >= w - 1)) {
-                const float dx = img[(size_t)y * w + x + 1] - img[(size_t)y * w + x - 1];
-                const float dy = img[(size_t)(y - 1) * w + x] - img[(size_t)(y + 1) * w + x];
                 const float W = sift_expf((i * i + j * j) * expf_scale);
-                const float ori = fast_atan2_deg(dy, dx), mag = sqrtf(dx * dx + dy * dy);
+                const float ori = gori[(size_t)y * w + x], mag = gmag[(size_t)y * w + x];
                 bin = cv_round((n / 360.f) * ori);
                 if (bin >= n) bin -= n;
                 if (bin < 0) bin += n;
@@ -396,36 +427,62 @@ __device__ inline bool key_before(const Key& a, int ia, const Key& b, int ib) {
     return ia < ib;
 }
 
-__global__ __launch_bounds__(256) void rank_scatter_kernel(const float* __restrict__ kp_raw, const int* __restrict__ counters, int cap,
-                                                           float* __restrict__ kp_sorted) {
+__device__ inline unsigned ordered_bits(float f) {   // monotone map float -> uint32
+    const unsigned u = __float_as_uint(f);
+    return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
+}
+
+constexpr int kRankSplit = 32;   // blockIdx.y: each workgroup of a 256-keypoint row tile visits every 32nd column tile
+// rank[i] += number of keypoints of the visited column tiles that are ordered before keypoint i.  (x, y) decide
+// almost every comparison, so they are packed into one 64-bit key; the full cascade runs only on (x, y) ties
+// (the several orientations of one extremum).
+__global__ __launch_bounds__(256) void rank_kernel(const float* __restrict__ kp_raw, const int* __restrict__ counters, int cap, int* __restrict__ rank) {
+    __shared__ unsigned long long tkey[256];
     __shared__ Key tile[256];
     const int n = min(counters[1], cap);
     if ((int)(blockIdx.x * 256) >= n) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
     Key me = {0, 0, 0, 0, 0, 0};
     if (i < n) { const float* q = kp_raw + (size_t)i * 8; me = {q[0], q[1], q[2], q[3], q[4], __float_as_int(q[5])}; }
-    int rank = 0;
-    for (int base = 0; base < n; base += 256) {
+    const unsigned long long mykey = ((unsigned long long)ordered_bits(me.x) << 32) | ordered_bits(me.y);
+    int r = 0;
+    for (int base = blockIdx.y * 256; base < n; base += kRankSplit * 256) {
         __syncthreads();
-        if (base + (int)threadIdx.x < n) { const float* q = kp_raw + (size_t)(base + threadIdx.x) * 8; tile[threadIdx.x] = {q[0], q[1], q[2], q[3], q[4], __float_as_int(q[5])}; }
+        if (base + (int)threadIdx.x < n) {
+            const float* q = kp_raw + (size_t)(base + threadIdx.x) * 8;
+            const Key k = {q[0], q[1], q[2], q[3], q[4], __float_as_int(q[5])};
+            tile[threadIdx.x] = k;
+            tkey[threadIdx.x] = ((unsigned long long)ordered_bits(k.x) << 32) | ordered_bits(k.y);
+        }
         __syncthreads();
         const int m = min(256, n - base);
         if (i < n)
-            for (int j = 0; j < m; ++j) rank += key_before(tile[j], base + j, me, i) ? 1 : 0;
+            for (int j = 0; j < m; ++j) {
+                const unsigned long long kj = tkey[j];
+                if (kj < mykey) ++r;
+                else if (kj == mykey) r += key_before(tile[j], base + j, me, i) ? 1 : 0;
+            }
     }
-    if (i < n) {
-        const float4* s = reinterpret_cast<const float4*>(kp_raw + (size_t)i * 8);
-        float4* d = reinterpret_cast<float4*>(kp_sorted + (size_t)rank * 8);
-        d[0] = s[0]; d[1] = s[1];
-    }
+    if (i < n && r) atomicAdd(&rank[i], r);
+}
+
+__global__ __launch_bounds__(256) void scatter_kernel(const float* __restrict__ kp_raw, const int* __restrict__ counters, int cap,
+                                                      const int* __restrict__ rank, float* __restrict__ kp_sorted) {
+    const int n = min(counters[1], cap);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4* s = reinterpret_cast<const float4*>(kp_raw + (size_t)i * 8);
+    float4* d = reinterpret_cast<float4*>(kp_sorted + (size_t)rank[i] * 8);
+    d[0] = s[0]; d[1] = s[1];
 }
 
 // single workgroup: drop keypoints equal to their predecessor in (x, y, size, angle), keep the order, undo the 2x
 // base (firstOctave = -1): pt and size halve, the octave byte decrements.
 __global__ __launch_bounds__(1024) void dedupe_kernel(const float* __restrict__ kp_sorted, int* __restrict__ counters, int cap, float* __restrict__ kp_out,
-                                                      int* __restrict__ count_out) {
+                                                      int* __restrict__ count_out, int nL, int* __restrict__ perm) {
     __shared__ int wsum[16];
     __shared__ int base_s;
+    __shared__ int bcnt[64], bpos[64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = min(counters[1], cap);
     if (threadIdx.x == 0) base_s = 0;
@@ -461,119 +518,142 @@ __global__ __launch_bounds__(1024) void dedupe_kernel(const float* __restrict__ 
         __syncthreads();
     }
     if (threadIdx.x == 0) { counters[2] = base_s; count_out[0] = base_s; count_out[1] = counters[1]; count_out[2] = counters[0]; }
+    // processing order of the descriptor kernel: keypoints bucketed by window size (layer and sub-layer offset are
+    // packed in the octave field), largest first, so that the four keypoints sharing a wave take equally long
+    const int nout = min(base_s, cap);
+    if (threadIdx.x < 64) bcnt[threadIdx.x] = 0;
+    __syncthreads();
+    auto bucket = [nL](const float* q) {
+        const int packed = __float_as_int(q[5]);
+        const int key = (((packed >> 8) & 255) - 1) * 256 + ((packed >> 16) & 255);
+        return 63 - min(63, max(0, key * 64 / (nL * 256)));
+    };
+    for (int i = threadIdx.x; i < nout; i += 1024) atomicAdd(&bcnt[bucket(kp_out + (size_t)i * 8)], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) { int acc = 0; for (int b = 0; b < 64; ++b) { bpos[b] = acc; acc += bcnt[b]; } }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nout; i += 1024) perm[atomicAdd(&bpos[bucket(kp_out + (size_t)i * 8)], 1)] = i;
 }
 
 // ------------------------------------------------------------------------------------------------ descriptors
-constexpr int kDescChunk = 512;
-constexpr int kHistCells = (kDescWidth + 2) * (kDescWidth + 2), kHistBins = kDescBins + 2;
-// One wave per keypoint.  The rotated (2r+1)^2 window is walked in raster order, 512 samples at a time: all lanes
-// evaluate samples (gradient, Gaussian weight, the three fractional bin coordinates) into LDS, then lane c < 36 owns
-// the 10 orientation bins of spatial cell c of the 6 x 6 x 10 trilinear histogram and adds the samples that touch its
-// cell, in order.  Normalisation, the 0.2 clip and the 512 / u8 quantisation follow; output is float32 holding integers.
+// Sixteen lanes per keypoint (four keypoints per wave), one lane per interior cell of the 6 x 6 x 10 trilinear
+// histogram — the border cells never reach the 4 x 4 x 8 descriptor, so they are not accumulated.  Float sums are
+// order sensitive: every bin must receive its contributions in raster order of the rotated window.  Instead of
+// routing samples to bins, each owner lane walks the bounding box of its own cell's footprint (a rotated square of
+// side 2 * hist_width; +-1 px slack, the exact per-sample test decides) in raster order and re-evaluates the samples
+// it finds there: lanes never wait for each other, every bin sees exactly the sequential algorithm's addends in its
+// order, and a sample is evaluated by the <= 4 cells it touches (gradient loads hit L1).  Normalisation, the 0.2
+// clip and the 512 / u8 quantisation follow; output is float32 holding integers.
+constexpr int kDescBinsUsed = kDescBins + 1;   // o0 in 0..7 writes bins o0 and o0+1: bin 9 of the 10 stays zero
 __global__ __launch_bounds__(256) void descriptor_kernel(Geom geo, const float* __restrict__ kp, const int* __restrict__ counters, int cap,
-                                                         float* __restrict__ desc) {
-    __shared__ float4 sfrac[4][kDescChunk];      // rbin, cbin, obin fractions, magnitude
-    __shared__ int scode[4][kDescChunk];         // -1 invalid, else (r0+1) | (c0+1) << 4 | o0 << 8
-    __shared__ float shist[4][kHistCells * kHistBins];
-    __shared__ float sdst[4][128];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int id = blockIdx.x * 4 + wave;
+                                                         const int* __restrict__ perm, float* __restrict__ desc) {
+    __shared__ float shist[256 * kDescBinsUsed];
+    __shared__ float sdst[16][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ql = lane & 15;
+    const int slot = wave * 4 + (lane >> 4);
     const int nkp = min(counters[2], cap);
-    if (id >= nkp) return;
-    const float* q = kp + (size_t)id * 8;
-    const int packed = __float_as_int(q[5]);
-    int octave = packed & 255; const int layer = (packed >> 8) & 255;
-    octave = octave < 128 ? octave : (-128 | octave);
-    const float scale = octave >= 0 ? 1.f / (1 << octave) : (float)(1 << -octave);
-    const float size = q[2] * scale;
-    float ori = 360.f - q[3];
-    if (fabsf(ori - 360.f) < FLT_EPSILON) ori = 0.f;
-    const int o = octave + 1;
-    const int w = geo.w(o), h = geo.h(o);
-    const float* img = geo.G(o, layer);
+    if ((int)(blockIdx.x * 16) >= nkp) return;
+    const bool live = (int)(blockIdx.x * 16) + slot < nkp;
+    const int id = live ? perm[blockIdx.x * 16 + slot] : 0;     // keypoints of similar window size share a wave
     const int d = kDescWidth, n = kDescBins;
-    const int px = cv_round(q[0] * scale), py = cv_round(q[1] * scale);
-    const float scl = size * 0.5f;
-    float cos_t, sin_t;
-    sift_sincos(ori * (float)(3.14159265358979323846 / 180), &sin_t, &cos_t);
-    const float bins_per_rad = n / 360.f, exp_scale = -1.f / (d * d * 0.5f), hist_width = kDescSclFctr * scl;
-    int radius = cv_round(hist_width * 1.4142135623730951f * (d + 1) * 0.5f);
-    radius = min(radius, (int)sqrt((double)w * w + (double)h * h));
-    cos_t /= hist_width; sin_t /= hist_width;
-    float* hist = shist[wave];
-    for (int e = lane; e < kHistCells * kHistBins; e += 64) hist[e] = 0.f;
-    const int side = 2 * radius + 1;
-    const long total = (long)side * side;
-    const int cell_r = lane / (d + 2), cell_c = lane % (d + 2);
-    float* mine = hist + lane * kHistBins;       // lanes >= 36 never touch it
-    for (long base = 0; base < total; base += kDescChunk) {
-        const int m = (int)min((long)kDescChunk, total - base);
-        for (int e = lane; e < m; e += 64) {
-            const long idx = base + e;
-            const int i = (int)(idx / side) - radius, j = (int)(idx % side) - radius;
+    const int ri = 1 + (ql >> 2), ci = 1 + (ql & 3);          // my cell in the (d+2) x (d+2) grid
+    float* mine = shist + threadIdx.x * kDescBinsUsed;
+#pragma unroll
+    for (int k = 0; k < kDescBinsUsed; ++k) mine[k] = 0.f;
+
+    int w = 0, h = 0, px = 0, py = 0, radius = -1;
+    const float *gmag = nullptr, *gori = nullptr;
+    float ori = 0.f, cos_t = 0.f, sin_t = 0.f, hist_width = 1.f;
+    if (live) {
+        const float* q = kp + (size_t)id * 8;
+        const int packed = __float_as_int(q[5]);
+        int octave = packed & 255; const int layer = (packed >> 8) & 255;
+        octave = octave < 128 ? octave : (-128 | octave);
+        const float scale = octave >= 0 ? 1.f / (1 << octave) : (float)(1 << -octave);
+        const float size = q[2] * scale;
+        ori = 360.f - q[3];
+        if (fabsf(ori - 360.f) < FLT_EPSILON) ori = 0.f;
+        const int o = octave + 1;
+        w = geo.w(o); h = geo.h(o);
+        gmag = geo.mag + geo.moff(o, layer);
+        gori = geo.ori + geo.moff(o, layer);
+        px = cv_round(q[0] * scale); py = cv_round(q[1] * scale);
+        const float scl = size * 0.5f;
+        sift_sincos(ori * (float)(3.14159265358979323846 / 180), &sin_t, &cos_t);
+        hist_width = kDescSclFctr * scl;
+        radius = cv_round(hist_width * 1.4142135623730951f * (d + 1) * 0.5f);
+        radius = min(radius, (int)sqrt((double)w * w + (double)h * h));
+        cos_t /= hist_width; sin_t /= hist_width;
+    }
+    const float bins_per_rad = n / 360.f, exp_scale = -1.f / (d * d * 0.5f);
+    // footprint of my cell: r_rot in [ri-3.5, ri-1.5), c_rot in [ci-3.5, ci-1.5); pixel offsets (j, i) = hw^2 * R^T (c_rot, r_rot)
+    int imin = 1, imax = 0, jmin = 0, jmax = 0;
+    if (live) {
+        const float C = cos_t * hist_width * hist_width, S = sin_t * hist_width * hist_width;
+        float jlo = FLT_MAX, jhi = -FLT_MAX, ilo = FLT_MAX, ihi = -FLT_MAX;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float cr = ci - 3.5f + 2.f * (k & 1), rr = ri - 3.5f + 2.f * (k >> 1);
+            const float jj = C * cr + S * rr, ii = C * rr - S * cr;
+            jlo = fminf(jlo, jj); jhi = fmaxf(jhi, jj); ilo = fminf(ilo, ii); ihi = fmaxf(ihi, ii);
+        }
+        jmin = max(-radius, (int)floorf(jlo) - 1); jmax = min(radius, (int)ceilf(jhi) + 1);
+        imin = max(-radius, (int)floorf(ilo) - 1); imax = min(radius, (int)ceilf(ihi) + 1);
+        if (jmin > jmax) imin = imax + 1;
+    }
+    int i = imin, j = jmin;
+    while (__any(i <= imax)) {
+        if (i <= imax) {
             const float c_rot = j * cos_t - i * sin_t, r_rot = j * sin_t + i * cos_t;
             float rbin = r_rot + d / 2 - 0.5f, cbin = c_rot + d / 2 - 0.5f;
             const int r = py + i, c = px + j;
-            int code = -1; float4 f = {0, 0, 0, 0};
             if (rbin > -1 && rbin < d && cbin > -1 && cbin < d && r > 0 && r < h - 1 && c > 0 && c < w - 1) {
-                const float dx = img[(size_t)r * w + c + 1] - img[(size_t)r * w + c - 1];
-                const float dy = img[(size_t)(r - 1) * w + c] - img[(size_t)(r + 1) * w + c];
-                const float W = sift_expf((c_rot * c_rot + r_rot * r_rot) * exp_scale);
-                float obin = (fast_atan2_deg(dy, dx) - ori) * bins_per_rad;
-                const float mag = sqrtf(dx * dx + dy * dy) * W;
                 const int r0 = cv_floor(rbin), c0 = cv_floor(cbin);
-                int o0 = cv_floor(obin);
-                rbin -= r0; cbin -= c0; obin -= o0;
-                if (o0 < 0) o0 += n;
-                if (o0 >= n) o0 -= n;
-                code = (r0 + 1) | ((c0 + 1) << 4) | (o0 << 8);
-                f = make_float4(rbin, cbin, obin, mag);
+                const int dr = ri - (r0 + 1), dc = ci - (c0 + 1);
+                if ((unsigned)dr <= 1u && (unsigned)dc <= 1u) {
+                    const float W = sift_expf((c_rot * c_rot + r_rot * r_rot) * exp_scale);
+                    float obin = (gori[(size_t)r * w + c] - ori) * bins_per_rad;
+                    const float mag = gmag[(size_t)r * w + c] * W;
+                    int o0 = cv_floor(obin);
+                    rbin -= r0; cbin -= c0; obin -= o0;
+                    if (o0 < 0) o0 += n;
+                    if (o0 >= n) o0 -= n;
+                    const float vr1 = mag * rbin;
+                    const float vr = dr ? vr1 : mag - vr1;
+                    const float vrc1 = vr * cbin;
+                    const float vrc = dc ? vrc1 : vr - vrc1;
+                    const float vo1 = vrc * obin, vo0 = vrc - vo1;
+                    mine[o0] += vo0;
+                    mine[o0 + 1] += vo1;
+                }
             }
-            scode[wave][e] = code; sfrac[wave][e] = f;
+            if (++j > jmax) { j = jmin; ++i; }
         }
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        for (int e = 0; e < m; ++e) {
-            const int code = scode[wave][e];
-            if (code < 0) continue;                       // wave-uniform
-            const int dr = cell_r - (code & 15), dc = cell_c - ((code >> 4) & 15);
-            if (lane < kHistCells && (unsigned)dr <= 1u && (unsigned)dc <= 1u) {
-                const float4 f = sfrac[wave][e];
-                const int o0 = code >> 8;
-                const float vr1 = f.w * f.x;
-                const float vr = dr ? vr1 : f.w - vr1;
-                const float vrc1 = vr * f.y;
-                const float vrc = dc ? vrc1 : vr - vrc1;
-                const float vo1 = vrc * f.z, vo0 = vrc - vo1;
-                mine[o0] += vo0;
-                mine[o0 + 1] += vo1;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_s_waitcnt(0xc07f);
     }
-    // circular orientation bins: bin n folds onto 0, n+1 onto 1; then the d x d interior cells are the descriptor
-    float* dst = sdst[wave];
-    if (lane < d * d) {
-        const int ci = lane / d, cj = lane % d;
-        float* hc = hist + ((ci + 1) * (d + 2) + (cj + 1)) * kHistBins;
-        hc[0] += hc[n]; hc[1] += hc[n + 1];
-        for (int k = 0; k < n; ++k) dst[lane * n + k] = hc[k];
-    }
+    // circular orientation: bin n folds onto bin 0 (bin n+1, which would fold onto 1, is never written)
+    float* dst = sdst[slot];
+    mine[0] += mine[n];
+#pragma unroll
+    for (int k = 0; k < kDescBins; ++k) dst[ql * n + k] = mine[k];
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);
     const int len = d * d * n;
     float nrm2 = 0.f;
-    for (int k = 0; k < len; ++k) nrm2 += dst[k] * dst[k];     // sequential on every lane: the order is part of the result
+    for (int k = 0; k < len; ++k) nrm2 += dst[k] * dst[k];     // sequential: the order is part of the result
     const float thr = sqrtf(nrm2) * kDescMagThr;
     nrm2 = 0.f;
     for (int k = 0; k < len; ++k) { const float v = fminf(dst[k], thr); nrm2 += v * v; }
-    const float s = sqrtf(nrm2);
-    const float mul = kIntDescrFctr / fmaxf(s, FLT_EPSILON);
-    for (int k = lane; k < len; k += 64) {
-        const float v = fminf(dst[k], thr);
-        const int iv = cv_round(v * mul);
-        desc[(size_t)id * 128 + k] = (float)(iv < 0 ? 0 : iv > 255 ? 255 : iv);
+    const float mul = kIntDescrFctr / fmaxf(sqrtf(nrm2), FLT_EPSILON);
+    if (live) {
+        float out[kDescBins];
+#pragma unroll
+        for (int k = 0; k < kDescBins; ++k) {
+            const int iv = cv_round(fminf(mine[k], thr) * mul);
+            out[k] = (float)(iv < 0 ? 0 : iv > 255 ? 255 : iv);
+        }
+        float4* o4 = reinterpret_cast<float4*>(desc + (size_t)id * 128 + ql * n);
+        o4[0] = make_float4(out[0], out[1], out[2], out[3]);
+        o4[1] = make_float4(out[4], out[5], out[6], out[7]);
     }
 }
 
@@ -595,7 +675,7 @@ int num_octaves(int64_t w, int64_t h) {
     return (int)lrint(std::log(m) / std::log(2.) - 2) + 1;
 }
 
-struct Layout { size_t g_floats, d_floats, up_floats; int nOct; };
+struct Layout { size_t g_floats, d_floats, m_floats, up_floats; int nOct; };
 Layout layout(int64_t w, int64_t h, int nL) {
     Layout L{};
     L.nOct = num_octaves(w, h);
@@ -603,6 +683,7 @@ Layout layout(int64_t w, int64_t h, int nL) {
         const size_t p = (size_t)((2 * w) >> o) * (size_t)((2 * h) >> o);
         L.g_floats += p * (nL + 3);
         L.d_floats += p * (nL + 2);
+        L.m_floats += p * nL;
     }
     L.up_floats = (size_t)4 * w * h;
     return L;
@@ -634,10 +715,14 @@ extern "C" size_t sfm_sift_ws_bytes(int64_t w, int64_t h, int n_octave_layers, i
     c.take<float>(L.up_floats);
     c.take<float>(L.g_floats);
     c.take<float>(L.d_floats);
+    c.take<float>(L.m_floats);
+    c.take<float>(L.m_floats);
+    c.take<int>((size_t)max_keypoints);
     c.take<Cand>((size_t)max_keypoints);
     c.take<float>((size_t)max_keypoints * 8);
     c.take<float>((size_t)max_keypoints * 8);
     c.take<int>(64);
+    c.take<int>((size_t)max_keypoints);
     return c.used();
 }
 
@@ -661,11 +746,15 @@ extern "C" int sfm_sift_detect_and_compute(const uint8_t* gray, int64_t w, int64
     Geom geo;
     geo.g = c.take<float>(L.g_floats);
     geo.d = c.take<float>(L.d_floats);
+    geo.mag = c.take<float>(L.m_floats);
+    geo.ori = c.take<float>(L.m_floats);
+    int* perm = c.take<int>((size_t)max_keypoints);
     geo.W0 = (int)(2 * w); geo.H0 = (int)(2 * h); geo.nL = nL; geo.nOct = L.nOct;
     Cand* cand = c.take<Cand>((size_t)cap);
     float* kp_raw = c.take<float>((size_t)cap * 8);
     float* kp_sorted = c.take<float>((size_t)cap * 8);
     int* counters = c.take<int>(64);
+    int* rank = c.take<int>((size_t)cap);
 
     // per-layer blur taps: sig[i]^2 = (sigma k^i)^2 - (sigma k^(i-1))^2, k = 2^(1/nL); the base blur lifts the assumed
     // 0.5 px camera blur (1.0 after doubling) to sigma
@@ -682,7 +771,7 @@ extern "C" int sfm_sift_detect_and_compute(const uint8_t* gray, int64_t w, int64
                           kMaxTaps);
         }
     }
-    SFM_CHECK_HIP(hipMemsetAsync(counters, 0, 64 * sizeof(int), stream));
+    SFM_CHECK_HIP(hipMemsetAsync(counters, 0, (size_t)((char*)(rank + cap) - (char*)counters), stream));   // counters and, behind them, rank
     auto grid2 = [](int ww, int hh) { return dim3((unsigned)((ww + 63) / 64), (unsigned)((hh + 3) / 4)); };
     auto tiles = [](int ww, int hh) { return dim3((unsigned)((ww + kTileW - 1) / kTileW), (unsigned)((hh + kTileH - 1) / kTileH)); };
     auto blur_lds = [](const Taps& t) {
@@ -705,24 +794,34 @@ extern "C" int sfm_sift_detect_and_compute(const uint8_t* gray, int64_t w, int64
                                taps[i]);
             SFM_CHECK_LAUNCH();
         }
-        if (ow > 2 * kImgBorder && oh > 2 * kImgBorder) {
+    }
+    {
+        int total_tiles = 0;
+        size_t grad_px = 0;
+        for (int o = 0; o < geo.nOct; ++o) { total_tiles += extrema_tiles(geo, o); grad_px += geo.plane(o) * nL; }
+        if (total_tiles > 0) {
             const int threshold = (int)std::floor(0.5 * contrast_threshold / nL * 255);
-            const dim3 g((unsigned)((ow - 2 * kImgBorder + 63) / 64), (unsigned)((oh - 2 * kImgBorder + 3) / 4), (unsigned)nL);
-            hipLaunchKernelGGL(extrema_kernel, g, dim3(256), 0, stream, geo, o, threshold, (float)contrast_threshold, (float)edge_threshold, (float)sigma,
-                               cand, counters, cap);
+            hipLaunchKernelGGL(extrema_kernel, dim3((unsigned)total_tiles), dim3(256), 0, stream, geo, threshold, (float)contrast_threshold,
+                               (float)edge_threshold, (float)sigma, cand, counters, cap);
             SFM_CHECK_LAUNCH();
         }
+        hipLaunchKernelGGL(gradient_kernel, dim3((unsigned)((grad_px + 255) / 256)), dim3(256), 0, stream, geo);
+        SFM_CHECK_LAUNCH();
     }
     const unsigned wave_blocks = (unsigned)((cap + 3) / 4);
     hipLaunchKernelGGL(orientation_kernel, dim3(wave_blocks), dim3(256), 0, stream, geo, (const Cand*)cand, counters, cap, kp_raw);
     SFM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(rank_scatter_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, stream, (const float*)kp_raw, (const int*)counters, cap,
-                       kp_sorted);
+    hipLaunchKernelGGL(rank_kernel, dim3((unsigned)((cap + 255) / 256), kRankSplit), dim3(256), 0, stream, (const float*)kp_raw, (const int*)counters,
+                       cap, rank);
     SFM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(dedupe_kernel, dim3(1), dim3(1024), 0, stream, (const float*)kp_sorted, counters, cap, keypoints, count);
+    hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, stream, (const float*)kp_raw, (const int*)counters, cap,
+                       (const int*)rank, kp_sorted);
+    SFM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(dedupe_kernel, dim3(1), dim3(1024), 0, stream, (const float*)kp_sorted, counters, cap, keypoints, count, nL, perm);
     SFM_CHECK_LAUNCH();
     if (descriptors) {
-        hipLaunchKernelGGL(descriptor_kernel, dim3(wave_blocks), dim3(256), 0, stream, geo, (const float*)keypoints, (const int*)counters, cap, descriptors);
+        hipLaunchKernelGGL(descriptor_kernel, dim3((unsigned)((cap + 15) / 16)), dim3(256), 0, stream, geo, (const float*)keypoints, (const int*)counters, cap,
+                           (const int*)perm, descriptors);
         SFM_CHECK_LAUNCH();
     }
     return SFM_OK;
