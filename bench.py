@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="knn", choices=["knn", "tri", "ba", "sfm", "c5"])
+    ap.add_argument("--workload", default="knn", choices=["knn", "tri", "ba", "sfm", "c5", "sift"])
     ap.add_argument("--nq", type=int, default=10000)
     ap.add_argument("--nt", type=int, default=10000)
     ap.add_argument("--images", type=int, default=32, help="workload c5: images in the sequence (BASELINE config 5 has 256)")
@@ -531,6 +531,73 @@ def bench_c5(args, world, rank, dev):
             "seconds_for_256_images_at_this_rate": 255 * n_desc * n_desc / (world * pairs * n_desc * n_desc / elapsed)}
 
 
+def bench_sift(args, world, rank, dev):
+    """cv2 SIFT detectAndCompute on frames of the reference's working size (sfm.py:40 halves the
+    1936 x 1296 photographs to 968 x 648).  No dataset on the box: procedural frames (tests/datagen.scene_image), a
+    different one per rank, resident in HBM as uint8.  One step = one frame: scale space, extrema, orientations,
+    ordering, descriptors; keypoints and descriptors stay in HBM (they feed the matcher)."""
+    from sfm_mvs_amd import ops, sift
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from datagen import scene_image
+    w, h = 968, 648
+    g_host = scene_image(w, h, 3 + rank)
+    gray = torch.as_tensor(g_host).to(dev)
+    pipe = sift.SiftPipeline(w, h, dev, depth=args.pipe_depth)
+    eng = pipe.engines[0]
+    for _ in range(max(2, args.warmup)):
+        pipe.submit(gray, after=False)
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pipe.submit(gray, after=False)
+    barrier_sync(world)
+    elapsed = max_over_ranks(time.perf_counter() - t0, world, dev)
+    nkp = int(eng.count[0].item())
+    t1 = time.perf_counter()
+    for _ in range(10):
+        eng.launch(gray)
+    torch.cuda.synchronize()
+    single_ms = (time.perf_counter() - t1) / 10 * 1e3
+    ops.profile_read(6); ops.profile_read(7)
+    ops.profile_enable(True)
+    for _ in range(5):
+        eng.launch(gray)
+    pyr_ms, pyr_n = ops.profile_read(6)
+    des_ms, des_n = ops.profile_read(7)
+    ops.profile_enable(False)
+    # algorithmic HBM bytes of the scale-space build: every blur reads one float plane and writes two (Gaussian + DoG),
+    # the base blur reads and writes one, decimation reads 1/4 and writes one plane, the 2x upsample writes one
+    n_oct = int(round(np.log2(min(2 * w, 2 * h)) - 2)) + 1
+    px = [((2 * w) >> o) * ((2 * h) >> o) for o in range(n_oct)]
+    pyr_bytes = sum(p * 12 * 5 for p in px) + px[0] * 8 + sum(px[o] * 5 for o in range(1, n_oct)) + px[0] * 4 + w * h
+    gbs = pyr_bytes / (pyr_ms / pyr_n * 1e-3) / 1e9
+    out = {"metric": "SIFT detectAndCompute frames/sec (968 x 648 uint8 frames)", "value": world * args.steps / elapsed, "unit": "frames/s",
+           "n_gpus": world, "steps": args.steps, "warmup": max(2, args.warmup), "ms_per_step": elapsed / args.steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "SURVEY 8f-1: SIFT (3 layers/octave, 0.04, 10, 1.6) on 968 x 648 procedural frames, one frame per step",
+                      "keypoints_per_frame": nkp, "octaves": n_oct,
+                      "parallelism": f"frame-sharded x{world}; {args.pipe_depth} frames in flight per GPU"},
+           "frame_latency_ms_single_stream": single_ms,
+           "keypoints_per_sec": world * nkp * args.steps / elapsed,
+           "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                        "kernel": "scale space: gauss_blur_kernel x 46 + decimate + upsample (one event pair around all of them)",
+                        "avg_launch_ms": pyr_ms / pyr_n, "algorithmic_bytes": pyr_bytes},
+           "descriptor_kernel": {"avg_launch_ms": des_ms / des_n, "keypoints_per_sec": nkp / (des_ms / des_n * 1e-3),
+                                 "note": "VALU/latency bound: per-cell raster walks in the sequential algorithm's float32 order"}}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as orc
+        t0 = time.perf_counter()
+        kpo, deso = orc.sift(g_host)
+        dt = time.perf_counter() - t0
+        kp = eng.keypoints[:nkp].cpu().numpy()
+        des = eng.descriptors[:nkp].cpu().numpy()
+        out["cpu_baseline"] = {"value": 1.0 / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+                               "sample": "the same 968 x 648 frame, once, oracle/sift_oracle.c (sequential C)"}
+        out["parity"] = {"keypoints_bit_identical": bool(len(kpo) == nkp and np.array_equal(kp.view(np.int32), kpo.view(np.int32))),
+                         "descriptors_bit_identical": bool(len(kpo) == nkp and np.array_equal(des, deso))}
+    return out
+
+
 def bench_sfm(args, world, rank, dev):
     """BASELINE configs[2] on Gustav GEOMETRY (the images are not available): the incremental driver over the 57
     cameras of the reference's pose.csv, features rendered from the reference's own cloud."""
@@ -579,6 +646,8 @@ def main():
         out = bench_sfm(args, world, rank, dev)
     elif args.workload == "c5":
         out = bench_c5(args, world, rank, dev)
+    elif args.workload == "sift":
+        out = bench_sift(args, world, rank, dev)
     else:
         out = bench_ba(args, world, rank, dev)
     if rank == 0:

@@ -309,6 +309,7 @@ int sfm_sift_detect_and_compute(const uint8_t* gray_dev, int64_t w, int64_t h, i
  * and launch count of one slot, and resets the slot (toggling the switch does not).
  *   slot 0 knn filter (MFMA)   1 knn refine (+ rescans)   2 triangulate
  *        3 dense BA sweep       4 indexed residual sweep    5 Schur products (W^T x, W v)
+ *        6 SIFT scale space (all blur + decimate launches of one image = 1 "launch")   7 SIFT descriptors
  * sfm_profile_enable(n) with n > 1: as 1, and the knn filter kernel is launched n times back-to-back
  * inside one event pair (idempotent), so the few microseconds an event pair adds to a single short
  * launch are amortised; sfm_profile_read then reports n launches per bracket.

@@ -13,7 +13,7 @@ void set_error(const char* fmt, ...);
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 // Optional per-kernel HIP-event timing (sfm_profile_enable): slot ids
-enum ProfSlot { kProfKnnFilter = 0, kProfKnnRefine = 1, kProfTriangulate = 2, kProfBaDense = 3, kProfResidual = 4, kProfBaSchur = 5, kProfSlots = 6 };
+enum ProfSlot { kProfKnnFilter = 0, kProfKnnRefine = 1, kProfTriangulate = 2, kProfBaDense = 3, kProfResidual = 4, kProfBaSchur = 5, kProfSiftPyramid = 6, kProfSiftDescriptor = 7, kProfSlots = 8 };
 void prof_begin(int slot, hipStream_t s);
 void prof_end(int slot, hipStream_t s, int launches = 1);
 int prof_repeat();   // launches per event pair requested with sfm_profile_enable(n > 1) (1 when profiling is off)

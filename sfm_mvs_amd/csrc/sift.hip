@@ -47,10 +47,13 @@ struct Geom {
     __device__ __host__ size_t moff(int o, int layer) const { size_t s = 0; for (int p = 0; p < o; ++p) s += plane(p) * nL; return s + plane(o) * (layer - 1); }
 };
 
-__device__ inline int reflect101(int p, int len) {
+__device__ inline int reflect101(int p, int len) {   // BORDER_REFLECT_101, any distance (period 2 len - 2)
+    if ((unsigned)p < (unsigned)len) return p;
     if (len == 1) return 0;
-    while ((unsigned)p >= (unsigned)len) p = p < 0 ? -p : 2 * len - p - 2;
-    return p;
+    const int period = 2 * len - 2;
+    p %= period;
+    if (p < 0) p += period;
+    return p < len ? p : period - p;
 }
 __device__ inline int cv_round(float v) { return __float2int_rn(v); }
 __device__ inline int cv_floor(float v) { return (int)floorf(v); }
@@ -203,6 +206,82 @@ __global__ __launch_bounds__(256) void gauss_blur_kernel(const float* __restrict
         for (int j = 1; j <= R; ++j) s += tk[R + j] * (p[j * kTileW] + p[-j * kTileW]);
         dst[(size_t)y * w + x] = s;
         if (dog) dog[(size_t)y * w + x] = s - tin[(ty + R) * pitch + tx + R];
+    }
+}
+
+// The same filter with the tap count known at compile time (the defaults need 11, 13, 17, 21 and 27 taps): taps live
+// in scalar registers, the row pass computes four adjacent outputs per lane from one run of 128-bit LDS reads
+// ((N+3)/4 reads per output instead of N, plus no tap reads), the column pass works on float4 columns.  Every output
+// is still the sequential dot product in tap order (rows) / the symmetric form (columns): results are identical to
+// gauss_blur_kernel's.  A single tile of this kernel is also what bounds the small octaves (one workgroup each).
+template <int N>
+__global__ __launch_bounds__(256) void gauss_blur_fixed_kernel(const float* __restrict__ src, float* __restrict__ dst, float* __restrict__ dog,
+                                                               int w, int h, Taps taps) {
+    constexpr int R = N / 2, ROWS = kTileH + 2 * R, COLS = kTileW + 2 * R, PITCH = (COLS + 3) & ~3, NV = (N + 3 + 3) / 4;
+    __shared__ __attribute__((aligned(16))) float tin[ROWS * PITCH];
+    __shared__ __attribute__((aligned(16))) float th[ROWS * kTileW];
+    const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
+    constexpr int LOADS = (ROWS * COLS + 255) / 256;     // all of a lane's loads are issued before the first is consumed
+    float ld[LOADS];
+    if (x0 >= R && y0 >= R && x0 + kTileW + R <= w && y0 + kTileH + R <= h) {     // interior tile: no border arithmetic
+        const float* base = src + (size_t)(y0 - R) * w + (x0 - R);
+#pragma unroll
+        for (int k = 0; k < LOADS; ++k) {
+            const int e = threadIdx.x + 256 * k, ry = e / COLS, rx = e - ry * COLS;
+            ld[k] = e < ROWS * COLS ? base[(size_t)ry * w + rx] : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < LOADS; ++k) {
+            const int e = threadIdx.x + 256 * k, ry = e / COLS, rx = e - ry * COLS;
+            ld[k] = e < ROWS * COLS ? src[(size_t)reflect101(y0 - R + ry, h) * w + reflect101(x0 - R + rx, w)] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < LOADS; ++k) {
+        const int e = threadIdx.x + 256 * k, ry = e / COLS, rx = e - ry * COLS;
+        if (e < ROWS * COLS) tin[ry * PITCH + rx] = ld[k];
+    }
+    __syncthreads();
+    for (int it = threadIdx.x; it < ROWS * (kTileW / 4); it += 256) {
+        const int ry = it >> 4, qx = it & 15;
+        const float4* p = reinterpret_cast<const float4*>(tin + ry * PITCH + 4 * qx);
+        float v[4 * NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) { const float4 t = p[k]; v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w; }
+        float o[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            float a = v[m] * taps.k[0];
+#pragma unroll
+            for (int j = 1; j < N; ++j) a += v[m + j] * taps.k[j];
+            o[m] = a;
+        }
+        *reinterpret_cast<float4*>(th + ry * kTileW + 4 * qx) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    __syncthreads();
+    for (int it = threadIdx.x; it < kTileH * (kTileW / 4); it += 256) {
+        const int ty = it >> 4, qx = it & 15;
+        const int x = x0 + 4 * qx, y = y0 + ty;
+        if (x >= w || y >= h) continue;
+        const float* p = th + (ty + R) * kTileW + 4 * qx;
+        const float4 c = *reinterpret_cast<const float4*>(p);
+        float o[4] = {taps.k[R] * c.x, taps.k[R] * c.y, taps.k[R] * c.z, taps.k[R] * c.w};
+#pragma unroll
+        for (int j = 1; j <= R; ++j) {
+            const float4 a = *reinterpret_cast<const float4*>(p + j * kTileW), b = *reinterpret_cast<const float4*>(p - j * kTileW);
+            o[0] += taps.k[R + j] * (a.x + b.x); o[1] += taps.k[R + j] * (a.y + b.y);
+            o[2] += taps.k[R + j] * (a.z + b.z); o[3] += taps.k[R + j] * (a.w + b.w);
+        }
+        const float* cin = tin + (ty + R) * PITCH + 4 * qx + R;
+        float* d = dst + (size_t)y * w + x;
+        float* g = dog ? dog + (size_t)y * w + x : nullptr;
+        if (x + 3 < w) {
+            *reinterpret_cast<float4*>(d) = make_float4(o[0], o[1], o[2], o[3]);
+            if (g) *reinterpret_cast<float4*>(g) = make_float4(o[0] - cin[0], o[1] - cin[1], o[2] - cin[2], o[3] - cin[3]);
+        } else {
+            for (int m = 0; m < 4 && x + m < w; ++m) { d[m] = o[m]; if (g) g[m] = o[m] - cin[m]; }
+        }
     }
 }
 
@@ -774,14 +853,25 @@ extern "C" int sfm_sift_detect_and_compute(const uint8_t* gray, int64_t w, int64
     SFM_CHECK_HIP(hipMemsetAsync(counters, 0, (size_t)((char*)(rank + cap) - (char*)counters), stream));   // counters and, behind them, rank
     auto grid2 = [](int ww, int hh) { return dim3((unsigned)((ww + 63) / 64), (unsigned)((hh + 3) / 4)); };
     auto tiles = [](int ww, int hh) { return dim3((unsigned)((ww + kTileW - 1) / kTileW), (unsigned)((hh + kTileH - 1) / kTileH)); };
+    auto launch_blur = [&](dim3 grid, const float* in, float* out, float* dg, int ww, int hh, const Taps& t) {
+        switch (t.n) {
+#define SFM_BLUR_CASE(N) case N: hipLaunchKernelGGL(gauss_blur_fixed_kernel<N>, grid, dim3(256), 0, stream, in, out, dg, ww, hh, t); return true;
+            SFM_BLUR_CASE(5) SFM_BLUR_CASE(7) SFM_BLUR_CASE(9) SFM_BLUR_CASE(11) SFM_BLUR_CASE(13) SFM_BLUR_CASE(15) SFM_BLUR_CASE(17)
+            SFM_BLUR_CASE(19) SFM_BLUR_CASE(21) SFM_BLUR_CASE(23) SFM_BLUR_CASE(25) SFM_BLUR_CASE(27)
+#undef SFM_BLUR_CASE
+            default: return false;
+        }
+    };
     auto blur_lds = [](const Taps& t) {
         const int R = t.n / 2, rows = kTileH + 2 * R;
         return (size_t)(kMaxTaps + 1 + rows * kTileW + rows * (kTileW + 2 * R)) * sizeof(float);
     };
+    sfm::prof_begin(sfm::kProfSiftPyramid, stream);
     hipLaunchKernelGGL(upsample2_kernel, grid2(geo.W0, geo.H0), dim3(256), 0, stream, gray, (int)w, (int)h, (long)stride, up);
     SFM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gauss_blur_kernel, tiles(geo.W0, geo.H0), dim3(256), blur_lds(taps[0]), stream, (const float*)up, geo.G(0, 0), (float*)nullptr, geo.W0, geo.H0,
-                       taps[0]);
+    if (!launch_blur(tiles(geo.W0, geo.H0), (const float*)up, geo.G(0, 0), (float*)nullptr, geo.W0, geo.H0, taps[0]))
+        hipLaunchKernelGGL(gauss_blur_kernel, tiles(geo.W0, geo.H0), dim3(256), blur_lds(taps[0]), stream, (const float*)up, geo.G(0, 0), (float*)nullptr,
+                           geo.W0, geo.H0, taps[0]);
     SFM_CHECK_LAUNCH();
     for (int o = 0; o < geo.nOct; ++o) {
         const int ow = geo.w(o), oh = geo.h(o);
@@ -790,11 +880,13 @@ extern "C" int sfm_sift_detect_and_compute(const uint8_t* gray, int64_t w, int64
             SFM_CHECK_LAUNCH();
         }
         for (int i = 1; i < nL + 3; ++i) {
-            hipLaunchKernelGGL(gauss_blur_kernel, tiles(ow, oh), dim3(256), blur_lds(taps[i]), stream, (const float*)geo.G(o, i - 1), geo.G(o, i), geo.D(o, i - 1), ow, oh,
-                               taps[i]);
+            if (!launch_blur(tiles(ow, oh), (const float*)geo.G(o, i - 1), geo.G(o, i), geo.D(o, i - 1), ow, oh, taps[i]))
+                hipLaunchKernelGGL(gauss_blur_kernel, tiles(ow, oh), dim3(256), blur_lds(taps[i]), stream, (const float*)geo.G(o, i - 1), geo.G(o, i),
+                                   geo.D(o, i - 1), ow, oh, taps[i]);
             SFM_CHECK_LAUNCH();
         }
     }
+    sfm::prof_end(sfm::kProfSiftPyramid, stream);
     {
         int total_tiles = 0;
         size_t grad_px = 0;
@@ -820,9 +912,11 @@ extern "C" int sfm_sift_detect_and_compute(const uint8_t* gray, int64_t w, int64
     hipLaunchKernelGGL(dedupe_kernel, dim3(1), dim3(1024), 0, stream, (const float*)kp_sorted, counters, cap, keypoints, count, nL, perm);
     SFM_CHECK_LAUNCH();
     if (descriptors) {
+        sfm::prof_begin(sfm::kProfSiftDescriptor, stream);
         hipLaunchKernelGGL(descriptor_kernel, dim3((unsigned)((cap + 15) / 16)), dim3(256), 0, stream, geo, (const float*)keypoints, (const int*)counters, cap,
                            (const int*)perm, descriptors);
         SFM_CHECK_LAUNCH();
+        sfm::prof_end(sfm::kProfSiftDescriptor, stream);
     }
     return SFM_OK;
 }

@@ -77,3 +77,35 @@ class Sift:
         if raw > self.cap or cand > self.cap:
             raise _lib.SfmHipError(f"SIFT found {max(raw, cand)} keypoints, more than max_keypoints={self.cap}")
         return self.keypoints[:n], (self.descriptors[:n] if want_descriptors else None)
+
+
+class SiftPipeline:
+    """Independent frames pipelined over `depth` HIP streams (one `Sift` = one scale-space workspace + output set per
+    stream).  A frame's launch chain is mostly latency: ~50 dependent blur launches of which the small octaves are one
+    workgroup each, a single-workgroup ordered compaction, and one long descriptor kernel that leaves CUs free; frames
+    on separate streams fill those gaps.  Results of submit() number i live in engine i % depth until submit() number
+    i + depth reuses it."""
+
+    def __init__(self, width, height, device, depth=3, **params):
+        self.depth = int(depth)
+        self.engines = [Sift(width, height, device, **params) for _ in range(self.depth)]
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(self.depth)]
+        self.n = 0
+
+    def submit(self, gray, after=None, want_descriptors=True):
+        """Enqueue one frame on the next stream; returns (slot, stream, engine).  `after` as in ops.PairPipeline.submit:
+        None waits for the caller's current stream, an Event for that event, False for nothing."""
+        k = self.n % self.depth
+        self.n += 1
+        st = self.streams[k]
+        if after is None:
+            st.wait_stream(torch.cuda.current_stream(st.device))
+        elif after is not False:
+            st.wait_event(after)
+        with torch.cuda.stream(st):
+            self.engines[k].launch(gray, want_descriptors)
+        return k, st, self.engines[k]
+
+    def synchronize(self):
+        for st in self.streams:
+            st.synchronize()
