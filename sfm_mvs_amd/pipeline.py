@@ -3,8 +3,9 @@
 Same names, argument meaning, shapes and quirks as the reference so that a user of sfm.py finds the same
 interface: `find_features` (sfm.py:242-270, matcher part), `Triangulation` (:45-56), `PnP`
 (:60-76), `ReprojectionError` (:79-100), `common_points` (:215-239), `to_ply` (:169-201) and the
-sliding-window driver (:274-423) as `run_sfm`.  SIFT itself is out of scope: an image is
-represented by its keypoint coordinates + 128-D descriptors ("features"), from any provider.
+sliding-window driver (:274-423) as `run_sfm`.  An image is represented by its keypoint coordinates + 128-D
+descriptors ("features"); `img_downscale` (:35-42) and `features_from_images` (the cvtColor + SIFT half of
+find_features, :243-252) produce them from pixels on the GPU, `run_sfm_images` chains both.
 
 Behavioural quirks that are load-bearing for parity are reproduced and marked `# quirk`.
 """
@@ -58,6 +59,55 @@ def find_features(feat0, feat1, be=None):
     Returns pts0, pts1 (M,2) float32 in ascending queryIdx order."""
     return _be(be).match(feat0, feat1)
 
+
+
+def img_downscale(img, downscale, be=None):
+    """sfm.py:35-42: `int(downscale / 2)` successive cv2.pyrDown calls (the reference's downscale = 2 halves once)."""
+    cv = _be(be).cv
+    for _ in range(int(downscale / 2)):
+        img = cv.pyrDown(img)
+    return img
+
+
+def features_from_images(images, depth=3):
+    """The detector half of find_features (sfm.py:243-252) for a whole sequence: BGR uint8 frames -> the `features` list
+    run_sfm takes, [(kp (n, 2) float32 pixel coordinates in cv2's keypoint order, des (n, 128) float32)].
+    Frames are uploaded once and go through cvtColor + SIFT on `depth` streams; one device->host copy per frame."""
+    from . import sift as _sift
+    dev = torch.device("cuda")
+    pipes, pending, feats = {}, [], []
+
+    def collect():
+        st, eng = pending.pop(0)
+        st.synchronize()
+        n, raw, cand = (int(v) for v in eng.count[:3].tolist())
+        if raw > eng.cap or cand > eng.cap:
+            raise _sift._lib.SfmHipError(f"SIFT found {max(raw, cand)} keypoints, more than max_keypoints={eng.cap}")
+        feats.append((eng.keypoints[:n, :2].cpu().numpy(), eng.descriptors[:n].cpu().numpy()))
+
+    for img in images:
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape[:2]
+        pipe = pipes.get((w, h))
+        if pipe is None:
+            pipe = pipes[(w, h)] = _sift.SiftPipeline(w, h, dev, depth=depth)
+        if len(pending) == depth:
+            collect()
+        d = torch.as_tensor(img).to(dev)
+        gray = _sift.bgr2gray(d) if d.dim() == 3 else d
+        _, st, eng = pipe.submit(gray)
+        gray.record_stream(st)
+        pending.append((st, eng))
+    while pending:
+        collect()
+    return feats
+
+
+def run_sfm_images(images, K, downscale=2, log=None, be=None):
+    """sfm.py's main loop from pixels: img_downscale (:40), cvtColor + SIFT (:243-252) and the driver (:274-423).
+    `images`: BGR uint8 frames in sequence order; K is scaled by the caller as in sfm.py:20-26."""
+    small = [img_downscale(im, downscale, be) for im in images]
+    return run_sfm(features_from_images(small), K, images=small, log=log, be=be)
 
 def Triangulation(P1, P2, pts1, pts2, K, repeat, be=None):
     """sfm.py:45-56."""

@@ -167,3 +167,36 @@ def scene_image(w, h, seed, shift=(0.0, 0.0)):
         ang, f, ph, a = rng.uniform(0, np.pi), rng.uniform(0.2, 1.2), rng.uniform(0, 6.28), rng.uniform(1, 5)
         img += a * np.sin((xx * np.cos(ang) + yy * np.sin(ang)) * f + ph)
     return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def layered_views(n_views, w, h, seed, f=None, baseline=0.25, depths=(10.0, 6.0, 4.0)):
+    """A synthetic image SEQUENCE with known geometry, for driving the pipeline from pixels: textured fronto-parallel
+    layers at `depths`, seen by a camera that translates along +x by `baseline` per view (no rotation), so layer l moves
+    by f * baseline / depth_l pixels per view and nearer layers occlude farther ones.
+    Returns (images: list of (h, w, 3) uint8 BGR, K (3, 3), P: list of 3x4 projection matrices)."""
+    f = float(f if f is not None else 0.9 * w)
+    K = np.array([[f, 0, w / 2.0], [0, f, h / 2.0], [0, 0, 1.0]])
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    shapes = []
+    for l in range(1, len(depths)):
+        s = []
+        for _ in range(5):
+            s.append((rng.uniform(-0.1, 1.3) * w, rng.uniform(0.05, 0.95) * h, rng.uniform(0.08, 0.2) * w, rng.uniform(0.1, 0.3) * h))
+        shapes.append(s)
+    images, P = [], []
+    for k in range(n_views):
+        b = k * baseline
+        img = scene_image(w, h, seed * 17 + 1, shift=(f * b / depths[0], 0.0)).astype(np.float64)
+        for l in range(1, len(depths)):
+            d = f * b / depths[l]
+            tex = scene_image(w, h, seed * 17 + 1 + l, shift=(d, 0.0))
+            mask = np.zeros((h, w), bool)
+            for cx, cy, a, bb in shapes[l - 1]:
+                mask |= (np.abs(xx + d - cx) < a) & (np.abs(yy - cy) < bb)
+            img = np.where(mask, tex, img)
+        g = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+        images.append(np.stack([g, g, g], -1))
+        Rt = np.hstack([np.eye(3), np.array([[-b], [0.0], [0.0]])])
+        P.append(K @ Rt)
+    return images, K, P

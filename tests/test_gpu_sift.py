@@ -126,3 +126,27 @@ def test_cv2compat_preprocessing(hip, oracle):
     assert small.shape == (45, 65, 3) and np.array_equal(small, oracle.pyrdown(bgr))
     gray = cv2.cvtColor(small, cv2.COLOR_BGR2GRAY)
     assert gray.shape == (45, 65) and np.array_equal(gray, oracle.bgr2gray(small))
+
+
+def test_driver_from_pixels_recovers_known_geometry(hip):
+    """sfm.py end to end from images: img_downscale(…, 2) -> cvtColor -> SIFT -> matcher -> essential matrix / PnP /
+    triangulation, on a rendered sequence with known cameras (translation along x, three depth layers)."""
+    from datagen import decompose_P, layered_views
+    from sfm_mvs_amd import pipeline as pl
+    images, K, P = layered_views(5, 400, 300, 4)
+    big = [np.repeat(np.repeat(im, 2, axis=0), 2, axis=1) for im in images]      # frames twice the working size
+    small = [pl.img_downscale(b, 2) for b in big]
+    assert small[0].shape == images[0].shape
+    feats = pl.features_from_images(images)
+    assert all(len(k) > 1500 and d.shape == (len(k), 128) for k, d in feats)
+    out = pl.run_sfm(feats, K, images=images)
+    pose = out["posearr"][9:].reshape(-1, 3, 4)
+    assert len(pose) == 5
+    for k, Pk in enumerate(pose):
+        R, t = decompose_P(K, Pk)
+        assert np.abs(R - np.eye(3)).max() < 5e-3
+        assert np.abs(-R.T @ t - np.array([k, 0.0, 0.0])).max() < 3e-2          # unit first baseline (recoverPose)
+    assert max(out["errors"]) < 1.0
+    Z = out["Xtot"][1:, 2] * 0.25                                              # metric scale: the true baseline is 0.25
+    near = [np.mean(np.abs(Z - d) < 0.15) for d in (10.0, 6.0, 4.0)]
+    assert sum(near) > 0.9 and min(near) > 0.05                                # the cloud sits on the three layers
