@@ -25,5 +25,10 @@ for wl in tri ba; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$wl -o $wl -- python $R/bench.py --workload $wl --steps 5 --warmup 1 > $OUT/bench_${wl}_under_rocprof.json 2>> $OUT/trace.log
   cp $OUT/trace_$wl/${wl}_kernel_stats.csv $OUT/${TAG}_${wl}_kernel_stats.csv
 done
-rm -rf $OUT/trace $OUT/trace1 $OUT/trace_tri $OUT/trace_ba
+# SIFT leg: one frame in flight (kernel durations as they are alone) and the default three
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_sift1 -o sift1 -- python $R/bench.py --workload sift --steps 30 --warmup 5 --pipe-depth 1 --no-cpu-baseline > $OUT/bench_sift_depth1_under_rocprof.json 2>> $OUT/trace.log
+cp $OUT/trace_sift1/sift1_kernel_stats.csv $OUT/${TAG}_sift_depth1_kernel_stats.csv
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_sift -o sift -- python $R/bench.py --workload sift --steps 30 --warmup 5 --no-cpu-baseline > $OUT/bench_sift_under_rocprof.json 2>> $OUT/trace.log
+cp $OUT/trace_sift/sift_kernel_stats.csv $OUT/${TAG}_sift_kernel_stats.csv
+rm -rf $OUT/trace $OUT/trace1 $OUT/trace_tri $OUT/trace_ba $OUT/trace_sift $OUT/trace_sift1
 ls $OUT

@@ -35,7 +35,7 @@ struct Taps { float k[kMaxTaps + 1]; int n; };
 // Scale-space geometry (octave o of a doubled base W0 x H0): planes are W0>>o by H0>>o; Gaussian planes of all
 // octaves are packed back to back, (nL+3) per octave, DoG planes (nL+2) per octave in a second region.
 struct Geom {
-    float* g; float* d; float* mag; float* ori; int W0, H0, nL, nOct;
+    float* g; float* d; float2* grad; int W0, H0, nL, nOct;   // grad: (magnitude, orientation) pairs
     __device__ __host__ int w(int o) const { return W0 >> o; }
     __device__ __host__ int h(int o) const { return H0 >> o; }
     __device__ __host__ size_t plane(int o) const { return (size_t)w(o) * h(o); }
@@ -61,6 +61,20 @@ __device__ inline int cv_floor(float v) { return (int)floorf(v); }
 __device__ inline float sift_expf(float x) {   // Cephes expf, fixed operation order (see the oracle)
     if (x < -80.f) x = -80.f;
     if (x > 80.f) x = 80.f;
+    const float n = rintf(x * 1.44269504f);
+    float r = x - n * 0.693359375f;
+    r = r - n * -2.12194440e-4f;
+    float p = 1.9875691500e-4f;
+    p = p * r + 1.3981999507e-3f;
+    p = p * r + 8.3334519073e-3f;
+    p = p * r + 4.1665795894e-2f;
+    p = p * r + 1.6666665459e-1f;
+    p = p * r + 5.0000001201e-1f;
+    const float y = p * (r * r) + r + 1.0f;
+    return y * __uint_as_float((unsigned)((int)n + 127) << 23);
+}
+
+__device__ inline float sift_expf_unclamped(float x) {   // sift_expf for |x| < 80, where its clamps are inactive
     const float n = rintf(x * 1.44269504f);
     float r = x - n * 0.693359375f;
     r = r - n * -2.12194440e-4f;
@@ -404,8 +418,7 @@ __global__ __launch_bounds__(256) void gradient_kernel(Geom geo) {
     const float dx = img[(size_t)y * w + x + 1] - img[(size_t)y * w + x - 1];
     const float dy = img[(size_t)(y - 1) * w + x] - img[(size_t)(y + 1) * w + x];
     const size_t at = geo.moff(o, layer) + (size_t)y * w + x;
-    geo.mag[at] = sqrtf(dx * dx + dy * dy);
-    geo.ori[at] = fast_atan2_deg(dy, dx);
+    geo.grad[at] = make_float2(sqrtf(dx * dx + dy * dy), fast_atan2_deg(dy, dx));
 }
 
 // ------------------------------------------------------------------------------------------------ orientation
@@ -425,8 +438,7 @@ __global__ __launch_bounds__(256) void orientation_kernel(Geom geo, const Cand* 
     if (id >= ncand) return;
     const Cand k = cand[id];
     const int w = geo.w(k.o), h = geo.h(k.o);
-    const float* gmag = geo.mag + geo.moff(k.o, k.layer);
-    const float* gori = geo.ori + geo.moff(k.o, k.layer);
+    const float2* grad = geo.grad + geo.moff(k.o, k.layer);
     const float scl_octv = k.size * 0.5f / (1 << k.o);
     const int radius = cv_round(kOriRadius * scl_octv);
     const float sigma = kOriSigFctr * scl_octv;
@@ -443,7 +455,8 @@ __global__ __launch_bounds__(256) void orientation_kernel(Geom geo, const Cand* 
             int bin = -1; float v = 0.f;
             if (!(y <= 0 || y >= h - 1 || x <= 0 || x >= w - 1)) {
                 const float W = sift_expf((i * i + j * j) * expf_scale);
-                const float ori = gori[(size_t)y * w + x], mag = gmag[(size_t)y * w + x];
+                const float2 mo = grad[(size_t)y * w + x];
+                const float ori = mo.y, mag = mo.x;
                 bin = cv_round((n / 360.f) * ori);
                 if (bin >= n) bin -= n;
                 if (bin < 0) bin += n;
@@ -641,7 +654,7 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom geo, const float* 
     for (int k = 0; k < kDescBinsUsed; ++k) mine[k] = 0.f;
 
     int w = 0, h = 0, px = 0, py = 0, radius = -1;
-    const float *gmag = nullptr, *gori = nullptr;
+    const float2* grad = nullptr;
     float ori = 0.f, cos_t = 0.f, sin_t = 0.f, hist_width = 1.f;
     if (live) {
         const float* q = kp + (size_t)id * 8;
@@ -654,8 +667,7 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom geo, const float* 
         if (fabsf(ori - 360.f) < FLT_EPSILON) ori = 0.f;
         const int o = octave + 1;
         w = geo.w(o); h = geo.h(o);
-        gmag = geo.mag + geo.moff(o, layer);
-        gori = geo.ori + geo.moff(o, layer);
+        grad = geo.grad + geo.moff(o, layer);
         px = cv_round(q[0] * scale); py = cv_round(q[1] * scale);
         const float scl = size * 0.5f;
         sift_sincos(ori * (float)(3.14159265358979323846 / 180), &sin_t, &cos_t);
@@ -665,48 +677,69 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom geo, const float* 
         cos_t /= hist_width; sin_t /= hist_width;
     }
     const float bins_per_rad = n / 360.f, exp_scale = -1.f / (d * d * 0.5f);
-    // footprint of my cell: r_rot in [ri-3.5, ri-1.5), c_rot in [ci-3.5, ci-1.5); pixel offsets (j, i) = hw^2 * R^T (c_rot, r_rot)
-    int imin = 1, imax = 0, jmin = 0, jmax = 0;
+    // Footprint of my cell: r_rot in [ri-3.5, ri-1.5), c_rot in [ci-3.5, ci-1.5) — a rotated square of side 2 hist_width
+    // centred (in pixel offsets from the keypoint) at T = hw^2 R^T (ci-2.5, ri-2.5).  All sixteen cells of a keypoint
+    // are translates of one square, so they share ONE walk: rows u and spans [v0(u), v1(u)] of the centred square
+    // dilated by the rounding of T (+ floor/ceil slack), visited at (i, j) = (round(T) + (u, v)).  The sixteen lanes
+    // stay in lockstep; the exact per-sample test below decides membership, the template only has to cover it.
+    int ti = 0, tj = 0, U = -1;
+    float inv_c = 0.f, inv_s = 0.f, B = 0.f;
+    bool use_c = false, use_s = false;
     if (live) {
         const float C = cos_t * hist_width * hist_width, S = sin_t * hist_width * hist_width;
-        float jlo = FLT_MAX, jhi = -FLT_MAX, ilo = FLT_MAX, ihi = -FLT_MAX;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float cr = ci - 3.5f + 2.f * (k & 1), rr = ri - 3.5f + 2.f * (k >> 1);
-            const float jj = C * cr + S * rr, ii = C * rr - S * cr;
-            jlo = fminf(jlo, jj); jhi = fmaxf(jhi, jj); ilo = fminf(ilo, ii); ihi = fmaxf(ihi, ii);
-        }
-        jmin = max(-radius, (int)floorf(jlo) - 1); jmax = min(radius, (int)ceilf(jhi) + 1);
-        imin = max(-radius, (int)floorf(ilo) - 1); imax = min(radius, (int)ceilf(ihi) + 1);
-        if (jmin > jmax) imin = imax + 1;
+        const float cc = ci - 2.5f, rc = ri - 2.5f;
+        tj = (int)rintf(C * cc + S * rc);
+        ti = (int)rintf(C * rc - S * cc);
+        const float ext = fabsf(cos_t) + fabsf(sin_t);
+        B = 1.f + 0.5f * ext + 1e-3f;
+        U = (int)ceilf(B * hist_width * hist_width * ext) + 1;
+        use_c = fabsf(cos_t) > 1e-4f; use_s = fabsf(sin_t) > 1e-4f;
+        inv_c = use_c ? 1.f / cos_t : 0.f; inv_s = use_s ? 1.f / sin_t : 0.f;
     }
-    int i = imin, j = jmin;
-    while (__any(i <= imax)) {
-        if (i <= imax) {
-            const float c_rot = j * cos_t - i * sin_t, r_rot = j * sin_t + i * cos_t;
-            float rbin = r_rot + d / 2 - 0.5f, cbin = c_rot + d / 2 - 0.5f;
-            const int r = py + i, c = px + j;
-            if (rbin > -1 && rbin < d && cbin > -1 && cbin < d && r > 0 && r < h - 1 && c > 0 && c < w - 1) {
-                const int r0 = cv_floor(rbin), c0 = cv_floor(cbin);
-                const int dr = ri - (r0 + 1), dc = ci - (c0 + 1);
-                if ((unsigned)dr <= 1u && (unsigned)dc <= 1u) {
-                    const float W = sift_expf((c_rot * c_rot + r_rot * r_rot) * exp_scale);
-                    float obin = (gori[(size_t)r * w + c] - ori) * bins_per_rad;
-                    const float mag = gmag[(size_t)r * w + c] * W;
-                    int o0 = cv_floor(obin);
-                    rbin -= r0; cbin -= c0; obin -= o0;
-                    if (o0 < 0) o0 += n;
-                    if (o0 >= n) o0 -= n;
-                    const float vr1 = mag * rbin;
-                    const float vr = dr ? vr1 : mag - vr1;
-                    const float vrc1 = vr * cbin;
-                    const float vrc = dc ? vrc1 : vr - vrc1;
-                    const float vo1 = vrc * obin, vo0 = vrc - vo1;
-                    mine[o0] += vo0;
-                    mine[o0 + 1] += vo1;
+    auto span = [&](int u, int& v0, int& v1) {
+        float lo = (float)(-radius - tj), hi = (float)(radius - tj);
+        if (use_c) { const float a = (u * sin_t - B) * inv_c, b = (u * sin_t + B) * inv_c; lo = fmaxf(lo, fminf(a, b)); hi = fminf(hi, fmaxf(a, b)); }
+        if (use_s) { const float a = (-u * cos_t - B) * inv_s, b = (-u * cos_t + B) * inv_s; lo = fmaxf(lo, fminf(a, b)); hi = fminf(hi, fmaxf(a, b)); }
+        v0 = (int)floorf(lo); v1 = (int)ceilf(hi);
+        if (ti + u < -radius || ti + u > radius) v1 = v0 - 1;
+    };
+    int u = -U, v = 0, vend = -1;
+    bool active = live;
+    if (active) span(u, v, vend);
+    while (__any(active)) {
+        if (active) {
+            if (v > vend) {
+                if (++u > U) active = false;
+                else span(u, v, vend);
+            } else {
+                const int i = ti + u, j = tj + v;
+                ++v;
+                const float c_rot = j * cos_t - i * sin_t, r_rot = j * sin_t + i * cos_t;
+                float rbin = r_rot + d / 2 - 0.5f, cbin = c_rot + d / 2 - 0.5f;
+                const int r = py + i, c = px + j;
+                if (rbin > -1 && rbin < d && cbin > -1 && cbin < d && r > 0 && r < h - 1 && c > 0 && c < w - 1 && j >= -radius && j <= radius) {
+                    const int r0 = cv_floor(rbin), c0 = cv_floor(cbin);
+                    const int dr = ri - (r0 + 1), dc = ci - (c0 + 1);
+                    if ((unsigned)dr <= 1u && (unsigned)dc <= 1u) {
+                        const unsigned at = (unsigned)(r * w + c);
+                        const float W = sift_expf_unclamped((c_rot * c_rot + r_rot * r_rot) * exp_scale);   // argument in (-1.6, 0]
+                        const float2 mo = grad[at];
+                        float obin = (mo.y - ori) * bins_per_rad;
+                        const float mag = mo.x * W;
+                        int o0 = cv_floor(obin);
+                        rbin -= r0; cbin -= c0; obin -= o0;
+                        if (o0 < 0) o0 += n;
+                        if (o0 >= n) o0 -= n;
+                        const float vr1 = mag * rbin;
+                        const float vr = dr ? vr1 : mag - vr1;
+                        const float vrc1 = vr * cbin;
+                        const float vrc = dc ? vrc1 : vr - vrc1;
+                        const float vo1 = vrc * obin, vo0 = vrc - vo1;
+                        mine[o0] += vo0;
+                        mine[o0 + 1] += vo1;
+                    }
                 }
             }
-            if (++j > jmax) { j = jmin; ++i; }
         }
     }
     // circular orientation: bin n folds onto bin 0 (bin n+1, which would fold onto 1, is never written)
@@ -794,8 +827,7 @@ extern "C" size_t sfm_sift_ws_bytes(int64_t w, int64_t h, int n_octave_layers, i
     c.take<float>(L.up_floats);
     c.take<float>(L.g_floats);
     c.take<float>(L.d_floats);
-    c.take<float>(L.m_floats);
-    c.take<float>(L.m_floats);
+    c.take<float2>(L.m_floats);
     c.take<int>((size_t)max_keypoints);
     c.take<Cand>((size_t)max_keypoints);
     c.take<float>((size_t)max_keypoints * 8);
@@ -825,8 +857,7 @@ extern "C" int sfm_sift_detect_and_compute(const uint8_t* gray, int64_t w, int64
     Geom geo;
     geo.g = c.take<float>(L.g_floats);
     geo.d = c.take<float>(L.d_floats);
-    geo.mag = c.take<float>(L.m_floats);
-    geo.ori = c.take<float>(L.m_floats);
+    geo.grad = c.take<float2>(L.m_floats);
     int* perm = c.take<int>((size_t)max_keypoints);
     geo.W0 = (int)(2 * w); geo.H0 = (int)(2 * h); geo.nL = nL; geo.nOct = L.nOct;
     Cand* cand = c.take<Cand>((size_t)cap);
