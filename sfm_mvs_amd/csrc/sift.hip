@@ -32,6 +32,12 @@ constexpr int kMaxOctaves = 16;
 
 struct Taps { float k[kMaxTaps + 1]; int n; };
 
+// device counters: [0] refined extrema, [1] keypoints (one per orientation peak), [2] keypoints after duplicate removal,
+// [kCntHist..) keypoints per x range, [kCntCursor..) scatter cursors of the ordering pass
+constexpr int kXBuckets = 256, kCntHist = 64, kCntCursor = kCntHist + kXBuckets, kCounterInts = kCntCursor + kXBuckets;
+__device__ inline int x_bucket(float x, int W0) { return min(kXBuckets - 1, max(0, (int)(x * ((float)kXBuckets / (float)W0)))); }
+
+
 // Scale-space geometry (octave o of a doubled base W0 x H0): planes are W0>>o by H0>>o; Gaussian planes of all
 // octaves are packed back to back, (nL+3) per octave, DoG planes (nL+2) per octave in a second region.
 struct Geom {
@@ -488,7 +494,10 @@ __global__ __launch_bounds__(256) void orientation_kernel(Geom geo, const Cand* 
     const bool peak = lane < n && hv > hl && hv > hr && hv >= mag_thr;
     const unsigned long long bal = __ballot(peak);
     int slot0 = 0;
-    if (lane == 0) slot0 = atomicAdd(&counters[1], __popcll(bal));
+    if (lane == 0 && bal) {
+        slot0 = atomicAdd(&counters[1], __popcll(bal));
+        atomicAdd(&counters[kCntHist + x_bucket(k.x, geo.W0)], __popcll(bal));
+    }
     slot0 = __shfl(slot0, 0);
     if (peak) {
         float bin = lane + 0.5f * (hl - hr) / (hl - 2 * hv + hr);
@@ -519,53 +528,73 @@ __device__ inline bool key_before(const Key& a, int ia, const Key& b, int ib) {
     return ia < ib;
 }
 
-__device__ inline unsigned ordered_bits(float f) {   // monotone map float -> uint32
-    const unsigned u = __float_as_uint(f);
-    return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
+// Ordering in two levels.  Keypoints are first binned by x into kXBuckets ranges of the (doubled) image width — the
+// histogram is filled by the orientation kernel as it appends keypoints — and scattered bucket by bucket
+// (unordered inside a bucket); then each keypoint counts the members of its own bucket that are ordered before it
+// (full comparison cascade; ~n / 256 candidates instead of n).  Buckets are monotone in x, the primary key, so
+// bucket start + rank inside the bucket is the global rank.
+
+__device__ inline void bucket_starts(const int* __restrict__ counters, int* start /* LDS [kXBuckets + 1] */) {   // 256 threads
+    __shared__ int wtot[4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int v = counters[kCntHist + t];
+    int inc = v;
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) { const int o = __shfl_up(inc, sft); if (lane >= sft) inc += o; }
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int k = 0; k < wave; ++k) base += wtot[k];
+    start[t] = base + inc - v;
+    if (t == 255) start[256] = base + inc;
+    __syncthreads();
 }
 
-constexpr int kRankSplit = 32;   // blockIdx.y: each workgroup of a 256-keypoint row tile visits every 32nd column tile
-// rank[i] += number of keypoints of the visited column tiles that are ordered before keypoint i.  (x, y) decide
-// almost every comparison, so they are packed into one 64-bit key; the full cascade runs only on (x, y) ties
-// (the several orientations of one extremum).
-__global__ __launch_bounds__(256) void rank_kernel(const float* __restrict__ kp_raw, const int* __restrict__ counters, int cap, int* __restrict__ rank) {
-    __shared__ unsigned long long tkey[256];
-    __shared__ Key tile[256];
+__global__ __launch_bounds__(256) void bucket_scatter_kernel(const float* __restrict__ kp_raw, int* __restrict__ counters, int cap, int W0,
+                                                             float* __restrict__ kp_bucketed) {
+    __shared__ int start[kXBuckets + 1];
     const int n = min(counters[1], cap);
     if ((int)(blockIdx.x * 256) >= n) return;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    Key me = {0, 0, 0, 0, 0, 0};
-    if (i < n) { const float* q = kp_raw + (size_t)i * 8; me = {q[0], q[1], q[2], q[3], q[4], __float_as_int(q[5])}; }
-    const unsigned long long mykey = ((unsigned long long)ordered_bits(me.x) << 32) | ordered_bits(me.y);
-    int r = 0;
-    for (int base = blockIdx.y * 256; base < n; base += kRankSplit * 256) {
-        __syncthreads();
-        if (base + (int)threadIdx.x < n) {
-            const float* q = kp_raw + (size_t)(base + threadIdx.x) * 8;
-            const Key k = {q[0], q[1], q[2], q[3], q[4], __float_as_int(q[5])};
-            tile[threadIdx.x] = k;
-            tkey[threadIdx.x] = ((unsigned long long)ordered_bits(k.x) << 32) | ordered_bits(k.y);
-        }
-        __syncthreads();
-        const int m = min(256, n - base);
-        if (i < n)
-            for (int j = 0; j < m; ++j) {
-                const unsigned long long kj = tkey[j];
-                if (kj < mykey) ++r;
-                else if (kj == mykey) r += key_before(tile[j], base + j, me, i) ? 1 : 0;
-            }
-    }
-    if (i < n && r) atomicAdd(&rank[i], r);
-}
-
-__global__ __launch_bounds__(256) void scatter_kernel(const float* __restrict__ kp_raw, const int* __restrict__ counters, int cap,
-                                                      const int* __restrict__ rank, float* __restrict__ kp_sorted) {
-    const int n = min(counters[1], cap);
+    bucket_starts(counters, start);
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const float4* s = reinterpret_cast<const float4*>(kp_raw + (size_t)i * 8);
-    float4* d = reinterpret_cast<float4*>(kp_sorted + (size_t)rank[i] * 8);
-    d[0] = s[0]; d[1] = s[1];
+    const float4* src = reinterpret_cast<const float4*>(kp_raw + (size_t)i * 8);
+    const float4 a = src[0], b = src[1];
+    const int bk = x_bucket(a.x, W0);
+    const int pos = start[bk] + atomicAdd(&counters[kCntCursor + bk], 1);
+    if (pos < cap) {
+        float4* d = reinterpret_cast<float4*>(kp_bucketed + (size_t)pos * 8);
+        d[0] = a; d[1] = b;
+    }
+}
+
+__global__ __launch_bounds__(256) void bucket_rank_kernel(const float* __restrict__ kp_bucketed, const int* __restrict__ counters, int cap, int W0,
+                                                          float* __restrict__ kp_sorted) {
+    __shared__ int start[kXBuckets + 1];
+    const int n = min(counters[1], cap);
+    if ((int)(blockIdx.x * 256) >= n) return;
+    bucket_starts(counters, start);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = reinterpret_cast<const float4*>(kp_bucketed + (size_t)i * 8)[0], b = reinterpret_cast<const float4*>(kp_bucketed + (size_t)i * 8)[1];
+    const Key me = {a.x, a.y, a.z, a.w, b.x, __float_as_int(b.y)};
+    const int bk = x_bucket(a.x, W0);
+    const int lo = start[bk], hi = min(start[bk + 1], n);
+    int r = 0;
+    for (int j = lo; j < hi; ++j) {
+        const float4 c = reinterpret_cast<const float4*>(kp_bucketed + (size_t)j * 8)[0];
+        if (c.x != me.x || c.y != me.y) r += (c.x < me.x || (c.x == me.x && c.y < me.y)) ? 1 : 0;
+        else {
+            const float4 e = reinterpret_cast<const float4*>(kp_bucketed + (size_t)j * 8)[1];
+            const Key other = {c.x, c.y, c.z, c.w, e.x, __float_as_int(e.y)};
+            r += key_before(other, j, me, i) ? 1 : 0;
+        }
+    }
+    const int pos = lo + r;
+    if (pos < cap) {
+        float4* d = reinterpret_cast<float4*>(kp_sorted + (size_t)pos * 8);
+        d[0] = a; d[1] = b;
+    }
 }
 
 // single workgroup: drop keypoints equal to their predecessor in (x, y, size, angle), keep the order, undo the 2x
@@ -832,8 +861,7 @@ extern "C" size_t sfm_sift_ws_bytes(int64_t w, int64_t h, int n_octave_layers, i
     c.take<Cand>((size_t)max_keypoints);
     c.take<float>((size_t)max_keypoints * 8);
     c.take<float>((size_t)max_keypoints * 8);
-    c.take<int>(64);
-    c.take<int>((size_t)max_keypoints);
+    c.take<int>(kCounterInts);
     return c.used();
 }
 
@@ -863,8 +891,7 @@ extern "C" int sfm_sift_detect_and_compute(const uint8_t* gray, int64_t w, int64
     Cand* cand = c.take<Cand>((size_t)cap);
     float* kp_raw = c.take<float>((size_t)cap * 8);
     float* kp_sorted = c.take<float>((size_t)cap * 8);
-    int* counters = c.take<int>(64);
-    int* rank = c.take<int>((size_t)cap);
+    int* counters = c.take<int>(kCounterInts);
 
     // per-layer blur taps: sig[i]^2 = (sigma k^i)^2 - (sigma k^(i-1))^2, k = 2^(1/nL); the base blur lifts the assumed
     // 0.5 px camera blur (1.0 after doubling) to sigma
@@ -881,7 +908,7 @@ extern "C" int sfm_sift_detect_and_compute(const uint8_t* gray, int64_t w, int64
                           kMaxTaps);
         }
     }
-    SFM_CHECK_HIP(hipMemsetAsync(counters, 0, (size_t)((char*)(rank + cap) - (char*)counters), stream));   // counters and, behind them, rank
+    SFM_CHECK_HIP(hipMemsetAsync(counters, 0, kCounterInts * sizeof(int), stream));
     auto grid2 = [](int ww, int hh) { return dim3((unsigned)((ww + 63) / 64), (unsigned)((hh + 3) / 4)); };
     auto tiles = [](int ww, int hh) { return dim3((unsigned)((ww + kTileW - 1) / kTileW), (unsigned)((hh + kTileH - 1) / kTileH)); };
     auto launch_blur = [&](dim3 grid, const float* in, float* out, float* dg, int ww, int hh, const Taps& t) {
@@ -934,13 +961,13 @@ extern "C" int sfm_sift_detect_and_compute(const uint8_t* gray, int64_t w, int64
     const unsigned wave_blocks = (unsigned)((cap + 3) / 4);
     hipLaunchKernelGGL(orientation_kernel, dim3(wave_blocks), dim3(256), 0, stream, geo, (const Cand*)cand, counters, cap, kp_raw);
     SFM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(rank_kernel, dim3((unsigned)((cap + 255) / 256), kRankSplit), dim3(256), 0, stream, (const float*)kp_raw, (const int*)counters,
-                       cap, rank);
+    hipLaunchKernelGGL(bucket_scatter_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, stream, (const float*)kp_raw, counters, cap, geo.W0,
+                       kp_sorted);
     SFM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(scatter_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, stream, (const float*)kp_raw, (const int*)counters, cap,
-                       (const int*)rank, kp_sorted);
+    hipLaunchKernelGGL(bucket_rank_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, stream, (const float*)kp_sorted, (const int*)counters, cap,
+                       geo.W0, kp_raw);
     SFM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(dedupe_kernel, dim3(1), dim3(1024), 0, stream, (const float*)kp_sorted, counters, cap, keypoints, count, nL, perm);
+    hipLaunchKernelGGL(dedupe_kernel, dim3(1), dim3(1024), 0, stream, (const float*)kp_raw, counters, cap, keypoints, count, nL, perm);
     SFM_CHECK_LAUNCH();
     if (descriptors) {
         sfm::prof_begin(sfm::kProfSiftDescriptor, stream);
