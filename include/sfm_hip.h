@@ -288,8 +288,9 @@ int sfm_host_epnp(const double* K_host, const double* Xw_host, const double* uv_
  *                   octave (int32 bits, OpenCV packing), class_id (int32 bits, -1), 0
  *   descriptors_dev [max_keypoints x 128] float32 (NULL: detect only)
  *   count_dev       int32[4]: [0] keypoints written (ordered), [1] keypoints before
- *                   duplicate removal, [2] refined extrema; [1] or [2] > max_keypoints
- *                   means the capacity was exceeded and the output is truncated
+ *                   duplicate removal, [2] refined extrema, [3] raw extrema (before the
+ *                   contrast / edge tests); [1] or [2] > max_keypoints, or [3] >
+ *                   8 * max_keypoints, means a capacity was exceeded and the output is truncated
  * Blur kernels longer than 55 taps (a per-layer sigma above 6.8) are rejected with
  * SFM_ERR_ARG; the defaults (3, 0.04, 10, 1.6) need 27.
  * ---------------------------------------------------------------------- */

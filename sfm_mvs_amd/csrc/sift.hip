@@ -33,8 +33,11 @@ constexpr int kMaxOctaves = 16;
 struct Taps { float k[kMaxTaps + 1]; int n; };
 
 // device counters: [0] refined extrema, [1] keypoints (one per orientation peak), [2] keypoints after duplicate removal,
-// [kCntHist..) keypoints per x range, [kCntCursor..) scatter cursors of the ordering pass
-constexpr int kXBuckets = 256, kCntHist = 64, kCntCursor = kCntHist + kXBuckets, kCounterInts = kCntCursor + kXBuckets;
+// [3] raw extrema (before refinement; summed from the kRawSegs segment counters at kCntRawSeg), [4] largest overflowing
+// raw segment count (0 = none), [5] the same for the keypoint segments at kCntKpSeg, [kCntHist..) keypoints per x range, [kCntCursor..) scatter cursors of the ordering pass
+constexpr int kXBuckets = 256, kCntHist = 64, kCntCursor = kCntHist + kXBuckets;
+constexpr int kRawSegs = 64, kSegStride = 32, kCntRawSeg = kCntCursor + kXBuckets, kCntKpSeg = kCntRawSeg + kRawSegs * kSegStride,
+              kCounterInts = kCntKpSeg + kRawSegs * kSegStride;
 __device__ inline int x_bucket(float x, int W0) { return min(kXBuckets - 1, max(0, (int)(x * ((float)kXBuckets / (float)W0)))); }
 
 
@@ -374,37 +377,75 @@ __device__ __host__ inline int extrema_tiles(const Geom& g, int o) {
     return iw > 0 && ih > 0 ? ((iw + 63) / 64) * ((ih + 3) / 4) * g.nL : 0;
 }
 
-__global__ __launch_bounds__(256) void extrema_kernel(Geom geo, int threshold, float contrastThreshold, float edgeThreshold, float sigma,
-                                                      Cand* __restrict__ cand, int* __restrict__ counters, int cap) {
+__global__ __launch_bounds__(256) void extrema_kernel(Geom geo, int threshold, int4* __restrict__ raw, int raw_cap, int* __restrict__ counters) {
     int o = 0, t = blockIdx.x;
     for (;; ++o) { const int k = extrema_tiles(geo, o); if (t < k) break; t -= k; }
     const int w = geo.w(o), h = geo.h(o);
     const int tx = (w - 2 * kImgBorder + 63) / 64, ty = (h - 2 * kImgBorder + 3) / 4;
     const int layer = 1 + t / (tx * ty);
     t -= (layer - 1) * tx * ty;
-    const int c = kImgBorder + (t % tx) * 64 + (threadIdx.x & 63), r = kImgBorder + (t / tx) * 4 + (threadIdx.x >> 6);
-    if (c >= w - kImgBorder || r >= h - kImgBorder) return;
-    const size_t plane = geo.plane(o);
-    const float* dog = geo.D(o, 0);
-    const float* img = dog + plane * layer + (size_t)r * w + c;
-    const float val = img[0];
-    if (!(fabsf(val) > (float)threshold)) return;
-    bool is_max = val > 0, is_min = val < 0;
+    const int lane = threadIdx.x & 63;
+    const int c = kImgBorder + (t % tx) * 64 + lane, r = kImgBorder + (t / tx) * 4 + (threadIdx.x >> 6);
+    bool ext = false;
+    if (c < w - kImgBorder && r < h - kImgBorder) {
+        const size_t plane = geo.plane(o);
+        const float* img = geo.D(o, 0) + plane * layer + (size_t)r * w + c;
+        const float val = img[0];
+        if (fabsf(val) > (float)threshold) {
+            bool is_max = val > 0, is_min = val < 0;
 #pragma unroll
-    for (int dl = -1; dl <= 1; ++dl)
+            for (int dl = -1; dl <= 1; ++dl)
 #pragma unroll
-        for (int dr = -1; dr <= 1; ++dr)
+                for (int dr = -1; dr <= 1; ++dr)
 #pragma unroll
-            for (int dc = -1; dc <= 1; ++dc) {
-                const float v = img[(long)dl * (long)plane + dr * w + dc];
-                is_max = is_max && val >= v;
-                is_min = is_min && val <= v;
-            }
-    if (!is_max && !is_min) return;
+                    for (int dc = -1; dc <= 1; ++dc) {
+                        const float v = img[(long)dl * (long)plane + dr * w + dc];
+                        is_max = is_max && val >= v;
+                        is_min = is_min && val <= v;
+                    }
+            ext = is_max || is_min;
+        }
+    }
+    // The raw list is kRawSegs independent segments, each with its own counter on its own cache line: tens of
+    // thousands of atomics on ONE address serialise in L2 (they, not the 27 loads, bounded this kernel: 250 us).
+    const unsigned long long bal = __ballot(ext);
+    if (bal) {                                                                  // wave-uniform: one atomic per wave
+        const int seg = blockIdx.x % kRawSegs, seg_cap = raw_cap / kRawSegs;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&counters[kCntRawSeg + seg * kSegStride], __popcll(bal));
+        base = __shfl(base, 0);
+        const int at = base + __popcll(bal & ((1ull << lane) - 1ull));
+        if (ext && at < seg_cap) raw[(size_t)seg * seg_cap + at] = make_int4(o, layer, r, c);
+    }
+}
+
+constexpr int kRawPerKeypoint = 8;   // capacity of the raw-extrema list (before contrast / edge rejection) per keypoint slot
+
+// sub-pixel refinement, contrast and edge tests of the raw extrema: one lane each
+__global__ __launch_bounds__(256) void refine_kernel(Geom geo, const int4* __restrict__ raw, int raw_cap, float contrastThreshold, float edgeThreshold,
+                                                     float sigma, Cand* __restrict__ cand, int* __restrict__ counters, int cap) {
+    const int seg_cap = raw_cap / kRawSegs;
+    const int id = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+    const int seg = id / seg_cap, at = id - seg * seg_cap;
+    bool ok = false;
     Cand k;
-    if (!adjust_local_extrema(dog, w, h, plane, o, layer, r, c, geo.nL, contrastThreshold, edgeThreshold, sigma, &k)) return;
-    const int slot = atomicAdd(&counters[0], 1);
-    if (slot < cap) cand[slot] = k;
+    if (seg < kRawSegs) {
+        const int cnt = counters[kCntRawSeg + seg * kSegStride];
+        if (at == 0) { atomicAdd(&counters[3], cnt); if (cnt > seg_cap) atomicMax(&counters[4], cnt); }   // totals for the caller
+        if (at < min(cnt, seg_cap)) {
+            const int4 e = raw[(size_t)seg * seg_cap + at];
+            ok = adjust_local_extrema(geo.D(e.x, 0), geo.w(e.x), geo.h(e.x), geo.plane(e.x), e.x, e.y, e.z, e.w, geo.nL, contrastThreshold, edgeThreshold,
+                                      sigma, &k);
+        }
+    }
+    const unsigned long long bal = __ballot(ok);
+    if (bal) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&counters[0], __popcll(bal));
+        base = __shfl(base, 0);
+        const int slot = base + __popcll(bal & ((1ull << lane) - 1ull));
+        if (ok && slot < cap) cand[slot] = k;
+    }
 }
 
 // Gradient magnitude and orientation (degrees, OpenCV's fastAtan2) of every interior pixel of Gaussian layers
@@ -435,8 +476,8 @@ constexpr int kOriChunk = 1024;
 // appended unordered; the sort below fixes the order.
 __global__ __launch_bounds__(256) void orientation_kernel(Geom geo, const Cand* __restrict__ cand, int* __restrict__ counters, int cap,
                                                           float* __restrict__ kp_raw) {
-    __shared__ float sval[4][kOriChunk];
-    __shared__ signed char sbin[4][kOriChunk];
+    __shared__ __attribute__((aligned(16))) float sval[4][kOriChunk];
+    __shared__ __attribute__((aligned(16))) unsigned char sbin[4][kOriChunk];      // 255 = no sample
     __shared__ float shist[4][kOriBins + 4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int id = blockIdx.x * 4 + wave;
@@ -453,13 +494,13 @@ __global__ __launch_bounds__(256) void orientation_kernel(Geom geo, const Cand* 
     const int n = kOriBins;
     float acc = 0.f;   // lane b: temphist[b]
     for (int base = 0; base < total; base += kOriChunk) {
-        const int m = min(kOriChunk, total - base);
-        for (int e = lane; e < m; e += 64) {
+        const int m = min(kOriChunk, total - base), m16 = (m + 15) & ~15;
+        for (int e = lane; e < m16; e += 64) {
             const int idx = base + e;
             const int i = idx / side - radius, j = idx % side - radius;
             const int y = k.r + i, x = k.c + j;
-            int bin = -1; float v = 0.f;
-            if (!(y <= 0 || y >= h - 1 || x <= 0 || x >= w - 1)) {
+            int bin = 255; float v = 0.f;
+            if (e < m && !(y <= 0 || y >= h - 1 || x <= 0 || x >= w - 1)) {
                 const float W = sift_expf((i * i + j * j) * expf_scale);
                 const float2 mo = grad[(size_t)y * w + x];
                 const float ori = mo.y, mag = mo.x;
@@ -468,12 +509,21 @@ __global__ __launch_bounds__(256) void orientation_kernel(Geom geo, const Cand* 
                 if (bin < 0) bin += n;
                 v = W * mag;
             }
-            sbin[wave][e] = (signed char)bin; sval[wave][e] = v;
+            sbin[wave][e] = (unsigned char)bin; sval[wave][e] = v;
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes are visible
-        for (int e = 0; e < m; ++e)
-            if (sbin[wave][e] == lane) acc += sval[wave][e];
+        // lane b adds the samples of bin b in raster order, 16 samples per LDS round trip; the others add +0, which leaves
+        // a non-negative float sum unchanged (every addend W * mag is >= +0)
+        for (int e = 0; e < m16; e += 16) {
+            const uint4 b16 = *reinterpret_cast<const uint4*>(&sbin[wave][e]);
+            const float4* vp = reinterpret_cast<const float4*>(&sval[wave][e]);
+            const float4 v0 = vp[0], v1 = vp[1], v2 = vp[2], v3 = vp[3];
+            const unsigned bw[4] = {b16.x, b16.y, b16.z, b16.w};
+            const float vv[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+#pragma unroll
+            for (int t = 0; t < 16; ++t) acc += ((bw[t >> 2] >> (8 * (t & 3))) & 255u) == (unsigned)lane ? vv[t] : 0.f;
+        }
         __builtin_amdgcn_wave_barrier();
     }
     float* th = &shist[wave][2];
@@ -494,8 +544,9 @@ __global__ __launch_bounds__(256) void orientation_kernel(Geom geo, const Cand* 
     const bool peak = lane < n && hv > hl && hv > hr && hv >= mag_thr;
     const unsigned long long bal = __ballot(peak);
     int slot0 = 0;
+    const int seg = blockIdx.x % kRawSegs, seg_cap = cap / kRawSegs;          // segmented list, see extrema_kernel
     if (lane == 0 && bal) {
-        slot0 = atomicAdd(&counters[1], __popcll(bal));
+        slot0 = atomicAdd(&counters[kCntKpSeg + seg * kSegStride], __popcll(bal));
         atomicAdd(&counters[kCntHist + x_bucket(k.x, geo.W0)], __popcll(bal));
     }
     slot0 = __shfl(slot0, 0);
@@ -505,8 +556,8 @@ __global__ __launch_bounds__(256) void orientation_kernel(Geom geo, const Cand* 
         float angle = 360.f - (360.f / n) * bin;
         if (fabsf(angle - 360.f) < FLT_EPSILON) angle = 0.f;
         const int slot = slot0 + __popcll(bal & ((1ull << lane) - 1ull));
-        if (slot < cap) {
-            float* q = kp_raw + (size_t)slot * 8;
+        if (slot < seg_cap) {
+            float* q = kp_raw + ((size_t)seg * seg_cap + slot) * 8;
             q[0] = k.x; q[1] = k.y; q[2] = k.size; q[3] = angle; q[4] = k.response; q[5] = __int_as_float(k.octave); q[6] = __int_as_float(-1); q[7] = 0.f;
         }
     }
@@ -553,12 +604,15 @@ __device__ inline void bucket_starts(const int* __restrict__ counters, int* star
 __global__ __launch_bounds__(256) void bucket_scatter_kernel(const float* __restrict__ kp_raw, int* __restrict__ counters, int cap, int W0,
                                                              float* __restrict__ kp_bucketed) {
     __shared__ int start[kXBuckets + 1];
-    const int n = min(counters[1], cap);
-    if ((int)(blockIdx.x * 256) >= n) return;
     bucket_starts(counters, start);
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float4* src = reinterpret_cast<const float4*>(kp_raw + (size_t)i * 8);
+    const int seg_cap = cap / kRawSegs;
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    const int seg = id / max(seg_cap, 1), at = id - seg * seg_cap;
+    if (seg >= kRawSegs || seg_cap == 0) return;
+    const int cnt = counters[kCntKpSeg + seg * kSegStride];
+    if (at == 0) { atomicAdd(&counters[1], min(cnt, seg_cap)); if (cnt > seg_cap) atomicMax(&counters[5], cnt); }   // dense count for the next kernels
+    if (at >= min(cnt, seg_cap)) return;
+    const float4* src = reinterpret_cast<const float4*>(kp_raw + ((size_t)seg * seg_cap + at) * 8);
     const float4 a = src[0], b = src[1];
     const int bk = x_bucket(a.x, W0);
     const int pos = start[bk] + atomicAdd(&counters[kCntCursor + bk], 1);
@@ -638,7 +692,7 @@ __global__ __launch_bounds__(1024) void dedupe_kernel(const float* __restrict__ 
         if (threadIdx.x == 0) base_s += total;
         __syncthreads();
     }
-    if (threadIdx.x == 0) { counters[2] = base_s; count_out[0] = base_s; count_out[1] = counters[1]; count_out[2] = counters[0]; }
+    if (threadIdx.x == 0) { counters[2] = base_s; count_out[0] = base_s; count_out[1] = counters[5] ? 0x7fffffff : counters[1]; count_out[2] = counters[0]; count_out[3] = counters[4] ? 0x7fffffff : counters[3]; }
     // processing order of the descriptor kernel: keypoints bucketed by window size (layer and sub-layer offset are
     // packed in the octave field), largest first, so that the four keypoints sharing a wave take equally long
     const int nout = min(base_s, cap);
@@ -862,6 +916,7 @@ extern "C" size_t sfm_sift_ws_bytes(int64_t w, int64_t h, int n_octave_layers, i
     c.take<float>((size_t)max_keypoints * 8);
     c.take<float>((size_t)max_keypoints * 8);
     c.take<int>(kCounterInts);
+    c.take<int4>((size_t)max_keypoints * kRawPerKeypoint);
     return c.used();
 }
 
@@ -892,6 +947,8 @@ extern "C" int sfm_sift_detect_and_compute(const uint8_t* gray, int64_t w, int64
     float* kp_raw = c.take<float>((size_t)cap * 8);
     float* kp_sorted = c.take<float>((size_t)cap * 8);
     int* counters = c.take<int>(kCounterInts);
+    const int raw_cap = (int)std::min<size_t>((size_t)cap * kRawPerKeypoint, (size_t)1 << 30);
+    int4* raw = c.take<int4>((size_t)cap * kRawPerKeypoint);
 
     // per-layer blur taps: sig[i]^2 = (sigma k^i)^2 - (sigma k^(i-1))^2, k = 2^(1/nL); the base blur lifts the assumed
     // 0.5 px camera blur (1.0 after doubling) to sigma
@@ -951,8 +1008,10 @@ extern "C" int sfm_sift_detect_and_compute(const uint8_t* gray, int64_t w, int64
         for (int o = 0; o < geo.nOct; ++o) { total_tiles += extrema_tiles(geo, o); grad_px += geo.plane(o) * nL; }
         if (total_tiles > 0) {
             const int threshold = (int)std::floor(0.5 * contrast_threshold / nL * 255);
-            hipLaunchKernelGGL(extrema_kernel, dim3((unsigned)total_tiles), dim3(256), 0, stream, geo, threshold, (float)contrast_threshold,
-                               (float)edge_threshold, (float)sigma, cand, counters, cap);
+            hipLaunchKernelGGL(extrema_kernel, dim3((unsigned)total_tiles), dim3(256), 0, stream, geo, threshold, raw, raw_cap, counters);
+            SFM_CHECK_LAUNCH();
+            hipLaunchKernelGGL(refine_kernel, dim3((unsigned)((raw_cap + 255) / 256)), dim3(256), 0, stream, geo, (const int4*)raw, raw_cap,
+                               (float)contrast_threshold, (float)edge_threshold, (float)sigma, cand, counters, cap);
             SFM_CHECK_LAUNCH();
         }
         hipLaunchKernelGGL(gradient_kernel, dim3((unsigned)((grad_px + 255) / 256)), dim3(256), 0, stream, geo);

@@ -80,9 +80,7 @@ def features_from_images(images, depth=3):
     def collect():
         st, eng = pending.pop(0)
         st.synchronize()
-        n, raw, cand = (int(v) for v in eng.count[:3].tolist())
-        if raw > eng.cap or cand > eng.cap:
-            raise _sift._lib.SfmHipError(f"SIFT found {max(raw, cand)} keypoints, more than max_keypoints={eng.cap}")
+        n = eng.check_capacity()
         feats.append((eng.keypoints[:n, :2].cpu().numpy(), eng.descriptors[:n].cpu().numpy()))
 
     for img in images:

@@ -70,12 +70,17 @@ class Sift:
                 _lib.ptr(self.descriptors) if want_descriptors else None, _lib.ptr(self.count), _lib.ptr(self.ws),
                 ctypes.c_size_t(self.ws.numel()), _lib.stream_ptr()), "sfm_sift_detect_and_compute")
 
+    def check_capacity(self):
+        """Read the device counters (synchronises); raise if any internal list overflowed; return the keypoint count."""
+        n, raw, cand, extrema = (int(v) for v in self.count.tolist())
+        if raw > self.cap or cand > self.cap or extrema > 8 * self.cap:
+            raise _lib.SfmHipError(f"SIFT found {max(raw, cand, extrema // 8)} keypoints, more than max_keypoints={self.cap}")
+        return n
+
     def run(self, gray, want_descriptors=True):
         """-> (keypoints (n, 8) f32, descriptors (n, 128) f32 or None), device views.  One device->host read (the count)."""
         self.launch(gray, want_descriptors)
-        n, raw, cand = (int(v) for v in self.count[:3].tolist())
-        if raw > self.cap or cand > self.cap:
-            raise _lib.SfmHipError(f"SIFT found {max(raw, cand)} keypoints, more than max_keypoints={self.cap}")
+        n = self.check_capacity()
         return self.keypoints[:n], (self.descriptors[:n] if want_descriptors else None)
 
 
