@@ -5,9 +5,10 @@
 //
 // Everything is stream-ordered device work; nothing is copied to the host:
 //   upsample 2x (u8 -> f32, bilinear) -> per octave { fused separable Gaussian (LDS tile, rows then columns) that also
-//   emits the DoG plane; nearest 2x decimation } -> per octave extrema + sub-pixel refinement (one lane per pixel,
-//   refined candidates appended) -> orientation histograms (one wave per candidate) -> counting-rank sort in OpenCV's
-//   keypoint order + duplicate removal (ordered compaction) -> descriptors (one wave per keypoint).
+//   emits the DoG plane; nearest 2x decimation } -> extrema of all octaves (one lane per pixel, raw list) -> sub-pixel
+//   refinement (one lane per raw extremum) -> gradient (magnitude, orientation) planes -> orientation histograms (one
+//   wave per extremum) -> x-bucketed ranking in OpenCV's keypoint order + duplicate removal (ordered compaction) ->
+//   descriptors (sixteen lanes per keypoint, one per histogram cell).
 //
 // Arithmetic contract: float32 operations in the order of the sequential algorithm (oracle/sift_oracle.c restates
 // it), no contraction (-ffp-contract=off), IEEE divide/sqrt, and fixed polynomial programs for exp / sincos / atan2,
@@ -15,8 +16,9 @@
 // accumulated by an owner lane per bin that walks the samples in raster order.
 //
 // Memory: one workspace holds the whole scale space: for a W x H input the doubled base is 2W x 2H floats and the
-// pyramid (6 Gaussian + 5 DoG planes per octave at the defaults) takes 11 * 4/3 * 16 WH bytes (147 MB for the
-// reference's 968 x 648 frames) — resident in HBM from the first blur to the last descriptor.
+// pyramid (6 Gaussian + 5 DoG planes + 3 float2 gradient planes per octave at the defaults) takes 17 * 4/3 * 16 WH
+// bytes plus the keypoint lists (268 MB for the reference's 968 x 648 frames and 131 072 keypoint slots) — resident in
+// HBM from the first blur to the last descriptor.
 #include <algorithm>
 #include <cfloat>
 #include <cmath>

@@ -41,7 +41,7 @@ def pyrdown(img):
 class Sift:
     """`cv2.SIFT_create(nfeatures=0, nOctaveLayers, contrastThreshold, edgeThreshold, sigma)` for one image size.
 
-    The workspace (the whole scale space, ~147 MB for a 968 x 648 frame) and the output buffers are allocated once and
+    The workspace (the whole scale space, 268 MB for a 968 x 648 frame) and the output buffers are allocated once and
     reused by every `run`; results are views into them, valid until the next `run`.
     """
 
