@@ -150,3 +150,14 @@ def test_driver_from_pixels_recovers_known_geometry(hip):
     Z = out["Xtot"][1:, 2] * 0.25                                              # metric scale: the true baseline is 0.25
     near = [np.mean(np.abs(Z - d) < 0.15) for d in (10.0, 6.0, 4.0)]
     assert sum(near) > 0.9 and min(near) > 0.05                                # the cloud sits on the three layers
+
+
+def test_sift_full_size_photograph_shape(hip, oracle):
+    """The reference's photographs are 1936 x 1296 before img_downscale; SIFT at that size (10 octaves, 3872 x 2592 base)
+    must still agree with the oracle bit for bit.  Content: a tiled procedural scene (generation cost, not coverage)."""
+    tile = scene_image(484, 324, 31)
+    g = np.ascontiguousarray(np.tile(tile, (4, 4)))
+    assert g.shape == (1296, 1936)
+    kpo, deso = oracle.sift(g)
+    kp, des, eng = _sift_hip(g, max_keypoints=1 << 18)
+    assert len(kpo) > 20000 and _same(kp, kpo) and _same(des, deso)
