@@ -802,10 +802,14 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom geo, const float* 
                 const float c_rot = j * cos_t - i * sin_t, r_rot = j * sin_t + i * cos_t;
                 float rbin = r_rot + d / 2 - 0.5f, cbin = c_rot + d / 2 - 0.5f;
                 const int r = py + i, c = px + j;
-                if (rbin > -1 && rbin < d && cbin > -1 && cbin < d && r > 0 && r < h - 1 && c > 0 && c < w - 1 && j >= -radius && j <= radius) {
-                    const int r0 = cv_floor(rbin), c0 = cv_floor(cbin);
-                    const int dr = ri - (r0 + 1), dc = ci - (c0 + 1);
-                    if ((unsigned)dr <= 1u && (unsigned)dc <= 1u) {
+                const int r0 = cv_floor(rbin), c0 = cv_floor(cbin);
+                const int dr = ri - (r0 + 1), dc = ci - (c0 + 1);
+                // one predicate, no short-circuit ladder: (unsigned) range checks fold the pairs of integer compares
+                const bool inside = (rbin > -1) & (rbin < d) & (cbin > -1) & (cbin < d) & ((unsigned)(r - 1) < (unsigned)(h - 2)) &
+                                    ((unsigned)(c - 1) < (unsigned)(w - 2)) & ((unsigned)(j + radius) <= (unsigned)(2 * radius)) &
+                                    ((unsigned)(dr | dc) <= 1u);
+                {
+                    if (inside) {
                         const unsigned at = (unsigned)(r * w + c);
                         const float W = sift_expf_unclamped((c_rot * c_rot + r_rot * r_rot) * exp_scale);   // argument in (-1.6, 0]
                         const float2 mo = grad[at];
