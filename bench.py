@@ -566,10 +566,10 @@ def bench_sift(args, world, rank, dev):
     des_ms, des_n = ops.profile_read(7)
     ops.profile_enable(False)
     # algorithmic HBM bytes of the scale-space build: every blur reads one float plane and writes two (Gaussian + DoG),
-    # the base blur reads and writes one, decimation reads 1/4 and writes one plane, the 2x upsample writes one
+    # the base blur reads and writes one, the 2x upsample writes one (2x decimation is a strided read of the next blur)
     n_oct = int(round(np.log2(min(2 * w, 2 * h)) - 2)) + 1
     px = [((2 * w) >> o) * ((2 * h) >> o) for o in range(n_oct)]
-    pyr_bytes = sum(p * 12 * 5 for p in px) + px[0] * 8 + sum(px[o] * 5 for o in range(1, n_oct)) + px[0] * 4 + w * h
+    pyr_bytes = sum(p * 12 * 5 for p in px) + px[0] * 8 + px[0] * 4 + w * h
     gbs = pyr_bytes / (pyr_ms / pyr_n * 1e-3) / 1e9
     out = {"metric": "SIFT detectAndCompute frames/sec (968 x 648 uint8 frames)", "value": world * args.steps / elapsed, "unit": "frames/s",
            "n_gpus": world, "steps": args.steps, "warmup": max(2, args.warmup), "ms_per_step": elapsed / args.steps * 1e3,
@@ -580,7 +580,7 @@ def bench_sift(args, world, rank, dev):
            "frame_latency_ms_single_stream": single_ms,
            "keypoints_per_sec": world * nkp * args.steps / elapsed,
            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
-                        "kernel": "scale space: gauss_blur_kernel x 46 + decimate + upsample (one event pair around all of them)",
+                        "kernel": "scale space: gauss_blur_fixed_kernel<N> x 46 + upsample (one event pair around all of them)",
                         "avg_launch_ms": pyr_ms / pyr_n, "algorithmic_bytes": pyr_bytes},
            "descriptor_kernel": {"avg_launch_ms": des_ms / des_n, "keypoints_per_sec": nkp / (des_ms / des_n * 1e-3),
                                  "note": "VALU/latency bound: per-cell raster walks in the sequential algorithm's float32 order"}}

@@ -284,6 +284,7 @@ int sfm_host_epnp(const double* K_host, const double* Xw_host, const double* uv_
  * orientation histograms (one keypoint per peak >= 0.8 max), OpenCV's keypoint
  * ordering + duplicate removal, 4x4x8 descriptors (clip 0.2, x512, u8-valued float32).
  *   gray_dev        [h x stride] uint8
+ *   max_keypoints   capacity of the outputs and of the internal lists, 64 <= max_keypoints < 2^24
  *   keypoints_dev   [max_keypoints x 8] float32: x, y, size, angle (degrees), response,
  *                   octave (int32 bits, OpenCV packing), class_id (int32 bits, -1), 0
  *   descriptors_dev [max_keypoints x 128] float32 (NULL: detect only)

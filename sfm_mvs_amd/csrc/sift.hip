@@ -5,7 +5,7 @@
 //
 // Everything is stream-ordered device work; nothing is copied to the host:
 //   upsample 2x (u8 -> f32, bilinear) -> per octave { fused separable Gaussian (LDS tile, rows then columns) that also
-//   emits the DoG plane; nearest 2x decimation } -> extrema of all octaves (one lane per pixel, raw list) -> sub-pixel
+//   emits the DoG plane; 2x decimation is a stride-2 read of the next octave's first blur } -> extrema of all octaves (one lane per pixel, raw list) -> sub-pixel
 //   refinement (one lane per raw extremum) -> gradient (magnitude, orientation) planes -> orientation histograms (one
 //   wave per extremum) -> x-bucketed ranking in OpenCV's keypoint order + duplicate removal (ordered compaction) ->
 //   descriptors (sixteen lanes per keypoint, one per histogram cell).
@@ -187,17 +187,16 @@ __global__ __launch_bounds__(256) void upsample2_kernel(const unsigned char* __r
     out[(size_t)dy * 2 * w + dx] = a * (1.f - fy) + b * fy;
 }
 
-__global__ __launch_bounds__(256) void decimate2_kernel(const float* __restrict__ src, int sw, float* __restrict__ dst, int dw, int dh) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x < dw && y < dh) dst[(size_t)y * dw + x] = src[(size_t)(2 * y) * sw + 2 * x];
-}
 
 // ------------------------------------------------------------------------------------------------ Gaussian + DoG
 // One 64 x 32 output tile per workgroup.  The (32+2R) x (64+2R) input window (BORDER_REFLECT_101) goes to LDS once,
 // the row pass writes (32+2R) x 64 partial results back to LDS, the column pass reads them: each input pixel is
 // fetched from HBM/L2 about (1+2R/64)(1+2R/32) times instead of 2(2R+1) times.  `dog` (optional) = dst - src.
+// `src` is read through a view: pixel (y, x) of the w x h input is src[(y * sstep) * spitch + x * sstep]; sstep = 2 with the
+// previous octave's pitch makes the first blur of an octave read the 2x decimation of layer nL directly (the
+// decimated plane itself is never materialised: nothing else reads layer 0 of octaves >= 1).
 __global__ __launch_bounds__(256) void gauss_blur_kernel(const float* __restrict__ src, float* __restrict__ dst, float* __restrict__ dog,
-                                                         int w, int h, Taps taps) {
+                                                         int w, int h, Taps taps, int sstep, int spitch) {
     extern __shared__ float blur_lds[];      // tk[kMaxTaps+1] | th[rows x 64] | tin[rows x pitch]
     const int n = taps.n, R = n >> 1;
     const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
@@ -211,7 +210,7 @@ __global__ __launch_bounds__(256) void gauss_blur_kernel(const float* __restrict
     }
     for (int e = threadIdx.x; e < rows * pitch; e += 256) {
         const int ry = e / pitch, rx = e - ry * pitch;
-        tin[e] = src[(size_t)reflect101(y0 - R + ry, h) * w + reflect101(x0 - R + rx, w)];
+        tin[e] = src[(size_t)(reflect101(y0 - R + ry, h) * sstep) * spitch + reflect101(x0 - R + rx, w) * sstep];
     }
     __syncthreads();
     for (int e = threadIdx.x; e < rows * kTileW; e += 256) {
@@ -241,7 +240,7 @@ __global__ __launch_bounds__(256) void gauss_blur_kernel(const float* __restrict
 // gauss_blur_kernel's.  A single tile of this kernel is also what bounds the small octaves (one workgroup each).
 template <int N>
 __global__ __launch_bounds__(256) void gauss_blur_fixed_kernel(const float* __restrict__ src, float* __restrict__ dst, float* __restrict__ dog,
-                                                               int w, int h, Taps taps) {
+                                                               int w, int h, Taps taps, int sstep, int spitch) {
     constexpr int R = N / 2, ROWS = kTileH + 2 * R, COLS = kTileW + 2 * R, PITCH = (COLS + 3) & ~3, NV = (N + 3 + 3) / 4;
     __shared__ __attribute__((aligned(16))) float tin[ROWS * PITCH];
     __shared__ __attribute__((aligned(16))) float th[ROWS * kTileW];
@@ -249,17 +248,17 @@ __global__ __launch_bounds__(256) void gauss_blur_fixed_kernel(const float* __re
     constexpr int LOADS = (ROWS * COLS + 255) / 256;     // all of a lane's loads are issued before the first is consumed
     float ld[LOADS];
     if (x0 >= R && y0 >= R && x0 + kTileW + R <= w && y0 + kTileH + R <= h) {     // interior tile: no border arithmetic
-        const float* base = src + (size_t)(y0 - R) * w + (x0 - R);
+        const float* base = src + (size_t)((y0 - R) * sstep) * spitch + (x0 - R) * sstep;
 #pragma unroll
         for (int k = 0; k < LOADS; ++k) {
             const int e = threadIdx.x + 256 * k, ry = e / COLS, rx = e - ry * COLS;
-            ld[k] = e < ROWS * COLS ? base[(size_t)ry * w + rx] : 0.f;
+            ld[k] = e < ROWS * COLS ? base[(size_t)(ry * sstep) * spitch + rx * sstep] : 0.f;
         }
     } else {
 #pragma unroll
         for (int k = 0; k < LOADS; ++k) {
             const int e = threadIdx.x + 256 * k, ry = e / COLS, rx = e - ry * COLS;
-            ld[k] = e < ROWS * COLS ? src[(size_t)reflect101(y0 - R + ry, h) * w + reflect101(x0 - R + rx, w)] : 0.f;
+            ld[k] = e < ROWS * COLS ? src[(size_t)(reflect101(y0 - R + ry, h) * sstep) * spitch + reflect101(x0 - R + rx, w) * sstep] : 0.f;
         }
     }
 #pragma unroll
@@ -931,8 +930,8 @@ extern "C" int sfm_sift_detect_and_compute(const uint8_t* gray, int64_t w, int64
                                            int32_t* count, void* ws, size_t ws_bytes, void* stream_) {
     SFM_CHECK_ARG(gray && keypoints && count && ws, "sfm_sift_detect_and_compute: null pointer");
     SFM_CHECK_ARG(w >= 8 && h >= 8 && w <= 16384 && h <= 16384 && stride >= w, "sfm_sift_detect_and_compute: image must be 8..16384 pixels a side");
-    SFM_CHECK_ARG(n_octave_layers >= 1 && n_octave_layers <= 8 && sigma > 0 && max_keypoints > 0 && max_keypoints < (1 << 24),
-                  "sfm_sift_detect_and_compute: bad parameters");
+    SFM_CHECK_ARG(n_octave_layers >= 1 && n_octave_layers <= 8 && sigma > 0 && max_keypoints >= 64 && max_keypoints < (1 << 24),
+                  "sfm_sift_detect_and_compute: bad parameters (1..8 layers, sigma > 0, 64 <= max_keypoints < 2^24)");
     if (ws_bytes < sfm_sift_ws_bytes(w, h, n_octave_layers, max_keypoints)) {
         sfm::set_error("sfm_sift_detect_and_compute: workspace too small");
         return SFM_ERR_WORKSPACE;
@@ -974,9 +973,9 @@ extern "C" int sfm_sift_detect_and_compute(const uint8_t* gray, int64_t w, int64
     SFM_CHECK_HIP(hipMemsetAsync(counters, 0, kCounterInts * sizeof(int), stream));
     auto grid2 = [](int ww, int hh) { return dim3((unsigned)((ww + 63) / 64), (unsigned)((hh + 3) / 4)); };
     auto tiles = [](int ww, int hh) { return dim3((unsigned)((ww + kTileW - 1) / kTileW), (unsigned)((hh + kTileH - 1) / kTileH)); };
-    auto launch_blur = [&](dim3 grid, const float* in, float* out, float* dg, int ww, int hh, const Taps& t) {
+    auto launch_blur = [&](dim3 grid, const float* in, float* out, float* dg, int ww, int hh, const Taps& t, int sstep, int spitch) {
         switch (t.n) {
-#define SFM_BLUR_CASE(N) case N: hipLaunchKernelGGL(gauss_blur_fixed_kernel<N>, grid, dim3(256), 0, stream, in, out, dg, ww, hh, t); return true;
+#define SFM_BLUR_CASE(N) case N: hipLaunchKernelGGL(gauss_blur_fixed_kernel<N>, grid, dim3(256), 0, stream, in, out, dg, ww, hh, t, sstep, spitch); return true;
             SFM_BLUR_CASE(5) SFM_BLUR_CASE(7) SFM_BLUR_CASE(9) SFM_BLUR_CASE(11) SFM_BLUR_CASE(13) SFM_BLUR_CASE(15) SFM_BLUR_CASE(17)
             SFM_BLUR_CASE(19) SFM_BLUR_CASE(21) SFM_BLUR_CASE(23) SFM_BLUR_CASE(25) SFM_BLUR_CASE(27)
 #undef SFM_BLUR_CASE
@@ -990,20 +989,19 @@ extern "C" int sfm_sift_detect_and_compute(const uint8_t* gray, int64_t w, int64
     sfm::prof_begin(sfm::kProfSiftPyramid, stream);
     hipLaunchKernelGGL(upsample2_kernel, grid2(geo.W0, geo.H0), dim3(256), 0, stream, gray, (int)w, (int)h, (long)stride, up);
     SFM_CHECK_LAUNCH();
-    if (!launch_blur(tiles(geo.W0, geo.H0), (const float*)up, geo.G(0, 0), (float*)nullptr, geo.W0, geo.H0, taps[0]))
-        hipLaunchKernelGGL(gauss_blur_kernel, tiles(geo.W0, geo.H0), dim3(256), blur_lds(taps[0]), stream, (const float*)up, geo.G(0, 0), (float*)nullptr,
-                           geo.W0, geo.H0, taps[0]);
+    auto blur = [&](const float* in, float* out, float* dg, int ww, int hh, const Taps& t, int sstep, int spitch) {
+        if (!launch_blur(tiles(ww, hh), in, out, dg, ww, hh, t, sstep, spitch))
+            hipLaunchKernelGGL(gauss_blur_kernel, tiles(ww, hh), dim3(256), blur_lds(t), stream, in, out, dg, ww, hh, t, sstep, spitch);
+    };
+    blur(up, geo.G(0, 0), nullptr, geo.W0, geo.H0, taps[0], 1, geo.W0);
     SFM_CHECK_LAUNCH();
     for (int o = 0; o < geo.nOct; ++o) {
         const int ow = geo.w(o), oh = geo.h(o);
-        if (o > 0) {
-            hipLaunchKernelGGL(decimate2_kernel, grid2(ow, oh), dim3(256), 0, stream, (const float*)geo.G(o - 1, nL), geo.w(o - 1), geo.G(o, 0), ow, oh);
-            SFM_CHECK_LAUNCH();
-        }
         for (int i = 1; i < nL + 3; ++i) {
-            if (!launch_blur(tiles(ow, oh), (const float*)geo.G(o, i - 1), geo.G(o, i), geo.D(o, i - 1), ow, oh, taps[i]))
-                hipLaunchKernelGGL(gauss_blur_kernel, tiles(ow, oh), dim3(256), blur_lds(taps[i]), stream, (const float*)geo.G(o, i - 1), geo.G(o, i),
-                                   geo.D(o, i - 1), ow, oh, taps[i]);
+            if (i == 1 && o > 0)      // layer 0 of this octave = every second pixel of the previous octave's layer nL, read in place
+                blur(geo.G(o - 1, nL), geo.G(o, 1), geo.D(o, 0), ow, oh, taps[1], 2, geo.w(o - 1));
+            else
+                blur(geo.G(o, i - 1), geo.G(o, i), geo.D(o, i - 1), ow, oh, taps[i], 1, ow);
             SFM_CHECK_LAUNCH();
         }
     }
