@@ -44,12 +44,14 @@ def _match_hip(feat0, feat1):
     kp0, des0 = feat0
     kp1, des1 = feat1
     dev = torch.device("cuda")
-    d0 = torch.as_tensor(np.ascontiguousarray(des0, np.float32)).to(dev)
-    d1 = torch.as_tensor(np.ascontiguousarray(des1, np.float32)).to(dev)
+
+    def up(a):      # features may already live in HBM (features_from_images(..., on_device=True))
+        return a.to(dev, torch.float32).contiguous() if torch.is_tensor(a) else torch.as_tensor(np.ascontiguousarray(a, np.float32)).to(dev)
+
+    d0, d1 = up(des0), up(des1)
     idx, dist = ops.knn2(d0, d1)                                   # bf.knnMatch(des0, des1, k=2)  sfm.py:260
     out_q, out_t, count = ops.ratio_compact(idx, dist, RATIO)      # m.distance < 0.70*n.distance   sfm.py:262-265
-    p0, p1 = ops.gather_matches(torch.as_tensor(np.ascontiguousarray(kp0, np.float32)).to(dev),
-                                torch.as_tensor(np.ascontiguousarray(kp1, np.float32)).to(dev), out_q, out_t, count)
+    p0, p1 = ops.gather_matches(up(kp0), up(kp1), out_q, out_t, count)
     m = int(count.item())
     return p0[:m].cpu().numpy(), p1[:m].cpu().numpy()              # sfm.py:267-268
 
@@ -69,10 +71,11 @@ def img_downscale(img, downscale, be=None):
     return img
 
 
-def features_from_images(images, depth=3):
+def features_from_images(images, depth=3, on_device=False):
     """The detector half of find_features (sfm.py:243-252) for a whole sequence: BGR uint8 frames -> the `features` list
     run_sfm takes, [(kp (n, 2) float32 pixel coordinates in cv2's keypoint order, des (n, 128) float32)].
-    Frames are uploaded once and go through cvtColor + SIFT on `depth` streams; one device->host copy per frame."""
+    Frames are uploaded once and go through cvtColor + SIFT on `depth` streams; one device->host copy per frame, or
+    none with on_device=True (the features stay in HBM as torch tensors, which the matcher takes as they are)."""
     from . import sift as _sift
     dev = torch.device("cuda")
     pipes, pending, feats = {}, [], []
@@ -81,7 +84,10 @@ def features_from_images(images, depth=3):
         st, eng = pending.pop(0)
         st.synchronize()
         n = eng.check_capacity()
-        feats.append((eng.keypoints[:n, :2].cpu().numpy(), eng.descriptors[:n].cpu().numpy()))
+        if on_device:
+            feats.append((eng.keypoints[:n, :2].contiguous(), eng.descriptors[:n].clone()))
+        else:
+            feats.append((eng.keypoints[:n, :2].cpu().numpy(), eng.descriptors[:n].cpu().numpy()))
 
     for img in images:
         img = np.ascontiguousarray(img, np.uint8)
@@ -105,7 +111,7 @@ def run_sfm_images(images, K, downscale=2, log=None, be=None):
     """sfm.py's main loop from pixels: img_downscale (:40), cvtColor + SIFT (:243-252) and the driver (:274-423).
     `images`: BGR uint8 frames in sequence order; K is scaled by the caller as in sfm.py:20-26."""
     small = [img_downscale(im, downscale, be) for im in images]
-    return run_sfm(features_from_images(small), K, images=small, log=log, be=be)
+    return run_sfm(features_from_images(small, on_device=be is None), K, images=small, log=log, be=be)
 
 def Triangulation(P1, P2, pts1, pts2, K, repeat, be=None):
     """sfm.py:45-56."""

@@ -147,6 +147,14 @@ def test_driver_from_pixels_recovers_known_geometry(hip):
         assert np.abs(R - np.eye(3)).max() < 5e-3
         assert np.abs(-R.T @ t - np.array([k, 0.0, 0.0])).max() < 3e-2          # unit first baseline (recoverPose)
     assert max(out["errors"]) < 1.0
+    feats_dev = pl.features_from_images(images, on_device=True)                # features kept in HBM: same values, same run
+    assert all(torch.is_tensor(k) and k.is_cuda and np.array_equal(k.cpu().numpy(), kh) and np.array_equal(d.cpu().numpy(), dh)
+               for (k, d), (kh, dh) in zip(feats_dev, feats))
+    assert np.array_equal(pl.run_sfm(feats_dev, K, images=images)["posearr"], out["posearr"])
+    out_px = pl.run_sfm_images(big, K, downscale=2)                            # pyrDown'ed frames: other pixels, same scene
+    for k, Pk in enumerate(out_px["posearr"][9:].reshape(-1, 3, 4)):
+        R, t = decompose_P(K, Pk)
+        assert np.abs(R - np.eye(3)).max() < 1e-2 and np.abs(-R.T @ t - np.array([k, 0.0, 0.0])).max() < 6e-2
     Z = out["Xtot"][1:, 2] * 0.25                                              # metric scale: the true baseline is 0.25
     near = [np.mean(np.abs(Z - d) < 0.15) for d in (10.0, 6.0, 4.0)]
     assert sum(near) > 0.9 and min(near) > 0.05                                # the cloud sits on the three layers
