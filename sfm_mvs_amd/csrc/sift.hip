@@ -566,9 +566,7 @@ __global__ __launch_bounds__(256) void orientation_kernel(Geom geo, const Cand* 
 
 // ------------------------------------------------------------------------------------------------ ordering
 // KeyPointsFilter::removeDuplicatedSorted order: x, y ascending, size descending, angle ascending, response, octave
-// descending.  rank[i] = number of keypoints ordered before i (all-pairs counting through LDS tiles: n is ~1e4, the
-// n^2 compares are a few tens of microseconds and need no multi-pass sort); keypoints equal in every field are
-// interchangeable, the index breaks the tie.
+// descending; keypoints equal in every field are interchangeable, the index breaks the tie.
 struct Key { float x, y, size, angle, response; int octave; };
 __device__ inline bool key_before(const Key& a, int ia, const Key& b, int ib) {
     if (a.x != b.x) return a.x < b.x;
