@@ -238,36 +238,37 @@ __global__ __launch_bounds__(256) void gauss_blur_kernel(const float* __restrict
 // ((N+3)/4 reads per output instead of N, plus no tap reads), the column pass works on float4 columns.  Every output
 // is still the sequential dot product in tap order (rows) / the symmetric form (columns): results are identical to
 // gauss_blur_kernel's.  A single tile of this kernel is also what bounds the small octaves (one workgroup each).
+constexpr int kBlurThreads = 512;    // per 64 x 32 tile: a tile's latency (what the one-workgroup octaves and the last round of the big ones pay) halves vs 256
 template <int N>
-__global__ __launch_bounds__(256) void gauss_blur_fixed_kernel(const float* __restrict__ src, float* __restrict__ dst, float* __restrict__ dog,
+__global__ __launch_bounds__(kBlurThreads) void gauss_blur_fixed_kernel(const float* __restrict__ src, float* __restrict__ dst, float* __restrict__ dog,
                                                                int w, int h, Taps taps, int sstep, int spitch) {
     constexpr int R = N / 2, ROWS = kTileH + 2 * R, COLS = kTileW + 2 * R, PITCH = (COLS + 3) & ~3, NV = (N + 3 + 3) / 4;
     __shared__ __attribute__((aligned(16))) float tin[ROWS * PITCH];
     __shared__ __attribute__((aligned(16))) float th[ROWS * kTileW];
     const int x0 = blockIdx.x * kTileW, y0 = blockIdx.y * kTileH;
-    constexpr int LOADS = (ROWS * COLS + 255) / 256;     // all of a lane's loads are issued before the first is consumed
+    constexpr int LOADS = (ROWS * COLS + kBlurThreads - 1) / kBlurThreads;     // all of a lane's loads are issued before the first is consumed
     float ld[LOADS];
     if (x0 >= R && y0 >= R && x0 + kTileW + R <= w && y0 + kTileH + R <= h) {     // interior tile: no border arithmetic
         const float* base = src + (size_t)((y0 - R) * sstep) * spitch + (x0 - R) * sstep;
 #pragma unroll
         for (int k = 0; k < LOADS; ++k) {
-            const int e = threadIdx.x + 256 * k, ry = e / COLS, rx = e - ry * COLS;
+            const int e = threadIdx.x + kBlurThreads * k, ry = e / COLS, rx = e - ry * COLS;
             ld[k] = e < ROWS * COLS ? base[(size_t)(ry * sstep) * spitch + rx * sstep] : 0.f;
         }
     } else {
 #pragma unroll
         for (int k = 0; k < LOADS; ++k) {
-            const int e = threadIdx.x + 256 * k, ry = e / COLS, rx = e - ry * COLS;
+            const int e = threadIdx.x + kBlurThreads * k, ry = e / COLS, rx = e - ry * COLS;
             ld[k] = e < ROWS * COLS ? src[(size_t)(reflect101(y0 - R + ry, h) * sstep) * spitch + reflect101(x0 - R + rx, w) * sstep] : 0.f;
         }
     }
 #pragma unroll
     for (int k = 0; k < LOADS; ++k) {
-        const int e = threadIdx.x + 256 * k, ry = e / COLS, rx = e - ry * COLS;
+        const int e = threadIdx.x + kBlurThreads * k, ry = e / COLS, rx = e - ry * COLS;
         if (e < ROWS * COLS) tin[ry * PITCH + rx] = ld[k];
     }
     __syncthreads();
-    for (int it = threadIdx.x; it < ROWS * (kTileW / 4); it += 256) {
+    for (int it = threadIdx.x; it < ROWS * (kTileW / 4); it += kBlurThreads) {
         const int ry = it >> 4, qx = it & 15;
         const float4* p = reinterpret_cast<const float4*>(tin + ry * PITCH + 4 * qx);
         float v[4 * NV];
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(256) void gauss_blur_fixed_kernel(const float* __re
         *reinterpret_cast<float4*>(th + ry * kTileW + 4 * qx) = make_float4(o[0], o[1], o[2], o[3]);
     }
     __syncthreads();
-    for (int it = threadIdx.x; it < kTileH * (kTileW / 4); it += 256) {
+    for (int it = threadIdx.x; it < kTileH * (kTileW / 4); it += kBlurThreads) {
         const int ty = it >> 4, qx = it & 15;
         const int x = x0 + 4 * qx, y = y0 + ty;
         if (x >= w || y >= h) continue;
@@ -958,7 +959,7 @@ extern "C" int sfm_sift_detect_and_compute(const uint8_t* gray, int64_t w, int64
     auto tiles = [](int ww, int hh) { return dim3((unsigned)((ww + kTileW - 1) / kTileW), (unsigned)((hh + kTileH - 1) / kTileH)); };
     auto launch_blur = [&](dim3 grid, const float* in, float* out, float* dg, int ww, int hh, const Taps& t, int sstep, int spitch) {
         switch (t.n) {
-#define SFM_BLUR_CASE(N) case N: hipLaunchKernelGGL(gauss_blur_fixed_kernel<N>, grid, dim3(256), 0, stream, in, out, dg, ww, hh, t, sstep, spitch); return true;
+#define SFM_BLUR_CASE(N) case N: hipLaunchKernelGGL(gauss_blur_fixed_kernel<N>, grid, dim3(kBlurThreads), 0, stream, in, out, dg, ww, hh, t, sstep, spitch); return true;
             SFM_BLUR_CASE(5) SFM_BLUR_CASE(7) SFM_BLUR_CASE(9) SFM_BLUR_CASE(11) SFM_BLUR_CASE(13) SFM_BLUR_CASE(15) SFM_BLUR_CASE(17)
             SFM_BLUR_CASE(19) SFM_BLUR_CASE(21) SFM_BLUR_CASE(23) SFM_BLUR_CASE(25) SFM_BLUR_CASE(27)
 #undef SFM_BLUR_CASE
