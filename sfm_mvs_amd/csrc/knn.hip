@@ -284,9 +284,10 @@ __device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t trs, int row_b
     }
 }
 
-constexpr int kKeyBits = 9;                       // 6 bits tile-in-substream + 3 bits accumulator-register PAIR
+constexpr int kRecRows = 4;                       // a candidate record names this many adjacent train rows (one accumulator-register quad)
+constexpr int kKeyBits = 8;                       // 6 bits tile-in-substream + 2 bits accumulator-register QUAD
 constexpr int kKeyMask = (1 << kKeyBits) - 1;
-constexpr int kSubTiles = 1 << (kKeyBits - 3);    // 64 tiles per substream
+constexpr int kSubTiles = 1 << (kKeyBits - 2);    // 64 tiles per substream
 static_assert(kSubTiles == kSubTilesHost, "make_plan's copy");
 constexpr int kKeyInf = 0x7F800000;               // +inf: larger than every finite non-negative score key
 
@@ -306,7 +307,7 @@ __device__ __forceinline__ void flush_keys(int k0, int k1, int k2, int sub_t0, i
         for (int r = 0; r < 3; ++r) {
             const int seq = ks[r] & kKeyMask;
             sc[r] = ks[r] == kKeyInf ? kInf : __int_as_float(ks[r] & ~kKeyMask);
-            id[r] = ks[r] == kKeyInf ? -1 : (sub_t0 + (seq >> 3)) * kTileT + 2 * (seq & 1) + 8 * ((seq >> 1) & 3) + 4 * h;
+            id[r] = ks[r] == kKeyInf ? -1 : (sub_t0 + (seq >> 2)) * kTileT + 8 * (seq & 3) + 4 * h;   // registers 4m..4m+3 = rows 8m + 4h + 0..3
         }
         *reinterpret_cast<f32x3*>(cs) = sc;
         *reinterpret_cast<i32x3*>(ci) = id;
@@ -316,7 +317,7 @@ __device__ __forceinline__ void flush_keys(int k0, int k1, int k2, int sub_t0, i
             const int seq = ks[r] & kKeyMask;
             const bool empty = ks[r] == kKeyInf;
             cs[r] = empty ? kInf : __int_as_float(ks[r] & ~kKeyMask);
-            ci[r] = empty ? -1 : (sub_t0 + (seq >> 3)) * kTileT + 2 * (seq & 1) + 8 * ((seq >> 1) & 3) + 4 * h;
+            ci[r] = empty ? -1 : (sub_t0 + (seq >> 2)) * kTileT + 8 * (seq & 3) + 4 * h;
         }
     }
 }
@@ -446,13 +447,13 @@ __global__ __launch_bounds__(64 * W, 4) void knn_filter_kernel(
             }
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(aug_a, aug_b, acc, 0, 0, 0);
             if (ABL & 16) __builtin_amdgcn_s_setprio(0);
-            const int seq0 = (t - sub_t0) << 3;
+            const int seq0 = (t - sub_t0) << 2;
             if (ABL & 1) {
                 k0 = min(k0, __float_as_int(acc[0]) + __float_as_int(acc[15]));
             } else
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {                              // one key per PAIR of adjacent trains (see key_insert4)
-                const int key = (__float_as_int(fminf(acc[r], acc[r + 1])) & ~kKeyMask) | (seq0 + (r >> 1));
+            for (int r = 0; r < 16; r += 4) {                              // one key per QUAD of adjacent trains (see key_insert4)
+                const int key = (__float_as_int(fminf(fminf(acc[r], acc[r + 1]), fminf(acc[r + 2], acc[r + 3]))) & ~kKeyMask) | (seq0 + (r >> 2));
                 const int lo = min(key, k0), hi = max(key, k0);            // (lo, hi) = sorted (key, k0)
                 const int m1 = max(min(key, k1), min(max(key, k1), k0));   // med3(key, k0, k1)
                 k2 = max(min(key, k1), min(max(key, k1), k2));             // med3(key, k1, k2)
@@ -611,10 +612,11 @@ __global__ __launch_bounds__(1024) void knn_prep_kernel(const float* __restrict_
 template <int W>
 __device__ __forceinline__ void key_insert4(const f32x16& a, int r0, int seq0 /*wave-uniform*/, int vmask /*VGPR holding ~kKeyMask*/,
                                             int& k0, int& k1, int& k2) {
+    static_assert(W % 4 == 0, "whole register quads");
 #pragma unroll
-    for (int r = r0; r < r0 + W; r += 2) {
+    for (int r = r0; r < r0 + W; r += 4) {
         int key;
-        asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(key) : "v"(fminf(a[r], a[r + 1])), "v"(vmask), "s"(seq0 + (r >> 1)));
+        asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(key) : "v"(fminf(fminf(a[r], a[r + 1]), fminf(a[r + 2], a[r + 3]))), "v"(vmask), "s"(seq0 + (r >> 2)));
         const int lo = min(key, k0);
         const int m1 = max(min(key, k1), min(max(key, k1), k0));
         k2 = max(min(key, k1), min(max(key, k1), k2));
@@ -820,7 +822,7 @@ __device__ __forceinline__ void filter_split2_body(
 #pragma unroll
                 for (int g = 0; g < 2; ++g) cur[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_aug, b_aug[g], zero, 0, 0, 0);
             }
-            const int seq0 = __builtin_amdgcn_readfirstlane(((t - 1) - sub_t0) << 3);
+            const int seq0 = __builtin_amdgcn_readfirstlane(((t - 1) - sub_t0) << 2);
 #pragma unroll
             for (int st = 0; st < 8; ++st) {
                 if constexpr (KMID) {
@@ -862,8 +864,10 @@ __device__ __forceinline__ void filter_split2_body(
                     ka[0] = min(ka[0], __float_as_int(prev[0][2 * st]) + __float_as_int(prev[0][2 * st + 1]));
                     ka[1] = min(ka[1], __float_as_int(prev[1][2 * st]) + __float_as_int(prev[1][2 * st + 1]));
                 } else if (have_prev) {          // 2 values of each group per k-step: 16 VALU beside the MFMAs
-                    key_insert4<2>(prev[0], 2 * st, seq0, vmask, ka[0], kb[0], kc[0]);
-                    key_insert4<2>(prev[1], 2 * st, seq0, vmask, ka[1], kb[1], kc[1]);
+                    if (st & 1) {                // one register quad of each group every second k-step
+                        key_insert4<4>(prev[0], 4 * (st >> 1), seq0, vmask, ka[0], kb[0], kc[0]);
+                        key_insert4<4>(prev[1], 4 * (st >> 1), seq0, vmask, ka[1], kb[1], kc[1]);
+                    }
                 }
             }
             // Tile t+1 must have landed for every wave before anyone reads it; tile t+2 (just issued) stays in flight
@@ -894,11 +898,11 @@ __device__ __forceinline__ void filter_split2_body(
                 sub_t0 = tl;
             }
             if ((t_end - t_begin) & 1) {
-                key_insert4<16>(accA[0], 0, __builtin_amdgcn_readfirstlane((tl - sub_t0) << 3), vmask, ka[0], kb[0], kc[0]);
-                key_insert4<16>(accA[1], 0, __builtin_amdgcn_readfirstlane((tl - sub_t0) << 3), vmask, ka[1], kb[1], kc[1]);
+                key_insert4<16>(accA[0], 0, __builtin_amdgcn_readfirstlane((tl - sub_t0) << 2), vmask, ka[0], kb[0], kc[0]);
+                key_insert4<16>(accA[1], 0, __builtin_amdgcn_readfirstlane((tl - sub_t0) << 2), vmask, ka[1], kb[1], kc[1]);
             } else {
-                key_insert4<16>(accB[0], 0, __builtin_amdgcn_readfirstlane((tl - sub_t0) << 3), vmask, ka[0], kb[0], kc[0]);
-                key_insert4<16>(accB[1], 0, __builtin_amdgcn_readfirstlane((tl - sub_t0) << 3), vmask, ka[1], kb[1], kc[1]);
+                key_insert4<16>(accB[0], 0, __builtin_amdgcn_readfirstlane((tl - sub_t0) << 2), vmask, ka[0], kb[0], kc[0]);
+                key_insert4<16>(accB[1], 0, __builtin_amdgcn_readfirstlane((tl - sub_t0) << 2), vmask, ka[1], kb[1], kc[1]);
             }
         }
         flush(sub, sub_t0);
@@ -1114,7 +1118,7 @@ constexpr int kS1 = 6;           // candidate records per lane fetched up front 
 constexpr int kRescanRows = 1;   // trains a quad has in flight during a rescan (32 VGPRs each)
 constexpr int kRefItems = 512;   // rescan work list (query, stream); more → 16 candidate slots per query at a time (<= 96)
 constexpr int kPreRows = 2;      // trains a quad has in flight during the rescan's fp16 prefilter (16 VGPRs each)
-constexpr int kQualCap = 80;     // exact-evaluation list per query (a chunk of 16 records adds up to 32 rows)
+constexpr int kQualCap = 144;    // exact-evaluation list per query (a chunk of 16 records adds up to 64 rows)
 
 // Sixteen lanes per query, sixteen queries per workgroup (one resident round for 10^4 queries).
 //   sweep 1  two smallest filter scores over the query's candidate records and each stream's 3rd best
@@ -1253,7 +1257,7 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
     const bool use_half = thalf && (mode == kModeHalf || mode == kModeHalfExact);
     for (int k0 = 0; k0 * 16 < NC;) {                     // (wave-uniform)
         for (; k0 * 16 < NC; ++k0) {
-            if (__any(cnt > kQualCap - 32)) break;        // the list might not take another chunk: evaluate first
+            if (__any(cnt > kQualCap - 16 * kRecRows)) break;   // the list might not take another chunk: evaluate first
             const int c = sl + 16 * k0;
             const float s = (valid && c < NC) ? cs[c] : kInf;
             const int id = (valid && c < NC) ? ci[c] : -1;                // (empty records: s = +inf, id = -1)
@@ -1261,12 +1265,12 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
             const unsigned long long mask = __ballot(take);
             if (mask == 0) continue;                      // wave-uniform
             const unsigned mine = (unsigned)(mask >> (16 * sub)) & 0xFFFFu;
-            if (take) {                                   // a record names a row PAIR (id, id + 1): both are evaluated
-                const int at = cnt + 2 * __popc(mine & ((1u << sl) - 1u));
-                qual[ql][at] = id;
-                qual[ql][at + 1] = id + 1 < nt ? id + 1 : id;
+            if (take) {                                   // a record names kRecRows adjacent rows: all are evaluated
+                const int at = cnt + kRecRows * __popc(mine & ((1u << sl) - 1u));
+#pragma unroll
+                for (int i = 0; i < kRecRows; ++i) qual[ql][at + i] = id + i < nt ? id + i : id;
             }
-            cnt += 2 * __popc(mine);
+            cnt += kRecRows * __popc(mine);
         }
         evaluate();                                       // the hot site
     }
