@@ -384,10 +384,10 @@ __global__ __launch_bounds__(64 * W, 4) void knn_filter_kernel(
         const float aug_a = h == 0 ? 1.f : 0.f;
         const float aug_b = h == 0 ? qn : 0.f;
 
-        // Running top-3 as PACKED KEYS, one per PAIR of adjacent trains: (min(score_r, score_r+1) bits & ~511) |
-        // (tile_in_substream << 3 | r/2).  Scores are non-negative up to rounding noise, so signed-integer order ==
-        // float order and one insertion is v_min_f32 + v_and_or + v_min_i32 + 2 v_med3_i32 (5 VALU per two scores)
-        // instead of 13 compare/select ops per score; the 9 dropped mantissa bits (2^-14 relative) are covered by the
+        // Running top-3 as PACKED KEYS, one per QUAD of adjacent trains: (min(score_r .. score_r+3) bits & ~255) |
+        // (tile_in_substream << 2 | r/4).  Scores are non-negative up to rounding noise, so signed-integer order ==
+        // float order and one insertion is 3 v_min_f32 + v_and_or + v_min_i32 + 2 v_med3_i32 (7 VALU per four scores)
+        // instead of 13 compare/select ops per score; the 8 dropped mantissa bits (2^-15 relative) are covered by the
         // refine kernel's slack.  A substream is 64 tiles.
         int k0 = kKeyInf, k1 = kKeyInf, k2 = kKeyInf;
         int sub = 0, sub_t0 = t_begin;
@@ -605,10 +605,11 @@ __global__ __launch_bounds__(1024) void knn_prep_kernel(const float* __restrict_
 //     tile t-1 (its accumulators are kept) is interleaved between the MFMAs on the vector pipe.
 // The pack is ONE v_and_or_b32 only if the mask sits in a VGPR and the sequence number in an SGPR (gfx9 VOP3 takes a
 // single scalar operand and no literal; left alone hipcc keeps both scalar and emits v_and + v_or).
-// One key per PAIR of adjacent trains (accumulator registers r, r+1 = rows 2m, 2m+1): min first, then one insertion —
-// 5 VALU per two scores instead of 8 (the packed-key epilogue was 31 % of a 50k x 50k launch).  A candidate record is
-// therefore a row pair; the refine kernel evaluates both rows exactly, and a discarded pair has BOTH scores >= the
-// stream's 3rd-best pair minimum, so the certificate is unchanged.
+// One key per QUAD of adjacent trains (accumulator registers 4m..4m+3 = rows 8m + 4h + 0..3): min first, then one
+// insertion — 7 VALU per four scores instead of 16 (the loop is instruction-issue bound: ~8 slots per 32-cycle MFMA
+// per SIMD, shared by two waves).  A candidate record is therefore a row quad; the refine kernel evaluates all four
+// rows exactly, and a discarded quad has ALL scores >= the stream's 3rd-best quad minimum, so the certificate is
+// unchanged.
 template <int W>
 __device__ __forceinline__ void key_insert4(const f32x16& a, int r0, int seq0 /*wave-uniform*/, int vmask /*VGPR holding ~kKeyMask*/,
                                             int& k0, int& k1, int& k2) {
@@ -995,13 +996,14 @@ __device__ __forceinline__ void best2_insert(Best2& b, float d, float dsq, int i
 // ---------------------------------------------------------------- refine
 // Slack coefficients of the refine kernel's certificate, relative to (|q|+|t|max)^2:
 //   common:   600u  fp32 rounding of norms / direct-form sums / sqrtf merge (+ GEMM-form chain for the f32 filter)
-//             2^-14 packed-key truncation of the score
+//             2^-15 packed-key truncation of the score (kKeyBits = 8 low mantissa bits)
 //   MFMA:     400 * 2^-22  ~400 accumulations inside the 16-bit MFMA chain, each assumed to lose <= 2^-22 relative
 //   split:    2 * 3.05 * 2^-16 / 4  neglected (mid.mid, delta) product terms, |q||t| <= N^2/4
 //   half:     2 * (2^-10 + 2^-22) / 4  both operands rounded to 11 bits: |q^.t^ - q.t| <= (2^-10 + 2^-22)|q||t|;
 //             plus, ABSOLUTE, 2 * 2^-14 * sqrt(128) * (|q|+|t|max) for elements below the fp16 normal range
 //             (each perturbed by at most 2^-14 even if the matrix pipe flushes them)
-constexpr float kEpsF32 = 600.f * 5.9604645e-8f + 6.1035156e-5f;
+constexpr float kEpsF32 = 600.f * 5.9604645e-8f + 3.0517578e-5f;
+static_assert(kKeyBits == 8, "kEpsF32 carries 2^(kKeyBits-23)");
 constexpr float kEpsExact = kEpsF32 + 9.54e-5f;
 constexpr float kEpsSplit = kEpsExact + 2.33e-5f;
 constexpr float kEpsHalf = kEpsExact + 4.8840e-4f;
