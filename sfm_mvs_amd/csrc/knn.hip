@@ -453,7 +453,7 @@ __global__ __launch_bounds__(64 * W, 4) void knn_filter_kernel(
             } else
 #pragma unroll
             for (int r = 0; r < 16; r += 4) {                              // one key per QUAD of adjacent trains (see key_insert4)
-                const int key = (__float_as_int(fminf(fminf(acc[r], acc[r + 1]), fminf(acc[r + 2], acc[r + 3]))) & ~kKeyMask) | (seq0 + (r >> 2));
+                const int key = (min(min(__float_as_int(acc[r]), __float_as_int(acc[r + 1])), min(__float_as_int(acc[r + 2]), __float_as_int(acc[r + 3]))) & ~kKeyMask) | (seq0 + (r >> 2));
                 const int lo = min(key, k0), hi = max(key, k0);            // (lo, hi) = sorted (key, k0)
                 const int m1 = max(min(key, k1), min(max(key, k1), k0));   // med3(key, k0, k1)
                 k2 = max(min(key, k1), min(max(key, k1), k2));             // med3(key, k1, k2)
@@ -617,7 +617,11 @@ __device__ __forceinline__ void key_insert4(const f32x16& a, int r0, int seq0 /*
 #pragma unroll
     for (int r = r0; r < r0 + W; r += 4) {
         int key;
-        asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(key) : "v"(fminf(fminf(a[r], a[r + 1]), fminf(a[r + 2], a[r + 3]))), "v"(vmask), "s"(seq0 + (r >> 2)));
+        // min on the BIT PATTERNS (v_min3_i32 + v_min_i32): fminf would add a canonicalising v_max_f32 per operand.
+        // Scores are >= 0 up to rounding noise; a negative one still wins against every non-negative one, and among
+        // negative ones (noise) any is a valid record score (such a stream never certifies, see the refine kernel).
+        const int m = min(min(__float_as_int(a[r]), __float_as_int(a[r + 1])), min(__float_as_int(a[r + 2]), __float_as_int(a[r + 3])));
+        asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(key) : "v"(m), "v"(vmask), "s"(seq0 + (r >> 2)));
         const int lo = min(key, k0);
         const int m1 = max(min(key, k1), min(max(key, k1), k0));
         k2 = max(min(key, k1), min(max(key, k1), k2));
@@ -784,6 +788,12 @@ __device__ __forceinline__ void filter_split2_body(
         if (trace && threadIdx.x == 0) trace[8192 + 4 * blockIdx.x + 0] += wall_clock64() - trace[4 * blockIdx.x];   // dev: prologue(s)
 
         f32x16 accA[2], accB[2];
+        // the first tile's "previous tile" is +inf everywhere: its insertions leave the (+inf) keys untouched, so the
+        // epilogue needs no have-a-previous-tile branch (which cost two register copies per quad at the join)
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accB[g][r] = kInf;
         // one tile: MFMAs of tile t into `cur`, packed-key inserts of tile t-1 from `prev` interleaved.
         // Every LDS access in here is inline asm: an ordinary load would make hipcc drain the in-flight LDS-DMA.
         auto tile = [&](f32x16(&cur)[2], f32x16(&prev)[2], int t, bool have_prev) {
@@ -823,7 +833,7 @@ __device__ __forceinline__ void filter_split2_body(
 #pragma unroll
                 for (int g = 0; g < 2; ++g) cur[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_aug, b_aug[g], zero, 0, 0, 0);
             }
-            const int seq0 = __builtin_amdgcn_readfirstlane(((t - 1) - sub_t0) << 2);
+            const int seq0 = __builtin_amdgcn_readfirstlane(max((t - 1) - sub_t0, 0) << 2);   // (first tile: the +inf previous tile)
 #pragma unroll
             for (int st = 0; st < 8; ++st) {
                 if constexpr (KMID) {
@@ -864,7 +874,7 @@ __device__ __forceinline__ void filter_split2_body(
                 if (have_prev && (ABL & 1)) {    // dev ablation: keep the MFMAs alive with one op per k-step
                     ka[0] = min(ka[0], __float_as_int(prev[0][2 * st]) + __float_as_int(prev[0][2 * st + 1]));
                     ka[1] = min(ka[1], __float_as_int(prev[1][2 * st]) + __float_as_int(prev[1][2 * st + 1]));
-                } else if (have_prev) {          // 2 values of each group per k-step: 16 VALU beside the MFMAs
+                } else {                         // a register quad of each group every second k-step, beside the MFMAs
                     if (st & 1) {                // one register quad of each group every second k-step
                         key_insert4<4>(prev[0], 4 * (st >> 1), seq0, vmask, ka[0], kb[0], kc[0]);
                         key_insert4<4>(prev[1], 4 * (st >> 1), seq0, vmask, ka[1], kb[1], kc[1]);
