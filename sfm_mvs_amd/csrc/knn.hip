@@ -1130,6 +1130,7 @@ constexpr int kS1 = 6;           // candidate records per lane fetched up front 
 constexpr int kRescanRows = 1;   // trains a quad has in flight during a rescan (32 VGPRs each)
 constexpr int kRefItems = 512;   // rescan work list (query, stream); more → 16 candidate slots per query at a time (<= 96)
 constexpr int kPreRows = 2;      // trains a quad has in flight during the rescan's fp16 prefilter (16 VGPRs each)
+constexpr int kHotPre = 2;       // rows a lane quad has in flight in the hot-path fp16 screen (16 VGPRs each)
 constexpr int kQualCap = 144;    // exact-evaluation list per query (a chunk of 16 records adds up to 64 rows)
 
 // Sixteen lanes per query, sixteen queries per workgroup (one resident round for 10^4 queries).
@@ -1212,6 +1213,7 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
     }
     qq += lane_xor<8>(qq); qq += lane_xor<4>(qq); qq += lane_xor<2>(qq); qq += lane_xor<1>(qq);
     const float nsum = sqrtf(qq) + sqrtf(tmax);
+    if (sl == 0) q_qq[ql] = qq;                           // parked in LDS: the kernel sits at the 168-VGPR limit of a single resident round
     const float eps = 1.01f * (eps_coef * nsum * nsum + (mode == kModeHalf ? kEpsHalfAbs * nsum : 0.f));
 #pragma unroll
     for (int k = 0; k < kS1; ++k) {
@@ -1267,6 +1269,63 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
     double lim = 0.0;
     bool rescanned = false;
     const bool use_half = thalf && (mode == kModeHalf || mode == kModeHalfExact);
+    // A record names four rows but usually only the one that produced its minimum is near the threshold.  In the fp16
+    // modes the rows are screened first against the fp16 train image (L2-resident: the filter just streamed it; half the
+    // bytes): s' = ||t||^2 + ||q||^2 - 2 q.t^ has |s' - d^2| <= eps (only t is rounded), and a row of the exact top-2 has
+    // d^2 <= m2 + eps, hence s' <= m2 + 2 eps < thr: rows with s' > thr cannot matter.  A lane quad per row, kHotPre rows
+    // per quad and pass (4 * kHotPre rows of the query per pass), survivors compacted in place.
+    auto prefilter = [&]() {
+        int nmax = cnt;
+        nmax = max(nmax, lane_xor<16>(nmax));
+        nmax = max(nmax, lane_xor<32>(nmax));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int jq = sl & 3, qd = sl >> 2;
+        int kept = 0;
+#pragma unroll 1
+        for (int e0 = 0; e0 < nmax; e0 += 4 * kHotPre) {
+            int tr[kHotPre];
+            uint4 hv[kHotPre][4];
+            float tnv[kHotPre];
+#pragma unroll
+            for (int r = 0; r < kHotPre; ++r) {
+                const int e = e0 + qd + 4 * r;
+                tr[r] = e < cnt ? qual[ql][e] : -1;
+                const int row = tr[r] >= 0 ? tr[r] : 0;
+#pragma unroll
+                for (int n = 0; n < 4; ++n) hv[r][n] = *reinterpret_cast<const uint4*>(thalf + (int64_t)row * kDim + 32 * n + 8 * jq);
+                tnv[r] = tn[row];
+            }
+            __builtin_amdgcn_wave_barrier();              // every entry of this pass is in registers before any is overwritten
+            bool pass[kHotPre];
+#pragma unroll
+            for (int r = 0; r < kHotPre; ++r) {
+                float dot = 0.f;
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const f16x8 hx = __builtin_bit_cast(f16x8, hv[r][n]);
+                    const float4 qa = *reinterpret_cast<const float4*>(&qrows[ql][32 * n + 8 * jq]);
+                    const float4 qb = *reinterpret_cast<const float4*>(&qrows[ql][32 * n + 8 * jq + 4]);
+                    dot = fmaf(qa.x, (float)hx[0], dot); dot = fmaf(qa.y, (float)hx[1], dot);
+                    dot = fmaf(qa.z, (float)hx[2], dot); dot = fmaf(qa.w, (float)hx[3], dot);
+                    dot = fmaf(qb.x, (float)hx[4], dot); dot = fmaf(qb.y, (float)hx[5], dot);
+                    dot = fmaf(qb.z, (float)hx[6], dot); dot = fmaf(qb.w, (float)hx[7], dot);
+                }
+                dot += lane_xor<2>(dot);
+                dot += lane_xor<1>(dot);
+                const float sp = (tnv[r] + q_qq[ql]) - 2.f * dot;
+                pass[r] = jq == 0 && tr[r] >= 0 && !(thr < sp);
+            }
+#pragma unroll
+            for (int r = 0; r < kHotPre; ++r) {
+                const unsigned m16 = (unsigned)(__ballot(pass[r]) >> (16 * sub)) & 0xFFFFu;
+                if (pass[r]) qual[ql][kept + __popc(m16 & ((1u << sl) - 1u))] = tr[r];
+                kept += __popc(m16);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        cnt = kept;
+    };
     for (int k0 = 0; k0 * 16 < NC;) {                     // (wave-uniform)
         for (; k0 * 16 < NC; ++k0) {
             if (__any(cnt > kQualCap - 16 * kRecRows)) break;   // the list might not take another chunk: evaluate first
@@ -1284,6 +1343,7 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
             }
             cnt += kRecRows * __popc(mine);
         }
+        if (use_half) prefilter();                        // (wave-uniform)
         evaluate();                                       // the hot site
     }
     for (int round = 0;; ++round) {
@@ -1300,7 +1360,6 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
         if (open) {
             if (sl == 0) {
                 q_lim[ql] = lim;
-                q_qq[ql] = qq;
                 cnt_lds[ql] = 0;
             }
             for (int c = sl; c < NC; c += 16)
