@@ -169,3 +169,31 @@ def test_sift_full_size_photograph_shape(hip, oracle):
     kpo, deso = oracle.sift(g)
     kp, des, eng = _sift_hip(g, max_keypoints=1 << 18)
     assert len(kpo) > 20000 and _same(kp, kpo) and _same(des, deso)
+
+
+def test_sift_pipeline_matches_single_engine(hip):
+    """Frames in flight on several streams (SiftPipeline) give exactly what one engine gives frame by frame."""
+    from sfm_mvs_amd import sift
+    frames = [torch.as_tensor(scene_image(288, 208, 40 + k)).cuda() for k in range(7)]
+    one = sift.Sift(288, 208, "cuda")
+    want = []
+    for f in frames:
+        kp, des = one.run(f)
+        want.append((kp.clone(), des.clone()))
+    pipe = sift.SiftPipeline(288, 208, "cuda", depth=3)
+    got, pending = [], []
+    for f in frames:
+        if len(pending) == pipe.depth:
+            st, eng = pending.pop(0)
+            st.synchronize()
+            n = eng.check_capacity()
+            got.append((eng.keypoints[:n].clone(), eng.descriptors[:n].clone()))
+        _, st, eng = pipe.submit(f)
+        pending.append((st, eng))
+    for st, eng in pending:
+        st.synchronize()
+        n = eng.check_capacity()
+        got.append((eng.keypoints[:n].clone(), eng.descriptors[:n].clone()))
+    assert len(got) == len(want)
+    for (ka, da), (kb, db) in zip(got, want):
+        assert torch.equal(ka.view(torch.int32), kb.view(torch.int32)) and torch.equal(da, db)
