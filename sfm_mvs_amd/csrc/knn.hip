@@ -663,8 +663,14 @@ __device__ __forceinline__ void filter_split2_body(
     const int j = lane & 31;
     const int h = lane >> 5;
     const int hm = h ^ (j & 15);
-    const int64_t u_end = wg_begin[blockIdx.x + 1];
-    int64_t u = wg_begin[blockIdx.x];
+    // XCD-aware order: consecutive workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2), while
+    // consecutive ranges of the partition share query row blocks and neighbouring train tiles.  Physical workgroup b
+    // takes range (b % 8) * (G / 8) + b / 8, so each XCD works on ONE contiguous eighth of the (row block, tile) space:
+    // its L2 then holds an eighth of the query image instead of all of it.
+    const int G = gridDim.x;
+    const int bid = (G & 7) == 0 ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int64_t u_end = wg_begin[bid + 1];
+    int64_t u = wg_begin[bid];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
     const unsigned lds_tn = lds0 + kRing * kTileFloats * 4;
     const int mid_off = nt_pad * 256;
@@ -702,7 +708,7 @@ __device__ __forceinline__ void filter_split2_body(
         const int rb = (int)(u / tiles);
         const int t_begin = (int)(u - (int64_t)rb * tiles);
         const int t_end = (int)min((int64_t)tiles, t_begin + (u_end - u));
-        const int slot = blockIdx.x - rb_first[rb];
+        const int slot = bid - rb_first[rb];
         const int qrow0 = rb * (W * 64) + wave * 64 + j;          // group g adds 32*g
         const bool qok[2] = {qrow0 < nq, qrow0 + 32 < nq};
 
