@@ -1156,6 +1156,12 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
     int* __restrict__ idx_out, float* __restrict__ dist_out, int* __restrict__ stats, double ratio,
     int* __restrict__ ratio_counts /*null unless fused with the Lowe ratio*/, unsigned char* __restrict__ ratio_mask,
     long long* __restrict__ trace) {
+    // XCD-aware order (see the filter): physical workgroup b takes query block (b % 8) * chunk + b / 8, so the queries an
+    // XCD refines are (roughly) those whose candidate records its own filter workgroups wrote
+    const int n_wg = (nq + kRefQ - 1) / kRefQ, wg_chunk = (n_wg + 7) >> 3;
+    const int bid = n_wg >= 64 ? (int)(blockIdx.x & 7) * wg_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (bid >= n_wg) return;
+
     __shared__ __attribute__((aligned(16))) float qrows[kRefQ][kDim];
     __shared__ int qual[kRefQ][kQualCap];
     __shared__ int items[kRefItems];                     // (query slot << 20) | stream
@@ -1165,16 +1171,16 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
     __shared__ int surv[kSubTiles * 16];
     __shared__ int nitem, nsurv;
     __shared__ Best2 wbest[4];
-    if (trace && threadIdx.x == 0) trace[16 * blockIdx.x + 0] = wall_clock64();   // dev diagnostics
+    if (trace && threadIdx.x == 0) trace[16 * bid + 0] = wall_clock64();   // dev diagnostics
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int sub = lane >> 4, sl = lane & 15;           // query slot inside the wave, lane inside the query
     const int ql = wave * 4 + sub;                       // query slot inside the workgroup
-    const int q = blockIdx.x * kRefQ + ql;
+    const int q = bid * kRefQ + ql;
     const bool valid = q < nq;
 
     for (int e = threadIdx.x; e < kRefQ * 32; e += 256) {
-        const int row = blockIdx.x * kRefQ + (e >> 5);
+        const int row = bid * kRefQ + (e >> 5);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (row < nq) v = *reinterpret_cast<const float4*>(Q + (int64_t)row * ldq + 4 * (e & 31));
         *reinterpret_cast<float4*>(&qrows[e >> 5][4 * (e & 31)]) = v;
@@ -1191,13 +1197,13 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
 
     // streams of this workgroup's query row block = filter blocks that touched it (contiguous slots from 0);
     // the queries of a workgroup share the row block (rows_per_block is a multiple of 16)
-    const int rb = (blockIdx.x * kRefQ) / rows_per_block;
+    const int rb = (bid * kRefQ) / rows_per_block;
     const int fb = rb_first[rb];
     const int lb = rb_last[rb];
     const int NC = 2 * (lb - fb + 1) * nsub * 3;
     const float* cs = cand_s + (int64_t)(valid ? q : 0) * (2 * smax * 3);
     const int* ci = cand_i + (int64_t)(valid ? q : 0) * (2 * smax * 3);
-    if (blockIdx.x == 0 && threadIdx.x == 0 && stats) {
+    if (bid == 0 && threadIdx.x == 0 && stats) {
         stats[1] = G; stats[2] = 2 * smax; stats[3] = mode;
     }
 
@@ -1211,7 +1217,7 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
         s1v[k] = (valid && c < NC) ? cs[c] : kInf;
     }
     __syncthreads();                                     // query rows in LDS
-    if (trace && threadIdx.x == 0) trace[16 * blockIdx.x + 1] = wall_clock64();
+    if (trace && threadIdx.x == 0) trace[16 * bid + 1] = wall_clock64();
     float qq;
     {
         const float4 a = *reinterpret_cast<const float4*>(&qrows[ql][8 * sl]), c4 = *reinterpret_cast<const float4*>(&qrows[ql][8 * sl + 4]);
@@ -1246,7 +1252,7 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
     // m2 + 1.5*eps: farther than both by > eps/2 >= 300u*(|q|+|t|)^2, which also separates the float32 square roots
     // (one ulp of sqrtf is < 2^-22 relative in d^2) — it cannot be in the exact top-2, ties included.
     const float thr = m2 + 2.5f * eps;
-    if (trace && threadIdx.x == 0) trace[16 * blockIdx.x + 2] = wall_clock64();
+    if (trace && threadIdx.x == 0) trace[16 * bid + 2] = wall_clock64();
 
     // Sweep 2: the survivors of ALL candidate chunks are compacted in LDS first, then evaluated 8 per pass (a lane
     // pair each), so the dependent train-row fetches of a query overlap instead of costing one round trip per chunk.
@@ -1355,7 +1361,7 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
     for (int round = 0;; ++round) {
         if (round == 1) evaluate();                       // rescan survivors (cold site)
         best2_group_reduce<16>(b);
-        if (trace && threadIdx.x == 0 && round == 0) trace[16 * blockIdx.x + 3] = wall_clock64();
+        if (trace && threadIdx.x == 0 && round == 0) trace[16 * bid + 3] = wall_clock64();
         if (round == 1) break;
         // Certificate.  (s3 < 0 can only be rounding noise: such a stream never certifies.)
         lim = b.i[1] != INT_MAX ? (double)b.dsq[1] + (double)eps : (double)kInf;
@@ -1405,7 +1411,7 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
                 const int t_end = min((int)(u1 - (int64_t)rb * tiles), t_begin + kSubTiles);
                 const int ntr = (t_end - t_begin) * 16;
                 auto train_of = [&](int i) { return (t_begin + (i >> 4)) * kTileT + (i & 3) + 8 * ((i >> 2) & 3) + 4 * h; };
-                if (trace && threadIdx.x == 0 && !trace[16 * blockIdx.x + 6]) trace[16 * blockIdx.x + 6] = wall_clock64();
+                if (trace && threadIdx.x == 0 && !trace[16 * bid + 6]) trace[16 * bid + 6] = wall_clock64();
                 // Which of the stream's trains need the exact arithmetic?  In the fp16 modes the fp16 image (L2-resident:
                 // the filter just streamed it; half the bytes of the fp32 rows in HBM) gives s' = ||t||^2 + ||q||^2 - 2 q.t^
                 // with |s' - d^2| <= eps (only t is rounded here, the filter rounds both operands), so only trains with
@@ -1455,7 +1461,7 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
                 }
                 __syncthreads();
                 const int ns = nsurv;
-                if (trace && threadIdx.x == 0 && !trace[16 * blockIdx.x + 7]) { trace[16 * blockIdx.x + 7] = wall_clock64(); trace[16 * blockIdx.x + 10] = ns; }
+                if (trace && threadIdx.x == 0 && !trace[16 * bid + 7]) { trace[16 * bid + 7] = wall_clock64(); trace[16 * bid + 10] = ns; }
                 const int have = cnt_lds[w];
                 if (have + ns <= kQualCap) {
                     // the usual case, a few survivors: queue them for the owning query's next (hot) evaluation
@@ -1500,7 +1506,7 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
             }
         }
         if (open) cnt = cnt_lds[ql];                       // survivors queued for this query → round 1
-        if (trace && threadIdx.x == 0) trace[16 * blockIdx.x + 8] = wall_clock64();
+        if (trace && threadIdx.x == 0) trace[16 * bid + 8] = wall_clock64();
     }
 
     if (valid && sl == 0) {
@@ -1516,11 +1522,11 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
         const bool pass = valid && sl == 0 && b.i[1] != INT_MAX && (double)b.d[0] < ratio * (double)b.d[1];
         if (ratio_mask && valid && sl == 0) ratio_mask[q] = pass ? 1 : 0;
         const int n = __popcll(__ballot(pass));
-        if (lane == 0 && n) atomicAdd(ratio_counts + (blockIdx.x * kRefQ) / kRatioBlock, n);
+        if (lane == 0 && n) atomicAdd(ratio_counts + (bid * kRefQ) / kRatioBlock, n);
     }
     if (trace && threadIdx.x == 0) {
-        trace[16 * blockIdx.x + 4] = wall_clock64();
-        trace[16 * blockIdx.x + 5] = __builtin_amdgcn_s_getreg(0xF804);
+        trace[16 * bid + 4] = wall_clock64();
+        trace[16 * bid + 5] = __builtin_amdgcn_s_getreg(0xF804);
     }
 }
 
@@ -1777,8 +1783,9 @@ int knn2_impl(const float* q, int64_t nq, int64_t ldq, const float* t, int64_t n
     sfm::prof_end(sfm::kProfKnnFilter, stream, prof_reps);
     SFM_CHECK_LAUNCH();
     const int force_mode = !p.split ? kModeF32 : g_force_mode;
+    const int64_t refine_wgs = (nq + kRefQ - 1) / kRefQ, refine_grid = refine_wgs >= 64 ? 8 * ((refine_wgs + 7) / 8) : refine_wgs;
     sfm::prof_begin(sfm::kProfKnnRefine, stream);
-    hipLaunchKernelGGL(knn_refine_kernel, dim3((unsigned)((nq + kRefQ - 1) / kRefQ)), dim3(256), 0, stream, q, ldq, (int)nq, t, ldt,
+    hipLaunchKernelGGL(knn_refine_kernel, dim3((unsigned)refine_grid), dim3(256), 0, stream, q, ldq, (int)nq, t, ldt,
                        (int)nt, w.cand_s, w.cand_i, p.rows_per_block, p.tiles, p.units, p.G, p.smax * p.nsub, p.nsub,
                        force_mode, w.midflag, w.bmax, p.split ? w.tsplit + (size_t)2 * p.tiles * kTileT * kDim : nullptr, w.tn, w.wg_begin, w.rb_first, w.rb_last, idx, dist,
                        stats, ratio, ratio_counts, ratio_mask, g_trace ? g_trace + 16384 : nullptr);
