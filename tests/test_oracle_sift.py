@@ -119,3 +119,20 @@ def test_sift_scale_covariance(oracle):
         b = kp2[np.hypot(kp2[:, 0] - 2 * cx - 0.5, kp2[:, 1] - 2 * cy - 0.5) < 1.5][0]
         assert abs(b[2] / a[2] - 2) < 0.12
         assert ((b[5:6].view(np.int32)[0] + 1) & 255) - ((a[5:6].view(np.int32)[0] + 1) & 255) == 1
+
+
+def test_scale_space_against_an_independent_gaussian_filter(oracle):
+    """Octave 0 of the oracle's pyramid against scipy.ndimage.gaussian_filter (float64, mirror = BORDER_REFLECT_101,
+    truncation at 4 sigma like OpenCV's ksize rule) applied layer to layer with OpenCV's sigma schedule."""
+    from scipy.ndimage import gaussian_filter
+    g = scene_image(96, 72, 8)
+    _, _, pyr = oracle.sift(g, want_pyramid=True)
+    assert pyr.shape == (6, 144, 192)
+    k = 2.0 ** (1.0 / 3)
+    prev = pyr[0].astype(np.float64)
+    for i in range(1, 6):
+        sp = 1.6 * k ** (i - 1)
+        sig = np.sqrt((sp * k) ** 2 - sp ** 2)
+        want = gaussian_filter(prev, sig, mode="mirror", truncate=4.0)
+        assert np.abs(pyr[i] - want).max() < 0.02           # grey levels of 255; the 27-tap layer differs by its last tap
+        prev = pyr[i].astype(np.float64)
