@@ -10,7 +10,8 @@ its own pair (the path shards by query image) and the step ends wit
 exchange: one RCCL all-gather of the fixed-stride match records.
 
 Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events around the dominant
-kernel (knn_filter_kernel, v_mfma_f32_32x32x2_f32) via the library's sfm_profile_* hook;
+kernel (knn_filter_split2_kernel, v_mfma_f32_32x32x16_f16) via the library's sfm_profile_* hook, on
+steps run after the timed region;
 `cpu_baseline` times the CPU oracle (a port of OpenCV's batchDistance semantics) on a bounded
 sample of the same workload with all host cores.
 """
@@ -28,7 +29,7 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (no sparsity)
-PROF_EVERY = 8                     # steps between profiled launches in the timed region
+PROF_SAMPLES = 6                   # profiled steps, run alone AFTER the timed region
 PIPE_DEPTH = 3                     # independent pairs in flight (one stream + workspace each)
 PROF_REPEAT = 3                    # filter launches per HIP-event pair on a profiled step (an event pair adds ~7 us to one)
 EXCH_BATCH = 8                     # pairs per RCCL all-gather at N > 1
@@ -132,6 +133,11 @@ def cpu_knn_baseline(nq, nt, seed_q, seed_t):
     return out
 
 
+def knn_source_hash():
+    import hashlib
+    return hashlib.sha256(open(os.path.join(ROOT, "sfm_mvs_amd", "csrc", "knn.hip"), "rb").read()).hexdigest()
+
+
 def bench_knn(args, world, rank, dev):
     from sfm_mvs_amd import ops
     nq, nt = args.nq, args.nt
@@ -182,42 +188,43 @@ def bench_knn(args, world, rank, dev):
         step()
     flush()
     barrier_sync(world)
-    # The library brackets its kernels with HIP events on the launch stream when profiling is on.  An event pair costs
-    # ~3.5 us of stream time, and with several pairs in flight a kernel's event-to-event time also contains the
-    # neighbours' kernels it shares the chip with — so a few steps of the timed region are run ALONE (pipeline drained
-    # before and after) with the events on; the roofline's launch duration is the average over those launches.
-    # The drains are inside the timed region and cost `value` 2-3 percent.
-    # Pipelined: the first and the last step of the timed region (the pipeline is empty there anyway) and the middle
-    # one (which costs a drain + refill).
-    if depth == 1:
-        profiled = set(range(0, args.steps, PROF_EVERY))
-    else:
-        profiled = {0, args.steps // 2, args.steps - 1}
-    ops.profile_read(0), ops.profile_read(1)               # clear the slots
+    # The timed region is ONLY step() calls (+ the closing exchange): barrier + device-wide sync on both sides.
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if i in profiled:
-            if depth > 1:
-                pipe.synchronize()
-            ops.profile_enable(PROF_REPEAT)
-            step()
-            ops.profile_enable(False)
-            if depth > 1:
-                pipe.synchronize()
-        else:
-            step()
+        step()
     flush()
     barrier_sync(world)
     elapsed = time.perf_counter() - t0
+    elapsed = max_over_ranks(elapsed, world, dev)
+    # Roofline sampling, AFTER the timed region: the library brackets its kernels with HIP events on the launch stream
+    # when profiling is on.  An event pair costs ~3.5 us of stream time, and with several pairs in flight a kernel's
+    # event-to-event time also contains the neighbours' kernels it shares the chip with — so the sampled steps run
+    # ALONE (pipeline drained before and after), and on them the (idempotent) filter kernel is launched PROF_REPEAT
+    # times inside one event pair so that the event overhead is amortised.
+    ops.profile_read(0), ops.profile_read(1)               # clear the slots
+    pipe.synchronize()
+    for i in range(PROF_SAMPLES):
+        ops.profile_enable(PROF_REPEAT)
+        step()
+        ops.profile_enable(False)
+        pipe.synchronize()
+    flush()
+    barrier_sync(world)
     filt_ms, filt_n = ops.profile_read(0)
     ref_ms, ref_n = ops.profile_read(1)
-    elapsed = max_over_ranks(elapsed, world, dev)
     stats = pm.stats.cpu().tolist()
 
-    traffic = None          # HBM-side bytes per launch of the dominant kernel, from the committed PMC passes
+    # HBM-side bytes per launch of the dominant kernel come from PMC passes (rocprofv3 cannot be driven from inside the
+    # process); the committed figure is stamped with the sha256 of the kernel source it was measured on and is
+    # reported only while that source is unchanged.
+    traffic, traffic_note = None, "no PMC figure for this shape"
     tpath = os.path.join(ROOT, "profiles", "knn_traffic.json")
     if os.path.exists(tpath) and (nq, nt) == (10000, 10000):
-        traffic = json.load(open(tpath)).get("bytes_per_launch")
+        tj = json.load(open(tpath))
+        if tj.get("knn_hip_sha256") == knn_source_hash():
+            traffic, traffic_note = tj.get("bytes_per_launch"), f"profiles/knn_traffic.json ({tj.get('source')})"
+        else:
+            traffic_note = "profiles/knn_traffic.json is stale (csrc/knn.hip changed since the PMC passes): not reported"
     value = world * nq * nt * args.steps / elapsed
     filt_avg_ms = filt_ms / max(filt_n, 1)
     algo_flop = nq * nt * FLOP_PER_DISTANCE
@@ -242,15 +249,14 @@ def bench_knn(args, world, rank, dev):
                                   + f"; {depth} independent pairs in flight per GPU (one HIP stream each)"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                     "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/knn_traffic.json)",
+                     "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_note,
                      "algorithmic_bytes_per_launch": 4 * 128 * (nq + nt) + 16 * nq,
                      "kernel": "knn_filter_split2_kernel<0, 4>", "avg_launch_ms": filt_avg_ms, "launches": filt_n,
                      "algorithmic_flop_per_launch": algo_flop,
                      "issued_mfma_tflops": issued, "issued_frac_of_peak": issued / BF16_MFMA_PEAK_TFLOPS,
-                     "launch_sampling": (f"HIP events on every {PROF_EVERY}th step of the timed region" if depth == 1 else
-                                         "HIP events on the first, middle and last step of the timed region, each run alone (pipeline drained)")
-                                        + f"; on those steps the filter kernel is launched {PROF_REPEAT}x back-to-back inside the event pair "
-                                          "(idempotent) so that the event overhead (~7 us per pair) is amortised",
+                     "launch_sampling": f"HIP events around the filter kernel on {PROF_SAMPLES} steps run alone AFTER the timed region "
+                                        f"(pipeline drained); on those steps the kernel is launched {PROF_REPEAT}x back-to-back inside "
+                                        "the event pair (idempotent) so that the event overhead (~7 us per pair) is amortised",
                      "note": "algorithmic = 256 FLOP per distance (SURVEY 8d); issued = MFMA flops of the arithmetic mode that ran"},
         "kernels_ms": {"knn_filter": filt_avg_ms, "knn_refine": ref_ms / max(ref_n, 1)},
         "knn_stats": {"rescanned_queries": stats[0], "filter_workgroups": stats[1], "streams_per_query": stats[2],
