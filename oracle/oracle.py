@@ -201,6 +201,133 @@ def recover_pose_score(Ps, x1n, x2n, dist=50.0, rows=4):
     return counts, mask
 
 
+# ---- RANSAC entry points (solvers_oracle.c): sequential restatements of the cv2 calls of sfm.py:67,307,311 ----
+class CvRNG:
+    """cv::RNG stream (seed 2^64-1 inside RANSAC)."""
+
+    def __init__(self, state=0xFFFFFFFFFFFFFFFF):
+        self.state = C.c_uint64(state)
+        lib().orc_rng_next.restype = C.c_uint32
+
+    def next(self):
+        return int(lib().orc_rng_next(C.byref(self.state)))
+
+    def uniform(self, a, b):
+        return int(lib().orc_rng_uniform(C.byref(self.state), C.c_int(a), C.c_int(b)))
+
+
+def ransac_update_num_iters(p, ep, model_points, max_iters):
+    return int(lib().orc_ransac_update_num_iters(C.c_double(p), C.c_double(ep), C.c_int(model_points), C.c_int(max_iters)))
+
+
+def svd(A, full_uv=False):
+    """cv::SVD::compute: returns w, U, Vt."""
+    A = _f64(A)
+    m, n = A.shape
+    k = min(m, n)
+    w = np.empty(k)
+    U = np.empty((m, m if full_uv else k))
+    Vt = np.empty((n if full_uv else k, n))
+    lib().orc_svd(_p(A), C.c_int(m), C.c_int(n), C.c_int(1 if full_uv else 0), _p(w), _p(U), _p(Vt))
+    return w, U, Vt
+
+
+def solve_poly(coeffs, max_iters=300):
+    """cv::solvePoly: coeffs[k] multiplies x^k; complex roots in OpenCV's order."""
+    c = _f64(coeffs).reshape(-1)
+    deg = len(c) - 1
+    re, im = np.empty(deg), np.empty(deg)
+    n = lib().orc_solve_poly(_p(c), C.c_int(deg), _p(re), _p(im), C.c_int(max_iters))
+    return re[:n] + 1j * im[:n]
+
+
+def five_point(x1n, x2n):
+    x1n, x2n = _f64(x1n).reshape(5, 2), _f64(x2n).reshape(5, 2)
+    E = np.empty((10, 9))
+    k = lib().orc_five_point(_p(x1n), _p(x2n), _p(E))
+    return E[:k].reshape(k, 3, 3).copy()
+
+
+def k_normalise(pts, K):
+    pts = _f32(pts).reshape(-1, 2)
+    out = np.empty((len(pts), 2))
+    lib().orc_k_normalise(_p(pts), C.c_int64(len(pts)), _p(_f64(K).reshape(9)), _p(out))
+    return out
+
+
+def find_essential_mat(pts0, pts1, K, prob=0.999, threshold=1.0, max_iters=1000, want_stats=False):
+    """cv2.findEssentialMat(pts0, pts1, K, RANSAC, prob, threshold) -> (E (3k,3) or None, mask (N,1) uint8 {0,1})."""
+    p0, p1 = _f32(pts0).reshape(-1, 2), _f32(pts1).reshape(-1, 2)
+    n = len(p0)
+    E = np.empty((10, 9))
+    mask = np.zeros(max(n, 1), np.uint8)
+    stats = np.zeros(3, np.int32)
+    k = lib().orc_find_essential_mat(_p(p0), _p(p1), C.c_int64(n), _p(_f64(K).reshape(9)), C.c_double(prob),
+                                     C.c_double(threshold), C.c_int(max_iters), _p(E), _p(mask), _p(stats))
+    out = (None, None) if k <= 0 else (E[:k].reshape(3 * k, 3).copy(), mask[:n].reshape(-1, 1))
+    return out + (stats,) if want_stats else out
+
+
+def decompose_essential(E):
+    R1, R2, t = np.empty((3, 3)), np.empty((3, 3)), np.empty(3)
+    lib().orc_decompose_essential(_p(_f64(E).reshape(9)), _p(R1), _p(R2), _p(t))
+    return R1, R2, t
+
+
+def recover_pose(E, pts0, pts1, K, dist=50.0, rows=4):
+    """cv2.recoverPose(E, pts0, pts1, K) -> (good, R, t (3,1), mask (N,1) uint8 {0,255})."""
+    p0, p1 = _f32(pts0).reshape(-1, 2), _f32(pts1).reshape(-1, 2)
+    n = len(p0)
+    R, t = np.empty((3, 3)), np.empty(3)
+    mask = np.zeros(max(n, 1), np.uint8)
+    good = lib().orc_recover_pose(_p(_f64(E).reshape(-1)[:9].copy()), _p(p0), _p(p1), C.c_int64(n), _p(_f64(K).reshape(9)),
+                                  C.c_double(dist), C.c_int(rows), _p(R), _p(t), _p(mask))
+    return int(good), R, t.reshape(3, 1), mask[:n].reshape(-1, 1)
+
+
+def epnp(K, Xw, uv):
+    Xw, uv = _f64(Xw).reshape(-1, 3), _f64(uv).reshape(-1, 2)
+    R, t = np.empty((3, 3)), np.empty(3)
+    rc = lib().orc_epnp(_p(_f64(K).reshape(9)), _p(Xw), _p(uv), C.c_int(len(Xw)), _p(R), _p(t))
+    if rc != 0:
+        raise ValueError("orc_epnp: 4 <= n <= 64 points")
+    return R, t
+
+
+def pnp_dlt_init(K, X, uv):
+    """Non-planar initialisation of solvePnP(ITERATIVE) -> (status, rvec, tvec); status 1 planar, 2 too few points."""
+    X, uv = _f64(X).reshape(-1, 3), _f64(uv).reshape(-1, 2)
+    r, t = np.zeros(3), np.zeros(3)
+    st = lib().orc_pnp_dlt_init(_p(X), _p(uv), C.c_int64(len(X)), _p(_f64(K).reshape(9)), _p(r), _p(t))
+    return int(st), r, t
+
+
+def levmarq_pose(K, X, uv, rvec, tvec):
+    X, uv = _f64(X).reshape(-1, 3), _f64(uv).reshape(-1, 2)
+    r, t = _f64(rvec).reshape(3).copy(), _f64(tvec).reshape(3).copy()
+    it = C.c_int(0)
+    lib().orc_levmarq_pose(_p(X), _p(uv), C.c_int64(len(X)), _p(_f64(K).reshape(9)), _p(r), _p(t), C.byref(it))
+    return r, t, it.value
+
+
+def solve_pnp_ransac(X, uv, K, iterations=100, reproj_error=8.0, confidence=0.99, want_model=False):
+    """cv2.solvePnPRansac(X, uv, K, zeros(5,1)) with the defaults -> (ok, rvec (3,1), tvec (3,1), inliers (k,1) int32)."""
+    X, uv = _f32(X).reshape(-1, 3), _f32(uv).reshape(-1, 2)
+    n = len(X)
+    r, t, model = np.zeros(3), np.zeros(3), np.zeros(6)
+    inl = np.empty(max(n, 1), np.int32)
+    ninl, st = C.c_int64(0), C.c_int(0)
+    ok = lib().orc_solve_pnp_ransac(_p(X), _p(uv), C.c_int64(n), _p(_f64(K).reshape(9)), C.c_int(iterations),
+                                    C.c_float(reproj_error), C.c_double(confidence), _p(r), _p(t), _p(inl), C.byref(ninl),
+                                    _p(model), C.byref(st))
+    if ok < 0:
+        raise ValueError("orc_solve_pnp_ransac: at least 5 correspondences (P3P branch not restated)")
+    if ok == 0:
+        return (False, None, None, None) + ((None, st.value) if want_model else ())
+    out = (True, r.reshape(3, 1), t.reshape(3, 1), inl[:ninl.value].reshape(-1, 1).copy())
+    return out + ((model, st.value) if want_model else ())
+
+
 def bgr2gray(bgr):
     bgr = np.ascontiguousarray(bgr, np.uint8)
     h, w, _ = bgr.shape

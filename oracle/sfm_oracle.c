@@ -144,7 +144,7 @@ static double dot_lanes(const double* x, const double* y, int m) {
 #define SVD_MAXN 12
 #define SVD_MAXM 32
 
-static void jacobi_core(double* At /* n x m */, int m, int n, double* W, double* Vt /* n x n */) {
+void orc_jacobi_core(double* At /* n x m */, int m, int n, double* W, double* Vt /* n x n */) {
     const double eps = DBL_EPSILON * 10;
     const int max_iter = m > 30 ? m : 30;
     for (int i = 0; i < n; ++i) {
@@ -237,7 +237,7 @@ void orc_jacobi_svd(const double* A, int m, int n, double* w, double* U, double*
     if (n > SVD_MAXN || m > SVD_MAXM || m < n) return;
     for (int i = 0; i < n; ++i)
         for (int k = 0; k < m; ++k) At[i * m + k] = A[k * n + i];
-    jacobi_core(At, m, n, w, Vt);
+    orc_jacobi_core(At, m, n, w, Vt);
     if (U) {
         /* left vectors = rotated columns / singular value (zero columns stay zero) */
         for (int i = 0; i < n; ++i) {

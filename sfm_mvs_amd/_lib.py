@@ -9,7 +9,7 @@ import os
 import torch  # noqa: F401  (loads the ROCm runtime torch was built with before our .so binds to it)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsfmhip.so")
+LIB_PATH = os.environ.get("SFM_HIP_LIB") or os.path.join(_HERE, "lib", "libsfmhip.so")   # (the override is a dev switch for A/B runs of two builds)
 
 ABI_VERSION = 1
 
