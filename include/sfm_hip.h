@@ -259,14 +259,74 @@ int sfm_score_pnp(const double* poses_dev, int h, const double* K_host,
                   int32_t* counts_dev, uint8_t* mask_dev, void* stream);
 
 /* ------------------------------------------------------------------------
- * A6  host-side minimal solver of solvePnPRansac (sfm.py:67): EPnP on a sample of 4..64
- *     correspondences — the hypothesis generator between two device scoring launches
- *     (sfm_score_pnp).  Pure host code, HOST pointers:
- *   K_host 9 doubles (row-major 3x3), Xw_host [n x 3] doubles, uv_host [n x 2] doubles (pixels)
- *   R_host 9 doubles (row-major), t_host 3 doubles
+ * A7  cv2.findEssentialMat(points1, points2, K, method=RANSAC, prob, threshold)      sfm.py:307
+ *     (also isfm.py:80, test.py:240)
+ * The whole call: K-normalisation, five-point hypotheses (host) drawn with OpenCV's RNG,
+ * Sampson scoring of a chunk of hypotheses per launch (device), OpenCV's sequential
+ * best-model / niters bookkeeping.  Returns host scalars, so it synchronises `stream`.
+ *   pts0_dev, pts1_dev [n x 2] float32 (pixels);  K_host 9 doubles (row-major 3x3)
+ *   E_host      9 doubles (row-major);  90 when n == 5 (OpenCV then returns all the solver's models stacked)
+ *   info_host   int32[4]: [0] models written to E_host (0 = no model), [1] inlier count,
+ *               [2] RANSAC iterations run, [3] models scored
+ *   mask_dev    [n] uint8, 1 = inlier of the returned model (OpenCV's {0,1} mask)
+ * ---------------------------------------------------------------------- */
+size_t sfm_find_essential_mat_ws_bytes(int64_t n);
+int sfm_find_essential_mat(const float* pts0_dev, const float* pts1_dev, int64_t n, const double* K_host,
+                           double prob, double threshold, int max_iters, double* E_host, int32_t* info_host,
+                           uint8_t* mask_dev, void* ws_dev, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
+ * A7' cv2.recoverPose(E, points1, points2, K)                                        sfm.py:311
+ * decomposeEssentialMat (host) + the cheirality vote of the four (R, t) candidates over all
+ * correspondences (device, fp64 DLT per point, distanceThresh = 50 by default) + OpenCV's
+ * cascade of >= tests.  rows = 4 (current cv::triangulatePoints system) or 6 (legacy).
+ *   R_host 9 doubles, t_host 3 doubles (unit norm), good_host int32[1] = return value of recoverPose
+ *   mask_dev (optional) [n] uint8, 255 = point passed the vote (OpenCV's {0,255} mask)
+ * ---------------------------------------------------------------------- */
+size_t sfm_recover_pose_ws_bytes(int64_t n);
+int sfm_recover_pose(const double* E_host, const float* pts0_dev, const float* pts1_dev, int64_t n,
+                     const double* K_host, double distance_thresh, int rows, double* R_host, double* t_host,
+                     int32_t* good_host, uint8_t* mask_dev, void* ws_dev, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
+ * A6  cv2.solvePnPRansac(objectPoints, imagePoints, K, distCoeffs = 0)               sfm.py:67
+ * (the reference's 5th positional argument lands in OpenCV's `rvec` slot — SURVEY 3.6-1 — so
+ * every tunable is the default: iterations 100, reprojectionError 8.0, confidence 0.99,
+ * flags ITERATIVE).  EPnP hypotheses on 5-point samples (host), reprojection scoring of a
+ * chunk of hypotheses per launch (device), then solvePnP(ITERATIVE) on the inliers: DLT
+ * initialisation (host) and Levenberg-Marquardt whose residual / J^T J sweeps run on the
+ * device.  n >= 5 (OpenCV's P3P branch for n == 4 is not on this path: SFM_ERR_ARG).
+ *   X_dev [n x 3] float32, uv_dev [n x 2] float32;  rvec_host, tvec_host 3 doubles each
+ *   info_host   int32[4]: [0] 1 = pose found, [1] inlier count, [2] initialisation of the
+ *               refinement (0 DLT, 1 planar object / 2 fewer than 6 inliers: the RANSAC model
+ *               is refined instead — OpenCV uses a homography / raises there), [3] LM iterations
+ *   inliers_dev [n] int32: indices of the best RANSAC model's inliers, ascending (first info[1])
+ * ---------------------------------------------------------------------- */
+size_t sfm_solve_pnp_ransac_ws_bytes(int64_t n);
+int sfm_solve_pnp_ransac(const float* X_dev, const float* uv_dev, int64_t n, const double* K_host, int iterations,
+                         float reproj_error, double confidence, double* rvec_host, double* tvec_host,
+                         int32_t* info_host, int32_t* inliers_dev, void* ws_dev, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
+ * The host-side hypothesis generators behind the three calls above, reachable on their own
+ * (pure host code, HOST pointers, no GPU needed): unit-tested against the oracle.
+ *   sfm_host_epnp                 EPnP on 4..64 correspondences (solvePnPRansac's minimal solver):
+ *                                 K 9 doubles, Xw [n x 3], uv [n x 2] pixels -> R 9, t 3 doubles
+ *   sfm_host_five_point           five K-normalised correspondences [5 x 2] each -> up to 10
+ *                                 essential matrices (E_host 90 doubles), count_host int32
+ *   sfm_host_decompose_essential  E -> R1, R2 (9 doubles each), t (3)
+ *   sfm_host_pnp_dlt_init         ITERATIVE's non-planar initialisation: X [n x 3], uv [n x 2]
+ *                                 doubles -> rvec, tvec; status 0 ok / 1 planar / 2 fewer than 6 points
+ *   sfm_host_rodrigues            cv2.Rodrigues (sfm.py:69,84,119): src 3 (vector) or 9 (matrix)
+ *                                 doubles; jac_host (optional, vector input) dR/dr 3 x 9
  * ---------------------------------------------------------------------- */
 int sfm_host_epnp(const double* K_host, const double* Xw_host, const double* uv_host, int n,
                   double* R_host, double* t_host);
+int sfm_host_five_point(const double* x1n_host, const double* x2n_host, double* E_host, int32_t* count_host);
+int sfm_host_decompose_essential(const double* E_host, double* R1_host, double* R2_host, double* t_host);
+int sfm_host_pnp_dlt_init(const double* K_host, const double* X_host, const double* uv_host, int64_t n,
+                          double* rvec_host, double* tvec_host, int32_t* status_host);
+int sfm_host_rodrigues(const double* src_host, int src_is_matrix, double* dst_host, double* jac_host);
 
 /* ------------------------------------------------------------------------
  * Next row f-1: image preprocessing + SIFT

@@ -47,6 +47,16 @@ SIGNATURES = {
     "sfm_ba_schur_indexed_ws_bytes": (_sz, [_i64]),
     "sfm_ba_schur_indexed": (_int, [_vp, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _int, _vp, _vp, _vp, _sz, _vp]),
     "sfm_host_epnp": (_int, [_vp, _vp, _vp, _int, _vp, _vp]),
+    "sfm_host_five_point": (_int, [_vp, _vp, _vp, _vp]),
+    "sfm_host_decompose_essential": (_int, [_vp, _vp, _vp, _vp]),
+    "sfm_host_pnp_dlt_init": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "sfm_host_rodrigues": (_int, [_vp, _int, _vp, _vp]),
+    "sfm_find_essential_mat_ws_bytes": (_sz, [_i64]),
+    "sfm_find_essential_mat": (_int, [_vp, _vp, _i64, _vp, _f64, _f64, _int, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sfm_recover_pose_ws_bytes": (_sz, [_i64]),
+    "sfm_recover_pose": (_int, [_vp, _vp, _vp, _i64, _vp, _f64, _int, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sfm_solve_pnp_ransac_ws_bytes": (_sz, [_i64]),
+    "sfm_solve_pnp_ransac": (_int, [_vp, _vp, _i64, _vp, _int, _f32, _f64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sfm_bgr2gray_u8": (_int, [_vp, _i64, _i64, _i64, _vp, _vp]),
     "sfm_pyrdown_u8": (_int, [_vp, _i64, _i64, _int, _vp, _vp]),
     "sfm_sift_ws_bytes": (_sz, [_i64, _i64, _int, _i64]),

@@ -1,0 +1,600 @@
+// The RANSAC entry points of the path as single C-ABI calls:
+//
+//   sfm_find_essential_mat   cv2.findEssentialMat(pts0, pts1, K, RANSAC, 0.999, 0.4)        sfm.py:307
+//   sfm_recover_pose         cv2.recoverPose(E, pts0, pts1, K)                              sfm.py:311
+//   sfm_solve_pnp_ransac     cv2.solvePnPRansac(X, p, K, zeros(5,1), <stray arg>)           sfm.py:67
+//
+// Division of labour (the MI355X-native shape of OpenCV's RANSACPointSetRegistrator): hypothesis GENERATION is a
+// few dozen doubles of sequential arithmetic per iteration and stays on the host (host_solvers.h: five-point, EPnP,
+// the ITERATIVE DLT initialisation, the 6x6 Levenberg-Marquardt step); everything that is a sweep over the
+// correspondences runs on the device — Sampson / reprojection scoring of a whole CHUNK of hypotheses in one launch
+// (H x N lanes, integer counts + masks), the cheirality vote of recoverPose, and the Gauss-Newton residual / J^T J
+// sweep of the refinement.  The subsets RANSAC draws do not depend on the scores, so iterations are generated in
+// chunks (8, 16, ... 64 iterations), scored in ONE launch, and the host then replays OpenCV's sequential bookkeeping
+// over the returned counts: every model of an iteration is examined, the best is replaced only on a STRICTLY larger
+// count (> max(best, modelPoints-1)), `niters` is re-estimated then and looked at only between iterations — the result
+// is the one a one-model-at-a-time loop produces.  Per chunk: one upload (models), one launch, one download (counts).
+// The winning mask never leaves the device except for the PnP inlier list.
+//
+// Points come in as device pointers (float32, as the reference holds them); the few values the host-side solvers need
+// (the sampled correspondences, and the inliers for the DLT initialisation) are read from one host copy made per call.
+#include "common.h"
+#include "host_solvers.h"
+#include <algorithm>
+#include <utility>
+#include <vector>
+
+namespace {
+
+namespace hs = sfm::host;
+
+// points.col(0) = (points.col(0) - cx) / fx as OpenCV evaluates it: ONE scaled conversion x * (1/fx) + (-cx * (1/fx)),
+// multiply and add separately rounded (the library is built with -ffp-contract=off).
+struct KNorm {
+    double ifx, ify, bx, by;
+    explicit KNorm(const double* K) : ifx(1. / K[0]), ify(1. / K[4]), bx(-K[2] * (1. / K[0])), by(-K[5] * (1. / K[4])) {}
+};
+
+__global__ __launch_bounds__(256) void k_normalise_kernel(const float* __restrict__ pts, int64_t n, KNorm k,
+                                                          double* __restrict__ out) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float2 p = reinterpret_cast<const float2*>(pts)[i];
+    reinterpret_cast<double2*>(out)[i] = make_double2((double)p.x * k.ifx + k.bx, (double)p.y * k.ify + k.by);
+}
+
+// ---- Gauss-Newton sweep of solvePnP(ITERATIVE) over the inlier set ---------------------------------------------------
+// One lane per inlier (grid-stride inside ONE to 64 workgroups): projection of the float32 object point through
+// (R, t, K) in fp64, residual against the float32 observation, and — mode 1 — the 2x6 Jacobian rows of OpenCV's
+// projectPoints (dp/drvec through dR/drvec, dp/dtvec) folded into the upper triangle of J^T J (21), J^T e (6) and
+// |e|^2.  R, t and dR/dr arrive as kernel arguments (computed on the host, so the sweep has no transcendental math).
+// Sums are reduced in a fixed order (lane tree -> waves -> workgroups): deterministic, no atomics.
+struct PnpCam {
+    double R[9], t[3], dR[27], fx, fy, cx, cy;
+};
+constexpr int kSweepAcc = 28;        // 21 + 6 + 1
+constexpr int kSweepThreads = 1024, kSweepMaxBlocks = 64;
+
+template <int MODE>
+__global__ __launch_bounds__(kSweepThreads) void pnp_sweep_kernel(PnpCam cam, const float* __restrict__ X, const float* __restrict__ uv,
+                                                                  const int32_t* __restrict__ sel, int64_t m,
+                                                                  double* __restrict__ partials) {
+    __shared__ double wacc[kSweepThreads / 64][kSweepAcc];
+    double acc[kSweepAcc];
+#pragma unroll
+    for (int k = 0; k < kSweepAcc; ++k) acc[k] = 0;
+    for (int64_t o = blockIdx.x * (int64_t)kSweepThreads + threadIdx.x; o < m; o += (int64_t)gridDim.x * kSweepThreads) {
+        const int64_t i = sel ? sel[o] : o;
+        const double Xw = X[3 * i], Yw = X[3 * i + 1], Zw = X[3 * i + 2];
+        double x = cam.R[0] * Xw + cam.R[1] * Yw + cam.R[2] * Zw + cam.t[0];
+        double y = cam.R[3] * Xw + cam.R[4] * Yw + cam.R[5] * Zw + cam.t[1];
+        double z = cam.R[6] * Xw + cam.R[7] * Yw + cam.R[8] * Zw + cam.t[2];
+        z = z != 0.0 ? 1. / z : 1.;
+        x *= z;
+        y *= z;
+        const double ru = (x * cam.fx + cam.cx) - (double)uv[2 * i], rv = (y * cam.fy + cam.cy) - (double)uv[2 * i + 1];
+        acc[27] += ru * ru + rv * rv;
+        if (MODE == 1) {
+            double Ju[6], Jv[6];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const double* d = cam.dR + 9 * j;
+                const double dx0 = Xw * d[0] + Yw * d[1] + Zw * d[2];
+                const double dy0 = Xw * d[3] + Yw * d[4] + Zw * d[5];
+                const double dz0 = Xw * d[6] + Yw * d[7] + Zw * d[8];
+                Ju[j] = cam.fx * (z * (dx0 - x * dz0));
+                Jv[j] = cam.fy * (z * (dy0 - y * dz0));
+            }
+            Ju[3] = cam.fx * z; Ju[4] = 0;          Ju[5] = cam.fx * (-x * z);
+            Jv[3] = 0;          Jv[4] = cam.fy * z; Jv[5] = cam.fy * (-y * z);
+            int q = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int b = a; b < 6; ++b) acc[q++] += Ju[a] * Ju[b] + Jv[a] * Jv[b];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) acc[21 + a] += Ju[a] * ru + Jv[a] * rv;
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int kFirst = MODE == 1 ? 0 : 27;
+#pragma unroll
+    for (int k = kFirst; k < kSweepAcc; ++k) {
+        double v = acc[k];
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
+        if (lane == 0) wacc[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x >= kFirst && threadIdx.x < kSweepAcc) {
+        double s = 0;
+        for (int w = 0; w < kSweepThreads / 64; ++w) s += wacc[w][threadIdx.x];
+        partials[(int64_t)blockIdx.x * kSweepAcc + threadIdx.x] = s;
+    }
+}
+
+__global__ void pnp_sweep_fold_kernel(const double* __restrict__ partials, int blocks, double* __restrict__ out) {
+    const int k = threadIdx.x;
+    if (k >= kSweepAcc) return;
+    double s = 0;
+    for (int b = 0; b < blocks; ++b) s += partials[(int64_t)b * kSweepAcc + k];
+    out[k] = s;
+}
+
+// cv::Rodrigues vector -> matrix with dR/dr (3 x 9), host side of the sweep
+void rodrigues_with_jac(const double* rv, double* R, double* J) {
+    const double theta = std::sqrt(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
+    if (theta < DBL_EPSILON) {
+        for (int k = 0; k < 9; ++k) R[k] = (k % 4 == 0) ? 1.0 : 0.0;
+        std::memset(J, 0, 27 * sizeof(double));
+        J[5] = J[15] = J[19] = -1;
+        J[7] = J[11] = J[21] = 1;
+        return;
+    }
+    const double c = std::cos(theta), s = std::sin(theta), c1 = 1. - c, itheta = 1. / theta;
+    const double r[3] = {rv[0] * itheta, rv[1] * itheta, rv[2] * itheta};
+    const double rrt[9] = {r[0] * r[0], r[0] * r[1], r[0] * r[2], r[0] * r[1], r[1] * r[1], r[1] * r[2], r[0] * r[2], r[1] * r[2], r[2] * r[2]};
+    const double rx[9] = {0, -r[2], r[1], r[2], 0, -r[0], -r[1], r[0], 0};
+    for (int k = 0; k < 9; ++k) R[k] = c * ((k % 4 == 0) ? 1.0 : 0.0) + c1 * rrt[k] + s * rx[k];
+    const double drrt[27] = {r[0] + r[0], r[1], r[2], r[1], 0, 0, r[2], 0, 0, 0, r[0], 0, r[0], r[1] + r[1], r[2], 0, r[2], 0,
+                             0, 0, r[0], 0, 0, r[1], r[0], r[1], r[2] + r[2]};
+    const double drx[27] = {0, 0, 0, 0, 0, -1, 0, 1, 0, 0, 0, 1, 0, 0, 0, -1, 0, 0, 0, -1, 0, 1, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 3; ++i) {
+        const double ri = r[i];
+        const double a0 = -s * ri, a1 = (s - 2 * c1 * itheta) * ri, a2 = c1 * itheta, a3 = (c - s * itheta) * ri, a4 = s * itheta;
+        for (int k = 0; k < 9; ++k)
+            J[i * 9 + k] = a0 * ((k % 4 == 0) ? 1.0 : 0.0) + a1 * rrt[k] + a2 * drrt[i * 9 + k] + a3 * rx[k] + a4 * drx[i * 9 + k];
+    }
+}
+
+// Chunk sizes of the batched RANSAC: small first (with a high inlier ratio `niters` collapses after the first good
+// model and hypotheses generated beyond it are wasted host work), doubling up to 64 iterations per launch.
+struct Chunker {
+    int chunk = 8;
+    int next(int remaining) {
+        const int m = std::min(chunk, remaining);
+        chunk = std::min(2 * chunk, 64);
+        return m;
+    }
+};
+
+// Sequential bookkeeping of RANSACPointSetRegistrator::run over one scored chunk.  owner[j] = iteration (relative to
+// `it0`) that produced model j; returns the index of the chunk's model that became the overall best (-1: none) and sets
+// `stop` when the loop condition `iter < niters` failed at an iteration boundary inside the chunk.
+struct RansacState {
+    int niters, best = 0, model_points;
+    double confidence;
+    int64_t count;
+    int last_improve = -1, models_scored = 0;
+    // iterations the sequential loop enters: `niters` only shrinks, and only inside the iteration that improved
+    int iterations_run() const { return std::max(niters, last_improve + 1); }
+};
+
+int replay_chunk(RansacState& st, int it0, const std::vector<int>& owner, const int32_t* counts, bool& stop) {
+    int best_j = -1, last_k = -1;
+    stop = false;
+    for (size_t j = 0; j < owner.size(); ++j) {
+        const int k = owner[j];
+        if (k != last_k) {                       // entering iteration it0 + k: the loop condition is evaluated here only
+            if (it0 + k >= st.niters) {
+                stop = true;
+                break;
+            }
+            last_k = k;
+        }
+        ++st.models_scored;
+        const int good = counts[j];
+        if (good > std::max(st.best, st.model_points - 1)) {
+            st.best = good;
+            best_j = (int)j;
+            st.last_improve = it0 + k;
+            st.niters = hs::ransac_update_num_iters(st.confidence, (double)(st.count - good) / (double)st.count, st.model_points, st.niters);
+        }
+    }
+    return best_j;
+}
+
+size_t essential_ws(int64_t n) {
+    const size_t hmax = 64 * 10;
+    return sfm::align_up(sizeof(double) * 4 * (size_t)n, 256) + sfm::align_up(sizeof(double) * 9 * hmax, 256) +
+           sfm::align_up(sizeof(int32_t) * hmax, 256) + sfm::align_up(hmax * (size_t)n, 256) + 1024;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------- findEssentialMat
+extern "C" size_t sfm_find_essential_mat_ws_bytes(int64_t n) { return n < 0 ? 0 : essential_ws(n); }
+
+extern "C" int sfm_find_essential_mat(const float* pts0_dev, const float* pts1_dev, int64_t n, const double* K, double prob,
+                                      double threshold, int max_iters, double* E_host, int32_t* info_host, uint8_t* mask_dev,
+                                      void* ws, size_t ws_bytes, void* stream_) {
+    SFM_CHECK_ARG(K && E_host && info_host, "sfm_find_essential_mat: null pointer");
+    SFM_CHECK_ARG(n >= 0 && n < (int64_t)1 << 30, "sfm_find_essential_mat: bad n");
+    info_host[0] = info_host[1] = info_host[2] = info_host[3] = 0;      // models in E, inliers, iterations run, models scored
+    if (n < 5) return SFM_OK;                                           // OpenCV: count < modelPoints -> no model
+    SFM_CHECK_ARG(pts0_dev && pts1_dev && mask_dev, "sfm_find_essential_mat: null pointer");
+    if (!ws || ws_bytes < essential_ws(n)) {
+        sfm::set_error("sfm_find_essential_mat: workspace too small (%zu < %zu)", ws_bytes, essential_ws(n));
+        return SFM_ERR_WORKSPACE;
+    }
+    hipStream_t stream = sfm::as_stream(stream_);
+    sfm::Carver c(reinterpret_cast<void*>(sfm::align_up((size_t)(uintptr_t)ws, 256)));
+    double* x0n = c.take<double>(2 * (size_t)n);
+    double* x1n = c.take<double>(2 * (size_t)n);
+    const size_t hmax = 640;
+    double* models_dev = c.take<double>(9 * hmax);
+    int32_t* counts_dev = c.take<int32_t>(hmax);
+    uint8_t* masks_dev = c.take<uint8_t>(hmax * (size_t)n);
+
+    const KNorm kn(K);
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_normalise_kernel, dim3(nb), dim3(256), 0, stream, pts0_dev, n, kn, x0n);
+    hipLaunchKernelGGL(k_normalise_kernel, dim3(nb), dim3(256), 0, stream, pts1_dev, n, kn, x1n);
+    SFM_CHECK_LAUNCH();
+    std::vector<float> h0(2 * (size_t)n), h1(2 * (size_t)n);
+    SFM_CHECK_HIP(hipMemcpyAsync(h0.data(), pts0_dev, sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost, stream));
+    SFM_CHECK_HIP(hipMemcpyAsync(h1.data(), pts1_dev, sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost, stream));
+    SFM_CHECK_HIP(hipStreamSynchronize(stream));
+    auto sample = [&](const int* idx, double* s0, double* s1) {
+        for (int k = 0; k < 5; ++k) {
+            s0[2 * k] = (double)h0[2 * idx[k]] * kn.ifx + kn.bx; s0[2 * k + 1] = (double)h0[2 * idx[k] + 1] * kn.ify + kn.by;
+            s1[2 * k] = (double)h1[2 * idx[k]] * kn.ifx + kn.bx; s1[2 * k + 1] = (double)h1[2 * idx[k] + 1] * kn.ify + kn.by;
+        }
+    };
+    if (n == 5) {                     // count == modelPoints: the solver's models as they are (stacked), every point an inlier
+        const int idx[5] = {0, 1, 2, 3, 4};
+        double s0[10], s1[10];
+        sample(idx, s0, s1);
+        const int k = hs::five_point(s0, s1, E_host);
+        info_host[0] = k;
+        info_host[1] = k > 0 ? 5 : 0;
+        if (k > 0) SFM_CHECK_HIP(hipMemsetAsync(mask_dev, 1, 5, stream));
+        return SFM_OK;
+    }
+    double thr = threshold;
+    thr /= (K[0] + K[4]) / 2;
+    const float thr2 = (float)(thr * thr);
+    hs::CvRng rng;
+    RansacState st;
+    st.niters = std::max(max_iters, 1);
+    st.model_points = 5;
+    st.confidence = prob;
+    st.count = n;
+    Chunker ch;
+    std::vector<double> models;
+    std::vector<int> owner;
+    std::vector<int32_t> counts;
+    int it = 0;
+    while (it < st.niters) {
+        const int m = ch.next(st.niters - it);
+        models.clear();
+        owner.clear();
+        for (int k = 0; k < m; ++k) {
+            int idx[5];
+            double s0[10], s1[10], E10[90];
+            rng.subset((int)n, 5, idx);
+            sample(idx, s0, s1);
+            const int nm = hs::five_point(s0, s1, E10);
+            for (int q = 0; q < nm; ++q) {
+                models.insert(models.end(), E10 + 9 * q, E10 + 9 * q + 9);
+                owner.push_back(k);
+            }
+        }
+        const int H = (int)owner.size();
+        if (H > 0) {
+            counts.resize(H);
+            SFM_CHECK_HIP(hipMemcpyAsync(models_dev, models.data(), sizeof(double) * 9 * (size_t)H, hipMemcpyHostToDevice, stream));
+            const int rc = sfm_score_essential(models_dev, H, x0n, x1n, n, thr2, counts_dev, masks_dev, stream_);
+            if (rc != SFM_OK) return rc;
+            SFM_CHECK_HIP(hipMemcpyAsync(counts.data(), counts_dev, sizeof(int32_t) * (size_t)H, hipMemcpyDeviceToHost, stream));
+            SFM_CHECK_HIP(hipStreamSynchronize(stream));
+            bool stop;
+            const int bj = replay_chunk(st, it, owner, counts.data(), stop);
+            if (bj >= 0) {
+                std::memcpy(E_host, models.data() + 9 * (size_t)bj, 9 * sizeof(double));
+                SFM_CHECK_HIP(hipMemcpyAsync(mask_dev, masks_dev + (size_t)bj * (size_t)n, (size_t)n, hipMemcpyDeviceToDevice, stream));
+            }
+            if (stop) {
+                it = st.niters;
+                break;
+            }
+        }
+        it += m;
+    }
+    info_host[0] = st.best > 0 ? 1 : 0;
+    info_host[1] = st.best;
+    info_host[2] = st.iterations_run();
+    info_host[3] = st.models_scored;
+    return SFM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- recoverPose
+extern "C" size_t sfm_recover_pose_ws_bytes(int64_t n) {
+    return n < 0 ? 0 : sfm::align_up(sizeof(double) * 4 * (size_t)n, 256) + sfm::align_up(4 * (size_t)n, 256) + 1024;
+}
+
+extern "C" int sfm_recover_pose(const double* E, const float* pts0_dev, const float* pts1_dev, int64_t n, const double* K,
+                                double distance_thresh, int rows, double* R_host, double* t_host, int32_t* good_host,
+                                uint8_t* mask_dev, void* ws, size_t ws_bytes, void* stream_) {
+    SFM_CHECK_ARG(E && K && R_host && t_host && good_host, "sfm_recover_pose: null pointer");
+    SFM_CHECK_ARG(n >= 0 && (rows == 4 || rows == 6), "sfm_recover_pose: bad n / rows");
+    SFM_CHECK_ARG(n == 0 || (pts0_dev && pts1_dev), "sfm_recover_pose: null points");
+    if (!ws || ws_bytes < sfm_recover_pose_ws_bytes(n)) {
+        sfm::set_error("sfm_recover_pose: workspace too small (%zu < %zu)", ws_bytes, sfm_recover_pose_ws_bytes(n));
+        return SFM_ERR_WORKSPACE;
+    }
+    hipStream_t stream = sfm::as_stream(stream_);
+    double R1[9], R2[9], tt[3], Ps[48];
+    hs::decompose_essential(E, R1, R2, tt);
+    const double* Rs[4] = {R1, R2, R1, R2};
+    const double sg[4] = {1, 1, -1, -1};
+    for (int cnd = 0; cnd < 4; ++cnd)
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) Ps[12 * cnd + 4 * i + j] = Rs[cnd][3 * i + j];
+            Ps[12 * cnd + 4 * i + 3] = sg[cnd] * tt[i];
+        }
+    int32_t g[4] = {0, 0, 0, 0};
+    uint8_t* masks_dev = nullptr;
+    if (n > 0) {
+        sfm::Carver c(reinterpret_cast<void*>(sfm::align_up((size_t)(uintptr_t)ws, 256)));
+        double* x0n = c.take<double>(2 * (size_t)n);
+        double* x1n = c.take<double>(2 * (size_t)n);
+        masks_dev = c.take<uint8_t>(4 * (size_t)n);
+        int32_t* counts_dev = c.take<int32_t>(4);
+        const KNorm kn(K);
+        const unsigned nb = (unsigned)((n + 255) / 256);
+        hipLaunchKernelGGL(k_normalise_kernel, dim3(nb), dim3(256), 0, stream, pts0_dev, n, kn, x0n);
+        hipLaunchKernelGGL(k_normalise_kernel, dim3(nb), dim3(256), 0, stream, pts1_dev, n, kn, x1n);
+        SFM_CHECK_LAUNCH();
+        const int rc = sfm_recover_pose_score(Ps, 4, x0n, x1n, n, distance_thresh, rows, counts_dev, masks_dev, stream_);
+        if (rc != SFM_OK) return rc;
+        SFM_CHECK_HIP(hipMemcpyAsync(g, counts_dev, sizeof(g), hipMemcpyDeviceToHost, stream));
+        SFM_CHECK_HIP(hipStreamSynchronize(stream));
+    }
+    int k;      // OpenCV's cascade of >= tests in candidate order
+    if (g[0] >= g[1] && g[0] >= g[2] && g[0] >= g[3]) k = 0;
+    else if (g[1] >= g[0] && g[1] >= g[2] && g[1] >= g[3]) k = 1;
+    else if (g[2] >= g[0] && g[2] >= g[1] && g[2] >= g[3]) k = 2;
+    else k = 3;
+    std::memcpy(R_host, Rs[k], 9 * sizeof(double));
+    for (int i = 0; i < 3; ++i) t_host[i] = sg[k] * tt[i];
+    *good_host = g[k];
+    if (mask_dev && n > 0) SFM_CHECK_HIP(hipMemcpyAsync(mask_dev, masks_dev + (size_t)k * (size_t)n, (size_t)n, hipMemcpyDeviceToDevice, stream));
+    return SFM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- solvePnPRansac
+extern "C" size_t sfm_solve_pnp_ransac_ws_bytes(int64_t n) {
+    if (n < 0) return 0;
+    const size_t hmax = 64;
+    return sfm::align_up(sizeof(double) * 6 * hmax, 256) + sfm::align_up(sizeof(int32_t) * hmax, 256) + sfm::align_up(hmax * (size_t)n, 256) +
+           sfm::align_up((size_t)n, 256) + sfm::align_up(sizeof(double) * kSweepAcc * (kSweepMaxBlocks + 1), 256) + 1024;
+}
+
+extern "C" int sfm_solve_pnp_ransac(const float* X_dev, const float* uv_dev, int64_t n, const double* K, int iterations,
+                                    float reproj_error, double confidence, double* rvec_host, double* tvec_host,
+                                    int32_t* info_host, int32_t* inliers_dev, void* ws, size_t ws_bytes, void* stream_) {
+    SFM_CHECK_ARG(K && rvec_host && tvec_host && info_host, "sfm_solve_pnp_ransac: null pointer");
+    info_host[0] = info_host[1] = info_host[2] = info_host[3] = 0;      // ok, inliers, init status, LM iterations
+    SFM_CHECK_ARG(n >= 5 && n < (int64_t)1 << 30,
+                  "sfm_solve_pnp_ransac: at least 5 correspondences are required (OpenCV's P3P branch for exactly 4 is not on this path; got %lld)",
+                  (long long)n);
+    SFM_CHECK_ARG(X_dev && uv_dev && inliers_dev, "sfm_solve_pnp_ransac: null pointer");
+    if (!ws || ws_bytes < sfm_solve_pnp_ransac_ws_bytes(n)) {
+        sfm::set_error("sfm_solve_pnp_ransac: workspace too small (%zu < %zu)", ws_bytes, sfm_solve_pnp_ransac_ws_bytes(n));
+        return SFM_ERR_WORKSPACE;
+    }
+    hipStream_t stream = sfm::as_stream(stream_);
+    sfm::Carver c(reinterpret_cast<void*>(sfm::align_up((size_t)(uintptr_t)ws, 256)));
+    const size_t hmax = 64;
+    double* poses_dev = c.take<double>(6 * hmax);
+    int32_t* counts_dev = c.take<int32_t>(hmax);
+    uint8_t* masks_dev = c.take<uint8_t>(hmax * (size_t)n);
+    uint8_t* best_dev = c.take<uint8_t>((size_t)n);
+    double* sweep_dev = c.take<double>((size_t)kSweepAcc * (kSweepMaxBlocks + 1));
+
+    std::vector<float> hX(3 * (size_t)n), huv(2 * (size_t)n);
+    SFM_CHECK_HIP(hipMemcpyAsync(hX.data(), X_dev, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, stream));
+    SFM_CHECK_HIP(hipMemcpyAsync(huv.data(), uv_dev, sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost, stream));
+    SFM_CHECK_HIP(hipStreamSynchronize(stream));
+    const double ifx = 1. / K[0], ify = 1. / K[4];
+    // solvePnP(EPNP) on a sample: undistortPoints writes float32 normalised coordinates (the image points' type) and
+    // epnp::init_points maps them back with u = x fu + uc
+    auto epnp_model = [&](const int* idx, double* model) -> bool {
+        double Xs[15], us[10], R[9], t[3];
+        for (int k = 0; k < 5; ++k) {
+            for (int j = 0; j < 3; ++j) Xs[3 * k + j] = (double)hX[3 * (size_t)idx[k] + j];
+            us[2 * k] = (double)(float)(((double)huv[2 * (size_t)idx[k]] - K[2]) * ifx) * K[0] + K[2];
+            us[2 * k + 1] = (double)(float)(((double)huv[2 * (size_t)idx[k] + 1] - K[5]) * ify) * K[4] + K[5];
+        }
+        hs::Epnp(K, Xs, us, 5).compute_pose(R, t);
+        for (int k = 0; k < 9; ++k)
+            if (!std::isfinite(R[k])) return false;
+        for (int k = 0; k < 3; ++k)
+            if (!std::isfinite(t[k])) return false;
+        hs::rodrigues_mat2vec(R, model);
+        std::memcpy(model + 3, t, sizeof(t));
+        return true;
+    };
+    if (n == 5) {                     // model_points == npoints: plain solvePnP(EPNP), every point an inlier
+        const int idx[5] = {0, 1, 2, 3, 4};
+        double model[6];
+        if (!epnp_model(idx, model)) return SFM_OK;
+        std::memcpy(rvec_host, model, 24);
+        std::memcpy(tvec_host, model + 3, 24);
+        const int32_t all[5] = {0, 1, 2, 3, 4};
+        SFM_CHECK_HIP(hipMemcpyAsync(inliers_dev, all, sizeof(all), hipMemcpyHostToDevice, stream));
+        SFM_CHECK_HIP(hipStreamSynchronize(stream));
+        info_host[0] = 1;
+        info_host[1] = 5;
+        return SFM_OK;
+    }
+    const float thr2 = (float)((double)reproj_error * (double)reproj_error);
+    hs::CvRng rng;
+    RansacState st;
+    st.niters = std::max(iterations, 1);
+    st.model_points = 5;
+    st.confidence = confidence;
+    st.count = n;
+    Chunker ch;
+    std::vector<double> models;
+    std::vector<int> owner;
+    std::vector<int32_t> counts;
+    double best_model[6] = {0, 0, 0, 0, 0, 0};
+    int it = 0;
+    while (it < st.niters) {
+        const int m = ch.next(st.niters - it);
+        models.clear();
+        owner.clear();
+        for (int k = 0; k < m; ++k) {
+            int idx[5];
+            double model[6];
+            rng.subset((int)n, 5, idx);
+            if (!epnp_model(idx, model)) continue;
+            models.insert(models.end(), model, model + 6);
+            owner.push_back(k);
+        }
+        const int H = (int)owner.size();
+        if (H > 0) {
+            counts.resize(H);
+            SFM_CHECK_HIP(hipMemcpyAsync(poses_dev, models.data(), sizeof(double) * 6 * (size_t)H, hipMemcpyHostToDevice, stream));
+            const int rc = sfm_score_pnp(poses_dev, H, K, X_dev, uv_dev, n, thr2, counts_dev, masks_dev, stream_);
+            if (rc != SFM_OK) return rc;
+            SFM_CHECK_HIP(hipMemcpyAsync(counts.data(), counts_dev, sizeof(int32_t) * (size_t)H, hipMemcpyDeviceToHost, stream));
+            SFM_CHECK_HIP(hipStreamSynchronize(stream));
+            bool stop;
+            const int bj = replay_chunk(st, it, owner, counts.data(), stop);
+            if (bj >= 0) {
+                std::memcpy(best_model, models.data() + 6 * (size_t)bj, sizeof(best_model));
+                SFM_CHECK_HIP(hipMemcpyAsync(best_dev, masks_dev + (size_t)bj * (size_t)n, (size_t)n, hipMemcpyDeviceToDevice, stream));
+            }
+            if (stop) break;
+        }
+        it += m;
+    }
+    if (st.best <= 0) return SFM_OK;
+    // inlier list (ascending, as OpenCV pushes them) — the one piece of the mask the host needs
+    std::vector<uint8_t> hmask((size_t)n);
+    SFM_CHECK_HIP(hipMemcpyAsync(hmask.data(), best_dev, (size_t)n, hipMemcpyDeviceToHost, stream));
+    SFM_CHECK_HIP(hipStreamSynchronize(stream));
+    std::vector<int32_t> inl;
+    inl.reserve((size_t)st.best);
+    for (int64_t i = 0; i < n; ++i)
+        if (hmask[(size_t)i]) inl.push_back((int32_t)i);
+    const int64_t m_in = (int64_t)inl.size();
+    SFM_CHECK_HIP(hipMemcpyAsync(inliers_dev, inl.data(), sizeof(int32_t) * (size_t)m_in, hipMemcpyHostToDevice, stream));
+    // solvePnP(ITERATIVE) on the inliers: DLT initialisation on the host, Levenberg-Marquardt with the sweeps on the device
+    double param[6];
+    const int init_status = hs::pnp_dlt_init<float>(hX.data(), huv.data(), inl.data(), m_in, K, param, param + 3);
+    if (init_status != 0) std::memcpy(param, best_model, sizeof(param));      // planar / < 6 inliers: refine the RANSAC model
+    const int blocks = (int)std::min<int64_t>((m_in + kSweepThreads - 1) / kSweepThreads, kSweepMaxBlocks);
+    double sums[kSweepAcc];
+    auto sweep = [&](const double* p, bool jac) -> int {
+        PnpCam cam;
+        rodrigues_with_jac(p, cam.R, cam.dR);
+        cam.t[0] = p[3]; cam.t[1] = p[4]; cam.t[2] = p[5];
+        cam.fx = K[0]; cam.fy = K[4]; cam.cx = K[2]; cam.cy = K[5];
+        double* out = blocks == 1 ? sweep_dev + (size_t)kSweepAcc * kSweepMaxBlocks : sweep_dev;
+        if (jac)
+            hipLaunchKernelGGL(pnp_sweep_kernel<1>, dim3(blocks), dim3(kSweepThreads), 0, stream, cam, X_dev, uv_dev, inliers_dev, m_in, out);
+        else
+            hipLaunchKernelGGL(pnp_sweep_kernel<0>, dim3(blocks), dim3(kSweepThreads), 0, stream, cam, X_dev, uv_dev, inliers_dev, m_in, out);
+        if (blocks > 1)
+            hipLaunchKernelGGL(pnp_sweep_fold_kernel, dim3(1), dim3(64), 0, stream, sweep_dev, blocks, sweep_dev + (size_t)kSweepAcc * kSweepMaxBlocks);
+        SFM_CHECK_LAUNCH();
+        SFM_CHECK_HIP(hipMemcpyAsync(sums, sweep_dev + (size_t)kSweepAcc * kSweepMaxBlocks, sizeof(sums), hipMemcpyDeviceToHost, stream));
+        SFM_CHECK_HIP(hipStreamSynchronize(stream));
+        return SFM_OK;
+    };
+    // CvLevMarq (J / err interface) as cvFindExtrinsicCameraParams2 drives it: <= 20 iterations, epsilon FLT_EPSILON,
+    // lambda = exp(k log 10) from k = -3, the DIAGONAL of J^T J scaled by 1 + lambda, SVD solve
+    const double LOG10 = std::log(10.);
+    int lambdaLg10 = -3, iters = 0;
+    double prev[6], JtJ[36], JtErr[6], prevErrNorm = DBL_MAX, errNorm = 0;
+    auto step = [&]() {
+        const double lambda = std::exp(lambdaLg10 * LOG10);
+        double A[36], dx[6];
+        std::memcpy(A, JtJ, sizeof(A));
+        for (int i = 0; i < 6; ++i) A[7 * i] *= 1. + lambda;
+        hs::Svd sv;
+        sv.compute(A, 6, 6);
+        sv.back_subst(JtErr, dx);
+        for (int i = 0; i < 6; ++i) param[i] = prev[i] - dx[i];
+    };
+    for (;;) {
+        int rc = sweep(param, true);
+        if (rc != SFM_OK) return rc;
+        int q = 0;
+        for (int a = 0; a < 6; ++a)
+            for (int b = a; b < 6; ++b) JtJ[6 * a + b] = JtJ[6 * b + a] = sums[q++];
+        for (int a = 0; a < 6; ++a) JtErr[a] = sums[21 + a];
+        std::memcpy(prev, param, sizeof(prev));
+        if (iters == 0) prevErrNorm = std::sqrt(sums[27]);
+        step();
+        if ((rc = sweep(param, false)) != SFM_OK) return rc;
+        for (;;) {
+            errNorm = std::sqrt(sums[27]);
+            if (errNorm > prevErrNorm && ++lambdaLg10 <= 16) {
+                step();
+                if ((rc = sweep(param, false)) != SFM_OK) return rc;
+                continue;
+            }
+            break;
+        }
+        lambdaLg10 = std::max(lambdaLg10 - 1, -16);
+        double dn = 0, pn = 0;
+        for (int i = 0; i < 6; ++i) {
+            dn += (param[i] - prev[i]) * (param[i] - prev[i]);
+            pn += prev[i] * prev[i];
+        }
+        ++iters;
+        if (iters >= 20 || std::sqrt(dn) / std::sqrt(pn) < FLT_EPSILON) break;
+        prevErrNorm = errNorm;
+    }
+    std::memcpy(rvec_host, param, 24);
+    std::memcpy(tvec_host, param + 3, 24);
+    info_host[0] = 1;
+    info_host[1] = (int32_t)m_in;
+    info_host[2] = init_status;
+    info_host[3] = iters;
+    return SFM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- host solver exports
+// (the generators above, reachable on their own: unit-tested against the oracle on the CPU)
+extern "C" int sfm_host_epnp(const double* K, const double* Xw, const double* uv, int n, double* R_out, double* t_out) {
+    SFM_CHECK_ARG(K && Xw && uv && R_out && t_out, "sfm_host_epnp: null pointer");
+    SFM_CHECK_ARG(n >= 4 && n <= hs::kEpnpMaxPts, "sfm_host_epnp: n must be in [4, %d] (got %d)", hs::kEpnpMaxPts, n);
+    hs::Epnp(K, Xw, uv, n).compute_pose(R_out, t_out);
+    return SFM_OK;
+}
+
+extern "C" int sfm_host_five_point(const double* x1n, const double* x2n, double* E_out, int32_t* count_out) {
+    SFM_CHECK_ARG(x1n && x2n && E_out && count_out, "sfm_host_five_point: null pointer");
+    *count_out = hs::five_point(x1n, x2n, E_out);
+    return SFM_OK;
+}
+
+extern "C" int sfm_host_decompose_essential(const double* E, double* R1, double* R2, double* t) {
+    SFM_CHECK_ARG(E && R1 && R2 && t, "sfm_host_decompose_essential: null pointer");
+    hs::decompose_essential(E, R1, R2, t);
+    return SFM_OK;
+}
+
+extern "C" int sfm_host_pnp_dlt_init(const double* K, const double* X, const double* uv, int64_t n, double* rvec, double* tvec,
+                                     int32_t* status_out) {
+    SFM_CHECK_ARG(K && X && uv && rvec && tvec && status_out && n >= 1, "sfm_host_pnp_dlt_init: bad argument");
+    *status_out = hs::pnp_dlt_init<double>(X, uv, nullptr, n, K, rvec, tvec);
+    return SFM_OK;
+}
+
+extern "C" int sfm_host_rodrigues(const double* src, int src_is_matrix, double* dst, double* jac) {
+    SFM_CHECK_ARG(src && dst, "sfm_host_rodrigues: null pointer");
+    if (src_is_matrix) {
+        hs::rodrigues_mat2vec(src, dst);
+    } else {
+        double J[27];
+        rodrigues_with_jac(src, dst, jac ? jac : J);
+    }
+    return SFM_OK;
+}

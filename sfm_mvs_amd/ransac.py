@@ -1,219 +1,123 @@
 """RANSAC entry points of the path — cv2.findEssentialMat (sfm.py:307), cv2.recoverPose (sfm.py:311),
-cv2.solvePnPRansac (sfm.py:67) — with OpenCV's sequential semantics and device-side scoring.
+cv2.solvePnPRansac (sfm.py:67) — as thin wrappers over ONE library call each (`sfm_find_essential_mat`,
+`sfm_recover_pose`, `sfm_solve_pnp_ransac`, csrc/ransac.hip).
 
-Control flow follows RANSACPointSetRegistrator::run: RNG seeded with 2^64-1, `modelPoints` distinct
-indices per iteration, every model of an iteration scored, the best replaced only on a STRICTLY larger
-inlier count, `niters` re-estimated after each improvement.  The subsets do not depend on scoring, so
-iterations are generated in chunks, all their hypotheses are scored in ONE kernel launch over all
-correspondences (H x N, integer counts + masks), and the host then replays the sequential bookkeeping
-— identical results, without one launch per hypothesis.
-
-`backend` supplies the device kernels (default: HipBackend over libsfmhip.so).  Tests inject a CPU
-backend built on the oracle to check masks/poses bit-for-bit; the product never imports it.
+The library generates hypotheses on the host in chunks (OpenCV's RNG and subsets, five-point / EPnP on five
+correspondences each), scores a whole chunk against every correspondence in one launch, replays OpenCV's sequential
+bookkeeping over the counts and runs the Levenberg-Marquardt sweeps of the PnP refinement on the device; masks and
+inlier lists stay in HBM until the caller asks for them.  Points may be NumPy arrays (uploaded once) or CUDA tensors.
+There is no CPU path: the functions raise without a HIP device.
 """
+import ctypes
+
 import numpy as np
 import torch
 
-from . import hostgeom as hg
-from . import ops
-from ._lib import on_device
+from . import _lib
+from ._lib import SfmHipError, check, on_device, ptr, stream_ptr
+
+_vp = ctypes.c_void_p
+_ws = {}
 
 
-class HipBackend:
-    """Scoring / sweep kernels on the current CUDA (HIP) device."""
-
-    def __init__(self, device=None, dlt_rows=4):
-        self.device = torch.device(device if device is not None else "cuda")
-        self.dlt_rows = dlt_rows
-
-    def _d(self, a, dtype):
-        return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(self.device)
-
-    def prepare_essential(self, x1n, x2n):
-        return self._d(x1n, torch.float64), self._d(x2n, torch.float64)
-
-    def score_essential(self, prep, Es, thr2):
-        counts, mask = ops.score_essential(self._d(Es, torch.float64), prep[0], prep[1], thr2, want_mask=True)
-        return counts.cpu().numpy(), mask.cpu().numpy()
-
-    def recover_pose_score(self, prep, Ps, dist):
-        import ctypes
-        from . import _lib
-        P = np.ascontiguousarray(Ps, np.float64).reshape(-1, 12)
-        h, n = P.shape[0], prep[0].shape[0]
-        counts = torch.empty(h, dtype=torch.int32, device=self.device)
-        mask = torch.empty((h, n), dtype=torch.uint8, device=self.device)
-        with on_device(self.device):
-            _lib.check(_lib.lib().sfm_recover_pose_score(P.ctypes.data_as(ctypes.c_void_p), h, _lib.ptr(prep[0]),
-                                                         _lib.ptr(prep[1]), n, float(dist), self.dlt_rows, _lib.ptr(counts),
-                                                         _lib.ptr(mask), _lib.stream_ptr()), "sfm_recover_pose_score")
-        return counts.cpu().numpy(), mask.cpu().numpy()
-
-    def prepare_pnp(self, X, uv):
-        return self._d(X, torch.float32), self._d(uv, torch.float32)
-
-    def score_pnp(self, prep, poses, K, thr2):
-        counts, mask = ops.score_pnp(self._d(poses, torch.float64), K, prep[0], prep[1], thr2, want_mask=True)
-        return counts.cpu().numpy(), mask.cpu().numpy()
-
-    def pose_sweep(self, prep, rvec, tvec, K, want_jac):
-        cams = self._d(np.hstack([rvec, tvec])[None], torch.float64)
-        out = ops.project_residual(cams, K, prep[0], prep[1], want_proj=False, want_jac=want_jac, want_res2=True)
-        if want_jac:
-            pack = torch.cat([out["JtJ_cam"].reshape(-1), out["Jtr_cam"].reshape(-1), out["res2"]]).cpu().numpy()
-            return pack[:36].reshape(6, 6), pack[36:42], float(np.sqrt(pack[42]))
-        return None, None, float(np.sqrt(out["res2"].item()))
+def _dev():
+    if not torch.cuda.is_available():
+        raise SfmHipError("sfm_mvs_amd.ransac needs a HIP device: there is no CPU fallback")
+    return torch.device("cuda")
 
 
-_default_backend = None
+def _workspace(device, nbytes):
+    """Grow-only scratch per (device, stream): the entry points synchronise their stream before returning, so a buffer
+    is never in use by two calls of the same stream."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = _ws[key] = torch.empty(max(int(nbytes), 1 << 16), dtype=torch.uint8, device=device)
+    return buf
 
 
-def default_backend():
-    global _default_backend
-    if _default_backend is None:
-        _default_backend = HipBackend()
-    return _default_backend
+def _points(a, cols):
+    """(n, cols) float32 on the device, contiguous; NumPy input of any cv2-accepted shape ((n,1,cols), (n,cols))."""
+    if torch.is_tensor(a):
+        if not a.is_cuda:
+            raise SfmHipError("tensor inputs must be CUDA tensors")
+        return a.reshape(-1, cols).to(torch.float32).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(np.asarray(a, np.float32).reshape(-1, cols))).to(_dev())
 
 
-def _sample_subsets(rng, count, model_points, iters):
-    """getSubset: `model_points` distinct indices per iteration, duplicates redrawn in place."""
-    out = np.empty((iters, model_points), np.int64)
-    for it in range(iters):
-        idx = []
-        while len(idx) < model_points:
-            v = rng.uniform(0, count)
-            if v not in idx:
-                idx.append(v)
-        out[it] = idx
-    return out
+def _k(K):
+    return np.ascontiguousarray(np.asarray(K, np.float64).reshape(9))
 
 
-def _ransac(count, model_points, max_iters, confidence, make_models, score, chunk=4, max_chunk=64):
-    """Sequential-semantics RANSAC with chunked hypothesis generation and batched scoring.  Chunks start small and
-    double: with a high inlier ratio `niters` collapses after the first good model, and hypotheses generated beyond it
-    would be wasted host work (the drawn subsets, and therefore the result, do not depend on the chunking)."""
-    rng = hg.CvRNG()
-    niters = max_iters
-    best_count, best_model, best_mask = 0, None, None
-    it = 0
-    while it < niters:
-        m = min(chunk, niters - it)
-        chunk = min(2 * chunk, max_chunk)
-        subsets = _sample_subsets(rng, count, model_points, m)
-        models, owner = [], []
-        for k in range(m):
-            for mod in make_models(subsets[k]):
-                models.append(mod)
-                owner.append(k)
-        if models:
-            counts, masks = score(np.array(models))
-        stop = False
-        for j, k in enumerate(owner):
-            if it + k >= niters:          # niters may have shrunk inside this chunk
-                stop = True
-                break
-            good = int(counts[j])
-            if good > max(best_count, model_points - 1):
-                best_count, best_model, best_mask = good, models[j], masks[j].copy()
-                niters = hg.ransac_update_num_iters(confidence, (count - good) / count, model_points, niters)
-        if stop:
-            break
-        it += m
-    return best_model, best_mask, best_count
+def find_essential_mat(pts0, pts1, K, prob=0.999, threshold=1.0, max_iters=1000, return_device_mask=False, want_info=False):
+    """cv2.findEssentialMat(points1, points2, K, method=RANSAC, prob, threshold) -> (E (3,3) float64, mask (N,1) uint8 in
+    {0,1}); (None, None) when no model was found.  With exactly five points OpenCV returns all the solver's models
+    stacked ((3k,3)) and an all-ones mask — so does this."""
+    p0, p1 = _points(pts0, 2), _points(pts1, 2)
+    n = p0.shape[0]
+    if p1.shape[0] != n:
+        raise SfmHipError("findEssentialMat: the two point sets differ in length")
+    Kc = _k(K)
+    E, info = np.zeros(90), np.zeros(4, np.int32)
+    lib = _lib.lib()
+    dev = p0.device
+    mask = torch.zeros(max(n, 1), dtype=torch.uint8, device=dev)
+    ws = _workspace(dev, lib.sfm_find_essential_mat_ws_bytes(n))
+    with on_device(dev):
+        check(lib.sfm_find_essential_mat(ptr(p0), ptr(p1), n, Kc.ctypes.data_as(_vp), float(prob), float(threshold), int(max_iters),
+                                         E.ctypes.data_as(_vp), info.ctypes.data_as(_vp), ptr(mask), ptr(ws), ws.numel(),
+                                         stream_ptr()), "sfm_find_essential_mat")
+    k = int(info[0])
+    if k <= 0:
+        return (None, None, info) if want_info else (None, None)
+    m = mask[:n].reshape(-1, 1)
+    out = (E[:9 * k].reshape(3 * k, 3).copy(), m if return_device_mask else m.cpu().numpy())
+    return out + (info,) if want_info else out
 
 
-# ------------------------------------------------------------------------------- findEssentialMat
-def find_essential_mat(pts0, pts1, K, prob=0.999, threshold=1.0, max_iters=1000, backend=None):
-    """cv2.findEssentialMat(points1, points2, K, method=RANSAC, prob, threshold) → (E, mask{0,1} (N,1) uint8)."""
-    be = backend or default_backend()
-    p0 = np.asarray(pts0, np.float64).reshape(-1, 2)
-    p1 = np.asarray(pts1, np.float64).reshape(-1, 2)
-    n = len(p0)
-    if n < 5:
-        return None, None
-    fx, fy, cx, cy = K[0][0], K[1][1], K[0][2], K[1][2]
-    x0 = np.stack([(p0[:, 0] - cx) / fx, (p0[:, 1] - cy) / fy], 1)
-    x1 = np.stack([(p1[:, 0] - cx) / fx, (p1[:, 1] - cy) / fy], 1)
-    thr = threshold / ((fx + fy) / 2)
-    thr2 = np.float32(thr * thr)
-    prep = be.prepare_essential(x0, x1)
-    if n == 5:
-        models = hg.five_point(x0, x1)
-        if len(models) == 0:
-            return None, None
-        return models[0], np.ones((n, 1), np.uint8)
-    model, mask, good = _ransac(n, 5, max_iters, prob, lambda idx: list(hg.five_point(x0[idx], x1[idx])),
-                                lambda Es: be.score_essential(prep, Es.reshape(-1, 9), thr2))
-    if model is None:
-        return None, None
-    return model.reshape(3, 3), mask.reshape(-1, 1).astype(np.uint8)
+def recover_pose(E, pts0, pts1, K, distance_thresh=50.0, rows=4, return_device_mask=False):
+    """cv2.recoverPose(E, points1, points2, K) -> (good, R (3,3), t (3,1), mask (N,1) uint8 in {0,255})."""
+    p0, p1 = _points(pts0, 2), _points(pts1, 2)
+    n = p0.shape[0]
+    Ec = np.ascontiguousarray(np.asarray(E, np.float64).reshape(-1)[:9])
+    Kc = _k(K)
+    R, t, good = np.empty(9), np.empty(3), np.zeros(1, np.int32)
+    lib = _lib.lib()
+    dev = p0.device
+    mask = torch.zeros(max(n, 1), dtype=torch.uint8, device=dev)
+    ws = _workspace(dev, lib.sfm_recover_pose_ws_bytes(n))
+    with on_device(dev):
+        check(lib.sfm_recover_pose(Ec.ctypes.data_as(_vp), ptr(p0), ptr(p1), n, Kc.ctypes.data_as(_vp), float(distance_thresh), int(rows),
+                                   R.ctypes.data_as(_vp), t.ctypes.data_as(_vp), good.ctypes.data_as(_vp), ptr(mask), ptr(ws),
+                                   ws.numel(), stream_ptr()), "sfm_recover_pose")
+    m = mask[:n].reshape(-1, 1)
+    return int(good[0]), R.reshape(3, 3), t.reshape(3, 1), (m if return_device_mask else m.cpu().numpy())
 
 
-# ------------------------------------------------------------------------------------ recoverPose
-def recover_pose(E, pts0, pts1, K, distance_thresh=50.0, backend=None):
-    """cv2.recoverPose(E, points1, points2, K) → (good, R, t (3,1), mask{0,255} (N,1) uint8)."""
-    be = backend or default_backend()
-    p0 = np.asarray(pts0, np.float64).reshape(-1, 2)
-    p1 = np.asarray(pts1, np.float64).reshape(-1, 2)
-    fx, fy, cx, cy = K[0][0], K[1][1], K[0][2], K[1][2]
-    x0 = np.stack([(p0[:, 0] - cx) / fx, (p0[:, 1] - cy) / fy], 1)
-    x1 = np.stack([(p1[:, 0] - cx) / fx, (p1[:, 1] - cy) / fy], 1)
-    R1, R2, t = hg.decompose_essential(E)
-    cands = [(R1, t), (R2, t), (R1, -t), (R2, -t)]
-    Ps = np.array([np.hstack([R, tt[:, None]]) for R, tt in cands])
-    counts, masks = be.recover_pose_score(be.prepare_essential(x0, x1), Ps, distance_thresh)
-    g = [int(c) for c in counts]
-    # OpenCV's cascade of >= tests in candidate order
-    if g[0] >= g[1] and g[0] >= g[2] and g[0] >= g[3]:
-        k = 0
-    elif g[1] >= g[0] and g[1] >= g[2] and g[1] >= g[3]:
-        k = 1
-    elif g[2] >= g[0] and g[2] >= g[1] and g[2] >= g[3]:
-        k = 2
-    else:
-        k = 3
-    R, tt = cands[k]
-    return g[k], R.copy(), tt.reshape(3, 1).copy(), masks[k].reshape(-1, 1).astype(np.uint8)
-
-
-# --------------------------------------------------------------------------------- solvePnPRansac
-def solve_pnp_ransac(X, uv, K, iterations_count=100, reprojection_error=8.0, confidence=0.99, backend=None):
-    """cv2.solvePnPRansac(objectPoints, imagePoints, K, dist) with all defaults (the reference's 5th
-    positional argument lands in `rvec` and is ignored: SURVEY §3.6-1): RANSAC over EPnP on 5-point
-    samples, then solvePnP(ITERATIVE) = DLT init + Levenberg-Marquardt on the inlier set.
-    Returns (ok, rvec (3,1), tvec (3,1), inliers (k,1) int32 or None)."""
-    be = backend or default_backend()
-    Xf = np.ascontiguousarray(np.asarray(X, np.float32).reshape(-1, 3))
-    uvf = np.ascontiguousarray(np.asarray(uv, np.float32).reshape(-1, 2))
-    K = np.asarray(K, np.float64).reshape(3, 3)
-    n = len(Xf)
+def solve_pnp_ransac(X, uv, K, iterations_count=100, reprojection_error=8.0, confidence=0.99, return_device_inliers=False,
+                     want_info=False):
+    """cv2.solvePnPRansac(objectPoints, imagePoints, K, dist) with all defaults (the reference's 5th positional argument
+    lands in `rvec` and is ignored: SURVEY 3.6-1): RANSAC over EPnP on 5-point samples, then solvePnP(ITERATIVE) on the
+    inlier set.  Returns (ok, rvec (3,1), tvec (3,1), inliers (k,1) int32 or None)."""
+    Xd, ud = _points(X, 3), _points(uv, 2)
+    n = Xd.shape[0]
+    if ud.shape[0] != n:
+        raise SfmHipError("solvePnPRansac: object and image points differ in length")
     if n < 5:          # OpenCV asserts npoints >= 4 and switches to P3P for exactly 4; not on this path
-        raise ValueError("solvePnPRansac: at least 5 correspondences are required on this path")
-    Xd, uvd = Xf.astype(np.float64), uvf.astype(np.float64)
-    prep = be.prepare_pnp(Xf, uvf)
-
-    def make(idx):
-        try:
-            R, t = hg.epnp(K, Xd[idx], uvd[idx])
-        except np.linalg.LinAlgError:
-            return []
-        if not (np.all(np.isfinite(R)) and np.all(np.isfinite(t))):
-            return []
-        return [np.hstack([hg.rodrigues_mat2vec(R), t])]
-
-    thr2 = np.float32(reprojection_error * reprojection_error)
-    if n == 5:
-        models = make(np.arange(5))
-        if not models:
-            return False, None, None, None
-        return True, models[0][:3].reshape(3, 1), models[0][3:].reshape(3, 1), np.arange(5, dtype=np.int32).reshape(-1, 1)
-    model, mask, good = _ransac(n, 5, iterations_count, confidence, make, lambda P: be.score_pnp(prep, P, K, thr2))
-    if model is None:
-        return False, None, None, None
-    inl = np.flatnonzero(mask)
-    prep_in = be.prepare_pnp(Xf[inl], uvf[inl])
-    init = hg.pnp_dlt_init(K, Xd[inl], uvd[inl]) if len(inl) >= 6 else None
-    if init is None:     # planar / too few points: start from the RANSAC model (OpenCV uses a homography here)
-        init = (model[:3], model[3:])
-    rvec, tvec = hg.levmarq_pose(lambda r, t, j: be.pose_sweep(prep_in, r, t, K, j), init[0], init[1])
-    return True, rvec.reshape(3, 1), tvec.reshape(3, 1), inl.astype(np.int32).reshape(-1, 1)
+        raise SfmHipError(f"solvePnPRansac: at least 5 correspondences are required on this path (got {n}); "
+                          "OpenCV's 4-point P3P branch is not provided")
+    Kc = _k(K)
+    r, t, info = np.zeros(3), np.zeros(3), np.zeros(4, np.int32)
+    lib = _lib.lib()
+    dev = Xd.device
+    inl = torch.empty(n, dtype=torch.int32, device=dev)
+    ws = _workspace(dev, lib.sfm_solve_pnp_ransac_ws_bytes(n))
+    with on_device(dev):
+        check(lib.sfm_solve_pnp_ransac(ptr(Xd), ptr(ud), n, Kc.ctypes.data_as(_vp), int(iterations_count), float(reprojection_error),
+                                       float(confidence), r.ctypes.data_as(_vp), t.ctypes.data_as(_vp), info.ctypes.data_as(_vp),
+                                       ptr(inl), ptr(ws), ws.numel(), stream_ptr()), "sfm_solve_pnp_ransac")
+    if not info[0]:
+        return (False, None, None, None, info) if want_info else (False, None, None, None)
+    il = inl[:int(info[1])].reshape(-1, 1)
+    out = (True, r.reshape(3, 1), t.reshape(3, 1), il if return_device_inliers else il.cpu().numpy())
+    return out + (info,) if want_info else out

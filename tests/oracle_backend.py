@@ -1,43 +1,15 @@
-"""CPU kernel backend for sfm_mvs_amd.ransac built on the oracle — injected by tests only."""
+"""CPU twins of the product's operator surface built on the ORACLE ONLY (oracle/liboracle.so) — tests and
+tests/golden/make_golden.py.  Nothing here imports sfm_mvs_amd: the RANSAC entry points, the minimal solvers, Rodrigues,
+projection, triangulation and matching all come from the oracle's own restatements."""
 import numpy as np
 
 
-class OracleBackend:
-    def __init__(self, oracle, dlt_rows=4):
-        self.O = oracle
-        self.dlt_rows = dlt_rows
-
-    def prepare_essential(self, x1n, x2n):
-        return np.ascontiguousarray(x1n, np.float64), np.ascontiguousarray(x2n, np.float64)
-
-    def score_essential(self, prep, Es, thr2):
-        return self.O.score_essential(Es, prep[0], prep[1], thr2)
-
-    def recover_pose_score(self, prep, Ps, dist):
-        return self.O.recover_pose_score(Ps, prep[0], prep[1], dist, self.dlt_rows)
-
-    def prepare_pnp(self, X, uv):
-        return np.ascontiguousarray(X, np.float32), np.ascontiguousarray(uv, np.float32)
-
-    def score_pnp(self, prep, poses, K, thr2):
-        return self.O.score_pnp(poses, K, prep[0], prep[1], thr2)
-
-    def pose_sweep(self, prep, rvec, tvec, K, want_jac):
-        out = self.O.project_residual(np.hstack([rvec, tvec])[None], K, prep[0], prep[1], want_jac=True)
-        err = float(np.sqrt(out["res2"][0]))
-        if want_jac:
-            return out["JtJ_cam"][0].reshape(6, 6), out["Jtr_cam"][0], err
-        return None, None, err
-
-
 class OracleCv2:
-    """cv2-named facade over the CPU oracle (the CPU twin of sfm_mvs_amd.cv2compat) — tests only."""
+    """cv2-named facade over the CPU oracle (the CPU twin of sfm_mvs_amd.cv2compat)."""
     RANSAC, NORM_L2, SOLVEPNP_ITERATIVE = 8, 4, 0
 
     def __init__(self, oracle, rows=4):
-        from sfm_mvs_amd import hostgeom, ransac
-        self.O, self.hg, self.ransac, self.rows = oracle, hostgeom, ransac, rows
-        self.be = OracleBackend(oracle, rows)
+        self.O, self.rows = oracle, rows
 
     def triangulatePoints(self, P1, P2, a, b):
         return self.O.triangulate(P1, P2, np.ascontiguousarray(a, np.float32), np.ascontiguousarray(b, np.float32), rows=self.rows)
@@ -45,12 +17,14 @@ class OracleCv2:
     def Rodrigues(self, src):
         src = np.asarray(src, np.float64)
         if src.size == 9:
-            return self.hg.rodrigues_mat2vec(src.reshape(3, 3)).reshape(3, 1), None
-        return self.hg.rodrigues_vec2mat(src.reshape(3)), None
+            return self.O.rodrigues_mat2vec(src.reshape(3, 3)).reshape(3, 1), None
+        return self.O.rodrigues_vec2mat(src.reshape(3)), None
 
     def convertPointsFromHomogeneous(self, src):
-        from sfm_mvs_amd import cv2compat
-        return cv2compat.convertPointsFromHomogeneous(src)
+        src = np.asarray(src)
+        w = src[:, -1:]
+        scale = np.where(w != 0, 1.0 / np.where(w != 0, w, 1), 1.0).astype(src.dtype)
+        return (src[:, :-1] * scale).reshape(src.shape[0], 1, src.shape[1] - 1)
 
     def projectPoints(self, objectPoints, rvec, tvec, cameraMatrix, distCoeffs=None):
         X = np.asarray(objectPoints)
@@ -62,18 +36,24 @@ class OracleCv2:
         return float(np.sqrt(np.sum(np.float64(d) ** 2)))                        # squares accumulated in double
 
     def findEssentialMat(self, p1, p2, K, method=8, prob=0.999, threshold=1.0, mask=None):
-        return self.ransac.find_essential_mat(p1, p2, np.asarray(K, np.float64), prob, threshold, backend=self.be)
+        return self.O.find_essential_mat(p1, p2, np.asarray(K, np.float64), prob, threshold)
 
     def recoverPose(self, E, p1, p2, K):
-        return self.ransac.recover_pose(E, p1, p2, np.asarray(K, np.float64), backend=self.be)
+        return self.O.recover_pose(E, p1, p2, np.asarray(K, np.float64), rows=self.rows)
 
     def solvePnPRansac(self, X, p, K, d, *a, **k):
-        return self.ransac.solve_pnp_ransac(X, p, K, backend=self.be)
+        return self.O.solve_pnp_ransac(X, p, K)
+
+
+class _Backend:
+    """Duck-typed stand-in for sfm_mvs_amd.pipeline.Backend (attributes cv, match, reproj)."""
+
+    def __init__(self, cv, match, reproj):
+        self.cv, self.match, self.reproj = cv, match, reproj
 
 
 def oracle_pipeline_backend(oracle):
-    """sfm_mvs_amd.pipeline.Backend whose every numeric operator is the CPU oracle."""
-    from sfm_mvs_amd.pipeline import Backend
+    """A driver backend whose every numeric operator is the CPU oracle."""
 
     def match(feat0, feat1):
         idx, dist = oracle.knn2(feat0[1], feat1[1], nthreads=8)
@@ -84,4 +64,4 @@ def oracle_pipeline_backend(oracle):
         out = oracle.project_residual(np.hstack([np.ravel(r), np.ravel(t)])[None], K, Xf, obs, want_jac=False)
         return float(out["sumsq"][0]), out["proj"]
 
-    return Backend(cv=OracleCv2(oracle), match=match, reproj=reproj)
+    return _Backend(cv=OracleCv2(oracle), match=match, reproj=reproj)

@@ -84,3 +84,21 @@ def test_product_never_imports_the_oracle():
                 src = open(path).read()
                 assert "liboracle" not in src and "sfm_oracle.h" not in src and "orc_" not in src.replace("orc_knn2_l2_f32)", ""), \
                     f"{f} links the oracle"
+
+
+def test_oracle_side_never_imports_the_product():
+    """The oracle, its cv2-named backend and the golden-vector generator must stand on their own: a golden produced
+    through product code would compare the product with itself."""
+    import ast
+    for rel in ("oracle/oracle.py", "tests/oracle_backend.py", "tests/golden/make_golden.py", "tests/np_solvers.py"):
+        tree = ast.parse(open(os.path.join(ROOT, rel)).read())
+        for node in ast.walk(tree):
+            names = []
+            if isinstance(node, ast.Import):
+                names = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom):
+                names = [node.module or ""]
+            assert not any(n.split(".")[0] in ("sfm_mvs_amd", "sfm-mvs_amd") for n in names), f"{rel} imports the product"
+    for rel in ("oracle/sfm_oracle.c", "oracle/solvers_oracle.c", "oracle/sift_oracle.c", "oracle/Makefile"):
+        src = open(os.path.join(ROOT, rel)).read()
+        assert "sfm_hip.h" not in src and "libsfmhip" not in src and "csrc/" not in src, f"{rel} reaches into the product"

@@ -1,0 +1,189 @@
+"""The oracle's sequential restatements of the RANSAC entry points (oracle/solvers_oracle.c; sfm.py:67,307,311), pinned by
+known answers, closed forms, planted ground truth and two independent NumPy solvers (tests/np_solvers.py).  CPU only."""
+import numpy as np
+import pytest
+
+import np_solvers
+from datagen import decompose_P, gustav_pair
+
+
+def _essential_truth(K, P1, P2):
+    R1, t1 = decompose_P(K, P1)
+    R2, t2 = decompose_P(K, P2)
+    R, t = R2 @ R1.T, t2 - R2 @ R1.T @ t1
+    tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    E = tx @ R
+    return E / np.linalg.norm(E), R, t
+
+
+def test_cv_rng_is_the_multiply_with_carry_stream(oracle):
+    r = oracle.CvRNG()
+    s, want = 0xFFFFFFFFFFFFFFFF, []
+    for _ in range(5):
+        s = ((s & 0xFFFFFFFF) * 4164903690 + (s >> 32)) & 0xFFFFFFFFFFFFFFFF
+        want.append(s & 0xFFFFFFFF)
+    assert [r.next() for _ in range(5)] == want
+    r = oracle.CvRNG()
+    assert [r.uniform(0, 100) for _ in range(6)] == [5, 4, 40, 73, 31, 12]
+
+
+def test_update_num_iters_closed_form(oracle):
+    assert oracle.ransac_update_num_iters(0.99, 0.5, 5, 1000) == int(np.rint(np.log(0.01) / np.log(1 - 0.5 ** 5)))
+    assert oracle.ransac_update_num_iters(0.99, 1.0, 5, 100) == 100
+    assert oracle.ransac_update_num_iters(0.999, 0.0, 5, 1000) == 0
+    assert oracle.ransac_update_num_iters(0.99, 0.2, 5, 7) == 7                     # never grows
+
+
+@pytest.mark.parametrize("shape,full", [((5, 9), True), ((9, 5), True), ((12, 12), False), ((6, 4), False), ((3, 3), False)])
+def test_svd_is_an_svd(oracle, shape, full):
+    A = np.random.default_rng(sum(shape)).normal(size=shape)
+    w, U, Vt = oracle.svd(A, full)
+    k = min(shape)
+    assert np.all(np.diff(w) <= 0) and np.allclose(w, np.linalg.svd(A, compute_uv=False), atol=1e-13)
+    assert np.allclose(U[:, :k] @ np.diag(w) @ Vt[:k], A, atol=1e-13)
+    assert np.allclose(U.T @ U, np.eye(U.shape[1]), atol=1e-13) and np.allclose(Vt @ Vt.T, np.eye(Vt.shape[0]), atol=1e-13)
+    if shape == (5, 9):       # FULL_UV completes the null space (the five-point solver's basis)
+        assert np.abs(A @ Vt[5:].T).max() < 1e-13
+
+
+def test_svd_of_a_rank_deficient_matrix_completes_the_left_basis(oracle):
+    rng = np.random.default_rng(3)
+    A = rng.normal(size=(6, 2)) @ rng.normal(size=(2, 4))
+    w, U, Vt = oracle.svd(A)
+    assert w[2] < 1e-12 * w[0] and np.allclose(U[:, :2] @ np.diag(w[:2]) @ Vt[:2], A, atol=1e-12)
+
+
+def test_solve_poly_finds_planted_roots(oracle):
+    roots = np.array([1, 2, 3, -0.5, 0.25 + 1j, 0.25 - 1j])
+    c = np.poly(roots)[::-1].real
+    got = oracle.solve_poly(c)
+    assert len(got) == 6 and np.allclose(np.sort_complex(got), np.sort_complex(roots), atol=1e-9)
+    assert len(oracle.solve_poly([1.0, -3.0, 2.0, 0.0, 0.0])) == 2                  # vanishing leading coefficients are dropped
+
+
+@pytest.mark.parametrize("k", [0, 7, 33, 50])
+def test_five_point_contains_the_true_essential_matrix(oracle, k):
+    K, P1, P2, X, x1, x2 = gustav_pair(k, 40, 0.0, seed=k)
+    Et, R, t = _essential_truth(K, P1, P2)
+    a, b = oracle.k_normalise(x1[:5], K), oracle.k_normalise(x2[:5], K)
+    Es = oracle.five_point(a, b)
+    assert 1 <= len(Es) <= 10
+    assert min(min(np.abs(E - Et).max(), np.abs(E + Et).max()) for E in Es) < 5e-3     # float32 pixels, minimal sample
+    for E in Es:          # every model satisfies the epipolar and the cubic constraints and has unit norm
+        r = np.einsum("ni,ij,nj->n", np.c_[b, np.ones(5)], E, np.c_[a, np.ones(5)])
+        assert np.abs(r).max() < 1e-9 and abs(np.linalg.det(E)) < 1e-9 and abs(np.linalg.norm(E) - 1) < 1e-12
+        assert np.abs(2 * E @ E.T @ E - np.trace(E @ E.T) * E).max() < 1e-8
+    # the same SOLUTION SET as an independent solver (LAPACK null space, numpy.roots)
+    En = np_solvers.five_point(a, b)
+    assert len(En) == len(Es)
+    for E in Es:
+        assert min(min(np.abs(E - F).max(), np.abs(E + F).max()) for F in En) < 1e-9
+    Ra, Rb, tt = oracle.decompose_essential(Et)
+    assert min(np.abs(Ra - R).max(), np.abs(Rb - R).max()) < 1e-9 and abs(np.linalg.det(Ra) - 1) < 1e-12
+    assert min(np.abs(tt - t / np.linalg.norm(t)).max(), np.abs(tt + t / np.linalg.norm(t)).max()) < 1e-9
+
+
+def test_k_normalise_is_one_scaled_conversion(oracle):
+    K, *_ , x1, _x2 = gustav_pair(0, 50, 0.3, seed=1)
+    got = oracle.k_normalise(x1, K)
+    ifx, ify = 1.0 / K[0, 0], 1.0 / K[1, 1]
+    want = np.stack([x1[:, 0].astype(np.float64) * ifx + (-K[0, 2] * ifx), x1[:, 1].astype(np.float64) * ify + (-K[1, 2] * ify)], 1)
+    assert np.array_equal(got, want)
+
+
+def test_epnp_recovers_planted_poses_and_matches_numpy_on_exact_data(oracle):
+    K, P1, P2, X, x1, x2 = gustav_pair(3, 400, 0.0, seed=11)
+    R, t = decompose_P(K, P2)
+    rng = np.random.default_rng(0)
+    for trial in range(60):
+        n = 5 if trial < 40 else int(rng.integers(6, 40))
+        sel = rng.choice(len(X), n, replace=False)
+        Ro, to = oracle.epnp(K, X[sel], x2[sel].astype(np.float64))
+        assert abs(np.linalg.det(Ro) - 1) < 1e-9 and np.allclose(Ro @ Ro.T, np.eye(3), atol=1e-9)
+        assert np.abs(Ro - R).max() < 1e-4 and np.abs(to - t).max() < 1e-3, trial
+        Rn, tn = np_solvers.epnp_numpy(K, X[sel], x2[sel].astype(np.float64))
+        assert np.abs(Ro - Rn).max() < 1e-5 and np.abs(to - tn).max() < 1e-4 * max(1.0, np.abs(tn).max()), trial
+
+
+def test_iterative_init_and_levenberg_marquardt(oracle):
+    K, P1, P2, X, x1, x2 = gustav_pair(3, 60, 0.0, seed=5)
+    R, t = decompose_P(K, P2)
+    st, rv, tv = oracle.pnp_dlt_init(K, X, x2.astype(np.float64))
+    assert st == 0 and np.abs(oracle.rodrigues_vec2mat(rv) - R).max() < 1e-6 and np.abs(tv - t).max() < 1e-5
+    r2, t2, iters = oracle.levmarq_pose(K, X, x2.astype(np.float64), rv + 0.02, tv + 0.1)
+    assert 2 <= iters <= 20 and np.abs(oracle.rodrigues_vec2mat(r2) - R).max() < 1e-6 and np.abs(t2 - t).max() < 1e-5
+    flat = X.copy()
+    flat[:, 2] = 0.3 * flat[:, 0] + 1.0                                             # coplanar object: the homography branch
+    assert oracle.pnp_dlt_init(K, flat, x2.astype(np.float64))[0] == 1
+    assert oracle.pnp_dlt_init(K, X[:5], x2[:5].astype(np.float64))[0] == 2
+
+
+def test_solve_pnp_ransac_rejects_planted_outliers(oracle):
+    K, P1, P2, X, x1, x2 = gustav_pair(10, 300, 0.3, seed=2)
+    R, t = decompose_P(K, P2)
+    rng = np.random.default_rng(0)
+    bad = rng.permutation(300)[:60]
+    x2 = x2.copy()
+    x2[bad] += rng.uniform(30, 200, (60, 2)).astype(np.float32)
+    ok, rvec, tvec, inl, model, st = oracle.solve_pnp_ransac(X.astype(np.float32), x2, K, want_model=True)
+    assert ok and st == 0 and inl.dtype == np.int32 and inl.shape[1] == 1 and np.all(np.diff(inl[:, 0]) > 0)
+    assert not set(inl[:, 0]) & set(bad) and len(inl) >= 230
+    assert np.abs(oracle.rodrigues_vec2mat(rvec.ravel()) - R).max() < 2e-3 and np.abs(tvec.ravel() - t).max() < 2e-2
+    # the returned inliers are those of the best RANSAC model, not re-scored after the refinement
+    _, mask = oracle.score_pnp(model[None], K, X.astype(np.float32), x2, 64.0)
+    assert np.array_equal(np.flatnonzero(mask[0]), inl[:, 0])
+    with pytest.raises(ValueError):
+        oracle.solve_pnp_ransac(X[:4].astype(np.float32), x2[:4], K)
+    ok5, r5, t5, i5 = oracle.solve_pnp_ransac(X[:5].astype(np.float32), x2[:5], K)      # model_points == npoints: plain EPnP
+    assert ok5 and i5[:, 0].tolist() == [0, 1, 2, 3, 4]
+
+
+def test_essential_ransac_and_recover_pose(oracle):
+    K, P1, P2, X, x1, x2 = gustav_pair(0, 400, 0.2, seed=3)
+    rng = np.random.default_rng(1)
+    bad = rng.permutation(400)[:80]
+    x2 = x2.copy()
+    x2[bad] += rng.uniform(20, 100, (80, 2)).astype(np.float32)
+    E, mask, stats = oracle.find_essential_mat(x1, x2, K, 0.999, 0.4, want_stats=True)
+    assert E.shape == (3, 3) and mask.shape == (400, 1) and mask.dtype == np.uint8 and set(np.unique(mask)) <= {0, 1}
+    assert mask[bad].sum() <= 2 and mask.sum() > 150 and stats[2] == mask.sum() and stats[1] >= stats[0] >= 1
+    # the mask is the model's own Sampson mask at (float)(thr^2), thr = 0.4 / mean focal length
+    thr = 0.4 / ((K[0, 0] + K[1, 1]) / 2)
+    _, m = oracle.score_essential(E[None], oracle.k_normalise(x1, K), oracle.k_normalise(x2, K), np.float32(thr * thr))
+    assert np.array_equal(m[0], mask.ravel())
+    sel = mask.ravel() == 1
+    good, R, t, m2 = oracle.recover_pose(E, x1[sel], x2[sel], K)
+    assert set(np.unique(m2)) <= {0, 255} and good == (m2 > 0).sum() > 150 and abs(np.linalg.norm(t) - 1) < 1e-12
+    Rt, tt = decompose_P(K, P2)           # P1 is the identity camera for pair 0
+    # E is the best MINIMAL-sample model (OpenCV does not refine it): loose pose tolerance under 0.2 px noise
+    assert np.abs(R - Rt).max() < 5e-2 and np.abs(t.ravel() - tt / np.linalg.norm(tt)).max() < 0.15
+    assert oracle.find_essential_mat(x1[:4], x2[:4], K) == (None, None)
+    E5, m5 = oracle.find_essential_mat(x1[:5], x2[:5], K)                                # count == modelPoints: all models, all ones
+    assert E5.shape[0] % 3 == 0 and E5.shape[0] >= 3 and m5.ravel().tolist() == [1] * 5
+
+
+def test_ransac_examines_every_model_of_an_iteration(oracle):
+    """RANSACPointSetRegistrator::run looks at `niters` only between iterations: with a very high inlier ratio the first
+    good model collapses niters to ~1, and the remaining models of THAT iteration must still be scored (a later root of
+    the same sample may be the better one).  Replayed here one model at a time from the oracle's own primitives."""
+    K, P1, P2, X, x1, x2 = gustav_pair(0, 300, 0.05, seed=9)
+    E, mask, stats = oracle.find_essential_mat(x1, x2, K, 0.999, 0.4, want_stats=True)
+    a, b = oracle.k_normalise(x1, K), oracle.k_normalise(x2, K)
+    thr = 0.4 / ((K[0, 0] + K[1, 1]) / 2)
+    thr2 = np.float32(thr * thr)
+    rng = oracle.CvRNG()
+    niters, best, bestE, scored, it = 1000, 0, None, 0, 0
+    while it < niters:
+        idx = []
+        while len(idx) < 5:
+            v = rng.uniform(0, 300)
+            if v not in idx:
+                idx.append(v)
+        for Em in oracle.five_point(a[idx], b[idx]):
+            cnt, _ = oracle.score_essential(Em[None], a, b, thr2)
+            scored += 1
+            if cnt[0] > max(best, 4):
+                best, bestE = int(cnt[0]), Em
+                niters = oracle.ransac_update_num_iters(0.999, (300 - best) / 300, 5, niters)
+        it += 1
+    assert np.array_equal(bestE, E) and best == stats[2] and scored == stats[1] and it == stats[0]
