@@ -84,6 +84,13 @@ def triangulate(P1, P2, pts1, pts2, rows=4, normalise_w=False):
     return X4
 
 
+def jacobi_stats(reset=True):
+    """{rotations applied, pairs skipped, calls} of the Jacobi core since the last reset (single-threaded use)."""
+    out = np.zeros(3, np.int64)
+    lib().orc_jacobi_stats(_p(out), C.c_int(1 if reset else 0))
+    return out
+
+
 def jacobi_svd(A):
     A = _f64(A)
     m, n = A.shape

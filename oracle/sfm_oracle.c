@@ -144,8 +144,17 @@ static double dot_lanes(const double* x, const double* y, int m) {
 #define SVD_MAXN 12
 #define SVD_MAXM 32
 
+static int64_t g_jacobi_rot = 0, g_jacobi_skip = 0, g_jacobi_calls = 0;
+/* counters of the Jacobi core since the last reset: {rotations applied, pairs skipped, calls} — bench.py derives the
+ * algorithmic FLOP count of the triangulation from them (not thread-safe: call from one thread) */
+void orc_jacobi_stats(int64_t* out, int reset) {
+    if (out) { out[0] = g_jacobi_rot; out[1] = g_jacobi_skip; out[2] = g_jacobi_calls; }
+    if (reset) g_jacobi_rot = g_jacobi_skip = g_jacobi_calls = 0;
+}
+
 void orc_jacobi_core(double* At /* n x m */, int m, int n, double* W, double* Vt /* n x n */) {
     const double eps = DBL_EPSILON * 10;
+    ++g_jacobi_calls;
     const int max_iter = m > 30 ? m : 30;
     for (int i = 0; i < n; ++i) {
         double sd = 0;
@@ -165,7 +174,8 @@ void orc_jacobi_core(double* At /* n x m */, int m, int n, double* W, double* Vt
                 double* Aj = At + j * m;
                 double a = W[i], b = W[j];
                 double p = dot_lanes(Ai, Aj, m);
-                if (fabs(p) <= eps * sqrt(a * b)) continue;
+                if (fabs(p) <= eps * sqrt(a * b)) { ++g_jacobi_skip; continue; }
+                ++g_jacobi_rot;
                 p *= 2;
                 const double beta = a - b, gamma = svd_hypot(p, beta);
                 double c, s;

@@ -63,8 +63,25 @@ def helper_goldens():
     np.savez_compressed(os.path.join(OUT, "helpers.npz"), **out)
 
 
+def photo_fixture():
+    """The reference's one sample photograph (image.jpg, 1936 x 1296, NIKON D60) as DATA: decoded with PIL, converted to
+    grey with the oracle's restatement of cv2.cvtColor(BGR2GRAY), stored as a uint8 array.  The SIFT parity tests run on
+    it at full size and at the reference's working size (one pyrDown, sfm.py:40)."""
+    import sys
+    root = os.path.dirname(os.path.dirname(OUT))
+    sys.path.insert(0, root)
+    from PIL import Image
+    from oracle import oracle as O
+    rgb = np.asarray(Image.open(os.path.join(REF, "image.jpg")).convert("RGB"))
+    bgr = np.ascontiguousarray(rgb[:, :, ::-1])
+    gray = O.bgr2gray(bgr)
+    assert gray.shape == (1296, 1936) and gray.dtype == np.uint8
+    np.savez_compressed(os.path.join(OUT, "photo_gray.npz"), gray=gray)
+
+
 def main():
     helper_goldens()
+    photo_fixture()
     ns = extract({"common_points", "to_ply"})
     rng = np.random.default_rng(20260928)
 
