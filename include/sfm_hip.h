@@ -231,6 +231,21 @@ int sfm_ba_schur_indexed(const double* cams_dev, int64_t ncam, const double* K_h
                          void* ws_dev, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Small batched block kernels of the Schur-complement solver (row f-3; the reference hands the
+ * problem to SciPy's dense least_squares, sfm.py:146) and cv2.norm of the metric (sfm.py:93,95).
+ *   sfm_block_inverse  A_dev [n x k x k] f64 (k = 3 point blocks, 6 camera blocks) -> Ainv_dev
+ *   sfm_block_matvec   y_i = A_i x_i;  x_dev, y_dev [n x k]
+ *   sfm_norm_l2        cv2.norm(a, b, NORM_L2) over n elements (float32, or float64 with is_f64):
+ *                      differences in the inputs' type, squares accumulated in double, fixed
+ *                      order; b_dev may be NULL (norm of a).  out_dev: one double (device).
+ * ---------------------------------------------------------------------- */
+int sfm_block_inverse(const double* A_dev, int64_t n, int k, double* Ainv_dev, void* stream);
+int sfm_block_matvec(const double* A_dev, const double* x_dev, int64_t n, int k, double* y_dev, void* stream);
+size_t sfm_norm_l2_ws_bytes(void);
+int sfm_norm_l2(const void* a_dev, const void* b_dev, int64_t n, int is_f64, double* out_dev,
+                void* ws_dev, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
  * A7  cv2.findEssentialMat RANSAC scoring                sfm.py:307
  *
  * For h candidate essential matrices (host-generated by the 5-point solver)

@@ -46,6 +46,10 @@ SIGNATURES = {
     "sfm_ba_schur_w": (_int, [_vp, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
     "sfm_ba_schur_indexed_ws_bytes": (_sz, [_i64]),
     "sfm_ba_schur_indexed": (_int, [_vp, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _int, _vp, _vp, _vp, _sz, _vp]),
+    "sfm_block_inverse": (_int, [_vp, _i64, _int, _vp, _vp]),
+    "sfm_block_matvec": (_int, [_vp, _vp, _i64, _int, _vp, _vp]),
+    "sfm_norm_l2_ws_bytes": (_sz, []),
+    "sfm_norm_l2": (_int, [_vp, _vp, _i64, _int, _vp, _vp, _sz, _vp]),
     "sfm_host_epnp": (_int, [_vp, _vp, _vp, _int, _vp, _vp]),
     "sfm_host_five_point": (_int, [_vp, _vp, _vp, _vp]),
     "sfm_host_decompose_essential": (_int, [_vp, _vp, _vp, _vp]),

@@ -95,8 +95,8 @@ def _inv3_sym(A):
 
 
 def _bmv(A, x, n):
-    """Batched (n x n blocks, row-major [m, n*n]) times [m, n] on the device."""
-    return torch.bmm(A.view(-1, n, n), x.unsqueeze(2)).squeeze(2)
+    """Batched (n x n blocks, row-major [m, n*n]) times [m, n] on the device (sfm_block_matvec)."""
+    return ops.block_matvec(A, x, n)
 
 
 def schur_step(cams, K, X, blocks, lam, fix_first_camera=True, cg_tol=1e-10, cg_iters=200, cam_idx=None, pt_idx=None):
@@ -123,18 +123,19 @@ def schur_step(cams, K, X, blocks, lam, fix_first_camera=True, cg_tol=1e-10, cg_
     free = torch.ones((ncam, 1), dtype=torch.float64, device=dev)
     if fix_first_camera:
         free[0] = 0                                                        # gauge: camera 0 does not move
-    Minv = torch.linalg.inv(B)                                             # block-Jacobi preconditioner
+    B = B.contiguous()
+    Minv = ops.block_inverse(B, 6)                                         # block-Jacobi preconditioner (sfm_block_inverse)
 
     def S(x):
         x = x * free
         u = ops.ba_schur_wt(cams, K, X, x, cam_idx, pt_idx)
         w = ops.ba_schur_w(cams, K, X, _bmv(Cinv, u, 3), cam_idx, pt_idx)
-        return (torch.bmm(B, x.unsqueeze(2)).squeeze(2) - w) * free
+        return (_bmv(B, x, 6) - w) * free
 
     rhs = (gc - ops.ba_schur_w(cams, K, X, _bmv(Cinv, gp, 3), cam_idx, pt_idx)) * free
     x = torch.zeros_like(rhs)
     r = rhs.clone()
-    z = torch.bmm(Minv, r.unsqueeze(2)).squeeze(2) * free
+    z = _bmv(Minv, r, 6) * free
     p = z.clone()
     rz = (r * z).sum()                                   # CG scalars stay on the device: one host sync per 5 iterations
     stop2 = (cg_tol * cg_tol) * (rhs * rhs).sum()
@@ -146,7 +147,7 @@ def schur_step(cams, K, X, blocks, lam, fix_first_camera=True, cg_tol=1e-10, cg_
         alpha = rz / (p * Sp).sum()
         x += alpha * p
         r -= alpha * Sp
-        z = torch.bmm(Minv, r.unsqueeze(2)).squeeze(2) * free
+        z = _bmv(Minv, r, 6) * free
         rz_new = (r * z).sum()
         p = z + (rz_new / rz) * p
         rz = rz_new

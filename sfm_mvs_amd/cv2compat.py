@@ -112,9 +112,12 @@ def norm(src1, src2=None, normType=NORM_L2):
     if normType != NORM_L2:
         raise NotImplementedError("NORM_L2 only")
     a = np.asarray(src1)
-    diff = a if src2 is None else a - np.asarray(src2)
+    if a.dtype not in (np.float32, np.float64):
+        a = a.astype(np.float64)
     d = _dev()
-    return float(torch.as_tensor(np.ascontiguousarray(diff)).to(d).to(torch.float64).square().sum().sqrt().item())
+    ta = torch.as_tensor(np.ascontiguousarray(a)).to(d)
+    tb = None if src2 is None else torch.as_tensor(np.ascontiguousarray(np.asarray(src2), a.dtype)).to(d)
+    return float(_ops.norm_l2(ta, tb).item())          # sfm_norm_l2: difference in the inputs' type, double accumulation
 
 
 def findEssentialMat(points1, points2, cameraMatrix, method=RANSAC, prob=0.999, threshold=1.0, mask=None):

@@ -241,6 +241,50 @@ def ba_dense_sweep(cams, K, X, obs, want_cam=True, want_pt=True):
     return out
 
 
+def block_inverse(A, k):
+    """Inverse of n independent k x k float64 blocks ([n, k*k] or [n, k, k]; k = 3 or 6) on the device (sfm_block_inverse)."""
+    require_cuda(A)
+    if A.dtype != torch.float64:
+        raise SfmHipError("block_inverse: float64 blocks")
+    a = A.contiguous()
+    out = torch.empty_like(a)
+    n = a.numel() // (k * k)
+    with on_device(a.device):
+        check(_lib.lib().sfm_block_inverse(ptr(a), n, int(k), ptr(out), stream_ptr()), "sfm_block_inverse")
+    return out
+
+
+def block_matvec(A, x, k):
+    """y_i = A_i x_i for n k x k float64 blocks and x [n, k] (sfm_block_matvec)."""
+    require_cuda(A, x)
+    if A.dtype != torch.float64 or x.dtype != torch.float64:
+        raise SfmHipError("block_matvec: float64 operands")
+    a, xv = A.contiguous(), x.contiguous()
+    n = xv.numel() // k
+    if a.numel() != n * k * k:
+        raise SfmHipError("block_matvec: shape mismatch")
+    y = torch.empty_like(xv)
+    with on_device(a.device):
+        check(_lib.lib().sfm_block_matvec(ptr(a), ptr(xv), n, int(k), ptr(y), stream_ptr()), "sfm_block_matvec")
+    return y
+
+
+def norm_l2(a, b=None):
+    """cv2.norm(a, b, NORM_L2) on device tensors of one dtype (float32 / float64): a [1] float64 device scalar."""
+    require_cuda(a, b)
+    if a.dtype not in (torch.float32, torch.float64) or (b is not None and (b.dtype != a.dtype or b.numel() != a.numel())):
+        raise SfmHipError("norm_l2: float32 or float64 operands of equal size")
+    av = a.contiguous()
+    bv = b.contiguous() if b is not None else None
+    out = torch.empty(1, dtype=torch.float64, device=a.device)
+    lib = _lib.lib()
+    ws = _workspace(a.device, lib.sfm_norm_l2_ws_bytes())
+    with on_device(a.device):
+        check(lib.sfm_norm_l2(ptr(av), ptr(bv), av.numel(), 1 if a.dtype == torch.float64 else 0, ptr(out), ptr(ws), ws.numel(),
+                              stream_ptr()), "sfm_norm_l2")
+    return out
+
+
 def _schur_args(cams, K, X):
     require_cuda(cams, X)
     cams = cams.contiguous().to(torch.float64).reshape(-1, 6)

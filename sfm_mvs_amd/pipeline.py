@@ -1,7 +1,7 @@
 """Host-side mirror of the reference's helper functions and driver (sfm.py), on top of the HIP back-end.
 
 Same names, argument meaning, shapes and quirks as the reference so that a user of sfm.py finds the same
-interface: `find_features` (sfm.py:242-270, matcher part), `Triangulation` (:45-56), `PnP`
+interface: `find_features(img0, img1)` (sfm.py:242-270; `match_features` is its matcher half), `Triangulation` (:45-56), `PnP`
 (:60-76), `ReprojectionError` (:79-100), `common_points` (:215-239), `to_ply` (:169-201) and the
 sliding-window driver (:274-423) as `run_sfm`.  An image is represented by its keypoint coordinates + 128-D
 descriptors ("features"); `img_downscale` (:35-42) and `features_from_images` (the cvtColor + SIFT half of
@@ -56,11 +56,32 @@ def _match_hip(feat0, feat1):
     return p0[:m].cpu().numpy(), p1[:m].cpu().numpy()              # sfm.py:267-268
 
 
-def find_features(feat0, feat1, be=None):
-    """Matcher half of sfm.py:242-270.  feat = (kp (n,2) float32 keypoint coordinates, des (n,128) float32).
-    Returns pts0, pts1 (M,2) float32 in ascending queryIdx order."""
+def match_features(feat0, feat1, be=None):
+    """Matcher half of sfm.py:242-270 on precomputed features.  feat = (kp (n,2) float32 keypoint coordinates,
+    des (n,128) float32), NumPy or CUDA tensors.  Returns pts0, pts1 (M,2) float32 in ascending queryIdx order."""
     return _be(be).match(feat0, feat1)
 
+
+def find_features(img0, img1, be=None):
+    """sfm.py:242-270 with the reference's signature: two BGR (or already grey) uint8 frames in, the matched pixel
+    coordinates `pts0, pts1` ((M,2) float32, ascending queryIdx) out — cvtColor (:243-244), SIFT detectAndCompute
+    (:246-252), BFMatcher.knnMatch k=2 (:259-260), the 0.70 ratio loop (:262-265) and the keypoint gather (:267-268),
+    all on the device; the features never visit the host.  (Feature tuples are still accepted and go to match_features:
+    the driver computes every image's features once instead of twice as the reference does.)"""
+    if isinstance(img0, (tuple, list)) and isinstance(img1, (tuple, list)):
+        return match_features(img0, img1, be)
+    b = _be(be)
+    if b.match is not _match_hip:            # a substituted backend (the tests' CPU twin): its own cv2 facade end to end
+        cv = b.cv
+        feats = []
+        for img in (img0, img1):
+            img = np.asarray(img)
+            gray = cv.cvtColor(img, cv.COLOR_BGR2GRAY) if img.ndim == 3 else img
+            kp, des = cv.xfeatures2d.SIFT_create().detectAndCompute(gray, None)
+            feats.append((np.float32([k.pt for k in kp]).reshape(-1, 2), des))
+        return b.match(feats[0], feats[1])
+    f0, f1 = features_from_images([img0, img1], depth=2, on_device=True)
+    return _match_hip(f0, f1)
 
 
 def img_downscale(img, downscale, be=None):
@@ -257,7 +278,7 @@ def run_sfm(features, K, images=None, log=None, be=None):
     Xtot = np.zeros((1, 3))               # quirk 8: leading zero row
     colorstot = np.zeros((1, 3))
 
-    pts0, pts1 = find_features(features[0], features[1], be)
+    pts0, pts1 = match_features(features[0], features[1], be)
     E, mask = cv2.findEssentialMat(pts0, pts1, K, method=cv2.RANSAC, prob=0.999, threshold=0.4, mask=None)
     pts0 = pts0[mask.ravel() == 1]        # quirk 4: {0,1} mask
     pts1 = pts1[mask.ravel() == 1]
@@ -276,7 +297,7 @@ def run_sfm(features, K, images=None, log=None, be=None):
 
     errors = []
     for i in range(len(features) - 2):
-        pts_, pts2 = find_features(features[i + 1], features[i + 2], be)
+        pts_, pts2 = match_features(features[i + 1], features[i + 2], be)
         if i != 0:
             pts0, pts1, points_3d = Triangulation(P1, P2, pts0, pts1, K, repeat=False, be=be)   # quirk 6: all ratio matches
             pts1 = pts1.T

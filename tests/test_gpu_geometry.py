@@ -336,3 +336,33 @@ def test_triangulation_one_million_distinct_points_vs_oracle(hip, oracle):
     fast = hip.triangulate(P[1], P[2], a, b, normalise_w="fast").cpu().numpy()
     assert (fast == got).all(0).mean() >= 0.995
     assert (np.abs(fast - got).max(0) / scale).max() <= 3e-7
+
+
+def test_block_kernels_and_norm(hip):
+    """sfm_block_inverse / sfm_block_matvec (the Schur solver's batched 3x3 and 6x6 blocks) and sfm_norm_l2 (cv2.norm)."""
+    rng = np.random.default_rng(8)
+    for k, n in ((3, 5000), (6, 777), (6, 1), (3, 0)):
+        J = rng.normal(size=(n, 2 * k, k))
+        A = np.einsum("nij,nik->njk", J, J) + 1e-3 * np.eye(k)          # SPD like the normal-equation blocks
+        inv = hip.block_inverse(cu64(A.reshape(n, k * k)), k).cpu().numpy().reshape(n, k, k)
+        if n:
+            assert np.abs(inv @ A - np.eye(k)).max() < 1e-8
+            assert np.abs(inv - np.linalg.inv(A)).max() <= 1e-9 * np.abs(np.linalg.inv(A)).max()
+        x = rng.normal(size=(n, k))
+        y = hip.block_matvec(cu64(A.reshape(n, k * k)), cu64(x), k).cpu().numpy()
+        assert np.allclose(y, np.einsum("nij,nj->ni", A, x), rtol=1e-13, atol=1e-13)
+    general = rng.normal(size=(100, 6, 6))                                # needs the pivoting
+    general[:, 0, 0] = 0
+    inv = hip.block_inverse(cu64(general.reshape(100, 36)), 6).cpu().numpy().reshape(100, 6, 6)
+    assert np.abs(inv @ general - np.eye(6)).max() < 1e-8
+    for dt in (np.float32, np.float64):
+        a, b = rng.normal(0, 30, 100_003).astype(dt), rng.normal(0, 30, 100_003).astype(dt)
+        want = np.sqrt(np.sum(np.float64(a - b) ** 2))
+        got = hip.norm_l2(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()).item()
+        assert got == pytest.approx(want, rel=1e-13)
+        assert hip.norm_l2(torch.from_numpy(a).cuda()).item() == pytest.approx(np.sqrt(np.sum(np.float64(a) ** 2)), rel=1e-13)
+    assert hip.norm_l2(torch.zeros(0, device="cuda")).item() == 0.0
+
+
+def cu64(a):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float64)).cuda()

@@ -117,6 +117,13 @@ def test_images_to_matches_round_trip(hip):
     d = p0 - p1
     ok = (np.abs(d[:, 0] - dx) < 0.5) & (np.abs(d[:, 1] - dy) < 0.5)
     assert ok.mean() > 0.95
+    # the reference's own entry point: find_features(img0, img1) -> pts0, pts1 (sfm.py:242), from BGR frames, on the device
+    from sfm_mvs_amd import pipeline as pl
+    q0, q1 = pl.find_features(np.repeat(g0[:, :, None], 3, 2), np.repeat(g1[:, :, None], 3, 2))
+    assert q0.dtype == np.float32 and q0.shape == q1.shape == (len(good), 2)
+    assert np.array_equal(q0, p0) and np.array_equal(q1, p1)                          # same matches, same (queryIdx) order
+    r0, r1 = pl.find_features(g0, g1)                                                  # already-grey frames are accepted too
+    assert np.array_equal(r0, p0) and np.array_equal(r1, p1)
 
 
 def test_cv2compat_preprocessing(hip, oracle):
