@@ -150,44 +150,37 @@ def bench_knn(args, world, rank, dev):
     pm = pipe.matchers[0]
     import torch.distributed as dist
     exchange = dist.is_available() and dist.is_initialized()
+    ex = None
     if exchange:
-        # The exchange: every rank ends up with every pair's {trainIdx x2, distance x2} block (16 B per query).
-        # EXCH_BATCH pairs are written straight into one batch buffer and exchanged by ONE RCCL all-gather (fewer, larger
-        # collectives: a 160 KB all-gather per pair costs more in launch + ring latency than the pair itself), issued from
-        # one stream in the same order on every rank; two batch buffers alternate.
-        batch = [torch.empty((EXCH_BATCH, 2, nq, 2), dtype=torch.int32, device=dev) for _ in range(2)]
-        gathered = [torch.empty((world, EXCH_BATCH, 2, nq, 2), dtype=torch.int32, device=dev) for _ in range(2)]
-        free = [None, None]                                  # per batch buffer: "its previous all-gather has read it"
-        state = {"cur": 0, "fill": 0}
+        # The exchange through the package's one multi-GPU code path, sfm_mvs_amd.sharded.BatchedExchange (the
+        # class match_pairs_sharded drives and the world-size-2 gloo tests cover): every rank ends up with every pair's
+        # {trainIdx x2, distance x2} block (16 B per query).  EXCH_BATCH pairs are written straight into one batch buffer
+        # and exchanged by ONE RCCL all-gather (fewer, larger collectives: a 160 KB all-gather per pair costs more in
+        # launch + ring latency than the pair itself), issued from one stream in the same order on every rank; two batch
+        # buffers alternate.
+        from sfm_mvs_amd import sharded
+        ex = sharded.BatchedExchange((2, nq, 2), torch.int32, dev, batch=EXCH_BATCH)
 
     def flush():
         """All-gather the pairs accumulated in the current batch buffer (a partial batch is sent whole)."""
-        if not exchange or state["fill"] == 0:
-            return
-        cur = state["cur"]
-        main = torch.cuda.current_stream()
-        for st in pipe.streams:
-            main.wait_stream(st)
-        dist.all_gather_into_tensor(gathered[cur], batch[cur])
-        ev = torch.cuda.Event()
-        ev.record(main)                                      # (the collective is complete on `main` here: async_op=False)
-        free[cur] = ev
-        state["cur"], state["fill"] = cur ^ 1, 0
+        if ex is not None and ex.fill > 0:
+            ex.flush(pipe.streams)
 
     def step():
-        if not exchange:
+        if ex is None:
             pipe.submit(q, t, after=False)                   # static inputs, nothing to wait for
             return
-        cur, b = state["cur"], state["fill"]
-        pipe.submit(q, t, after=free[cur] if (b < depth and free[cur] is not None) else False, result=batch[cur][b])
-        state["fill"] = b + 1
-        if state["fill"] == EXCH_BATCH:
-            flush()
+        slot, free_ev = ex.next_slot()
+        pipe.submit(q, t, after=free_ev if (ex.fill < depth and free_ev is not None) else False, result=slot)
+        if ex.commit():
+            ex.flush(pipe.streams)
 
     for _ in range(args.warmup):
         step()
     flush()
     barrier_sync(world)
+    if ex is not None:
+        ex.exchange_ms()                                     # drop the warm-up collectives' timings
     # The timed region is ONLY step() calls (+ the closing exchange): barrier + device-wide sync on both sides.
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -196,6 +189,8 @@ def bench_knn(args, world, rank, dev):
     barrier_sync(world)
     elapsed = time.perf_counter() - t0
     elapsed = max_over_ranks(elapsed, world, dev)
+    exchange_ms = ex.exchange_ms() if ex is not None else None       # device time inside the timed region's collectives
+    exchange_calls = ex.collectives if ex is not None else 0
     # Roofline sampling, AFTER the timed region: the library brackets its kernels with HIP events on the launch stream
     # when profiling is on.  An event pair costs ~3.5 us of stream time, and with several pairs in flight a kernel's
     # event-to-event time also contains the neighbours' kernels it shares the chip with — so the sampled steps run
@@ -262,6 +257,12 @@ def bench_knn(args, world, rank, dev):
         "knn_stats": {"rescanned_queries": stats[0], "filter_workgroups": stats[1], "streams_per_query": stats[2],
                       "filter_mode": mode_name},
     }
+    if ex is not None:
+        out["exchange"] = {"ms_total_in_timed_region": exchange_ms, "ms_per_step": exchange_ms / args.steps,
+                           "collectives_since_start": exchange_calls, "pairs_per_collective": EXCH_BATCH,
+                           "bytes_per_rank_per_collective": EXCH_BATCH * nq * 16,
+                           "note": "device time between the events bracketing each all_gather_into_tensor on the issuing stream "
+                                   "(includes waiting for the batch's producers); the pair kernels of the next batch overlap it"}
     # latency of ONE pair on one stream (no overlap with neighbouring pairs), outside the timed region
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -699,6 +700,11 @@ def bench_sfm(args, world, rank, dev):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line (the JSON): libraries that write to the C-level stdout (RCCL prints a version banner
+    # from its own stdio buffer at exit) are sent to stderr for the whole run, the JSON goes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world, rank, local = init_dist(args)
     dev = torch.device("cuda", local)
     import sfm_mvs_amd
@@ -721,7 +727,7 @@ def main():
     else:
         out = bench_ba(args, world, rank, dev)
     if rank == 0:
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()

@@ -1,12 +1,20 @@
-"""Pair-sharded feature matching across the GPUs of one node (BASELINE config 5).
+"""Pair-sharded feature matching and triangulation across the GPUs of one node (BASELINE config 5).
 
-The hot path shards by image pair: rank r owns a contiguous block of the pair list (sequential pairs
-(k, k+1) as in sfm.py:347, or any list such as isfm.py's all-pairs) and matches it with NO data-path
-collective.  The path's one exchange step is an all-gather of fixed-stride match records
-{queryIdx, trainIdx, dist1, dist2} (16 B) + a per-pair survivor count, after which every rank holds
-every pair's matches (camera registration is sequential and replicated).  One process per GPU,
-`torch.distributed` with backend "nccl" (= RCCL over xGMI); the same code runs under "gloo" on CPU
-tensors in the tests, with an injected matcher.
+The hot path shards by image pair: rank r owns a contiguous block of the pair list — sequential pairs (k, k+1) as in
+sfm.py:347, or any list such as isfm.py's all-pairs — and matches it with NO data-path collective.  For sequential
+pairs a rank needs only its block's images plus ONE halo image (the train image of its last pair): `halo_images`.
+The path has two exchange steps, both all-gathers of fixed-stride blocks (one process per GPU, `torch.distributed`
+backend "nccl" = RCCL over xGMI; the same code runs under "gloo" on CPU tensors in the tests):
+
+  1. match records: per pair the KNN block {trainIdx x2, distance x2} of every query (16 B per query, = the DMatch
+     pairs of sfm.py:260; the Lowe survivors of sfm.py:262-265 are a function of it), and
+  2. triangulated points: per pair float32 x 4 per surviving match (sfm.py:349,371 run on the owning rank).
+
+Blocks are exchanged `batch` pairs at a time: a 160 KB all-gather per 10k-query pair costs more in launch and ring
+latency than the pair itself, and xGMI is point-to-point (a ring is bound by one link), so fewer, larger collectives.
+Batch buffers alternate (double buffering); every rank issues the same collectives in the same order whatever its own
+pair count (uneven blocks and a partial last batch send unused slots).  Camera registration (the PnP chain) is
+sequential and stays replicated.  `bench.py --gpus N` drives the same `BatchedExchange`.
 """
 import numpy as np
 import torch
@@ -20,64 +28,6 @@ def shard_range(n_items, world, rank):
     return lo, lo + per + (1 if rank < extra else 0)
 
 
-def hip_matcher(ratio=0.70):
-    """Default matcher: KNN + ratio on the local GPU → (q_idx, t_idx, d1, d2) device tensors of the survivors."""
-    from . import ops
-
-    def match(des0, des1):
-        idx, d = ops.knn2(des0, des1)
-        out_q, out_t, count = ops.ratio_compact(idx, d, ratio)
-        m = int(count.item())
-        q = out_q[:m].long()
-        return out_q[:m], out_t[:m], d[q, 0], d[q, 1]
-
-    return match
-
-
-def match_pairs_sharded(descriptors, pairs, matcher=None, group=None, device=None):
-    """descriptors: list of [n_i,128] float32 tensors (all images resident, or None for images this rank
-    never touches); pairs: list of (i, j).  Returns, on EVERY rank, a list with one entry per pair:
-    dict(q=int32[m], t=int32[m], d1=float32[m], d2=float32[m])."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
-    matcher = matcher or hip_matcher()
-    lo, hi = shard_range(len(pairs), world, rank)
-    cap = max((descriptors[i].shape[0] for i, _ in pairs if descriptors[i] is not None), default=0)
-    if world > 1:   # the record stride must agree on all ranks
-        capt = torch.tensor([cap], dtype=torch.int64, device=device)
-        dist.all_reduce(capt, op=dist.ReduceOp.MAX, group=group)
-        cap = int(capt.item())
-    slots = -(-len(pairs) // world)                       # pairs per rank, padded
-    dev = device if device is not None else (descriptors[pairs[lo][0]].device if hi > lo else torch.device("cpu"))
-    rec = torch.zeros((slots, cap, 4), dtype=torch.int32, device=dev)
-    cnt = torch.zeros(slots, dtype=torch.int32, device=dev)
-    for s, p in enumerate(range(lo, hi)):
-        i, j = pairs[p]
-        q, t, d1, d2 = matcher(descriptors[i], descriptors[j])
-        m = q.shape[0]
-        rec[s, :m, 0] = q.to(torch.int32)
-        rec[s, :m, 1] = t.to(torch.int32)
-        rec[s, :m, 2] = d1.to(torch.float32).view(torch.int32)
-        rec[s, :m, 3] = d2.to(torch.float32).view(torch.int32)
-        cnt[s] = m
-    if world > 1:
-        all_rec = torch.empty((world * slots, cap, 4), dtype=torch.int32, device=dev)
-        all_cnt = torch.empty(world * slots, dtype=torch.int32, device=dev)
-        dist.all_gather_into_tensor(all_rec, rec, group=group)
-        dist.all_gather_into_tensor(all_cnt, cnt, group=group)
-    else:
-        all_rec, all_cnt = rec, cnt
-    counts = all_cnt.cpu().numpy()
-    out = []
-    for p in range(len(pairs)):
-        r = next(r for r in range(world) if shard_range(len(pairs), world, r)[0] <= p < shard_range(len(pairs), world, r)[1])
-        s = r * slots + (p - shard_range(len(pairs), world, r)[0])
-        m = int(counts[s])
-        block = all_rec[s, :m]
-        out.append(dict(q=block[:, 0], t=block[:, 1], d1=block[:, 2].view(torch.float32), d2=block[:, 3].view(torch.float32)))
-    return out
-
-
 def sequential_pairs(n_images):
     return [(k, k + 1) for k in range(n_images - 1)]
 
@@ -85,3 +35,200 @@ def sequential_pairs(n_images):
 def all_pairs(n_images):
     """isfm.py:56-71: every (j, i) with j < i."""
     return [(j, i) for i in range(n_images) for j in range(i)]
+
+
+def halo_images(pairs, world, rank):
+    """Images rank `rank` must hold to match its block of `pairs`: for sequential pairs its own images + one halo image."""
+    lo, hi = shard_range(len(pairs), world, rank)
+    return sorted({i for p in pairs[lo:hi] for i in p})
+
+
+def _world_rank(group):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group), dist.get_rank(group)
+    return 1, 0
+
+
+class BatchedExchange:
+    """All-gather of fixed-stride blocks, `batch` blocks per collective, two alternating batch buffers.
+
+    A producer asks for the next slot (`next_slot` -> tensor view + the event after which the slot may be overwritten),
+    enqueues the work that fills it on any stream, then `commit`s; when the batch is full — or on `flush` — the buffer is
+    all-gathered from the CURRENT stream after waiting for `producer_streams`.  `flush` returns the gathered tensor
+    [world][batch][*block_shape] (a view of an internal buffer, valid until the second next flush) and how many slots
+    this rank had filled; ranks may fill different numbers of slots, but must call flush the same number of times."""
+
+    def __init__(self, block_shape, dtype, device, batch=8, group=None, nbuf=2):
+        self.world, self.rank = _world_rank(group)
+        self.group, self.batch, self.device = group, int(batch), torch.device(device)
+        self.block_shape = tuple(int(x) for x in block_shape)
+        self.local = [torch.zeros((self.batch,) + self.block_shape, dtype=dtype, device=self.device) for _ in range(nbuf)]
+        self.gathered = [torch.empty((self.world, self.batch) + self.block_shape, dtype=dtype, device=self.device) for _ in range(nbuf)]
+        self.free = [None] * nbuf                       # per buffer: event "its previous all-gather has read it"
+        self.cur, self.fill, self.collectives = 0, 0, 0
+        self.cuda = self.device.type == "cuda"
+        self._timed = []                                # (start, end) events of the collectives, for exchange_ms()
+
+    def next_slot(self):
+        """(slot view, event to wait for before writing it or None).  Only the first `depth` producers of a batch need
+        the event (later ones are ordered behind them on their own streams); handing it to all is harmless."""
+        if self.fill >= self.batch:
+            raise RuntimeError("BatchedExchange: batch is full — flush first")
+        return self.local[self.cur][self.fill], self.free[self.cur]
+
+    def commit(self):
+        """The slot returned by the last next_slot() has its producer enqueued.  True when the batch is now full."""
+        self.fill += 1
+        return self.fill == self.batch
+
+    def flush(self, producer_streams=()):
+        """Exchange the current batch buffer now (a partial batch is sent whole).  Every rank must call this the same
+        number of times.  Returns (gathered [world][batch][...], slots filled by this rank)."""
+        cur, filled = self.cur, self.fill
+        if self.cuda:
+            main = torch.cuda.current_stream(self.device)
+            for st in producer_streams:
+                main.wait_stream(st)
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record(main)
+        if self.world > 1:
+            # (concatenated form [world * batch][...]: gloo accepts no other; nccl takes both)
+            dist.all_gather_into_tensor(self.gathered[cur].view((self.world * self.batch,) + self.block_shape), self.local[cur], group=self.group)
+        else:
+            self.gathered[cur][0].copy_(self.local[cur])
+        if self.cuda:
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev1.record(main)                            # (the collective is complete on `main` here: async_op=False)
+            self.free[cur] = ev1
+            self._timed.append((ev0, ev1))
+        self.collectives += 1
+        self.cur, self.fill = (cur + 1) % len(self.local), 0
+        return self.gathered[cur], filled
+
+    def exchange_ms(self, reset=True):
+        """Device time spent in the collectives since the last reset (synchronises their events)."""
+        ms = 0.0
+        for a, b in self._timed:
+            b.synchronize()
+            ms += a.elapsed_time(b)
+        if reset:
+            self._timed = []
+        return ms
+
+
+class HipMatchEngine:
+    """KNN + ratio of one pair into a caller-provided KNN block, pipelined over HIP streams (ops.PairPipeline)."""
+
+    def __init__(self, device, ratio=0.70, depth=3):
+        self.device, self.ratio, self.depth = torch.device(device), ratio, depth
+        self.pipes = {}
+
+    @property
+    def streams(self):
+        return [st for p in self.pipes.values() for st in p.streams]
+
+    def match(self, des0, des1, block, after=None):
+        """block: int32 [2][cap][2] view (cap >= nq) receiving (trainIdx x2, distance bits x2) of the nq queries."""
+        from . import ops
+        nq, nt = des0.shape[0], des1.shape[0]
+        pipe = self.pipes.get((nq, nt))
+        if pipe is None:
+            pipe = self.pipes[(nq, nt)] = ops.PairPipeline(nq, nt, self.device, ratio=self.ratio, depth=self.depth)
+        direct = block.shape[1] == nq and block.is_contiguous()
+        slot, st, out = pipe.submit(des0, des1, after=after if after is not None else False, result=block if direct else None)
+        if not direct:
+            with torch.cuda.stream(st):
+                block[0, :nq].copy_(out[0], non_blocking=True)
+                block[1, :nq].copy_(out[1].view(torch.int32), non_blocking=True)
+
+
+def ratio_survivors(block, nq, ratio=0.70):
+    """The Lowe loop of sfm.py:262-265 on a gathered KNN block -> (queryIdx, trainIdx) int64 tensors, ascending queryIdx.
+    float32 distances promoted to double, strict <, as Python compares them."""
+    idx = block[0, :nq]
+    d = block[1, :nq].view(torch.float32).to(torch.float64)
+    keep = (idx[:, 1] >= 0) & (d[:, 0] < ratio * d[:, 1])
+    q = torch.nonzero(keep, as_tuple=False).reshape(-1)
+    return q, idx[q, 0].long()
+
+
+def match_pairs_sharded(descriptors, pairs, n_desc=None, engine=None, group=None, device=None, batch=8, ratio=0.70):
+    """descriptors: list over images of [n_i,128] float32 tensors — None for images this rank never touches
+    (`halo_images`); pairs: list of (i, j); n_desc: descriptor count of EVERY image (needed for images held elsewhere;
+    taken from `descriptors` when all are present).  Every rank matches its block of pairs and the KNN blocks are
+    all-gathered `batch` pairs at a time.  Returns, on every rank, (store, n_query): store int32 [n_pairs][2][cap][2]
+    with store[p][0] = trainIdx x2 and store[p][1] = float32 distance bits x2 of pair p's n_query[p] queries."""
+    world, rank = _world_rank(group)
+    if n_desc is None:
+        n_desc = [d.shape[0] for d in descriptors]
+    n_pairs = len(pairs)
+    dev = torch.device(device) if device is not None else next(d.device for d in descriptors if d is not None)
+    cap = max((n_desc[i] for i, _ in pairs), default=0)
+    engine = engine or HipMatchEngine(dev, ratio)
+    ex = BatchedExchange((2, cap, 2), torch.int32, dev, batch, group)
+    spans = [shard_range(n_pairs, world, r) for r in range(world)]
+    lo, hi = spans[rank]
+    per = max((h - l for l, h in spans), default=0)
+    store = torch.zeros((n_pairs + 1, 2, cap, 2), dtype=torch.int32, device=dev)      # [+1]: dump row for unused slots
+    for rd in range(-(-per // batch) if per else 0):
+        for b in range(batch):
+            p = lo + rd * batch + b
+            if p < hi:
+                i, j = pairs[p]
+                slot, ev = ex.next_slot()
+                engine.match(descriptors[i], descriptors[j], slot, after=ev)
+                ex.commit()
+        gathered, _ = ex.flush(getattr(engine, "streams", ()))
+        # scatter the round's blocks to their pairs in ONE indexed copy (unused slots go to the dump row)
+        dst = torch.full((world, batch), n_pairs, dtype=torch.int64)
+        for r, (l, h) in enumerate(spans):
+            k = np.arange(batch) + l + rd * batch
+            dst[r] = torch.from_numpy(np.where(k < h, k, n_pairs))
+        store.index_copy_(0, dst.reshape(-1).to(dev), gathered.reshape((world * batch,) + gathered.shape[2:]))
+    return store[:n_pairs], [n_desc[i] for i, _ in pairs]
+
+
+def triangulate_pairs_sharded(store, n_query, pairs, keypoints, proj, triangulate=None, group=None, batch=8, ratio=0.70):
+    """The path's second exchange (north_star: "all-gather of 3D points"): every rank triangulates the Lowe survivors of
+    ITS pairs (sfm.py:349,371: cv2.triangulatePoints + division by w) and the float32 x 4 points are all-gathered.
+    keypoints: list over images of [n_i,2] float32 (None where not held: a rank needs its block + halo, as for the
+    descriptors); proj: list over images of 3x4 float64 projection matrices (replicated: the PnP chain is sequential).
+    triangulate(P1, P2, x1 (2,m), x2 (2,m)) -> (4,m) float32; default: the HIP kernel.
+    Returns (points float32 [n_pairs][4][cap], counts int64 [n_pairs]) on every rank."""
+    world, rank = _world_rank(group)
+    dev = store.device
+    n_pairs, cap = len(pairs), store.shape[2]
+    if triangulate is None:
+        from . import ops
+
+        def triangulate(P1, P2, x1, x2):
+            return ops.triangulate(P1, P2, x1, x2, normalise_w=True)
+    ex = BatchedExchange((4, cap), torch.float32, dev, batch, group)
+    spans = [shard_range(n_pairs, world, r) for r in range(world)]
+    lo, hi = spans[rank]
+    per = max((h - l for l, h in spans), default=0)
+    points = torch.zeros((n_pairs + 1, 4, cap), dtype=torch.float32, device=dev)
+    # the survivor counts are a function of the gathered KNN blocks: every rank derives all of them, no collective
+    counts = torch.tensor([len(ratio_survivors(store[p], n_query[p], ratio)[0]) for p in range(n_pairs)], dtype=torch.int64)
+    for rd in range(-(-per // batch) if per else 0):
+        for b in range(batch):
+            p = lo + rd * batch + b
+            if p < hi:
+                i, j = pairs[p]
+                q, t = ratio_survivors(store[p], n_query[p], ratio)
+                slot, ev = ex.next_slot()
+                if ev is not None:
+                    torch.cuda.current_stream(dev).wait_event(ev)
+                slot.zero_()                                     # (the buffer still holds the points of two rounds ago)
+                if len(q):
+                    x1 = keypoints[i].to(dev)[q].t().contiguous()
+                    x2 = keypoints[j].to(dev)[t].t().contiguous()
+                    slot[:, :len(q)].copy_(triangulate(proj[i], proj[j], x1, x2))
+                ex.commit()
+        gathered, _ = ex.flush()
+        dst = torch.full((world, batch), n_pairs, dtype=torch.int64)
+        for r, (l, h) in enumerate(spans):
+            k = np.arange(batch) + l + rd * batch
+            dst[r] = torch.from_numpy(np.where(k < h, k, n_pairs))
+        points.index_copy_(0, dst.reshape(-1).to(dev), gathered.reshape((world * batch,) + gathered.shape[2:]))
+    return points[:n_pairs], counts

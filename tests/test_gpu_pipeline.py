@@ -250,3 +250,36 @@ def test_hip_helpers_against_the_references_own_helpers(hip, oracle):
             else:
                 scale = max(np.abs(want).max(), 1e-30)
                 assert np.abs(v - want).max() <= 1e-4 * scale, (tag, k, np.abs(v - want).max(), scale)
+
+
+def test_sharded_path_on_one_gpu(hip, oracle):
+    """sfm_mvs_amd.sharded with its default HIP engines on a single rank (the code bench.py --gpus N and the gloo tests
+    drive): images of different sizes (padded blocks), batches of 2 with a partial last one, then the point exchange."""
+    import torch
+    from datagen import load_pose_csv
+    from sfm_mvs_amd import sharded
+    rng = np.random.default_rng(5)
+    sizes = [700, 640, 700, 512, 700, 333]
+    des = [planted_pair(rng, n, 10, 0.0)[0] for n in sizes]
+    for k in range(5):
+        m = min(sizes[k], sizes[k + 1]) // 2
+        des[k + 1][:m] = des[k][rng.permutation(sizes[k])[:m]]
+    kps = [rng.uniform(0, 900, (n, 2)).astype(np.float32) for n in sizes]
+    pairs = sharded.sequential_pairs(6)
+    dd = [torch.from_numpy(d).cuda() for d in des]
+    store, nq = sharded.match_pairs_sharded(dd, pairs, batch=2)
+    torch.cuda.synchronize()
+    assert tuple(store.shape) == (5, 2, 700, 2) and nq == sizes[:5]
+    for p, (i, j) in enumerate(pairs):
+        wi, wd = oracle.knn2(des[i], des[j])
+        assert np.array_equal(store[p, 0, :nq[p]].cpu().numpy(), wi)
+        assert np.array_equal(store[p, 1, :nq[p]].cpu().numpy().view(np.float32), wd)
+    K, P = load_pose_csv()
+    pts, counts = sharded.triangulate_pairs_sharded(store, nq, pairs, [torch.from_numpy(k).cuda() for k in kps], list(P[:6]), batch=2)
+    for p, (i, j) in enumerate(pairs):
+        q, t = sharded.ratio_survivors(store[p], nq[p])
+        wq, wt, _ = oracle.ratio_filter(*oracle.knn2(des[i], des[j]), 0.70)
+        assert np.array_equal(q.cpu().numpy(), wq) and np.array_equal(t.cpu().numpy(), wt) and int(counts[p]) == len(wq) > 50
+        want = oracle.triangulate(P[i], P[j], kps[i][wq].T.copy(), kps[j][wt].T.copy(), normalise_w=True)
+        got = pts[p, :, :len(wq)].cpu().numpy()
+        assert np.allclose(got, want, rtol=1e-6, atol=1e-7) and float(pts[p, :, len(wq):].abs().sum()) == 0.0

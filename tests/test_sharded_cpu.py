@@ -1,9 +1,12 @@
-"""World-size-2 `gloo` test of the pair-sharded matcher (the N>1 path of bench.py / config 5), on CPU
-tensors with the oracle injected as the per-pair matcher."""
+"""World-size-2 `gloo` tests of the pair-sharded path (the N > 1 code of bench.py / BASELINE config 5) on CPU tensors
+with the oracle injected as the per-pair engines: halo partition (a rank holds only its block + one image), batched
+exchange with a partial last batch and uneven pair counts, the all-gather of triangulated points, and the
+BatchedExchange protocol bench.py drives."""
 import os
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -11,52 +14,130 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, ret):
+class OracleEngine:
+    """CPU stand-in for sharded.HipMatchEngine: the oracle's KNN written into the exchange slot."""
+
+    def __init__(self, oracle):
+        self.O, self.streams, self.calls = oracle, (), 0
+
+    def match(self, des0, des1, block, after=None):
+        idx, d = self.O.knn2(des0.numpy(), des1.numpy())
+        nq = len(idx)
+        block[0, :nq] = torch.from_numpy(idx)
+        block[1, :nq] = torch.from_numpy(d.view(np.int32))
+        self.calls += 1
+
+
+def _scene(n_images, seed):
+    from datagen import planted_pair
+    rng = np.random.default_rng(seed)          # same data on every rank
+    des = [torch.from_numpy(planted_pair(rng, 90 + 7 * (k % 5), 10, 0.0)[0]) for k in range(n_images)]
+    for k in range(n_images - 1):               # plant matches between consecutive images
+        n = min(len(des[k]), len(des[k + 1])) // 2
+        des[k + 1][:n] = des[k][torch.randperm(len(des[k]), generator=torch.Generator().manual_seed(k))[:n]]
+    kps = [torch.from_numpy(rng.uniform(0, 900, (len(d), 2)).astype(np.float32)) for d in des]
+    return des, kps
+
+
+def _worker(rank, world, port, n_images, batch, ret):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from datagen import planted_pair
+    from datagen import load_pose_csv
     from oracle import oracle as O
     from sfm_mvs_amd import sharded
 
-    rng = np.random.default_rng(0)          # same data on every rank
-    des = [torch.from_numpy(planted_pair(rng, 120 + 10 * k, 10, 0.0)[0]) for k in range(6)]
-    for k in range(5):                       # plant matches between consecutive images
-        n = min(len(des[k]), len(des[k + 1])) // 2
-        des[k + 1][:n] = des[k][torch.randperm(len(des[k]), generator=torch.Generator().manual_seed(k))[:n]]
-
-    def matcher(a, b):
-        idx, d = O.knn2(a.numpy(), b.numpy())
-        q, t, _ = O.ratio_filter(idx, d, 0.70)
-        return torch.from_numpy(q), torch.from_numpy(t), torch.from_numpy(d[q, 0]), torch.from_numpy(d[q, 1])
-
-    pairs = sharded.sequential_pairs(6)
-    got = sharded.match_pairs_sharded(des, pairs, matcher=matcher, device=torch.device("cpu"))
-    want = [matcher(des[i], des[j]) for i, j in pairs]
-    ok = all(torch.equal(g["q"], w[0]) and torch.equal(g["t"], w[1]) and torch.equal(g["d1"], w[2]) and
-             torch.equal(g["d2"], w[3]) for g, w in zip(got, want))
+    des, kps = _scene(n_images, 0)
+    n_desc = [len(d) for d in des]
+    pairs = sharded.sequential_pairs(n_images)
+    mine = sharded.halo_images(pairs, world, rank)
     lo, hi = sharded.shard_range(len(pairs), world, rank)
-    ret[rank] = (ok, hi - lo, sum(len(g["q"]) for g in got))
+    held = [d if i in mine else None for i, d in enumerate(des)]        # the halo partition: nothing else is resident
+    held_kp = [k if i in mine else None for i, k in enumerate(kps)]
+    eng = OracleEngine(O)
+    store, nq = sharded.match_pairs_sharded(held, pairs, n_desc=n_desc, engine=eng, device=torch.device("cpu"), batch=batch)
+    ok = eng.calls == hi - lo and len(mine) == (hi - lo + 1 if hi > lo else 0)
+    total = 0
+    for p, (i, j) in enumerate(pairs):                                  # every pair's block, on every rank, = the oracle's
+        wi, wd = O.knn2(des[i].numpy(), des[j].numpy())
+        ok = ok and np.array_equal(store[p, 0, :nq[p]].numpy(), wi) and np.array_equal(store[p, 1, :nq[p]].numpy().view(np.float32), wd)
+        q, t = sharded.ratio_survivors(store[p], nq[p])
+        wq, wt, _ = O.ratio_filter(wi, wd, 0.70)
+        ok = ok and np.array_equal(q.numpy(), wq) and np.array_equal(t.numpy(), wt)
+        total += len(q)
+    # second exchange: triangulated points of the survivors (cameras replicated)
+    K, P = load_pose_csv()
+
+    def tri(P1, P2, x1, x2):
+        return torch.from_numpy(O.triangulate(P1, P2, x1.numpy(), x2.numpy(), normalise_w=True))
+
+    pts, counts = sharded.triangulate_pairs_sharded(store, nq, pairs, held_kp, list(P[:n_images]), triangulate=tri, batch=batch)
+    for p, (i, j) in enumerate(pairs):
+        q, t = sharded.ratio_survivors(store[p], nq[p])
+        m = int(counts[p])
+        ok = ok and m == len(q)
+        if m:
+            want = O.triangulate(P[i], P[j], kps[i][q].numpy().T.copy(), kps[j][t].numpy().T.copy(), normalise_w=True)
+            ok = ok and np.array_equal(pts[p, :, :m].numpy(), want) and float(pts[p, :, m:].abs().sum()) == 0.0
+    ret[rank] = (bool(ok), hi - lo, total)
     dist.destroy_process_group()
 
 
-def test_two_rank_pair_sharding_gathers_every_pair_on_every_rank():
+@pytest.mark.parametrize("n_images,batch,port", [(6, 8, 29517), (12, 2, 29518), (8, 3, 29519), (2, 4, 29520)])
+def test_two_rank_pair_sharding(n_images, batch, port):
+    """(6, 8): one partial batch; (12, 2): 11 pairs -> 6 + 5 (uneven), several rounds; (8, 3): partial last round;
+    (2, 4): one pair — rank 1 owns nothing and still takes part in every collective."""
     world = 2
-    mgr = mp.Manager()
-    ret = mgr.dict()
-    mp.spawn(_worker, args=(world, 29517, ret), nprocs=world, join=True)
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, port, n_images, batch, ret), nprocs=world, join=True)
     assert ret[0][0] and ret[1][0]
-    assert ret[0][1] + ret[1][1] == 5 and abs(ret[0][1] - ret[1][1]) <= 1
-    assert ret[0][2] == ret[1][2] > 100
+    assert ret[0][1] + ret[1][1] == n_images - 1 and abs(ret[0][1] - ret[1][1]) <= 1
+    assert ret[0][2] == ret[1][2] > 20
 
 
-def test_shard_range_partitions():
-    from sfm_mvs_amd.sharded import all_pairs, shard_range
+def _exchange_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sfm_mvs_amd import sharded
+    ex = sharded.BatchedExchange((3, 2), torch.int32, torch.device("cpu"), batch=4)
+    seen, steps = [], 10                       # bench.py's protocol: a slot per step, flush when full, final partial flush
+    for s in range(steps):
+        slot, ev = ex.next_slot()
+        slot.fill_(1000 * rank + s)
+        if ex.commit():
+            g, filled = ex.flush()
+            seen.append((g.clone(), filled))
+    g, filled = ex.flush()
+    seen.append((g.clone(), filled))
+    ok = ex.collectives == 3 and [f for _, f in seen] == [4, 4, 2]
+    for b, (g, f) in enumerate(seen):
+        for r in range(world):
+            for k in range(f):
+                ok = ok and bool((g[r, k] == 1000 * r + 4 * b + k).all())
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_batched_exchange_protocol():
+    ret = mp.Manager().dict()
+    mp.spawn(_exchange_worker, args=(2, 29521, ret), nprocs=2, join=True)
+    assert ret[0] and ret[1]
+
+
+def test_shard_range_and_halo_partitions():
+    from sfm_mvs_amd.sharded import all_pairs, halo_images, sequential_pairs, shard_range
     for n in (0, 1, 5, 255, 256):
         for w in (1, 2, 4, 8):
             spans = [shard_range(n, w, r) for r in range(w)]
             assert spans[0][0] == 0 and spans[-1][1] == n and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
     assert len(all_pairs(10)) == 45
+    pairs = sequential_pairs(256)               # config 5: 255 pairs over 8 ranks -> 31 or 32 pairs, + 1 halo image each
+    for r in range(8):
+        lo, hi = shard_range(255, 8, r)
+        assert halo_images(pairs, 8, r) == list(range(lo, hi + 1))
+    assert sum(len(halo_images(pairs, 8, r)) for r in range(8)) == 256 + 7
