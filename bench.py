@@ -125,6 +125,19 @@ def cpu_knn_baseline(nq, nt, seed_q, seed_t):
         out["torch_topk_first_neighbour_agreement"] = float((idx[:, 0].numpy() == wi[:, 0]).mean())
     except Exception as e:                                    # a sanity point only
         out["torch_cdist_topk_error"] = str(e)
+    try:                                                      # SURVEY 8d baseline item 1: the reference's own operator, if the box has it
+        import cv2
+        cv2.setNumThreads(cores)
+        r3 = min(nq, max(probe, 2000))
+        t0 = time.perf_counter()
+        m = cv2.BFMatcher().knnMatch(q[:r3], t, k=2)
+        dt3 = time.perf_counter() - t0
+        out["opencv"] = {"value": r3 * nt / dt3, "unit": "distances/s", "kind": "reference", "version": cv2.__version__,
+                         "threads": cv2.getNumThreads(), "sample": f"cv2.BFMatcher().knnMatch on the first {r3} query rows, {dt3:.1f} s "
+                                                                   "(includes building the DMatch lists, as sfm.py:260 pays for them)",
+                         "first_neighbour_agreement_with_oracle": float(np.mean([a[0].trainIdx for a in m] == O.knn2(q[:r3], t, nthreads=cores)[0][:, 0]))}
+    except ImportError:
+        out["opencv"] = None                                  # cv2 is not installed on this box: the oracle (kind "port") is the baseline
     try:
         model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")]
         out["cpu_model"] = model[0] if model else None
@@ -175,6 +188,9 @@ def bench_knn(args, world, rank, dev):
         if ex.commit():
             ex.flush(pipe.streams)
 
+    for pmx in pipe.matchers:                                # set-up, not a step: every stream's matcher loads its kernels once
+        pmx.run(q, t)
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     flush()

@@ -7,7 +7,8 @@ makes sfm.py's helper functions (Triangulation sfm.py:45, PnP :60, ReprojectionE
 part of find_features :259-268, findEssentialMat/recoverPose :307-311) run on the MI355X unchanged.
 NumPy in, NumPy out; every call uploads, launches the kernels of libsfmhip.so and downloads.
 Also provided: `SIFT_create` / `xfeatures2d.SIFT_create` (`detectAndCompute`), `cvtColor(BGR2GRAY)`,
-`pyrDown`, `KeyPoint`.  Not provided (out of scope): imread, GUI.
+`pyrDown`, `KeyPoint`, and `imread` (host-side decode through PIL: file I/O, not a kernel).  Not provided (out of scope,
+DESIGN.md §7): GUI.
 """
 import numpy as np
 import torch
@@ -150,6 +151,21 @@ class KeyPoint:
 
     def __repr__(self):
         return f"KeyPoint(pt={self.pt}, size={self.size}, angle={self.angle})"
+
+
+def imread(filename, flags=1):
+    """cv2.imread(path) (sfm.py:301-302,343): decoded on the HOST with PIL into cv2's layout — (H, W, 3) uint8 in B, G, R
+    order (flags=1, the default) or (H, W) grey (flags=0) — and None when the file cannot be read, as cv2 does.  File
+    decoding is I/O in front of the path, not a kernel; libjpeg builds may differ from OpenCV's in the last
+    bit of a pixel."""
+    try:
+        from PIL import Image
+        with Image.open(filename) as im:
+            if flags == 0:
+                return np.ascontiguousarray(np.asarray(im.convert("L"), np.uint8))
+            return np.ascontiguousarray(np.asarray(im.convert("RGB"), np.uint8)[:, :, ::-1])
+    except (OSError, ValueError):
+        return None
 
 
 def cvtColor(src, code):

@@ -1,0 +1,82 @@
+"""True reference parity, IF the box has OpenCV: every cv2-backed operator of the hot path compared with cv2 itself
+(SURVEY 8c last fixture row).  cv2 is not installable in the build container (no network), so this module is skipped there;
+on a box that has it, the oracle — "parity unpinned" everywhere else — gets pinned by the reference's own arithmetic.
+The KNN / ratio / mask comparisons are bit-exact; floating-point operators are scored in float ulps / relative error and
+the observed worst case is printed (`pytest -s`) rather than assumed."""
+import numpy as np
+import pytest
+
+cv2 = pytest.importorskip("cv2", reason="OpenCV is not installed here: oracle parity stays unpinned (DESIGN.md 2)")
+
+from datagen import decompose_P, gustav_pair, planted_pair, scene_image  # noqa: E402
+
+
+def ulps32(a, b):
+    """Distance in float32 ulps between two float32 arrays (same sign assumed near equality)."""
+    ai = np.ascontiguousarray(a, np.float32).view(np.int32).astype(np.int64)
+    bi = np.ascontiguousarray(b, np.float32).view(np.int32).astype(np.int64)
+    return np.abs(ai - bi)
+
+
+def test_oracle_knn_and_ratio_equal_cv2(oracle):
+    rng = np.random.default_rng(0)
+    for q, t in (planted_pair(rng, 700, 900, 0.3)[:2], (rng.random((300, 128), np.float32), rng.random((500, 128), np.float32))):
+        m = cv2.BFMatcher().knnMatch(q, t, k=2)
+        wi, wd = oracle.knn2(q, t)
+        assert [[x.trainIdx for x in r] for r in m] == wi.tolist()
+        assert ulps32(np.float32([[x.distance for x in r] for r in m]), wd).max() <= 1     # SIMD accumulation order may differ
+        good = [a.queryIdx for a, b in m if a.distance < 0.70 * b.distance]
+        assert good == oracle.ratio_filter(wi, np.float32([[x.distance for x in r] for r in m]), 0.70)[0].tolist()
+
+
+def test_oracle_triangulation_projection_rodrigues_vs_cv2(oracle):
+    K, P1, P2, X, x1, x2 = gustav_pair(1, 2000, 0.3, seed=2)
+    want = cv2.triangulatePoints(P1, P2, x1.T, x2.T)
+    got = oracle.triangulate(P1, P2, np.ascontiguousarray(x1.T), np.ascontiguousarray(x2.T))
+    sign = np.sign((want * got).sum(0))                                                 # a singular vector's sign is free
+    rel = np.abs(got * sign - want).max(0) / np.abs(want).max(0)
+    print("triangulatePoints (%s): max rel diff %.3g, bit-identical %.4f" % (cv2.__version__, rel.max(), (got * sign == want).all(0).mean()))
+    assert rel.max() < 1e-5
+    R, t = decompose_P(K, P2)
+    r_cv, _ = cv2.Rodrigues(R)
+    assert np.abs(r_cv.ravel() - oracle.rodrigues_mat2vec(R)).max() < 1e-12
+    assert np.abs(cv2.Rodrigues(r_cv)[0] - oracle.rodrigues_vec2mat(r_cv.ravel())).max() < 1e-14
+    p_cv, _ = cv2.projectPoints(X.astype(np.float32), r_cv, t, K, None)
+    _, p32 = oracle.project_points(r_cv.ravel(), t, K, X.astype(np.float32))
+    assert ulps32(p_cv.reshape(-1, 2), p32).max() <= 1
+    assert cv2.norm(p_cv.reshape(-1, 2), x2, cv2.NORM_L2) == pytest.approx(np.sqrt(np.sum(np.float64(p_cv.reshape(-1, 2) - x2) ** 2)), rel=1e-12)
+
+
+def test_oracle_ransac_entry_points_vs_cv2(oracle):
+    """Masks of the minimal-solver RANSACs depend on OpenCV's exact solver numerics (root order, null-space basis): the
+    comparison reports agreement instead of asserting identity, and asserts what must hold for any faithful build."""
+    K, P1, P2, X, x1, x2 = gustav_pair(0, 900, 0.3, seed=11)
+    rng = np.random.default_rng(5)
+    bad = rng.permutation(900)[:200]
+    x2 = x2.copy()
+    x2[bad] += rng.uniform(10, 150, (200, 2)).astype(np.float32)
+    E_cv, m_cv = cv2.findEssentialMat(x1, x2, K, method=cv2.RANSAC, prob=0.999, threshold=0.4)
+    E_o, m_o = oracle.find_essential_mat(x1, x2, K, 0.999, 0.4)
+    agree = (m_cv.ravel() == m_o.ravel()).mean()
+    print("findEssentialMat (%s): mask agreement %.4f, identical E: %s" % (cv2.__version__, agree, np.array_equal(E_cv[:3], E_o)))
+    assert agree > 0.9 and m_cv[bad].sum() <= 3 and m_o[bad].sum() <= 3
+    ok, r_cv, t_cv, i_cv = cv2.solvePnPRansac(X.astype(np.float32), x2, K, np.zeros((5, 1), np.float32), cv2.SOLVEPNP_ITERATIVE)
+    ok_o, r_o, t_o, i_o = oracle.solve_pnp_ransac(X.astype(np.float32), x2, K)
+    same = np.array_equal(i_cv, i_o)
+    print("solvePnPRansac: identical inlier list: %s (%d vs %d), |dr| %.3g |dt| %.3g" %
+          (same, len(i_cv), len(i_o), np.abs(r_cv - r_o).max(), np.abs(t_cv - t_o).max()))
+    assert ok and ok_o and np.abs(r_cv - r_o).max() < 1e-3 and np.abs(t_cv - t_o).max() < 1e-2
+
+
+def test_oracle_sift_vs_cv2(oracle):
+    sift = cv2.SIFT_create() if hasattr(cv2, "SIFT_create") else cv2.xfeatures2d.SIFT_create()
+    g = scene_image(320, 240, 21)
+    kp_cv, des_cv = sift.detectAndCompute(g, None)
+    kp_o, des_o = oracle.sift(g)
+    print("SIFT (%s): %d vs %d keypoints" % (cv2.__version__, len(kp_cv), len(kp_o)))
+    assert abs(len(kp_cv) - len(kp_o)) <= 0.02 * len(kp_cv) + 5
+    pts_cv = np.float32([k.pt for k in kp_cv])
+    d = np.abs(pts_cv[:, None, :] - kp_o[None, :, :2]).max(2).min(1)
+    assert (d < 0.05).mean() > 0.97                                                     # the same keypoints to 1/20 pixel
+    assert np.array_equal(cv2.cvtColor(np.repeat(g[:, :, None], 3, 2), cv2.COLOR_BGR2GRAY), oracle.bgr2gray(np.repeat(g[:, :, None], 3, 2)))
+    assert np.array_equal(cv2.pyrDown(g), oracle.pyrdown(g))
