@@ -322,6 +322,11 @@ int sfm_solve_pnp_ransac(const float* X_dev, const float* uv_dev, int64_t n, con
                          float reproj_error, double confidence, double* rvec_host, double* tvec_host,
                          int32_t* info_host, int32_t* inliers_dev, void* ws_dev, size_t ws_bytes, void* stream);
 
+/* cv2.projectPoints(X, rvec, tvec, K, None) on float64 object points (sfm.py:119-121: the residual of the
+ * reference's BundleAdjustment is fp64 end to end).  rvec, tvec, K on the host; X_dev [n x 3], proj_dev [n x 2] f64. */
+int sfm_project_points_f64(const double* rvec_host, const double* tvec_host, const double* K_host,
+                           const double* X_dev, int64_t n, double* proj_dev, void* stream);
+
 /* ------------------------------------------------------------------------
  * The host-side hypothesis generators behind the three calls above, reachable on their own
  * (pure host code, HOST pointers, no GPU needed): unit-tested against the oracle.

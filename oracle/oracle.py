@@ -126,6 +126,13 @@ def project_points(rvec, tvec, K, X):
     return p64, p32
 
 
+def project_points_f64(rvec, tvec, K, X):
+    X = _f64(X).reshape(-1, 3)
+    out = np.empty((len(X), 2))
+    lib().orc_project_points_f64(_p(_f64(rvec).reshape(3)), _p(_f64(tvec).reshape(3)), _p(_f64(K).reshape(9)), _p(X), C.c_int64(len(X)), _p(out))
+    return out
+
+
 def reprojection_error(Rt, K, X, obs):
     """X (N,3) float32, obs (N,2) float32 → (error, projected float32 (N,2))."""
     X = _f32(X).reshape(-1, 3)

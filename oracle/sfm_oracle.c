@@ -447,6 +447,13 @@ void orc_project_points(const double* rvec, const double* tvec, const double* K,
     }
 }
 
+/* the same on float64 object points (the reference's BA residual, sfm.py:119-121, is fp64 end to end) */
+void orc_project_points_f64(const double* rvec, const double* tvec, const double* K, const double* X, int64_t n, double* proj64) {
+    cam_t c;
+    cam_init(&c, rvec, tvec, K, NULL);
+    for (int64_t i = 0; i < n; ++i) cam_project(&c, X[3 * i], X[3 * i + 1], X[3 * i + 2], &proj64[2 * i], &proj64[2 * i + 1], NULL);
+}
+
 /* ------------------------------------------------------------------------------------------
  * A5  ReprojectionError                                                        sfm.py:79-100
  * r = Rodrigues(R); p = float32(projectPoints(X, r, t, K)); err = cv2.norm(p, pts, NORM_L2)/len(p)

@@ -55,6 +55,7 @@ SIGNATURES = {
     "sfm_host_decompose_essential": (_int, [_vp, _vp, _vp, _vp]),
     "sfm_host_pnp_dlt_init": (_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "sfm_host_rodrigues": (_int, [_vp, _int, _vp, _vp]),
+    "sfm_project_points_f64": (_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "sfm_find_essential_mat_ws_bytes": (_sz, [_i64]),
     "sfm_find_essential_mat": (_int, [_vp, _vp, _i64, _vp, _f64, _f64, _int, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sfm_recover_pose_ws_bytes": (_sz, [_i64]),

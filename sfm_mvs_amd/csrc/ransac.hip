@@ -121,6 +121,20 @@ __global__ void pnp_sweep_fold_kernel(const double* __restrict__ partials, int b
     out[k] = s;
 }
 
+// cv2.projectPoints on float64 object points (the reference's bundle-adjustment residual, sfm.py:119-121, is fp64 end to
+// end: SciPy's finite-difference steps of ~1.5e-8 relative vanish in a float32 round trip)
+__global__ __launch_bounds__(256) void project_f64_kernel(PnpCam cam, const double* __restrict__ X, int64_t n, double* __restrict__ out) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double Xw = X[3 * i], Yw = X[3 * i + 1], Zw = X[3 * i + 2];
+    double x = cam.R[0] * Xw + cam.R[1] * Yw + cam.R[2] * Zw + cam.t[0];
+    double y = cam.R[3] * Xw + cam.R[4] * Yw + cam.R[5] * Zw + cam.t[1];
+    double z = cam.R[6] * Xw + cam.R[7] * Yw + cam.R[8] * Zw + cam.t[2];
+    z = z != 0.0 ? 1. / z : 1.;
+    out[2 * i] = (x * z) * cam.fx + cam.cx;
+    out[2 * i + 1] = (y * z) * cam.fy + cam.cy;
+}
+
 // cv::Rodrigues vector -> matrix with dR/dr (3 x 9), host side of the sweep
 void rodrigues_with_jac(const double* rv, double* R, double* J) {
     const double theta = std::sqrt(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
@@ -585,6 +599,20 @@ extern "C" int sfm_host_pnp_dlt_init(const double* K, const double* X, const dou
                                      int32_t* status_out) {
     SFM_CHECK_ARG(K && X && uv && rvec && tvec && status_out && n >= 1, "sfm_host_pnp_dlt_init: bad argument");
     *status_out = hs::pnp_dlt_init<double>(X, uv, nullptr, n, K, rvec, tvec);
+    return SFM_OK;
+}
+
+extern "C" int sfm_project_points_f64(const double* rvec, const double* tvec, const double* K, const double* X_dev, int64_t n,
+                                      double* proj_dev, void* stream_) {
+    SFM_CHECK_ARG(rvec && tvec && K && n >= 0, "sfm_project_points_f64: bad argument");
+    if (n == 0) return SFM_OK;
+    SFM_CHECK_ARG(X_dev && proj_dev, "sfm_project_points_f64: null pointer");
+    PnpCam cam;
+    rodrigues_with_jac(rvec, cam.R, cam.dR);
+    cam.t[0] = tvec[0]; cam.t[1] = tvec[1]; cam.t[2] = tvec[2];
+    cam.fx = K[0]; cam.fy = K[4]; cam.cx = K[2]; cam.cy = K[5];
+    hipLaunchKernelGGL(project_f64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sfm::as_stream(stream_), cam, X_dev, n, proj_dev);
+    SFM_CHECK_LAUNCH();
     return SFM_OK;
 }
 

@@ -15,8 +15,11 @@ _ws_cache = {}
 
 
 def _workspace(device, nbytes):
-    """Grow-only per-device scratch buffer (the C-ABI never allocates)."""
-    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    """Grow-only scratch buffer per (device, current stream) — the C-ABI never allocates.  Work enqueued on different
+    streams therefore never shares scratch; within a stream, calls are ordered.  (A buffer that has to grow is replaced:
+    the caching allocator keeps the old block alive for the kernels already enqueued on its stream.)"""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (device.type, idx, torch.cuda.current_stream(idx).cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
@@ -267,6 +270,21 @@ def block_matvec(A, x, k):
     with on_device(a.device):
         check(_lib.lib().sfm_block_matvec(ptr(a), ptr(xv), n, int(k), ptr(y), stream_ptr()), "sfm_block_matvec")
     return y
+
+
+def project_points_f64(rvec, tvec, K, X):
+    """cv2.projectPoints on float64 object points [n,3] (CUDA) -> [n,2] float64 (sfm_project_points_f64)."""
+    require_cuda(X)
+    if X.dtype != torch.float64:
+        raise SfmHipError("project_points_f64: float64 object points")
+    Xc = X.contiguous().reshape(-1, 3)
+    out = torch.empty((Xc.shape[0], 2), dtype=torch.float64, device=X.device)
+    r, t, k = _f64_host(rvec, 3, "rvec"), _f64_host(tvec, 3, "tvec"), _f64_host(K, 9, "K")
+    vp = ctypes.c_void_p
+    with on_device(X.device):
+        check(_lib.lib().sfm_project_points_f64(r.ctypes.data_as(vp), t.ctypes.data_as(vp), k.ctypes.data_as(vp), ptr(Xc), Xc.shape[0],
+                                                ptr(out), stream_ptr()), "sfm_project_points_f64")
+    return out
 
 
 def norm_l2(a, b=None):

@@ -200,9 +200,15 @@ def OptimReprojectionError(x, be=None):
     p = x[21:21 + rest].reshape((2, int(rest / 2))).T
     X = x[21 + rest:].reshape((int(len(x[21 + rest:]) / 3), 3))
     r, _ = cv2.Rodrigues(Rt[:3, :3])
-    _, p2d = b.reproj(r, Rt[:3, 3], K, np.ascontiguousarray(X, np.float32), np.ascontiguousarray(p, np.float32))
+    # fp64 end to end, like the reference's cv2.projectPoints on float64 points: SciPy's 2-point finite differences
+    # (relative step ~1.5e-8) would vanish in a float32 round trip of X or of the projection
+    if b.reproj is _reproj_hip:
+        p2d = ops.project_points_f64(r, Rt[:3, 3], K, torch.as_tensor(np.ascontiguousarray(X, np.float64)).to("cuda")).cpu().numpy()
+    else:
+        p2d, _ = cv2.projectPoints(np.ascontiguousarray(X, np.float64), r, Rt[:3, 3], K, distCoeffs=None)
+        p2d = np.asarray(p2d, np.float64).reshape(-1, 2)
     num_pts = len(p)
-    return (((p - p2d.astype(np.float64)) ** 2).ravel()) / num_pts
+    return (((p - p2d) ** 2).ravel()) / num_pts
 
 
 def BundleAdjustment(points_3d, temp2, Rtnew, K, r_error, be=None):

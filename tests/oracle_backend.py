@@ -28,8 +28,10 @@ class OracleCv2:
 
     def projectPoints(self, objectPoints, rvec, tvec, cameraMatrix, distCoeffs=None):
         X = np.asarray(objectPoints)
-        p64, p32 = self.O.project_points(np.ravel(rvec), np.ravel(tvec), cameraMatrix, np.float32(X).reshape(-1, 3))
-        return (p32 if X.dtype == np.float32 else p64).reshape(-1, 1, 2), None
+        if X.dtype == np.float64:                      # cv2 computes in the object points' type
+            return self.O.project_points_f64(np.ravel(rvec), np.ravel(tvec), cameraMatrix, X.reshape(-1, 3)).reshape(-1, 1, 2), None
+        _, p32 = self.O.project_points(np.ravel(rvec), np.ravel(tvec), cameraMatrix, np.float32(X).reshape(-1, 3))
+        return p32.reshape(-1, 1, 2), None
 
     def norm(self, a, b=None, normType=4):
         d = np.asarray(a) if b is None else np.asarray(a) - np.asarray(b)      # difference in the inputs' dtype
