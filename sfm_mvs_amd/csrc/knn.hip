@@ -1211,10 +1211,12 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
     // sweeps instead of being held in registers: the kernel needs <= 168 VGPRs for a single resident round.)
     float m1 = kInf, m2 = kInf, tau = kInf;
     float s1v[kS1];
-#pragma unroll
+    int i1v[kS1];                                        // the records' row ids ride along: sweep 2 takes its first 16 * kS1
+#pragma unroll                                           // records from these registers instead of a second, dependent round trip
     for (int k = 0; k < kS1; ++k) {
         const int c = sl + 16 * k;
         s1v[k] = (valid && c < NC) ? cs[c] : kInf;
+        i1v[k] = (valid && c < NC) ? ci[c] : -1;
     }
     __syncthreads();                                     // query rows in LDS
     if (trace && threadIdx.x == 0) trace[16 * bid + 1] = wall_clock64();
@@ -1338,22 +1340,32 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
         __builtin_amdgcn_wave_barrier();
         cnt = kept;
     };
-    for (int k0 = 0; k0 * 16 < NC;) {                     // (wave-uniform)
+    // one chunk of 16 records per query: the ones within `thr` are appended (all kRecRows rows each) to the query's list
+    auto push = [&](bool take, int id) {
+        const unsigned long long mask = __ballot(take);
+        if (mask == 0) return;                            // wave-uniform
+        const unsigned mine = (unsigned)(mask >> (16 * sub)) & 0xFFFFu;
+        if (take) {                                       // a record names kRecRows adjacent rows: all are evaluated
+            const int at = cnt + kRecRows * __popc(mine & ((1u << sl) - 1u));
+#pragma unroll
+            for (int i = 0; i < kRecRows; ++i) qual[ql][at + i] = id + i < nt ? id + i : id;
+        }
+        cnt += kRecRows * __popc(mine);
+    };
+    int k0 = 0;
+#pragma unroll
+    for (int k = 0; k < kS1; ++k)                         // chunks still in registers from sweep 1 (wave-uniform conditions)
+        if (k0 == k && k * 16 < NC && !__any(cnt > kQualCap - 16 * kRecRows)) {
+            push(i1v[k] >= 0 && s1v[k] <= thr, i1v[k]);
+            k0 = k + 1;
+        }
+    for (bool first = true; first || k0 * 16 < NC; first = false) {   // (wave-uniform) the rest — and everything after a full list — is re-read
         for (; k0 * 16 < NC; ++k0) {
             if (__any(cnt > kQualCap - 16 * kRecRows)) break;   // the list might not take another chunk: evaluate first
             const int c = sl + 16 * k0;
-            const float s = (valid && c < NC) ? cs[c] : kInf;
+            const float sc = (valid && c < NC) ? cs[c] : kInf;
             const int id = (valid && c < NC) ? ci[c] : -1;                // (empty records: s = +inf, id = -1)
-            const bool take = id >= 0 && s <= thr;
-            const unsigned long long mask = __ballot(take);
-            if (mask == 0) continue;                      // wave-uniform
-            const unsigned mine = (unsigned)(mask >> (16 * sub)) & 0xFFFFu;
-            if (take) {                                   // a record names kRecRows adjacent rows: all are evaluated
-                const int at = cnt + kRecRows * __popc(mine & ((1u << sl) - 1u));
-#pragma unroll
-                for (int i = 0; i < kRecRows; ++i) qual[ql][at + i] = id + i < nt ? id + i : id;
-            }
-            cnt += kRecRows * __popc(mine);
+            push(id >= 0 && sc <= thr, id);
         }
         if (use_half) prefilter();                        // (wave-uniform)
         evaluate();                                       // the hot site
