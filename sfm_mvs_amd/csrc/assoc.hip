@@ -6,36 +6,41 @@
 // float compares per frame: one lane per row of pts1 scanning pts2 through LDS tiles (coalesced, early exit per
 // wave), then an ordered ballot compaction.  Integer outputs, bit-exact by construction.
 #include "common.h"
+#include <climits>
 
 namespace {
 
 constexpr int kTile = 1024;   // rows of pts2 staged per iteration (8 KiB)
 
+// 64 rows of pts1 per workgroup, FOUR lanes per row: lane l of a row's quad scans entries l, l+4, ... of the staged
+// pts2 tile branch-free (running minimum of the matching indices), the quad folds its minima after every tile and the
+// workgroup stops at the first tile boundary where every row has its answer.  (One lane per row with an early `break`
+// ran the whole wave at the pace of its slowest lane, one dependent LDS read per entry: 0.35 ms per frame.)
 __global__ __launch_bounds__(256) void first_match_kernel(const float2* __restrict__ p1, int n1, const float2* __restrict__ p2,
                                                           int n2, int* __restrict__ first, unsigned char* __restrict__ keep2) {
     __shared__ float2 tile[kTile];
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int l = threadIdx.x & 3;
+    const int i = blockIdx.x * 64 + (threadIdx.x >> 2);
     const float2 a = i < n1 ? p1[i] : make_float2(0.f, 0.f);
-    int found = i < n1 ? -1 : 0;          // lanes past n1 are "done"
+    int found = INT_MAX;
     for (int base = 0; base < n2; base += kTile) {
         __syncthreads();
         for (int k = threadIdx.x; k < kTile && base + k < n2; k += 256) tile[k] = p2[base + k];
         __syncthreads();
-        if (__syncthreads_and(found >= 0)) break;
-        if (found < 0) {
-            const int m = min(kTile, n2 - base);
-            for (int k = 0; k < m; ++k) {
-                const float2 b = tile[k];
-                if (b.x == a.x || b.y == a.y) {     // x OR y, exact float equality (NaN never matches, like NumPy)
-                    found = base + k;
-                    break;
-                }
-            }
+        const int m = min(kTile, n2 - base);
+#pragma unroll 4
+        for (int k = l; k < m; k += 4) {
+            const float2 b = tile[k];
+            const bool hit = b.x == a.x || b.y == a.y;      // x OR y, exact float equality (NaN never matches, like NumPy)
+            found = min(found, hit ? base + k : INT_MAX);
         }
+        found = min(found, __shfl_xor(found, 1, 64));
+        found = min(found, __shfl_xor(found, 2, 64));
+        if (__syncthreads_and(found != INT_MAX || i >= n1)) break;
     }
-    if (i < n1) {
-        first[i] = found;
-        if (found >= 0) keep2[found] = 0;           // all writers store the same value
+    if (i < n1 && l == 0) {
+        first[i] = found == INT_MAX ? -1 : found;
+        if (found != INT_MAX) keep2[found] = 0;       // all writers store the same value
     }
 }
 
@@ -91,7 +96,7 @@ extern "C" int sfm_common_points(const float* pts1, int64_t n1, const float* pts
         SFM_CHECK_HIP(hipMemsetAsync(count, 0, sizeof(int32_t), stream));
         return SFM_OK;
     }
-    hipLaunchKernelGGL(first_match_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, stream,
+    hipLaunchKernelGGL(first_match_kernel, dim3((unsigned)((n1 + 63) / 64)), dim3(256), 0, stream,
                        reinterpret_cast<const float2*>(pts1), (int)n1, reinterpret_cast<const float2*>(pts2), (int)n2, first_ws,
                        keep2);
     SFM_CHECK_LAUNCH();

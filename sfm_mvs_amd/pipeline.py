@@ -268,11 +268,21 @@ def to_ply(path, point_cloud, colors, densify=False):
     return len(verts)
 
 
-def run_sfm(features, K, images=None, log=None, be=None):
+def run_sfm(features, K, images=None, log=None, be=None, device_resident=None):
     """The reference's driver, sfm.py:274-423 (bundle_adjustment=False, its default).
     features: list of (kp (n,2) float32, des (n,128) float32) per image, in sequence order.
     images:   optional list of HxWx3 uint8 arrays for the colour lookup (sfm.py:393-394).
-    Returns dict(posearr (9+12*n_cam,), Xtot (m,3), colorstot (m,3), errors [per-frame], first_error)."""
+    Returns dict(posearr (9+12*n_cam,), Xtot (m,3), colorstot (m,3), errors [per-frame], first_error).
+    On the HIP back-end (be=None) the driver keeps every per-frame array in HBM between the operators
+    (`_run_sfm_device`: same kernels, same results bit for bit, a handful of host synchronisations per frame instead of
+    an upload and a download around every operator); device_resident=False forces the array-in / array-out form below,
+    which is also what a substituted backend (the tests' CPU twin) runs."""
+    if device_resident is None:
+        device_resident = be is None
+    if device_resident:
+        if be is not None:
+            raise ops.SfmHipError("run_sfm: device_resident needs the HIP back-end")
+        return _run_sfm_device(features, K, images, log)
     K = np.asarray(K, np.float64)
     be = _be(be)
     cv2 = be.cv
@@ -339,6 +349,113 @@ def run_sfm(features, K, images=None, log=None, be=None):
         pts1 = np.copy(pts2)
         P2 = np.copy(Pnew)
     return dict(posearr=posearr, Xtot=Xtot, colorstot=colorstot, errors=errors, first_error=first_error)
+
+
+def _run_sfm_device(features, K, images=None, log=None):
+    """run_sfm with the per-frame state resident in HBM: matched points, clouds, association indices, masks and inlier
+    lists are device tensors handed from kernel to kernel; what crosses to the host per frame is one survivor count, one
+    association count, the few scalars solvePnPRansac returns, and (at the very end) the clouds, the points of the colour
+    lookup and the per-frame squared error sums.  The arithmetic is that of the array form, call for call."""
+    from . import hostgeom as hg
+    from . import ransac
+    dev = torch.device("cuda")
+    K = np.asarray(K, np.float64)
+    say = log or (lambda *a: None)
+    cache = {}
+
+    def feat(i):          # every image's features are uploaded once (the array form uploads them for both of its pairs)
+        if i not in cache:
+            kp, des = features[i]
+            up = lambda a: a.to(dev, torch.float32).contiguous() if torch.is_tensor(a) else torch.as_tensor(np.ascontiguousarray(a, np.float32)).to(dev)
+            cache[i] = (up(kp), up(des))
+            cache.pop(i - 2, None)
+        return cache[i]
+
+    def match(i, j):      # find_features' matcher half (sfm.py:259-268)
+        (kp0, d0), (kp1, d1) = feat(i), feat(j)
+        idx, dist = ops.knn2(d0, d1)
+        out_q, out_t, count = ops.ratio_compact(idx, dist, RATIO)
+        p0, p1 = ops.gather_matches(kp0, kp1, out_q, out_t, count)
+        m = int(count.item())
+        return p0[:m], p1[:m]
+
+    def triangulate(Pa, Pb, a, b):      # Triangulation (sfm.py:45-56) on (M,2) device points -> (4,M), w == 1
+        return ops.triangulate(Pa, Pb, a.t(), b.t(), rows=cv2.TRIANGULATE_ROWS, normalise_w=True)
+
+    def reproj_sumsq(X4, obs, Rt):      # ReprojectionError (sfm.py:79-100): the squared error sum stays on the device
+        r = hg.rodrigues_mat2vec(Rt[:3, :3])
+        cams = torch.as_tensor(np.hstack([r, Rt[:3, 3]])[None]).to(dev)
+        Xf = X4[:3].t().contiguous()
+        return ops.project_residual(cams, K, Xf, obs.contiguous(), want_proj=False)["sumsq"], Xf
+
+    def pnp(X, p, p_0):                 # PnP (sfm.py:60-76)
+        ok, rvec, t, inl = ransac.solve_pnp_ransac(X, p, K, return_device_inliers=True)
+        R = hg.rodrigues_vec2mat(rvec)
+        if inl is not None:
+            sel = inl[:, 0].long()
+            p, X, p_0 = p[sel], X[sel], p_0[sel]
+        return R, t, p, X, p_0
+
+    posearr = K.ravel()
+    R_t_0 = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0]], np.float64)
+    R_t_1 = np.empty((3, 4))
+    P1 = np.matmul(K, R_t_0)
+    pts0, pts1 = match(0, 1)
+    E, mask = ransac.find_essential_mat(pts0, pts1, K, 0.999, 0.4, return_device_mask=True)
+    sel = torch.nonzero(mask.ravel() == 1).ravel()            # quirk 4: {0,1} mask
+    pts0, pts1 = pts0[sel], pts1[sel]
+    _, R, t, mask = ransac.recover_pose(E, pts0, pts1, K, return_device_mask=True)
+    sel = torch.nonzero(mask.ravel() > 0).ravel()             # quirk 4: {0,255} mask
+    pts0, pts1 = pts0[sel], pts1[sel]
+    R_t_1[:3, :3] = np.matmul(R, R_t_0[:3, :3])
+    R_t_1[:3, 3] = R_t_0[:3, 3] + np.matmul(R_t_0[:3, :3], t.ravel())
+    P2 = np.matmul(K, R_t_1)
+    X4 = triangulate(P1, P2, pts0, pts1)
+    ss, Xf = reproj_sumsq(X4, pts1, R_t_1)
+    first_error = float(np.sqrt(ss.item())) / len(pts1)
+    say("REPROJECTION ERROR: ", first_error)
+    Rot, trans, pts1, points_3d, _ = pnp(Xf, pts1, pts0)      # only its inlier filtering of pts1 / points_3d survives
+    posearr = np.hstack((posearr, P1.ravel(), P2.ravel()))
+
+    sums, counts, clouds, lookups = [], [], [], []
+    for i in range(len(features) - 2):
+        pts_, pts2 = match(i + 1, i + 2)
+        if i != 0:
+            points_3d = triangulate(P1, P2, pts0, pts1)[:3].t().contiguous()       # quirk 6: all ratio matches
+        indx1, indx2, keep = ops.common_points(pts1, pts_)
+        i1, i2 = indx1.long(), indx2.long()
+        rest = torch.nonzero(keep).ravel()
+        temp1, temp2 = pts_[rest], pts2[rest]
+        Rot, trans, com_pts2, points_3d, com_pts_ = pnp(points_3d[i1], pts2[i2], pts_[i2])
+        Rtnew = np.hstack((Rot, trans))
+        Pnew = np.matmul(K, Rtnew)
+        X4 = triangulate(P2, Pnew, temp1, temp2)
+        ss, Xf = reproj_sumsq(X4, temp2, Rtnew)
+        sums.append(ss)
+        counts.append(len(temp2))
+        if log is not None:
+            say("Reprojection Error: ", float(np.sqrt(ss.item())) / len(temp2))
+        posearr = np.hstack((posearr, Pnew.ravel()))
+        clouds.append(Xf)
+        lookups.append(temp2)
+        P1, P2 = np.copy(P2), np.copy(Pnew)
+        pts0, pts1 = pts_, pts2
+    # one download at the end: error sums, clouds, colour-lookup coordinates
+    if sums:
+        sv = torch.cat(sums).cpu().numpy()
+        errors = [float(np.sqrt(v)) / n for v, n in zip(sv, counts)]
+        Xtot = np.vstack([np.zeros((1, 3))] + [c.cpu().numpy() for c in clouds])      # quirk 8: leading zero row
+    else:
+        errors, Xtot = [], np.zeros((1, 3))
+    cols = [np.zeros((1, 3))]
+    for i, t2 in enumerate(lookups):
+        reg = np.array(t2.cpu().numpy().T, dtype=np.int32)                            # quirk 10: truncation toward zero
+        if images is not None:
+            img2 = images[i + 2]
+            cols.append(np.array([img2[l[1], l[0]] for l in reg.T]).reshape(-1, 3))
+        else:
+            cols.append(np.zeros((reg.shape[1], 3)))
+    return dict(posearr=posearr, Xtot=Xtot, colorstot=np.vstack(cols), errors=errors, first_error=first_error)
 
 
 def save_pose_csv(path, posearr):

@@ -292,3 +292,17 @@ def test_sharded_path_on_one_gpu(hip, oracle):
         want = oracle.triangulate(P[i], P[j], kps[i][wq].T.copy(), kps[j][wt].T.copy(), normalise_w=True)
         got = pts[p, :, :len(wq)].cpu().numpy()
         assert np.allclose(got, want, rtol=1e-6, atol=1e-7) and float(pts[p, :, len(wq):].abs().sum()) == 0.0
+
+
+def test_device_resident_driver_equals_the_array_form(hip):
+    """run_sfm's HBM-resident form (the default on the HIP back-end) against its array-in / array-out form: the same
+    kernels in the same order, so every output is identical — poses, cloud, per-frame errors, colours."""
+    from sfm_mvs_amd import pipeline as pl
+    K, P, feats, ids = gustav_scene(9, seed=7, pix_noise=0.2)
+    rng = np.random.default_rng(0)
+    images = [rng.integers(0, 256, (648, 968, 3), dtype=np.uint8) for _ in range(9)]
+    a = pl.run_sfm(feats, K, images=images, device_resident=True)
+    b = pl.run_sfm(feats, K, images=images, device_resident=False)
+    for k in ("posearr", "Xtot", "colorstot"):
+        assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), k
+    assert a["errors"] == b["errors"] and a["first_error"] == b["first_error"]
