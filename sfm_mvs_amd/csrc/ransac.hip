@@ -21,6 +21,8 @@
 #include "common.h"
 #include "host_solvers.h"
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
 #include <utility>
 #include <vector>
 
@@ -164,7 +166,8 @@ void rodrigues_with_jac(const double* rv, double* R, double* J) {
 // Chunk sizes of the batched RANSAC: small first (with a high inlier ratio `niters` collapses after the first good
 // model and hypotheses generated beyond it are wasted host work), doubling up to 64 iterations per launch.
 struct Chunker {
-    int chunk = 8;
+    int chunk;
+    explicit Chunker(int first = 8) : chunk(first) {}
     int next(int remaining) {
         const int m = std::min(chunk, remaining);
         chunk = std::min(2 * chunk, 64);
@@ -207,6 +210,47 @@ int replay_chunk(RansacState& st, int it0, const std::vector<int>& owner, const 
     }
     return best_j;
 }
+
+// dev: SFM_PNP_PROF=1 prints where sfm_solve_pnp_ransac's host time goes (accumulated, at process exit)
+struct PnpProf {
+    bool on = getenv("SFM_PNP_PROF") != nullptr;
+    double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long calls = 0, chunks = 0, sweeps = 0;
+    ~PnpProf() {
+        if (on && calls)
+            fprintf(stderr, "[pnp prof] calls %ld  per call us: copy-in %.1f  epnp %.1f  score+sync %.1f  mask/inliers %.1f  dlt %.1f  lm-sweeps %.1f  lm-host %.1f | chunks/call %.2f sweeps/call %.2f\n",
+                    calls, t[0] / calls, t[1] / calls, t[2] / calls, t[3] / calls, t[4] / calls, t[5] / calls, t[6] / calls, (double)chunks / calls, (double)sweeps / calls);
+    }
+};
+PnpProf g_pnp_prof;
+inline double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// Pinned, device-visible host memory for what the host-returning entry points move across the bus per call (sampled
+// correspondences in, counts / sums / masks out): copies to and from pageable memory go through the runtime's staging
+// path (~20 us each), pinned ones are plain DMA, and the sweeps store their 28 sums straight into it.  One buffer per
+// host thread, grown on demand, released at thread exit — the only memory this library allocates itself.
+struct HostMailbox {
+    void* p = nullptr;
+    size_t cap = 0;
+    void* get(size_t bytes) {
+        if (bytes > cap) {
+            if (p) (void)hipHostFree(p);
+            p = nullptr;
+            cap = 0;
+            const size_t want = sfm::align_up(bytes + (bytes >> 1), 4096);
+            if (hipHostMalloc(&p, want, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
+                p = nullptr;
+                return nullptr;
+            }
+            cap = want;
+        }
+        return p;
+    }
+    ~HostMailbox() {
+        if (p) (void)hipHostFree(p);
+    }
+};
+thread_local HostMailbox g_mailbox;
 
 size_t essential_ws(int64_t n) {
     const size_t hmax = 64 * 10;
@@ -401,16 +445,34 @@ extern "C" int sfm_solve_pnp_ransac(const float* X_dev, const float* uv_dev, int
     hipStream_t stream = sfm::as_stream(stream_);
     sfm::Carver c(reinterpret_cast<void*>(sfm::align_up((size_t)(uintptr_t)ws, 256)));
     const size_t hmax = 64;
-    double* poses_dev = c.take<double>(6 * hmax);
+    (void)c.take<double>(6 * hmax);                      // (models are read from the pinned mailbox)
     int32_t* counts_dev = c.take<int32_t>(hmax);
     uint8_t* masks_dev = c.take<uint8_t>(hmax * (size_t)n);
     uint8_t* best_dev = c.take<uint8_t>((size_t)n);
     double* sweep_dev = c.take<double>((size_t)kSweepAcc * (kSweepMaxBlocks + 1));
 
-    std::vector<float> hX(3 * (size_t)n), huv(2 * (size_t)n);
-    SFM_CHECK_HIP(hipMemcpyAsync(hX.data(), X_dev, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, stream));
-    SFM_CHECK_HIP(hipMemcpyAsync(huv.data(), uv_dev, sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost, stream));
+    double tp = now_us();
+    auto lap = [&](int k) { const double t1 = now_us(); g_pnp_prof.t[k] += t1 - tp; tp = t1; };
+    ++g_pnp_prof.calls;
+    // mailbox layout: X [3n] f32 | uv [2n] f32 | mask [n] u8 | poses [6 hmax] f64 | counts [hmax] i32 | sums [28] f64
+    const size_t o_uv = sizeof(float) * 3 * (size_t)n, o_mask = o_uv + sizeof(float) * 2 * (size_t)n;
+    const size_t o_pose = sfm::align_up(o_mask + (size_t)n, 64), o_cnt = o_pose + sizeof(double) * 6 * hmax;
+    const size_t o_sum = sfm::align_up(o_cnt + sizeof(int32_t) * hmax, 64);
+    char* mb = static_cast<char*>(g_mailbox.get(o_sum + sizeof(double) * kSweepAcc));
+    if (!mb) {
+        sfm::set_error("sfm_solve_pnp_ransac: hipHostMalloc failed");
+        return SFM_ERR_DEVICE;
+    }
+    float* hX = reinterpret_cast<float*>(mb);
+    float* huv = reinterpret_cast<float*>(mb + o_uv);
+    uint8_t* hmask = reinterpret_cast<uint8_t*>(mb + o_mask);
+    double* hposes = reinterpret_cast<double*>(mb + o_pose);
+    int32_t* hcounts = reinterpret_cast<int32_t*>(mb + o_cnt);
+    double* sums = reinterpret_cast<double*>(mb + o_sum);
+    SFM_CHECK_HIP(hipMemcpyAsync(hX, X_dev, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, stream));
+    SFM_CHECK_HIP(hipMemcpyAsync(huv, uv_dev, sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost, stream));
     SFM_CHECK_HIP(hipStreamSynchronize(stream));
+    lap(0);
     const double ifx = 1. / K[0], ify = 1. / K[4];
     // solvePnP(EPNP) on a sample: undistortPoints writes float32 normalised coordinates (the image points' type) and
     // epnp::init_points maps them back with u = x fu + uc
@@ -450,46 +512,43 @@ extern "C" int sfm_solve_pnp_ransac(const float* X_dev, const float* uv_dev, int
     st.model_points = 5;
     st.confidence = confidence;
     st.count = n;
-    Chunker ch;
-    std::vector<double> models;
+    Chunker ch(5);      // a clean scene needs log(0.01) / log(1 - 0.9^5) ~ 5 iterations: every EPnP solve beyond that is 18 us of host time
     std::vector<int> owner;
-    std::vector<int32_t> counts;
     double best_model[6] = {0, 0, 0, 0, 0, 0};
     int it = 0;
     while (it < st.niters) {
         const int m = ch.next(st.niters - it);
-        models.clear();
         owner.clear();
         for (int k = 0; k < m; ++k) {
             int idx[5];
             double model[6];
             rng.subset((int)n, 5, idx);
             if (!epnp_model(idx, model)) continue;
-            models.insert(models.end(), model, model + 6);
+            std::memcpy(hposes + 6 * owner.size(), model, sizeof(model));       // the scoring kernel reads the models in place
             owner.push_back(k);
         }
         const int H = (int)owner.size();
+        lap(1);
+        ++g_pnp_prof.chunks;
         if (H > 0) {
-            counts.resize(H);
-            SFM_CHECK_HIP(hipMemcpyAsync(poses_dev, models.data(), sizeof(double) * 6 * (size_t)H, hipMemcpyHostToDevice, stream));
-            const int rc = sfm_score_pnp(poses_dev, H, K, X_dev, uv_dev, n, thr2, counts_dev, masks_dev, stream_);
+            const int rc = sfm_score_pnp(hposes, H, K, X_dev, uv_dev, n, thr2, counts_dev, masks_dev, stream_);
             if (rc != SFM_OK) return rc;
-            SFM_CHECK_HIP(hipMemcpyAsync(counts.data(), counts_dev, sizeof(int32_t) * (size_t)H, hipMemcpyDeviceToHost, stream));
+            SFM_CHECK_HIP(hipMemcpyAsync(hcounts, counts_dev, sizeof(int32_t) * (size_t)H, hipMemcpyDeviceToHost, stream));
             SFM_CHECK_HIP(hipStreamSynchronize(stream));
             bool stop;
-            const int bj = replay_chunk(st, it, owner, counts.data(), stop);
+            const int bj = replay_chunk(st, it, owner, hcounts, stop);
             if (bj >= 0) {
-                std::memcpy(best_model, models.data() + 6 * (size_t)bj, sizeof(best_model));
+                std::memcpy(best_model, hposes + 6 * (size_t)bj, sizeof(best_model));
                 SFM_CHECK_HIP(hipMemcpyAsync(best_dev, masks_dev + (size_t)bj * (size_t)n, (size_t)n, hipMemcpyDeviceToDevice, stream));
             }
+            lap(2);
             if (stop) break;
         }
         it += m;
     }
     if (st.best <= 0) return SFM_OK;
     // inlier list (ascending, as OpenCV pushes them) — the one piece of the mask the host needs
-    std::vector<uint8_t> hmask((size_t)n);
-    SFM_CHECK_HIP(hipMemcpyAsync(hmask.data(), best_dev, (size_t)n, hipMemcpyDeviceToHost, stream));
+    SFM_CHECK_HIP(hipMemcpyAsync(hmask, best_dev, (size_t)n, hipMemcpyDeviceToHost, stream));
     SFM_CHECK_HIP(hipStreamSynchronize(stream));
     std::vector<int32_t> inl;
     inl.reserve((size_t)st.best);
@@ -497,27 +556,30 @@ extern "C" int sfm_solve_pnp_ransac(const float* X_dev, const float* uv_dev, int
         if (hmask[(size_t)i]) inl.push_back((int32_t)i);
     const int64_t m_in = (int64_t)inl.size();
     SFM_CHECK_HIP(hipMemcpyAsync(inliers_dev, inl.data(), sizeof(int32_t) * (size_t)m_in, hipMemcpyHostToDevice, stream));
+    lap(3);
     // solvePnP(ITERATIVE) on the inliers: DLT initialisation on the host, Levenberg-Marquardt with the sweeps on the device
     double param[6];
-    const int init_status = hs::pnp_dlt_init<float>(hX.data(), huv.data(), inl.data(), m_in, K, param, param + 3);
+    const int init_status = hs::pnp_dlt_init<float>(hX, huv, inl.data(), m_in, K, param, param + 3);
     if (init_status != 0) std::memcpy(param, best_model, sizeof(param));      // planar / < 6 inliers: refine the RANSAC model
+    lap(4);
     const int blocks = (int)std::min<int64_t>((m_in + kSweepThreads - 1) / kSweepThreads, kSweepMaxBlocks);
-    double sums[kSweepAcc];
     auto sweep = [&](const double* p, bool jac) -> int {
+        lap(6);
+        ++g_pnp_prof.sweeps;
         PnpCam cam;
         rodrigues_with_jac(p, cam.R, cam.dR);
         cam.t[0] = p[3]; cam.t[1] = p[4]; cam.t[2] = p[5];
         cam.fx = K[0]; cam.fy = K[4]; cam.cx = K[2]; cam.cy = K[5];
-        double* out = blocks == 1 ? sweep_dev + (size_t)kSweepAcc * kSweepMaxBlocks : sweep_dev;
+        double* out = blocks == 1 ? sums : sweep_dev;           // one workgroup: its 28 sums go straight to the pinned mailbox
         if (jac)
             hipLaunchKernelGGL(pnp_sweep_kernel<1>, dim3(blocks), dim3(kSweepThreads), 0, stream, cam, X_dev, uv_dev, inliers_dev, m_in, out);
         else
             hipLaunchKernelGGL(pnp_sweep_kernel<0>, dim3(blocks), dim3(kSweepThreads), 0, stream, cam, X_dev, uv_dev, inliers_dev, m_in, out);
         if (blocks > 1)
-            hipLaunchKernelGGL(pnp_sweep_fold_kernel, dim3(1), dim3(64), 0, stream, sweep_dev, blocks, sweep_dev + (size_t)kSweepAcc * kSweepMaxBlocks);
+            hipLaunchKernelGGL(pnp_sweep_fold_kernel, dim3(1), dim3(64), 0, stream, sweep_dev, blocks, sums);
         SFM_CHECK_LAUNCH();
-        SFM_CHECK_HIP(hipMemcpyAsync(sums, sweep_dev + (size_t)kSweepAcc * kSweepMaxBlocks, sizeof(sums), hipMemcpyDeviceToHost, stream));
         SFM_CHECK_HIP(hipStreamSynchronize(stream));
+        lap(5);
         return SFM_OK;
     };
     // CvLevMarq (J / err interface) as cvFindExtrinsicCameraParams2 drives it: <= 20 iterations, epsilon FLT_EPSILON,
@@ -535,9 +597,12 @@ extern "C" int sfm_solve_pnp_ransac(const float* X_dev, const float* uv_dev, int
         sv.back_subst(JtErr, dx);
         for (int i = 0; i < 6; ++i) param[i] = prev[i] - dx[i];
     };
+    // Every sweep returns J^T J, J^T e AND |e|^2 at its parameters: the error check of a trial step and the normal
+    // equations of the next iteration (which OpenCV evaluates at the same, accepted, parameters) are one launch and one
+    // download instead of two — same sums, half the host round trips.
+    int rc = sweep(param, true);
+    if (rc != SFM_OK) return rc;
     for (;;) {
-        int rc = sweep(param, true);
-        if (rc != SFM_OK) return rc;
         int q = 0;
         for (int a = 0; a < 6; ++a)
             for (int b = a; b < 6; ++b) JtJ[6 * a + b] = JtJ[6 * b + a] = sums[q++];
@@ -545,12 +610,12 @@ extern "C" int sfm_solve_pnp_ransac(const float* X_dev, const float* uv_dev, int
         std::memcpy(prev, param, sizeof(prev));
         if (iters == 0) prevErrNorm = std::sqrt(sums[27]);
         step();
-        if ((rc = sweep(param, false)) != SFM_OK) return rc;
+        if ((rc = sweep(param, true)) != SFM_OK) return rc;
         for (;;) {
             errNorm = std::sqrt(sums[27]);
             if (errNorm > prevErrNorm && ++lambdaLg10 <= 16) {
                 step();
-                if ((rc = sweep(param, false)) != SFM_OK) return rc;
+                if ((rc = sweep(param, true)) != SFM_OK) return rc;
                 continue;
             }
             break;
@@ -565,6 +630,7 @@ extern "C" int sfm_solve_pnp_ransac(const float* X_dev, const float* uv_dev, int
         if (iters >= 20 || std::sqrt(dn) / std::sqrt(pn) < FLT_EPSILON) break;
         prevErrNorm = errNorm;
     }
+    lap(6);
     std::memcpy(rvec_host, param, 24);
     std::memcpy(tvec_host, param + 3, 24);
     info_host[0] = 1;
