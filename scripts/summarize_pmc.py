@@ -35,3 +35,19 @@ for k, v in agg.items():
     if "TCC_HIT_sum" in m:
         print(f"\nL2 hit rate = {m['TCC_HIT_sum'] / (m['TCC_HIT_sum'] + m['TCC_MISS_sum']):.3f}")
     print()
+
+# HBM-side bytes per launch of the dominant kernel, stamped with the kernel source it was measured on (bench.py reports
+# it only while csrc/knn.hip is unchanged)
+import hashlib, json
+for k, v in agg.items():
+    if k.startswith("knn_filter_split2_kernel") and "FETCH_SIZE" in v:
+        m = {c: sum(x) / len(x) for c, x in v.items()}
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        out = {"kernel": k, "bytes_per_launch": 2 * m["FETCH_SIZE"] * 1024 + m.get("WRITE_SIZE", 0) * 1024,
+               "fetch_size_kib": m["FETCH_SIZE"], "write_size_kib": m.get("WRITE_SIZE"),
+               "mfma_pipe_busy_frac": (m["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * m["SQ_BUSY_CU_CYCLES"])) if "SQ_BUSY_CU_CYCLES" in m else None,
+               "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE doubled per MI355X_MICROARCH.md gfx950 correction; workload 10k x 10k",
+               "source": f"profiles/{tag}_knn_pmc.md",
+               "knn_hip_sha256": hashlib.sha256(open(os.path.join(root, "sfm_mvs_amd", "csrc", "knn.hip"), "rb").read()).hexdigest()}
+        json.dump(out, open(os.path.join(d, "..", "knn_traffic.json"), "w"), indent=1)
+        break
