@@ -30,7 +30,8 @@ sys.path.insert(0, ROOT)
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (no sparsity)
 PROF_SAMPLES = 6                   # profiled steps, run alone AFTER the timed region
-PIPE_DEPTH = 3                     # independent pairs in flight (one stream + workspace each)
+PIPE_DEPTH = 3                     # launch sets in flight (one stream + workspace each)
+PAIR_BATCH = 4                     # independent pairs per launch set (sfm_match_batch_l2_f32): prologue / ramp / kernel boundaries once per batch
 PROF_REPEAT = 3                    # filter launches per HIP-event pair on a profiled step (an event pair adds ~7 us to one)
 EXCH_BATCH = 8                     # pairs per RCCL all-gather at N > 1
 SPLIT_MFMA_PER_TILE, F32_MFMA_PER_TILE = 24, 65
@@ -50,7 +51,8 @@ def parse():
     ap.add_argument("--images", type=int, default=32, help="workload c5: images in the sequence (BASELINE config 5 has 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
-    ap.add_argument("--pipe-depth", type=int, default=PIPE_DEPTH, help="independent pairs in flight per GPU (1 = one stream)")
+    ap.add_argument("--pipe-depth", type=int, default=PIPE_DEPTH, help="launch sets in flight per GPU (1 = one stream)")
+    ap.add_argument("--pair-batch", type=int, default=PAIR_BATCH, help="independent pairs per launch set (1..8)")
     return ap.parse_args()
 
 
@@ -156,10 +158,13 @@ def bench_knn(args, world, rank, dev):
     nq, nt = args.nq, args.nt
     q = torch.rand((nq, 128), generator=torch.Generator().manual_seed(2 * rank)).to(dev)
     t = torch.rand((nt, 128), generator=torch.Generator().manual_seed(2 * rank + 1)).to(dev)
-    # Pairs are independent units: consecutive steps are pipelined over PIPE_DEPTH streams so that the
-    # low-occupancy tail of one pair (rescans, ordered scatter) and the prep pass of the next overlap a filter kernel.
+    # Pairs are independent units.  A step = one pair; the pairs of consecutive steps are issued PAIR_BATCH per
+    # launch set (one prep / filter / refine / scatter launch for the batch: a filter workgroup pays its prologue once per
+    # batch, and there are PAIR_BATCH times fewer kernel boundaries), and launch sets are pipelined over PIPE_DEPTH streams
+    # so that the low-occupancy tail of one (rescans, ordered scatter) and the prep pass of the next overlap a filter kernel.
     depth = max(1, args.pipe_depth)
-    pipe = ops.PairPipeline(nq, nt, dev, ratio=0.70, depth=depth)
+    pbatch = max(1, min(8, args.pair_batch))
+    pipe = ops.BatchPipeline(nq, nt, dev, ratio=0.70, depth=depth, batch=pbatch)
     pm = pipe.matchers[0]
     import torch.distributed as dist
     exchange = dist.is_available() and dist.is_initialized()
@@ -175,7 +180,8 @@ def bench_knn(args, world, rank, dev):
         ex = sharded.BatchedExchange((2, nq, 2), torch.int32, dev, batch=EXCH_BATCH)
 
     def flush():
-        """All-gather the pairs accumulated in the current batch buffer (a partial batch is sent whole)."""
+        """Launch a partially filled pair batch and all-gather what the exchange buffer holds (a partial buffer is sent whole)."""
+        pipe.flush()
         if ex is not None and ex.fill > 0:
             ex.flush(pipe.streams)
 
@@ -184,12 +190,15 @@ def bench_knn(args, world, rank, dev):
             pipe.submit(q, t, after=False)                   # static inputs, nothing to wait for
             return
         slot, free_ev = ex.next_slot()
-        pipe.submit(q, t, after=free_ev if (ex.fill < depth and free_ev is not None) else False, result=slot)
+        pipe.submit(q, t, after=free_ev if free_ev is not None else False, result=slot)
         if ex.commit():
+            pipe.flush()
             ex.flush(pipe.streams)
 
-    for pmx in pipe.matchers:                                # set-up, not a step: every stream's matcher loads its kernels once
-        pmx.run(q, t)
+    for st, pmx in zip(pipe.streams, pipe.matchers):         # set-up, not a step: every stream is created and every matcher's
+        with torch.cuda.stream(st):                          # kernels are loaded once (a HIP stream's first launch costs milliseconds)
+            pmx.run([(q, t)] * pbatch)
+            pmx.run([(q, t)])
     torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
@@ -214,16 +223,16 @@ def bench_knn(args, world, rank, dev):
     # times inside one event pair so that the event overhead is amortised.
     ops.profile_read(0), ops.profile_read(1)               # clear the slots
     pipe.synchronize()
-    for i in range(PROF_SAMPLES):
+    for i in range(PROF_SAMPLES):                           # one launch set (a whole pair batch) alone on the device
         ops.profile_enable(PROF_REPEAT)
-        step()
+        pm.run([(q, t)] * pbatch)
         ops.profile_enable(False)
-        pipe.synchronize()
+        torch.cuda.synchronize()
     flush()
     barrier_sync(world)
     filt_ms, filt_n = ops.profile_read(0)
     ref_ms, ref_n = ops.profile_read(1)
-    stats = pm.stats.cpu().tolist()
+    stats = pm.stats[0].cpu().tolist()
 
     # HBM-side bytes per launch of the dominant kernel come from PMC passes (rocprofv3 cannot be driven from inside the
     # process); the committed figure is stamped with the sha256 of the kernel source it was measured on and is
@@ -232,19 +241,19 @@ def bench_knn(args, world, rank, dev):
     tpath = os.path.join(ROOT, "profiles", "knn_traffic.json")
     if os.path.exists(tpath) and (nq, nt) == (10000, 10000):
         tj = json.load(open(tpath))
-        if tj.get("knn_hip_sha256") == knn_source_hash():
+        if tj.get("knn_hip_sha256") == knn_source_hash() and tj.get("pairs_per_launch", 1) == pbatch:
             traffic, traffic_note = tj.get("bytes_per_launch"), f"profiles/knn_traffic.json ({tj.get('source')})"
         else:
-            traffic_note = "profiles/knn_traffic.json is stale (csrc/knn.hip changed since the PMC passes): not reported"
+            traffic_note = "profiles/knn_traffic.json is stale (csrc/knn.hip or the pair batch changed since the PMC passes): not reported"
     value = world * nq * nt * args.steps / elapsed
     filt_avg_ms = filt_ms / max(filt_n, 1)
-    algo_flop = nq * nt * FLOP_PER_DISTANCE
+    algo_flop = pbatch * nq * nt * FLOP_PER_DISTANCE        # one filter launch covers the whole pair batch
     achieved = algo_flop / (filt_avg_ms * 1e-3) / 1e12
     # MFMA work actually issued by the filter arithmetic the device chose (stats[3]): one fp16 product per fp32 product
     # (8 MFMAs per 32x32x128 tile) or the 3-product bf16 split (24)
     mode = stats[3]
     mfma_per_tile = {0: 8, 1: 8, 2: SPLIT_MFMA_PER_TILE}.get(mode, 8)
-    issued = (nq / 32.0) * (nt / 32.0) * mfma_per_tile * 2 * 32 * 32 * 16 / (filt_avg_ms * 1e-3) / 1e12
+    issued = pbatch * (nq / 32.0) * (nt / 32.0) * mfma_per_tile * 2 * 32 * 32 * 16 / (filt_avg_ms * 1e-3) / 1e12
     mode_name = {0: "fp16 single product (inputs exact in fp16)", 1: "fp16 single product", 2: "bf16 hi+mid split (3 products)",
                  3: "fp32 MFMA"}.get(mode, str(mode))
     out = {
@@ -257,16 +266,17 @@ def bench_knn(args, world, rank, dev):
         "config": {"workload": "BASELINE configs[1]: 10k x 10k uniform[0,1) float32 128-D descriptors, BF-KNN k=2 + "
                                "Lowe ratio 0.70, one image pair per GPU per step", "nq": nq, "nt": nt, "dim": 128,
                    "parallelism": f"pair-sharded x{world}" + (f" + one RCCL all-gather of the match records per {EXCH_BATCH} pairs" if world > 1 else "")
-                                  + f"; {depth} independent pairs in flight per GPU (one HIP stream each)"},
+                                  + f"; independent pairs issued {pbatch} per launch set (sfm_match_batch_l2_f32), {depth} launch sets in flight per GPU (one HIP stream each)",
+                   "pairs_per_launch": pbatch},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": traffic,
                      "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_note,
-                     "algorithmic_bytes_per_launch": 4 * 128 * (nq + nt) + 16 * nq,
-                     "kernel": "knn_filter_split2_kernel<0, 4>", "avg_launch_ms": filt_avg_ms, "launches": filt_n,
+                     "algorithmic_bytes_per_launch": pbatch * (4 * 128 * (nq + nt) + 16 * nq),
+                     "kernel": "knn_filter_split2_kernel<0, 4>", "avg_launch_ms": filt_avg_ms, "launches": filt_n, "pairs_per_launch": pbatch,
                      "algorithmic_flop_per_launch": algo_flop,
                      "issued_mfma_tflops": issued, "issued_frac_of_peak": issued / BF16_MFMA_PEAK_TFLOPS,
-                     "launch_sampling": f"HIP events around the filter kernel on {PROF_SAMPLES} steps run alone AFTER the timed region "
-                                        f"(pipeline drained); on those steps the kernel is launched {PROF_REPEAT}x back-to-back inside "
+                     "launch_sampling": f"HIP events around the filter kernel on {PROF_SAMPLES} launch sets run alone AFTER the timed region "
+                                        f"(pipeline drained); on those the kernel is launched {PROF_REPEAT}x back-to-back inside "
                                         "the event pair (idempotent) so that the event overhead (~7 us per pair) is amortised",
                      "note": "algorithmic = 256 FLOP per distance (SURVEY 8d); issued = MFMA flops of the arithmetic mode that ran"},
         "kernels_ms": {"knn_filter": filt_avg_ms, "knn_refine": ref_ms / max(ref_n, 1)},
@@ -279,13 +289,24 @@ def bench_knn(args, world, rank, dev):
                            "bytes_per_rank_per_collective": EXCH_BATCH * nq * 16,
                            "note": "device time between the events bracketing each all_gather_into_tensor on the issuing stream "
                                    "(includes waiting for the batch's producers); the pair kernels of the next batch overlap it"}
-    # latency of ONE pair on one stream (no overlap with neighbouring pairs), outside the timed region
+    # latency of ONE pair launched alone (batch of one, one stream), and of one whole batch, outside the timed region
+    pm = pm1 = ops.PairMatcher(nq, nt, dev, ratio=0.70)
+    for _ in range(3):
+        pm1.run(q, t)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(50):
-        pm.run(q, t)
+        pm1.run(q, t)
     torch.cuda.synchronize()
     out["pair_latency_ms_single_stream"] = (time.perf_counter() - t0) / 50 * 1e3
+    bm0 = pipe.matchers[0]
+    t0 = time.perf_counter()
+    for _ in range(20):
+        bm0.run([(q, t)] * pbatch)
+    torch.cuda.synchronize()
+    out["batch_latency_ms_single_stream"] = (time.perf_counter() - t0) / 20 * 1e3
+    same_as_single = all(bool(torch.equal(bm0.idx[b], pm1.idx) and torch.equal(bm0.dist[b], pm1.dist)) for b in range(pbatch))
+    out["batched_results_identical_to_single_pair_call"] = same_as_single
     if world == 1 and not args.no_extras:
         # boundary handing over HOST buffers: pinned H2D of both descriptor sets + the step + D2H of the results
         qh, th = q.cpu().pin_memory(), t.cpu().pin_memory()

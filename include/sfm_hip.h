@@ -105,6 +105,24 @@ int sfm_match_l2_f32(const float* q_dev, int64_t nq, int64_t ldq,
                      uint8_t* mask_dev /*optional*/, int32_t* stats_dev /*optional*/,
                      void* ws_dev, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------
+ * The same for `batch` (1..8) image pairs of ONE shape in one set of launches — what a caller
+ * with many independent pairs (sfm.py:347 matches every consecutive pair; isfm.py:56-71 all
+ * pairs) should use: the filter's unit space becomes batch x query row blocks x train tiles
+ * under a single work partition, so a workgroup's prologue, the launch ramp and the kernel
+ * boundaries are paid once per batch instead of once per pair (10k x 10k: 31 -> ~23 us of
+ * filter time per pair at batch 4).  Results are those of `batch` separate calls, bit for bit.
+ * q, t, idx, dist, out_q, out_t, out_count, mask, stats: HOST arrays of `batch` device
+ * pointers (mask / stats: NULL array or NULL entries allowed); all pairs share nq, nt, ldq, ldt.
+ * Not available while sfm_knn_set_filter(1) (the fp32-MFMA variant) is selected.
+ * ---------------------------------------------------------------------- */
+size_t sfm_match_batch_l2_f32_ws_bytes(int64_t nq, int64_t nt, int dim, int batch);
+int sfm_match_batch_l2_f32(int batch, const float* const* q_dev, int64_t nq, int64_t ldq,
+                           const float* const* t_dev, int64_t nt, int64_t ldt, int dim, double ratio,
+                           int32_t* const* idx_dev, float* const* dist_dev, int32_t* const* out_q_dev,
+                           int32_t* const* out_t_dev, int32_t* const* out_count_dev, uint8_t* const* mask_dev,
+                           int32_t* const* stats_dev, void* ws_dev, size_t ws_bytes, void* stream);
+
 /* Gather keypoint coordinates of the survivors: pts0 = kp0[out_q], pts1 = kp1[out_t]
  * (sfm.py:267-268).  kp*_dev are [n x 2] float32 (KeyPoint.pt); count_dev is the
  * device scalar written by sfm_ratio_compact; capacity = rows available in pts*_dev. */

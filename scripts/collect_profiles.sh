@@ -16,11 +16,12 @@ P2="FETCH_SIZE"
 P3="WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"
 P4="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_WAVES"
 i=1
+BATCH=${SFM_PROFILE_BATCH:-4}          # pairs per launch set: what bench.py runs by default
 for P in "$P1" "$P2" "$P3" "$P4"; do
-  rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/pmc -o pass$i -- python $R/scripts/run_knn_steps.py 6 > $OUT/pmc_pass$i.log 2>&1
+  SFM_BATCH=$BATCH rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/pmc -o pass$i -- python $R/scripts/run_knn_steps.py 6 > $OUT/pmc_pass$i.log 2>&1
   i=$((i+1))
 done
-python $R/scripts/summarize_pmc.py $OUT/pmc $TAG > $OUT/${TAG}_knn_pmc.md
+python $R/scripts/summarize_pmc.py $OUT/pmc $TAG $BATCH > $OUT/${TAG}_knn_pmc.md
 for wl in tri ba; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$wl -o $wl -- python $R/bench.py --workload $wl --steps 5 --warmup 1 > $OUT/bench_${wl}_under_rocprof.json 2>> $OUT/trace.log
   cp $OUT/trace_$wl/${wl}_kernel_stats.csv $OUT/${TAG}_${wl}_kernel_stats.csv

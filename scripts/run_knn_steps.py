@@ -13,8 +13,21 @@ if kind == "sift":      # integer-valued 0..255 like cv2 SIFT output
 else:
     q = torch.rand((nq, 128), generator=torch.Generator().manual_seed(0)).cuda()
     t = torch.rand((nt, 128), generator=torch.Generator().manual_seed(1)).cuda()
-pm = ops.PairMatcher(nq, nt, q.device)
 import time
+B = int(os.environ.get("SFM_BATCH", "1"))
+if B > 1:      # one launch set per step for B pairs (what bench.py drives): the PMC passes profile THIS filter launch
+    bm = ops.BatchMatcher(nq, nt, q.device, batch=B)
+    for _ in range(3):
+        bm.run([(q, t)] * B)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        bm.run([(q, t)] * B)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / (n * B)
+    print(f"done {kind} {nq}x{nt}: batch {B}: {dt*1e3:.4f} ms per pair  {nq*nt/dt:.3e} dist/s  stats", bm.stats[0].cpu().tolist())
+    sys.exit(0)
+pm = ops.PairMatcher(nq, nt, q.device)
 for _ in range(3):
     pm.run(q, t)
 torch.cuda.synchronize()

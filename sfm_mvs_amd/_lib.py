@@ -33,6 +33,8 @@ SIGNATURES = {
     "sfm_ratio_compact": (_int, [_vp, _vp, _i64, _f64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sfm_match_l2_f32_ws_bytes": (_sz, [_i64, _i64, _int]),
     "sfm_match_l2_f32": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _int, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sfm_match_batch_l2_f32_ws_bytes": (_sz, [_i64, _i64, _int, _int]),
+    "sfm_match_batch_l2_f32": (_int, [_int, _vp, _i64, _i64, _vp, _i64, _i64, _int, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sfm_gather_matches": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "sfm_common_points": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sfm_triangulate_dlt": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _int, _int, _vp, _vp]),

@@ -49,13 +49,30 @@ constexpr int kSubTilesHost = 64;      // = kSubTiles (tiles per substream), nee
 // block b owns units [units*b/G, units*(b+1)/G).  Every block gets the same number of units (+-1),
 // so all 2x256 resident workgroups finish together whatever nq, nt are; a block that crosses a
 // row-block boundary flushes its candidates and reloads the query fragment.
+constexpr int kMaxBatch = 8;           // image pairs of equal shape matched by ONE set of launches (sfm_match_batch_l2_f32)
+
+// Per-pair user buffers of a batched call (kernel argument, by value; entries >= B are unused).
+struct BatchPtrs {
+    const float* q[kMaxBatch];
+    const float* t[kMaxBatch];
+    int* idx[kMaxBatch];
+    float* dist[kMaxBatch];
+    int* stats[kMaxBatch];
+    int* out_q[kMaxBatch];
+    int* out_t[kMaxBatch];
+    int* out_count[kMaxBatch];
+    unsigned char* mask[kMaxBatch];
+};
+
 struct Plan {
     int split;         // 1: split-bf16 filter (default), 0: fp32-MFMA filter
     int qg;            // 32-query groups per wave (2: knn_filter_split2_kernel at 2 waves/SIMD)
-    int nq_pad;        // query rows padded to whole row blocks
+    int nq_pad;        // query rows (of ONE pair) padded to whole row blocks
     int waves;         // waves per filter workgroup (4, 8 or 16); 16 waves are resident per CU either way
     int rows_per_block;
-    int n_rb;          // query row blocks
+    int B;             // image pairs in the batch: the unit space is B x (row blocks of a pair) x tiles, one partition over all of it
+    int n_rb1;         // query row blocks of one pair
+    int n_rb;          // query row blocks of the whole batch = B * n_rb1 (pair b owns [b * n_rb1, (b + 1) * n_rb1))
     int tiles;         // train tiles of 32
     int64_t units;     // n_rb * tiles
     int G;             // filter blocks
@@ -145,32 +162,47 @@ __device__ inline void fill_partition_tables(const Partition pt, int n_rb, int64
 // sfm_knn_set_filter().  Both give bit-identical results; they differ in speed only.
 int g_filter_mode = [] { const char* e = getenv("SFM_KNN_FILTER"); return (e && e[0] == 'f') ? 1 : 0; }();
 
-Plan make_plan_uncached(int64_t nq, int64_t nt);
+Plan make_plan_uncached(int64_t nq, int64_t nt, int B);
 
-// Planning walks the partition (O(G + row blocks)): keep the last plan.
-Plan make_plan(int64_t nq, int64_t nt) {
+// Planning walks the partition (O(G + row blocks)): keep the last few plans (a pipeline alternates between its full
+// batch and the partial batch that ends a sequence).
+Plan make_plan(int64_t nq, int64_t nt, int B = 1) {
+    struct Entry {
+        int64_t nq = -1, nt = -1;
+        int B = -1, mode = -1, seg = -1;
+        unsigned long long used = 0;
+        Plan plan;
+    };
     static std::mutex mu;
-    static int64_t k_nq = -1, k_nt = -1;
-    static int k_mode = -1, k_seg = -1;
-    static Plan cached;
+    static Entry cache[4];
+    static unsigned long long tick = 0;
     std::lock_guard<std::mutex> lk(mu);
-    if (nq != k_nq || nt != k_nt || g_filter_mode != k_mode || g_seg_cost != k_seg) {
-        cached = make_plan_uncached(nq, nt);
-        k_nq = nq; k_nt = nt; k_mode = g_filter_mode; k_seg = g_seg_cost;
+    Entry* victim = &cache[0];
+    for (Entry& e : cache) {
+        if (e.nq == nq && e.nt == nt && e.B == B && e.mode == g_filter_mode && e.seg == g_seg_cost) {
+            e.used = ++tick;
+            return e.plan;
+        }
+        if (e.used < victim->used) victim = &e;
     }
-    return cached;
+    victim->plan = make_plan_uncached(nq, nt, B);
+    victim->nq = nq; victim->nt = nt; victim->B = B; victim->mode = g_filter_mode; victim->seg = g_seg_cost;
+    victim->used = ++tick;
+    return victim->plan;
 }
 
-Plan make_plan_uncached(int64_t nq, int64_t nt) {
+Plan make_plan_uncached(int64_t nq, int64_t nt, int B) {
     Plan p;
+    p.B = B;
     static const int env_w = [] { const char* e = getenv("SFM_KNN_WAVES"); return e ? atoi(e) : 0; }();   // dev override
     p.waves = (env_w == 4 || env_w == 8 || env_w == 16) ? env_w : 8;
     p.split = g_filter_mode == 1 ? 0 : 1;
     p.qg = p.split ? 2 : 1;
     if (p.split && !(env_w == 4 || env_w == 8 || env_w == 16)) p.waves = p.qg == 2 ? 4 : 16;   // split2: two 4-wave workgroups per CU (their barrier stalls interleave; ~3 % over one 8-wave group)
     p.rows_per_block = p.waves * 32 * p.qg;
-    p.n_rb = (int)((nq + p.rows_per_block - 1) / p.rows_per_block);
-    p.nq_pad = p.n_rb * p.rows_per_block;
+    p.n_rb1 = (int)((nq + p.rows_per_block - 1) / p.rows_per_block);
+    p.n_rb = B * p.n_rb1;
+    p.nq_pad = p.n_rb1 * p.rows_per_block;
     p.tiles = (int)((nt + kTileT - 1) / kTileT);
     p.units = (int64_t)p.n_rb * p.tiles;
     static const int env_res = [] { const char* e = getenv("SFM_KNN_RESIDENT"); return e ? atoi(e) : 0; }();   // dev override
@@ -517,23 +549,41 @@ __device__ __forceinline__ int knn_filter_mode(const int* __restrict__ flags, co
     return tmax >= 0.25f ? kModeHalf : kModeSplit;
 }
 
+// The arithmetic mode of a BATCH of pairs (one launch, one body): the most general mode any of its pairs needs — the
+// modes are nested (fp16-exact data are fp16-representable data are split-representable data), and the refine kernel
+// prices its slack with the same batch mode, so every pair is certified against the arithmetic that actually ran.
+__device__ __forceinline__ int knn_batch_mode(const int* __restrict__ flags, const float* __restrict__ bmax, int n_pairs, int lane) {
+    int mode = kModeHalfExact;
+    for (int b = 0; b < n_pairs; ++b) mode = max(mode, knn_filter_mode(flags + b * kNormBlocks, bmax + b * kNormBlocks, lane));
+    return mode;
+}
+
 // One pass over Q and T: rows → (hi, mid) bf16 images and an fp16 image (Q pre-scaled by -2, exact), fp32 squared
 // norms, per-block max of ||t||^2 and exactness / range flags, zero the rescan counter.  Rows >= n of the padded
 // images are zero-filled.  Image layout: [3][n_pad][128] 16-bit: bf16 hi, bf16 mid, fp16.
-__global__ __launch_bounds__(1024) void knn_prep_kernel(const float* __restrict__ Q, int64_t ldq, int nq, int nq_pad,
-                                                       const float* __restrict__ T, int64_t ldt, int nt, int nt_pad,
+// Batched: grid = (blocks + 1, B); column b works on pair b (its workspace arrays sit at b * stride).
+__global__ __launch_bounds__(1024) void knn_prep_kernel(BatchPtrs P, int64_t ldq, int nq, int nq_pad,
+                                                       int64_t ldt, int nt, int nt_pad,
                                                        unsigned short* __restrict__ qsplit, float* __restrict__ qn,
                                                        unsigned short* __restrict__ tsplit, float* __restrict__ tn,
                                                        float* __restrict__ bmax, int* __restrict__ midflag,
-                                                       int* __restrict__ stats, int* __restrict__ zero, int nzero,
+                                                       int64_t s_qsplit, int64_t s_tsplit, int64_t s_qn, int64_t s_tn,
+                                                       int* __restrict__ zero, int nzero,
                                                        int64_t units, int tiles, int G, int seg_cost, int n_rb,
                                                        int64_t* __restrict__ wg_begin, int* __restrict__ rb_first,
                                                        int* __restrict__ rb_last) {
     __shared__ float wmax[16];
-    if (blockIdx.x == gridDim.x - 1) {                     // the extra workgroup: partition tables, nothing else
-        fill_partition_tables(make_partition(units, tiles, G, seg_cost), n_rb, wg_begin, rb_first, rb_last);
+    const int pb = blockIdx.y;
+    if (blockIdx.x == gridDim.x - 1) {                     // the extra workgroup (of column 0): partition tables, nothing else
+        if (pb == 0) fill_partition_tables(make_partition(units, tiles, G, seg_cost), n_rb, wg_begin, rb_first, rb_last);
         return;
     }
+    const float* __restrict__ Q = P.q[pb];
+    const float* __restrict__ T = P.t[pb];
+    int* __restrict__ stats = P.stats[pb];
+    qsplit += pb * s_qsplit; tsplit += pb * s_tsplit; qn += pb * s_qn; tn += pb * s_tn;
+    bmax += pb * kNormBlocks; midflag += pb * kNormBlocks;
+    zero += pb * nzero;
     const int nblk = gridDim.x - 1;
     __shared__ int wmid[16];
     const int l = threadIdx.x & 31;
@@ -657,7 +707,10 @@ __device__ __forceinline__ void filter_split2_body(
     float* smem, const unsigned short* __restrict__ qsplit, const float* __restrict__ qnorm, int nq, int nq_pad,
     const unsigned short* __restrict__ tsplit, int nt_pad, const float* __restrict__ tn, int tiles, int64_t units,
     int smax, int nsub, float* __restrict__ cand_s, int* __restrict__ cand_i, const int64_t* __restrict__ wg_begin,
-    const int* __restrict__ rb_first, long long* __restrict__ trace) {
+    const int* __restrict__ rb_first, int n_rb1, int64_t s_qsplit, int64_t s_tsplit, int64_t s_qn, int64_t s_tn, int64_t s_cand,
+    long long* __restrict__ trace) {
+    // All pointers are pair 0's; pair b of the batch sits at + b * stride.  A segment (the part of this workgroup's range
+    // inside one query row block) belongs to one pair: its images, norms and candidate arrays are selected per segment.
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31;
@@ -675,8 +728,12 @@ __device__ __forceinline__ void filter_split2_body(
     const unsigned lds_tn = lds0 + kRing * kTileFloats * 4;
     const int mid_off = nt_pad * 256;
     const int img_off = KMID ? 0 : 2 * mid_off;                 // single-product modes read the fp16 image
-    const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc((void*)tsplit, 0, 3 * mid_off, 0x00020000);
-    const __amdgpu_buffer_rsrc_t tnrs = __builtin_amdgcn_make_buffer_rsrc((void*)tn, 0, nt_pad * 4, 0x00020000);
+    __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc((void*)tsplit, 0, 3 * mid_off, 0x00020000);      // (re-made per segment:
+    __amdgpu_buffer_rsrc_t tnrs = __builtin_amdgcn_make_buffer_rsrc((void*)tn, 0, nt_pad * 4, 0x00020000);          //  the pair's own arrays)
+    const unsigned short* __restrict__ qsplit0 = qsplit;
+    const float* __restrict__ qnorm0 = qnorm;
+    float* __restrict__ cand_s0 = cand_s;
+    int* __restrict__ cand_i0 = cand_i;
     constexpr int PIECES = 16 / W;
     const int p0 = wave * PIECES;
     const int r0 = 4 * (p0 & 7) + (lane >> 4);
@@ -708,8 +765,16 @@ __device__ __forceinline__ void filter_split2_body(
         const int rb = (int)(u / tiles);
         const int t_begin = (int)(u - (int64_t)rb * tiles);
         const int t_end = (int)min((int64_t)tiles, t_begin + (u_end - u));
-        const int slot = bid - rb_first[rb];
-        const int qrow0 = rb * (W * 64) + wave * 64 + j;          // group g adds 32*g
+        const int slot = bid - rb_first[rb];                       // (rb is the GLOBAL row block: the tables span the batch)
+        const int pb = n_rb1 > 0 ? rb / n_rb1 : 0;                 // pair of the batch this row block belongs to
+        const int rbl = rb - pb * n_rb1;                           // row block inside the pair
+        qsplit = qsplit0 + pb * s_qsplit;
+        qnorm = qnorm0 + pb * s_qn;
+        cand_s = cand_s0 + pb * s_cand;
+        cand_i = cand_i0 + pb * s_cand;
+        trs = __builtin_amdgcn_make_buffer_rsrc((void*)(tsplit + pb * s_tsplit), 0, 3 * mid_off, 0x00020000);
+        tnrs = __builtin_amdgcn_make_buffer_rsrc((void*)(tn + pb * s_tn), 0, nt_pad * 4, 0x00020000);
+        const int qrow0 = rbl * (W * 64) + wave * 64 + j;         // group g adds 32*g
         const bool qok[2] = {qrow0 < nq, qrow0 + 32 < nq};
 
         __syncthreads();                                           // previous segment fully consumed, nothing in flight
@@ -726,7 +791,7 @@ __device__ __forceinline__ void filter_split2_body(
         uint4 bh[2][8], bm[2][8];
         float qn[2];
         if constexpr (kCoalescedQ) {
-            const unsigned short* img = qsplit + (2 * (int64_t)nq_pad + rb * (W * 64) + wave * 64) * kDim;   // fp16 image, this wave's 64 rows
+            const unsigned short* img = qsplit + (2 * (int64_t)nq_pad + rbl * (W * 64) + wave * 64) * kDim;   // fp16 image, this wave's 64 rows
             const int lr = lane >> 4, lc = lane & 15;                // row within a 4-row load, 16-byte chunk
 #pragma unroll
             for (int g = 0; g < 2; ++g)
@@ -948,7 +1013,7 @@ __global__ __launch_bounds__(64 * W, 2) void knn_filter_split2_kernel(
     const unsigned short* __restrict__ tsplit, int nt, int nt_pad, const float* __restrict__ tn, int tiles, int64_t units,
     int smax, int nsub, const int* __restrict__ midflag, const float* __restrict__ bmax, int force_mode,
     float* __restrict__ cand_s, int* __restrict__ cand_i, const int64_t* __restrict__ wg_begin, const int* __restrict__ rb_first,
-    long long* __restrict__ trace) {
+    int n_rb1, int n_pairs, int64_t s_qsplit, int64_t s_tsplit, int64_t s_qn, int64_t s_tn, int64_t s_cand, long long* __restrict__ trace) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if (trace && threadIdx.x == 0) {
         trace[4 * blockIdx.x + 0] = wall_clock64();
@@ -957,11 +1022,13 @@ __global__ __launch_bounds__(64 * W, 2) void knn_filter_split2_kernel(
         trace[8192 + 4 * blockIdx.x + 2] = clock64();
     }
     const int lane = threadIdx.x & 63;
-    const bool need_mid = (force_mode >= 0 ? force_mode : knn_filter_mode(midflag, bmax, lane)) == kModeSplit;
+    const bool need_mid = (force_mode >= 0 ? force_mode : knn_batch_mode(midflag, bmax, n_pairs, lane)) == kModeSplit;
     if (need_mid)
-        filter_split2_body<ABL, W, true>(smem, qsplit, qnorm, nq, nq_pad, tsplit, nt_pad, tn, tiles, units, smax, nsub, cand_s, cand_i, wg_begin, rb_first, trace);
+        filter_split2_body<ABL, W, true>(smem, qsplit, qnorm, nq, nq_pad, tsplit, nt_pad, tn, tiles, units, smax, nsub, cand_s, cand_i, wg_begin, rb_first,
+                                         n_rb1, s_qsplit, s_tsplit, s_qn, s_tn, s_cand, trace);
     else
-        filter_split2_body<ABL, W, false>(smem, qsplit, qnorm, nq, nq_pad, tsplit, nt_pad, tn, tiles, units, smax, nsub, cand_s, cand_i, wg_begin, rb_first, trace);
+        filter_split2_body<ABL, W, false>(smem, qsplit, qnorm, nq, nq_pad, tsplit, nt_pad, tn, tiles, units, smax, nsub, cand_s, cand_i, wg_begin, rb_first,
+                                          n_rb1, s_qsplit, s_tsplit, s_qn, s_tn, s_cand, trace);
     if (trace && threadIdx.x == 0) {
         trace[4 * blockIdx.x + 1] = wall_clock64();
         trace[8192 + 4 * blockIdx.x + 3] = clock64();
@@ -1148,19 +1215,33 @@ constexpr int kQualCap = 144;    // exact-evaluation list per query (a chunk of 
 //            train sets) has its <= 512 trains evaluated exactly by the whole workgroup and merged into the query's
 //            answer.  After that the answer equals a full direct-form scan.
 __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
-    const float* __restrict__ Q, int64_t ldq, int nq, const float* __restrict__ T, int64_t ldt, int nt,
+    BatchPtrs P, int B, int64_t ldq, int nq, int64_t ldt, int nt,
     const float* __restrict__ cand_s, const int* __restrict__ cand_i, int rows_per_block, int tiles, int64_t units,
     int G, int smax, int nsub, int force_mode, const int* __restrict__ midflag, const float* __restrict__ bmax,
     const unsigned short* __restrict__ thalf /*fp16 image of T, or null*/, const float* __restrict__ tn,
     const int64_t* __restrict__ wg_begin, const int* __restrict__ rb_first, const int* __restrict__ rb_last,
-    int* __restrict__ idx_out, float* __restrict__ dist_out, int* __restrict__ stats, double ratio,
-    int* __restrict__ ratio_counts /*null unless fused with the Lowe ratio*/, unsigned char* __restrict__ ratio_mask,
-    long long* __restrict__ trace) {
+    int n_rb1, int64_t s_cand, int64_t s_tsplit, int64_t s_tn, double ratio,
+    int* __restrict__ ratio_counts /*null unless fused with the Lowe ratio*/, int ratio_stride, long long* __restrict__ trace) {
     // XCD-aware order (see the filter): physical workgroup b takes query block (b % 8) * chunk + b / 8, so the queries an
-    // XCD refines are (roughly) those whose candidate records its own filter workgroups wrote
-    const int n_wg = (nq + kRefQ - 1) / kRefQ, wg_chunk = (n_wg + 7) >> 3;
-    const int bid = n_wg >= 64 ? (int)(blockIdx.x & 7) * wg_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    if (bid >= n_wg) return;
+    // XCD refines are (roughly) those whose candidate records its own filter workgroups wrote.  Batched: the query
+    // blocks of all pairs form one sequence, pair after pair.
+    const int n_wg = (nq + kRefQ - 1) / kRefQ, n_tot = B * n_wg, wg_chunk = (n_tot + 7) >> 3;
+    const int bidt = n_tot >= 64 ? (int)(blockIdx.x & 7) * wg_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (bidt >= n_tot) return;
+    const int pb = bidt / n_wg, bid = bidt - pb * n_wg;
+    const float* __restrict__ Q = P.q[pb];
+    const float* __restrict__ T = P.t[pb];
+    int* __restrict__ idx_out = P.idx[pb];
+    float* __restrict__ dist_out = P.dist[pb];
+    int* __restrict__ stats = P.stats[pb];
+    unsigned char* __restrict__ ratio_mask = P.mask[pb];
+    cand_s += pb * s_cand; cand_i += pb * s_cand;
+    const int* __restrict__ midflag0 = midflag;
+    const float* __restrict__ bmax0 = bmax;
+    midflag += pb * kNormBlocks; bmax += pb * kNormBlocks;
+    if (thalf) thalf += pb * s_tsplit;
+    tn += pb * s_tn;
+    if (ratio_counts) ratio_counts += pb * ratio_stride;
 
     __shared__ __attribute__((aligned(16))) float qrows[kRefQ][kDim];
     __shared__ int qual[kRefQ][kQualCap];
@@ -1171,7 +1252,7 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
     __shared__ int surv[kSubTiles * 16];
     __shared__ int nitem, nsurv;
     __shared__ Best2 wbest[4];
-    if (trace && threadIdx.x == 0) trace[16 * bid + 0] = wall_clock64();   // dev diagnostics
+    if (trace && threadIdx.x == 0) trace[16 * bidt + 0] = wall_clock64();   // dev diagnostics
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int sub = lane >> 4, sl = lane & 15;           // query slot inside the wave, lane inside the query
@@ -1191,13 +1272,14 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
     // sums (<= 24u*d^2) and the final sqrtf merge (8u*d^2) — 600u*(|q|+|t|max)^2, u = 2^-24 — plus what the
     // filter arithmetic that ran loses on top (packed keys; 16-bit operands): see kEps*.
     float tmax;
-    int mode = knn_filter_mode(midflag, bmax, lane, &tmax);
+    int mode = knn_filter_mode(midflag, bmax, lane, &tmax);           // this pair's ||t||max (the slack is relative to it) ...
+    if (B > 1) mode = knn_batch_mode(midflag0, bmax0, B, lane);       // ... and the arithmetic the batch's filter launch ran
     if (force_mode >= 0) mode = force_mode;
     const float eps_coef = mode == kModeHalfExact ? kEpsExact : mode == kModeHalf ? kEpsHalf : mode == kModeSplit ? kEpsSplit : kEpsF32;
 
     // streams of this workgroup's query row block = filter blocks that touched it (contiguous slots from 0);
     // the queries of a workgroup share the row block (rows_per_block is a multiple of 16)
-    const int rb = (bid * kRefQ) / rows_per_block;
+    const int rb = pb * n_rb1 + (bid * kRefQ) / rows_per_block;      // GLOBAL row block (the partition tables span the batch)
     const int fb = rb_first[rb];
     const int lb = rb_last[rb];
     const int NC = 2 * (lb - fb + 1) * nsub * 3;
@@ -1219,7 +1301,7 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
         i1v[k] = (valid && c < NC) ? ci[c] : -1;
     }
     __syncthreads();                                     // query rows in LDS
-    if (trace && threadIdx.x == 0) trace[16 * bid + 1] = wall_clock64();
+    if (trace && threadIdx.x == 0) trace[16 * bidt + 1] = wall_clock64();
     float qq;
     {
         const float4 a = *reinterpret_cast<const float4*>(&qrows[ql][8 * sl]), c4 = *reinterpret_cast<const float4*>(&qrows[ql][8 * sl + 4]);
@@ -1254,7 +1336,7 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
     // m2 + 1.5*eps: farther than both by > eps/2 >= 300u*(|q|+|t|)^2, which also separates the float32 square roots
     // (one ulp of sqrtf is < 2^-22 relative in d^2) — it cannot be in the exact top-2, ties included.
     const float thr = m2 + 2.5f * eps;
-    if (trace && threadIdx.x == 0) trace[16 * bid + 2] = wall_clock64();
+    if (trace && threadIdx.x == 0) trace[16 * bidt + 2] = wall_clock64();
 
     // Sweep 2: the survivors of ALL candidate chunks are compacted in LDS first, then evaluated 8 per pass (a lane
     // pair each), so the dependent train-row fetches of a query overlap instead of costing one round trip per chunk.
@@ -1373,7 +1455,7 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
     for (int round = 0;; ++round) {
         if (round == 1) evaluate();                       // rescan survivors (cold site)
         best2_group_reduce<16>(b);
-        if (trace && threadIdx.x == 0 && round == 0) trace[16 * bid + 3] = wall_clock64();
+        if (trace && threadIdx.x == 0 && round == 0) trace[16 * bidt + 3] = wall_clock64();
         if (round == 1) break;
         // Certificate.  (s3 < 0 can only be rounding noise: such a stream never certifies.)
         lim = b.i[1] != INT_MAX ? (double)b.dsq[1] + (double)eps : (double)kInf;
@@ -1423,7 +1505,7 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
                 const int t_end = min((int)(u1 - (int64_t)rb * tiles), t_begin + kSubTiles);
                 const int ntr = (t_end - t_begin) * 16;
                 auto train_of = [&](int i) { return (t_begin + (i >> 4)) * kTileT + (i & 3) + 8 * ((i >> 2) & 3) + 4 * h; };
-                if (trace && threadIdx.x == 0 && !trace[16 * bid + 6]) trace[16 * bid + 6] = wall_clock64();
+                if (trace && threadIdx.x == 0 && !trace[16 * bidt + 6]) trace[16 * bidt + 6] = wall_clock64();
                 // Which of the stream's trains need the exact arithmetic?  In the fp16 modes the fp16 image (L2-resident:
                 // the filter just streamed it; half the bytes of the fp32 rows in HBM) gives s' = ||t||^2 + ||q||^2 - 2 q.t^
                 // with |s' - d^2| <= eps (only t is rounded here, the filter rounds both operands), so only trains with
@@ -1473,7 +1555,7 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
                 }
                 __syncthreads();
                 const int ns = nsurv;
-                if (trace && threadIdx.x == 0 && !trace[16 * bid + 7]) { trace[16 * bid + 7] = wall_clock64(); trace[16 * bid + 10] = ns; }
+                if (trace && threadIdx.x == 0 && !trace[16 * bidt + 7]) { trace[16 * bidt + 7] = wall_clock64(); trace[16 * bidt + 10] = ns; }
                 const int have = cnt_lds[w];
                 if (have + ns <= kQualCap) {
                     // the usual case, a few survivors: queue them for the owning query's next (hot) evaluation
@@ -1518,7 +1600,7 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
             }
         }
         if (open) cnt = cnt_lds[ql];                       // survivors queued for this query → round 1
-        if (trace && threadIdx.x == 0) trace[16 * bid + 8] = wall_clock64();
+        if (trace && threadIdx.x == 0) trace[16 * bidt + 8] = wall_clock64();
     }
 
     if (valid && sl == 0) {
@@ -1537,8 +1619,8 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
         if (lane == 0 && n) atomicAdd(ratio_counts + (bid * kRefQ) / kRatioBlock, n);
     }
     if (trace && threadIdx.x == 0) {
-        trace[16 * bid + 4] = wall_clock64();
-        trace[16 * bid + 5] = __builtin_amdgcn_s_getreg(0xF804);
+        trace[16 * bidt + 4] = wall_clock64();
+        trace[16 * bidt + 5] = __builtin_amdgcn_s_getreg(0xF804);
     }
 }
 
@@ -1585,10 +1667,10 @@ __global__ __launch_bounds__(256) void ratio_count_kernel(const int* __restrict_
     if (threadIdx.x == 0) block_count[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-__global__ __launch_bounds__(256) void ratio_scatter_kernel(const int* __restrict__ idx, const float* __restrict__ dist, int nq,
-                                                            double ratio, const int* __restrict__ block_count,
-                                                            int* __restrict__ out_q, int* __restrict__ out_t,
-                                                            int* __restrict__ out_count) {
+__device__ __forceinline__ void ratio_scatter_body(const int* __restrict__ idx, const float* __restrict__ dist, int nq,
+                                                   double ratio, const int* __restrict__ block_count,
+                                                   int* __restrict__ out_q, int* __restrict__ out_t,
+                                                   int* __restrict__ out_count) {
     __shared__ int wsum[4];
     __shared__ int base_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1629,6 +1711,20 @@ __global__ __launch_bounds__(256) void ratio_scatter_kernel(const int* __restric
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) *out_count = pos;   // last thread of the last workgroup: total
 }
 
+__global__ __launch_bounds__(256) void ratio_scatter_kernel(const int* __restrict__ idx, const float* __restrict__ dist, int nq,
+                                                            double ratio, const int* __restrict__ block_count,
+                                                            int* __restrict__ out_q, int* __restrict__ out_t,
+                                                            int* __restrict__ out_count) {
+    ratio_scatter_body(idx, dist, nq, ratio, block_count, out_q, out_t, out_count);
+}
+
+// Batched form: grid = (blocks, B), column b scatters pair b.
+__global__ __launch_bounds__(256) void ratio_scatter_batch_kernel(BatchPtrs P, int nq, double ratio, const int* __restrict__ block_count,
+                                                                  int count_stride) {
+    const int pb = blockIdx.y;
+    ratio_scatter_body(P.idx[pb], P.dist[pb], nq, ratio, block_count + pb * count_stride, P.out_q[pb], P.out_t[pb], P.out_count[pb]);
+}
+
 __global__ __launch_bounds__(256) void gather_matches_kernel(const float2* __restrict__ kp0, const float2* __restrict__ kp1,
                                                              const int* __restrict__ oq, const int* __restrict__ ot,
                                                              const int* __restrict__ count, int64_t capacity,
@@ -1655,34 +1751,42 @@ long long* g_trace = nullptr;   // dev diagnostics only
 int g_force_mode = [] { const char* e = getenv("SFM_KNN_MODE"); return !e ? -1 : e[0] == 's' ? kModeSplit : e[0] == 'h' ? kModeHalf : -1; }();
 
 struct KnnWs {
-    unsigned short* qsplit;
+    unsigned short* qsplit;       // per-pair arrays: pair b at base + b * stride (elements)
     unsigned short* tsplit;
     float* qn;
     float* tn;
-    float* bmax;
+    float* bmax;                  // [B][kNormBlocks]
     int* midflag;
-    int64_t* wg_begin;            // partition tables (filled by the prep / norms launch)
+    int64_t* wg_begin;            // partition tables over the whole batch (filled by the prep / norms launch)
     int* rb_first;
     int* rb_last;
     float* cand_s;
     int* cand_i;
+    int64_t s_qsplit, s_tsplit, s_qn, s_tn, s_cand;
     size_t bytes;
 };
 
 KnnWs carve_ws(void* ws, int64_t nq, int64_t nt, const Plan& p) {
+    (void)nt;
     sfm::Carver c(ws);
     KnnWs w;
-    w.bmax = c.take<float>(kNormBlocks);
-    w.midflag = c.take<int>(kNormBlocks);
+    const size_t B = (size_t)p.B;
+    w.s_tn = (int64_t)p.tiles * kTileT;
+    w.s_qn = p.nq_pad;
+    w.s_qsplit = (int64_t)p.nq_pad * kDim * 3;
+    w.s_tsplit = (int64_t)p.tiles * kTileT * kDim * 3;
+    w.s_cand = (int64_t)nq * 2 * p.smax * p.nsub * 3;
+    w.bmax = c.take<float>(B * kNormBlocks);
+    w.midflag = c.take<int>(B * kNormBlocks);
     w.wg_begin = c.take<int64_t>((size_t)p.G + 1);
     w.rb_first = c.take<int>((size_t)p.n_rb);
     w.rb_last = c.take<int>((size_t)p.n_rb);
-    w.tn = c.take<float>((size_t)p.tiles * kTileT);
-    w.qn = c.take<float>((size_t)p.nq_pad);
-    w.qsplit = c.take<unsigned short>((size_t)p.nq_pad * kDim * 3);
-    w.tsplit = c.take<unsigned short>((size_t)p.tiles * kTileT * kDim * 3);
-    w.cand_s = c.take<float>((size_t)nq * 2 * p.smax * p.nsub * 3);
-    w.cand_i = c.take<int>((size_t)nq * 2 * p.smax * p.nsub * 3);
+    w.tn = c.take<float>(B * (size_t)w.s_tn);
+    w.qn = c.take<float>(B * (size_t)w.s_qn);
+    w.qsplit = c.take<unsigned short>(B * (size_t)w.s_qsplit);
+    w.tsplit = c.take<unsigned short>(B * (size_t)w.s_tsplit);
+    w.cand_s = c.take<float>(B * (size_t)w.s_cand);
+    w.cand_i = c.take<int>(B * (size_t)w.s_cand);
     w.bytes = c.used();
     return w;
 }
@@ -1701,33 +1805,43 @@ extern "C" int sfm_debug_set_trace(void* dev_buf) {
     return SFM_OK;
 }
 
-extern "C" size_t sfm_knn2_l2_f32_ws_bytes(int64_t nq, int64_t nt, int dim) {
-    if (nq < 0 || nt < 0 || dim != kDim) return 0;
-    const Plan p = make_plan(nq, nt);
+namespace {
+size_t knn_ws_bytes(int64_t nq, int64_t nt, int dim, int B) {
+    if (nq < 0 || nt < 0 || dim != kDim || B < 1 || B > kMaxBatch) return 0;
+    if (B > 1 && g_filter_mode == 1) return 0;                 // the fp32-MFMA variant is single-pair
+    const Plan p = make_plan(nq, nt, B);
     return carve_ws(nullptr, nq, nt, p).bytes + 256;
 }
 
-namespace {
-// KNN, optionally fused with the Lowe-ratio survivor count (ratio_counts != null: one int per 1024 queries).
-int knn2_impl(const float* q, int64_t nq, int64_t ldq, const float* t, int64_t nt, int64_t ldt, int dim, int32_t* idx,
-              float* dist, int32_t* stats, void* ws, size_t ws_bytes, void* stream_, double ratio, int* ratio_counts,
-              unsigned char* ratio_mask) {
+size_t ratio_ws_bytes(int64_t nq, int B) {
+    return sfm::align_up((size_t)B * (size_t)((nq + kRatioBlock - 1) / kRatioBlock + 1) * sizeof(int), 256) + 256;
+}
+
+// KNN of B equally shaped pairs in ONE set of launches (prep, filter, refine), optionally fused with the Lowe-ratio
+// survivor count (ratio_counts != null: ratio_stride ints per pair, one per 1024 queries).
+int knn_batch_impl(int B, const BatchPtrs& P, int64_t nq, int64_t ldq, int64_t nt, int64_t ldt, int dim, void* ws, size_t ws_bytes,
+                   void* stream_, double ratio, int* ratio_counts, int ratio_stride) {
     const int ratio_blocks = ratio_counts ? (int)((nq + kRatioBlock - 1) / kRatioBlock) : 0;
     SFM_CHECK_ARG(dim == kDim, "sfm_knn2_l2_f32: dim must be 128 (got %d)", dim);
+    SFM_CHECK_ARG(B >= 1 && B <= kMaxBatch, "sfm_match_batch_l2_f32: 1 <= batch <= %d (got %d)", kMaxBatch, B);
     SFM_CHECK_ARG(nq >= 0 && nt >= 0 && nq < INT_MAX / 256 && nt < INT_MAX / 2, "sfm_knn2_l2_f32: bad sizes nq=%lld nt=%lld",
                   (long long)nq, (long long)nt);
     if (nq == 0) return SFM_OK;
-    SFM_CHECK_ARG(q && idx && dist && (t || nt == 0), "sfm_knn2_l2_f32: null pointer");
+    for (int b = 0; b < B; ++b) {
+        SFM_CHECK_ARG(P.q[b] && P.idx[b] && P.dist[b] && (P.t[b] || nt == 0), "sfm_knn2_l2_f32: null pointer");
+        SFM_CHECK_ARG(((uintptr_t)P.q[b] & 15) == 0 && ((uintptr_t)P.t[b] & 15) == 0, "sfm_knn2_l2_f32: q/t must be 16-byte aligned");
+    }
     SFM_CHECK_ARG(ldq >= dim && ldt >= dim && ldq % 4 == 0 && ldt % 4 == 0, "sfm_knn2_l2_f32: ldq/ldt must be >= dim and multiples of 4");
-    SFM_CHECK_ARG(((uintptr_t)q & 15) == 0 && ((uintptr_t)t & 15) == 0, "sfm_knn2_l2_f32: q/t must be 16-byte aligned");
+    hipStream_t stream = sfm::as_stream(stream_);
     if (nt == 0) {   // no train rows: OpenCV leaves idx = -1 (and emits no DMatch)
-        hipLaunchKernelGGL(knn_fill_empty_kernel, dim3((unsigned)((2 * nq + 255) / 256)), dim3(256), 0, sfm::as_stream(stream_),
-                           idx, dist, 2 * nq, stats);
+        for (int b = 0; b < B; ++b)
+            hipLaunchKernelGGL(knn_fill_empty_kernel, dim3((unsigned)((2 * nq + 255) / 256)), dim3(256), 0, stream, P.idx[b], P.dist[b], 2 * nq, P.stats[b]);
         SFM_CHECK_LAUNCH();
         return SFM_OK;
     }
-    const Plan p = make_plan(nq, nt);
-    const size_t need = sfm_knn2_l2_f32_ws_bytes(nq, nt, dim);
+    SFM_CHECK_ARG(B == 1 || g_filter_mode != 1, "sfm_match_batch_l2_f32: the fp32-MFMA filter variant is single-pair");
+    const Plan p = make_plan(nq, nt, B);
+    const size_t need = knn_ws_bytes(nq, nt, dim, B);
     if (!ws || ws_bytes < need) {
         sfm::set_error("sfm_knn2_l2_f32: workspace too small (%zu < %zu)", ws_bytes, need);
         return SFM_ERR_WORKSPACE;
@@ -1735,23 +1849,24 @@ int knn2_impl(const float* q, int64_t nq, int64_t ldq, const float* t, int64_t n
     // carve from a 256-aligned base inside the caller's buffer
     char* base = reinterpret_cast<char*>(sfm::align_up((size_t)(uintptr_t)ws, 256));
     const KnnWs w = carve_ws(base, nq, nt, p);
-    hipStream_t stream = sfm::as_stream(stream_);
 
     const dim3 grid((unsigned)p.G);
     const int prof_reps = p.split ? sfm::prof_repeat() : 1;
     static const int abl = [] { const char* e = getenv("SFM_KNN_ABL"); return e ? atoi(e) : 0; }();   // dev only
     if (p.split) {
-        hipLaunchKernelGGL(knn_prep_kernel, dim3(kNormBlocks + 1), dim3(1024), 0, stream, q, ldq, (int)nq, p.nq_pad, t, ldt, (int)nt,
-                           p.tiles * kTileT, w.qsplit, w.qn, w.tsplit, w.tn, w.bmax, w.midflag, stats, ratio_counts, ratio_blocks,
+        hipLaunchKernelGGL(knn_prep_kernel, dim3(kNormBlocks + 1, (unsigned)B), dim3(1024), 0, stream, P, ldq, (int)nq, p.nq_pad, ldt, (int)nt,
+                           p.tiles * kTileT, w.qsplit, w.qn, w.tsplit, w.tn, w.bmax, w.midflag, w.s_qsplit, w.s_tsplit, w.s_qn, w.s_tn,
+                           ratio_counts, ratio_counts ? ratio_stride : 0,
                            p.units, p.tiles, p.G, p.seg_cost, p.n_rb, w.wg_begin, w.rb_first, w.rb_last);
         SFM_CHECK_LAUNCH();
         sfm::prof_begin(sfm::kProfKnnFilter, stream);
 #define SFM_LAUNCH_SPLIT2(A, WV)                                                                                        \
     hipLaunchKernelGGL((knn_filter_split2_kernel<A, WV>), grid, dim3(64 * WV), kRingLdsBytes + (WV == 4 ? kQScratchBytes : 0), stream, w.qsplit, w.qn,    \
                        (int)nq, p.nq_pad, w.tsplit, (int)nt, p.tiles * kTileT, w.tn, p.tiles, p.units, p.smax, p.nsub,    \
-                       w.midflag, w.bmax, g_force_mode, w.cand_s, w.cand_i, w.wg_begin, w.rb_first, g_trace)
+                       w.midflag, w.bmax, g_force_mode, w.cand_s, w.cand_i, w.wg_begin, w.rb_first, p.n_rb1, B, w.s_qsplit, w.s_tsplit,    \
+                       w.s_qn, w.s_tn, w.s_cand, g_trace)
         // sfm_profile_enable(n > 1): the filter is launched n times back-to-back inside ONE event pair (idempotent: same
-        // inputs, same candidate records), so the ~7 us an event pair adds to a single 39 us launch is amortised
+        // inputs, same candidate records), so the ~7 us an event pair adds to a single launch is amortised
         for (int rep = 0; rep < prof_reps; ++rep) {
         if (p.waves == 4) {
             if (abl == 1) SFM_LAUNCH_SPLIT2(1, 4); else if (abl == 2) SFM_LAUNCH_SPLIT2(2, 4); else if (abl == 4) SFM_LAUNCH_SPLIT2(4, 4);
@@ -1764,8 +1879,10 @@ int knn2_impl(const float* q, int64_t nq, int64_t ldq, const float* t, int64_t n
         }
 #undef SFM_LAUNCH_SPLIT2
     } else {
+    const float* q = P.q[0];
+    const float* t = P.t[0];
     hipLaunchKernelGGL(knn_norms_kernel, dim3(kNormBlocks + 1), dim3(256), 0, stream, t, ldt, (int)nt, w.tn, w.bmax,
-                       stats, ratio_counts, ratio_blocks, p.units, p.tiles, p.G, p.seg_cost, p.n_rb, w.wg_begin, w.rb_first, w.rb_last);
+                       P.stats[0], ratio_counts, ratio_blocks, p.units, p.tiles, p.G, p.seg_cost, p.n_rb, w.wg_begin, w.rb_first, w.rb_last);
     SFM_CHECK_LAUNCH();
     sfm::prof_begin(sfm::kProfKnnFilter, stream);
 #define SFM_LAUNCH_FILTER(A, WV)                                                                                     \
@@ -1795,22 +1912,33 @@ int knn2_impl(const float* q, int64_t nq, int64_t ldq, const float* t, int64_t n
     sfm::prof_end(sfm::kProfKnnFilter, stream, prof_reps);
     SFM_CHECK_LAUNCH();
     const int force_mode = !p.split ? kModeF32 : g_force_mode;
-    const int64_t refine_wgs = (nq + kRefQ - 1) / kRefQ, refine_grid = refine_wgs >= 64 ? 8 * ((refine_wgs + 7) / 8) : refine_wgs;
+    const int64_t refine_wgs = (int64_t)B * ((nq + kRefQ - 1) / kRefQ), refine_grid = refine_wgs >= 64 ? 8 * ((refine_wgs + 7) / 8) : refine_wgs;
     sfm::prof_begin(sfm::kProfKnnRefine, stream);
-    hipLaunchKernelGGL(knn_refine_kernel, dim3((unsigned)refine_grid), dim3(256), 0, stream, q, ldq, (int)nq, t, ldt,
+    hipLaunchKernelGGL(knn_refine_kernel, dim3((unsigned)refine_grid), dim3(256), 0, stream, P, B, ldq, (int)nq, ldt,
                        (int)nt, w.cand_s, w.cand_i, p.rows_per_block, p.tiles, p.units, p.G, p.smax * p.nsub, p.nsub,
-                       force_mode, w.midflag, w.bmax, p.split ? w.tsplit + (size_t)2 * p.tiles * kTileT * kDim : nullptr, w.tn, w.wg_begin, w.rb_first, w.rb_last, idx, dist,
-                       stats, ratio, ratio_counts, ratio_mask, g_trace ? g_trace + 16384 : nullptr);
+                       force_mode, w.midflag, w.bmax, p.split ? w.tsplit + (size_t)2 * p.tiles * kTileT * kDim : nullptr, w.tn, w.wg_begin, w.rb_first, w.rb_last,
+                       p.n_rb1, w.s_cand, w.s_tsplit, w.s_tn, ratio, ratio_counts, ratio_stride, g_trace ? g_trace + 16384 : nullptr);
     sfm::prof_end(sfm::kProfKnnRefine, stream);
     SFM_CHECK_LAUNCH();
     return SFM_OK;
 }
+
+BatchPtrs single_pair(const float* q, const float* t, int32_t* idx, float* dist, int32_t* stats, int32_t* out_q, int32_t* out_t,
+                      int32_t* out_count, uint8_t* mask) {
+    BatchPtrs P{};
+    P.q[0] = q; P.t[0] = t; P.idx[0] = idx; P.dist[0] = dist; P.stats[0] = stats;
+    P.out_q[0] = out_q; P.out_t[0] = out_t; P.out_count[0] = out_count; P.mask[0] = mask;
+    return P;
+}
 }  // namespace
+
+extern "C" size_t sfm_knn2_l2_f32_ws_bytes(int64_t nq, int64_t nt, int dim) { return knn_ws_bytes(nq, nt, dim, 1); }
 
 extern "C" int sfm_knn2_l2_f32(const float* q, int64_t nq, int64_t ldq, const float* t, int64_t nt, int64_t ldt,
                                int dim, int32_t* idx, float* dist, int32_t* stats, void* ws, size_t ws_bytes,
                                void* stream_) {
-    return knn2_impl(q, nq, ldq, t, nt, ldt, dim, idx, dist, stats, ws, ws_bytes, stream_, 0.0, nullptr, nullptr);
+    return knn_batch_impl(1, single_pair(q, t, idx, dist, stats, nullptr, nullptr, nullptr, nullptr), nq, ldq, nt, ldt, dim, ws, ws_bytes,
+                          stream_, 0.0, nullptr, 0);
 }
 
 extern "C" size_t sfm_ratio_compact_ws_bytes(int64_t nq) {
@@ -1843,39 +1971,71 @@ extern "C" int sfm_ratio_compact(const int32_t* idx, const float* dist, int64_t 
     return SFM_OK;
 }
 
-extern "C" size_t sfm_match_l2_f32_ws_bytes(int64_t nq, int64_t nt, int dim) {
-    const size_t k = sfm_knn2_l2_f32_ws_bytes(nq, nt, dim);
-    return k ? k + sfm_ratio_compact_ws_bytes(nq) : 0;
+extern "C" size_t sfm_match_batch_l2_f32_ws_bytes(int64_t nq, int64_t nt, int dim, int batch) {
+    const size_t k = knn_ws_bytes(nq, nt, dim, batch);
+    return k ? k + ratio_ws_bytes(nq, batch) : 0;
 }
+
+extern "C" size_t sfm_match_l2_f32_ws_bytes(int64_t nq, int64_t nt, int dim) { return sfm_match_batch_l2_f32_ws_bytes(nq, nt, dim, 1); }
+
+namespace {
+int match_batch_impl(int B, const BatchPtrs& P, int64_t nq, int64_t ldq, int64_t nt, int64_t ldt, int dim, double ratio, void* ws,
+                     size_t ws_bytes, void* stream_) {
+    SFM_CHECK_ARG(B >= 1 && B <= kMaxBatch, "sfm_match_batch_l2_f32: 1 <= batch <= %d (got %d)", kMaxBatch, B);
+    SFM_CHECK_ARG(nq >= 0 && nq < INT_MAX / 256, "sfm_match_l2_f32: bad nq");
+    for (int b = 0; b < B; ++b) SFM_CHECK_ARG(P.out_count[b] && (nq == 0 || (P.out_q[b] && P.out_t[b])), "sfm_match_l2_f32: null pointer");
+    hipStream_t stream = sfm::as_stream(stream_);
+    if (nq == 0 || nt == 0) {   // no neighbours, no matches
+        for (int b = 0; b < B; ++b) {
+            SFM_CHECK_HIP(hipMemsetAsync(P.out_count[b], 0, sizeof(int32_t), stream));
+            if (P.mask[b] && nq > 0) SFM_CHECK_HIP(hipMemsetAsync(P.mask[b], 0, (size_t)nq, stream));
+        }
+        return knn_batch_impl(B, P, nq, ldq, nt, ldt, dim, ws, ws_bytes, stream_, 0.0, nullptr, 0);
+    }
+    const size_t rbytes = ratio_ws_bytes(nq, B);
+    const size_t need = sfm_match_batch_l2_f32_ws_bytes(nq, nt, dim, B);
+    if (!ws || ws_bytes < need || need == 0) {
+        SFM_CHECK_ARG(dim == kDim, "sfm_match_l2_f32: dim must be 128 (got %d)", dim);
+        SFM_CHECK_ARG(B == 1 || g_filter_mode != 1, "sfm_match_batch_l2_f32: the fp32-MFMA filter variant is single-pair");
+        sfm::set_error("sfm_match_l2_f32: workspace too small (%zu < %zu)", ws_bytes, need);
+        return SFM_ERR_WORKSPACE;
+    }
+    int* counts = reinterpret_cast<int*>(sfm::align_up((size_t)(uintptr_t)ws, 256));
+    const unsigned blocks = (unsigned)((nq + kRatioBlock - 1) / kRatioBlock);
+    const int stride = (int)blocks + 1;
+    const int rc = knn_batch_impl(B, P, nq, ldq, nt, ldt, dim, static_cast<char*>(ws) + rbytes, ws_bytes - rbytes, stream_, ratio, counts, stride);
+    if (rc != SFM_OK) return rc;
+    hipLaunchKernelGGL(ratio_scatter_batch_kernel, dim3(blocks, (unsigned)B), dim3(256), 0, stream, P, (int)nq, ratio, counts, stride);
+    SFM_CHECK_LAUNCH();
+    return SFM_OK;
+}
+}  // namespace
 
 extern "C" int sfm_match_l2_f32(const float* q, int64_t nq, int64_t ldq, const float* t, int64_t nt, int64_t ldt, int dim,
                                 double ratio, int32_t* idx, float* dist, int32_t* out_q, int32_t* out_t,
                                 int32_t* out_count, uint8_t* mask, int32_t* stats, void* ws, size_t ws_bytes,
                                 void* stream_) {
     SFM_CHECK_ARG(out_count && (nq == 0 || (out_q && out_t)), "sfm_match_l2_f32: null pointer");
-    SFM_CHECK_ARG(nq >= 0 && nq < INT_MAX / 256, "sfm_match_l2_f32: bad nq");
-    hipStream_t stream = sfm::as_stream(stream_);
-    if (nq == 0 || nt == 0) {   // no neighbours, no matches
-        SFM_CHECK_HIP(hipMemsetAsync(out_count, 0, sizeof(int32_t), stream));
-        if (mask && nq > 0) SFM_CHECK_HIP(hipMemsetAsync(mask, 0, (size_t)nq, stream));
-        return knn2_impl(q, nq, ldq, t, nt, ldt, dim, idx, dist, stats, ws, ws_bytes, stream_, 0.0, nullptr, nullptr);
+    return match_batch_impl(1, single_pair(q, t, idx, dist, stats, out_q, out_t, out_count, mask), nq, ldq, nt, ldt, dim, ratio, ws, ws_bytes, stream_);
+}
+
+// `batch` (<= 8) image pairs of one shape in ONE set of launches: the unit space of the filter is batch x row blocks x
+// tiles under a single partition, so a workgroup's prologue, the launch ramp and the kernel boundaries are paid once
+// per batch instead of once per pair.  Pointer arrays are HOST arrays of device pointers (mask / stats entries may be NULL).
+extern "C" int sfm_match_batch_l2_f32(int batch, const float* const* q, int64_t nq, int64_t ldq, const float* const* t, int64_t nt,
+                                      int64_t ldt, int dim, double ratio, int32_t* const* idx, float* const* dist,
+                                      int32_t* const* out_q, int32_t* const* out_t, int32_t* const* out_count, uint8_t* const* mask,
+                                      int32_t* const* stats, void* ws, size_t ws_bytes, void* stream_) {
+    SFM_CHECK_ARG(batch >= 1 && batch <= kMaxBatch, "sfm_match_batch_l2_f32: 1 <= batch <= %d (got %d)", kMaxBatch, batch);
+    SFM_CHECK_ARG(q && t && idx && dist && out_q && out_t && out_count, "sfm_match_batch_l2_f32: null pointer array");
+    BatchPtrs P{};
+    for (int b = 0; b < batch; ++b) {
+        P.q[b] = q[b]; P.t[b] = t[b]; P.idx[b] = idx[b]; P.dist[b] = dist[b];
+        P.out_q[b] = out_q[b]; P.out_t[b] = out_t[b]; P.out_count[b] = out_count[b];
+        P.mask[b] = mask ? mask[b] : nullptr;
+        P.stats[b] = stats ? stats[b] : nullptr;
     }
-    const size_t rbytes = sfm_ratio_compact_ws_bytes(nq);
-    const size_t need = sfm_match_l2_f32_ws_bytes(nq, nt, dim);
-    if (!ws || ws_bytes < need || need == 0) {
-        SFM_CHECK_ARG(dim == kDim, "sfm_match_l2_f32: dim must be 128 (got %d)", dim);
-        sfm::set_error("sfm_match_l2_f32: workspace too small (%zu < %zu)", ws_bytes, need);
-        return SFM_ERR_WORKSPACE;
-    }
-    int* counts = reinterpret_cast<int*>(sfm::align_up((size_t)(uintptr_t)ws, 256));
-    const int rc = knn2_impl(q, nq, ldq, t, nt, ldt, dim, idx, dist, stats, static_cast<char*>(ws) + rbytes, ws_bytes - rbytes,
-                             stream_, ratio, counts, mask);
-    if (rc != SFM_OK) return rc;
-    const unsigned blocks = (unsigned)((nq + kRatioBlock - 1) / kRatioBlock);
-    hipLaunchKernelGGL(ratio_scatter_kernel, dim3(blocks), dim3(256), 0, stream, idx, dist, (int)nq, ratio, counts, out_q,
-                       out_t, out_count);
-    SFM_CHECK_LAUNCH();
-    return SFM_OK;
+    return match_batch_impl(batch, P, nq, ldq, nt, ldt, dim, ratio, ws, ws_bytes, stream_);
 }
 
 extern "C" int sfm_gather_matches(const float* kp0, const float* kp1, const int32_t* out_q, const int32_t* out_t,

