@@ -1,0 +1,24 @@
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sfm_mvs_amd import ops
+nq = nt = 10000
+q = torch.rand((nq, 128)).cuda(); t = torch.rand((nt, 128)).cuda()
+for B in (1, 4, 8):
+    bm = ops.BatchMatcher(nq, nt, q.device, batch=B)
+    pairs = [(q, t)] * B
+    for _ in range(3): bm.run(pairs)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(50): bm.run(pairs)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print(f"B={B}: enqueue {1e6*(t1-t0)/50:.1f} us per run(), total {1e6*(t2-t0)/50:.1f} us per run()")
+pm = ops.PairMatcher(nq, nt, q.device)
+for _ in range(3): pm.run(q, t)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(50): pm.run(q, t)
+t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+print(f"PairMatcher: enqueue {1e6*(t1-t0)/50:.1f} us, total {1e6*(t2-t0)/50:.1f} us")
