@@ -520,6 +520,17 @@ __global__ __launch_bounds__(64 * W, 4) void knn_filter_kernel(
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// c + sum of eight fp16 products (v_dot2_f32_f16 x 4: exact products, fp32 accumulation)
+__device__ __forceinline__ float dot8_f16(const uint4& a, const uint4& b, float c) {
+    c = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, a.x), __builtin_bit_cast(f16x2, b.x), c, false);
+    c = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, a.y), __builtin_bit_cast(f16x2, b.y), c, false);
+    c = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, a.z), __builtin_bit_cast(f16x2, b.z), c, false);
+    c = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, a.w), __builtin_bit_cast(f16x2, b.w), c, false);
+    return c;
+}
 
 __device__ __forceinline__ unsigned bf16_rn_bits(float x) {
     const unsigned u = __float_as_uint(x);
@@ -552,6 +563,7 @@ __device__ __forceinline__ int knn_filter_mode(const int* __restrict__ flags, co
 // The arithmetic mode of a BATCH of pairs (one launch, one body): the most general mode any of its pairs needs — the
 // modes are nested (fp16-exact data are fp16-representable data are split-representable data), and the refine kernel
 // prices its slack with the same batch mode, so every pair is certified against the arithmetic that actually ran.
+constexpr int kMinfoPairMode = 0, kMinfoBatchMode = kMaxBatch, kMinfoTmax = 16, kMinfoWords = 32;   // written by filter block 0
 __device__ __forceinline__ int knn_batch_mode(const int* __restrict__ flags, const float* __restrict__ bmax, int n_pairs, int lane) {
     int mode = kModeHalfExact;
     for (int b = 0; b < n_pairs; ++b) mode = max(mode, knn_filter_mode(flags + b * kNormBlocks, bmax + b * kNormBlocks, lane));
@@ -1013,8 +1025,24 @@ __global__ __launch_bounds__(64 * W, 2) void knn_filter_split2_kernel(
     const unsigned short* __restrict__ tsplit, int nt, int nt_pad, const float* __restrict__ tn, int tiles, int64_t units,
     int smax, int nsub, const int* __restrict__ midflag, const float* __restrict__ bmax, int force_mode,
     float* __restrict__ cand_s, int* __restrict__ cand_i, const int64_t* __restrict__ wg_begin, const int* __restrict__ rb_first,
-    int n_rb1, int n_pairs, int64_t s_qsplit, int64_t s_tsplit, int64_t s_qn, int64_t s_tn, int64_t s_cand, long long* __restrict__ trace) {
+    int n_rb1, int n_pairs, int64_t s_qsplit, int64_t s_tsplit, int64_t s_qn, int64_t s_tn, int64_t s_cand, int* __restrict__ minfo,
+    long long* __restrict__ trace) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        // what the refine kernel needs of the flags, reduced ONCE (its 4 waves x thousands of workgroups used to re-derive
+        // it from the 2 x 256 x n_pairs words): per pair the mode and ||t||max, and the batch's mode
+        int bm = kModeHalfExact;
+        for (int b = 0; b < n_pairs; ++b) {
+            float tmax;
+            const int m = knn_filter_mode(midflag + b * kNormBlocks, bmax + b * kNormBlocks, (int)threadIdx.x, &tmax);
+            bm = max(bm, m);
+            if (threadIdx.x == 0) {
+                minfo[kMinfoPairMode + b] = m;
+                minfo[kMinfoTmax + b] = __float_as_int(tmax);
+            }
+        }
+        if (threadIdx.x == 0) minfo[kMinfoBatchMode] = bm;
+    }
     if (trace && threadIdx.x == 0) {
         trace[4 * blockIdx.x + 0] = wall_clock64();
         trace[4 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg(0xF804);
@@ -1057,9 +1085,10 @@ __device__ __forceinline__ float lane_odd_neighbour(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xF5 /*quad_perm [1,1,3,3]*/, 0xF, 0xF, false));
 }
 
+__device__ __forceinline__ int imed3(int a, int b, int c) { return max(min(a, b), min(max(a, b), c)); }   // v_med3_i32
+
 struct Best2 {
     float d[2];     // sqrtf distance
-    float dsq[2];   // its square (certificate)
     int i[2];
 };
 
@@ -1067,14 +1096,18 @@ __device__ __forceinline__ bool key_less(float da, int ia, float db, int ib) {
     return da < db || (da == db && ia < ib);
 }
 
-__device__ __forceinline__ void best2_insert(Best2& b, float d, float dsq, int i) {
+__device__ __forceinline__ void best2_insert(Best2& b, float d, int i) {
     if (key_less(d, i, b.d[0], b.i[0])) {
-        b.d[1] = b.d[0]; b.dsq[1] = b.dsq[0]; b.i[1] = b.i[0];
-        b.d[0] = d; b.dsq[0] = dsq; b.i[0] = i;
+        b.d[1] = b.d[0]; b.i[1] = b.i[0];
+        b.d[0] = d; b.i[0] = i;
     } else if (key_less(d, i, b.d[1], b.i[1])) {
-        b.d[1] = d; b.dsq[1] = dsq; b.i[1] = i;
+        b.d[1] = d; b.i[1] = i;
     }
 }
+
+// Upper bound of the exact d^2 behind a float32 distance d = RN(sqrt(d^2)): d^2 <= (d / (1 - 2^-24))^2 < d*d * (1 + 2^-22)
+// (the certificate needs d2^2 from above; carrying the squares next to the distances cost a third of the merge network).
+__device__ __forceinline__ double dsq_upper(float d) { return (double)d * (double)d * (1.0 + 2.384185791015625e-07); }
 
 // ---------------------------------------------------------------- refine
 // Slack coefficients of the refine kernel's certificate, relative to (|q|+|t|max)^2:
@@ -1093,18 +1126,18 @@ constexpr float kEpsHalf = kEpsExact + 4.8840e-4f;
 constexpr float kEpsHalfAbs = 1.3811e-3f;
 constexpr int kModeF32 = 3;   // fp32-MFMA filter (host-selected)
 
-__device__ __forceinline__ void best2_insert_unique(Best2& b, float d, float dsq, int i) {
+__device__ __forceinline__ void best2_insert_unique(Best2& b, float d, int i) {
     if (i == b.i[0] || i == b.i[1]) return;          // the same train seen twice (a stream's own top-3 are rescanned)
-    best2_insert(b, d, dsq, i);
+    best2_insert(b, d, i);
 }
 
 template <int M>
 __device__ __forceinline__ void best2_exchange_step(Best2& b) {
     Best2 o;
-    o.d[0] = lane_xor<M>(b.d[0]); o.dsq[0] = lane_xor<M>(b.dsq[0]); o.i[0] = lane_xor<M>(b.i[0]);
-    o.d[1] = lane_xor<M>(b.d[1]); o.dsq[1] = lane_xor<M>(b.dsq[1]); o.i[1] = lane_xor<M>(b.i[1]);
-    best2_insert_unique(b, o.d[0], o.dsq[0], o.i[0]);
-    best2_insert_unique(b, o.d[1], o.dsq[1], o.i[1]);
+    o.d[0] = lane_xor<M>(b.d[0]); o.i[0] = lane_xor<M>(b.i[0]);
+    o.d[1] = lane_xor<M>(b.d[1]); o.i[1] = lane_xor<M>(b.i[1]);
+    best2_insert_unique(b, o.d[0], o.i[0]);
+    best2_insert_unique(b, o.d[1], o.i[1]);
 }
 
 template <int WIDTH>
@@ -1128,36 +1161,11 @@ __device__ __forceinline__ float quad_swap(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E /*quad_perm [2,3,0,1]*/, 0xF, 0xF, false));
 }
 
-// Exact d^2 with TWO lanes per train: lane p owns accumulator lanes 4p..4p+3 of the reference order for all 16
-// steps (float4 at elements 8i + 4p), so there is no cross-lane chain and 8 candidates of a 16-lane query group are
-// evaluated in ONE pass — the latency-optimal layout for the refine kernel's short candidate lists.
-// Result valid on the even lane.
-__device__ __forceinline__ float exact_l2sq_pair(const float* __restrict__ qrow /*LDS*/, const float* __restrict__ trow, int p) {
-    float4 t[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) t[i] = *reinterpret_cast<const float4*>(trow + 8 * i + 4 * p);
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    __builtin_amdgcn_sched_barrier(0);                   // all 16 row fetches first ...
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        // ... and the query reads / products at most 4 steps ahead of the adds (hipcc otherwise hoists all of them:
-        // 190 VGPRs, 2 waves per SIMD, and the refine kernel needs 3 for a single resident round at 10^4 queries)
-        if (i % 4 == 0) __builtin_amdgcn_sched_barrier(0);
-        const float4 qv = *reinterpret_cast<const float4*>(qrow + 8 * i + 4 * p);
-        float d;
-        d = qv.x - t[i].x; acc.x = acc.x + d * d;
-        d = qv.y - t[i].y; acc.y = acc.y + d * d;
-        d = qv.z - t[i].z; acc.z = acc.z + d * d;
-        d = qv.w - t[i].w; acc.w = acc.w + d * d;
-    }
-    const float s0 = acc.x + lane_odd_neighbour(acc.x), s1 = acc.y + lane_odd_neighbour(acc.y);
-    const float s2 = acc.z + lane_odd_neighbour(acc.z), s3 = acc.w + lane_odd_neighbour(acc.w);
-    return ((s0 + s1) + s2) + s3;
-}
-
-// The quad evaluation for R trains at once: all 8R row fetches are issued before the first add (the rescan is bound
-// by memory round trips, not arithmetic).  trow[r] == nullptr skips row r.
-template <int R>
+// The quad evaluation for R trains at once: all 8R row fetches are issued before the first add (the kernel is bound by
+// vector-ALU issue and memory round trips, not arithmetic).  NULLABLE: trow[r] == nullptr skips row r.  Differences and
+// squares two elements per instruction (v_pk_add_f32 / v_pk_mul_f32: each half rounds exactly like the scalar op); the
+// running sums stay scalar (their DPP operand is per instruction).
+template <int R, bool NULLABLE>
 __device__ __forceinline__ void exact_l2sq_quad_rows(const float* __restrict__ qrow /*LDS*/, const float* const (&trow)[R], int j,
                                                      float (&out)[R]) {
     float4 t[R][8];
@@ -1165,7 +1173,7 @@ __device__ __forceinline__ void exact_l2sq_quad_rows(const float* __restrict__ q
     for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int n = 0; n < 8; ++n)
-            t[r][n] = trow[r] ? *reinterpret_cast<const float4*>(trow[r] + 16 * n + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+            t[r][n] = (!NULLABLE || trow[r]) ? *reinterpret_cast<const float4*>(trow[r] + 16 * n + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 acc[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1174,18 +1182,14 @@ __device__ __forceinline__ void exact_l2sq_quad_rows(const float* __restrict__ q
         const float4 qv = *reinterpret_cast<const float4*>(qrow + 16 * n + 4 * j);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            float4 x;
-            float d;
-            d = qv.x - t[r][n].x; x.x = d * d;
-            d = qv.y - t[r][n].y; x.y = d * d;
-            d = qv.z - t[r][n].z; x.z = d * d;
-            d = qv.w - t[r][n].w; x.w = d * d;
+            const f32x2 d0 = f32x2{qv.x, qv.y} - f32x2{t[r][n].x, t[r][n].y}, d1 = f32x2{qv.z, qv.w} - f32x2{t[r][n].z, t[r][n].w};
+            const f32x2 x0 = d0 * d0, x1 = d1 * d1;
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
-                acc[r].x = quad_swap(acc[r].x) + x.x;
-                acc[r].y = quad_swap(acc[r].y) + x.y;
-                acc[r].z = quad_swap(acc[r].z) + x.z;
-                acc[r].w = quad_swap(acc[r].w) + x.w;
+                acc[r].x = quad_swap(acc[r].x) + x0.x;
+                acc[r].y = quad_swap(acc[r].y) + x0.y;
+                acc[r].z = quad_swap(acc[r].z) + x1.x;
+                acc[r].w = quad_swap(acc[r].w) + x1.y;
             }
         }
     }
@@ -1204,6 +1208,7 @@ constexpr int kRescanRows = 1;   // trains a quad has in flight during a rescan 
 constexpr int kRefItems = 512;   // rescan work list (query, stream); more → 16 candidate slots per query at a time (<= 96)
 constexpr int kPreRows = 2;      // trains a quad has in flight during the rescan's fp16 prefilter (16 VGPRs each)
 constexpr int kHotPre = 2;       // rows a lane quad has in flight in the hot-path fp16 screen (16 VGPRs each)
+constexpr int kRecCap = 112;     // record list per query
 constexpr int kQualCap = 144;    // exact-evaluation list per query (a chunk of 16 records adds up to 64 rows)
 
 // Sixteen lanes per query, sixteen queries per workgroup (one resident round for 10^4 queries).
@@ -1214,10 +1219,11 @@ constexpr int kQualCap = 144;    // exact-evaluation list per query (a chunk of 
 //   rescan   every other FULL stream (typically none; a handful for ~0.1 % of the queries; all of them for degenerate
 //            train sets) has its <= 512 trains evaluated exactly by the whole workgroup and merged into the query's
 //            answer.  After that the answer equals a full direct-form scan.
-__global__ __launch_bounds__(256, 3) void knn_refine_kernel(
+__global__ __launch_bounds__(256, 4) void knn_refine_kernel(
     BatchPtrs P, int B, int64_t ldq, int nq, int64_t ldt, int nt,
     const float* __restrict__ cand_s, const int* __restrict__ cand_i, int rows_per_block, int tiles, int64_t units,
     int G, int smax, int nsub, int force_mode, const int* __restrict__ midflag, const float* __restrict__ bmax,
+    const int* __restrict__ minfo /*null: derive from the flags (fp32-MFMA filter)*/,
     const unsigned short* __restrict__ thalf /*fp16 image of T, or null*/, const float* __restrict__ tn,
     const int64_t* __restrict__ wg_begin, const int* __restrict__ rb_first, const int* __restrict__ rb_last,
     int n_rb1, int64_t s_cand, int64_t s_tsplit, int64_t s_tn, double ratio,
@@ -1244,7 +1250,9 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
     if (ratio_counts) ratio_counts += pb * ratio_stride;
 
     __shared__ __attribute__((aligned(16))) float qrows[kRefQ][kDim];
-    __shared__ int qual[kRefQ][kQualCap];
+    __shared__ __attribute__((aligned(16))) _Float16 qhalf[kRefQ][kDim];   // fp16(-2 q): the screens' operand (as the filter's)
+    __shared__ int qual[kRefQ][kQualCap];                // rows awaiting the exact evaluation
+    __shared__ int rec[kRefQ][kRecCap];                  // records (first row of four) within the threshold
     __shared__ int items[kRefItems];                     // (query slot << 20) | stream
     __shared__ double q_lim[kRefQ];
     __shared__ float q_qq[kRefQ];
@@ -1265,41 +1273,55 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (row < nq) v = *reinterpret_cast<const float4*>(Q + (int64_t)row * ldq + 4 * (e & 31));
         *reinterpret_cast<float4*>(&qrows[e >> 5][4 * (e & 31)]) = v;
+        const f16x2 h0 = {(_Float16)(-2.f * v.x), (_Float16)(-2.f * v.y)}, h1 = {(_Float16)(-2.f * v.z), (_Float16)(-2.f * v.w)};
+        *reinterpret_cast<uint2*>(&qhalf[e >> 5][4 * (e & 31)]) = make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
     }
     if (threadIdx.x == 0) nitem = nsurv = 0;
 
     // Slack that dominates: rounding of the filter's dot-product chain, of ||q||^2, ||t||^2, of the direct-form
     // sums (<= 24u*d^2) and the final sqrtf merge (8u*d^2) — 600u*(|q|+|t|max)^2, u = 2^-24 — plus what the
     // filter arithmetic that ran loses on top (packed keys; 16-bit operands): see kEps*.
-    float tmax;
-    int mode = knn_filter_mode(midflag, bmax, lane, &tmax);           // this pair's ||t||max (the slack is relative to it) ...
-    if (B > 1) mode = knn_batch_mode(midflag0, bmax0, B, lane);       // ... and the arithmetic the batch's filter launch ran
+    float tmax;                                                       // this pair's ||t||max (the slack is relative to it) ...
+    int mode;                                                         // ... and the arithmetic the batch's filter launch ran
+    if (minfo) {                                                      // (scalar loads of what filter block 0 reduced)
+        tmax = __int_as_float(minfo[kMinfoTmax + pb]);
+        mode = minfo[kMinfoBatchMode];
+    } else {
+        mode = knn_filter_mode(midflag, bmax, lane, &tmax);
+        if (B > 1) mode = knn_batch_mode(midflag0, bmax0, B, lane);
+    }
     if (force_mode >= 0) mode = force_mode;
     const float eps_coef = mode == kModeHalfExact ? kEpsExact : mode == kModeHalf ? kEpsHalf : mode == kModeSplit ? kEpsSplit : kEpsF32;
 
     // streams of this workgroup's query row block = filter blocks that touched it (contiguous slots from 0);
     // the queries of a workgroup share the row block (rows_per_block is a multiple of 16)
     const int rb = pb * n_rb1 + (bid * kRefQ) / rows_per_block;      // GLOBAL row block (the partition tables span the batch)
-    const int fb = rb_first[rb];
-    const int lb = rb_last[rb];
-    const int NC = 2 * (lb - fb + 1) * nsub * 3;
     const float* cs = cand_s + (int64_t)(valid ? q : 0) * (2 * smax * 3);
     const int* ci = cand_i + (int64_t)(valid ? q : 0) * (2 * smax * 3);
     if (bid == 0 && threadIdx.x == 0 && stats) {
         stats[1] = G; stats[2] = 2 * smax; stats[3] = mode;
     }
 
-    // Sweep 1: two smallest scores and the smallest 3rd-best.  (The records are re-read from L1/L2 by the later
-    // sweeps instead of being held in registers: the kernel needs <= 168 VGPRs for a single resident round.)
-    float m1 = kInf, m2 = kInf, tau = kInf;
+    // Sweep 1: two smallest scores and the smallest 3rd-best, on the scores' BIT PATTERNS (scores are >= 0 up to rounding
+    // noise, so integer order = float order and min / med3 are single instructions without canonicalisation; among
+    // negative noise values any order is as good as another: they differ by far less than eps).
     float s1v[kS1];
     int i1v[kS1];                                        // the records' row ids ride along: sweep 2 takes its first 16 * kS1
 #pragma unroll                                           // records from these registers instead of a second, dependent round trip
-    for (int k = 0; k < kS1; ++k) {
-        const int c = sl + 16 * k;
-        s1v[k] = (valid && c < NC) ? cs[c] : kInf;
-        i1v[k] = (valid && c < NC) ? ci[c] : -1;
+    for (int k = 0; k < kS1; ++k) {                      // (issued before NC is known: one dependent round trip less; slots
+        const int c = min(sl + 16 * k, 2 * smax * 3 - 1);   // past NC hold stale records and are masked below)
+        s1v[k] = valid ? cs[c] : kInf;
+        i1v[k] = valid ? ci[c] : -1;
     }
+    const int fb = rb_first[rb];
+    const int lb = rb_last[rb];
+    const int NC = 2 * (lb - fb + 1) * nsub * 3;
+#pragma unroll
+    for (int k = 0; k < kS1; ++k)
+        if (sl + 16 * k >= NC) {
+            s1v[k] = kInf;
+            i1v[k] = -1;
+        }
     __syncthreads();                                     // query rows in LDS
     if (trace && threadIdx.x == 0) trace[16 * bidt + 1] = wall_clock64();
     float qq;
@@ -1309,156 +1331,205 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
     }
     qq += lane_xor<8>(qq); qq += lane_xor<4>(qq); qq += lane_xor<2>(qq); qq += lane_xor<1>(qq);
     const float nsum = sqrtf(qq) + sqrtf(tmax);
-    if (sl == 0) q_qq[ql] = qq;                           // parked in LDS: the kernel sits at the 168-VGPR limit of a single resident round
+    if (sl == 0) q_qq[ql] = qq;                           // (the rescan's operand)
     const float eps = 1.01f * (eps_coef * nsum * nsum + (mode == kModeHalf ? kEpsHalfAbs * nsum : 0.f));
+    int a1 = kKeyInf, a2 = kKeyInf, atau;
+    static_assert(kS1 == 6, "the 3rd-best selection below is written for six records per lane");
+    {
 #pragma unroll
-    for (int k = 0; k < kS1; ++k) {
-        if ((sl + 16 * k) % 3 == 2) tau = fminf(tau, s1v[k]);
-        if (s1v[k] < m1) { m2 = m1; m1 = s1v[k]; } else if (s1v[k] < m2) { m2 = s1v[k]; }
+        for (int k = 0; k < kS1; ++k) {
+            const int x = __float_as_int(s1v[k]);
+            a2 = imed3(a1, a2, x);         // (a1 <= a2): the second smallest of the three
+            a1 = min(a1, x);
+        }
+        // record c = sl + 16 k is a stream's 3rd best iff c % 3 == 2 iff (sl % 3 + k) % 3 == 2: two of a lane's six
+        const int r3 = sl % 3;
+        const int t0 = __float_as_int(r3 == 0 ? s1v[2] : r3 == 1 ? s1v[1] : s1v[0]);
+        const int t1 = __float_as_int(r3 == 0 ? s1v[5] : r3 == 1 ? s1v[4] : s1v[3]);
+        atau = min(t0, t1);
     }
     if (valid)
         for (int c = sl + 16 * kS1; c < NC; c += 16) {
-            const float s = cs[c];
-            if (c % 3 == 2) tau = fminf(tau, s);
-            if (s < m1) { m2 = m1; m1 = s; } else if (s < m2) { m2 = s; }
+            const int x = __float_as_int(cs[c]);
+            if (c % 3 == 2) atau = min(atau, x);
+            a2 = imed3(a1, a2, x);
+            a1 = min(a1, x);
         }
-    auto fold = [&](float o1, float o2, float ot) {
-        const float lo = fminf(m1, o1), hi = fmaxf(m1, o1);
-        m2 = fminf(hi, fminf(m2, o2));
-        m1 = lo;
-        tau = fminf(tau, ot);
+    auto fold = [&](int o1, int o2, int ot) {
+        const int hi = max(a1, o1);
+        a1 = min(a1, o1);
+        a2 = min(hi, min(a2, o2));
+        atau = min(atau, ot);
     };
-    fold(lane_xor<8>(m1), lane_xor<8>(m2), lane_xor<8>(tau));
-    fold(lane_xor<4>(m1), lane_xor<4>(m2), lane_xor<4>(tau));
-    fold(lane_xor<2>(m1), lane_xor<2>(m2), lane_xor<2>(tau));
-    fold(lane_xor<1>(m1), lane_xor<1>(m2), lane_xor<1>(tau));
-    // The two best-scored candidates have d^2 <= m2 + eps.  A candidate with s > m2 + 2.5*eps has d^2 >= s - eps >
-    // m2 + 1.5*eps: farther than both by > eps/2 >= 300u*(|q|+|t|)^2, which also separates the float32 square roots
-    // (one ulp of sqrtf is < 2^-22 relative in d^2) — it cannot be in the exact top-2, ties included.
-    const float thr = m2 + 2.5f * eps;
+    fold(lane_xor<8>(a1), lane_xor<8>(a2), lane_xor<8>(atau));
+    fold(lane_xor<4>(a1), lane_xor<4>(a2), lane_xor<4>(atau));
+    fold(lane_xor<2>(a1), lane_xor<2>(a2), lane_xor<2>(atau));
+    fold(lane_xor<1>(a1), lane_xor<1>(a2), lane_xor<1>(atau));
+    const float m2 = __int_as_float(a2), tau = __int_as_float(atau);
+    // The two best-scored candidates have d^2 <= m2 + eps.  A candidate with s > m2 + 2.25*eps has d^2 >= s - eps >
+    // m2 + 1.25*eps: farther than both by > eps/4 >= 150u*(|q|+|t|)^2, which also separates the float32 square roots
+    // (one ulp of sqrtf is < 2^-22 relative in d^2, i.e. < 4u*(|q|+|t|)^2) — it cannot be in the exact top-2, ties included.
+    const float thr = m2 + 2.25f * eps;
     if (trace && threadIdx.x == 0) trace[16 * bidt + 2] = wall_clock64();
 
-    // Sweep 2: the survivors of ALL candidate chunks are compacted in LDS first, then evaluated 8 per pass (a lane
-    // pair each), so the dependent train-row fetches of a query overlap instead of costing one round trip per chunk.
+    // Sweep 2.  The kernel is bound by vector-ALU ISSUE (four waves per SIMD, ~1000 instructions each), so every stage
+    // is written for instruction count:
+    //   compaction  records within `thr` -> the query's record list: one prefix sum over the lanes' counts (DPP row
+    //               shifts: a query's 16 lanes are one DPP row), not a ballot per chunk;
+    //   screen      (fp16 modes) a record names four adjacent rows, usually only the one that produced its minimum is
+    //               near the threshold: rows are screened against the fp16 train image (L2-resident: the filter just
+    //               streamed it; half the bytes) with v_dot2_f32_f16 on fp16(-2q), the filter's own operand:
+    //               s' = ||t||^2 + ||q||^2 - 2 q^.t^ has |s' - d^2| <= eps, and a row of the exact top-2 has
+    //               d^2 <= m2 + eps, hence s' <= m2 + 2 eps < thr.  A lane quad per pair of adjacent rows (512 contiguous
+    //               bytes), survivors appended through an LDS counter;
+    //   evaluate    survivors with the reference arithmetic, a lane quad per row.
     Best2 b;
-    b.d[0] = b.d[1] = kInf; b.dsq[0] = b.dsq[1] = kInf; b.i[0] = b.i[1] = INT_MAX;
-    const int pr = sl >> 1, pp = sl & 1;                  // candidate pair inside the query's 16 lanes
-    int cnt = 0;                                          // entries of qual[ql] (uniform inside a query's 16 lanes)
-    // Exact evaluation of the listed trains (two sites: the candidates' and, rarely, the rescan survivors').
-    auto evaluate = [&]() {
-        int nmax = cnt;
-        nmax = max(nmax, lane_xor<16>(nmax));
-        nmax = max(nmax, lane_xor<32>(nmax));
+    b.d[0] = b.d[1] = kInf; b.i[0] = b.i[1] = INT_MAX;
+    const int jq = sl & 3, qd = sl >> 2;                  // lane inside the quad, quad inside the query's 16 lanes
+    int cnt = 0;                                          // entries of rows[ql] (uniform inside a query's 16 lanes)
+    int nrec = 0;                                         // entries of rec[ql]
+    auto wave_max = [&](int v) {
+        v = max(v, lane_xor<16>(v));
+        return max(v, __shfl_xor(v, 32, 64));
+    };
+    // Exact evaluation of listed trains: FROM_REC = false the row list (screen / rescan survivors), true the record list
+    // expanded (modes without a screen).  A row index past the last train (a record's tail) is clamped: evaluating an
+    // extra REAL row exactly is always harmless.
+    auto evaluate = [&](auto from_rec) {
+        constexpr bool kFromRec = decltype(from_rec)::value;
+        const int n = kFromRec ? kRecRows * nrec : cnt;
+        const int nmax = wave_max(n);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll 1
-        for (int e0 = 0; e0 < nmax; e0 += 8) {
-            const int e = e0 + pr;
-            const int tid = e < cnt ? qual[ql][e] : 0;    // idle pairs re-read train 0 (nt >= 1 here)
-            const float dsq = exact_l2sq_pair(qrows[ql], T + (int64_t)tid * ldt, pp);
-            if (pp == 0 && e < cnt) best2_insert_unique(b, sqrtf(dsq), dsq, tid);
+        for (int e0 = 0; e0 < nmax; e0 += 4) {
+            const int e = e0 + qd;
+            int tid = 0;                                  // idle quads re-read train 0 (nt >= 1 here)
+            if (e < n) tid = min(kFromRec ? rec[ql][e >> 2] + (e & 3) : qual[ql][e], nt - 1);
+            const float* const rows[1] = {T + (int64_t)tid * (int)ldt};
+            float dsq[1];
+            exact_l2sq_quad_rows<1, false>(qrows[ql], rows, jq, dsq);
+            if (jq == 2 && e < n) best2_insert_unique(b, sqrtf(dsq[0]), tid);
         }
         __builtin_amdgcn_wave_barrier();
-        cnt = 0;
+        if (kFromRec) nrec = 0; else cnt = 0;
     };
-
-    double lim = 0.0;
-    bool rescanned = false;
     const bool use_half = thalf && (mode == kModeHalf || mode == kModeHalfExact);
-    // A record names four rows but usually only the one that produced its minimum is near the threshold.  In the fp16
-    // modes the rows are screened first against the fp16 train image (L2-resident: the filter just streamed it; half the
-    // bytes): s' = ||t||^2 + ||q||^2 - 2 q.t^ has |s' - d^2| <= eps (only t is rounded), and a row of the exact top-2 has
-    // d^2 <= m2 + eps, hence s' <= m2 + 2 eps < thr: rows with s' > thr cannot matter.  A lane quad per row, kHotPre rows
-    // per quad and pass (4 * kHotPre rows of the query per pass), survivors compacted in place.
-    auto prefilter = [&]() {
-        int nmax = cnt;
-        nmax = max(nmax, lane_xor<16>(nmax));
-        nmax = max(nmax, lane_xor<32>(nmax));
+    auto screen = [&]() {
+        const int nrow = kRecRows * nrec, nmax = wave_max(nrow);
+        const bool tight = nmax > kQualCap;               // (wave-uniform) the row list might not hold every survivor
+        if (sl == 0) cnt_lds[ql] = 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const int jq = sl & 3, qd = sl >> 2;
-        int kept = 0;
+        static_assert((kHotPre == 2 || kHotPre == 4) && kRecRows == 4, "a quad screens half a record or a whole one (adjacent rows) per pass");
 #pragma unroll 1
         for (int e0 = 0; e0 < nmax; e0 += 4 * kHotPre) {
-            int tr[kHotPre];
-            uint4 hv[kHotPre][4];
-            float tnv[kHotPre];
-#pragma unroll
-            for (int r = 0; r < kHotPre; ++r) {
-                const int e = e0 + qd + 4 * r;
-                tr[r] = e < cnt ? qual[ql][e] : -1;
-                const int row = tr[r] >= 0 ? tr[r] : 0;
-#pragma unroll
-                for (int n = 0; n < 4; ++n) hv[r][n] = *reinterpret_cast<const uint4*>(thalf + (int64_t)row * kDim + 32 * n + 8 * jq);
-                tnv[r] = tn[row];
-            }
-            __builtin_amdgcn_wave_barrier();              // every entry of this pass is in registers before any is overwritten
-            bool pass[kHotPre];
-#pragma unroll
-            for (int r = 0; r < kHotPre; ++r) {
-                float dot = 0.f;
-#pragma unroll
-                for (int n = 0; n < 4; ++n) {
-                    const f16x8 hx = __builtin_bit_cast(f16x8, hv[r][n]);
-                    const float4 qa = *reinterpret_cast<const float4*>(&qrows[ql][32 * n + 8 * jq]);
-                    const float4 qb = *reinterpret_cast<const float4*>(&qrows[ql][32 * n + 8 * jq + 4]);
-                    dot = fmaf(qa.x, (float)hx[0], dot); dot = fmaf(qa.y, (float)hx[1], dot);
-                    dot = fmaf(qa.z, (float)hx[2], dot); dot = fmaf(qa.w, (float)hx[3], dot);
-                    dot = fmaf(qb.x, (float)hx[4], dot); dot = fmaf(qb.y, (float)hx[5], dot);
-                    dot = fmaf(qb.z, (float)hx[6], dot); dot = fmaf(qb.w, (float)hx[7], dot);
+            if (tight) {                                  // degenerate inputs only
+                __builtin_amdgcn_wave_barrier();
+                cnt = cnt_lds[ql];
+                if (__any(cnt > kQualCap - 4 * kHotPre)) {
+                    evaluate(std::false_type{});
+                    if (sl == 0) cnt_lds[ql] = 0;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
                 }
-                dot += lane_xor<2>(dot);
-                dot += lane_xor<1>(dot);
-                const float sp = (tnv[r] + q_qq[ql]) - 2.f * dot;
-                pass[r] = jq == 0 && tr[r] >= 0 && !(thr < sp);
+            }
+            const int e = e0 + kHotPre * qd;              // rows e .. e + kHotPre - 1 of the list: rows (e & 3) ... of record e >> 2
+            const bool live = e < nrow;
+            const int row0 = live ? rec[ql][e >> 2] + (e & 3) : 0;   // (< the padded image's rows: a record never leaves its tile)
+            const unsigned short* hp = thalf + (int64_t)row0 * kDim + 8 * jq;
+            uint4 hv[kHotPre][4];
+#pragma unroll
+            for (int r = 0; r < kHotPre; ++r)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) hv[r][n] = *reinterpret_cast<const uint4*>(hp + r * kDim + 32 * n);
+            float tnv = tn[row0 + (jq & (kHotPre - 1))];   // (padded rows: +inf, never pass)
+            float dot[kHotPre];
+#pragma unroll
+            for (int r = 0; r < kHotPre; ++r) dot[r] = 0.f;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const uint4 qh = *reinterpret_cast<const uint4*>(&qhalf[ql][32 * n + 8 * jq]);
+#pragma unroll
+                for (int r = 0; r < kHotPre; ++r) dot[r] = dot8_f16(hv[r][n], qh, dot[r]);
             }
 #pragma unroll
             for (int r = 0; r < kHotPre; ++r) {
-                const unsigned m16 = (unsigned)(__ballot(pass[r]) >> (16 * sub)) & 0xFFFFu;
-                if (pass[r]) qual[ql][kept + __popc(m16 & ((1u << sl) - 1u))] = tr[r];
-                kept += __popc(m16);
+                dot[r] += lane_xor<2>(dot[r]);
+                dot[r] += lane_xor<1>(dot[r]);
             }
+            asm volatile("" : "+v"(tnv));                  // (keeps the load up here: sunk into the branch below it is a second round trip)
+            // lane j of the quad finishes row j of its kHotPre
+            float mine = dot[0];
+#pragma unroll
+            for (int r = 1; r < kHotPre; ++r) mine = (jq & (kHotPre - 1)) == r ? dot[r] : mine;
+            const float sp = (tnv + qq) + mine;
+            if (jq < kHotPre && live && !(thr < sp)) qual[ql][atomicAdd(&cnt_lds[ql], 1)] = row0 + jq;
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        cnt = kept;
+        cnt = cnt_lds[ql];
+        nrec = 0;
+        if (trace && threadIdx.x == 0 && !trace[16 * bidt + 12]) { trace[16 * bidt + 12] = wall_clock64(); trace[16 * bidt + 14] = cnt; }
     };
-    // one chunk of 16 records per query: the ones within `thr` are appended (all kRecRows rows each) to the query's list
-    auto push = [&](bool take, int id) {
-        const unsigned long long mask = __ballot(take);
-        if (mask == 0) return;                            // wave-uniform
-        const unsigned mine = (unsigned)(mask >> (16 * sub)) & 0xFFFFu;
-        if (take) {                                       // a record names kRecRows adjacent rows: all are evaluated
-            const int at = cnt + kRecRows * __popc(mine & ((1u << sl) - 1u));
-#pragma unroll
-            for (int i = 0; i < kRecRows; ++i) qual[ql][at + i] = id + i < nt ? id + i : id;
-        }
-        cnt += kRecRows * __popc(mine);
+#define SFM_REFINE_PROCESS()                    \
+    do {                                        \
+        if (use_half) {                         \
+            screen();                           \
+            evaluate(std::false_type{});        \
+        } else {                                \
+            evaluate(std::true_type{});         \
+        }                                       \
+    } while (0)                                           /* (wave-uniform branches) */
+    // inclusive prefix sum over the 16 lanes of a query (one DPP row) and its total
+    auto row_scan = [&](int v, int& total) {
+        v += __builtin_amdgcn_update_dpp(0, v, 0x111 /*row_shr:1*/, 0xF, 0xF, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x112 /*row_shr:2*/, 0xF, 0xF, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x114 /*row_shr:4*/, 0xF, 0xF, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x118 /*row_shr:8*/, 0xF, 0xF, true);
+        total = __builtin_amdgcn_ds_swizzle(v, 0x10 | (0x0F << 5));   // lane 15 of the row: (lane & 0x10) | 0x0F
+        return v;
     };
-    int k0 = 0;
+    {   // the chunks still in registers from sweep 1: at most 96 records, the list holds them all
+        bool take[kS1];
+        int mine = 0;
 #pragma unroll
-    for (int k = 0; k < kS1; ++k)                         // chunks still in registers from sweep 1 (wave-uniform conditions)
-        if (k0 == k && k * 16 < NC && !__any(cnt > kQualCap - 16 * kRecRows)) {
-            push(i1v[k] >= 0 && s1v[k] <= thr, i1v[k]);
-            k0 = k + 1;
+        for (int k = 0; k < kS1; ++k) {
+            take[k] = i1v[k] >= 0 && s1v[k] <= thr;
+            mine += take[k] ? 1 : 0;
         }
-    for (bool first = true; first || k0 * 16 < NC; first = false) {   // (wave-uniform) the rest — and everything after a full list — is re-read
-        for (; k0 * 16 < NC; ++k0) {
-            if (__any(cnt > kQualCap - 16 * kRecRows)) break;   // the list might not take another chunk: evaluate first
-            const int c = sl + 16 * k0;
-            const float sc = (valid && c < NC) ? cs[c] : kInf;
-            const int id = (valid && c < NC) ? ci[c] : -1;                // (empty records: s = +inf, id = -1)
-            push(id >= 0 && sc <= thr, id);
-        }
-        if (use_half) prefilter();                        // (wave-uniform)
-        evaluate();                                       // the hot site
+        int total;
+        int at = row_scan(mine, total) - mine;
+#pragma unroll
+        for (int k = 0; k < kS1; ++k)
+            if (take[k]) rec[ql][at++] = i1v[k];
+        nrec = total;
     }
+    static_assert(kRecCap >= 16 * kS1 + 16, "the register round plus one more chunk");
+    for (int k0 = kS1; k0 * 16 < NC; ++k0) {              // (wave-uniform) further chunks — more streams than 32 per query — are re-read
+        if (__any(nrec > kRecCap - 16)) SFM_REFINE_PROCESS();   // the list might not take another chunk: work it off first
+        const int c = sl + 16 * k0;
+        const float sc = (valid && c < NC) ? cs[c] : kInf;
+        const int id = (valid && c < NC) ? ci[c] : -1;                // (empty records: s = +inf, id = -1)
+        const bool take = id >= 0 && sc <= thr;
+        int total;
+        const int at = row_scan(take ? 1 : 0, total) - (take ? 1 : 0);
+        if (take) rec[ql][nrec + at] = id;
+        nrec += total;
+    }
+    if (trace && threadIdx.x == 0) { trace[16 * bidt + 11] = wall_clock64(); trace[16 * bidt + 13] = kRecRows * nrec; }
+    SFM_REFINE_PROCESS();                                 // the hot site
+#undef SFM_REFINE_PROCESS
+    if (trace && threadIdx.x == 0) trace[16 * bidt + 15] = wall_clock64();
+    double lim = 0.0;
+    bool rescanned = false;
     for (int round = 0;; ++round) {
-        if (round == 1) evaluate();                       // rescan survivors (cold site)
+        if (round == 1) evaluate(std::false_type{});      // rescan survivors (cold site)
         best2_group_reduce<16>(b);
         if (trace && threadIdx.x == 0 && round == 0) trace[16 * bidt + 3] = wall_clock64();
         if (round == 1) break;
         // Certificate.  (s3 < 0 can only be rounding noise: such a stream never certifies.)
-        lim = b.i[1] != INT_MAX ? (double)b.dsq[1] + (double)eps : (double)kInf;
+        lim = b.i[1] != INT_MAX ? dsq_upper(b.d[1]) + (double)eps : (double)kInf;
         const bool open = valid && tau < kInf && !(lim < (double)tau);    // some stream could not be certified
         if (!__syncthreads_or(open ? 1 : 0)) break;
 
@@ -1530,19 +1601,12 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
                         for (int r = 0; r < kPreRows; ++r) {
                             float dot = 0.f;
 #pragma unroll
-                            for (int n = 0; n < 4; ++n) {
-                                const f16x8 hx = __builtin_bit_cast(f16x8, hv[r][n]);
-                                const float4 qa = *reinterpret_cast<const float4*>(&qrows[w][32 * n + 8 * jq]);
-                                const float4 qb = *reinterpret_cast<const float4*>(&qrows[w][32 * n + 8 * jq + 4]);
-                                dot = fmaf(qa.x, (float)hx[0], dot); dot = fmaf(qa.y, (float)hx[1], dot);
-                                dot = fmaf(qa.z, (float)hx[2], dot); dot = fmaf(qa.w, (float)hx[3], dot);
-                                dot = fmaf(qb.x, (float)hx[4], dot); dot = fmaf(qb.y, (float)hx[5], dot);
-                                dot = fmaf(qb.z, (float)hx[6], dot); dot = fmaf(qb.w, (float)hx[7], dot);
-                            }
+                            for (int n = 0; n < 4; ++n)
+                                dot = dot8_f16(hv[r][n], *reinterpret_cast<const uint4*>(&qhalf[w][32 * n + 8 * jq]), dot);
                             dot += lane_xor<2>(dot);
                             dot += lane_xor<1>(dot);
                             if (jq == 0 && tr[r] < nt) {
-                                const float sp = (tn[tr[r]] + qq_w) - 2.f * dot;
+                                const float sp = (tn[tr[r]] + qq_w) + dot;
                                 if (!(lim_w < (double)sp)) surv[atomicAdd(&nsurv, 1)] = tr[r];
                             }
                         }
@@ -1568,7 +1632,7 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
                 } else {
                     // many survivors: evaluate them here with the whole workgroup, a quad per train
                     Best2 pb;
-                    pb.d[0] = pb.d[1] = kInf; pb.dsq[0] = pb.dsq[1] = kInf; pb.i[0] = pb.i[1] = INT_MAX;
+                    pb.d[0] = pb.d[1] = kInf; pb.i[0] = pb.i[1] = INT_MAX;
                     for (int i0 = threadIdx.x >> 2; i0 < ns; i0 += 64 * kRescanRows) {
                         const float* rows[kRescanRows];
                         int tr[kRescanRows];
@@ -1579,10 +1643,10 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
                             rows[r] = tr[r] >= 0 ? T + (int64_t)tr[r] * ldt : nullptr;
                         }
                         float dsq[kRescanRows];
-                        exact_l2sq_quad_rows<kRescanRows>(qrows[w], rows, threadIdx.x & 3, dsq);
+                        exact_l2sq_quad_rows<kRescanRows, true>(qrows[w], rows, threadIdx.x & 3, dsq);
 #pragma unroll
                         for (int r = 0; r < kRescanRows; ++r)
-                            if ((threadIdx.x & 3) == 2 && rows[r]) best2_insert(pb, sqrtf(dsq[r]), dsq[r], tr[r]);
+                            if ((threadIdx.x & 3) == 2 && rows[r]) best2_insert(pb, sqrtf(dsq[r]), tr[r]);
                     }
                     best2_group_reduce<64>(pb);
                     if (lane == 0) wbest[wave] = pb;
@@ -1590,8 +1654,8 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
                     if (ql == w) {
 #pragma unroll
                         for (int x = 0; x < 4; ++x) {
-                            best2_insert_unique(b, wbest[x].d[0], wbest[x].dsq[0], wbest[x].i[0]);
-                            best2_insert_unique(b, wbest[x].d[1], wbest[x].dsq[1], wbest[x].i[1]);
+                            best2_insert_unique(b, wbest[x].d[0], wbest[x].i[0]);
+                            best2_insert_unique(b, wbest[x].d[1], wbest[x].i[1]);
                         }
                     }
                     if (threadIdx.x == 0) nsurv = 0;
@@ -1603,18 +1667,19 @@ __global__ __launch_bounds__(256, 3) void knn_refine_kernel(
         if (trace && threadIdx.x == 0) trace[16 * bidt + 8] = wall_clock64();
     }
 
+    int tq = threadIdx.x;
+    asm volatile("" : "+v"(tq));                          // output addresses are formed HERE (hoisted to the top they are spilled)
+    const int qo = bid * kRefQ + (tq >> 4);
     if (valid && sl == 0) {
-        idx_out[2 * q + 0] = b.i[0] == INT_MAX ? -1 : b.i[0];
-        idx_out[2 * q + 1] = b.i[1] == INT_MAX ? -1 : b.i[1];
-        dist_out[2 * q + 0] = b.d[0];
-        dist_out[2 * q + 1] = b.d[1];
+        *reinterpret_cast<int2*>(idx_out + 2 * (int64_t)qo) = make_int2(b.i[0] == INT_MAX ? -1 : b.i[0], b.i[1] == INT_MAX ? -1 : b.i[1]);
+        *reinterpret_cast<float2*>(dist_out + 2 * (int64_t)qo) = make_float2(b.d[0], b.d[1]);
         if (rescanned && stats) atomicAdd(stats, 1);
     }
     if (ratio_counts) {
         // fused sfm_match_l2_f32: the Lowe test of sfm.py:264 here, survivors counted per 1024-query block (integer
         // atomics: order-independent), so the match list needs the ordered scatter pass only
         const bool pass = valid && sl == 0 && b.i[1] != INT_MAX && (double)b.d[0] < ratio * (double)b.d[1];
-        if (ratio_mask && valid && sl == 0) ratio_mask[q] = pass ? 1 : 0;
+        if (ratio_mask && valid && sl == 0) ratio_mask[qo] = pass ? 1 : 0;
         const int n = __popcll(__ballot(pass));
         if (lane == 0 && n) atomicAdd(ratio_counts + (bid * kRefQ) / kRatioBlock, n);
     }
@@ -1757,6 +1822,7 @@ struct KnnWs {
     float* tn;
     float* bmax;                  // [B][kNormBlocks]
     int* midflag;
+    int* minfo;                   // [kMinfoWords] modes / ||t||max reduced by filter block 0 for the refine kernel
     int64_t* wg_begin;            // partition tables over the whole batch (filled by the prep / norms launch)
     int* rb_first;
     int* rb_last;
@@ -1778,6 +1844,7 @@ KnnWs carve_ws(void* ws, int64_t nq, int64_t nt, const Plan& p) {
     w.s_cand = (int64_t)nq * 2 * p.smax * p.nsub * 3;
     w.bmax = c.take<float>(B * kNormBlocks);
     w.midflag = c.take<int>(B * kNormBlocks);
+    w.minfo = c.take<int>(kMinfoWords);
     w.wg_begin = c.take<int64_t>((size_t)p.G + 1);
     w.rb_first = c.take<int>((size_t)p.n_rb);
     w.rb_last = c.take<int>((size_t)p.n_rb);
@@ -1830,6 +1897,7 @@ int knn_batch_impl(int B, const BatchPtrs& P, int64_t nq, int64_t ldq, int64_t n
     for (int b = 0; b < B; ++b) {
         SFM_CHECK_ARG(P.q[b] && P.idx[b] && P.dist[b] && (P.t[b] || nt == 0), "sfm_knn2_l2_f32: null pointer");
         SFM_CHECK_ARG(((uintptr_t)P.q[b] & 15) == 0 && ((uintptr_t)P.t[b] & 15) == 0, "sfm_knn2_l2_f32: q/t must be 16-byte aligned");
+        SFM_CHECK_ARG(((uintptr_t)P.idx[b] & 7) == 0 && ((uintptr_t)P.dist[b] & 7) == 0, "sfm_knn2_l2_f32: idx/dist must be 8-byte aligned");
     }
     SFM_CHECK_ARG(ldq >= dim && ldt >= dim && ldq % 4 == 0 && ldt % 4 == 0, "sfm_knn2_l2_f32: ldq/ldt must be >= dim and multiples of 4");
     hipStream_t stream = sfm::as_stream(stream_);
@@ -1864,7 +1932,7 @@ int knn_batch_impl(int B, const BatchPtrs& P, int64_t nq, int64_t ldq, int64_t n
     hipLaunchKernelGGL((knn_filter_split2_kernel<A, WV>), grid, dim3(64 * WV), kRingLdsBytes + (WV == 4 ? kQScratchBytes : 0), stream, w.qsplit, w.qn,    \
                        (int)nq, p.nq_pad, w.tsplit, (int)nt, p.tiles * kTileT, w.tn, p.tiles, p.units, p.smax, p.nsub,    \
                        w.midflag, w.bmax, g_force_mode, w.cand_s, w.cand_i, w.wg_begin, w.rb_first, p.n_rb1, B, w.s_qsplit, w.s_tsplit,    \
-                       w.s_qn, w.s_tn, w.s_cand, g_trace)
+                       w.s_qn, w.s_tn, w.s_cand, w.minfo, g_trace)
         // sfm_profile_enable(n > 1): the filter is launched n times back-to-back inside ONE event pair (idempotent: same
         // inputs, same candidate records), so the ~7 us an event pair adds to a single launch is amortised
         for (int rep = 0; rep < prof_reps; ++rep) {
@@ -1916,7 +1984,7 @@ int knn_batch_impl(int B, const BatchPtrs& P, int64_t nq, int64_t ldq, int64_t n
     sfm::prof_begin(sfm::kProfKnnRefine, stream);
     hipLaunchKernelGGL(knn_refine_kernel, dim3((unsigned)refine_grid), dim3(256), 0, stream, P, B, ldq, (int)nq, ldt,
                        (int)nt, w.cand_s, w.cand_i, p.rows_per_block, p.tiles, p.units, p.G, p.smax * p.nsub, p.nsub,
-                       force_mode, w.midflag, w.bmax, p.split ? w.tsplit + (size_t)2 * p.tiles * kTileT * kDim : nullptr, w.tn, w.wg_begin, w.rb_first, w.rb_last,
+                       force_mode, w.midflag, w.bmax, p.split ? w.minfo : nullptr, p.split ? w.tsplit + (size_t)2 * p.tiles * kTileT * kDim : nullptr, w.tn, w.wg_begin, w.rb_first, w.rb_last,
                        p.n_rb1, w.s_cand, w.s_tsplit, w.s_tn, ratio, ratio_counts, ratio_stride, g_trace ? g_trace + 16384 : nullptr);
     sfm::prof_end(sfm::kProfKnnRefine, stream);
     SFM_CHECK_LAUNCH();
