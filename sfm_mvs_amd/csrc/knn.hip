@@ -545,7 +545,7 @@ __device__ __forceinline__ unsigned bf16_rn_bits(float x) {
 //                   range, which the matrix pipe may flush) — the refine kernel's slack (kEpsHalf*) covers it.
 //   kModeSplit      anything else (huge / tiny magnitudes): bf16 hi+mid split, three products, full fp32 range.
 constexpr int kModeHalfExact = 0, kModeHalf = 1, kModeSplit = 2;
-constexpr int kFlagBf16Inexact = 1, kFlagHalfInexact = 2, kFlagRangeBad = 4;
+constexpr int kFlagHalfInexact = 2, kFlagRangeBad = 4;
 
 // Wave-uniform mode from the per-block flags and per-block max ||t||^2 (256 entries each).
 __device__ __forceinline__ int knn_filter_mode(const int* __restrict__ flags, const float* __restrict__ bmax, int lane,
@@ -570,9 +570,11 @@ __device__ __forceinline__ int knn_batch_mode(const int* __restrict__ flags, con
     return mode;
 }
 
-// One pass over Q and T: rows → (hi, mid) bf16 images and an fp16 image (Q pre-scaled by -2, exact), fp32 squared
-// norms, per-block max of ||t||^2 and exactness / range flags, zero the rescan counter.  Rows >= n of the padded
-// images are zero-filled.  Image layout: [3][n_pad][128] 16-bit: bf16 hi, bf16 mid, fp16.
+// One pass over Q and T: rows → the fp16 image (Q pre-scaled by -2, exact), fp32 squared norms, per-block max of
+// ||t||^2 and exactness / range flags, zero the rescan counter.  Rows >= n of the padded images are zero-filled.
+// Image layout: [3][n_pad][128] 16-bit: bf16 hi, bf16 mid, fp16; the two bf16 planes are only needed by the split
+// arithmetic (values outside fp16's range) and are written by knn_split_images_kernel, which runs when the flags say so:
+// the common case moves 15 MB per 10k x 10k pair instead of 25.
 // Batched: grid = (blocks + 1, B); column b works on pair b (its workspace arrays sit at b * stride).
 __global__ __launch_bounds__(1024) void knn_prep_kernel(BatchPtrs P, int64_t ldq, int nq, int nq_pad,
                                                        int64_t ldt, int nt, int nt_pad,
@@ -613,12 +615,9 @@ __global__ __launch_bounds__(1024) void knn_prep_kernel(BatchPtrs P, int64_t ldq
         for (int m = 16; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
         const float sc = isq ? -2.f : 1.f;
         const float e[4] = {sc * v.x, sc * v.y, sc * v.z, sc * v.w};
-        unsigned hb[4], mb[4], fb[4];
+        unsigned fb[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            hb[k] = bf16_rn_bits(e[k]);
-            mb[k] = bf16_rn_bits(e[k] - __uint_as_float(hb[k] << 16));   // x - hi is exact in fp32
-            if (mb[k] & 0x7FFFu) flags |= kFlagBf16Inexact;
             const float ae = fabsf(e[k]);
             const _Float16 hv = (_Float16)e[k];                          // round to nearest even
             fb[k] = (unsigned)__builtin_bit_cast(unsigned short, hv);
@@ -626,8 +625,6 @@ __global__ __launch_bounds__(1024) void knn_prep_kernel(BatchPtrs P, int64_t ldq
             if ((float)hv != e[k] || (ae != 0.f && ae < 6.103515625e-5f)) flags |= kFlagHalfInexact;
         }
         unsigned short* img = isq ? qsplit : tsplit;
-        *reinterpret_cast<uint2*>(img + (int64_t)r * kDim + 4 * l) = make_uint2(hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16));
-        *reinterpret_cast<uint2*>(img + ((int64_t)npad + r) * kDim + 4 * l) = make_uint2(mb[0] | (mb[1] << 16), mb[2] | (mb[3] << 16));
         *reinterpret_cast<uint2*>(img + (2 * (int64_t)npad + r) * kDim + 4 * l) = make_uint2(fb[0] | (fb[1] << 16), fb[2] | (fb[3] << 16));
         if (l == 0) (isq ? qn : tn)[r] = (isq || r < n) ? s : kInf;   // padded train rows can never be candidates
         if (!isq) mx = fmaxf(mx, s);
@@ -654,6 +651,47 @@ __global__ __launch_bounds__(1024) void knn_prep_kernel(BatchPtrs P, int64_t ldq
         if (blockIdx.x == 0 && stats) stats[0] = 0;   // rescanned-query counter (refine kernel)
         if (blockIdx.x == 1 || nblk == 1)
             for (int i = 0; i < nzero; ++i) zero[i] = 0;   // Lowe-ratio survivor counters of the fused match call
+    }
+}
+
+// The bf16 (hi, mid) planes of the images, for the split arithmetic only: every workgroup derives the batch's mode from
+// the flags the prep launch left (as the filter will) and returns at once unless it is the split mode.
+// (A small grid — one 512-thread workgroup per CU, every one loops over the pairs: launching the waves of a prep-sized
+// grid only to have them return cost 7 us.)
+constexpr int kSplitThreads = 512;
+__global__ __launch_bounds__(kSplitThreads) void knn_split_images_kernel(BatchPtrs P, int B, int64_t ldq, int nq, int nq_pad, int64_t ldt, int nt,
+                                                                        int nt_pad, unsigned short* __restrict__ qsplit0,
+                                                                        unsigned short* __restrict__ tsplit0, int64_t s_qsplit, int64_t s_tsplit,
+                                                                        const int* __restrict__ midflag, const float* __restrict__ bmax,
+                                                                        int force_mode) {
+    const int mode = force_mode >= 0 ? force_mode : knn_batch_mode(midflag, bmax, B, (int)(threadIdx.x & 63));
+    if (mode != kModeSplit) return;
+    const int l = threadIdx.x & 31;
+    const int rows = nq_pad + nt_pad;
+    constexpr int kRowsPerPass = kSplitThreads / 32;
+    for (int pb = 0; pb < B; ++pb) {
+    const float* __restrict__ Q = P.q[pb];
+    const float* __restrict__ T = P.t[pb];
+    unsigned short* __restrict__ qsplit = qsplit0 + pb * s_qsplit;
+    unsigned short* __restrict__ tsplit = tsplit0 + pb * s_tsplit;
+    for (int row = blockIdx.x * kRowsPerPass + (threadIdx.x >> 5); row < rows; row += gridDim.x * kRowsPerPass) {
+        const bool isq = row < nq_pad;
+        const int r = isq ? row : row - nq_pad;
+        const int n = isq ? nq : nt, npad = isq ? nq_pad : nt_pad;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < n) v = *reinterpret_cast<const float4*>((isq ? Q + (int64_t)r * ldq : T + (int64_t)r * ldt) + 4 * l);
+        const float sc = isq ? -2.f : 1.f;
+        const float e[4] = {sc * v.x, sc * v.y, sc * v.z, sc * v.w};
+        unsigned hb[4], mb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            hb[k] = bf16_rn_bits(e[k]);
+            mb[k] = bf16_rn_bits(e[k] - __uint_as_float(hb[k] << 16));   // x - hi is exact in fp32
+        }
+        unsigned short* img = isq ? qsplit : tsplit;
+        *reinterpret_cast<uint2*>(img + (int64_t)r * kDim + 4 * l) = make_uint2(hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16));
+        *reinterpret_cast<uint2*>(img + ((int64_t)npad + r) * kDim + 4 * l) = make_uint2(mb[0] | (mb[1] << 16), mb[2] | (mb[3] << 16));
+    }
     }
 }
 
@@ -1926,6 +1964,9 @@ int knn_batch_impl(int B, const BatchPtrs& P, int64_t nq, int64_t ldq, int64_t n
                            p.tiles * kTileT, w.qsplit, w.qn, w.tsplit, w.tn, w.bmax, w.midflag, w.s_qsplit, w.s_tsplit, w.s_qn, w.s_tn,
                            ratio_counts, ratio_counts ? ratio_stride : 0,
                            p.units, p.tiles, p.G, p.seg_cost, p.n_rb, w.wg_begin, w.rb_first, w.rb_last);
+        SFM_CHECK_LAUNCH();
+        hipLaunchKernelGGL(knn_split_images_kernel, dim3(kNormBlocks), dim3(kSplitThreads), 0, stream, P, B, ldq, (int)nq, p.nq_pad, ldt, (int)nt,
+                           p.tiles * kTileT, w.qsplit, w.tsplit, w.s_qsplit, w.s_tsplit, w.midflag, w.bmax, g_force_mode);
         SFM_CHECK_LAUNCH();
         sfm::prof_begin(sfm::kProfKnnFilter, stream);
 #define SFM_LAUNCH_SPLIT2(A, WV)                                                                                        \
