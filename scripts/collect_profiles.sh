@@ -11,12 +11,16 @@ cp $OUT/trace/knn_kernel_stats.csv $OUT/${TAG}_knn_kernel_stats.csv
 # the same bench with ONE pair in flight: kernel durations without the neighbouring pairs' kernels sharing the chip
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace1 -o knn1 -- python $R/bench.py --steps 100 --warmup 10 --pipe-depth 1 --no-cpu-baseline --no-extras > $OUT/bench_depth1_under_rocprof.json 2>> $OUT/trace.log
 cp $OUT/trace1/knn1_kernel_stats.csv $OUT/${TAG}_knn_depth1_kernel_stats.csv
+# one launch set per step and nothing else (bench.py also launches single pairs for its latency and variant legs, which
+# mix into the averages above): the per-kernel durations of the batch the roofline is quoted on
+SFM_BATCH=${SFM_PROFILE_BATCH:-8} rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/traceb -o knnb -- python $R/scripts/run_knn_steps.py 60 > $OUT/knn_batch_steps.log 2>> $OUT/trace.log
+cp $OUT/traceb/knnb_kernel_stats.csv $OUT/${TAG}_knn_batch_kernel_stats.csv
 P1="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA"
 P2="FETCH_SIZE"
 P3="WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"
 P4="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_WAVES"
 i=1
-BATCH=${SFM_PROFILE_BATCH:-4}          # pairs per launch set: what bench.py runs by default
+BATCH=${SFM_PROFILE_BATCH:-8}          # pairs per launch set: what bench.py runs by default
 for P in "$P1" "$P2" "$P3" "$P4"; do
   SFM_BATCH=$BATCH rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/pmc -o pass$i -- python $R/scripts/run_knn_steps.py 6 > $OUT/pmc_pass$i.log 2>&1
   i=$((i+1))
@@ -31,5 +35,5 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_sift1 -o sift
 cp $OUT/trace_sift1/sift1_kernel_stats.csv $OUT/${TAG}_sift_depth1_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_sift -o sift -- python $R/bench.py --workload sift --steps 30 --warmup 5 --no-cpu-baseline > $OUT/bench_sift_under_rocprof.json 2>> $OUT/trace.log
 cp $OUT/trace_sift/sift_kernel_stats.csv $OUT/${TAG}_sift_kernel_stats.csv
-rm -rf $OUT/trace $OUT/trace1 $OUT/trace_tri $OUT/trace_ba $OUT/trace_sift $OUT/trace_sift1
+rm -rf $OUT/trace $OUT/traceb $OUT/trace1 $OUT/trace_tri $OUT/trace_ba $OUT/trace_sift $OUT/trace_sift1
 ls $OUT

@@ -565,9 +565,11 @@ class BatchPipeline:
         st, bm = self.streams[k], self.matchers[k]
         if any(a is None for a in self._after):
             st.wait_stream(torch.cuda.current_stream(st.device))
-        for a in self._after:
-            if a is not None and a is not False:
+        waited = set()
+        for a in self._after:                             # (the pairs of a batch usually share one event)
+            if a is not None and a is not False and id(a) not in waited:
                 st.wait_event(a)
+                waited.add(id(a))
         with torch.cuda.stream(st):
             n = bm.run(self._pairs, self._results if self._results else None)
         self._pairs, self._results, self._after = [], [], []
