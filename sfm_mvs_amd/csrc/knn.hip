@@ -1,22 +1,27 @@
 // Brute-force 128-D L2 2-NN (cv2.BFMatcher().knnMatch(des0, des1, k=2), sfm.py:259-260)
 // for gfx950 — "certified filter + exact refine":
 //
-//   1. knn_prep_kernel    one pass over Q and T: 16-bit operand images (bf16 hi/mid split and fp16), fp32
-//                         ||.||^2, exactness / range flags.  (knn_norms_kernel for the fp32-MFMA variant.)
+//   1. knn_prep_kernel    one pass over Q and T: the fp16 operand image, fp32 ||.||^2, exactness / range flags, the
+//                         work-partition tables (knn_norms_kernel for the fp32-MFMA variant);
+//      knn_split_images_kernel  the bf16 hi/mid planes, only when the flags ask for the split arithmetic.
 //   2. knn_filter_*       s(q,t) = ||t||^2 + ||q||^2 - 2 q.t on the matrix pipe with the OPERANDS SWAPPED
 //                         (A = train tile from LDS, B = query fragments resident in VGPRs) so that a lane
 //                         owns ONE query column and the running top-3 per lane needs no cross-lane traffic.
 //                         Default: knn_filter_split2_kernel — v_mfma_f32_32x32x16_{f16,bf16}, one fp16 product
 //                         or three bf16 hi/mid products, chosen on the device from the data; train tiles stream
 //                         L2 -> LDS by buffer_load ... lds into a 3-slot ring (XOR-swizzled image); 2 x 32 queries
-//                         per wave, one 8-wave workgroup per CU, stream-K work split.  Every (workgroup segment,
-//                         32-tile substream, half-wave) triple is an independent "stream" that emits its 3 best.
-//   3. knn_refine_kernel  one wave per query: re-evaluates the few candidates that can still be in the top-2
-//                         with the reference's direct-form float32 arithmetic (sub, mul, add — no FMA — in
-//                         OpenCV's 2x4-lane accumulation order, then sqrtf), orders them by (dist, idx) and
-//                         CERTIFIES the answer stream by stream against the lower bound of what each stream
-//                         discarded.  Streams that cannot be certified are queued …
-//   4. knn_rescan_kernel  … and their <= 512 trains evaluated exactly and merged (64-bit atomic top-2).
+//                         per wave, two 4-wave workgroups per CU, cost-weighted stream-K split over batch x row blocks
+//                         x tiles.  Every (workgroup segment, 64-tile substream, half-wave) triple is an independent
+//                         "stream" that emits its 3 best records (a record = a quad of adjacent trains).
+//   3. knn_refine_kernel  16 lanes per query: screens the rows of the records that can still matter against the fp16
+//                         image, re-evaluates the survivors with the reference's direct-form float32 arithmetic (sub,
+//                         mul, add — no FMA — in OpenCV's 2x4-lane accumulation order, then sqrtf), orders them by
+//                         (dist, idx) and CERTIFIES the answer stream by stream against the lower bound of what each
+//                         stream discarded.  Streams that cannot be certified are rescanned in the same kernel by the
+//                         whole workgroup (fp16 screen of the stream's trains, exact evaluation of the few that pass).
+//   4. ratio_scatter_*    Lowe survivors (counted by the refine kernel) written in ascending queryIdx order.
+//
+// Up to 8 equally shaped pairs share one set of launches (sfm_match_batch_l2_f32).
 //
 // The GEMM-form value is therefore never returned: indices and distances are bit-identical
 // to the direct-form oracle (oracle/sfm_oracle.c: orc_knn2_l2_f32) for any finite input.
