@@ -22,6 +22,11 @@ import os
 import sys
 import time
 
+# The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); two streams sharing one are serialised by
+# each other's barrier packets.  A rank uses three launch-set streams + the stream that issues the collectives + RCCL's
+# own: with 4 queues the exchange path lost 14 % (scripts/dev_exchange.py).  Must be set before the runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 
@@ -169,7 +174,7 @@ def bench_knn(args, world, rank, dev):
     pipe = ops.BatchPipeline(nq, nt, dev, ratio=0.70, depth=depth, batch=pbatch)
     pm = pipe.matchers[0]
     import torch.distributed as dist
-    exchange = dist.is_available() and dist.is_initialized()
+    exchange = dist.is_available() and dist.is_initialized() and not os.environ.get("SFM_BENCH_NOEX")
     ex = None
     if exchange:
         # The exchange through the package's one multi-GPU code path, sfm_mvs_amd.sharded.BatchedExchange (the
@@ -224,6 +229,7 @@ def bench_knn(args, world, rank, dev):
     t0 = time.perf_counter()
     for i in range(args.steps):
         step()
+    t_enq = time.perf_counter() - t0                         # host time to enqueue the K steps (reported, not the metric)
     drain()
     barrier_sync(world)
     elapsed = time.perf_counter() - t0
@@ -273,7 +279,8 @@ def bench_knn(args, world, rank, dev):
     out = {
         "metric": "descriptor-pair distances/sec (BF-KNN k=2 + Lowe ratio)", "value": value, "unit": "distances/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-        "ms_per_pair": elapsed / (args.steps * pbatch) * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_pair": elapsed / (args.steps * pbatch) * 1e3, "host_enqueue_ms_per_step": t_enq / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": f"f32 results (bit-identical to the direct-form f32 reference); filter arithmetic on MFMA: {mode_name}; "
                  "f32 exact refine",
         "data": "synthetic",

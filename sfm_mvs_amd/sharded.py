@@ -13,7 +13,9 @@ backend "nccl" = RCCL over xGMI; the same code runs under "gloo" on CPU tensors 
 Blocks are exchanged `batch` pairs at a time: a 160 KB all-gather per 10k-query pair costs more in launch and ring
 latency than the pair itself, and xGMI is point-to-point (a ring is bound by one link), so fewer, larger collectives.
 Batch buffers alternate (double buffering); every rank issues the same collectives in the same order whatever its own
-pair count (uneven blocks and a partial last batch send unused slots).  Camera registration (the PnP chain) is
+pair count (uneven blocks and a partial last batch send unused slots).  A rank then has more streams in flight than the
+HIP runtime's default four hardware queues (matching streams + the collective's stream + RCCL's own): export
+GPU_MAX_HW_QUEUES=8 before the process touches the GPU, or streams that share a queue serialise (measured: -14 %).  Camera registration (the PnP chain) is
 sequential and stays replicated.  `bench.py --gpus N` drives the same `BatchedExchange`.
 """
 import numpy as np
