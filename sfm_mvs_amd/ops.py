@@ -19,7 +19,7 @@ def _workspace(device, nbytes):
     streams therefore never shares scratch; within a stream, calls are ordered.  (A buffer that has to grow is replaced:
     the caching allocator keeps the old block alive for the kernels already enqueued on its stream.)"""
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    key = (device.type, idx, torch.cuda.current_stream(idx).cuda_stream)
+    key = (device.type, idx, _lib.raw_stream(idx))
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

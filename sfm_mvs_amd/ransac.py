@@ -29,7 +29,8 @@ def _dev():
 def _workspace(device, nbytes):
     """Grow-only scratch per (device, stream): the entry points synchronise their stream before returning, so a buffer
     is never in use by two calls of the same stream."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (idx, _lib.raw_stream(idx))
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = _ws[key] = torch.empty(max(int(nbytes), 1 << 16), dtype=torch.uint8, device=device)
