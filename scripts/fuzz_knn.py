@@ -46,7 +46,7 @@ def make(kind, nq, nt):
 
 kinds = ["uniform", "normal_scaled", "sift", "planted", "duplicates", "near_ties", "unit", "mixed_magnitude"]
 t_end = time.time() + budget
-cases = fails = 0
+cases = fails = batched = 0
 modes = {}
 while time.time() < t_end:
     kind = kinds[cases % len(kinds)]
@@ -60,6 +60,32 @@ while time.time() < t_end:
     nq, nt = len(q), len(t)
     variant = ["auto", "auto", "auto", "split", "f32"][cases % 5]
     ops.set_knn_filter(variant)
+    if variant != "f32" and cases % 4 == 1:
+        # a batch of 2..8 pairs of this shape in ONE launch set (sfm_match_batch_l2_f32), data families mixed: the batch runs
+        # the most general arithmetic mode any pair needs, every pair must still equal the oracle
+        B = int(rng.integers(2, 9))
+        nqb, ntb = min(nq, 1500), min(nt, 4000)
+        pairs = [make(kinds[(cases + 3 * b) % len(kinds)] if b else kind, nqb, ntb) for b in range(B)]
+        pairs = [(q[:nqb], t[:ntb]) for q, t in pairs if len(q) >= nqb and len(t) >= ntb]
+        nqb, ntb = min(len(p[0]) for p in pairs), min(len(p[1]) for p in pairs)
+        pairs = [(np.ascontiguousarray(q[:nqb]), np.ascontiguousarray(t[:ntb])) for q, t in pairs]
+        bm = ops.BatchMatcher(nqb, ntb, "cuda", ratio=0.70, batch=len(pairs))
+        bm.run([(torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda()) for q, t in pairs])
+        ok = True
+        for b, (q, t) in enumerate(pairs):
+            wi, wd = O.knn2(q, t, nthreads=os.cpu_count() or 8)
+            wq, wt, _ = O.ratio_filter(wi, wd, 0.70)
+            m = int(bm.count[b].item())
+            ok = ok and np.array_equal(bm.idx[b].cpu().numpy(), wi) and np.array_equal(bm.dist[b].cpu().numpy().view(np.uint32), wd.view(np.uint32)) \
+                and m == len(wq) and np.array_equal(bm.out_q[b, :m].cpu().numpy(), wq) and np.array_equal(bm.out_t[b, :m].cpu().numpy(), wt)
+        st = bm.stats[0].cpu().tolist()
+        modes[st[3]] = modes.get(st[3], 0) + 1
+        cases += 1
+        batched += 1
+        if not ok:
+            fails += 1
+            print(f"MISMATCH case {cases}: BATCH of {len(pairs)} kind={kind} nq={nqb} nt={ntb} variant={variant} stats={st}", flush=True)
+        continue
     pm = ops.PairMatcher(nq, nt, "cuda", ratio=0.70)
     idx, dist, oq, ot, cnt = pm.run(torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda())
     gi, gd, m = idx.cpu().numpy(), dist.cpu().numpy(), int(cnt.item())
@@ -74,5 +100,5 @@ while time.time() < t_end:
         fails += 1
         print(f"MISMATCH case {cases}: kind={kind} nq={nq} nt={nt} variant={variant} stats={st} rows differing={(gi != wi).any(1).sum()}", flush=True)
 ops.set_knn_filter("auto")
-print(f"fuzz: {cases} cases, {fails} mismatches, filter modes used {modes} (seed {seed})")
+print(f"fuzz: {cases} cases ({batched} of them batches of 2..8 pairs), {fails} mismatches, filter modes used {modes} (seed {seed})")
 sys.exit(1 if fails else 0)
