@@ -69,6 +69,8 @@ class BatchedExchange:
         self.free = [None] * nbuf                       # per buffer: event "its previous all-gather has read it"
         self.cur, self.fill, self.collectives = 0, 0, 0
         self.cuda = self.device.type == "cuda"
+        # a one-rank process group still goes through the collective (the same RCCL / gloo call as at N > 1)
+        self.collective = dist.is_available() and dist.is_initialized()
         self._timed = []                                # (start, end) events of the collectives, for exchange_ms()
 
     def next_slot(self):
@@ -93,7 +95,7 @@ class BatchedExchange:
                 main.wait_stream(st)
             ev0 = torch.cuda.Event(enable_timing=True)
             ev0.record(main)
-        if self.world > 1:
+        if self.collective:
             # (concatenated form [world * batch][...]: gloo accepts no other; nccl takes both)
             dist.all_gather_into_tensor(self.gathered[cur].view((self.world * self.batch,) + self.block_shape), self.local[cur], group=self.group)
         else:
