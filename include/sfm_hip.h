@@ -350,6 +350,8 @@ int sfm_project_points_f64(const double* rvec_host, const double* tvec_host, con
  * (pure host code, HOST pointers, no GPU needed): unit-tested against the oracle.
  *   sfm_host_epnp                 EPnP on 4..64 correspondences (solvePnPRansac's minimal solver):
  *                                 K 9 doubles, Xw [n x 3], uv [n x 2] pixels -> R 9, t 3 doubles
+ *   sfm_host_p3p                  solvePnP(P3P) on exactly four correspondences (solvePnPRansac's npoints == 4
+ *                                 branch): Xw [4 x 3], uv [4 x 2] pixels -> R 9, t 3 doubles, ok_host 1 / 0
  *   sfm_host_five_point           five K-normalised correspondences [5 x 2] each -> up to 10
  *                                 essential matrices (E_host 90 doubles), count_host int32
  *   sfm_host_decompose_essential  E -> R1, R2 (9 doubles each), t (3)
@@ -360,6 +362,8 @@ int sfm_project_points_f64(const double* rvec_host, const double* tvec_host, con
  * ---------------------------------------------------------------------- */
 int sfm_host_epnp(const double* K_host, const double* Xw_host, const double* uv_host, int n,
                   double* R_host, double* t_host);
+int sfm_host_p3p(const double* K_host, const double* Xw_host, const double* uv_host, double* R_host, double* t_host,
+                 int32_t* ok_host);
 int sfm_host_five_point(const double* x1n_host, const double* x2n_host, double* E_host, int32_t* count_host);
 int sfm_host_decompose_essential(const double* E_host, double* R1_host, double* R2_host, double* t_host);
 int sfm_host_pnp_dlt_init(const double* K_host, const double* X_host, const double* uv_host, int64_t n,

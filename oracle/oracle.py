@@ -308,6 +308,14 @@ def epnp(K, Xw, uv):
     return R, t
 
 
+def p3p(K, Xw, uv):
+    """solvePnP(P3P) on exactly four correspondences -> (ok, R, t)."""
+    Xw, uv = _f64(Xw).reshape(4, 3), _f64(uv).reshape(4, 2)
+    R, t = np.zeros((3, 3)), np.zeros(3)
+    ok = lib().orc_p3p(_p(_f64(K).reshape(9)), _p(Xw), _p(uv), _p(R), _p(t))
+    return bool(ok), R, t
+
+
 def pnp_dlt_init(K, X, uv):
     """Non-planar initialisation of solvePnP(ITERATIVE) -> (status, rvec, tvec); status 1 planar, 2 too few points."""
     X, uv = _f64(X).reshape(-1, 3), _f64(uv).reshape(-1, 2)
@@ -335,7 +343,7 @@ def solve_pnp_ransac(X, uv, K, iterations=100, reproj_error=8.0, confidence=0.99
                                     C.c_float(reproj_error), C.c_double(confidence), _p(r), _p(t), _p(inl), C.byref(ninl),
                                     _p(model), C.byref(st))
     if ok < 0:
-        raise ValueError("orc_solve_pnp_ransac: at least 5 correspondences (P3P branch not restated)")
+        raise ValueError("orc_solve_pnp_ransac: at least 4 correspondences (OpenCV asserts npoints >= 4)")
     if ok == 0:
         return (False, None, None, None) + ((None, st.value) if want_model else ())
     out = (True, r.reshape(3, 1), t.reshape(3, 1), inl[:ninl.value].reshape(-1, 1).copy())

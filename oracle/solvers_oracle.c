@@ -1090,6 +1090,102 @@ int orc_levmarq_pose(const double* X, const double* uv, int64_t n, const double*
 }
 
 /* ------------------------------------------------------------------------------------------
+ * solvePnP(SOLVEPNP_P3P) — what solvePnPRansac runs when it is given exactly FOUR points
+ * (model_points = npoints = 4: no RANSAC, every point an inlier).  OpenCV's p3p.cpp solves the
+ * perspective-three-point problem on the first three correspondences (Gao et al. 2003: a
+ * quartic from the law of cosines, then an absolute orientation) and keeps, of its up to four
+ * poses, the one that reprojects the FOURTH point best.  That source is not available here
+ * (un-vendored third party), so this restatement takes the classical route to the same quartic
+ * problem — Grunert's elimination in Haralick et al.'s notation (IJCV 1994): with
+ * a = |P2 P3|, b = |P1 P3|, c = |P1 P2| and the cosines of the angles between the bearings,
+ * s2 = u s1, s3 = v s1, v is a root of A4 v^4 + ... + A0 — solved with solvePoly, the pose from
+ * the two orthonormal frames of the triangle, and OpenCV's selection rule (squared pixel error
+ * of point 4).  Every minimal solver returns the roots of the same system; which formula
+ * produced them shows in the last digits only.  Returns 1 with R (row-major), t, or 0.
+ * ---------------------------------------------------------------------------------------- */
+static void p3p_frame(const double* Q /*3 points x 3*/, double* F /*3x3 row-major, columns e1 e2 e3*/) {
+    double e1[3], w[3], e3[3], e2[3];
+    for (int k = 0; k < 3; ++k) { e1[k] = Q[3 + k] - Q[k]; w[k] = Q[6 + k] - Q[k]; }
+    double n1 = sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+    for (int k = 0; k < 3; ++k) e1[k] = e1[k] / n1;
+    e3[0] = e1[1] * w[2] - e1[2] * w[1];
+    e3[1] = e1[2] * w[0] - e1[0] * w[2];
+    e3[2] = e1[0] * w[1] - e1[1] * w[0];
+    double n3 = sqrt(e3[0] * e3[0] + e3[1] * e3[1] + e3[2] * e3[2]);
+    for (int k = 0; k < 3; ++k) e3[k] = e3[k] / n3;
+    e2[0] = e3[1] * e1[2] - e3[2] * e1[1];
+    e2[1] = e3[2] * e1[0] - e3[0] * e1[2];
+    e2[2] = e3[0] * e1[1] - e3[1] * e1[0];
+    for (int k = 0; k < 3; ++k) { F[3 * k] = e1[k]; F[3 * k + 1] = e2[k]; F[3 * k + 2] = e3[k]; }
+}
+
+int orc_p3p(const double* K, const double* Xw /*4 x 3*/, const double* uv /*4 x 2 pixels*/, double* Rout, double* tout) {
+    const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    double f[3][3];
+    for (int i = 0; i < 3; ++i) {
+        const double x = (uv[2 * i] - cx) / fx, y = (uv[2 * i + 1] - cy) / fy;
+        const double nrm = sqrt(x * x + y * y + 1.0);
+        f[i][0] = x / nrm; f[i][1] = y / nrm; f[i][2] = 1.0 / nrm;
+    }
+    double d12[3], d13[3], d23[3];
+    for (int k = 0; k < 3; ++k) { d23[k] = Xw[3 + k] - Xw[6 + k]; d13[k] = Xw[k] - Xw[6 + k]; d12[k] = Xw[k] - Xw[3 + k]; }
+    const double a2 = d23[0] * d23[0] + d23[1] * d23[1] + d23[2] * d23[2];
+    const double b2 = d13[0] * d13[0] + d13[1] * d13[1] + d13[2] * d13[2];
+    const double c2 = d12[0] * d12[0] + d12[1] * d12[1] + d12[2] * d12[2];
+    if (!(a2 > 0) || !(b2 > 0) || !(c2 > 0)) return 0;
+    const double ca = f[1][0] * f[2][0] + f[1][1] * f[2][1] + f[1][2] * f[2][2];
+    const double cb = f[0][0] * f[2][0] + f[0][1] * f[2][1] + f[0][2] * f[2][2];
+    const double cg = f[0][0] * f[1][0] + f[0][1] * f[1][1] + f[0][2] * f[1][2];
+    const double k1 = (a2 - c2) / b2, k2 = (a2 + c2) / b2, k3 = (b2 - c2) / b2, k4 = (b2 - a2) / b2;
+    const double cab = c2 / b2, aab = a2 / b2;
+    double A[5];
+    A[4] = (k1 - 1) * (k1 - 1) - 4 * cab * ca * ca;
+    A[3] = 4 * (k1 * (1 - k1) * cb - (1 - k2) * ca * cg + 2 * cab * ca * ca * cb);
+    A[2] = 2 * (k1 * k1 - 1 + 2 * k1 * k1 * cb * cb + 2 * k3 * ca * ca - 4 * k2 * ca * cb * cg + 2 * k4 * cg * cg);
+    A[1] = 4 * (-k1 * (1 + k1) * cb + 2 * aab * cg * cg * cb - (1 - k2) * ca * cg);
+    A[0] = (1 + k1) * (1 + k1) - 4 * aab * cg * cg;
+    double rre[4], rim[4];
+    const int nr = orc_solve_poly(A, 4, rre, rim, 300);
+    int found = 0;
+    double best = 0;
+    for (int r = 0; r < nr; ++r) {
+        const double v = rre[r];
+        if (!(fabs(rim[r]) <= 1e-9 * (1.0 + fabs(v))) || !(v > 0)) continue;
+        const double den = 2 * (cg - v * ca);
+        if (den == 0) continue;
+        const double u = ((k1 - 1) * v * v - 2 * k1 * cb * v + 1 + k1) / den;
+        if (!(u > 0)) continue;
+        const double q = 1 + v * v - 2 * v * cb;
+        if (!(q > 0)) continue;
+        const double s1 = sqrt(b2 / q), s2 = u * s1, s3 = v * s1;
+        double Y[9], FY[9], FP[9], R[9], t[3];
+        for (int k = 0; k < 3; ++k) { Y[k] = s1 * f[0][k]; Y[3 + k] = s2 * f[1][k]; Y[6 + k] = s3 * f[2][k]; }
+        p3p_frame(Y, FY);
+        p3p_frame(Xw, FP);
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) R[3 * i + j] = FY[3 * i] * FP[3 * j] + FY[3 * i + 1] * FP[3 * j + 1] + FY[3 * i + 2] * FP[3 * j + 2];
+        for (int i = 0; i < 3; ++i) t[i] = Y[i] - (R[3 * i] * Xw[0] + R[3 * i + 1] * Xw[1] + R[3 * i + 2] * Xw[2]);
+        int finite = 1;
+        for (int k = 0; k < 9; ++k) finite = finite && isfinite(R[k]);
+        for (int k = 0; k < 3; ++k) finite = finite && isfinite(t[k]);
+        if (!finite) continue;
+        const double* P4 = Xw + 9;
+        const double x4 = R[0] * P4[0] + R[1] * P4[1] + R[2] * P4[2] + t[0];
+        const double y4 = R[3] * P4[0] + R[4] * P4[1] + R[5] * P4[2] + t[1];
+        const double z4 = R[6] * P4[0] + R[7] * P4[1] + R[8] * P4[2] + t[2];
+        const double eu = fx * (x4 / z4) + cx - uv[6], ev = fy * (y4 / z4) + cy - uv[7];
+        const double err = eu * eu + ev * ev;
+        if (!found || err < best) {
+            best = err;
+            found = 1;
+            memcpy(Rout, R, sizeof(R));
+            memcpy(tout, t, sizeof(t));
+        }
+    }
+    return found;
+}
+
+/* ------------------------------------------------------------------------------------------
  * cv2.solvePnPRansac(objectPoints, imagePoints, K, distCoeffs = zeros(5,1), <rvec slot>)  sfm.py:67
  * (calib3d/solvepnp.cpp) with every tunable at its default: iterationsCount 100,
  * reprojectionError 8.0, confidence 0.99, flags ITERATIVE.  model_points = 5, minimal solver
@@ -1099,7 +1195,7 @@ int orc_levmarq_pose(const double* X, const double* uv, int64_t n, const double*
  * tvec) via Rodrigues; error = squared pixel distance of the float32 projection, as float, <=
  * (float)(8*8).  After RANSAC the inliers (as doubles) go through solvePnP(ITERATIVE); the
  * returned inliers are those of the best RANSAC model.
- * n == 4 is OpenCV's P3P branch and n < 4 an assertion: both return -1 here (not on the path).
+ * n == 4 is OpenCV's P3P branch (orc_p3p above); n < 4 is an assertion there and returns -1 here.
  * Returns 1 on success, 0 if RANSAC found no model.  status_out (optional): 0 DLT init,
  * 1 planar fallback, 2 too few inliers for the DLT (RANSAC model refined instead).
  * ---------------------------------------------------------------------------------------- */
@@ -1108,8 +1204,26 @@ int orc_solve_pnp_ransac(const float* X, const float* uv, int64_t n, const doubl
                          double* ransac_model, int* status_out) {
     if (n_inliers) *n_inliers = 0;
     if (status_out) *status_out = 0;
-    if (n < 5) return -1;
+    if (n < 4) return -1;
     const double ifx = 1. / K[0], ify = 1. / K[4];
+    if (n == 4) {
+        /* model_points == npoints == 4: a plain solvePnP(P3P), every point an inlier */
+        double Xs[12], us[8], R[9], t[3];
+        for (int k = 0; k < 4; ++k) {
+            for (int j = 0; j < 3; ++j) Xs[3 * k + j] = (double)X[3 * k + j];
+            us[2 * k] = (double)(float)(((double)uv[2 * k] - K[2]) * ifx) * K[0] + K[2];
+            us[2 * k + 1] = (double)(float)(((double)uv[2 * k + 1] - K[5]) * ify) * K[4] + K[5];
+        }
+        const int ok = orc_p3p(K, Xs, us, R, t);
+        if (ok) {
+            orc_rodrigues_mat2vec(R, rvec);
+            memcpy(tvec, t, sizeof(t));
+            for (int k = 0; k < 4; ++k) inliers[k] = k;
+            if (n_inliers) *n_inliers = 4;
+            if (ransac_model) { memcpy(ransac_model, rvec, 24); memcpy(ransac_model + 3, tvec, 24); }
+        }
+        return ok;
+    }
     uint8_t* cur = (uint8_t*)malloc((size_t)n);
     uint8_t* bestmask = (uint8_t*)malloc((size_t)n);
     double best_model[6] = {0, 0, 0, 0, 0, 0};

@@ -865,6 +865,110 @@ private:
     }
 };
 
+// ------------------------------------------------------------------------------------------------ P3P
+// solvePnP(SOLVEPNP_P3P): what solvePnPRansac runs on exactly four points (model_points = npoints = 4: no RANSAC).  The
+// perspective-three-point problem on the first three correspondences — Grunert's quartic in Haralick et al.'s notation
+// (a = |P2 P3|, b = |P1 P3|, c = |P1 P2|, s2 = u s1, s3 = v s1), roots by solve_poly, pose from the two orthonormal frames of
+// the triangle — and, as OpenCV's p3p class does, the pose that reprojects the fourth point best.  R row-major.
+inline void p3p_frame(const double* Q, double* F) {
+    double e1[3], w[3], e3[3], e2[3];
+    for (int k = 0; k < 3; ++k) {
+        e1[k] = Q[3 + k] - Q[k];
+        w[k] = Q[6 + k] - Q[k];
+    }
+    const double n1 = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+    for (int k = 0; k < 3; ++k) e1[k] = e1[k] / n1;
+    e3[0] = e1[1] * w[2] - e1[2] * w[1];
+    e3[1] = e1[2] * w[0] - e1[0] * w[2];
+    e3[2] = e1[0] * w[1] - e1[1] * w[0];
+    const double n3 = std::sqrt(e3[0] * e3[0] + e3[1] * e3[1] + e3[2] * e3[2]);
+    for (int k = 0; k < 3; ++k) e3[k] = e3[k] / n3;
+    e2[0] = e3[1] * e1[2] - e3[2] * e1[1];
+    e2[1] = e3[2] * e1[0] - e3[0] * e1[2];
+    e2[2] = e3[0] * e1[1] - e3[1] * e1[0];
+    for (int k = 0; k < 3; ++k) {
+        F[3 * k] = e1[k];
+        F[3 * k + 1] = e2[k];
+        F[3 * k + 2] = e3[k];
+    }
+}
+
+inline bool p3p(const double* K, const double* Xw /*4 x 3*/, const double* uv /*4 x 2 pixels*/, double* Rout, double* tout) {
+    const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    double f[3][3];
+    for (int i = 0; i < 3; ++i) {
+        const double x = (uv[2 * i] - cx) / fx, y = (uv[2 * i + 1] - cy) / fy;
+        const double nrm = std::sqrt(x * x + y * y + 1.0);
+        f[i][0] = x / nrm;
+        f[i][1] = y / nrm;
+        f[i][2] = 1.0 / nrm;
+    }
+    double d12[3], d13[3], d23[3];
+    for (int k = 0; k < 3; ++k) {
+        d23[k] = Xw[3 + k] - Xw[6 + k];
+        d13[k] = Xw[k] - Xw[6 + k];
+        d12[k] = Xw[k] - Xw[3 + k];
+    }
+    const double a2 = d23[0] * d23[0] + d23[1] * d23[1] + d23[2] * d23[2];
+    const double b2 = d13[0] * d13[0] + d13[1] * d13[1] + d13[2] * d13[2];
+    const double c2 = d12[0] * d12[0] + d12[1] * d12[1] + d12[2] * d12[2];
+    if (!(a2 > 0) || !(b2 > 0) || !(c2 > 0)) return false;
+    const double ca = f[1][0] * f[2][0] + f[1][1] * f[2][1] + f[1][2] * f[2][2];
+    const double cb = f[0][0] * f[2][0] + f[0][1] * f[2][1] + f[0][2] * f[2][2];
+    const double cg = f[0][0] * f[1][0] + f[0][1] * f[1][1] + f[0][2] * f[1][2];
+    const double k1 = (a2 - c2) / b2, k2 = (a2 + c2) / b2, k3 = (b2 - c2) / b2, k4 = (b2 - a2) / b2;
+    const double cab = c2 / b2, aab = a2 / b2;
+    double A[5];
+    A[4] = (k1 - 1) * (k1 - 1) - 4 * cab * ca * ca;
+    A[3] = 4 * (k1 * (1 - k1) * cb - (1 - k2) * ca * cg + 2 * cab * ca * ca * cb);
+    A[2] = 2 * (k1 * k1 - 1 + 2 * k1 * k1 * cb * cb + 2 * k3 * ca * ca - 4 * k2 * ca * cb * cg + 2 * k4 * cg * cg);
+    A[1] = 4 * (-k1 * (1 + k1) * cb + 2 * aab * cg * cg * cb - (1 - k2) * ca * cg);
+    A[0] = (1 + k1) * (1 + k1) - 4 * aab * cg * cg;
+    Cx roots[4];
+    const int nr = solve_poly(A, 4, roots);
+    bool found = false;
+    double best = 0;
+    for (int r = 0; r < nr; ++r) {
+        const double v = roots[r].re;
+        if (!(std::fabs(roots[r].im) <= 1e-9 * (1.0 + std::fabs(v))) || !(v > 0)) continue;
+        const double den = 2 * (cg - v * ca);
+        if (den == 0) continue;
+        const double u = ((k1 - 1) * v * v - 2 * k1 * cb * v + 1 + k1) / den;
+        if (!(u > 0)) continue;
+        const double q = 1 + v * v - 2 * v * cb;
+        if (!(q > 0)) continue;
+        const double s1 = std::sqrt(b2 / q), s2 = u * s1, s3 = v * s1;
+        double Y[9], FY[9], FP[9], R[9], t[3];
+        for (int k = 0; k < 3; ++k) {
+            Y[k] = s1 * f[0][k];
+            Y[3 + k] = s2 * f[1][k];
+            Y[6 + k] = s3 * f[2][k];
+        }
+        p3p_frame(Y, FY);
+        p3p_frame(Xw, FP);
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) R[3 * i + j] = FY[3 * i] * FP[3 * j] + FY[3 * i + 1] * FP[3 * j + 1] + FY[3 * i + 2] * FP[3 * j + 2];
+        for (int i = 0; i < 3; ++i) t[i] = Y[i] - (R[3 * i] * Xw[0] + R[3 * i + 1] * Xw[1] + R[3 * i + 2] * Xw[2]);
+        bool finite = true;
+        for (int k = 0; k < 9; ++k) finite = finite && std::isfinite(R[k]);
+        for (int k = 0; k < 3; ++k) finite = finite && std::isfinite(t[k]);
+        if (!finite) continue;
+        const double* P4 = Xw + 9;
+        const double x4 = R[0] * P4[0] + R[1] * P4[1] + R[2] * P4[2] + t[0];
+        const double y4 = R[3] * P4[0] + R[4] * P4[1] + R[5] * P4[2] + t[1];
+        const double z4 = R[6] * P4[0] + R[7] * P4[1] + R[8] * P4[2] + t[2];
+        const double eu = fx * (x4 / z4) + cx - uv[6], ev = fy * (y4 / z4) + cy - uv[7];
+        const double err = eu * eu + ev * ev;
+        if (!found || err < best) {
+            best = err;
+            found = true;
+            std::memcpy(Rout, R, sizeof(R));
+            std::memcpy(tout, t, sizeof(t));
+        }
+    }
+    return found;
+}
+
 // ------------------------------------------------------------------------------------------------ ITERATIVE init
 // cvFindExtrinsicCameraParams2's non-planar initialisation: 2n x 12 DLT on normalised image points, SVD of L^T L, the
 // 3x3 part re-orthonormalised, translation rescaled.  Returns 0, 1 (planar object: not handled here) or 2 (< 6 points).

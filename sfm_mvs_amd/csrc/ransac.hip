@@ -434,8 +434,7 @@ extern "C" int sfm_solve_pnp_ransac(const float* X_dev, const float* uv_dev, int
                                     int32_t* info_host, int32_t* inliers_dev, void* ws, size_t ws_bytes, void* stream_) {
     SFM_CHECK_ARG(K && rvec_host && tvec_host && info_host, "sfm_solve_pnp_ransac: null pointer");
     info_host[0] = info_host[1] = info_host[2] = info_host[3] = 0;      // ok, inliers, init status, LM iterations
-    SFM_CHECK_ARG(n >= 5 && n < (int64_t)1 << 30,
-                  "sfm_solve_pnp_ransac: at least 5 correspondences are required (OpenCV's P3P branch for exactly 4 is not on this path; got %lld)",
+    SFM_CHECK_ARG(n >= 4 && n < (int64_t)1 << 30, "sfm_solve_pnp_ransac: at least 4 correspondences are required (OpenCV asserts npoints >= 4; got %lld)",
                   (long long)n);
     SFM_CHECK_ARG(X_dev && uv_dev && inliers_dev, "sfm_solve_pnp_ransac: null pointer");
     if (!ws || ws_bytes < sfm_solve_pnp_ransac_ws_bytes(n)) {
@@ -492,6 +491,24 @@ extern "C" int sfm_solve_pnp_ransac(const float* X_dev, const float* uv_dev, int
         std::memcpy(model + 3, t, sizeof(t));
         return true;
     };
+    if (n == 4) {                     // OpenCV switches to model_points = 4 / SOLVEPNP_P3P: plain solvePnP(P3P), every point an inlier
+        double Xs[12], us[8], R[9], t[3], model[6];
+        for (int k = 0; k < 4; ++k) {
+            for (int j = 0; j < 3; ++j) Xs[3 * k + j] = (double)hX[3 * k + j];
+            us[2 * k] = (double)(float)(((double)huv[2 * k] - K[2]) * ifx) * K[0] + K[2];
+            us[2 * k + 1] = (double)(float)(((double)huv[2 * k + 1] - K[5]) * ify) * K[4] + K[5];
+        }
+        if (!hs::p3p(K, Xs, us, R, t)) return SFM_OK;
+        hs::rodrigues_mat2vec(R, model);
+        std::memcpy(rvec_host, model, 24);
+        std::memcpy(tvec_host, t, 24);
+        const int32_t all[4] = {0, 1, 2, 3};
+        SFM_CHECK_HIP(hipMemcpyAsync(inliers_dev, all, sizeof(all), hipMemcpyHostToDevice, stream));
+        SFM_CHECK_HIP(hipStreamSynchronize(stream));
+        info_host[0] = 1;
+        info_host[1] = 4;
+        return SFM_OK;
+    }
     if (n == 5) {                     // model_points == npoints: plain solvePnP(EPNP), every point an inlier
         const int idx[5] = {0, 1, 2, 3, 4};
         double model[6];
@@ -647,6 +664,12 @@ extern "C" int sfm_host_epnp(const double* K, const double* Xw, const double* uv
     SFM_CHECK_ARG(K && Xw && uv && R_out && t_out, "sfm_host_epnp: null pointer");
     SFM_CHECK_ARG(n >= 4 && n <= hs::kEpnpMaxPts, "sfm_host_epnp: n must be in [4, %d] (got %d)", hs::kEpnpMaxPts, n);
     hs::Epnp(K, Xw, uv, n).compute_pose(R_out, t_out);
+    return SFM_OK;
+}
+
+extern "C" int sfm_host_p3p(const double* K, const double* Xw, const double* uv, double* R_out, double* t_out, int32_t* ok_out) {
+    SFM_CHECK_ARG(K && Xw && uv && R_out && t_out && ok_out, "sfm_host_p3p: null pointer");
+    *ok_out = hs::p3p(K, Xw, uv, R_out, t_out) ? 1 : 0;
     return SFM_OK;
 }
 

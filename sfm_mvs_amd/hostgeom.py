@@ -59,6 +59,17 @@ def epnp(K, Xw, uv):
     return R.reshape(3, 3), t
 
 
+def p3p(K, Xw, uv):
+    """solvePnP(P3P) on exactly four correspondences (`sfm_host_p3p`): (ok, R (3,3), t (3,))."""
+    Kc = np.ascontiguousarray(np.asarray(K, np.float64).reshape(9))
+    X = np.ascontiguousarray(np.asarray(Xw, np.float64).reshape(4, 3))
+    u = np.ascontiguousarray(np.asarray(uv, np.float64).reshape(4, 2))
+    R, t, ok = np.zeros(9), np.zeros(3), np.zeros(1, np.int32)
+    _lib.check(_lib.lib().sfm_host_p3p(Kc.ctypes.data_as(_vp), X.ctypes.data_as(_vp), u.ctypes.data_as(_vp),
+                                       R.ctypes.data_as(_vp), t.ctypes.data_as(_vp), ok.ctypes.data_as(_vp)), "sfm_host_p3p")
+    return bool(ok[0]), R.reshape(3, 3), t
+
+
 def pnp_dlt_init(K, Xw, uv):
     """Non-planar initialisation of solvePnP(ITERATIVE) (`sfm_host_pnp_dlt_init`): (status, rvec, tvec);
     status 0 ok, 1 planar object, 2 fewer than 6 points."""

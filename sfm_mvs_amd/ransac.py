@@ -99,14 +99,13 @@ def solve_pnp_ransac(X, uv, K, iterations_count=100, reprojection_error=8.0, con
                      want_info=False):
     """cv2.solvePnPRansac(objectPoints, imagePoints, K, dist) with all defaults (the reference's 5th positional argument
     lands in `rvec` and is ignored: SURVEY 3.6-1): RANSAC over EPnP on 5-point samples, then solvePnP(ITERATIVE) on the
-    inlier set.  Returns (ok, rvec (3,1), tvec (3,1), inliers (k,1) int32 or None)."""
+    inlier set (exactly 4 points: solvePnP(P3P); exactly 5: solvePnP(EPNP)).  Returns (ok, rvec (3,1), tvec (3,1), inliers (k,1) int32 or None)."""
     Xd, ud = _points(X, 3), _points(uv, 2)
     n = Xd.shape[0]
     if ud.shape[0] != n:
         raise SfmHipError("solvePnPRansac: object and image points differ in length")
-    if n < 5:          # OpenCV asserts npoints >= 4 and switches to P3P for exactly 4; not on this path
-        raise SfmHipError(f"solvePnPRansac: at least 5 correspondences are required on this path (got {n}); "
-                          "OpenCV's 4-point P3P branch is not provided")
+    if n < 4:          # OpenCV asserts npoints >= 4 (exactly 4: solvePnP(P3P), every point an inlier)
+        raise SfmHipError(f"solvePnPRansac: at least 4 correspondences are required (got {n})")
     Kc = _k(K)
     r, t, info = np.zeros(3), np.zeros(3), np.zeros(4, np.int32)
     lib = _lib.lib()

@@ -60,8 +60,11 @@ def test_ransac_entry_point_edge_cases(hip, oracle):
     ok5o, r5o, t5o, i5o = oracle.solve_pnp_ransac(Xf[:5], x2[:5], K)
     ok5h, r5h, t5h, i5h = ransac.solve_pnp_ransac(Xf[:5], x2[:5], K)
     assert ok5o and ok5h and np.array_equal(r5o, r5h) and np.array_equal(t5o, t5h) and np.array_equal(i5o, i5h)
+    ok4o, r4o, t4o, i4o = oracle.solve_pnp_ransac(Xf[:4], x2[:4], K)                         # npoints == 4: solvePnP(P3P)
+    ok4h, r4h, t4h, i4h = ransac.solve_pnp_ransac(Xf[:4], x2[:4], K)
+    assert ok4o and ok4h and np.array_equal(r4o, r4h) and np.array_equal(t4o, t4h) and np.array_equal(i4o, i4h)
     with pytest.raises(SfmHipError):
-        ransac.solve_pnp_ransac(Xf[:4], x2[:4], K)                                            # OpenCV's P3P branch: not on the path
+        ransac.solve_pnp_ransac(Xf[:3], x2[:3], K)                                            # OpenCV asserts npoints >= 4
     # pure outliers: no model survives (good must exceed modelPoints - 1)
     rng = np.random.default_rng(0)
     junk = rng.uniform(0, 900, (60, 2)).astype(np.float32)

@@ -33,6 +33,10 @@ def test_host_solvers_are_bit_identical_to_the_oracle(oracle, sigma):
         if len(Eo):
             for x, y in zip(oracle.decompose_essential(Eo[0]), hg.decompose_essential(Eo[0])):
                 assert np.array_equal(x, y)
+        sel = rng.choice(40, 4, replace=False)
+        oko, Rp, tp = oracle.p3p(K, X[sel], x2[sel].astype(np.float64))
+        okh, Rq, tq = hg.p3p(K, X[sel], x2[sel].astype(np.float64))
+        assert oko == okh and np.array_equal(Rp, Rq) and np.array_equal(tp, tq), trial
 
 
 def test_rodrigues_matches_the_oracle_and_round_trips(oracle):

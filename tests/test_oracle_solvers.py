@@ -105,6 +105,40 @@ def test_epnp_recovers_planted_poses_and_matches_numpy_on_exact_data(oracle):
         assert np.abs(Ro - Rn).max() < 1e-5 and np.abs(to - tn).max() < 1e-4 * max(1.0, np.abs(tn).max()), trial
 
 
+def test_p3p_recovers_planted_poses_and_picks_by_the_fourth_point(oracle):
+    """solvePnPRansac's npoints == 4 branch (solvePnP(P3P)): exact observations of a planted pose must give it back — every
+    real root of the quartic is a pose that reprojects the first three points exactly, the fourth point selects among them —
+    and the solution must satisfy the problem's own equations whatever the noise."""
+    K, P1, P2, X, x1, x2 = gustav_pair(5, 400, 0.0, seed=21)
+    R, t = decompose_P(K, P2)
+    rng = np.random.default_rng(3)
+    for trial in range(200):
+        sel = rng.choice(len(X), 4, replace=False)
+        Y = X[sel] @ R.T + t
+        uv = (K @ (Y / Y[:, 2:]).T).T[:, :2]                       # float64 observations: exact
+        ok, Rg, tg = oracle.p3p(K, X[sel], uv)
+        assert ok, trial
+        assert abs(np.linalg.det(Rg) - 1) < 1e-9 and np.allclose(Rg @ Rg.T, np.eye(3), atol=1e-9)
+        assert np.abs(Rg - R).max() < 1e-5 and np.abs(tg - t).max() < 1e-4, trial
+        noisy = uv + rng.normal(0, 0.5, uv.shape)
+        ok, Rn, tn = oracle.p3p(K, X[sel], noisy)
+        if ok:                                                      # the first three points reproject exactly
+            Yn = X[sel[:3]] @ Rn.T + tn
+            assert np.abs((K @ (Yn / Yn[:, 2:]).T).T[:, :2] - noisy[:3]).max() < 1e-3, trial          # (pixels; the quartic can be ill-conditioned)
+            assert (Yn[:, 2] > 0).all()
+    # three collinear object points have no triangle frame: no pose, no crash
+    line = np.array([[0, 0, 5.0], [1, 0, 5.0], [2, 0, 5.0], [0.3, 0.7, 6.0]])
+    ok, *_ = oracle.p3p(K, line, (K @ (line / line[:, 2:]).T).T[:, :2])
+    assert ok in (True, False)
+    # through solvePnPRansac: four points -> that pose, every point an inlier
+    sel = np.arange(4)
+    ok, r, tv, inl = oracle.solve_pnp_ransac(X[sel].astype(np.float32), x2[sel], K)
+    assert ok and inl.ravel().tolist() == [0, 1, 2, 3]
+    assert np.abs(oracle.rodrigues_vec2mat(r.ravel()) - R).max() < 1e-3 and np.abs(tv.ravel() - t).max() < 2e-2
+    with pytest.raises(ValueError):
+        oracle.solve_pnp_ransac(X[:3].astype(np.float32), x2[:3], K)
+
+
 def test_iterative_init_and_levenberg_marquardt(oracle):
     K, P1, P2, X, x1, x2 = gustav_pair(3, 60, 0.0, seed=5)
     R, t = decompose_P(K, P2)
@@ -133,7 +167,7 @@ def test_solve_pnp_ransac_rejects_planted_outliers(oracle):
     _, mask = oracle.score_pnp(model[None], K, X.astype(np.float32), x2, 64.0)
     assert np.array_equal(np.flatnonzero(mask[0]), inl[:, 0])
     with pytest.raises(ValueError):
-        oracle.solve_pnp_ransac(X[:4].astype(np.float32), x2[:4], K)
+        oracle.solve_pnp_ransac(X[:3].astype(np.float32), x2[:3], K)                    # OpenCV asserts npoints >= 4
     ok5, r5, t5, i5 = oracle.solve_pnp_ransac(X[:5].astype(np.float32), x2[:5], K)      # model_points == npoints: plain EPnP
     assert ok5 and i5[:, 0].tolist() == [0, 1, 2, 3, 4]
 
