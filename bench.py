@@ -622,7 +622,22 @@ def bench_ba(args, world, rank, dev):
               "cost_noise_floor": 2.0 * nobs * 0.25,
               "note": "Schur-complement LM (sfm_mvs_amd.ba.bundle_adjust_schur): PCG on the reduced camera system, "
                       "S x = B x - W C^-1 W^T x with W never formed (sfm_ba_schur_wt / sfm_ba_schur_w)"}
-    return {"solver": solver,
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        # the oracle's sweep (sequential C, one thread: its accumulation order is the reference order) on a bounded slice of
+        # the same problem: all 500 cameras x the first 4 000 points = 2e6 observations, residual + all four block sets
+        from oracle import oracle as O
+        ns = 40000
+        cam_idx = np.repeat(np.arange(ncam, dtype=np.int32), ns)
+        pt_idx = np.tile(np.arange(ns, dtype=np.int32), ncam)
+        ch, Xh, oh = cams_p.cpu().numpy(), X[:ns].cpu().numpy(), obs[:, :ns].reshape(-1, 2).cpu().numpy()
+        t1 = time.perf_counter()
+        O.project_residual(ch, K, Xh, oh, cam_idx, pt_idx)
+        dt = time.perf_counter() - t1
+        cpu = {"value": ncam * ns / dt, "unit": "observations/s", "cores": 1, "kind": "port",
+               "sample": f"all {ncam} cameras x the first {ns} points of the same problem ({ncam * ns} observations), once, oracle "
+                         f"orc_project_residual (sequential C, 1 thread), {dt:.1f} s"}
+    return {"solver": solver, "cpu_baseline": cpu,
             "metric": "BA observations/sec (residual + J^T J sweep)", "value": world * nobs * steps / elapsed,
             "unit": "observations/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
             "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

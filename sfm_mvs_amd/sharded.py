@@ -236,3 +236,41 @@ def triangulate_pairs_sharded(store, n_query, pairs, keypoints, proj, triangulat
             dst[r] = torch.from_numpy(np.where(k < h, k, n_pairs))
         points.index_copy_(0, dst.reshape(-1).to(dev), gathered.reshape((world * batch,) + gathered.shape[2:]))
     return points[:n_pairs], counts
+
+
+def knn2_train_split(des0, des1_shard, train_offset, knn2=None, group=None):
+    """SURVEY 8e's fallback for ONE pair whose train set is split over the ranks (a descriptor set that does not fit one
+    device, or a single huge pair to be sped up): every rank holds all queries and the train rows
+    [train_offset, train_offset + len(des1_shard)), computes its partial top-2, the partial results are all-gathered and
+    merged 2 * world -> 2 by (distance, global train index) — associative, and the lower index wins ties exactly as in a
+    single scan (cv2.BFMatcher keeps the earlier row).  knn2(des0, des1) -> (idx [nq,2] int32, dist [nq,2] float32), -1 /
+    anything where a neighbour is missing; default: the HIP kernel.  Returns (idx, dist) on every rank."""
+    world, rank = _world_rank(group)
+    if knn2 is None:
+        from . import ops
+        knn2 = ops.knn2
+    nq, dev = des0.shape[0], des0.device
+    local = torch.empty((2, nq, 2), dtype=torch.int32, device=dev)
+    if des1_shard.shape[0] > 0:
+        idx, d = knn2(des0, des1_shard)
+        local[0] = torch.where(idx >= 0, idx + int(train_offset), idx)
+        local[1] = d.contiguous().view(torch.int32)
+    else:
+        local[0].fill_(-1)
+        local[1].zero_()
+    gathered = torch.empty((world, 2, nq, 2), dtype=torch.int32, device=dev)
+    if dist.is_available() and dist.is_initialized():
+        dist.all_gather_into_tensor(gathered.view(world * 2, nq, 2), local, group=group)
+    else:
+        gathered[0].copy_(local)
+    cand_i = gathered[:, 0].permute(1, 0, 2).reshape(nq, 2 * world)                       # [nq][2 world]
+    cand_d = gathered[:, 1].permute(1, 0, 2).reshape(nq, 2 * world).contiguous().view(torch.float32)
+    cand_d = torch.where(cand_i >= 0, cand_d, torch.full_like(cand_d, float("inf")))
+    key_i = torch.where(cand_i >= 0, cand_i, torch.full_like(cand_i, 2 ** 31 - 1))
+    o1 = torch.sort(key_i, dim=1, stable=True).indices                                    # by index ...
+    d1 = torch.gather(cand_d, 1, o1)
+    o2 = torch.sort(d1, dim=1, stable=True).indices                                       # ... then (stable) by distance
+    order = torch.gather(o1, 1, o2)[:, :2]
+    out_i = torch.gather(cand_i, 1, order)
+    out_d = torch.gather(cand_d, 1, order)
+    return out_i.contiguous(), torch.where(out_i >= 0, out_d, torch.zeros_like(out_d)).contiguous()

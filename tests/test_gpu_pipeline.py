@@ -295,6 +295,10 @@ def test_sharded_path_on_one_gpu(hip, oracle):
         want = oracle.triangulate(P[i], P[j], kps[i][wq].T.copy(), kps[j][wt].T.copy(), normalise_w=True)
         got = pts[p, :, :len(wq)].cpu().numpy()
         assert np.allclose(got, want, rtol=1e-6, atol=1e-7) and float(pts[p, :, len(wq):].abs().sum()) == 0.0
+    # the train-split form on one rank with the HIP kernel as its engine: a no-op merge that must equal the plain call
+    gi, gd = sharded.knn2_train_split(dd[0], dd[1], 0)
+    wi, wd = oracle.knn2(des[0], des[1])
+    assert np.array_equal(gi.cpu().numpy(), wi) and np.array_equal(gd.cpu().numpy(), wd)
 
 
 def test_device_resident_driver_equals_the_array_form(hip):

@@ -39,7 +39,7 @@ def _scene(n_images, seed):
     return des, kps
 
 
-def _worker(rank, world, port, n_images, batch, ret):
+def _worker(rank, world, port, n_images, batch, ret, all_pairs=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -51,14 +51,14 @@ def _worker(rank, world, port, n_images, batch, ret):
 
     des, kps = _scene(n_images, 0)
     n_desc = [len(d) for d in des]
-    pairs = sharded.sequential_pairs(n_images)
+    pairs = sharded.all_pairs(n_images) if all_pairs else sharded.sequential_pairs(n_images)    # isfm.py:56-71 / sfm.py:347
     mine = sharded.halo_images(pairs, world, rank)
     lo, hi = sharded.shard_range(len(pairs), world, rank)
     held = [d if i in mine else None for i, d in enumerate(des)]        # the halo partition: nothing else is resident
     held_kp = [k if i in mine else None for i, k in enumerate(kps)]
     eng = OracleEngine(O)
     store, nq = sharded.match_pairs_sharded(held, pairs, n_desc=n_desc, engine=eng, device=torch.device("cpu"), batch=batch)
-    ok = eng.calls == hi - lo and len(mine) == (hi - lo + 1 if hi > lo else 0)
+    ok = eng.calls == hi - lo and (all_pairs or len(mine) == (hi - lo + 1 if hi > lo else 0))
     total = 0
     for p, (i, j) in enumerate(pairs):                                  # every pair's block, on every rank, = the oracle's
         wi, wd = O.knn2(des[i].numpy(), des[j].numpy())
@@ -95,6 +95,49 @@ def test_two_rank_pair_sharding(n_images, batch, port):
     assert ret[0][0] and ret[1][0]
     assert ret[0][1] + ret[1][1] == n_images - 1 and abs(ret[0][1] - ret[1][1]) <= 1
     assert ret[0][2] == ret[1][2] > 20
+
+
+def test_two_rank_all_pairs():
+    """isfm.py's exhaustive pair list (every j < i) through the same sharded matcher and point gather: 5 images -> 10
+    pairs, 5 per rank; a rank holds the images its block of pairs names, nothing else."""
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(2, 29523, 5, 4, ret, True), nprocs=2, join=True)
+    assert ret[0][0] and ret[1][0] and ret[0][1] + ret[1][1] == 10 and ret[0][2] == ret[1][2]
+
+
+def _train_split_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from datagen import sift_like
+    from oracle import oracle as O
+    from sfm_mvs_amd import sharded
+    rng = np.random.default_rng(5)             # same data on every rank
+    ok = True
+    for nq, nt, cut in ((200, 301, 120), (50, 3, 1), (40, 2, 2), (30, 1, 1)):
+        q, t = sift_like(rng, nq), sift_like(rng, nt)
+        if nt > 200:
+            t[250] = t[7]                      # exact duplicates across the two shards: the lower global index must win
+            t[130] = t[7]
+            q[0] = t[7]
+        wi, wd = O.knn2(q, t)
+        lo, hi = (0, cut) if rank == 0 else (cut, nt)
+        knn = lambda a, b: tuple(torch.from_numpy(x) for x in O.knn2(a.numpy(), b.numpy()))
+        gi, gd = sharded.knn2_train_split(torch.from_numpy(q), torch.from_numpy(t[lo:hi]), lo, knn2=knn)
+        valid = wi >= 0
+        ok = ok and np.array_equal(gi.numpy(), wi) and np.array_equal(gd.numpy()[valid], wd[valid])
+    ret[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_train_dimension_split_merges_partial_top2():
+    """the train rows of one pair split over two ranks, partial top-2 all-gathered and merged 4 -> 2 by
+    (distance, global index): equal to the single scan, ties and tiny shards (fewer than two rows on a rank) included."""
+    ret = mp.Manager().dict()
+    mp.spawn(_train_split_worker, args=(2, 29524, ret), nprocs=2, join=True)
+    assert ret[0] and ret[1]
 
 
 def _exchange_worker(rank, world, port, ret):
