@@ -46,6 +46,40 @@ class OracleCv2:
     def solvePnPRansac(self, X, p, K, d, *a, **k):
         return self.O.solve_pnp_ransac(X, p, K)
 
+    # the detector side (sfm.py:40, 243-252)
+    COLOR_BGR2GRAY = 6
+
+    def cvtColor(self, img, code):
+        assert code == self.COLOR_BGR2GRAY
+        return self.O.bgr2gray(img)
+
+    def pyrDown(self, img):
+        return self.O.pyrdown(img)
+
+    @property
+    def xfeatures2d(self):
+        return self
+
+    def SIFT_create(self):
+        return _OracleSift(self.O)
+
+
+class _KeyPoint:
+    __slots__ = ("pt", "size", "angle", "response", "octave", "class_id")
+
+    def __init__(self, row):
+        self.pt, self.size, self.angle, self.response = (float(row[0]), float(row[1])), float(row[2]), float(row[3]), float(row[4])
+        self.octave, self.class_id = int(np.float32(row[5]).view(np.int32)), int(np.float32(row[6]).view(np.int32))
+
+
+class _OracleSift:
+    def __init__(self, oracle):
+        self.O = oracle
+
+    def detectAndCompute(self, gray, mask):
+        kp, des = self.O.sift(np.asarray(gray))
+        return [_KeyPoint(r) for r in kp], des
+
 
 class _Backend:
     """Duck-typed stand-in for sfm_mvs_amd.pipeline.Backend (attributes cv, match, reproj)."""

@@ -130,3 +130,28 @@ def test_sift_on_the_references_sample_photograph(hip, oracle, downscaled):
     assert len(kpo) > 1000 and kp.shape == kpo.shape
     assert np.array_equal(kp.view(np.int32), kpo.view(np.int32)) and np.array_equal(des, deso)
     assert np.all(des == np.rint(des)) and des.max() <= 255 and abs(np.linalg.norm(des, axis=1).mean() - 512) < 20
+
+
+def test_config1_surrogate_two_views_of_the_photograph(hip, oracle):
+    """BASELINE config 1 is "the first two Gustav images"; the dataset is not available, the reference ships ONE photograph.
+    Two overlapping 968 x 648 windows of its pyrDown-ed half-size frame... are not enough pixels, so the windows are cut
+    from the full frame and halved as sfm.py:40 does: the second view is the first displaced by a known (dx, dy).  Through
+    the reference's own entry point find_features(img0, img1) (sfm.py:242: BGR frames in, pts0 / pts1 out), HIP end to end,
+    against the same call over the oracle's cv2 facade (bit-identical: SIFT, KNN, ratio and gather all are), and against
+    the known displacement."""
+    from oracle_backend import oracle_pipeline_backend
+    from sfm_mvs_amd import pipeline as pl
+    gray = np.load(os.path.join(GOLDEN, "photo_gray.npz"))["gray"]
+    dx, dy = 148, 64                                            # full-resolution displacement (even: exact after pyrDown)
+    h, w = 1296 - dy, 1936 - dx
+    h, w = h - h % 2, w - w % 2
+    v0 = gray[:h, :w]
+    v1 = gray[dy:dy + h, dx:dx + w]
+    frames = [np.ascontiguousarray(np.repeat(pl.img_downscale(v, 2)[:, :, None], 3, axis=2)) for v in (v0, v1)]   # BGR, half size
+    p0, p1 = pl.find_features(frames[0], frames[1])
+    q0, q1 = pl.find_features(frames[0], frames[1], be=oracle_pipeline_backend(oracle))
+    assert p0.shape == p1.shape == q0.shape and p0.shape[0] > 300
+    assert np.array_equal(p0, q0) and np.array_equal(p1, q1)
+    d = p0 - p1                                                 # a point of view 0 sits (dx, dy) / 2 further right / down than in view 1
+    good = (np.abs(d[:, 0] - dx / 2) < 1.0) & (np.abs(d[:, 1] - dy / 2) < 1.0)
+    assert good.mean() > 0.9, good.mean()
