@@ -363,16 +363,49 @@ def _run_sfm_device(features, K, images=None, log=None):
     say = log or (lambda *a: None)
     cache = {}
 
+    # The matches of consecutive frames (sfm.py:347: find_features(img_k, img_k+1)) do not depend on the pose chain, so the
+    # pairs of equal shape are matched up front, 8 per launch set (sfm_match_batch_l2_f32: bit-identical to per-pair
+    # calls), and their survivor counts come back in ONE download; pairs of a shape that occurs once are matched in the loop.
+    pre = {}
+    shapes = {}
+    for k in range(len(features) - 1):
+        shapes.setdefault((len(features[k][0]), len(features[k + 1][0])), []).append(k)
+    keep_all = set()
+    for plist in shapes.values():
+        if len(plist) >= 2:
+            keep_all.update(plist)
+            keep_all.update(k + 1 for k in plist)
+
     def feat(i):          # every image's features are uploaded once (the array form uploads them for both of its pairs)
         if i not in cache:
             kp, des = features[i]
             up = lambda a: a.to(dev, torch.float32).contiguous() if torch.is_tensor(a) else torch.as_tensor(np.ascontiguousarray(a, np.float32)).to(dev)
             cache[i] = (up(kp), up(des))
-            cache.pop(i - 2, None)
+            if i - 2 not in keep_all:
+                cache.pop(i - 2, None)
         return cache[i]
+
+    pre_counts = []
+    for (nq, nt), plist in shapes.items():
+        if len(plist) < 2 or nq == 0 or nt == 0:
+            continue
+        bm = ops.BatchMatcher(nq, nt, dev, ratio=RATIO, batch=min(8, len(plist)))
+        for c0 in range(0, len(plist), 8):
+            chunk = plist[c0:c0 + 8]
+            bm.run([(feat(k)[1], feat(k + 1)[1]) for k in chunk])
+            oq, ot, cn = bm.out_q[:len(chunk)].clone(), bm.out_t[:len(chunk)].clone(), bm.count[:len(chunk)].clone()
+            for b, k in enumerate(chunk):
+                pre[k] = (oq[b], ot[b], cn[b], len(pre_counts) + b)
+            pre_counts.extend([cn[b] for b in range(len(chunk))])
+    pre_m = torch.cat(pre_counts).cpu().tolist() if pre_counts else []
 
     def match(i, j):      # find_features' matcher half (sfm.py:259-268)
         (kp0, d0), (kp1, d1) = feat(i), feat(j)
+        if i in pre and j == i + 1:
+            out_q, out_t, count, slot = pre[i]
+            p0, p1 = ops.gather_matches(kp0, kp1, out_q, out_t, count)
+            m = int(pre_m[slot])
+            return p0[:m], p1[:m]
         idx, dist = ops.knn2(d0, d1)
         out_q, out_t, count = ops.ratio_compact(idx, dist, RATIO)
         p0, p1 = ops.gather_matches(kp0, kp1, out_q, out_t, count)
