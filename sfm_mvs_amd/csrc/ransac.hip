@@ -453,11 +453,16 @@ extern "C" int sfm_solve_pnp_ransac(const float* X_dev, const float* uv_dev, int
     double tp = now_us();
     auto lap = [&](int k) { const double t1 = now_us(); g_pnp_prof.t[k] += t1 - tp; tp = t1; };
     ++g_pnp_prof.calls;
-    // mailbox layout: X [3n] f32 | uv [2n] f32 | mask [n] u8 | poses [6 hmax] f64 | counts [hmax] i32 | sums [28] f64
+    // mailbox layout: X [3n] f32 | uv [2n] f32 | mask [n] u8 | poses [6 hmax] f64 | counts [hmax] i32 | sums [28] f64 |
+    //                 chunk masks [kSmallMasks n] u8 (small chunks: their masks ride along with the counts, so the
+    //                 winner's mask is already on the host when RANSAC stops — one synchronisation less per call)
+    constexpr int kSmallMasks = 4;
     const size_t o_uv = sizeof(float) * 3 * (size_t)n, o_mask = o_uv + sizeof(float) * 2 * (size_t)n;
     const size_t o_pose = sfm::align_up(o_mask + (size_t)n, 64), o_cnt = o_pose + sizeof(double) * 6 * hmax;
     const size_t o_sum = sfm::align_up(o_cnt + sizeof(int32_t) * hmax, 64);
-    char* mb = static_cast<char*>(g_mailbox.get(o_sum + sizeof(double) * kSweepAcc));
+    const size_t o_cm = sfm::align_up(o_sum + sizeof(double) * kSweepAcc, 64);
+    const bool ride_along = (size_t)n * kSmallMasks <= (1u << 18);
+    char* mb = static_cast<char*>(g_mailbox.get(o_cm + (ride_along ? (size_t)n * kSmallMasks : 0)));
     if (!mb) {
         sfm::set_error("sfm_solve_pnp_ransac: hipHostMalloc failed");
         return SFM_ERR_DEVICE;
@@ -468,6 +473,8 @@ extern "C" int sfm_solve_pnp_ransac(const float* X_dev, const float* uv_dev, int
     double* hposes = reinterpret_cast<double*>(mb + o_pose);
     int32_t* hcounts = reinterpret_cast<int32_t*>(mb + o_cnt);
     double* sums = reinterpret_cast<double*>(mb + o_sum);
+    uint8_t* hchunk = reinterpret_cast<uint8_t*>(mb + o_cm);
+    bool host_mask_valid = false;
     SFM_CHECK_HIP(hipMemcpyAsync(hX, X_dev, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, stream));
     SFM_CHECK_HIP(hipMemcpyAsync(huv, uv_dev, sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost, stream));
     SFM_CHECK_HIP(hipStreamSynchronize(stream));
@@ -552,12 +559,16 @@ extern "C" int sfm_solve_pnp_ransac(const float* X_dev, const float* uv_dev, int
             const int rc = sfm_score_pnp(hposes, H, K, X_dev, uv_dev, n, thr2, counts_dev, masks_dev, stream_);
             if (rc != SFM_OK) return rc;
             SFM_CHECK_HIP(hipMemcpyAsync(hcounts, counts_dev, sizeof(int32_t) * (size_t)H, hipMemcpyDeviceToHost, stream));
+            const bool with_masks = ride_along && H <= kSmallMasks;
+            if (with_masks) SFM_CHECK_HIP(hipMemcpyAsync(hchunk, masks_dev, (size_t)H * (size_t)n, hipMemcpyDeviceToHost, stream));
             SFM_CHECK_HIP(hipStreamSynchronize(stream));
             bool stop;
             const int bj = replay_chunk(st, it, owner, hcounts, stop);
             if (bj >= 0) {
                 std::memcpy(best_model, hposes + 6 * (size_t)bj, sizeof(best_model));
                 SFM_CHECK_HIP(hipMemcpyAsync(best_dev, masks_dev + (size_t)bj * (size_t)n, (size_t)n, hipMemcpyDeviceToDevice, stream));
+                host_mask_valid = with_masks;
+                if (with_masks) std::memcpy(hmask, hchunk + (size_t)bj * (size_t)n, (size_t)n);
             }
             lap(2);
             if (stop) break;
@@ -566,8 +577,10 @@ extern "C" int sfm_solve_pnp_ransac(const float* X_dev, const float* uv_dev, int
     }
     if (st.best <= 0) return SFM_OK;
     // inlier list (ascending, as OpenCV pushes them) — the one piece of the mask the host needs
-    SFM_CHECK_HIP(hipMemcpyAsync(hmask, best_dev, (size_t)n, hipMemcpyDeviceToHost, stream));
-    SFM_CHECK_HIP(hipStreamSynchronize(stream));
+    if (!host_mask_valid) {
+        SFM_CHECK_HIP(hipMemcpyAsync(hmask, best_dev, (size_t)n, hipMemcpyDeviceToHost, stream));
+        SFM_CHECK_HIP(hipStreamSynchronize(stream));
+    }
     std::vector<int32_t> inl;
     inl.reserve((size_t)st.best);
     for (int64_t i = 0; i < n; ++i)
