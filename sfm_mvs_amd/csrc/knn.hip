@@ -922,7 +922,20 @@ __device__ __forceinline__ void filter_split2_body(
             for (int r = 0; r < 16; ++r) accB[g][r] = kInf;
         // one tile: MFMAs of tile t into `cur`, packed-key inserts of tile t-1 from `prev` interleaved.
         // Every LDS access in here is inline asm: an ordinary load would make hipcc drain the in-flight LDS-DMA.
-        auto tile = [&](f32x16(&cur)[2], f32x16(&prev)[2], int t, bool have_prev) {
+        // Single-product body: the loop is bound by a wave's own instruction stream, and the fragment addresses cost 10
+        // VALU + a dozen SALU per tile (ring slot = (tile / 2) % 3, then 7 v_xor for the swizzle).  Instead: eight address
+        // registers (swizzle applied once), the tile's half of the slot as the instructions' immediate offset (it is fixed
+        // in each of the two unrolled copies), and the slot advanced by one add per register every SECOND tile.
+        constexpr bool kFastAddr = !KMID && ABL == 0;
+        unsigned fa[8] = {}, ta = 0;
+        int rbuf = 0;
+        if constexpr (kFastAddr) {
+#pragma unroll
+            for (int st = 0; st < 8; ++st) fa[st] = lds0 + (((unsigned)j * 256u + ((unsigned)hm << 4)) ^ (32u * st));
+            ta = lds_tn + 4u * j;
+        }
+        auto tile = [&](f32x16(&cur)[2], f32x16(&prev)[2], int t, bool have_prev, auto half_c) {
+            constexpr int kHalf = KMID ? 0 : decltype(half_c)::value;   // which tile of the slot's pair (fixed per unrolled copy)
             if (have_prev && (t - 1) - sub_t0 == kSubTiles) {
                 flush(sub, sub_t0);
                 wait_vmcnt<0>();                                   // stores are counted in vmcnt too: restart the count
@@ -930,15 +943,20 @@ __device__ __forceinline__ void filter_split2_body(
                 sub_t0 = t - 1;
             }
             const int rel = t - t_begin;
-            const int buf = (KMID ? rel : rel >> 1) % kRing;
-            const int half = KMID ? 0 : (rel & 1);                  // which tile of the slot's pair
-            if (half == 0 && t + 2 * kPerSlot < t_end && !(ABL & 4)) stage(t + 2 * kPerSlot, (buf + 2) % kRing);
+            const int buf = kFastAddr ? rbuf : (KMID ? rel : rel >> 1) % kRing;
+            const int half = kHalf;
+            if (half == 0 && t + 2 * kPerSlot < t_end && !(ABL & 4)) stage(t + 2 * kPerSlot, buf + 2 >= kRing ? buf + 2 - kRing : buf + 2);
             const unsigned abase = lds0 + (unsigned)(((ABL & 4) ? 0 : buf) * kTileFloats) * 4u + (unsigned)half * 8192u +
                                    (unsigned)j * 256u + ((unsigned)hm << 4);
             const unsigned tnad = lds_tn + (unsigned)((ABL & 4) ? 0 : buf) * 256u + (unsigned)half * 128u + 4u * j;
             float tnj;
             u32x4 ah[KMID ? 2 : 8], am[2];
-            asm volatile("ds_read_b32 %0, %1" : "=v"(tnj) : "v"(tnad));
+            if constexpr (kFastAddr) {
+                if constexpr (kHalf == 0) asm volatile("ds_read_b32 %0, %1" : "=v"(tnj) : "v"(ta));
+                else asm volatile("ds_read_b32 %0, %1 offset:128" : "=v"(tnj) : "v"(ta));
+            } else {
+                asm volatile("ds_read_b32 %0, %1" : "=v"(tnj) : "v"(tnad));
+            }
             if (KMID) {
                 asm volatile("ds_read_b128 %0, %1" : "=v"(ah[0]) : "v"(abase));
                 asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(am[0]) : "v"(abase));
@@ -947,8 +965,20 @@ __device__ __forceinline__ void filter_split2_body(
                 // single-product body: a k-step is only 2 MFMAs (64 pipe cycles), less than the LDS latency, so the
                 // whole A fragment of the tile (8 x 16 B per lane) is requested up front; LDS returns in order
 #pragma unroll
-                for (int st = 0; st < 8; ++st) asm volatile("ds_read_b128 %0, %1" : "=v"(ah[st]) : "v"(abase ^ (32u * st)));
+                for (int st = 0; st < 8; ++st) {
+                    if constexpr (!kFastAddr) asm volatile("ds_read_b128 %0, %1" : "=v"(ah[st]) : "v"(abase ^ (32u * st)));
+                    else if constexpr (kHalf == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(ah[st]) : "v"(fa[st]));
+                    else asm volatile("ds_read_b128 %0, %1 offset:8192" : "=v"(ah[st]) : "v"(fa[st]));
+                }
                 asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(tnj));
+                if constexpr (kFastAddr && kHalf == 1) {            // the slot's second tile has issued its reads: on to the next slot
+                    const int nb = rbuf == kRing - 1 ? 0 : rbuf + 1;
+                    const int delta = nb == 0 ? -(kRing - 1) * (kTileFloats * 4) : kTileFloats * 4;
+#pragma unroll
+                    for (int st = 0; st < 8; ++st) fa[st] += (unsigned)delta;
+                    ta += (unsigned)(nb == 0 ? -(kRing - 1) * 256 : 256);
+                    rbuf = nb;
+                }
             }
             // accumulator init ||t||^2 + ||q||^2 as one fp32 MFMA (A = [||t||^2, 1], B = [1; ||q||^2], C = 0): the loop is
             // bound by VALU issue (the matrix pipe idles more than half the time), so 32 v_add per tile cost more
@@ -1023,8 +1053,8 @@ __device__ __forceinline__ void filter_split2_body(
         // Two copies of the tile body with the accumulator sets swapping roles (tile being computed / previous tile,
         // whose epilogue runs inside tile()): the loop is VALU-issue bound and a rotating copy would cost 32 v_mov per tile.
         for (int t = t_begin; t < t_end; t += 2) {
-            tile(accA, accB, t, t > t_begin);
-            if (t + 1 < t_end) tile(accB, accA, t + 1, true);
+            tile(accA, accB, t, t > t_begin, std::integral_constant<int, 0>{});
+            if (t + 1 < t_end) tile(accB, accA, t + 1, true, std::integral_constant<int, 1>{});
         }
         if (trace && threadIdx.x == 0) trace[8192 + 4 * blockIdx.x + 1] = wall_clock64();   // dev: tile loop done
         if (t_end > t_begin) {                             // epilogue of the last tile
