@@ -659,7 +659,12 @@ __global__ __launch_bounds__(1024) void dedupe_kernel(const float* __restrict__ 
     __shared__ int base_s;
     __shared__ int bcnt[64], bpos[64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int n = min(counters[1], cap);
+    // A list that overflowed upstream leaves slots of kp_sorted unwritten (the x-range histogram counts keypoints that
+    // were never stored): what the later kernels would read there is whatever the workspace held before — a "keypoint"
+    // with a 1e30 window keeps the descriptor kernel busy for minutes.  The caller raises on the counts reported below
+    // anyway, so nothing downstream runs on such a frame.
+    const bool overflow = counters[4] != 0 || counters[5] != 0 || counters[0] > cap;
+    const int n = overflow ? 0 : min(counters[1], cap);
     if (threadIdx.x == 0) base_s = 0;
     __syncthreads();
     for (int i0 = 0; i0 < n; i0 += 1024) {
