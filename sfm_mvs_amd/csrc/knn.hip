@@ -568,7 +568,7 @@ __device__ __forceinline__ int knn_filter_mode(const int* __restrict__ flags, co
 // The arithmetic mode of a BATCH of pairs (one launch, one body): the most general mode any of its pairs needs — the
 // modes are nested (fp16-exact data are fp16-representable data are split-representable data), and the refine kernel
 // prices its slack with the same batch mode, so every pair is certified against the arithmetic that actually ran.
-constexpr int kMinfoPairMode = 0, kMinfoBatchMode = kMaxBatch, kMinfoTmax = 16, kMinfoWords = 32;   // written by filter block 0
+constexpr int kMinfoPairMode = 0, kMinfoBatchMode = kMaxBatch, kMinfoTmax = 16, kMinfoTerr = 24, kMinfoWords = 32;   // written by filter block 0
 __device__ __forceinline__ int knn_batch_mode(const int* __restrict__ flags, const float* __restrict__ bmax, int n_pairs, int lane) {
     int mode = kModeHalfExact;
     for (int b = 0; b < n_pairs; ++b) mode = max(mode, knn_filter_mode(flags + b * kNormBlocks, bmax + b * kNormBlocks, lane));
@@ -586,6 +586,7 @@ __global__ __launch_bounds__(1024) void knn_prep_kernel(BatchPtrs P, int64_t ldq
                                                        unsigned short* __restrict__ qsplit, float* __restrict__ qn,
                                                        unsigned short* __restrict__ tsplit, float* __restrict__ tn,
                                                        float* __restrict__ bmax, int* __restrict__ midflag,
+                                                       float* __restrict__ qerr /*[s_qn] per pair*/, float* __restrict__ bmaxerr /*[kNormBlocks] per pair*/,
                                                        int64_t s_qsplit, int64_t s_tsplit, int64_t s_qn, int64_t s_tn,
                                                        int* __restrict__ zero, int nzero,
                                                        int64_t units, int tiles, int G, int seg_cost, int n_rb,
@@ -602,11 +603,12 @@ __global__ __launch_bounds__(1024) void knn_prep_kernel(BatchPtrs P, int64_t ldq
     int* __restrict__ stats = P.stats[pb];
     qsplit += pb * s_qsplit; tsplit += pb * s_tsplit; qn += pb * s_qn; tn += pb * s_tn;
     bmax += pb * kNormBlocks; midflag += pb * kNormBlocks;
+    qerr += pb * s_qn; bmaxerr += pb * kNormBlocks;
     zero += pb * nzero;
     const int nblk = gridDim.x - 1;
     __shared__ int wmid[16];
     const int l = threadIdx.x & 31;
-    float mx = 0.f;
+    float mx = 0.f, mxe = 0.f;
     unsigned flags = 0;
     const int rows = nq_pad + nt_pad;
     for (int row = blockIdx.x * 32 + (threadIdx.x >> 5); row < rows; row += nblk * 32) {   // 32 rows in flight per block
@@ -621,6 +623,7 @@ __global__ __launch_bounds__(1024) void knn_prep_kernel(BatchPtrs P, int64_t ldq
         const float sc = isq ? -2.f : 1.f;
         const float e[4] = {sc * v.x, sc * v.y, sc * v.z, sc * v.w};
         unsigned fb[4];
+        float err2 = 0.f;                                                // ||fp16(row) - row||^2: the certificate's operand-rounding term
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float ae = fabsf(e[k]);
@@ -628,30 +631,49 @@ __global__ __launch_bounds__(1024) void knn_prep_kernel(BatchPtrs P, int64_t ldq
             fb[k] = (unsigned)__builtin_bit_cast(unsigned short, hv);
             if (!(ae <= 60000.f)) flags |= kFlagRangeBad;                // also catches NaN / inf
             if ((float)hv != e[k] || (ae != 0.f && ae < 6.103515625e-5f)) flags |= kFlagHalfInexact;
+            // below fp16's normal range the matrix pipe may flush the operand to zero: the whole element is the error then
+            // (|e - hv| <= |e| holds for the rounded subnormal too, so this bounds both behaviours)
+            const float dv = ae < 6.103515625e-5f ? e[k] : e[k] - (float)hv;
+            err2 = fmaf(dv, dv, err2);
         }
+#pragma unroll
+        for (int m = 16; m >= 1; m >>= 1) err2 += __shfl_xor(err2, m, 64);
+        if (!(err2 < kInf)) err2 = 0.f;                                  // (out-of-range data: the split arithmetic runs, this term is unused)
         unsigned short* img = isq ? qsplit : tsplit;
         *reinterpret_cast<uint2*>(img + (2 * (int64_t)npad + r) * kDim + 4 * l) = make_uint2(fb[0] | (fb[1] << 16), fb[2] | (fb[3] << 16));
         if (l == 0) (isq ? qn : tn)[r] = (isq || r < n) ? s : kInf;   // padded train rows can never be candidates
-        if (!isq) mx = fmaxf(mx, s);
+        if (isq) {
+            if (l == 0) qerr[r] = err2;
+        } else {
+            mx = fmaxf(mx, s);
+            mxe = fmaxf(mxe, err2);
+        }
     }
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+    for (int m = 32; m >= 1; m >>= 1) {
+        mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+        mxe = fmaxf(mxe, __shfl_xor(mxe, m, 64));
+    }
     int wfl = 0;
 #pragma unroll
     for (int b = 1; b <= 4; b <<= 1) wfl |= __any((flags & b) != 0) ? b : 0;
+    __shared__ float wmaxe[16];
     if ((threadIdx.x & 63) == 0) {
         wmax[threadIdx.x >> 6] = mx;
+        wmaxe[threadIdx.x >> 6] = mxe;
         wmid[threadIdx.x >> 6] = wfl;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        float bm = wmax[0];
+        float bm = wmax[0], bme = wmaxe[0];
         int fl = wmid[0];
         for (int w = 1; w < 16; ++w) {
             bm = fmaxf(bm, wmax[w]);
+            bme = fmaxf(bme, wmaxe[w]);
             fl |= wmid[w];
         }
         bmax[blockIdx.x] = bm;
+        bmaxerr[blockIdx.x] = bme;
         midflag[blockIdx.x] = fl;
         if (blockIdx.x == 0 && stats) stats[0] = 0;   // rescanned-query counter (refine kernel)
         if (blockIdx.x == 1 || nblk == 1)
@@ -1099,7 +1121,7 @@ __global__ __launch_bounds__(64 * W, 2) void knn_filter_split2_kernel(
     int smax, int nsub, const int* __restrict__ midflag, const float* __restrict__ bmax, int force_mode,
     float* __restrict__ cand_s, int* __restrict__ cand_i, const int64_t* __restrict__ wg_begin, const int* __restrict__ rb_first,
     int n_rb1, int n_pairs, int64_t s_qsplit, int64_t s_tsplit, int64_t s_qn, int64_t s_tn, int64_t s_cand, int* __restrict__ minfo,
-    long long* __restrict__ trace) {
+    const float* __restrict__ bmaxerr, long long* __restrict__ trace) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if (blockIdx.x == 0 && threadIdx.x < 64) {
         // what the refine kernel needs of the flags, reduced ONCE (its 4 waves x thousands of workgroups used to re-derive
@@ -1109,9 +1131,14 @@ __global__ __launch_bounds__(64 * W, 2) void knn_filter_split2_kernel(
             float tmax;
             const int m = knn_filter_mode(midflag + b * kNormBlocks, bmax + b * kNormBlocks, (int)threadIdx.x, &tmax);
             bm = max(bm, m);
+            const float* be = bmaxerr + b * kNormBlocks;
+            float te = fmaxf(fmaxf(be[threadIdx.x], be[threadIdx.x + 64]), fmaxf(be[threadIdx.x + 128], be[threadIdx.x + 192]));
+#pragma unroll
+            for (int sh = 32; sh >= 1; sh >>= 1) te = fmaxf(te, __shfl_xor(te, sh, 64));
             if (threadIdx.x == 0) {
                 minfo[kMinfoPairMode + b] = m;
                 minfo[kMinfoTmax + b] = __float_as_int(tmax);
+                minfo[kMinfoTerr + b] = __float_as_int(te);
             }
         }
         if (threadIdx.x == 0) minfo[kMinfoBatchMode] = bm;
@@ -1296,7 +1323,7 @@ __global__ __launch_bounds__(256, 4) void knn_refine_kernel(
     BatchPtrs P, int B, int64_t ldq, int nq, int64_t ldt, int nt,
     const float* __restrict__ cand_s, const int* __restrict__ cand_i, int rows_per_block, int tiles, int64_t units,
     int G, int smax, int nsub, int force_mode, const int* __restrict__ midflag, const float* __restrict__ bmax,
-    const int* __restrict__ minfo /*null: derive from the flags (fp32-MFMA filter)*/,
+    const int* __restrict__ minfo /*null: derive from the flags (fp32-MFMA filter)*/, const float* __restrict__ qerr, int64_t s_qn,
     const unsigned short* __restrict__ thalf /*fp16 image of T, or null*/, const float* __restrict__ tn,
     const int64_t* __restrict__ wg_begin, const int* __restrict__ rb_first, const int* __restrict__ rb_last,
     int n_rb1, int64_t s_cand, int64_t s_tsplit, int64_t s_tn, double ratio,
@@ -1386,6 +1413,7 @@ __global__ __launch_bounds__(256, 4) void knn_refine_kernel(
         s1v[k] = valid ? cs[c] : kInf;
         i1v[k] = valid ? ci[c] : -1;
     }
+    const float qe2 = (qerr && valid) ? qerr[pb * s_qn + q] : 0.f;   // (issued with the record loads: not a round trip of its own)
     const int fb = rb_first[rb];
     const int lb = rb_last[rb];
     const int NC = 2 * (lb - fb + 1) * nsub * 3;
@@ -1405,7 +1433,19 @@ __global__ __launch_bounds__(256, 4) void knn_refine_kernel(
     qq += lane_xor<8>(qq); qq += lane_xor<4>(qq); qq += lane_xor<2>(qq); qq += lane_xor<1>(qq);
     const float nsum = sqrtf(qq) + sqrtf(tmax);
     if (sl == 0) q_qq[ql] = qq;                           // (the rescan's operand)
-    const float eps = 1.01f * (eps_coef * nsum * nsum + (mode == kModeHalf ? kEpsHalfAbs * nsum : 0.f));
+    // Operand rounding of the fp16 single product, bounded from the data instead of the worst case 2^-10 (|q|+|t|)^2 / 2:
+    // the filter scores with Q' = fp16(-2 q) and T' = fp16(t), so its product is off by at most
+    // |dQ'| |t| + |Q'| |dT| + |dQ'| |dT| (Cauchy-Schwarz) with the residual norms |dQ'| of THIS query and max |dT| of the
+    // pair's train rows, both measured by the prep pass (2-3 x smaller than the worst case on ordinary data: the threshold
+    // window, the rows to screen and the rescans shrink with it; exactly 0 for fp16-exact descriptors).
+    float eps;
+    if (mode == kModeHalf && minfo && qerr) {
+        const float dq = sqrtf(qe2), dt = sqrtf(__int_as_float(minfo[kMinfoTerr + pb]));
+        const float op = dq * sqrtf(tmax) + 2.f * sqrtf(qq) * dt + dq * dt;
+        eps = 1.01f * (kEpsExact * nsum * nsum + 1.001f * op);
+    } else {
+        eps = 1.01f * (eps_coef * nsum * nsum + (mode == kModeHalf ? kEpsHalfAbs * nsum : 0.f));
+    }
     int a1 = kKeyInf, a2 = kKeyInf, atau;
     static_assert(kS1 == 6, "the 3rd-best selection below is written for six records per lane");
     {
@@ -1894,6 +1934,8 @@ struct KnnWs {
     float* qn;
     float* tn;
     float* bmax;                  // [B][kNormBlocks]
+    float* qerr;                  // [B][s_qn]: ||fp16(-2 q) - (-2 q)||^2 per query; bmaxerr [B][kNormBlocks]: per-block max of ||fp16(t) - t||^2
+    float* bmaxerr;
     int* midflag;
     int* minfo;                   // [kMinfoWords] modes / ||t||max reduced by filter block 0 for the refine kernel
     int64_t* wg_begin;            // partition tables over the whole batch (filled by the prep / norms launch)
@@ -1923,6 +1965,8 @@ KnnWs carve_ws(void* ws, int64_t nq, int64_t nt, const Plan& p) {
     w.rb_last = c.take<int>((size_t)p.n_rb);
     w.tn = c.take<float>(B * (size_t)w.s_tn);
     w.qn = c.take<float>(B * (size_t)w.s_qn);
+    w.qerr = c.take<float>(B * (size_t)w.s_qn);
+    w.bmaxerr = c.take<float>(B * kNormBlocks);
     w.qsplit = c.take<unsigned short>(B * (size_t)w.s_qsplit);
     w.tsplit = c.take<unsigned short>(B * (size_t)w.s_tsplit);
     w.cand_s = c.take<float>(B * (size_t)w.s_cand);
@@ -1996,7 +2040,7 @@ int knn_batch_impl(int B, const BatchPtrs& P, int64_t nq, int64_t ldq, int64_t n
     static const int abl = [] { const char* e = getenv("SFM_KNN_ABL"); return e ? atoi(e) : 0; }();   // dev only
     if (p.split) {
         hipLaunchKernelGGL(knn_prep_kernel, dim3(kNormBlocks + 1, (unsigned)B), dim3(1024), 0, stream, P, ldq, (int)nq, p.nq_pad, ldt, (int)nt,
-                           p.tiles * kTileT, w.qsplit, w.qn, w.tsplit, w.tn, w.bmax, w.midflag, w.s_qsplit, w.s_tsplit, w.s_qn, w.s_tn,
+                           p.tiles * kTileT, w.qsplit, w.qn, w.tsplit, w.tn, w.bmax, w.midflag, w.qerr, w.bmaxerr, w.s_qsplit, w.s_tsplit, w.s_qn, w.s_tn,
                            ratio_counts, ratio_counts ? ratio_stride : 0,
                            p.units, p.tiles, p.G, p.seg_cost, p.n_rb, w.wg_begin, w.rb_first, w.rb_last);
         SFM_CHECK_LAUNCH();
@@ -2008,7 +2052,7 @@ int knn_batch_impl(int B, const BatchPtrs& P, int64_t nq, int64_t ldq, int64_t n
     hipLaunchKernelGGL((knn_filter_split2_kernel<A, WV>), grid, dim3(64 * WV), kRingLdsBytes + (WV == 4 ? kQScratchBytes : 0), stream, w.qsplit, w.qn,    \
                        (int)nq, p.nq_pad, w.tsplit, (int)nt, p.tiles * kTileT, w.tn, p.tiles, p.units, p.smax, p.nsub,    \
                        w.midflag, w.bmax, g_force_mode, w.cand_s, w.cand_i, w.wg_begin, w.rb_first, p.n_rb1, B, w.s_qsplit, w.s_tsplit,    \
-                       w.s_qn, w.s_tn, w.s_cand, w.minfo, g_trace)
+                       w.s_qn, w.s_tn, w.s_cand, w.minfo, w.bmaxerr, g_trace)
         // sfm_profile_enable(n > 1): the filter is launched n times back-to-back inside ONE event pair (idempotent: same
         // inputs, same candidate records), so the ~7 us an event pair adds to a single launch is amortised
         for (int rep = 0; rep < prof_reps; ++rep) {
@@ -2060,7 +2104,7 @@ int knn_batch_impl(int B, const BatchPtrs& P, int64_t nq, int64_t ldq, int64_t n
     sfm::prof_begin(sfm::kProfKnnRefine, stream);
     hipLaunchKernelGGL(knn_refine_kernel, dim3((unsigned)refine_grid), dim3(256), 0, stream, P, B, ldq, (int)nq, ldt,
                        (int)nt, w.cand_s, w.cand_i, p.rows_per_block, p.tiles, p.units, p.G, p.smax * p.nsub, p.nsub,
-                       force_mode, w.midflag, w.bmax, p.split ? w.minfo : nullptr, p.split ? w.tsplit + (size_t)2 * p.tiles * kTileT * kDim : nullptr, w.tn, w.wg_begin, w.rb_first, w.rb_last,
+                       force_mode, w.midflag, w.bmax, p.split ? w.minfo : nullptr, p.split ? w.qerr : nullptr, w.s_qn, p.split ? w.tsplit + (size_t)2 * p.tiles * kTileT * kDim : nullptr, w.tn, w.wg_begin, w.rb_first, w.rb_last,
                        p.n_rb1, w.s_cand, w.s_tsplit, w.s_tn, ratio, ratio_counts, ratio_stride, g_trace ? g_trace + 16384 : nullptr);
     sfm::prof_end(sfm::kProfKnnRefine, stream);
     SFM_CHECK_LAUNCH();
