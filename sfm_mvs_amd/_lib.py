@@ -53,6 +53,7 @@ SIGNATURES = {
     "sfm_norm_l2_ws_bytes": (_sz, []),
     "sfm_norm_l2": (_int, [_vp, _vp, _i64, _int, _vp, _vp, _sz, _vp]),
     "sfm_host_epnp": (_int, [_vp, _vp, _vp, _int, _vp, _vp]),
+    "sfm_selftest_mfma_accumulation": (_int, [_int, _int, _vp, _vp, _sz, _vp]),
     "sfm_host_p3p": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "sfm_host_five_point": (_int, [_vp, _vp, _vp, _vp]),
     "sfm_host_decompose_essential": (_int, [_vp, _vp, _vp, _vp]),

@@ -1213,15 +1213,20 @@ __device__ __forceinline__ double dsq_upper(float d) { return (double)d * (doubl
 // Slack coefficients of the refine kernel's certificate, relative to (|q|+|t|max)^2:
 //   common:   600u  fp32 rounding of norms / direct-form sums / sqrtf merge (+ GEMM-form chain for the f32 filter)
 //             2^-15 packed-key truncation of the score (kKeyBits = 8 low mantissa bits)
-//   MFMA:     400 * 2^-22  ~400 accumulations inside the 16-bit MFMA chain, each assumed to lose <= 2^-22 relative
+//   MFMA:     the accumulations inside the 16-bit MFMA chain.  One v_mfma_f32_32x32x16_{f16,bf16} returns c + sum a_k b_k
+//             within E * 2^-24 (|c| + sum |a_k b_k|); measured on gfx950 (sfm_selftest_mfma_accumulation, 3.4e9 samples
+//             per regime): E <= 2.0 for operands of similar magnitude — the filter's regime — and <= 7.1 for exponents
+//             spread over 2^16 with cancellation; the certificate assumes E = 16 (tests/test_gpu_knn.py holds the device
+//             to E <= 8).  A chain is 8 product MFMAs + the init (24 + 1 in the split mode), each with
+//             |c| + sum |a b| <= 1.5 N^2: 9 * 16 * 1.5 = 216 -> 256 u (split: 600 -> 640 u).  (Round 1 assumed 1600 u.)
 //   split:    2 * 3.05 * 2^-16 / 4  neglected (mid.mid, delta) product terms, |q||t| <= N^2/4
 //   half:     2 * (2^-10 + 2^-22) / 4  both operands rounded to 11 bits: |q^.t^ - q.t| <= (2^-10 + 2^-22)|q||t|;
 //             plus, ABSOLUTE, 2 * 2^-14 * sqrt(128) * (|q|+|t|max) for elements below the fp16 normal range
 //             (each perturbed by at most 2^-14 even if the matrix pipe flushes them)
 constexpr float kEpsF32 = 600.f * 5.9604645e-8f + 3.0517578e-5f;
 static_assert(kKeyBits == 8, "kEpsF32 carries 2^(kKeyBits-23)");
-constexpr float kEpsExact = kEpsF32 + 9.54e-5f;
-constexpr float kEpsSplit = kEpsExact + 2.33e-5f;
+constexpr float kEpsExact = kEpsF32 + 256.f * 5.9604645e-8f;
+constexpr float kEpsSplit = kEpsF32 + 640.f * 5.9604645e-8f + 2.33e-5f;
 constexpr float kEpsHalf = kEpsExact + 4.8840e-4f;
 constexpr float kEpsHalfAbs = 1.3811e-3f;
 constexpr int kModeF32 = 3;   // fp32-MFMA filter (host-selected)
@@ -1976,6 +1981,104 @@ KnnWs carve_ws(void* ws, int64_t nq, int64_t nt, const Plan& p) {
 }
 
 }  // namespace
+
+// ---------------------------------------------------------------- self-test: accumulation error of the 16-bit MFMA
+// The certificate's chain term rests on a property of the matrix pipe that no manual states: how far
+// v_mfma_f32_32x32x16_{f16,bf16} is from the exact c + sum_k a_k b_k.  This kernel measures it: operands come from a hash
+// (so a lane can recompute the row and column of every element it holds), the exact value is formed in fp64 (products
+// of 16-bit floats are exact, 17 terms), and the error is reported in units of 2^-24 (|c| + sum |a_k b_k|), maximum
+// over every output element of every trial, for regimes from "equal exponents" to "2^16 spread with cancellation".
+namespace {
+struct MfmaRegime { int ea, sa, eb, sb, ec, sc, signed_; };
+
+__device__ inline uint32_t st_hash(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t h = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA77u ^ (c + 0x165667B1u) * 0xC2B2AE3Du;
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12; h *= 0x297A2D39u; h ^= h >> 15;
+    return h;
+}
+__device__ inline float st_gen(uint32_t h, int e0, int span, bool sg, int mant_bits) {     // 2^[e0, e0+span), mant_bits of mantissa
+    const int e = e0 + (int)((h >> 11) % (uint32_t)span);
+    const float m = 1.f + (float)(h & ((1u << mant_bits) - 1u)) / (float)(1u << mant_bits);
+    return ldexpf(m, e) * ((sg && (h >> 31)) ? -1.f : 1.f);
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void mfma_selftest_kernel(MfmaRegime rg, int trials, uint32_t seed, double* __restrict__ maxerr) {
+    const int lane = threadIdx.x & 63, wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int rc = lane & 31, h = lane >> 5;
+    constexpr int kMant = BF16 ? 7 : 10;
+    double worst = 0;
+    for (int t = 0; t < trials; ++t) {
+        const uint32_t s = seed + 7919u * (uint32_t)(wid * trials + t);
+        float av[8], bv[8];
+        for (int e = 0; e < 8; ++e) {
+            av[e] = st_gen(st_hash(s, rc, 8 * h + e), rg.ea, rg.sa, rg.signed_, kMant);               // A[row rc][k = 8 h + e]
+            bv[e] = st_gen(st_hash(s ^ 0xABCDu, rc, 8 * h + e), rg.eb, rg.sb, rg.signed_, kMant);     // B[k][col rc]
+        }
+        f32x16 C, D;
+        for (int r = 0; r < 16; ++r) C[r] = st_gen(st_hash(s ^ 0x1234u, 8 * (r >> 2) + 4 * h + (r & 3), rc), rg.ec, rg.sc, rg.signed_, 23);
+        if constexpr (BF16) {
+            bf16x8 A, B;
+            for (int e = 0; e < 8; ++e) { A[e] = (__bf16)av[e]; B[e] = (__bf16)bv[e]; }
+            D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, 0, 0, 0);
+        } else {
+            f16x8 A, B;
+            for (int e = 0; e < 8; ++e) { A[e] = (_Float16)av[e]; B[e] = (_Float16)bv[e]; }
+            D = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, B, C, 0, 0, 0);
+        }
+        for (int r = 0; r < 16; ++r) {
+            const int row = 8 * (r >> 2) + 4 * h + (r & 3);
+            double ref = (double)C[r], mag = fabs((double)C[r]);
+            for (int kk = 0; kk < 16; ++kk) {
+                const double a = (double)st_gen(st_hash(s, row, kk), rg.ea, rg.sa, rg.signed_, kMant);
+                const double b = (double)st_gen(st_hash(s ^ 0xABCDu, rc, kk), rg.eb, rg.sb, rg.signed_, kMant);
+                ref += a * b;
+                mag += fabs(a * b);
+            }
+            const double err = fabs((double)D[r] - ref) / (mag * 5.9604644775390625e-08);
+            if (err > worst) worst = err;
+        }
+    }
+    for (int m = 32; m >= 1; m >>= 1) {
+        const double o = __shfl_xor(worst, m, 64);
+        if (o > worst) worst = o;
+    }
+    if (lane == 0) maxerr[wid] = worst;
+}
+}  // namespace
+
+extern "C" int sfm_selftest_mfma_accumulation(int use_bf16, int trials_per_wave, double* regime_max_host /*[7]*/, void* ws, size_t ws_bytes,
+                                              void* stream_) {
+    constexpr int kBlocks = 1024;
+    SFM_CHECK_ARG(regime_max_host && trials_per_wave >= 1, "sfm_selftest_mfma_accumulation: bad argument");
+    if (!ws || ws_bytes < sizeof(double) * kBlocks * 4 + 256) {
+        sfm::set_error("sfm_selftest_mfma_accumulation: workspace too small (need %zu bytes)", sizeof(double) * kBlocks * 4 + 256);
+        return SFM_ERR_WORKSPACE;
+    }
+    hipStream_t stream = sfm::as_stream(stream_);
+    double* d = reinterpret_cast<double*>(sfm::align_up((size_t)(uintptr_t)ws, 256));
+    static const MfmaRegime regs[7] = {
+        {0, 1, 0, 1, 4, 1, 0},         // equal exponents, positive
+        {-3, 6, -3, 6, 0, 8, 1},       // spread exponents, signed (cancellation)
+        {-8, 16, -8, 16, -8, 24, 1},   // wide spread
+        {0, 1, 0, 1, 20, 1, 1},        // c dominates
+        {6, 2, 6, 2, -10, 4, 1},       // products dominate
+        {-14, 4, 0, 4, -10, 8, 1},     // small operands (down to fp16's smallest normals)
+        {-1, 2, -1, 2, 5, 3, 0},       // the KNN filter's own regime: operands in [0.5, 2), accumulator 32 .. 256, positive
+    };
+    std::vector<double> host((size_t)kBlocks * 4);
+    for (int r = 0; r < 7; ++r) {
+        if (use_bf16) hipLaunchKernelGGL(mfma_selftest_kernel<true>, dim3(kBlocks), dim3(256), 0, stream, regs[r], trials_per_wave, 17u + 4096u * r, d);
+        else hipLaunchKernelGGL(mfma_selftest_kernel<false>, dim3(kBlocks), dim3(256), 0, stream, regs[r], trials_per_wave, 17u + 4096u * r, d);
+        SFM_CHECK_LAUNCH();
+        SFM_CHECK_HIP(hipMemcpyAsync(host.data(), d, sizeof(double) * host.size(), hipMemcpyDeviceToHost, stream));
+        SFM_CHECK_HIP(hipStreamSynchronize(stream));
+        double w = 0;
+        for (double v : host) w = std::max(w, v);
+        regime_max_host[r] = w;
+    }
+    return SFM_OK;
+}
 
 extern "C" int sfm_knn_set_filter(int mode) {
     SFM_CHECK_ARG(mode >= 0 && mode <= 2, "sfm_knn_set_filter: mode must be 0 (16-bit MFMA, auto), 1 (fp32 MFMA) or 2 (bf16 split pinned)");

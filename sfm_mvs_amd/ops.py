@@ -587,6 +587,18 @@ def set_knn_filter(mode):
     _ws_cache.clear()
 
 
+def selftest_mfma_accumulation(bf16=False, trials_per_wave=50, device="cuda"):
+    """Largest error of one v_mfma_f32_32x32x16_{f16,bf16} against the exact c + sum a_k b_k, in units of
+    2^-24 (|c| + sum |a_k b_k|), for seven operand regimes (sfm_selftest_mfma_accumulation): the hardware property the KNN
+    certificate's chain term assumes to be <= 16."""
+    ws = torch.empty(32768 + 512, dtype=torch.uint8, device=device)
+    out = (ctypes.c_double * 7)()
+    with on_device(ws.device):
+        check(_lib.lib().sfm_selftest_mfma_accumulation(int(bool(bf16)), int(trials_per_wave), out, ptr(ws), ws.numel(), stream_ptr()),
+              "sfm_selftest_mfma_accumulation")
+    return list(out)
+
+
 def profile_enable(on=True):
     """False / True, or an int n > 1: the knn filter kernel is launched n times inside each event pair."""
     check(_lib.lib().sfm_profile_enable(int(on)), "sfm_profile_enable")
