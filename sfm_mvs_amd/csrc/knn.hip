@@ -1210,9 +1210,11 @@ __device__ __forceinline__ void best2_insert(Best2& b, float d, int i) {
 __device__ __forceinline__ double dsq_upper(float d) { return (double)d * (double)d * (1.0 + 2.384185791015625e-07); }
 
 // ---------------------------------------------------------------- refine
-// Slack coefficients of the refine kernel's certificate, relative to (|q|+|t|max)^2:
-//   common:   600u  fp32 rounding of norms / direct-form sums / sqrtf merge (+ GEMM-form chain for the f32 filter)
-//             2^-15 packed-key truncation of the score (kKeyBits = 8 low mantissa bits)
+// Slack coefficients of the refine kernel's certificate: |filter score - exact d^2| <= eps0 = c (|q|+|t|max)^2 + op, with c =
+//   rounding: fp32 arithmetic around the product — ||t||^2, ||q||^2 in the prep pass (9 roundings deep, relative to the
+//             norm), ||q||^2 again in this kernel (13), the screen's v_dot2 chain (17 u of 2|q||t|) and its two adds, the
+//             direct-form sums the answer is defined by (23 u d^2) and one ulp of sqrtf in d^2 terms (8 u, the tie margin
+//             of hidden rows): <= 75 u (|q|+|t|)^2 -> 200 u.  (fp32-MFMA filter: its 64-MFMA chain too -> 600 u.)
 //   MFMA:     the accumulations inside the 16-bit MFMA chain.  One v_mfma_f32_32x32x16_{f16,bf16} returns c + sum a_k b_k
 //             within E * 2^-24 (|c| + sum |a_k b_k|); measured on gfx950 (sfm_selftest_mfma_accumulation, 3.4e9 samples
 //             per regime): E <= 2.0 for operands of similar magnitude — the filter's regime — and <= 7.1 for exponents
@@ -1220,13 +1222,17 @@ __device__ __forceinline__ double dsq_upper(float d) { return (double)d * (doubl
 //             to E <= 8).  A chain is 8 product MFMAs + the init (24 + 1 in the split mode), each with
 //             |c| + sum |a b| <= 1.5 N^2: 9 * 16 * 1.5 = 216 -> 256 u (split: 600 -> 640 u).  (Round 1 assumed 1600 u.)
 //   split:    2 * 3.05 * 2^-16 / 4  neglected (mid.mid, delta) product terms, |q||t| <= N^2/4
-//   half:     2 * (2^-10 + 2^-22) / 4  both operands rounded to 11 bits: |q^.t^ - q.t| <= (2^-10 + 2^-22)|q||t|;
-//             plus, ABSOLUTE, 2 * 2^-14 * sqrt(128) * (|q|+|t|max) for elements below the fp16 normal range
-//             (each perturbed by at most 2^-14 even if the matrix pipe flushes them)
-constexpr float kEpsF32 = 600.f * 5.9604645e-8f + 3.0517578e-5f;
-static_assert(kKeyBits == 8, "kEpsF32 carries 2^(kKeyBits-23)");
-constexpr float kEpsExact = kEpsF32 + 256.f * 5.9604645e-8f;
-constexpr float kEpsSplit = kEpsF32 + 640.f * 5.9604645e-8f + 2.33e-5f;
+//   half:     op is bounded from the data (see the kernel); without the measured residuals the worst case
+//             2 * (2^-10 + 2^-22) / 4 (both operands rounded to 11 bits) plus, ABSOLUTE, 2 * 2^-14 * sqrt(128) * (|q|+|t|max)
+//             for elements below the fp16 normal range.
+// The packed-key TRUNCATION of a record's score (kKeyBits low mantissa bits cleared: record score in (s (1 - 2^-15), s]) is
+// not part of eps0 — it is one-sided and relative to the score, so it only widens the record threshold by 2^-15 m2 (see thr).
+constexpr float kU = 5.9604645e-8f;
+constexpr float kEpsF32 = 600.f * kU;
+static_assert(kKeyBits == 8, "kKeyTrunc = 2^(kKeyBits-23)");
+constexpr float kKeyTrunc = 3.0517578e-5f * 1.002f;
+constexpr float kEpsExact = 200.f * kU + 256.f * kU;
+constexpr float kEpsSplit = 200.f * kU + 640.f * kU + 2.33e-5f;
 constexpr float kEpsHalf = kEpsExact + 4.8840e-4f;
 constexpr float kEpsHalfAbs = 1.3811e-3f;
 constexpr int kModeF32 = 3;   // fp32-MFMA filter (host-selected)
@@ -1484,10 +1490,12 @@ __global__ __launch_bounds__(256, 4) void knn_refine_kernel(
     fold(lane_xor<2>(a1), lane_xor<2>(a2), lane_xor<2>(atau));
     fold(lane_xor<1>(a1), lane_xor<1>(a2), lane_xor<1>(atau));
     const float m2 = __int_as_float(a2), tau = __int_as_float(atau);
-    // The two best-scored candidates have d^2 <= m2 + eps.  A candidate with s > m2 + 2.25*eps has d^2 >= s - eps >
-    // m2 + 1.25*eps: farther than both by > eps/4 >= 150u*(|q|+|t|)^2, which also separates the float32 square roots
-    // (one ulp of sqrtf is < 2^-22 relative in d^2, i.e. < 4u*(|q|+|t|)^2) — it cannot be in the exact top-2, ties included.
-    const float thr = m2 + 2.25f * eps;
+    // Record scores are truncated (never raised): the rows behind the two best records have s <= m2 (1 + 2^-15), hence
+    // d^2 <= U = m2 (1 + 2^-15) + eps.  A record with score > U + 1.25 eps holds only rows with s > U + 1.25 eps, i.e.
+    // d^2 > U + eps/4: farther than both by more than eps/4 >= 100u (|q|+|t|)^2, which also separates the float32 square
+    // roots (one ulp of sqrtf is < 4u (|q|+|t|)^2 in d^2 terms) — it cannot be in the exact top-2, ties included.  A
+    // stream's certificate needs no such allowance: what it discarded has s >= its third record's (truncated) score.
+    const float thr = (m2 + kKeyTrunc * fabsf(m2)) + 2.25f * eps;
     if (trace && threadIdx.x == 0) trace[16 * bidt + 2] = wall_clock64();
 
     // Sweep 2.  The kernel is bound by vector-ALU ISSUE (four waves per SIMD, ~1000 instructions each), so every stage
