@@ -552,6 +552,17 @@ __device__ __forceinline__ unsigned bf16_rn_bits(float x) {
 constexpr int kModeHalfExact = 0, kModeHalf = 1, kModeSplit = 2;
 constexpr int kFlagHalfInexact = 2, kFlagRangeBad = 4;
 
+// Lane exchanges without an address register: lane ^ M by DPP quad_perm (M = 1, 2) or ds_swizzle bit mode
+// (M = 4, 8, 16); __shfl_xor compiles to ds_bpermute and keeps one address VGPR alive per distinct pattern.
+template <int M>
+__device__ __forceinline__ int lane_xor(int v) {
+    if constexpr (M == 1) return __builtin_amdgcn_update_dpp(0, v, 0xB1 /*quad_perm [1,0,3,2]*/, 0xF, 0xF, false);
+    else if constexpr (M == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4E /*quad_perm [2,3,0,1]*/, 0xF, 0xF, false);
+    else if constexpr (M == 4 || M == 8 || M == 16) return __builtin_amdgcn_ds_swizzle(v, 0x1F | (M << 10));
+    else return __shfl_xor(v, M, 64);
+}
+template <int M>
+__device__ __forceinline__ float lane_xor(float v) { return __int_as_float(lane_xor<M>(__float_as_int(v))); }
 // Wave-uniform mode from the per-block flags and per-block max ||t||^2 (256 entries each).
 __device__ __forceinline__ int knn_filter_mode(const int* __restrict__ flags, const float* __restrict__ bmax, int lane,
                                                float* tmax_out = nullptr) {
@@ -618,8 +629,7 @@ __global__ __launch_bounds__(1024) void knn_prep_kernel(BatchPtrs P, int64_t ldq
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < n) v = *reinterpret_cast<const float4*>((isq ? Q + (int64_t)r * ldq : T + (int64_t)r * ldt) + 4 * l);
         float s = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-#pragma unroll
-        for (int m = 16; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+        s += lane_xor<16>(s); s += lane_xor<8>(s); s += lane_xor<4>(s); s += lane_xor<2>(s); s += lane_xor<1>(s);   // (32 lanes per row)
         const float sc = isq ? -2.f : 1.f;
         const float e[4] = {sc * v.x, sc * v.y, sc * v.z, sc * v.w};
         unsigned fb[4];
@@ -636,8 +646,7 @@ __global__ __launch_bounds__(1024) void knn_prep_kernel(BatchPtrs P, int64_t ldq
             const float dv = ae < 6.103515625e-5f ? e[k] : e[k] - (float)hv;
             err2 = fmaf(dv, dv, err2);
         }
-#pragma unroll
-        for (int m = 16; m >= 1; m >>= 1) err2 += __shfl_xor(err2, m, 64);
+        err2 += lane_xor<16>(err2); err2 += lane_xor<8>(err2); err2 += lane_xor<4>(err2); err2 += lane_xor<2>(err2); err2 += lane_xor<1>(err2);
         if (!(err2 < kInf)) err2 = 0.f;                                  // (out-of-range data: the split arithmetic runs, this term is unused)
         unsigned short* img = isq ? qsplit : tsplit;
         *reinterpret_cast<uint2*>(img + (2 * (int64_t)npad + r) * kDim + 4 * l) = make_uint2(fb[0] | (fb[1] << 16), fb[2] | (fb[3] << 16));
@@ -1169,17 +1178,6 @@ __global__ __launch_bounds__(64 * W, 2) void knn_filter_split2_kernel(
 // Compiled with -ffp-contract=off so none of this fuses.  The evaluators below (lane pair / quad per train) keep that
 // order: which hardware lane owns which accumulator lane is free, the order of the 16 adds per accumulator is not.
 
-// Lane exchanges without an address register: lane ^ M by DPP quad_perm (M = 1, 2) or ds_swizzle bit mode
-// (M = 4, 8, 16); __shfl_xor compiles to ds_bpermute and keeps one address VGPR alive per distinct pattern.
-template <int M>
-__device__ __forceinline__ int lane_xor(int v) {
-    if constexpr (M == 1) return __builtin_amdgcn_update_dpp(0, v, 0xB1 /*quad_perm [1,0,3,2]*/, 0xF, 0xF, false);
-    else if constexpr (M == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4E /*quad_perm [2,3,0,1]*/, 0xF, 0xF, false);
-    else if constexpr (M == 4 || M == 8 || M == 16) return __builtin_amdgcn_ds_swizzle(v, 0x1F | (M << 10));
-    else return __shfl_xor(v, M, 64);
-}
-template <int M>
-__device__ __forceinline__ float lane_xor(float v) { return __int_as_float(lane_xor<M>(__float_as_int(v))); }
 // value of the next lane inside an aligned pair (valid on even lanes) / of lane 3 on lane 2 of a quad
 __device__ __forceinline__ float lane_odd_neighbour(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xF5 /*quad_perm [1,1,3,3]*/, 0xF, 0xF, false));
