@@ -373,8 +373,7 @@ def bench_knn(args, world, rank, dev):
         out["pcie_inclusive"] = {"distances_per_sec": nq * nt * 20 / (time.perf_counter() - t0),
                                  "note": "pinned-host descriptors in, results out, same stream (not the headline value)"}
         # the exact-f32-MFMA filter variant on the same inputs (identical results), for the fp32 roofline
-        ops.set_knn_filter("f32")
-        pm32 = ops.PairMatcher(nq, nt, dev, ratio=0.70)
+        pm32 = ops.PairMatcher(nq, nt, dev, ratio=0.70, filter="f32")
         for _ in range(5):
             pm32.run(q, t)
         torch.cuda.synchronize()
@@ -384,7 +383,6 @@ def bench_knn(args, world, rank, dev):
         f32_ms, f32_n = ops.profile_read(0)
         ops.profile_read(1)
         ops.profile_enable(False)
-        ops.set_knn_filter("auto")
         same = bool(torch.equal(pm32.idx, pm.idx) and torch.equal(pm32.dist, pm.dist))
         f32_avg = f32_ms / max(f32_n, 1)
         out["fp32_filter_variant"] = {"kernel": "knn_filter_kernel (v_mfma_f32_32x32x2_f32)", "avg_launch_ms": f32_avg,
@@ -392,8 +390,7 @@ def bench_knn(args, world, rank, dev):
                                       "frac": algo_flop / (f32_avg * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
                                       "results_identical_to_default": same}
         # ... and the 3-product bf16 split pinned (what the device picks for data outside fp16's comfortable range)
-        ops.set_knn_filter("split")
-        pms = ops.PairMatcher(nq, nt, dev, ratio=0.70)
+        pms = ops.PairMatcher(nq, nt, dev, ratio=0.70, filter="split")
         for _ in range(5):
             pms.run(q, t)
         torch.cuda.synchronize()
@@ -403,7 +400,6 @@ def bench_knn(args, world, rank, dev):
         sp_ms, sp_n = ops.profile_read(0)
         ops.profile_read(1)
         ops.profile_enable(False)
-        ops.set_knn_filter("auto")
         sp_avg = sp_ms / max(sp_n, 1)
         out["bf16_split_variant"] = {"kernel": "knn_filter_split2_kernel<0, 4> (3 x v_mfma_f32_32x32x16_bf16 per product)",
                                      "avg_launch_ms": sp_avg, "achieved_tflops": algo_flop / (sp_avg * 1e-3) / 1e12,

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SFM_ABI_VERSION 1
+#define SFM_ABI_VERSION 2
 
 #define SFM_OK             0
 #define SFM_ERR_ARG       -1   /* null pointer, negative size, unsupported dim, misaligned pointer/stride */
@@ -58,20 +58,27 @@ const char* sfm_last_error(void);
  *       [3] filter arithmetic that ran: 0 fp16 single product, exact inputs; 1 fp16 single product;
  *           2 bf16 hi/mid split; 3 fp32 MFMA
  *
- * dim must be 128 (SIFT); q_dev/t_dev 16-byte aligned; ldq, ldt multiples of 4.
+ * dim must be 128 (SIFT); q_dev/t_dev 16-byte aligned; ldq, ldt multiples of 4; nt <= 4 000 000.
  * The result is bit-identical to the direct-form float32 evaluation for ANY
  * finite input (see DESIGN.md "certified filter + exact refine").
+ *
+ * `filter` — the candidate filter that runs before the exact refine.  A per-call argument (ABI 1 had
+ * a process-global switch); results are bit-identical whichever runs, the _ws_bytes twin takes the same value:
+ *   SFM_KNN_FILTER_AUTO       16-bit MFMA filter, fragments streamed L2 -> registers (knn_filter_q4_kernel); its
+ *                             arithmetic is chosen ON THE DEVICE from the data: one fp16 product when the values fit
+ *                             fp16's range (exact for integer descriptors), else the three-product bf16 hi/mid split
+ *   SFM_KNN_FILTER_F32        fp32 MFMA filter (single pair only)
+ *   SFM_KNN_FILTER_SPLIT      as AUTO but pinned to the bf16 split
+ *   SFM_KNN_FILTER_LDS, SFM_KNN_FILTER_LDS_SPLIT   round 2's LDS-ring kernel (knn_filter_split2_kernel), auto / pinned
  * ---------------------------------------------------------------------- */
-size_t sfm_knn2_l2_f32_ws_bytes(int64_t nq, int64_t nt, int dim);
-/* Filter variant used by sfm_knn2_l2_f32 (results are bit-identical whichever runs):
- *   0  16-bit MFMA filter (default); its arithmetic is chosen on the device from the data:
- *      one fp16 product when the values fit fp16's range (exact for integer descriptors),
- *      else the three-product bf16 hi/mid split
- *   1  fp32 MFMA filter                       2  as 0 but pinned to the bf16 split
- * Call before sizing the workspace; the _ws_bytes twin follows the current mode. */
-int    sfm_knn_set_filter(int mode);
+#define SFM_KNN_FILTER_AUTO      0
+#define SFM_KNN_FILTER_F32       1
+#define SFM_KNN_FILTER_SPLIT     2
+#define SFM_KNN_FILTER_LDS       3
+#define SFM_KNN_FILTER_LDS_SPLIT 4
+size_t sfm_knn2_l2_f32_ws_bytes(int64_t nq, int64_t nt, int dim, int filter);
 int    sfm_knn2_l2_f32(const float* q_dev, int64_t nq, int64_t ldq,
-                       const float* t_dev, int64_t nt, int64_t ldt, int dim,
+                       const float* t_dev, int64_t nt, int64_t ldt, int dim, int filter,
                        int32_t* idx_dev, float* dist_dev, int32_t* stats_dev,
                        void* ws_dev, size_t ws_bytes, void* stream);
 
@@ -97,9 +104,9 @@ int sfm_ratio_compact(const int32_t* idx_dev, const float* dist_dev, int64_t nq,
 /* A2 + A3 in one call: the matcher part of find_features (sfm.py:259-266).  Same outputs as
  * sfm_knn2_l2_f32 followed by sfm_ratio_compact, bit for bit; the Lowe test is folded into the
  * last KNN kernel, which saves one launch per image pair.  Workspace: sfm_match_l2_f32_ws_bytes. */
-size_t sfm_match_l2_f32_ws_bytes(int64_t nq, int64_t nt, int dim);
+size_t sfm_match_l2_f32_ws_bytes(int64_t nq, int64_t nt, int dim, int filter);
 int sfm_match_l2_f32(const float* q_dev, int64_t nq, int64_t ldq,
-                     const float* t_dev, int64_t nt, int64_t ldt, int dim, double ratio,
+                     const float* t_dev, int64_t nt, int64_t ldt, int dim, int filter, double ratio,
                      int32_t* idx_dev, float* dist_dev,
                      int32_t* out_q_dev, int32_t* out_t_dev, int32_t* out_count_dev,
                      uint8_t* mask_dev /*optional*/, int32_t* stats_dev /*optional*/,
@@ -114,11 +121,11 @@ int sfm_match_l2_f32(const float* q_dev, int64_t nq, int64_t ldq,
  * filter time per pair at batch 4).  Results are those of `batch` separate calls, bit for bit.
  * q, t, idx, dist, out_q, out_t, out_count, mask, stats: HOST arrays of `batch` device
  * pointers (mask / stats: NULL array or NULL entries allowed); all pairs share nq, nt, ldq, ldt.
- * Not available while sfm_knn_set_filter(1) (the fp32-MFMA variant) is selected.
+ * Not available with SFM_KNN_FILTER_F32 (the fp32-MFMA variant is single-pair).
  * ---------------------------------------------------------------------- */
-size_t sfm_match_batch_l2_f32_ws_bytes(int64_t nq, int64_t nt, int dim, int batch);
+size_t sfm_match_batch_l2_f32_ws_bytes(int64_t nq, int64_t nt, int dim, int batch, int filter);
 int sfm_match_batch_l2_f32(int batch, const float* const* q_dev, int64_t nq, int64_t ldq,
-                           const float* const* t_dev, int64_t nt, int64_t ldt, int dim, double ratio,
+                           const float* const* t_dev, int64_t nt, int64_t ldt, int dim, int filter, double ratio,
                            int32_t* const* idx_dev, float* const* dist_dev, int32_t* const* out_q_dev,
                            int32_t* const* out_t_dev, int32_t* const* out_count_dev, uint8_t* const* mask_dev,
                            int32_t* const* stats_dev, void* ws_dev, size_t ws_bytes, void* stream);

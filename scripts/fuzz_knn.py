@@ -58,8 +58,7 @@ while time.time() < t_end:
         nq, nt = min(nq, 600), min(nt, 3000)             # every stream is rescanned: keep the exact work bounded
     q, t = make(kind, nq, nt)
     nq, nt = len(q), len(t)
-    variant = ["auto", "auto", "auto", "split", "f32"][cases % 5]
-    ops.set_knn_filter(variant)
+    variant = ["auto", "auto", "auto", "split", "f32", "auto", "lds"][cases % 7]
     if variant != "f32" and cases % 4 == 1:
         # a batch of 2..8 pairs of this shape in ONE launch set (sfm_match_batch_l2_f32), data families mixed: the batch runs
         # the most general arithmetic mode any pair needs, every pair must still equal the oracle
@@ -69,7 +68,7 @@ while time.time() < t_end:
         pairs = [(q[:nqb], t[:ntb]) for q, t in pairs if len(q) >= nqb and len(t) >= ntb]
         nqb, ntb = min(len(p[0]) for p in pairs), min(len(p[1]) for p in pairs)
         pairs = [(np.ascontiguousarray(q[:nqb]), np.ascontiguousarray(t[:ntb])) for q, t in pairs]
-        bm = ops.BatchMatcher(nqb, ntb, "cuda", ratio=0.70, batch=len(pairs))
+        bm = ops.BatchMatcher(nqb, ntb, "cuda", ratio=0.70, batch=len(pairs), filter=variant)
         bm.run([(torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda()) for q, t in pairs])
         ok = True
         for b, (q, t) in enumerate(pairs):
@@ -86,7 +85,7 @@ while time.time() < t_end:
             fails += 1
             print(f"MISMATCH case {cases}: BATCH of {len(pairs)} kind={kind} nq={nqb} nt={ntb} variant={variant} stats={st}", flush=True)
         continue
-    pm = ops.PairMatcher(nq, nt, "cuda", ratio=0.70)
+    pm = ops.PairMatcher(nq, nt, "cuda", ratio=0.70, filter=variant)
     idx, dist, oq, ot, cnt = pm.run(torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda())
     gi, gd, m = idx.cpu().numpy(), dist.cpu().numpy(), int(cnt.item())
     wi, wd = O.knn2(q, t, nthreads=os.cpu_count() or 8)
@@ -99,6 +98,5 @@ while time.time() < t_end:
     if not ok:
         fails += 1
         print(f"MISMATCH case {cases}: kind={kind} nq={nq} nt={nt} variant={variant} stats={st} rows differing={(gi != wi).any(1).sum()}", flush=True)
-ops.set_knn_filter("auto")
 print(f"fuzz: {cases} cases ({batched} of them batches of 2..8 pairs), {fails} mismatches, filter modes used {modes} (seed {seed})")
 sys.exit(1 if fails else 0)

@@ -15,8 +15,9 @@ else:
     t = torch.rand((nt, 128), generator=torch.Generator().manual_seed(1)).cuda()
 import time
 B = int(os.environ.get("SFM_BATCH", "1"))
+FILT = os.environ.get("SFM_FILTER", "auto")
 if B > 1:      # one launch set per step for B pairs (what bench.py drives): the PMC passes profile THIS filter launch
-    bm = ops.BatchMatcher(nq, nt, q.device, batch=B)
+    bm = ops.BatchMatcher(nq, nt, q.device, batch=B, filter=FILT)
     # bring the device to its sustained clock with SOMEONE ELSE's kernels (the ramp after idle takes ~25 ms and would
     # sit in the per-kernel averages of a short trace): 100 ms of rocBLAS GEMMs
     wa = torch.rand((4096, 4096), device=q.device, dtype=torch.float16)
@@ -37,7 +38,7 @@ if B > 1:      # one launch set per step for B pairs (what bench.py drives): the
     dt = (time.perf_counter() - t0) / (n * B)
     print(f"done {kind} {nq}x{nt}: batch {B}: {dt*1e3:.4f} ms per pair  {nq*nt/dt:.3e} dist/s  stats", bm.stats[0].cpu().tolist())
     sys.exit(0)
-pm = ops.PairMatcher(nq, nt, q.device)
+pm = ops.PairMatcher(nq, nt, q.device, filter=FILT)
 for _ in range(3):
     pm.run(q, t)
 torch.cuda.synchronize()

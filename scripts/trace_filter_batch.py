@@ -28,3 +28,10 @@ for rep in range(3):
         if s.any():
             print(f"   XCD {x}: {int(s.sum()):3d} WGs  end med {np.median(en[s]):6.1f} max {en[s].max():6.1f} us   clock med {np.median(mhz[s]):5.0f} MHz")
     print(f"   idle tail: sum over WGs of (kernel end - WG end) = {((en.max() - en).sum() / G):.1f} us average per WG = {100 * (en.max() - en).mean() / en.max():.1f} % of the launch")
+    pro = b[:, 0] / 100.0                                   # (accumulated: start -> loop begin, once per segment)
+    loop_done = (b[:, 1] - t0) / 100.0
+    dur = en - st
+    print(f"   per WG: duration med {np.median(dur):.1f} min {dur.min():.1f} max {dur.max():.1f} us | start->first loop (+ later segments, accumulated) med {np.median(pro):.1f} us | "
+          f"last loop end -> WG end med {np.median(en - loop_done):.2f} us | kernel = {en.max():.1f} us, first WG start spread {st.max():.1f} us")
+    cyc = (b[:, 3] - b[:, 2])
+    print(f"   shader cycles per WG med {np.median(cyc):.0f}  (x{G} WGs / 100160 unit tile-steps = {np.median(cyc) * G / (B * 40 * 313):.0f} cycles per tile-step incl. everything)")

@@ -11,7 +11,7 @@ import torch  # noqa: F401  (loads the ROCm runtime torch was built with before 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SFM_HIP_LIB") or os.path.join(_HERE, "lib", "libsfmhip.so")   # (the override is a dev switch for A/B runs of two builds)
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class SfmHipError(RuntimeError):
@@ -26,15 +26,14 @@ _i64, _i32, _int, _f32, _f64, _sz, _vp = (_c.c_int64, _c.c_int32, _c.c_int, _c.c
 SIGNATURES = {
     "sfm_abi_version": (_int, []),
     "sfm_last_error": (_c.c_char_p, []),
-    "sfm_knn2_l2_f32_ws_bytes": (_sz, [_i64, _i64, _int]),
-    "sfm_knn2_l2_f32": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _int, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "sfm_knn_set_filter": (_int, [_int]),
+    "sfm_knn2_l2_f32_ws_bytes": (_sz, [_i64, _i64, _int, _int]),
+    "sfm_knn2_l2_f32": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _int, _int, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sfm_ratio_compact_ws_bytes": (_sz, [_i64]),
     "sfm_ratio_compact": (_int, [_vp, _vp, _i64, _f64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "sfm_match_l2_f32_ws_bytes": (_sz, [_i64, _i64, _int]),
-    "sfm_match_l2_f32": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _int, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "sfm_match_batch_l2_f32_ws_bytes": (_sz, [_i64, _i64, _int, _int]),
-    "sfm_match_batch_l2_f32": (_int, [_int, _vp, _i64, _i64, _vp, _i64, _i64, _int, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sfm_match_l2_f32_ws_bytes": (_sz, [_i64, _i64, _int, _int]),
+    "sfm_match_l2_f32": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _int, _int, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sfm_match_batch_l2_f32_ws_bytes": (_sz, [_i64, _i64, _int, _int, _int]),
+    "sfm_match_batch_l2_f32": (_int, [_int, _vp, _i64, _i64, _vp, _i64, _i64, _int, _int, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sfm_gather_matches": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "sfm_common_points": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sfm_triangulate_dlt": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _int, _int, _vp, _vp]),

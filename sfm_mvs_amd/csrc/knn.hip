@@ -69,9 +69,14 @@ struct BatchPtrs {
     unsigned char* mask[kMaxBatch];
 };
 
+// Filter variants (the `filter` argument of the entry points, include/sfm_hip.h): results are bit-identical whichever runs.
+constexpr int kFilterAuto = 0, kFilterF32 = 1, kFilterSplit = 2, kFilterLds = 3, kFilterLdsSplit = 4;
+
 struct Plan {
-    int split;         // 1: split-bf16 filter (default), 0: fp32-MFMA filter
-    int qg;            // 32-query groups per wave (2: knn_filter_split2_kernel at 2 waves/SIMD)
+    int split;         // 1: 16-bit MFMA filter (default), 0: fp32-MFMA filter
+    int q4;            // 1: knn_filter_q4_kernel (register-streamed fragments, 4 query groups per wave), 0: the LDS-ring kernels
+    int force_mode;    // -1: arithmetic chosen on the device from the data; kModeSplit: pinned to the bf16 split
+    int qg;            // 32-query groups per wave (4: q4; 2: knn_filter_split2_kernel at 2 waves/SIMD)
     int nq_pad;        // query rows (of ONE pair) padded to whole row blocks
     int waves;         // waves per filter workgroup (4, 8 or 16); 16 waves are resident per CU either way
     int rows_per_block;
@@ -127,6 +132,7 @@ __host__ __device__ inline int64_t part_begin(const Partition& pt, int b) {
 }
 constexpr int kSegCostTiles = 5;
 int g_seg_cost = [] { const char* e = getenv("SFM_KNN_SEGCOST"); return e ? atoi(e) : kSegCostTiles; }();   // dev override
+int g_seg_cost_q4 = [] { const char* e = getenv("SFM_KNN_SEGCOST_Q4"); return e ? atoi(e) : 3; }();              // q4 kernel: a segment's prologue in tile-steps
 
 // One workgroup fills the partition tables the filter / refine kernels read: begin[G+1], and per query row block the
 // first and last block that touches it.
@@ -163,15 +169,11 @@ __device__ inline void fill_partition_tables(const Partition pt, int n_rb, int64
     }
 }
 
-// 0 = split-bf16 filter (default), 1 = fp32-MFMA filter.  Initialised from SFM_KNN_FILTER=f32, changed by
-// sfm_knn_set_filter().  Both give bit-identical results; they differ in speed only.
-int g_filter_mode = [] { const char* e = getenv("SFM_KNN_FILTER"); return (e && e[0] == 'f') ? 1 : 0; }();
-
-Plan make_plan_uncached(int64_t nq, int64_t nt, int B);
+Plan make_plan_uncached(int64_t nq, int64_t nt, int B, int filter);
 
 // Planning walks the partition (O(G + row blocks)): keep the last few plans (a pipeline alternates between its full
 // batch and the partial batch that ends a sequence).
-Plan make_plan(int64_t nq, int64_t nt, int B = 1) {
+Plan make_plan(int64_t nq, int64_t nt, int B, int filter) {
     struct Entry {
         int64_t nq = -1, nt = -1;
         int B = -1, mode = -1, seg = -1;
@@ -184,26 +186,29 @@ Plan make_plan(int64_t nq, int64_t nt, int B = 1) {
     std::lock_guard<std::mutex> lk(mu);
     Entry* victim = &cache[0];
     for (Entry& e : cache) {
-        if (e.nq == nq && e.nt == nt && e.B == B && e.mode == g_filter_mode && e.seg == g_seg_cost) {
+        if (e.nq == nq && e.nt == nt && e.B == B && e.mode == filter && e.seg == g_seg_cost) {
             e.used = ++tick;
             return e.plan;
         }
         if (e.used < victim->used) victim = &e;
     }
-    victim->plan = make_plan_uncached(nq, nt, B);
-    victim->nq = nq; victim->nt = nt; victim->B = B; victim->mode = g_filter_mode; victim->seg = g_seg_cost;
+    victim->plan = make_plan_uncached(nq, nt, B, filter);
+    victim->nq = nq; victim->nt = nt; victim->B = B; victim->mode = filter; victim->seg = g_seg_cost;
     victim->used = ++tick;
     return victim->plan;
 }
 
-Plan make_plan_uncached(int64_t nq, int64_t nt, int B) {
+Plan make_plan_uncached(int64_t nq, int64_t nt, int B, int filter) {
     Plan p;
     p.B = B;
     static const int env_w = [] { const char* e = getenv("SFM_KNN_WAVES"); return e ? atoi(e) : 0; }();   // dev override
     p.waves = (env_w == 4 || env_w == 8 || env_w == 16) ? env_w : 8;
-    p.split = g_filter_mode == 1 ? 0 : 1;
-    p.qg = p.split ? 2 : 1;
-    if (p.split && !(env_w == 4 || env_w == 8 || env_w == 16)) p.waves = p.qg == 2 ? 4 : 16;   // split2: two 4-wave workgroups per CU (their barrier stalls interleave; ~3 % over one 8-wave group)
+    p.split = filter == kFilterF32 ? 0 : 1;
+    p.q4 = (filter == kFilterAuto || filter == kFilterSplit) ? 1 : 0;
+    p.force_mode = (filter == kFilterSplit || filter == kFilterLdsSplit) ? 2 /*kModeSplit*/ : -1;
+    p.qg = p.q4 ? 4 : p.split ? 2 : 1;
+    if (p.q4) p.waves = 4;                     // one 4-wave workgroup per CU: one wave per SIMD, 512 registers each
+    else if (p.split && !(env_w == 4 || env_w == 8 || env_w == 16)) p.waves = p.qg == 2 ? 4 : 16;   // split2: two 4-wave workgroups per CU (their barrier stalls interleave; ~3 % over one 8-wave group)
     p.rows_per_block = p.waves * 32 * p.qg;
     p.n_rb1 = (int)((nq + p.rows_per_block - 1) / p.rows_per_block);
     p.n_rb = B * p.n_rb1;
@@ -216,7 +221,7 @@ Plan make_plan_uncached(int64_t nq, int64_t nt, int B) {
     if (g > (int64_t)p.n_rb * (kMaxSlots - 2)) g = (int64_t)p.n_rb * (kMaxSlots - 2);
     if (g < 1) g = 1;
     p.G = (int)g;
-    p.seg_cost = (p.split && p.qg == 2) ? g_seg_cost : 0;
+    p.seg_cost = p.q4 ? g_seg_cost_q4 : (p.split && p.qg == 2) ? g_seg_cost : 0;
     {   // candidate slots per row block / substreams per slot from the actual partition
         std::vector<int64_t> begin((size_t)p.G + 1);
         const Partition pt = make_partition(p.units, p.tiles, p.G, p.seg_cost);
@@ -586,6 +591,29 @@ __device__ __forceinline__ int knn_batch_mode(const int* __restrict__ flags, con
     return mode;
 }
 
+// ---- fragment-order images of the q4 filter
+constexpr int kFragBytes = 1024;                            // one MFMA operand fragment of a 32-row tile: 64 lanes x 16 B
+constexpr int kTileFrags = 9;                               // 8 k-steps of 16 + the accumulator-init fragment
+constexpr int kTileFragBytes = kTileFrags * kFragBytes;
+
+// The accumulator init ||t||^2 + ||q||^2 as ONE v_mfma_f32_32x32x16_bf16: a float32 x >= 0 is split EXACTLY into three
+// bf16 pieces hi + mid + lo (8 + 8 + 8 significant bits; every residual is exact in float32), the train side carries
+// {hi, mid, lo, 1, 1, 1, 0, 0} and the query side {1, 1, 1, hi, mid, lo, 0, 0} in the k-slots of the lanes with h = 0 (the
+// h = 1 lanes hold zeros), so the product sums the six pieces in the fp32 accumulator.  +inf (padded train rows) is
+// {inf, 0, 0}: no inf - inf.  Pieces below bf16's normal range (x < 2^-110) may be flushed by the matrix pipe: an absolute
+// error < 2^-120, far below the certificate's slack (which is relative to (|q| + |t|max)^2 >= 2^-28 in every mode).
+__device__ __forceinline__ uint4 frag_init_operand(float x, bool query_side) {
+    unsigned hi = bf16_rn_bits(x), mid = 0, lo = 0;
+    if (x < kInf) {
+        const float r1 = x - __uint_as_float(hi << 16);
+        mid = bf16_rn_bits(r1);
+        lo = bf16_rn_bits(r1 - __uint_as_float(mid << 16));
+    }
+    const unsigned one = 0x3F80u;
+    return query_side ? make_uint4(one | (one << 16), one | (hi << 16), mid | (lo << 16), 0u)
+                      : make_uint4(hi | (mid << 16), lo | (one << 16), one | (one << 16), 0u);
+}
+
 // One pass over Q and T: rows → the fp16 image (Q pre-scaled by -2, exact), fp32 squared norms, per-block max of
 // ||t||^2 and exactness / range flags, zero the rescan counter.  Rows >= n of the padded images are zero-filled.
 // Image layout: [3][n_pad][128] 16-bit: bf16 hi, bf16 mid, fp16; the two bf16 planes are only needed by the split
@@ -599,6 +627,8 @@ __global__ __launch_bounds__(1024) void knn_prep_kernel(BatchPtrs P, int64_t ldq
                                                        float* __restrict__ bmax, int* __restrict__ midflag,
                                                        float* __restrict__ qerr /*[s_qn] per pair*/, float* __restrict__ bmaxerr /*[kNormBlocks] per pair*/,
                                                        int64_t s_qsplit, int64_t s_tsplit, int64_t s_qn, int64_t s_tn,
+                                                       unsigned char* __restrict__ qfrag /*null: row-major images only (LDS-ring filter)*/,
+                                                       unsigned char* __restrict__ tfrag, int64_t s_qfrag, int64_t s_tfrag,
                                                        int* __restrict__ zero, int nzero,
                                                        int64_t units, int tiles, int G, int seg_cost, int n_rb,
                                                        int64_t* __restrict__ wg_begin, int* __restrict__ rb_first,
@@ -616,6 +646,8 @@ __global__ __launch_bounds__(1024) void knn_prep_kernel(BatchPtrs P, int64_t ldq
     bmax += pb * kNormBlocks; midflag += pb * kNormBlocks;
     qerr += pb * s_qn; bmaxerr += pb * kNormBlocks;
     zero += pb * nzero;
+    const bool frag = qfrag != nullptr;
+    if (frag) { qfrag += pb * s_qfrag; tfrag += pb * s_tfrag; }
     const int nblk = gridDim.x - 1;
     __shared__ int wmid[16];
     const int l = threadIdx.x & 31;
@@ -649,8 +681,19 @@ __global__ __launch_bounds__(1024) void knn_prep_kernel(BatchPtrs P, int64_t ldq
         err2 += lane_xor<16>(err2); err2 += lane_xor<8>(err2); err2 += lane_xor<4>(err2); err2 += lane_xor<2>(err2); err2 += lane_xor<1>(err2);
         if (!(err2 < kInf)) err2 = 0.f;                                  // (out-of-range data: the split arithmetic runs, this term is unused)
         unsigned short* img = isq ? qsplit : tsplit;
-        *reinterpret_cast<uint2*>(img + (2 * (int64_t)npad + r) * kDim + 4 * l) = make_uint2(fb[0] | (fb[1] << 16), fb[2] | (fb[3] << 16));
-        if (l == 0) (isq ? qn : tn)[r] = (isq || r < n) ? s : kInf;   // padded train rows can never be candidates
+        const uint2 packed = make_uint2(fb[0] | (fb[1] << 16), fb[2] | (fb[3] << 16));
+        if (!frag || !isq) *reinterpret_cast<uint2*>(img + (2 * (int64_t)npad + r) * kDim + 4 * l) = packed;   // (row-major fp16 T: the refine kernel's screens)
+        const float nrm = (isq || r < n) ? s : kInf;                  // padded train rows can never be candidates
+        if (frag) {
+            // the same row in FRAGMENT ORDER (knn_filter_q4_kernel): [32-row tile][9 fragments][64 lanes][16 B]; fragment f < 8 is
+            // k-step f of v_mfma_f32_32x32x16_f16 (lane 32 h + j holds elements 16 f + 8 h .. + 7 of row j of the tile), fragment 8
+            // is the accumulator-init operand (frag_init_operand)
+            unsigned char* fimg = (isq ? qfrag : tfrag) + ((int64_t)(r >> 5) * kTileFrags) * kFragBytes;
+            const int c = l >> 1;                                      // 16-byte chunk of the row
+            *reinterpret_cast<uint2*>(fimg + (((c >> 1) * 64 + (c & 1) * 32 + (r & 31)) << 4) + ((l & 1) << 3)) = packed;
+            if (l < 2) *reinterpret_cast<uint4*>(fimg + ((8 * 64 + l * 32 + (r & 31)) << 4)) = l == 0 ? frag_init_operand(nrm, isq) : make_uint4(0u, 0u, 0u, 0u);
+        }
+        if (l == 0) (isq ? qn : tn)[r] = nrm;
         if (isq) {
             if (l == 0) qerr[r] = err2;
         } else {
@@ -699,9 +742,11 @@ __global__ __launch_bounds__(kSplitThreads) void knn_split_images_kernel(BatchPt
                                                                         int nt_pad, unsigned short* __restrict__ qsplit0,
                                                                         unsigned short* __restrict__ tsplit0, int64_t s_qsplit, int64_t s_tsplit,
                                                                         const int* __restrict__ midflag, const float* __restrict__ bmax,
-                                                                        int force_mode) {
+                                                                        int force_mode, unsigned char* __restrict__ qhm0 /*null: row-major planes*/,
+                                                                        unsigned char* __restrict__ thm0, int64_t s_qhm, int64_t s_thm) {
     const int mode = force_mode >= 0 ? force_mode : knn_batch_mode(midflag, bmax, B, (int)(threadIdx.x & 63));
     if (mode != kModeSplit) return;
+    const bool frag = qhm0 != nullptr;
     const int l = threadIdx.x & 31;
     const int rows = nq_pad + nt_pad;
     constexpr int kRowsPerPass = kSplitThreads / 32;
@@ -724,9 +769,18 @@ __global__ __launch_bounds__(kSplitThreads) void knn_split_images_kernel(BatchPt
             hb[k] = bf16_rn_bits(e[k]);
             mb[k] = bf16_rn_bits(e[k] - __uint_as_float(hb[k] << 16));   // x - hi is exact in fp32
         }
-        unsigned short* img = isq ? qsplit : tsplit;
-        *reinterpret_cast<uint2*>(img + (int64_t)r * kDim + 4 * l) = make_uint2(hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16));
-        *reinterpret_cast<uint2*>(img + ((int64_t)npad + r) * kDim + 4 * l) = make_uint2(mb[0] | (mb[1] << 16), mb[2] | (mb[3] << 16));
+        const uint2 hp = make_uint2(hb[0] | (hb[1] << 16), hb[2] | (hb[3] << 16)), mp = make_uint2(mb[0] | (mb[1] << 16), mb[2] | (mb[3] << 16));
+        if (frag) {      // fragment order (q4 filter): per 32-row tile 8 hi fragments then 8 mid fragments, 1 KiB each (see knn_prep_kernel)
+            unsigned char* fimg = (isq ? qhm0 + pb * s_qhm : thm0 + pb * s_thm) + (int64_t)(r >> 5) * (16 * kFragBytes);
+            const int c = l >> 1;
+            const int off = (((c >> 1) * 64 + (c & 1) * 32 + (r & 31)) << 4) + ((l & 1) << 3);
+            *reinterpret_cast<uint2*>(fimg + off) = hp;
+            *reinterpret_cast<uint2*>(fimg + 8 * kFragBytes + off) = mp;
+        } else {
+            unsigned short* img = isq ? qsplit : tsplit;
+            *reinterpret_cast<uint2*>(img + (int64_t)r * kDim + 4 * l) = hp;
+            *reinterpret_cast<uint2*>(img + ((int64_t)npad + r) * kDim + 4 * l) = mp;
+        }
     }
     }
 }
@@ -1166,6 +1220,356 @@ __global__ __launch_bounds__(64 * W, 2) void knn_filter_split2_kernel(
     else
         filter_split2_body<ABL, W, false>(smem, qsplit, qnorm, nq, nq_pad, tsplit, nt_pad, tn, tiles, units, smax, nsub, cand_s, cand_i, wg_begin, rb_first,
                                           n_rb1, s_qsplit, s_tsplit, s_qn, s_tn, s_cand, trace);
+    if (trace && threadIdx.x == 0) {
+        trace[4 * blockIdx.x + 1] = wall_clock64();
+        trace[8192 + 4 * blockIdx.x + 3] = clock64();
+    }
+}
+
+// ---------------------------------------------------------------- q4 filter: fragments streamed L2 -> registers, no LDS
+// Round 3.  The LDS-ring kernel above runs its tile loop at ~80 % of the matrix pipe's rate but spends 20 % of the pipe on
+// the fp32 accumulator-init MFMA, needs two co-resident waves per SIMD to cover its barriers / LDS-DMA issue / ds_reads
+// (which then contend for the one pipe), and pays a 5 us prologue per segment for the LDS transposition of the query
+// fragments.  This kernel removes all of that:
+//   * ONE wave per SIMD (a 256-thread workgroup per CU, 512 registers per lane): a wave owns FOUR 32-query groups whose B
+//     fragments (4 x 8 k-steps x 4 registers + 4 init fragments = 144 registers) live in ACCUMULATION registers — MFMA
+//     A/B operands may be AGPRs on gfx950, the vector ALU never touches them — while the four accumulators (64), the
+//     packed keys (12) and the train fragments sit in VGPRs.  Every train fragment feeds four MFMAs.
+//   * NO LDS, no barrier, no LDS-DMA: the prep pass stores both images in FRAGMENT ORDER ([32-row tile][9][64 lanes][16 B]),
+//     so an MFMA A operand of a whole tile is ONE coalesced 1 KiB buffer_load_dwordx4 straight into the registers the MFMA
+//     reads.  A ring of kQ4Ring tiles of fragments (27 loads in flight per wave) replaces the LDS ring; a fragment's
+//     registers are refilled for tile t + kQ4Ring right after its last MFMA of tile t.  The four waves of a workgroup walk
+//     the same tiles (L1 / L2 hits) but nothing synchronises them.  (An LDS-DMA piece costs its wave 60-185 issue cycles
+//     and there is no partner wave to hide them behind: the same loop fed through the LDS ring runs 10 % slower —
+//     scripts/ubench/filter_q4.hip, V = 3 against V = 4.)
+//   * accumulator init ||t||^2 + ||q||^2 as one bf16 MFMA on exact bf16 triples (frag_init_operand): 32 pipe cycles per
+//     group and tile instead of 64, no LDS read, no v_cndmask.
+//   * the accumulators are single-buffered: a tile is two phases — the chains of groups 0, 1 with the packed-key epilogue
+//     of groups 2, 3 (previous tile) as fillers between the MFMAs, then the chains of 2, 3 with the epilogue of 0, 1 —
+//     ~3 VALU per MFMA gap, below the ~5 a wave alone on its SIMD can hide per 32-cycle MFMA.
+// In isolation (scripts/ubench/filter_q4.hip) the loop sustains 1520-1560 algorithmic TFLOP/s against 1610 for the same
+// MFMA stream with operands in registers and 1220 for the LDS-ring loop: what is left is the power-limited clock
+// (~1.75 GHz under a dense MFMA stream) and the init MFMAs (4 of 36).
+// Candidate records, streams and the partition tables are exactly those of the LDS-ring kernel (a row block is 512
+// queries, 256 workgroups), so the refine kernel is shared.
+// MFMAs are inline asm (B operands constrained to "a"): hipcc pads nothing around them.  The hazards that matter —
+// an MFMA's D read by a VALU (8-pass: 12 wait states) — are covered by construction: an accumulator is first read by the
+// epilogue at least two later MFMAs (>= 16 passes) after the MFMA that completed it, and the segment tail carries explicit
+// s_nops.
+constexpr int kQ4Rows = 4 * 4 * 32;                         // queries per workgroup: 4 waves x 4 groups x 32
+constexpr int kQ4Ring = 3;                                  // tiles of train fragments in registers (fp16 bodies)
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+#define SFM_MFMA_F16(acc, a, b) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b))
+#define SFM_MFMA_BF16(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b))
+#define SFM_MFMA_BF16_INIT(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "a"(b))
+
+__device__ __forceinline__ void key_insert_quad(const f32x16& a, int r, int seq /*wave-uniform*/, int vmask, int& k0, int& k1, int& k2) {
+    const int m = min(min(__float_as_int(a[r]), __float_as_int(a[r + 1])), min(__float_as_int(a[r + 2]), __float_as_int(a[r + 3])));
+    int key;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(key) : "v"(m), "v"(vmask), "s"(seq));
+    const int lo = min(key, k0);
+    const int m1 = max(min(key, k1), min(max(key, k1), k0));
+    k2 = max(min(key, k1), min(max(key, k1), k2));
+    k1 = m1;
+    k0 = lo;
+}
+
+__device__ __forceinline__ int key_make(const f32x16& a, int r, int seq /*wave-uniform*/, int vmask) {
+    const int m = min(min(__float_as_int(a[r]), __float_as_int(a[r + 1])), min(__float_as_int(a[r + 2]), __float_as_int(a[r + 3])));
+    int key;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(key) : "v"(m), "v"(vmask), "s"(seq));
+    return key;
+}
+__device__ __forceinline__ void key_put(int key, int& k0, int& k1, int& k2) {
+    const int lo = min(key, k0);
+    const int m1 = max(min(key, k1), min(max(key, k1), k0));
+    k2 = max(min(key, k1), min(max(key, k1), k2));
+    k1 = m1;
+    k0 = lo;
+}
+
+// KMID = false: fp16 single product, 4 groups per wave in one pass.  KMID = true: bf16 hi/mid split (three products), two
+// passes of 2 groups (their hi + mid B fragments fill the same 128 AGPRs), ring of 2 tiles x 17 fragments.
+// ABL != 0: dev-only timing ablations (results are WRONG): bit0 no fragment refills in the loop, bit1 no packed-key epilogue.
+template <bool KMID, int ABL>
+__device__ __forceinline__ void filter_q4_body(
+    const unsigned char* __restrict__ qfrag, const unsigned char* __restrict__ tfrag, const unsigned char* __restrict__ qhm,
+    const unsigned char* __restrict__ thm, int nq, int nq_pad, int tiles, int smax, int nsub, float* __restrict__ cand_s0,
+    int* __restrict__ cand_i0, const int64_t* __restrict__ wg_begin, const int* __restrict__ rb_first, int n_rb1, int64_t s_qfrag,
+    int64_t s_tfrag, int64_t s_qhm, int64_t s_thm, int64_t s_cand) {
+    constexpr int NG = KMID ? 2 : 4;                          // groups per pass
+    constexpr int NPASS = KMID ? 2 : 1;
+    constexpr int P = NG / 2;                                 // groups per phase
+    constexpr int D = KMID ? 2 : kQ4Ring;                     // ring depth in tiles
+    constexpr int NF = KMID ? 17 : 9;                         // fragments per tile: [hi 0..7][mid 8..15][init] / [fp16 0..7][init]
+    constexpr int FI = NF - 1;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int G = gridDim.x;
+    const int bid = (G & 7) == 0 ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;   // XCD-aware order (see the LDS-ring kernel)
+    const int64_t u_end = wg_begin[bid + 1];
+    int64_t u = wg_begin[bid];
+    const int voff = lane * 16;
+    const int qtiles = nq_pad >> 5;
+    int vmask;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(vmask) : "s"(~kKeyMask));
+
+    while (u < u_end) {
+        const int rb = (int)(u / tiles);
+        const int t_begin = (int)(u - (int64_t)rb * tiles);
+        const int t_end = (int)min((int64_t)tiles, t_begin + (u_end - u));
+        const int slot = bid - rb_first[rb];
+        const int pb = n_rb1 > 0 ? rb / n_rb1 : 0;
+        const int rbl = rb - pb * n_rb1;
+        float* __restrict__ cand_s = cand_s0 + pb * s_cand;
+        int* __restrict__ cand_i = cand_i0 + pb * s_cand;
+        const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc((void*)(tfrag + pb * s_tfrag), 0, tiles * kTileFragBytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc((void*)(qfrag + pb * s_qfrag), 0, qtiles * kTileFragBytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t thrs = __builtin_amdgcn_make_buffer_rsrc((void*)(KMID ? thm + pb * s_thm : tfrag), 0, KMID ? tiles * 16 * kFragBytes : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t qhrs = __builtin_amdgcn_make_buffer_rsrc((void*)(KMID ? qhm + pb * s_qhm : qfrag), 0, KMID ? qtiles * 16 * kFragBytes : 0, 0x00020000);
+
+#pragma unroll 1
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const int qg0 = rbl * (kQ4Rows / 32) + wave * 4 + pass * NG;        // first 32-query tile of this pass
+            const int qrow0 = qg0 * 32 + j;                                    // group g adds 32 g
+            bool qok[NG];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) qok[g] = qrow0 + 32 * g < nq;
+
+            // ---- train fragments of the first D tiles, then the query fragments
+            i32x4 fr[D][NF];
+            auto load_frag = [&](int s, int f, int tile_, bool live, bool in_loop = false) {
+                // fragment f of `tile` -> ring slot s (live = false: the ring runs past the segment's end; the segment's last
+                // tile is fetched again — L1 / L2 hits — and never used)
+                if ((ABL & 1) && in_loop) return;
+                const int tile = live ? tile_ : t_end - 1;
+                int soff;
+                if constexpr (KMID) {
+                    soff = __builtin_amdgcn_readfirstlane(f == FI ? tile * kTileFragBytes + 8 * kFragBytes : tile * (16 * kFragBytes) + f * kFragBytes);
+                    fr[s][f] = f == FI ? __builtin_amdgcn_raw_buffer_load_b128(trs, voff, soff, 0) : __builtin_amdgcn_raw_buffer_load_b128(thrs, voff, soff, 0);
+                } else {
+                    soff = __builtin_amdgcn_readfirstlane(tile * kTileFragBytes + f * kFragBytes);
+                    fr[s][f] = __builtin_amdgcn_raw_buffer_load_b128(trs, voff, soff, 0);
+                }
+            };
+#pragma unroll
+            for (int d = 0; d < D; ++d)
+#pragma unroll
+                for (int f = 0; f < NF; ++f) load_frag(d, (f + FI) % NF, t_begin + d, t_begin + d < t_end);   // (init fragment first: it is consumed first)
+
+            __builtin_amdgcn_sched_barrier(0);
+            // the query fragments go straight into accumulation registers (hipcc makes the loads' destinations the AGPRs the
+            // tied "a" constraints below ask for); ALL of them are requested before the first is waited for
+            u32x4 bq[NG][KMID ? 16 : 8], bi[NG];
+            {
+                i32x4 tmp[NG][KMID ? 16 : 8], tmpi[NG];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+#pragma unroll
+                    for (int f = 0; f < (KMID ? 16 : 8); ++f)
+                        tmp[g][f] = KMID ? __builtin_amdgcn_raw_buffer_load_b128(qhrs, voff, __builtin_amdgcn_readfirstlane((qg0 + g) * (16 * kFragBytes) + f * kFragBytes), 0)
+                                         : __builtin_amdgcn_raw_buffer_load_b128(qrs, voff, __builtin_amdgcn_readfirstlane((qg0 + g) * kTileFragBytes + f * kFragBytes), 0);
+                    tmpi[g] = __builtin_amdgcn_raw_buffer_load_b128(qrs, voff, __builtin_amdgcn_readfirstlane((qg0 + g) * kTileFragBytes + 8 * kFragBytes), 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+#pragma unroll
+                    for (int f = 0; f < (KMID ? 16 : 8); ++f) asm volatile("" : "=a"(bq[g][f]) : "0"(__builtin_bit_cast(u32x4, tmp[g][f])));
+                    asm volatile("" : "=a"(bi[g]) : "0"(__builtin_bit_cast(u32x4, tmpi[g])));
+                }
+            }
+            asm volatile("s_nop 4");                                           // v_accvgpr_write -> MFMA operand
+
+            int k0[NG], k1[NG], k2[NG];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) k0[g] = k1[g] = k2[g] = kKeyInf;
+            int sub = 0, sub_t0 = t_begin;
+            auto flush = [&](int sb, int st0) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    if (qok[g]) {
+                        const int64_t ob = ((int64_t)(qrow0 + 32 * g) * (2 * smax * nsub) + (int64_t)slot * nsub * 2 + h) * 3 + 6 * sb;
+                        flush_keys<true>(k0[g], k1[g], k2[g], st0, h, cand_s + ob, cand_i + ob);
+                    }
+                    k0[g] = k1[g] = k2[g] = kKeyInf;
+                }
+            };
+            f32x16 acc[NG];
+            // the first tile's "previous tile" (phase A runs the epilogue of the second half's groups) is +inf everywhere: its
+            // insertions leave the keys untouched
+#pragma unroll
+            for (int g = P; g < NG; ++g)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[g][r] = kInf;
+
+            // k-step st of group g: one fp16 product, or the three bf16 products hi.hi + hi.mid + mid.hi
+            auto tile = [&](int t, auto slot_c) {
+                constexpr int S = decltype(slot_c)::value;
+                const bool more = t + D < t_end;
+                const int seq_prev = __builtin_amdgcn_readfirstlane(max((t - 1) - sub_t0, 0) << 2);
+                // ---- phase A: chains of the first half's groups; epilogue of the second half's groups (previous tile)
+                {
+                    const u32x4 ai = __builtin_bit_cast(u32x4, fr[S][FI]);
+#pragma unroll
+                    for (int g = 0; g < P; ++g) SFM_MFMA_BF16_INIT(acc[g], ai, bi[g]);
+                }
+#pragma unroll
+                for (int st = 0; st < 8; ++st) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    const u32x4 a = __builtin_bit_cast(u32x4, fr[S][st]);
+                    if constexpr (KMID) {
+                        const u32x4 am = __builtin_bit_cast(u32x4, fr[S][8 + st]);
+                        SFM_MFMA_BF16(acc[0], a, bq[0][st]);
+                        SFM_MFMA_BF16(acc[0], a, bq[0][8 + st]);
+                        SFM_MFMA_BF16(acc[0], am, bq[0][st]);
+                        if (st & 1) key_insert_quad(acc[1], 4 * (st >> 1), seq_prev + (st >> 1), vmask, k0[1], k1[1], k2[1]);
+                    } else {
+                        // the epilogue's six VALU per quad are dealt to BOTH gaps (three after each MFMA): a wave alone on its SIMD
+                        // hides ~5 single-issue instructions per 32-cycle MFMA, and none behind an MFMA it is still waiting to issue
+                        const int g = 2 + (st >> 2);
+                        SFM_MFMA_F16(acc[0], a, bq[0][st]);
+                        int key = 0;
+                        if (!(ABL & 2)) key = key_make(acc[g], 4 * (st & 3), seq_prev + (st & 3), vmask);
+                        __builtin_amdgcn_sched_barrier(0);
+                        SFM_MFMA_F16(acc[1], a, bq[1][st]);
+                        if (ABL & 2) {
+                            if (st == 0) k0[2] = min(k0[2], __float_as_int(acc[2][0]) + __float_as_int(acc[3][5]));
+                        } else
+                            key_put(key, k0[g], k1[g], k2[g]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // ---- substream boundary: every group's keys now cover exactly the tiles before t
+                if (t - sub_t0 == kSubTiles) {
+                    flush(sub, sub_t0);
+                    ++sub;
+                    sub_t0 = t;
+                }
+                const int seq_cur = __builtin_amdgcn_readfirstlane((t - sub_t0) << 2);
+                // ---- phase B: chains of the second half's groups; epilogue of the first half's (this tile); the fragments die
+                // one by one and are refilled for tile t + D
+                {
+                    const u32x4 ai = __builtin_bit_cast(u32x4, fr[S][FI]);
+#pragma unroll
+                    for (int g = P; g < NG; ++g) SFM_MFMA_BF16_INIT(acc[g], ai, bi[g]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                load_frag(S, FI, t + D, more, true);
+#pragma unroll
+                for (int st = 0; st < 8; ++st) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    const u32x4 a = __builtin_bit_cast(u32x4, fr[S][st]);
+                    if constexpr (KMID) {
+                        const u32x4 am = __builtin_bit_cast(u32x4, fr[S][8 + st]);
+                        SFM_MFMA_BF16(acc[1], a, bq[1][st]);
+                        SFM_MFMA_BF16(acc[1], a, bq[1][8 + st]);
+                        SFM_MFMA_BF16(acc[1], am, bq[1][st]);
+                    } else {
+                        const int g = st >> 2;
+                        SFM_MFMA_F16(acc[2], a, bq[2][st]);
+                        int key = 0;
+                        if (!(ABL & 2)) key = key_make(acc[g], 4 * (st & 3), seq_cur + (st & 3), vmask);
+                        __builtin_amdgcn_sched_barrier(0);
+                        SFM_MFMA_F16(acc[3], a, bq[3][st]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        load_frag(S, st, t + D, more, true);
+                        if (ABL & 2) {
+                            if (st == 0) k0[0] = min(k0[0], __float_as_int(acc[0][0]) + __float_as_int(acc[1][5]));
+                        } else
+                            key_put(key, k0[g], k1[g], k2[g]);
+                    }
+                    if constexpr (KMID) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        load_frag(S, st, t + D, more, true);
+                        load_frag(S, 8 + st, t + D, more, true);
+                        if (st & 1) key_insert_quad(acc[0], 4 * (st >> 1), seq_cur + (st >> 1), vmask, k0[0], k1[0], k2[0]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            // Whole rounds of D tiles first, the remainder after the loop: with conditional tiles INSIDE the loop hipcc's
+            // waitcnt pass has to merge "only the first tile ran" into the back edge and makes every round's first tile wait for
+            // ALL outstanding loads (vmcnt(8) .. (0) instead of (26) .. (18)): the ring's prefetch distance would be zero there.
+            int t = t_begin;
+            for (; t + D <= t_end; t += D) {
+                tile(t, std::integral_constant<int, 0>{});
+                tile(t + 1, std::integral_constant<int, 1>{});
+                if constexpr (D > 2) tile(t + 2, std::integral_constant<int, (D > 2 ? 2 : 0)>{});
+            }
+            if (t < t_end) {
+                tile(t, std::integral_constant<int, 0>{});
+                if constexpr (D > 2)
+                    if (t + 1 < t_end) tile(t + 1, std::integral_constant<int, 1>{});
+            }
+            // epilogue of the last tile's second-half groups (the MFMAs that completed them were the last instructions issued)
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+            if (t_end > t_begin) {
+                const int seq = __builtin_amdgcn_readfirstlane(((t_end - 1) - sub_t0) << 2);
+#pragma unroll
+                for (int g = P; g < NG; ++g)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 4) key_insert_quad(acc[g], r, seq + (r >> 2), vmask, k0[g], k1[g], k2[g]);
+            }
+            flush(sub, sub_t0);
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+                if (qok[g]) {
+                    const int64_t ob = ((int64_t)(qrow0 + 32 * g) * (2 * smax * nsub) + (int64_t)slot * nsub * 2 + h) * 3;
+                    for (int e = sub + 1; e < nsub; ++e)
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) {
+                            cand_s[ob + 6 * e + r] = kInf;
+                            cand_i[ob + 6 * e + r] = -1;
+                        }
+                }
+        }
+        u += t_end - t_begin;
+    }
+}
+
+template <int ABL>
+__global__ __launch_bounds__(256, 1) void knn_filter_q4_kernel(
+    const unsigned char* __restrict__ qfrag, const unsigned char* __restrict__ tfrag, const unsigned char* __restrict__ qhm,
+    const unsigned char* __restrict__ thm, int nq, int nq_pad, int tiles, int smax, int nsub, const int* __restrict__ midflag,
+    const float* __restrict__ bmax, int force_mode, float* __restrict__ cand_s, int* __restrict__ cand_i,
+    const int64_t* __restrict__ wg_begin, const int* __restrict__ rb_first, int n_rb1, int n_pairs, int64_t s_qfrag, int64_t s_tfrag,
+    int64_t s_qhm, int64_t s_thm, int64_t s_cand, int* __restrict__ minfo, const float* __restrict__ bmaxerr,
+    long long* __restrict__ trace) {
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        // what the refine kernel needs of the flags, reduced ONCE: per pair the mode and ||t||max, and the batch's mode
+        int bm = kModeHalfExact;
+        for (int b = 0; b < n_pairs; ++b) {
+            float tmax;
+            const int m = knn_filter_mode(midflag + b * kNormBlocks, bmax + b * kNormBlocks, (int)threadIdx.x, &tmax);
+            bm = max(bm, m);
+            const float* be = bmaxerr + b * kNormBlocks;
+            float te = fmaxf(fmaxf(be[threadIdx.x], be[threadIdx.x + 64]), fmaxf(be[threadIdx.x + 128], be[threadIdx.x + 192]));
+#pragma unroll
+            for (int sh = 32; sh >= 1; sh >>= 1) te = fmaxf(te, __shfl_xor(te, sh, 64));
+            if (threadIdx.x == 0) {
+                minfo[kMinfoPairMode + b] = m;
+                minfo[kMinfoTmax + b] = __float_as_int(tmax);
+                minfo[kMinfoTerr + b] = __float_as_int(te);
+            }
+        }
+        if (threadIdx.x == 0) minfo[kMinfoBatchMode] = bm;
+    }
+    if (trace && threadIdx.x == 0) {
+        trace[4 * blockIdx.x + 0] = wall_clock64();
+        trace[4 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg(0xF804);
+        trace[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg(0xF814);
+        trace[8192 + 4 * blockIdx.x + 2] = clock64();
+    }
+    const bool need_mid = (force_mode >= 0 ? force_mode : knn_batch_mode(midflag, bmax, n_pairs, (int)(threadIdx.x & 63))) == kModeSplit;
+    if (need_mid)
+        filter_q4_body<true, 0>(qfrag, tfrag, qhm, thm, nq, nq_pad, tiles, smax, nsub, cand_s, cand_i, wg_begin, rb_first, n_rb1, s_qfrag, s_tfrag, s_qhm,
+                             s_thm, s_cand);
+    else
+        filter_q4_body<false, ABL>(qfrag, tfrag, qhm, thm, nq, nq_pad, tiles, smax, nsub, cand_s, cand_i, wg_begin, rb_first, n_rb1, s_qfrag, s_tfrag, s_qhm,
+                              s_thm, s_cand);
     if (trace && threadIdx.x == 0) {
         trace[4 * blockIdx.x + 1] = wall_clock64();
         trace[8192 + 4 * blockIdx.x + 3] = clock64();
@@ -1936,8 +2340,6 @@ __global__ void knn_fill_empty_kernel(int* __restrict__ idx, float* __restrict__
 }
 
 long long* g_trace = nullptr;   // dev diagnostics only
-// dev/test only: SFM_KNN_MODE=split|half pins the 16-bit filter's arithmetic mode (default: decided on the device)
-int g_force_mode = [] { const char* e = getenv("SFM_KNN_MODE"); return !e ? -1 : e[0] == 's' ? kModeSplit : e[0] == 'h' ? kModeHalf : -1; }();
 
 struct KnnWs {
     unsigned short* qsplit;       // per-pair arrays: pair b at base + b * stride (elements)
@@ -1954,7 +2356,11 @@ struct KnnWs {
     int* rb_last;
     float* cand_s;
     int* cand_i;
-    int64_t s_qsplit, s_tsplit, s_qn, s_tn, s_cand;
+    unsigned char* qfrag;         // q4 filter: fragment-order fp16 images (+ init fragments), kTileFragBytes per 32 rows
+    unsigned char* tfrag;
+    unsigned char* qhm;           // ... and the bf16 hi / mid planes in fragment order (split arithmetic only), 16 KiB per 32 rows
+    unsigned char* thm;
+    int64_t s_qsplit, s_tsplit, s_qn, s_tn, s_cand, s_qfrag, s_tfrag, s_qhm, s_thm;
     size_t bytes;
 };
 
@@ -1965,7 +2371,7 @@ KnnWs carve_ws(void* ws, int64_t nq, int64_t nt, const Plan& p) {
     const size_t B = (size_t)p.B;
     w.s_tn = (int64_t)p.tiles * kTileT;
     w.s_qn = p.nq_pad;
-    w.s_qsplit = (int64_t)p.nq_pad * kDim * 3;
+    w.s_qsplit = p.q4 ? 0 : (int64_t)p.nq_pad * kDim * 3;   // (q4: the query images exist in fragment order only)
     w.s_tsplit = (int64_t)p.tiles * kTileT * kDim * 3;
     w.s_cand = (int64_t)nq * 2 * p.smax * p.nsub * 3;
     w.bmax = c.take<float>(B * kNormBlocks);
@@ -1982,6 +2388,14 @@ KnnWs carve_ws(void* ws, int64_t nq, int64_t nt, const Plan& p) {
     w.tsplit = c.take<unsigned short>(B * (size_t)w.s_tsplit);
     w.cand_s = c.take<float>(B * (size_t)w.s_cand);
     w.cand_i = c.take<int>(B * (size_t)w.s_cand);
+    w.s_qfrag = p.q4 ? (int64_t)(p.nq_pad / 32) * kTileFragBytes : 0;
+    w.s_tfrag = p.q4 ? (int64_t)p.tiles * kTileFragBytes : 0;
+    w.s_qhm = p.q4 ? (int64_t)(p.nq_pad / 32) * 16 * kFragBytes : 0;
+    w.s_thm = p.q4 ? (int64_t)p.tiles * 16 * kFragBytes : 0;
+    w.qfrag = c.take<unsigned char>(B * (size_t)w.s_qfrag);
+    w.tfrag = c.take<unsigned char>(B * (size_t)w.s_tfrag);
+    w.qhm = c.take<unsigned char>(B * (size_t)w.s_qhm);
+    w.thm = c.take<unsigned char>(B * (size_t)w.s_thm);
     w.bytes = c.used();
     return w;
 }
@@ -2086,23 +2500,20 @@ extern "C" int sfm_selftest_mfma_accumulation(int use_bf16, int trials_per_wave,
     return SFM_OK;
 }
 
-extern "C" int sfm_knn_set_filter(int mode) {
-    SFM_CHECK_ARG(mode >= 0 && mode <= 2, "sfm_knn_set_filter: mode must be 0 (16-bit MFMA, auto), 1 (fp32 MFMA) or 2 (bf16 split pinned)");
-    g_filter_mode = mode == 1 ? 1 : 0;
-    g_force_mode = mode == 2 ? kModeSplit : -1;
-    return SFM_OK;
-}
-
 extern "C" int sfm_debug_set_trace(void* dev_buf) {
     g_trace = static_cast<long long*>(dev_buf);
     return SFM_OK;
 }
 
 namespace {
-size_t knn_ws_bytes(int64_t nq, int64_t nt, int dim, int B) {
-    if (nq < 0 || nt < 0 || dim != kDim || B < 1 || B > kMaxBatch) return 0;
-    if (B > 1 && g_filter_mode == 1) return 0;                 // the fp32-MFMA variant is single-pair
-    const Plan p = make_plan(nq, nt, B);
+constexpr int64_t kMaxTrainRows = 4000000;                     // fragment offsets are 32-bit: 16 KiB per 32 rows in the split images
+
+bool filter_ok(int filter) { return filter >= kFilterAuto && filter <= kFilterLdsSplit; }
+
+size_t knn_ws_bytes(int64_t nq, int64_t nt, int dim, int B, int filter) {
+    if (nq < 0 || nt < 0 || nt > kMaxTrainRows || dim != kDim || B < 1 || B > kMaxBatch || !filter_ok(filter)) return 0;
+    if (B > 1 && filter == kFilterF32) return 0;               // the fp32-MFMA variant is single-pair
+    const Plan p = make_plan(nq, nt, B, filter);
     return carve_ws(nullptr, nq, nt, p).bytes + 256;
 }
 
@@ -2112,13 +2523,14 @@ size_t ratio_ws_bytes(int64_t nq, int B) {
 
 // KNN of B equally shaped pairs in ONE set of launches (prep, filter, refine), optionally fused with the Lowe-ratio
 // survivor count (ratio_counts != null: ratio_stride ints per pair, one per 1024 queries).
-int knn_batch_impl(int B, const BatchPtrs& P, int64_t nq, int64_t ldq, int64_t nt, int64_t ldt, int dim, void* ws, size_t ws_bytes,
+int knn_batch_impl(int B, const BatchPtrs& P, int64_t nq, int64_t ldq, int64_t nt, int64_t ldt, int dim, int filter, void* ws, size_t ws_bytes,
                    void* stream_, double ratio, int* ratio_counts, int ratio_stride) {
     const int ratio_blocks = ratio_counts ? (int)((nq + kRatioBlock - 1) / kRatioBlock) : 0;
     SFM_CHECK_ARG(dim == kDim, "sfm_knn2_l2_f32: dim must be 128 (got %d)", dim);
     SFM_CHECK_ARG(B >= 1 && B <= kMaxBatch, "sfm_match_batch_l2_f32: 1 <= batch <= %d (got %d)", kMaxBatch, B);
-    SFM_CHECK_ARG(nq >= 0 && nt >= 0 && nq < INT_MAX / 256 && nt < INT_MAX / 2, "sfm_knn2_l2_f32: bad sizes nq=%lld nt=%lld",
-                  (long long)nq, (long long)nt);
+    SFM_CHECK_ARG(filter_ok(filter), "sfm_knn2_l2_f32: filter must be 0 (auto), 1 (fp32 MFMA), 2 (bf16 split pinned), 3 / 4 (LDS-ring kernel, auto / split) (got %d)", filter);
+    SFM_CHECK_ARG(nq >= 0 && nt >= 0 && nq < INT_MAX / 256 && nt <= kMaxTrainRows, "sfm_knn2_l2_f32: bad sizes nq=%lld nt=%lld (nt <= %lld)",
+                  (long long)nq, (long long)nt, (long long)kMaxTrainRows);
     if (nq == 0) return SFM_OK;
     for (int b = 0; b < B; ++b) {
         SFM_CHECK_ARG(P.q[b] && P.idx[b] && P.dist[b] && (P.t[b] || nt == 0), "sfm_knn2_l2_f32: null pointer");
@@ -2133,9 +2545,9 @@ int knn_batch_impl(int B, const BatchPtrs& P, int64_t nq, int64_t ldq, int64_t n
         SFM_CHECK_LAUNCH();
         return SFM_OK;
     }
-    SFM_CHECK_ARG(B == 1 || g_filter_mode != 1, "sfm_match_batch_l2_f32: the fp32-MFMA filter variant is single-pair");
-    const Plan p = make_plan(nq, nt, B);
-    const size_t need = knn_ws_bytes(nq, nt, dim, B);
+    SFM_CHECK_ARG(B == 1 || filter != kFilterF32, "sfm_match_batch_l2_f32: the fp32-MFMA filter variant is single-pair");
+    const Plan p = make_plan(nq, nt, B, filter);
+    const size_t need = knn_ws_bytes(nq, nt, dim, B, filter);
     if (!ws || ws_bytes < need) {
         sfm::set_error("sfm_knn2_l2_f32: workspace too small (%zu < %zu)", ws_bytes, need);
         return SFM_ERR_WORKSPACE;
@@ -2150,22 +2562,31 @@ int knn_batch_impl(int B, const BatchPtrs& P, int64_t nq, int64_t ldq, int64_t n
     if (p.split) {
         hipLaunchKernelGGL(knn_prep_kernel, dim3(kNormBlocks + 1, (unsigned)B), dim3(1024), 0, stream, P, ldq, (int)nq, p.nq_pad, ldt, (int)nt,
                            p.tiles * kTileT, w.qsplit, w.qn, w.tsplit, w.tn, w.bmax, w.midflag, w.qerr, w.bmaxerr, w.s_qsplit, w.s_tsplit, w.s_qn, w.s_tn,
+                           p.q4 ? w.qfrag : nullptr, w.tfrag, w.s_qfrag, w.s_tfrag,
                            ratio_counts, ratio_counts ? ratio_stride : 0,
                            p.units, p.tiles, p.G, p.seg_cost, p.n_rb, w.wg_begin, w.rb_first, w.rb_last);
         SFM_CHECK_LAUNCH();
         hipLaunchKernelGGL(knn_split_images_kernel, dim3(kNormBlocks), dim3(kSplitThreads), 0, stream, P, B, ldq, (int)nq, p.nq_pad, ldt, (int)nt,
-                           p.tiles * kTileT, w.qsplit, w.tsplit, w.s_qsplit, w.s_tsplit, w.midflag, w.bmax, g_force_mode);
+                           p.tiles * kTileT, w.qsplit, w.tsplit, w.s_qsplit, w.s_tsplit, w.midflag, w.bmax, p.force_mode,
+                           p.q4 ? w.qhm : nullptr, w.thm, w.s_qhm, w.s_thm);
         SFM_CHECK_LAUNCH();
         sfm::prof_begin(sfm::kProfKnnFilter, stream);
 #define SFM_LAUNCH_SPLIT2(A, WV)                                                                                        \
     hipLaunchKernelGGL((knn_filter_split2_kernel<A, WV>), grid, dim3(64 * WV), kRingLdsBytes + (WV == 4 ? kQScratchBytes : 0), stream, w.qsplit, w.qn,    \
                        (int)nq, p.nq_pad, w.tsplit, (int)nt, p.tiles * kTileT, w.tn, p.tiles, p.units, p.smax, p.nsub,    \
-                       w.midflag, w.bmax, g_force_mode, w.cand_s, w.cand_i, w.wg_begin, w.rb_first, p.n_rb1, B, w.s_qsplit, w.s_tsplit,    \
+                       w.midflag, w.bmax, p.force_mode, w.cand_s, w.cand_i, w.wg_begin, w.rb_first, p.n_rb1, B, w.s_qsplit, w.s_tsplit,    \
                        w.s_qn, w.s_tn, w.s_cand, w.minfo, w.bmaxerr, g_trace)
         // sfm_profile_enable(n > 1): the filter is launched n times back-to-back inside ONE event pair (idempotent: same
         // inputs, same candidate records), so the ~7 us an event pair adds to a single launch is amortised
         for (int rep = 0; rep < prof_reps; ++rep) {
-        if (p.waves == 4) {
+        if (p.q4) {
+#define SFM_LAUNCH_Q4(A)                                                                                                                         \
+    hipLaunchKernelGGL(knn_filter_q4_kernel<A>, grid, dim3(256), 0, stream, w.qfrag, w.tfrag, w.qhm, w.thm, (int)nq, p.nq_pad, p.tiles, p.smax, p.nsub, \
+                       w.midflag, w.bmax, p.force_mode, w.cand_s, w.cand_i, w.wg_begin, w.rb_first, p.n_rb1, B, w.s_qfrag, w.s_tfrag, w.s_qhm,         \
+                       w.s_thm, w.s_cand, w.minfo, w.bmaxerr, g_trace)
+            if (abl == 1) SFM_LAUNCH_Q4(1); else if (abl == 2) SFM_LAUNCH_Q4(2); else if (abl == 3) SFM_LAUNCH_Q4(3); else SFM_LAUNCH_Q4(0);
+#undef SFM_LAUNCH_Q4
+        } else if (p.waves == 4) {
             if (abl == 1) SFM_LAUNCH_SPLIT2(1, 4); else if (abl == 2) SFM_LAUNCH_SPLIT2(2, 4); else if (abl == 4) SFM_LAUNCH_SPLIT2(4, 4);
             else if (abl == 6) SFM_LAUNCH_SPLIT2(6, 4); else if (abl == 7) SFM_LAUNCH_SPLIT2(7, 4); else SFM_LAUNCH_SPLIT2(0, 4);
         } else if (p.waves == 16) {
@@ -2208,7 +2629,7 @@ int knn_batch_impl(int B, const BatchPtrs& P, int64_t nq, int64_t ldq, int64_t n
     }
     sfm::prof_end(sfm::kProfKnnFilter, stream, prof_reps);
     SFM_CHECK_LAUNCH();
-    const int force_mode = !p.split ? kModeF32 : g_force_mode;
+    const int force_mode = !p.split ? kModeF32 : p.force_mode;
     const int64_t refine_wgs = (int64_t)B * ((nq + kRefQ - 1) / kRefQ), refine_grid = refine_wgs >= 64 ? 8 * ((refine_wgs + 7) / 8) : refine_wgs;
     sfm::prof_begin(sfm::kProfKnnRefine, stream);
     hipLaunchKernelGGL(knn_refine_kernel, dim3((unsigned)refine_grid), dim3(256), 0, stream, P, B, ldq, (int)nq, ldt,
@@ -2229,12 +2650,12 @@ BatchPtrs single_pair(const float* q, const float* t, int32_t* idx, float* dist,
 }
 }  // namespace
 
-extern "C" size_t sfm_knn2_l2_f32_ws_bytes(int64_t nq, int64_t nt, int dim) { return knn_ws_bytes(nq, nt, dim, 1); }
+extern "C" size_t sfm_knn2_l2_f32_ws_bytes(int64_t nq, int64_t nt, int dim, int filter) { return knn_ws_bytes(nq, nt, dim, 1, filter); }
 
 extern "C" int sfm_knn2_l2_f32(const float* q, int64_t nq, int64_t ldq, const float* t, int64_t nt, int64_t ldt,
-                               int dim, int32_t* idx, float* dist, int32_t* stats, void* ws, size_t ws_bytes,
+                               int dim, int filter, int32_t* idx, float* dist, int32_t* stats, void* ws, size_t ws_bytes,
                                void* stream_) {
-    return knn_batch_impl(1, single_pair(q, t, idx, dist, stats, nullptr, nullptr, nullptr, nullptr), nq, ldq, nt, ldt, dim, ws, ws_bytes,
+    return knn_batch_impl(1, single_pair(q, t, idx, dist, stats, nullptr, nullptr, nullptr, nullptr), nq, ldq, nt, ldt, dim, filter, ws, ws_bytes,
                           stream_, 0.0, nullptr, 0);
 }
 
@@ -2268,15 +2689,15 @@ extern "C" int sfm_ratio_compact(const int32_t* idx, const float* dist, int64_t 
     return SFM_OK;
 }
 
-extern "C" size_t sfm_match_batch_l2_f32_ws_bytes(int64_t nq, int64_t nt, int dim, int batch) {
-    const size_t k = knn_ws_bytes(nq, nt, dim, batch);
+extern "C" size_t sfm_match_batch_l2_f32_ws_bytes(int64_t nq, int64_t nt, int dim, int batch, int filter) {
+    const size_t k = knn_ws_bytes(nq, nt, dim, batch, filter);
     return k ? k + ratio_ws_bytes(nq, batch) : 0;
 }
 
-extern "C" size_t sfm_match_l2_f32_ws_bytes(int64_t nq, int64_t nt, int dim) { return sfm_match_batch_l2_f32_ws_bytes(nq, nt, dim, 1); }
+extern "C" size_t sfm_match_l2_f32_ws_bytes(int64_t nq, int64_t nt, int dim, int filter) { return sfm_match_batch_l2_f32_ws_bytes(nq, nt, dim, 1, filter); }
 
 namespace {
-int match_batch_impl(int B, const BatchPtrs& P, int64_t nq, int64_t ldq, int64_t nt, int64_t ldt, int dim, double ratio, void* ws,
+int match_batch_impl(int B, const BatchPtrs& P, int64_t nq, int64_t ldq, int64_t nt, int64_t ldt, int dim, int filter, double ratio, void* ws,
                      size_t ws_bytes, void* stream_) {
     SFM_CHECK_ARG(B >= 1 && B <= kMaxBatch, "sfm_match_batch_l2_f32: 1 <= batch <= %d (got %d)", kMaxBatch, B);
     SFM_CHECK_ARG(nq >= 0 && nq < INT_MAX / 256, "sfm_match_l2_f32: bad nq");
@@ -2287,20 +2708,22 @@ int match_batch_impl(int B, const BatchPtrs& P, int64_t nq, int64_t ldq, int64_t
             SFM_CHECK_HIP(hipMemsetAsync(P.out_count[b], 0, sizeof(int32_t), stream));
             if (P.mask[b] && nq > 0) SFM_CHECK_HIP(hipMemsetAsync(P.mask[b], 0, (size_t)nq, stream));
         }
-        return knn_batch_impl(B, P, nq, ldq, nt, ldt, dim, ws, ws_bytes, stream_, 0.0, nullptr, 0);
+        return knn_batch_impl(B, P, nq, ldq, nt, ldt, dim, filter, ws, ws_bytes, stream_, 0.0, nullptr, 0);
     }
     const size_t rbytes = ratio_ws_bytes(nq, B);
-    const size_t need = sfm_match_batch_l2_f32_ws_bytes(nq, nt, dim, B);
+    const size_t need = sfm_match_batch_l2_f32_ws_bytes(nq, nt, dim, B, filter);
     if (!ws || ws_bytes < need || need == 0) {
         SFM_CHECK_ARG(dim == kDim, "sfm_match_l2_f32: dim must be 128 (got %d)", dim);
-        SFM_CHECK_ARG(B == 1 || g_filter_mode != 1, "sfm_match_batch_l2_f32: the fp32-MFMA filter variant is single-pair");
+        SFM_CHECK_ARG(filter_ok(filter), "sfm_match_l2_f32: bad filter variant %d", filter);
+        SFM_CHECK_ARG(nt <= kMaxTrainRows, "sfm_match_l2_f32: nt <= %lld", (long long)kMaxTrainRows);
+        SFM_CHECK_ARG(B == 1 || filter != kFilterF32, "sfm_match_batch_l2_f32: the fp32-MFMA filter variant is single-pair");
         sfm::set_error("sfm_match_l2_f32: workspace too small (%zu < %zu)", ws_bytes, need);
         return SFM_ERR_WORKSPACE;
     }
     int* counts = reinterpret_cast<int*>(sfm::align_up((size_t)(uintptr_t)ws, 256));
     const unsigned blocks = (unsigned)((nq + kRatioBlock - 1) / kRatioBlock);
     const int stride = (int)blocks + 1;
-    const int rc = knn_batch_impl(B, P, nq, ldq, nt, ldt, dim, static_cast<char*>(ws) + rbytes, ws_bytes - rbytes, stream_, ratio, counts, stride);
+    const int rc = knn_batch_impl(B, P, nq, ldq, nt, ldt, dim, filter, static_cast<char*>(ws) + rbytes, ws_bytes - rbytes, stream_, ratio, counts, stride);
     if (rc != SFM_OK) return rc;
     hipLaunchKernelGGL(ratio_scatter_batch_kernel, dim3(blocks, (unsigned)B), dim3(256), 0, stream, P, (int)nq, ratio, counts, stride);
     SFM_CHECK_LAUNCH();
@@ -2308,19 +2731,19 @@ int match_batch_impl(int B, const BatchPtrs& P, int64_t nq, int64_t ldq, int64_t
 }
 }  // namespace
 
-extern "C" int sfm_match_l2_f32(const float* q, int64_t nq, int64_t ldq, const float* t, int64_t nt, int64_t ldt, int dim,
+extern "C" int sfm_match_l2_f32(const float* q, int64_t nq, int64_t ldq, const float* t, int64_t nt, int64_t ldt, int dim, int filter,
                                 double ratio, int32_t* idx, float* dist, int32_t* out_q, int32_t* out_t,
                                 int32_t* out_count, uint8_t* mask, int32_t* stats, void* ws, size_t ws_bytes,
                                 void* stream_) {
     SFM_CHECK_ARG(out_count && (nq == 0 || (out_q && out_t)), "sfm_match_l2_f32: null pointer");
-    return match_batch_impl(1, single_pair(q, t, idx, dist, stats, out_q, out_t, out_count, mask), nq, ldq, nt, ldt, dim, ratio, ws, ws_bytes, stream_);
+    return match_batch_impl(1, single_pair(q, t, idx, dist, stats, out_q, out_t, out_count, mask), nq, ldq, nt, ldt, dim, filter, ratio, ws, ws_bytes, stream_);
 }
 
 // `batch` (<= 8) image pairs of one shape in ONE set of launches: the unit space of the filter is batch x row blocks x
 // tiles under a single partition, so a workgroup's prologue, the launch ramp and the kernel boundaries are paid once
 // per batch instead of once per pair.  Pointer arrays are HOST arrays of device pointers (mask / stats entries may be NULL).
 extern "C" int sfm_match_batch_l2_f32(int batch, const float* const* q, int64_t nq, int64_t ldq, const float* const* t, int64_t nt,
-                                      int64_t ldt, int dim, double ratio, int32_t* const* idx, float* const* dist,
+                                      int64_t ldt, int dim, int filter, double ratio, int32_t* const* idx, float* const* dist,
                                       int32_t* const* out_q, int32_t* const* out_t, int32_t* const* out_count, uint8_t* const* mask,
                                       int32_t* const* stats, void* ws, size_t ws_bytes, void* stream_) {
     SFM_CHECK_ARG(batch >= 1 && batch <= kMaxBatch, "sfm_match_batch_l2_f32: 1 <= batch <= %d (got %d)", kMaxBatch, batch);
@@ -2332,7 +2755,7 @@ extern "C" int sfm_match_batch_l2_f32(int batch, const float* const* q, int64_t 
         P.mask[b] = mask ? mask[b] : nullptr;
         P.stats[b] = stats ? stats[b] : nullptr;
     }
-    return match_batch_impl(batch, P, nq, ldq, nt, ldt, dim, ratio, ws, ws_bytes, stream_);
+    return match_batch_impl(batch, P, nq, ldq, nt, ldt, dim, filter, ratio, ws, ws_bytes, stream_);
 }
 
 extern "C" int sfm_gather_matches(const float* kp0, const float* kp1, const int32_t* out_q, const int32_t* out_t,

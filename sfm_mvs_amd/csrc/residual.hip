@@ -189,15 +189,45 @@ __global__ __launch_bounds__(256) void residual_kernel(
     }
 }
 
-// Sums the per-block partial rows in block order (deterministic) and scatters into the outputs.
-__global__ void final_reduce_kernel(const double* __restrict__ partials, int nblocks, int with_jac,
-                                    double* __restrict__ sumsq, double* __restrict__ JtJ_cam, double* __restrict__ Jtr_cam,
-                                    double* __restrict__ res2) {
+// Folds partial rows (one per residual workgroup, kNAcc doubles each) in a FIXED two-level shape — the result depends on
+// the row count only, never on timing.  1024 threads = 32 groups x 32 entry lanes: group g adds rows g, g + 32, g + 64 ...
+// of its workgroup's chunk in ascending order (a group reads one whole 232-byte row per step: coalesced, and the loads of
+// a group's next rows do not depend on its running sums), then the 32 group sums of an entry are added pairwise
+// (stride 16, 8, 4, 2, 1).  Round 2 walked all rows with one thread per entry: 167 us at 782 rows (200k points), 33 %
+// of a 500-call trace whose residual kernel takes 5 us; this is one 1024-thread workgroup for <= kReduceChunk rows
+// (25 dependent adds per thread at 782 rows) and a first level of ceil(rows / kReduceChunk) workgroups above that.
+constexpr int kReduceChunk = 2048;   // rows folded by one workgroup
+
+__device__ __forceinline__ double fold_rows(const double* __restrict__ rows, int nrows, double (*lds)[32]) {
+    const int k = threadIdx.x & 31, g = threadIdx.x >> 5;
+    double s = 0;
+    if (k < kNAcc)
+        for (int r = g; r < nrows; r += 32) s += rows[(int64_t)r * kNAcc + k];
+    lds[g][k] = s;
+    __syncthreads();
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) {
+        if (g < m) lds[g][k] = lds[g][k] + lds[g + m][k];
+        __syncthreads();
+    }
+    return lds[0][k];
+}
+
+__global__ __launch_bounds__(1024) void reduce_rows_kernel(const double* __restrict__ partials, int nrows, double* __restrict__ out_rows) {
+    __shared__ double lds[32][32];
+    const int r0 = blockIdx.x * kReduceChunk;
+    const double s = fold_rows(partials + (int64_t)r0 * kNAcc, min(kReduceChunk, nrows - r0), lds);
+    if (threadIdx.x < kNAcc) out_rows[(int64_t)blockIdx.x * kNAcc + threadIdx.x] = s;
+}
+
+__global__ __launch_bounds__(1024) void final_reduce_kernel(const double* __restrict__ partials, int nblocks, int with_jac,
+                                                            double* __restrict__ sumsq, double* __restrict__ JtJ_cam, double* __restrict__ Jtr_cam,
+                                                            double* __restrict__ res2) {
+    __shared__ double lds[32][32];
+    const double s = fold_rows(partials, nblocks, lds);
     const int k = threadIdx.x;
     if (k >= kNAcc) return;
     if (!with_jac && k != 27) return;
-    double s = 0;
-    for (int b = 0; b < nblocks; ++b) s += partials[(int64_t)b * kNAcc + k];
     if (k == 28) {
         if (res2) *res2 += s;
     } else if (k == 27) {
@@ -273,8 +303,9 @@ extern "C" size_t sfm_project_residual_ws_bytes(int64_t nobs, int64_t ncam, int6
     (void)npt;
     if (nobs < 0 || ncam < 0) return 0;
     const size_t blocks = (size_t)((nobs + 255) / 256);
+    const size_t level1 = (blocks + kReduceChunk - 1) / kReduceChunk;
     return sfm::align_up((size_t)ncam * kCamStride * sizeof(double), 256) +
-           sfm::align_up((blocks + 1) * kNAcc * sizeof(double), 256) + 512;
+           sfm::align_up((blocks + 1 + level1) * kNAcc * sizeof(double), 256) + 512;
 }
 
 extern "C" int sfm_project_residual(const double* cams, int64_t ncam, const double* K_host, const float* X, int64_t npt,
@@ -287,6 +318,7 @@ extern "C" int sfm_project_residual(const double* cams, int64_t ncam, const doub
     if (nobs == 0) return SFM_OK;
     SFM_CHECK_ARG(X && obs, "sfm_project_residual: null X/obs");
     SFM_CHECK_ARG(pt_idx || nobs <= npt, "sfm_project_residual: pt_idx NULL requires nobs <= npt");
+    SFM_CHECK_ARG(nobs <= (int64_t)256 * kReduceChunk * kReduceChunk, "sfm_project_residual: more than 2^30 observations per call");
     const size_t need = sfm_project_residual_ws_bytes(nobs, ncam, npt);
     if (!ws || ws_bytes < need) {
         sfm::set_error("sfm_project_residual: workspace too small (%zu < %zu)", ws_bytes, need);
@@ -296,7 +328,8 @@ extern "C" int sfm_project_residual(const double* cams, int64_t ncam, const doub
     sfm::Carver c(reinterpret_cast<void*>(sfm::align_up((size_t)(uintptr_t)ws, 256)));
     double* table = c.take<double>((size_t)ncam * kCamStride);
     const int blocks = (int)((nobs + 255) / 256);
-    double* partials = c.take<double>((size_t)(blocks + 1) * kNAcc);
+    const int level1 = (blocks + kReduceChunk - 1) / kReduceChunk;
+    double* partials = c.take<double>((size_t)(blocks + 1 + level1) * kNAcc);
 
     hipLaunchKernelGGL(cam_prepare_kernel, dim3((unsigned)((ncam + 63) / 64)), dim3(64), 0, stream, cams, ncam, table);
     SFM_CHECK_LAUNCH();
@@ -311,7 +344,16 @@ extern "C" int sfm_project_residual(const double* cams, int64_t ncam, const doub
                            nobs, proj, inlier, thr2, single, partials, JtJ_cam, Jtr_cam, JtJ_pt, Jtr_pt);
     SFM_CHECK_LAUNCH();
     if (sumsq || res2 || (jac && single)) {
-        hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(64), 0, stream, partials, blocks, jac ? 1 : 0, sumsq,
+        const double* rows = partials;
+        int nrows = blocks;
+        if (level1 > 1) {                                  // (level1 <= kReduceChunk up to 1e9 observations: checked above)
+            double* rows1 = partials + (size_t)(blocks + 1) * kNAcc;
+            hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)level1), dim3(1024), 0, stream, partials, blocks, rows1);
+            SFM_CHECK_LAUNCH();
+            rows = rows1;
+            nrows = level1;
+        }
+        hipLaunchKernelGGL(final_reduce_kernel, dim3(1), dim3(1024), 0, stream, rows, nrows, jac ? 1 : 0, sumsq,
                            single ? JtJ_cam : nullptr, single ? Jtr_cam : nullptr, res2);
         SFM_CHECK_LAUNCH();
     }

@@ -13,6 +13,17 @@ from ._lib import SfmHipError, check, on_device, ptr, require_cuda, stream_ptr
 
 _ws_cache = {}
 
+# `filter` argument of the KNN entry points (include/sfm_hip.h SFM_KNN_FILTER_*): which candidate filter runs before the
+# exact refine.  Results are bit-identical whichever runs.
+KNN_FILTERS = {"auto": 0, "f32": 1, "split": 2, "lds": 3, "lds_split": 4}
+
+
+def _filter_code(name):
+    try:
+        return KNN_FILTERS[name]
+    except KeyError:
+        raise SfmHipError(f"unknown KNN filter variant {name!r} (one of {sorted(KNN_FILTERS)})") from None
+
 
 def _workspace(device, nbytes):
     """Grow-only scratch buffer per (device, current stream) — the C-ABI never allocates.  Work enqueued on different
@@ -34,12 +45,14 @@ def _f64_host(a, n, what):
     return arr
 
 
-def knn2(des0, des1, return_stats=False):
+def knn2(des0, des1, return_stats=False, filter="auto"):
     """cv2.BFMatcher().knnMatch(des0, des1, k=2) on device (sfm.py:259-260).
 
     des0 [nq,128] / des1 [nt,128] float32 CUDA tensors (rows may be strided).
     Returns idx [nq,2] int32 (trainIdx), dist [nq,2] float32 (DMatch.distance).
+    filter: 'auto' (default) | 'f32' | 'split' | 'lds' | 'lds_split' — see KNN_FILTERS; identical results.
     """
+    fcode = _filter_code(filter)
     require_cuda(des0, des1)
     if des0.dtype != torch.float32 or des1.dtype != torch.float32:
         raise SfmHipError("knn2: descriptors must be float32 (cv2 SIFT descriptors are CV_32F)")
@@ -55,14 +68,14 @@ def knn2(des0, des1, return_stats=False):
     idx = torch.empty((nq, 2), dtype=torch.int32, device=des0.device)
     dist = torch.empty((nq, 2), dtype=torch.float32, device=des0.device)
     stats = torch.zeros(4, dtype=torch.int32, device=des0.device) if return_stats else None
-    need = lib.sfm_knn2_l2_f32_ws_bytes(nq, nt, dim)
+    need = lib.sfm_knn2_l2_f32_ws_bytes(nq, nt, dim, fcode)
     if need == 0 and nq > 0:
         raise SfmHipError(f"knn2: unsupported shape nq={nq} nt={nt} dim={dim} (dim must be 128)")
     ws = _workspace(des0.device, need)
     ldq = des0.stride(0) if nq > 1 else dim
     ldt = des1.stride(0) if nt > 1 else dim
     with on_device(des0.device):
-        check(lib.sfm_knn2_l2_f32(ptr(des0), nq, ldq, ptr(des1), nt, ldt, dim, ptr(idx), ptr(dist), ptr(stats),
+        check(lib.sfm_knn2_l2_f32(ptr(des0), nq, ldq, ptr(des1), nt, ldt, dim, fcode, ptr(idx), ptr(dist), ptr(stats),
                                   ptr(ws), ws.numel(), stream_ptr()), "sfm_knn2_l2_f32")
     return (idx, dist, stats) if return_stats else (idx, dist)
 
@@ -123,7 +136,7 @@ def common_points(pts1, pts2):
     return idx1[:m], idx2[:m], keep2[:n2].bool()
 
 
-def match_pair(des0, des1, ratio=0.70):
+def match_pair(des0, des1, ratio=0.70, filter="auto"):
     """KNN + ratio for one image pair; returns (query_idx, train_idx, dist1) trimmed to the survivors.
 
     One host sync (reading the survivor count) — this is the find_features() boundary.
@@ -133,7 +146,7 @@ def match_pair(des0, des1, ratio=0.70):
         raise SfmHipError("match_pair: descriptors must be [n,128]")
     if des0.dtype != torch.float32 or des1.dtype != torch.float32:
         raise SfmHipError("match_pair: descriptors must be float32 (cv2 SIFT output)")
-    pm = PairMatcher(des0.shape[0], des1.shape[0], des0.device, ratio)
+    pm = PairMatcher(des0.shape[0], des1.shape[0], des0.device, ratio, filter=filter)
     idx, dist, out_q, out_t, count = pm.run(des0 if des0.stride(1) == 1 else des0.contiguous(),
                                             des1 if des1.stride(1) == 1 else des1.contiguous())
     m = int(count.item())
@@ -399,11 +412,12 @@ class PairMatcher:
     once, so a call enqueues kernels only (no allocator traffic, no host sync).  This is the object the
     pair-sharded matcher and bench.py drive."""
 
-    def __init__(self, nq, nt, device, ratio=0.70, dim=128):
+    def __init__(self, nq, nt, device, ratio=0.70, dim=128, filter="auto"):
         self.nq, self.nt, self.dim, self.ratio = int(nq), int(nt), int(dim), float(ratio)
         self.device = torch.device(device)
+        self.filter = _filter_code(filter)
         lib = _lib.lib()
-        need = lib.sfm_match_l2_f32_ws_bytes(self.nq, self.nt, self.dim)
+        need = lib.sfm_match_l2_f32_ws_bytes(self.nq, self.nt, self.dim, self.filter)
         if need == 0 and self.nq > 0:
             raise SfmHipError(f"PairMatcher: unsupported shape nq={nq} nt={nt} dim={dim}")
         self.ws = torch.empty(max(need, 256), dtype=torch.uint8, device=self.device)
@@ -430,10 +444,11 @@ class PairMatcher:
             idx, dist = result[0], result[1].view(torch.float32)
         if des0.dtype != torch.float32 or des1.dtype != torch.float32 or des0.stride(1) != 1 or des1.stride(1) != 1:
             raise SfmHipError("PairMatcher.run: float32 row-major descriptors required")
-        check(_lib.lib().sfm_match_l2_f32(ptr(des0), self.nq, des0.stride(0), ptr(des1), self.nt, des1.stride(0), self.dim,
-                                          self.ratio, ptr(idx), ptr(dist), ptr(self.out_q), ptr(self.out_t),
-                                          ptr(self.count), None, ptr(self.stats), ptr(self.ws), self.ws.numel(), stream_ptr()),
-              "sfm_match_l2_f32")
+        with on_device(self.device):
+            check(_lib.lib().sfm_match_l2_f32(ptr(des0), self.nq, des0.stride(0), ptr(des1), self.nt, des1.stride(0), self.dim, self.filter,
+                                              self.ratio, ptr(idx), ptr(dist), ptr(self.out_q), ptr(self.out_t),
+                                              ptr(self.count), None, ptr(self.stats), ptr(self.ws), self.ws.numel(), stream_ptr()),
+                  "sfm_match_l2_f32")
         return idx, dist, self.out_q, self.out_t, self.count
 
 
@@ -443,11 +458,12 @@ class BatchMatcher:
     times the work, and there are `batch` times fewer kernel boundaries.  Outputs and workspace are allocated once.
     Results of pair b: idx[b] [nq,2] int32, dist[b] [nq,2] float32, out_q[b], out_t[b] [nq] int32, count[b] [1] int32."""
 
-    def __init__(self, nq, nt, device, ratio=0.70, batch=4, dim=128):
+    def __init__(self, nq, nt, device, ratio=0.70, batch=4, dim=128, filter="auto"):
         self.nq, self.nt, self.dim, self.ratio, self.batch = int(nq), int(nt), int(dim), float(ratio), int(batch)
         self.device = torch.device(device)
+        self.filter = _filter_code(filter)
         lib = _lib.lib()
-        need = lib.sfm_match_batch_l2_f32_ws_bytes(self.nq, self.nt, self.dim, self.batch)
+        need = lib.sfm_match_batch_l2_f32_ws_bytes(self.nq, self.nt, self.dim, self.batch, self.filter)
         if need == 0 and self.nq > 0:
             raise SfmHipError(f"BatchMatcher: unsupported configuration nq={nq} nt={nt} dim={dim} batch={batch}")
         self.ws = torch.empty(max(need, 256), dtype=torch.uint8, device=self.device)
@@ -484,6 +500,8 @@ class BatchMatcher:
         t = self._arr([p[1].data_ptr() for p in pairs])
         idx, dist = self._own
         if results is not None:
+            if len(results) != n:                          # (a short pointer array would be read past its end by the library)
+                raise SfmHipError(f"BatchMatcher.run: {n} pairs but {len(results)} result blocks")
             for r in results:
                 require_cuda(r)
                 if tuple(r.shape) != (2, self.nq, 2) or r.dtype != torch.int32 or not r.is_contiguous():
@@ -491,9 +509,10 @@ class BatchMatcher:
             idx = self._arr([r[0].data_ptr() for r in results])
             dist = self._arr([r[1].data_ptr() for r in results])
         f = self._fixed
-        check(_lib.lib().sfm_match_batch_l2_f32(n, q, self.nq, pairs[0][0].stride(0), t, self.nt, pairs[0][1].stride(0), self.dim,
-                                                self.ratio, idx, dist, f["out_q"], f["out_t"], f["count"], None, f["stats"],
-                                                ptr(self.ws), self.ws.numel(), stream_ptr()), "sfm_match_batch_l2_f32")
+        with on_device(self.device):
+            check(_lib.lib().sfm_match_batch_l2_f32(n, q, self.nq, pairs[0][0].stride(0), t, self.nt, pairs[0][1].stride(0), self.dim, self.filter,
+                                                    self.ratio, idx, dist, f["out_q"], f["out_t"], f["count"], None, f["stats"],
+                                                    ptr(self.ws), self.ws.numel(), stream_ptr()), "sfm_match_batch_l2_f32")
         return n
 
 
@@ -504,9 +523,9 @@ class PairPipeline:
     they overlap the neighbouring pairs' filter kernels (measured at 10k x 10k: 0.072 -> 0.052 ms per pair at depth 3).
     Results of submit() number i live in slot i % depth until submit() number i + depth reuses it."""
 
-    def __init__(self, nq, nt, device, ratio=0.70, depth=3):
+    def __init__(self, nq, nt, device, ratio=0.70, depth=3, filter="auto"):
         self.depth = int(depth)
-        self.matchers = [PairMatcher(nq, nt, device, ratio) for _ in range(self.depth)]
+        self.matchers = [PairMatcher(nq, nt, device, ratio, filter=filter) for _ in range(self.depth)]
         self.streams = [torch.cuda.Stream(device=device) for _ in range(self.depth)]
         self.n = 0
 
@@ -537,9 +556,9 @@ class BatchPipeline:
     submit() queues a pair; the batch is launched on the next stream when it is full (or on flush()).  Results of launch
     set i live in matcher i % depth until launch set i + depth reuses it — or in the caller's `result` blocks."""
 
-    def __init__(self, nq, nt, device, ratio=0.70, depth=3, batch=4):
+    def __init__(self, nq, nt, device, ratio=0.70, depth=3, batch=4, filter="auto"):
         self.depth, self.batch = int(depth), int(batch)
-        self.matchers = [BatchMatcher(nq, nt, device, ratio, batch) for _ in range(self.depth)]
+        self.matchers = [BatchMatcher(nq, nt, device, ratio, batch, filter=filter) for _ in range(self.depth)]
         self.streams = [torch.cuda.Stream(device=device) for _ in range(self.depth)]
         self.n = 0
         self._pairs, self._results, self._after = [], [], []
@@ -550,6 +569,8 @@ class BatchPipeline:
         False -> no wait.  `result`: optional int32 [2][nq][2] block for this pair's (trainIdx, distance bits) — either every
         pair of a batch has one or none has.  Returns the launch record (slot, stream, matcher, pairs) when this pair
         completed a batch, else None."""
+        if self._pairs and (result is not None) != bool(self._results):
+            raise SfmHipError("BatchPipeline.submit: either every pair of a batch has a result block or none has")
         self._pairs.append((des0, des1))
         if result is not None:
             self._results.append(result)
@@ -578,13 +599,6 @@ class BatchPipeline:
     def synchronize(self):
         for st in self.streams:
             st.synchronize()
-
-
-def set_knn_filter(mode):
-    """'auto' (16-bit MFMA filter, fp16 single product or bf16 split chosen on the device; default), 'f32'
-    (fp32 MFMA filter) or 'split' (bf16 split pinned); identical results."""
-    check(_lib.lib().sfm_knn_set_filter({"auto": 0, "f32": 1, "split": 2}[mode]), "sfm_knn_set_filter")
-    _ws_cache.clear()
 
 
 def selftest_mfma_accumulation(bf16=False, trials_per_wave=50, device="cuda"):

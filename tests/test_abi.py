@@ -34,14 +34,18 @@ def test_library_exports_every_declared_symbol():
 def test_binding_table_matches_header():
     from sfm_mvs_amd import _lib
     assert sorted(_lib.SIGNATURES) == declared_symbols()
-    assert _lib.lib().sfm_abi_version() == 1
+    assert _lib.lib().sfm_abi_version() == 2          # ABI 2: the KNN filter variant is a per-call argument
 
 
 def test_ws_bytes_twins():
     from sfm_mvs_amd import _lib
     L = _lib.lib()
-    assert L.sfm_knn2_l2_f32_ws_bytes(10000, 10000, 128) > 10000 * 24
-    assert L.sfm_knn2_l2_f32_ws_bytes(10, 10, 64) == 0          # dim != 128 unsupported
+    assert L.sfm_knn2_l2_f32_ws_bytes(10000, 10000, 128, 0) > 10000 * 24
+    assert L.sfm_knn2_l2_f32_ws_bytes(10, 10, 64, 0) == 0          # dim != 128 unsupported
+    assert L.sfm_knn2_l2_f32_ws_bytes(10, 10, 128, 9) == 0         # unknown filter variant
+    assert L.sfm_match_batch_l2_f32_ws_bytes(100, 100, 128, 4, 1) == 0   # the fp32-MFMA variant is single-pair
+    for f in range(5):
+        assert L.sfm_match_l2_f32_ws_bytes(1000, 1000, 128, f) > 0
     assert L.sfm_project_residual_ws_bytes(1000, 1, 1000) > 0
     assert L.sfm_ba_dense_sweep_ws_bytes(500, 200000) > 0
 
@@ -49,7 +53,7 @@ def test_ws_bytes_twins():
 def test_argument_errors_are_reported_without_a_gpu():
     from sfm_mvs_amd import _lib
     L = _lib.lib()
-    rc = L.sfm_knn2_l2_f32(None, 4, 128, None, 4, 128, 64, None, None, None, None, 0, None)
+    rc = L.sfm_knn2_l2_f32(None, 4, 128, None, 4, 128, 64, 0, None, None, None, None, 0, None)
     assert rc == -1 and b"dim must be 128" in L.sfm_last_error()
     rc = L.sfm_triangulate_dlt(None, None, None, None, 4, 1, 4, 5, 0, None, None)
     assert rc == -1 and b"rows must be 4 or 6" in L.sfm_last_error()

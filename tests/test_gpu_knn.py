@@ -9,8 +9,8 @@ from datagen import planted_pair, sift_like
 pytestmark = pytest.mark.gpu
 
 
-def run(hip, q, t, stats=False):
-    out = hip.knn2(torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda(), return_stats=stats)
+def run(hip, q, t, stats=False, filter="auto"):
+    out = hip.knn2(torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda(), return_stats=stats, filter=filter)
     torch.cuda.synchronize()
     return tuple(o.cpu().numpy() for o in out)
 
@@ -187,15 +187,12 @@ def _mode_cases():
 def test_filter_modes_all_agree_with_oracle(hip, oracle, name):
     q, t, expect_mode = _mode_cases()[name]
     want = oracle.knn2(q, t, nthreads=8)
-    try:
-        for variant, mode in (("auto", expect_mode), ("split", 2), ("f32", 3)):
-            hip.set_knn_filter(variant)
-            gi, gd, stats = run(hip, q, t, stats=True)
-            assert stats[3] == mode, f"{name}/{variant}: filter mode {stats[3]}, expected {mode}"
-            assert_bit_equal((gi, gd), want)
-            assert stats[0] < len(q) // 4, f"{name}/{variant}: {stats[0]} of {len(q)} queries fell back"
-    finally:
-        hip.set_knn_filter("auto")
+    # the filter variant is a per-call argument (ABI 2): q4 kernel auto / split, fp32 MFMA, and round 2's LDS-ring kernel
+    for variant, mode in (("auto", expect_mode), ("split", 2), ("f32", 3), ("lds", expect_mode), ("lds_split", 2)):
+        gi, gd, stats = run(hip, q, t, stats=True, filter=variant)
+        assert stats[3] == mode, f"{name}/{variant}: filter mode {stats[3]}, expected {mode}"
+        assert_bit_equal((gi, gd), want)
+        assert stats[0] < len(q) // 4, f"{name}/{variant}: {stats[0]} of {len(q)} queries fell back"
 
 
 def test_fp16_mode_near_ties_and_duplicates(hip, oracle):
