@@ -35,3 +35,5 @@ for rep in range(3):
           f"last loop end -> WG end med {np.median(en - loop_done):.2f} us | kernel = {en.max():.1f} us, first WG start spread {st.max():.1f} us")
     cyc = (b[:, 3] - b[:, 2])
     print(f"   shader cycles per WG med {np.median(cyc):.0f}  (x{G} WGs / 100160 unit tile-steps = {np.median(cyc) * G / (B * 40 * 313):.0f} cycles per tile-step incl. everything)")
+    print("   WG start percentiles (us): " + " ".join(f"p{p}={np.percentile(st, p):.1f}" for p in (10, 25, 50, 75, 90, 99, 100)) +
+          " | by XCD median: " + " ".join(f"{np.median(st[xcc == x]):.1f}" for x in range(8)))

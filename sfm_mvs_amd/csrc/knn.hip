@@ -204,7 +204,7 @@ Plan make_plan_uncached(int64_t nq, int64_t nt, int B, int filter) {
     static const int env_w = [] { const char* e = getenv("SFM_KNN_WAVES"); return e ? atoi(e) : 0; }();   // dev override
     p.waves = (env_w == 4 || env_w == 8 || env_w == 16) ? env_w : 8;
     p.split = filter == kFilterF32 ? 0 : 1;
-    p.q4 = (filter == kFilterAuto || filter == kFilterSplit) ? 1 : 0;
+    p.q4 = (filter == kFilterLds || filter == kFilterLdsSplit || filter == kFilterF32) ? 0 : 1;
     p.force_mode = (filter == kFilterSplit || filter == kFilterLdsSplit) ? 2 /*kModeSplit*/ : -1;
     p.qg = p.q4 ? 4 : p.split ? 2 : 1;
     if (p.q4) p.waves = 4;                     // one 4-wave workgroup per CU: one wave per SIMD, 512 registers each
@@ -584,7 +584,7 @@ __device__ __forceinline__ int knn_filter_mode(const int* __restrict__ flags, co
 // The arithmetic mode of a BATCH of pairs (one launch, one body): the most general mode any of its pairs needs — the
 // modes are nested (fp16-exact data are fp16-representable data are split-representable data), and the refine kernel
 // prices its slack with the same batch mode, so every pair is certified against the arithmetic that actually ran.
-constexpr int kMinfoPairMode = 0, kMinfoBatchMode = kMaxBatch, kMinfoTmax = 16, kMinfoTerr = 24, kMinfoWords = 32;   // written by filter block 0
+constexpr int kMinfoPairMode = 0, kMinfoBatchMode = kMaxBatch, kMinfoTmax = 16, kMinfoTerr = 24, kMinfoWords = 32;   // written by knn_split_images_kernel (block 0)
 __device__ __forceinline__ int knn_batch_mode(const int* __restrict__ flags, const float* __restrict__ bmax, int n_pairs, int lane) {
     int mode = kModeHalfExact;
     for (int b = 0; b < n_pairs; ++b) mode = max(mode, knn_filter_mode(flags + b * kNormBlocks, bmax + b * kNormBlocks, lane));
@@ -650,56 +650,82 @@ __global__ __launch_bounds__(1024) void knn_prep_kernel(BatchPtrs P, int64_t ldq
     if (frag) { qfrag += pb * s_qfrag; tfrag += pb * s_tfrag; }
     const int nblk = gridDim.x - 1;
     __shared__ int wmid[16];
-    const int l = threadIdx.x & 31;
+    // SIXTEEN lanes per row, one 16-byte chunk (8 elements) each: a lane reads 32 contiguous bytes of its row (a wave = 4
+    // rows x 512 B) and its eight fp16 values ARE one chunk of the images — row-major: 16 B at row * 256 + 16 c; fragment
+    // order: 16 B at fragment c >> 1, lane 32 (c & 1) + row % 32 of the row's tile, so the four adjacent rows of a wave
+    // store 64 contiguous bytes per chunk.  No transposition pass (through LDS, between two barriers, it cost 7 us of a
+    // 46 us launch), no shared memory in the loop.
+    const int c = threadIdx.x & 15;
     float mx = 0.f, mxe = 0.f;
     unsigned flags = 0;
     const int rows = nq_pad + nt_pad;
-    for (int row = blockIdx.x * 32 + (threadIdx.x >> 5); row < rows; row += nblk * 32) {   // 32 rows in flight per block
+    // A workgroup takes 64 consecutive rows per trip; the rows of up to kPrepAhead trips are requested before the first is
+    // worked on (the body is a dependent chain and a workgroup has only 1-2 trips).
+    constexpr int kPrepAhead = 2;
+    const int row0 = blockIdx.x * 64 + (threadIdx.x >> 4), rstep = nblk * 64;
+    for (int rbase = row0; rbase < rows; rbase += kPrepAhead * rstep) {
+    float4 vin[kPrepAhead][2];
+#pragma unroll
+    for (int k = 0; k < kPrepAhead; ++k) {
+        const int row = rbase + k * rstep;
+        const bool isq = row < nq_pad;
+        const int r = isq ? row : row - nq_pad;
+        vin[k][0] = vin[k][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < rows && r < (isq ? nq : nt)) {
+            const float* src = (isq ? Q + (int64_t)r * ldq : T + (int64_t)r * ldt) + 8 * c;
+            vin[k][0] = *reinterpret_cast<const float4*>(src);
+            vin[k][1] = *reinterpret_cast<const float4*>(src + 4);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kPrepAhead; ++k) {
+        const int row = rbase + k * rstep;
+        if (row >= rows) break;
         const bool isq = row < nq_pad;
         const int r = isq ? row : row - nq_pad;
         const int n = isq ? nq : nt, npad = isq ? nq_pad : nt_pad;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < n) v = *reinterpret_cast<const float4*>((isq ? Q + (int64_t)r * ldq : T + (int64_t)r * ldt) + 4 * l);
-        float s = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-        s += lane_xor<16>(s); s += lane_xor<8>(s); s += lane_xor<4>(s); s += lane_xor<2>(s); s += lane_xor<1>(s);   // (32 lanes per row)
+        const float in[8] = {vin[k][0].x, vin[k][0].y, vin[k][0].z, vin[k][0].w, vin[k][1].x, vin[k][1].y, vin[k][1].z, vin[k][1].w};
+        // ||row||^2: the lane's eight squares as a balanced tree, then the 16 lanes of the row by xor 8, 4, 2, 1 — a fixed
+        // shape 8 roundings deep (square, 3 + 4 adds): the refine kernel's certificate allows 9 for this norm (kEps*)
+        float s = ((in[0] * in[0] + in[1] * in[1]) + (in[2] * in[2] + in[3] * in[3])) + ((in[4] * in[4] + in[5] * in[5]) + (in[6] * in[6] + in[7] * in[7]));
+        s += lane_xor<8>(s); s += lane_xor<4>(s); s += lane_xor<2>(s); s += lane_xor<1>(s);
         const float sc = isq ? -2.f : 1.f;
-        const float e[4] = {sc * v.x, sc * v.y, sc * v.z, sc * v.w};
-        unsigned fb[4];
+        unsigned fb[8];
         float err2 = 0.f;                                                // ||fp16(row) - row||^2: the certificate's operand-rounding term
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float ae = fabsf(e[k]);
-            const _Float16 hv = (_Float16)e[k];                          // round to nearest even
-            fb[k] = (unsigned)__builtin_bit_cast(unsigned short, hv);
+        for (int e = 0; e < 8; ++e) {
+            const float ev = sc * in[e], ae = fabsf(ev);
+            const _Float16 hv = (_Float16)ev;                            // round to nearest even
+            fb[e] = (unsigned)__builtin_bit_cast(unsigned short, hv);
             if (!(ae <= 60000.f)) flags |= kFlagRangeBad;                // also catches NaN / inf
-            if ((float)hv != e[k] || (ae != 0.f && ae < 6.103515625e-5f)) flags |= kFlagHalfInexact;
+            if ((float)hv != ev || (ae != 0.f && ae < 6.103515625e-5f)) flags |= kFlagHalfInexact;
             // below fp16's normal range the matrix pipe may flush the operand to zero: the whole element is the error then
             // (|e - hv| <= |e| holds for the rounded subnormal too, so this bounds both behaviours)
-            const float dv = ae < 6.103515625e-5f ? e[k] : e[k] - (float)hv;
+            const float dv = ae < 6.103515625e-5f ? ev : ev - (float)hv;
             err2 = fmaf(dv, dv, err2);
         }
-        err2 += lane_xor<16>(err2); err2 += lane_xor<8>(err2); err2 += lane_xor<4>(err2); err2 += lane_xor<2>(err2); err2 += lane_xor<1>(err2);
+        err2 += lane_xor<8>(err2); err2 += lane_xor<4>(err2); err2 += lane_xor<2>(err2); err2 += lane_xor<1>(err2);
         if (!(err2 < kInf)) err2 = 0.f;                                  // (out-of-range data: the split arithmetic runs, this term is unused)
-        unsigned short* img = isq ? qsplit : tsplit;
-        const uint2 packed = make_uint2(fb[0] | (fb[1] << 16), fb[2] | (fb[3] << 16));
-        if (!frag || !isq) *reinterpret_cast<uint2*>(img + (2 * (int64_t)npad + r) * kDim + 4 * l) = packed;   // (row-major fp16 T: the refine kernel's screens)
-        const float nrm = (isq || r < n) ? s : kInf;                  // padded train rows can never be candidates
+        const uint4 packed = make_uint4(fb[0] | (fb[1] << 16), fb[2] | (fb[3] << 16), fb[4] | (fb[5] << 16), fb[6] | (fb[7] << 16));
+        const float nrm = (isq || r < n) ? s : kInf;                     // padded train rows can never be candidates
         if (frag) {
-            // the same row in FRAGMENT ORDER (knn_filter_q4_kernel): [32-row tile][9 fragments][64 lanes][16 B]; fragment f < 8 is
-            // k-step f of v_mfma_f32_32x32x16_f16 (lane 32 h + j holds elements 16 f + 8 h .. + 7 of row j of the tile), fragment 8
-            // is the accumulator-init operand (frag_init_operand)
+            // FRAGMENT ORDER (knn_filter_q4_kernel): [32-row tile][9 fragments][64 lanes][16 B]; fragment f < 8 is k-step f of
+            // v_mfma_f32_32x32x16_f16 (lane 32 h + j holds elements 16 f + 8 h .. + 7 of row j of the tile: chunk c = 2 f + h),
+            // fragment 8 the accumulator-init operand (frag_init_operand; zeros for the h = 1 lanes)
             unsigned char* fimg = (isq ? qfrag : tfrag) + ((int64_t)(r >> 5) * kTileFrags) * kFragBytes;
-            const int c = l >> 1;                                      // 16-byte chunk of the row
-            *reinterpret_cast<uint2*>(fimg + (((c >> 1) * 64 + (c & 1) * 32 + (r & 31)) << 4) + ((l & 1) << 3)) = packed;
-            if (l < 2) *reinterpret_cast<uint4*>(fimg + ((8 * 64 + l * 32 + (r & 31)) << 4)) = l == 0 ? frag_init_operand(nrm, isq) : make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4*>(fimg + (((c >> 1) * 64 + (c & 1) * 32 + (r & 31)) << 4)) = packed;
+            if (c < 2) *reinterpret_cast<uint4*>(fimg + ((8 * 64 + c * 32 + (r & 31)) << 4)) = c == 0 ? frag_init_operand(nrm, isq) : make_uint4(0u, 0u, 0u, 0u);
+        } else {
+            *reinterpret_cast<uint4*>((isq ? qsplit : tsplit) + (2 * (int64_t)npad + r) * kDim + 8 * c) = packed;   // row-major fp16 plane (LDS-ring filter, its refine screens)
         }
-        if (l == 0) (isq ? qn : tn)[r] = nrm;
+        if (c == 0) (isq ? qn : tn)[r] = nrm;
         if (isq) {
-            if (l == 0) qerr[r] = err2;
+            if (c == 0) qerr[r] = err2;
         } else {
             mx = fmaxf(mx, s);
             mxe = fmaxf(mxe, err2);
         }
+    }
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
@@ -743,8 +769,38 @@ __global__ __launch_bounds__(kSplitThreads) void knn_split_images_kernel(BatchPt
                                                                         unsigned short* __restrict__ tsplit0, int64_t s_qsplit, int64_t s_tsplit,
                                                                         const int* __restrict__ midflag, const float* __restrict__ bmax,
                                                                         int force_mode, unsigned char* __restrict__ qhm0 /*null: row-major planes*/,
-                                                                        unsigned char* __restrict__ thm0, int64_t s_qhm, int64_t s_thm) {
-    const int mode = force_mode >= 0 ? force_mode : knn_batch_mode(midflag, bmax, B, (int)(threadIdx.x & 63));
+                                                                        unsigned char* __restrict__ thm0, int64_t s_qhm, int64_t s_thm,
+                                                                        const float* __restrict__ bmaxerr, int* __restrict__ minfo) {
+    // The batch's arithmetic mode, reduced ONCE for the launch set: wave b of every workgroup reduces pair b's 2 x 256 flag
+    // words (the eight pairs in parallel: one round trip; as a loop over the pairs inside every filter workgroup this was
+    // 8-10 us of dependent loads at the head of the filter launch), workgroup 0 leaves the result — per pair the mode,
+    // ||t||max and the largest fp16 residual, and the batch's mode — in `minfo` for the filter and refine kernels.
+    __shared__ int smode[kMaxBatch];
+    {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        static_assert(kSplitThreads / 64 >= kMaxBatch, "one wave per pair");
+        if (wave < B) {
+            float tmax;
+            const int m = knn_filter_mode(midflag + wave * kNormBlocks, bmax + wave * kNormBlocks, lane, &tmax);
+            const float* be = bmaxerr + wave * kNormBlocks;
+            float te = fmaxf(fmaxf(be[lane], be[lane + 64]), fmaxf(be[lane + 128], be[lane + 192]));
+#pragma unroll
+            for (int sh = 32; sh >= 1; sh >>= 1) te = fmaxf(te, __shfl_xor(te, sh, 64));
+            if (lane == 0) {
+                smode[wave] = m;
+                if (blockIdx.x == 0) {
+                    minfo[kMinfoPairMode + wave] = m;
+                    minfo[kMinfoTmax + wave] = __float_as_int(tmax);
+                    minfo[kMinfoTerr + wave] = __float_as_int(te);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    int mode = kModeHalfExact;
+    for (int b = 0; b < B; ++b) mode = max(mode, smode[b]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) minfo[kMinfoBatchMode] = mode;
+    if (force_mode >= 0) mode = force_mode;
     if (mode != kModeSplit) return;
     const bool frag = qhm0 != nullptr;
     const int l = threadIdx.x & 31;
@@ -1186,34 +1242,13 @@ __global__ __launch_bounds__(64 * W, 2) void knn_filter_split2_kernel(
     int n_rb1, int n_pairs, int64_t s_qsplit, int64_t s_tsplit, int64_t s_qn, int64_t s_tn, int64_t s_cand, int* __restrict__ minfo,
     const float* __restrict__ bmaxerr, long long* __restrict__ trace) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    if (blockIdx.x == 0 && threadIdx.x < 64) {
-        // what the refine kernel needs of the flags, reduced ONCE (its 4 waves x thousands of workgroups used to re-derive
-        // it from the 2 x 256 x n_pairs words): per pair the mode and ||t||max, and the batch's mode
-        int bm = kModeHalfExact;
-        for (int b = 0; b < n_pairs; ++b) {
-            float tmax;
-            const int m = knn_filter_mode(midflag + b * kNormBlocks, bmax + b * kNormBlocks, (int)threadIdx.x, &tmax);
-            bm = max(bm, m);
-            const float* be = bmaxerr + b * kNormBlocks;
-            float te = fmaxf(fmaxf(be[threadIdx.x], be[threadIdx.x + 64]), fmaxf(be[threadIdx.x + 128], be[threadIdx.x + 192]));
-#pragma unroll
-            for (int sh = 32; sh >= 1; sh >>= 1) te = fmaxf(te, __shfl_xor(te, sh, 64));
-            if (threadIdx.x == 0) {
-                minfo[kMinfoPairMode + b] = m;
-                minfo[kMinfoTmax + b] = __float_as_int(tmax);
-                minfo[kMinfoTerr + b] = __float_as_int(te);
-            }
-        }
-        if (threadIdx.x == 0) minfo[kMinfoBatchMode] = bm;
-    }
     if (trace && threadIdx.x == 0) {
         trace[4 * blockIdx.x + 0] = wall_clock64();
         trace[4 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg(0xF804);
         trace[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg(0xF814);
         trace[8192 + 4 * blockIdx.x + 2] = clock64();
     }
-    const int lane = threadIdx.x & 63;
-    const bool need_mid = (force_mode >= 0 ? force_mode : knn_batch_mode(midflag, bmax, n_pairs, lane)) == kModeSplit;
+    const bool need_mid = (force_mode >= 0 ? force_mode : minfo[kMinfoBatchMode]) == kModeSplit;   // (reduced by knn_split_images_kernel)
     if (need_mid)
         filter_split2_body<ABL, W, true>(smem, qsplit, qnorm, nq, nq_pad, tsplit, nt_pad, tn, tiles, units, smax, nsub, cand_s, cand_i, wg_begin, rb_first,
                                          n_rb1, s_qsplit, s_tsplit, s_qn, s_tn, s_cand, trace);
@@ -1344,7 +1379,7 @@ __device__ __forceinline__ void filter_q4_body(
                 // fragment f of `tile` -> ring slot s (live = false: the ring runs past the segment's end; the segment's last
                 // tile is fetched again — L1 / L2 hits — and never used)
                 if ((ABL & 1) && in_loop) return;
-                const int tile = live ? tile_ : t_end - 1;
+                const int tile = (ABL & 4) ? t_begin : live ? tile_ : t_end - 1;      // (ABL & 4: every refill re-reads the segment's first tile — L1 hits)
                 int soff;
                 if constexpr (KMID) {
                     soff = __builtin_amdgcn_readfirstlane(f == FI ? tile * kTileFragBytes + 8 * kFragBytes : tile * (16 * kFragBytes) + f * kFragBytes);
@@ -1538,32 +1573,13 @@ __global__ __launch_bounds__(256, 1) void knn_filter_q4_kernel(
     const int64_t* __restrict__ wg_begin, const int* __restrict__ rb_first, int n_rb1, int n_pairs, int64_t s_qfrag, int64_t s_tfrag,
     int64_t s_qhm, int64_t s_thm, int64_t s_cand, int* __restrict__ minfo, const float* __restrict__ bmaxerr,
     long long* __restrict__ trace) {
-    if (blockIdx.x == 0 && threadIdx.x < 64) {
-        // what the refine kernel needs of the flags, reduced ONCE: per pair the mode and ||t||max, and the batch's mode
-        int bm = kModeHalfExact;
-        for (int b = 0; b < n_pairs; ++b) {
-            float tmax;
-            const int m = knn_filter_mode(midflag + b * kNormBlocks, bmax + b * kNormBlocks, (int)threadIdx.x, &tmax);
-            bm = max(bm, m);
-            const float* be = bmaxerr + b * kNormBlocks;
-            float te = fmaxf(fmaxf(be[threadIdx.x], be[threadIdx.x + 64]), fmaxf(be[threadIdx.x + 128], be[threadIdx.x + 192]));
-#pragma unroll
-            for (int sh = 32; sh >= 1; sh >>= 1) te = fmaxf(te, __shfl_xor(te, sh, 64));
-            if (threadIdx.x == 0) {
-                minfo[kMinfoPairMode + b] = m;
-                minfo[kMinfoTmax + b] = __float_as_int(tmax);
-                minfo[kMinfoTerr + b] = __float_as_int(te);
-            }
-        }
-        if (threadIdx.x == 0) minfo[kMinfoBatchMode] = bm;
-    }
     if (trace && threadIdx.x == 0) {
         trace[4 * blockIdx.x + 0] = wall_clock64();
         trace[4 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg(0xF804);
         trace[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg(0xF814);
         trace[8192 + 4 * blockIdx.x + 2] = clock64();
     }
-    const bool need_mid = (force_mode >= 0 ? force_mode : knn_batch_mode(midflag, bmax, n_pairs, (int)(threadIdx.x & 63))) == kModeSplit;
+    const bool need_mid = (force_mode >= 0 ? force_mode : minfo[kMinfoBatchMode]) == kModeSplit;   // (reduced by knn_split_images_kernel)
     if (need_mid)
         filter_q4_body<true, 0>(qfrag, tfrag, qhm, thm, nq, nq_pad, tiles, smax, nsub, cand_s, cand_i, wg_begin, rb_first, n_rb1, s_qfrag, s_tfrag, s_qhm,
                              s_thm, s_cand);
@@ -1732,6 +1748,11 @@ constexpr int kQualCap = 144;    // exact-evaluation list per query (a chunk of 
 //   rescan   every other FULL stream (typically none; a handful for ~0.1 % of the queries; all of them for degenerate
 //            train sets) has its <= 512 trains evaluated exactly by the whole workgroup and merged into the query's
 //            answer.  After that the answer equals a full direct-form scan.
+// FRAG: the fp16 train image is the q4 filter's FRAGMENT-ORDER image (`thalf` = tfrag: [32-row tile][9][64 lanes][16 B], tile
+// stride kTileFragBytes) — what is contiguous there is a 16-byte chunk of ADJACENT ROWS, so the screens give a lane one row
+// (a quad = the four adjacent rows of one record: 64 contiguous bytes per load instruction, as before) and every lane walks
+// all 16 chunks of its row; there is no row-major fp16 copy of T at all.
+template <bool FRAG>
 __global__ __launch_bounds__(256, 4) void knn_refine_kernel(
     BatchPtrs P, int B, int64_t ldq, int nq, int64_t ldt, int nt,
     const float* __restrict__ cand_s, const int* __restrict__ cand_i, int rows_per_block, int tiles, int64_t units,
@@ -1950,49 +1971,83 @@ __global__ __launch_bounds__(256, 4) void knn_refine_kernel(
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         static_assert((kHotPre == 2 || kHotPre == 4) && kRecRows == 4, "a quad screens half a record or a whole one (adjacent rows) per pass");
+        if constexpr (FRAG) {
 #pragma unroll 1
-        for (int e0 = 0; e0 < nmax; e0 += 4 * kHotPre) {
-            if (tight) {                                  // degenerate inputs only
-                __builtin_amdgcn_wave_barrier();
-                cnt = cnt_lds[ql];
-                if (__any(cnt > kQualCap - 4 * kHotPre)) {
-                    evaluate(std::false_type{});
-                    if (sl == 0) cnt_lds[ql] = 0;
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            for (int e0 = 0; e0 < nmax; e0 += 16) {           // a record per quad, a row per lane
+                if (tight) {                                  // degenerate inputs only
                     __builtin_amdgcn_wave_barrier();
+                    cnt = cnt_lds[ql];
+                    if (__any(cnt > kQualCap - 16)) {
+                        evaluate(std::false_type{});
+                        if (sl == 0) cnt_lds[ql] = 0;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                    }
                 }
+                const int e = e0 + 4 * qd;
+                const bool live = e < nrow;
+                const int row = live ? rec[ql][e >> 2] + jq : 0;      // (< the padded image's rows: a record never leaves its tile)
+                const unsigned char* fp = reinterpret_cast<const unsigned char*>(thalf) + (int64_t)(row >> 5) * kTileFragBytes + ((row & 31) << 4);
+                float tnv = tn[row];                                  // (padded rows: +inf, never pass)
+                float d[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+                for (int hf = 0; hf < 2; ++hf) {                      // 8 chunks (32 VGPRs) in flight at a time (unrolled: 138 spills at the 128-VGPR bound)
+                    uint4 hv[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) hv[k] = *reinterpret_cast<const uint4*>(fp + (4 * hf + (k >> 1)) * kFragBytes + (k & 1) * 512);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        d[k & 3] = dot8_f16(hv[k], *reinterpret_cast<const uint4*>(&qhalf[ql][8 * (8 * hf + k)]), d[k & 3]);
+                }
+                asm volatile("" : "+v"(tnv));
+                const float sp = (tnv + qq) + ((d[0] + d[2]) + (d[1] + d[3]));
+                if (live && !(thr < sp)) qual[ql][atomicAdd(&cnt_lds[ql], 1)] = row;
             }
-            const int e = e0 + kHotPre * qd;              // rows e .. e + kHotPre - 1 of the list: rows (e & 3) ... of record e >> 2
-            const bool live = e < nrow;
-            const int row0 = live ? rec[ql][e >> 2] + (e & 3) : 0;   // (< the padded image's rows: a record never leaves its tile)
-            const unsigned short* hp = thalf + (int64_t)row0 * kDim + 8 * jq;
-            uint4 hv[kHotPre][4];
-#pragma unroll
-            for (int r = 0; r < kHotPre; ++r)
-#pragma unroll
-                for (int n = 0; n < 4; ++n) hv[r][n] = *reinterpret_cast<const uint4*>(hp + r * kDim + 32 * n);
-            float tnv = tn[row0 + (jq & (kHotPre - 1))];   // (padded rows: +inf, never pass)
-            float dot[kHotPre];
-#pragma unroll
-            for (int r = 0; r < kHotPre; ++r) dot[r] = 0.f;
-#pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                const uint4 qh = *reinterpret_cast<const uint4*>(&qhalf[ql][32 * n + 8 * jq]);
-#pragma unroll
-                for (int r = 0; r < kHotPre; ++r) dot[r] = dot8_f16(hv[r][n], qh, dot[r]);
+        } else {
+#pragma unroll 1
+            for (int e0 = 0; e0 < nmax; e0 += 4 * kHotPre) {
+                if (tight) {                                  // degenerate inputs only
+                    __builtin_amdgcn_wave_barrier();
+                    cnt = cnt_lds[ql];
+                    if (__any(cnt > kQualCap - 4 * kHotPre)) {
+                        evaluate(std::false_type{});
+                        if (sl == 0) cnt_lds[ql] = 0;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+                const int e = e0 + kHotPre * qd;              // rows e .. e + kHotPre - 1 of the list: rows (e & 3) ... of record e >> 2
+                const bool live = e < nrow;
+                const int row0 = live ? rec[ql][e >> 2] + (e & 3) : 0;   // (< the padded image's rows: a record never leaves its tile)
+                const unsigned short* hp = thalf + (int64_t)row0 * kDim + 8 * jq;
+                uint4 hv[kHotPre][4];
+    #pragma unroll
+                for (int r = 0; r < kHotPre; ++r)
+    #pragma unroll
+                    for (int n = 0; n < 4; ++n) hv[r][n] = *reinterpret_cast<const uint4*>(hp + r * kDim + 32 * n);
+                float tnv = tn[row0 + (jq & (kHotPre - 1))];   // (padded rows: +inf, never pass)
+                float dot[kHotPre];
+    #pragma unroll
+                for (int r = 0; r < kHotPre; ++r) dot[r] = 0.f;
+    #pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const uint4 qh = *reinterpret_cast<const uint4*>(&qhalf[ql][32 * n + 8 * jq]);
+    #pragma unroll
+                    for (int r = 0; r < kHotPre; ++r) dot[r] = dot8_f16(hv[r][n], qh, dot[r]);
+                }
+    #pragma unroll
+                for (int r = 0; r < kHotPre; ++r) {
+                    dot[r] += lane_xor<2>(dot[r]);
+                    dot[r] += lane_xor<1>(dot[r]);
+                }
+                asm volatile("" : "+v"(tnv));                  // (keeps the load up here: sunk into the branch below it is a second round trip)
+                // lane j of the quad finishes row j of its kHotPre
+                float mine = dot[0];
+    #pragma unroll
+                for (int r = 1; r < kHotPre; ++r) mine = (jq & (kHotPre - 1)) == r ? dot[r] : mine;
+                const float sp = (tnv + qq) + mine;
+                if (jq < kHotPre && live && !(thr < sp)) qual[ql][atomicAdd(&cnt_lds[ql], 1)] = row0 + jq;
             }
-#pragma unroll
-            for (int r = 0; r < kHotPre; ++r) {
-                dot[r] += lane_xor<2>(dot[r]);
-                dot[r] += lane_xor<1>(dot[r]);
-            }
-            asm volatile("" : "+v"(tnv));                  // (keeps the load up here: sunk into the branch below it is a second round trip)
-            // lane j of the quad finishes row j of its kHotPre
-            float mine = dot[0];
-#pragma unroll
-            for (int r = 1; r < kHotPre; ++r) mine = (jq & (kHotPre - 1)) == r ? dot[r] : mine;
-            const float sp = (tnv + qq) + mine;
-            if (jq < kHotPre && live && !(thr < sp)) qual[ql][atomicAdd(&cnt_lds[ql], 1)] = row0 + jq;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -2109,7 +2164,26 @@ __global__ __launch_bounds__(256, 4) void knn_refine_kernel(
                 // the filter just streamed it; half the bytes of the fp32 rows in HBM) gives s' = ||t||^2 + ||q||^2 - 2 q.t^
                 // with |s' - d^2| <= eps (only t is rounded here, the filter rounds both operands), so only trains with
                 // s' <= d2^2 + eps can enter the top-2.  Otherwise: all of them.
-                if (use_half) {
+                if (use_half && FRAG) {
+                    const double lim_w = q_lim[w];
+                    const float qq_w = q_qq[w];
+                    for (int i = threadIdx.x; i < ntr; i += 256) {     // a lane per train; four consecutive i are four adjacent rows
+                        const int tr = train_of(i);                   // (< the padded image's rows; padded rows: ||t||^2 = +inf)
+                        const unsigned char* fp = reinterpret_cast<const unsigned char*>(thalf) + (int64_t)(tr >> 5) * kTileFragBytes + ((tr & 31) << 4);
+                        float d[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+                        for (int hf = 0; hf < 2; ++hf) {
+                            uint4 hv[8];
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) hv[k] = *reinterpret_cast<const uint4*>(fp + (4 * hf + (k >> 1)) * kFragBytes + (k & 1) * 512);
+#pragma unroll
+                            for (int k = 0; k < 8; ++k)
+                                d[k & 3] = dot8_f16(hv[k], *reinterpret_cast<const uint4*>(&qhalf[w][8 * (8 * hf + k)]), d[k & 3]);
+                        }
+                        const float sp = (tn[tr] + qq_w) + ((d[0] + d[2]) + (d[1] + d[3]));
+                        if (tr < nt && !(lim_w < (double)sp)) surv[atomicAdd(&nsurv, 1)] = tr;
+                    }
+                } else if (use_half) {
                     const double lim_w = q_lim[w];
                     const float qq_w = q_qq[w];
                     const int jq = threadIdx.x & 3;
@@ -2372,7 +2446,7 @@ KnnWs carve_ws(void* ws, int64_t nq, int64_t nt, const Plan& p) {
     w.s_tn = (int64_t)p.tiles * kTileT;
     w.s_qn = p.nq_pad;
     w.s_qsplit = p.q4 ? 0 : (int64_t)p.nq_pad * kDim * 3;   // (q4: the query images exist in fragment order only)
-    w.s_tsplit = (int64_t)p.tiles * kTileT * kDim * 3;
+    w.s_tsplit = p.q4 ? 0 : (int64_t)p.tiles * kTileT * kDim * 3;
     w.s_cand = (int64_t)nq * 2 * p.smax * p.nsub * 3;
     w.bmax = c.take<float>(B * kNormBlocks);
     w.midflag = c.take<int>(B * kNormBlocks);
@@ -2568,7 +2642,7 @@ int knn_batch_impl(int B, const BatchPtrs& P, int64_t nq, int64_t ldq, int64_t n
         SFM_CHECK_LAUNCH();
         hipLaunchKernelGGL(knn_split_images_kernel, dim3(kNormBlocks), dim3(kSplitThreads), 0, stream, P, B, ldq, (int)nq, p.nq_pad, ldt, (int)nt,
                            p.tiles * kTileT, w.qsplit, w.tsplit, w.s_qsplit, w.s_tsplit, w.midflag, w.bmax, p.force_mode,
-                           p.q4 ? w.qhm : nullptr, w.thm, w.s_qhm, w.s_thm);
+                           p.q4 ? w.qhm : nullptr, w.thm, w.s_qhm, w.s_thm, w.bmaxerr, w.minfo);
         SFM_CHECK_LAUNCH();
         sfm::prof_begin(sfm::kProfKnnFilter, stream);
 #define SFM_LAUNCH_SPLIT2(A, WV)                                                                                        \
@@ -2584,7 +2658,7 @@ int knn_batch_impl(int B, const BatchPtrs& P, int64_t nq, int64_t ldq, int64_t n
     hipLaunchKernelGGL(knn_filter_q4_kernel<A>, grid, dim3(256), 0, stream, w.qfrag, w.tfrag, w.qhm, w.thm, (int)nq, p.nq_pad, p.tiles, p.smax, p.nsub, \
                        w.midflag, w.bmax, p.force_mode, w.cand_s, w.cand_i, w.wg_begin, w.rb_first, p.n_rb1, B, w.s_qfrag, w.s_tfrag, w.s_qhm,         \
                        w.s_thm, w.s_cand, w.minfo, w.bmaxerr, g_trace)
-            if (abl == 1) SFM_LAUNCH_Q4(1); else if (abl == 2) SFM_LAUNCH_Q4(2); else if (abl == 3) SFM_LAUNCH_Q4(3); else SFM_LAUNCH_Q4(0);
+            if (abl == 1) SFM_LAUNCH_Q4(1); else if (abl == 2) SFM_LAUNCH_Q4(2); else if (abl == 3) SFM_LAUNCH_Q4(3); else if (abl == 4) SFM_LAUNCH_Q4(4); else SFM_LAUNCH_Q4(0);
 #undef SFM_LAUNCH_Q4
         } else if (p.waves == 4) {
             if (abl == 1) SFM_LAUNCH_SPLIT2(1, 4); else if (abl == 2) SFM_LAUNCH_SPLIT2(2, 4); else if (abl == 4) SFM_LAUNCH_SPLIT2(4, 4);
@@ -2632,10 +2706,14 @@ int knn_batch_impl(int B, const BatchPtrs& P, int64_t nq, int64_t ldq, int64_t n
     const int force_mode = !p.split ? kModeF32 : p.force_mode;
     const int64_t refine_wgs = (int64_t)B * ((nq + kRefQ - 1) / kRefQ), refine_grid = refine_wgs >= 64 ? 8 * ((refine_wgs + 7) / 8) : refine_wgs;
     sfm::prof_begin(sfm::kProfKnnRefine, stream);
-    hipLaunchKernelGGL(knn_refine_kernel, dim3((unsigned)refine_grid), dim3(256), 0, stream, P, B, ldq, (int)nq, ldt,
-                       (int)nt, w.cand_s, w.cand_i, p.rows_per_block, p.tiles, p.units, p.G, p.smax * p.nsub, p.nsub,
-                       force_mode, w.midflag, w.bmax, p.split ? w.minfo : nullptr, p.split ? w.qerr : nullptr, w.s_qn, p.split ? w.tsplit + (size_t)2 * p.tiles * kTileT * kDim : nullptr, w.tn, w.wg_begin, w.rb_first, w.rb_last,
-                       p.n_rb1, w.s_cand, w.s_tsplit, w.s_tn, ratio, ratio_counts, ratio_stride, g_trace ? g_trace + 16384 : nullptr);
+#define SFM_LAUNCH_REFINE(FRAG, THALF, S_THALF)                                                                                          \
+    hipLaunchKernelGGL(knn_refine_kernel<FRAG>, dim3((unsigned)refine_grid), dim3(256), 0, stream, P, B, ldq, (int)nq, ldt, (int)nt, w.cand_s,    \
+                       w.cand_i, p.rows_per_block, p.tiles, p.units, p.G, p.smax * p.nsub, p.nsub, force_mode, w.midflag, w.bmax,               \
+                       p.split ? w.minfo : nullptr, p.split ? w.qerr : nullptr, w.s_qn, THALF, w.tn, w.wg_begin, w.rb_first, w.rb_last, p.n_rb1, \
+                       w.s_cand, S_THALF, w.s_tn, ratio, ratio_counts, ratio_stride, g_trace ? g_trace + 16384 : nullptr)
+    if (p.q4) SFM_LAUNCH_REFINE(true, reinterpret_cast<const unsigned short*>(w.tfrag), w.s_tfrag / 2);      // (stride in 16-bit elements)
+    else SFM_LAUNCH_REFINE(false, p.split ? w.tsplit + (size_t)2 * p.tiles * kTileT * kDim : nullptr, w.s_tsplit);
+#undef SFM_LAUNCH_REFINE
     sfm::prof_end(sfm::kProfKnnRefine, stream);
     SFM_CHECK_LAUNCH();
     return SFM_OK;
