@@ -132,7 +132,7 @@ __host__ __device__ inline int64_t part_begin(const Partition& pt, int b) {
 }
 constexpr int kSegCostTiles = 5;
 int g_seg_cost = [] { const char* e = getenv("SFM_KNN_SEGCOST"); return e ? atoi(e) : kSegCostTiles; }();   // dev override
-int g_seg_cost_q4 = [] { const char* e = getenv("SFM_KNN_SEGCOST_Q4"); return e ? atoi(e) : 3; }();              // q4 kernel: a segment's prologue in tile-steps
+int g_seg_cost_q4 = [] { const char* e = getenv("SFM_KNN_SEGCOST_Q4"); return e ? atoi(e) : 5; }();              // q4 kernel: a segment's prologue in tile-steps
 
 // One workgroup fills the partition tables the filter / refine kernels read: begin[G+1], and per query row block the
 // first and last block that touches it.
@@ -593,16 +593,17 @@ __device__ __forceinline__ int knn_batch_mode(const int* __restrict__ flags, con
 
 // ---- fragment-order images of the q4 filter
 constexpr int kFragBytes = 1024;                            // one MFMA operand fragment of a 32-row tile: 64 lanes x 16 B
-constexpr int kTileFrags = 9;                               // 8 k-steps of 16 + the accumulator-init fragment
-constexpr int kTileFragBytes = kTileFrags * kFragBytes;
+constexpr int kInitFragBytes = 512;                         // the accumulator-init fragment: 64 lanes x 8 B (K = 8 bf16 MFMA)
+constexpr int kTileFragBytes = 8 * kFragBytes + kInitFragBytes;   // 8 k-steps of 16, then the init fragment
 
-// The accumulator init ||t||^2 + ||q||^2 as ONE v_mfma_f32_32x32x16_bf16: a float32 x >= 0 is split EXACTLY into three
-// bf16 pieces hi + mid + lo (8 + 8 + 8 significant bits; every residual is exact in float32), the train side carries
-// {hi, mid, lo, 1, 1, 1, 0, 0} and the query side {1, 1, 1, hi, mid, lo, 0, 0} in the k-slots of the lanes with h = 0 (the
-// h = 1 lanes hold zeros), so the product sums the six pieces in the fp32 accumulator.  +inf (padded train rows) is
-// {inf, 0, 0}: no inf - inf.  Pieces below bf16's normal range (x < 2^-110) may be flushed by the matrix pipe: an absolute
-// error < 2^-120, far below the certificate's slack (which is relative to (|q| + |t|max)^2 >= 2^-28 in every mode).
-__device__ __forceinline__ uint4 frag_init_operand(float x, bool query_side) {
+// The accumulator init ||t||^2 + ||q||^2 as ONE v_mfma_f32_32x32x8_bf16 (K = 8: 16 pipe cycles, half a product MFMA): a
+// float32 x >= 0 is split EXACTLY into three bf16 pieces hi + mid + lo (8 + 8 + 8 significant bits; every residual is exact
+// in float32); the k-slots 0 .. 3 (lanes with h = 0) and 4 .. 7 (h = 1) carry
+//     train side  {hi, mid, lo, 1 | 1, 1, 0, 0}        query side  {1, 1, 1, hi | mid, lo, 0, 0}
+// so the product sums the six pieces in the fp32 accumulator.  +inf (padded train rows) is {inf, 0, 0}: no inf - inf.
+// Pieces below bf16's normal range (x < 2^-110) may be flushed by the matrix pipe: an absolute error < 2^-120, far below
+// the certificate's slack (which is relative to (|q| + |t|max)^2 >= 2^-28 in every mode).
+__device__ __forceinline__ uint2 frag_init_operand(float x, bool query_side, int h) {
     unsigned hi = bf16_rn_bits(x), mid = 0, lo = 0;
     if (x < kInf) {
         const float r1 = x - __uint_as_float(hi << 16);
@@ -610,8 +611,8 @@ __device__ __forceinline__ uint4 frag_init_operand(float x, bool query_side) {
         lo = bf16_rn_bits(r1 - __uint_as_float(mid << 16));
     }
     const unsigned one = 0x3F80u;
-    return query_side ? make_uint4(one | (one << 16), one | (hi << 16), mid | (lo << 16), 0u)
-                      : make_uint4(hi | (mid << 16), lo | (one << 16), one | (one << 16), 0u);
+    if (query_side) return h == 0 ? make_uint2(one | (one << 16), one | (hi << 16)) : make_uint2(mid | (lo << 16), 0u);
+    return h == 0 ? make_uint2(hi | (mid << 16), lo | (one << 16)) : make_uint2(one | (one << 16), 0u);
 }
 
 // One pass over Q and T: rows → the fp16 image (Q pre-scaled by -2, exact), fp32 squared norms, per-block max of
@@ -711,10 +712,10 @@ __global__ __launch_bounds__(1024) void knn_prep_kernel(BatchPtrs P, int64_t ldq
         if (frag) {
             // FRAGMENT ORDER (knn_filter_q4_kernel): [32-row tile][9 fragments][64 lanes][16 B]; fragment f < 8 is k-step f of
             // v_mfma_f32_32x32x16_f16 (lane 32 h + j holds elements 16 f + 8 h .. + 7 of row j of the tile: chunk c = 2 f + h),
-            // fragment 8 the accumulator-init operand (frag_init_operand; zeros for the h = 1 lanes)
-            unsigned char* fimg = (isq ? qfrag : tfrag) + ((int64_t)(r >> 5) * kTileFrags) * kFragBytes;
+            // then the 512-byte accumulator-init fragment (frag_init_operand: 8 B per lane)
+            unsigned char* fimg = (isq ? qfrag : tfrag) + (int64_t)(r >> 5) * kTileFragBytes;
             *reinterpret_cast<uint4*>(fimg + (((c >> 1) * 64 + (c & 1) * 32 + (r & 31)) << 4)) = packed;
-            if (c < 2) *reinterpret_cast<uint4*>(fimg + ((8 * 64 + c * 32 + (r & 31)) << 4)) = c == 0 ? frag_init_operand(nrm, isq) : make_uint4(0u, 0u, 0u, 0u);
+            if (c < 2) *reinterpret_cast<uint2*>(fimg + 8 * kFragBytes + ((c * 32 + (r & 31)) << 3)) = frag_init_operand(nrm, isq, c);
         } else {
             *reinterpret_cast<uint4*>((isq ? qsplit : tsplit) + (2 * (int64_t)npad + r) * kDim + 8 * c) = packed;   // row-major fp16 plane (LDS-ring filter, its refine screens)
         }
@@ -1295,9 +1296,11 @@ constexpr int kQ4Rows = 4 * 4 * 32;                         // queries per workg
 constexpr int kQ4Ring = 3;                                  // tiles of train fragments in registers (fp16 bodies)
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #define SFM_MFMA_F16(acc, a, b) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b))
 #define SFM_MFMA_BF16(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b))
-#define SFM_MFMA_BF16_INIT(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "a"(b))
+#define SFM_MFMA_BF16_INIT(acc, a, b) asm volatile("v_mfma_f32_32x32x8_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "a"(b))
 
 __device__ __forceinline__ void key_insert_quad(const f32x16& a, int r, int seq /*wave-uniform*/, int vmask, int& k0, int& k1, int& k2) {
     const int m = min(min(__float_as_int(a[r]), __float_as_int(a[r + 1])), min(__float_as_int(a[r + 2]), __float_as_int(a[r + 3])));
@@ -1337,8 +1340,7 @@ __device__ __forceinline__ void filter_q4_body(
     constexpr int NPASS = KMID ? 2 : 1;
     constexpr int P = NG / 2;                                 // groups per phase
     constexpr int D = KMID ? 2 : kQ4Ring;                     // ring depth in tiles
-    constexpr int NF = KMID ? 17 : 9;                         // fragments per tile: [hi 0..7][mid 8..15][init] / [fp16 0..7][init]
-    constexpr int FI = NF - 1;
+    constexpr int NF = KMID ? 16 : 8;                         // 16-byte fragments per tile: [hi 0..7][mid 8..15] / [fp16 0..7]; + the init fragment
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
@@ -1346,7 +1348,7 @@ __device__ __forceinline__ void filter_q4_body(
     const int bid = (G & 7) == 0 ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;   // XCD-aware order (see the LDS-ring kernel)
     const int64_t u_end = wg_begin[bid + 1];
     int64_t u = wg_begin[bid];
-    const int voff = lane * 16;
+    const int voff = lane * 16, voffi = lane * 8;
     const int qtiles = nq_pad >> 5;
     int vmask;
     asm volatile("v_mov_b32 %0, %1" : "=v"(vmask) : "s"(~kKeyMask));
@@ -1375,45 +1377,49 @@ __device__ __forceinline__ void filter_q4_body(
 
             // ---- train fragments of the first D tiles, then the query fragments
             i32x4 fr[D][NF];
+            i32x2 fri[D];
             auto load_frag = [&](int s, int f, int tile_, bool live, bool in_loop = false) {
-                // fragment f of `tile` -> ring slot s (live = false: the ring runs past the segment's end; the segment's last
-                // tile is fetched again — L1 / L2 hits — and never used)
+                // fragment f (f == NF: the init fragment) of `tile` -> ring slot s (live = false: the ring runs past the segment's
+                // end; the segment's last tile is fetched again — L1 / L2 hits — and never used)
                 if ((ABL & 1) && in_loop) return;
                 const int tile = (ABL & 4) ? t_begin : live ? tile_ : t_end - 1;      // (ABL & 4: every refill re-reads the segment's first tile — L1 hits)
-                int soff;
-                if constexpr (KMID) {
-                    soff = __builtin_amdgcn_readfirstlane(f == FI ? tile * kTileFragBytes + 8 * kFragBytes : tile * (16 * kFragBytes) + f * kFragBytes);
-                    fr[s][f] = f == FI ? __builtin_amdgcn_raw_buffer_load_b128(trs, voff, soff, 0) : __builtin_amdgcn_raw_buffer_load_b128(thrs, voff, soff, 0);
+                if (f == NF) {
+                    fri[s] = __builtin_amdgcn_raw_buffer_load_b64(trs, voffi, __builtin_amdgcn_readfirstlane(tile * kTileFragBytes + 8 * kFragBytes), 0);
+                } else if constexpr (KMID) {
+                    fr[s][f] = __builtin_amdgcn_raw_buffer_load_b128(thrs, voff, __builtin_amdgcn_readfirstlane(tile * (16 * kFragBytes) + f * kFragBytes), 0);
                 } else {
-                    soff = __builtin_amdgcn_readfirstlane(tile * kTileFragBytes + f * kFragBytes);
-                    fr[s][f] = __builtin_amdgcn_raw_buffer_load_b128(trs, voff, soff, 0);
+                    fr[s][f] = __builtin_amdgcn_raw_buffer_load_b128(trs, voff, __builtin_amdgcn_readfirstlane(tile * kTileFragBytes + f * kFragBytes), 0);
                 }
             };
 #pragma unroll
-            for (int d = 0; d < D; ++d)
+            for (int d = 0; d < D; ++d) {
+                load_frag(d, NF, t_begin + d, t_begin + d < t_end);           // (init fragment first: it is consumed first)
 #pragma unroll
-                for (int f = 0; f < NF; ++f) load_frag(d, (f + FI) % NF, t_begin + d, t_begin + d < t_end);   // (init fragment first: it is consumed first)
+                for (int f = 0; f < NF; ++f) load_frag(d, f, t_begin + d, t_begin + d < t_end);
+            }
 
             __builtin_amdgcn_sched_barrier(0);
             // the query fragments go straight into accumulation registers (hipcc makes the loads' destinations the AGPRs the
             // tied "a" constraints below ask for); ALL of them are requested before the first is waited for
-            u32x4 bq[NG][KMID ? 16 : 8], bi[NG];
+            u32x4 bq[NG][KMID ? 16 : 8];
+            u32x2 bi[NG];
             {
-                i32x4 tmp[NG][KMID ? 16 : 8], tmpi[NG];
+                i32x4 tmp[NG][KMID ? 16 : 8];
+                i32x2 tmpi[NG];
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
 #pragma unroll
                     for (int f = 0; f < (KMID ? 16 : 8); ++f)
                         tmp[g][f] = KMID ? __builtin_amdgcn_raw_buffer_load_b128(qhrs, voff, __builtin_amdgcn_readfirstlane((qg0 + g) * (16 * kFragBytes) + f * kFragBytes), 0)
                                          : __builtin_amdgcn_raw_buffer_load_b128(qrs, voff, __builtin_amdgcn_readfirstlane((qg0 + g) * kTileFragBytes + f * kFragBytes), 0);
-                    tmpi[g] = __builtin_amdgcn_raw_buffer_load_b128(qrs, voff, __builtin_amdgcn_readfirstlane((qg0 + g) * kTileFragBytes + 8 * kFragBytes), 0);
+                    tmpi[g] = __builtin_amdgcn_raw_buffer_load_b64(qrs, voffi, __builtin_amdgcn_readfirstlane((qg0 + g) * kTileFragBytes + 8 * kFragBytes), 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
 #pragma unroll
                     for (int f = 0; f < (KMID ? 16 : 8); ++f) asm volatile("" : "=a"(bq[g][f]) : "0"(__builtin_bit_cast(u32x4, tmp[g][f])));
-                    asm volatile("" : "=a"(bi[g]) : "0"(__builtin_bit_cast(u32x4, tmpi[g])));
+                    asm volatile("" : "=a"(bi[g]) : "0"(__builtin_bit_cast(u32x2, tmpi[g])));
                 }
             }
             asm volatile("s_nop 4");                                           // v_accvgpr_write -> MFMA operand
@@ -1447,7 +1453,7 @@ __device__ __forceinline__ void filter_q4_body(
                 const int seq_prev = __builtin_amdgcn_readfirstlane(max((t - 1) - sub_t0, 0) << 2);
                 // ---- phase A: chains of the first half's groups; epilogue of the second half's groups (previous tile)
                 {
-                    const u32x4 ai = __builtin_bit_cast(u32x4, fr[S][FI]);
+                    const u32x2 ai = __builtin_bit_cast(u32x2, fri[S]);
 #pragma unroll
                     for (int g = 0; g < P; ++g) SFM_MFMA_BF16_INIT(acc[g], ai, bi[g]);
                 }
@@ -1487,12 +1493,12 @@ __device__ __forceinline__ void filter_q4_body(
                 // ---- phase B: chains of the second half's groups; epilogue of the first half's (this tile); the fragments die
                 // one by one and are refilled for tile t + D
                 {
-                    const u32x4 ai = __builtin_bit_cast(u32x4, fr[S][FI]);
+                    const u32x2 ai = __builtin_bit_cast(u32x2, fri[S]);
 #pragma unroll
                     for (int g = P; g < NG; ++g) SFM_MFMA_BF16_INIT(acc[g], ai, bi[g]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                load_frag(S, FI, t + D, more, true);
+                load_frag(S, NF, t + D, more, true);
 #pragma unroll
                 for (int st = 0; st < 8; ++st) {
                     __builtin_amdgcn_sched_barrier(0);
