@@ -37,6 +37,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32,
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (no sparsity)
 PROF_SAMPLES = 6                   # profiled steps, run alone AFTER the timed region
 PIPE_DEPTH = 3                     # launch sets in flight (one stream + workspace each)
+N_SETS = 2                         # sets of PAIR_BATCH distinct image pairs rotating over the steps
 PAIR_BATCH = 8                     # independent pairs per launch set = per step (sfm_match_batch_l2_f32): prologue / ramp / kernel boundaries once per batch
 PROF_REPEAT = 3                    # filter launches per HIP-event pair on a profiled step (an event pair adds ~7 us to one)
 EXCH_BATCH = 8                     # pairs per RCCL all-gather at N > 1
@@ -163,14 +164,20 @@ def knn_source_hash():
 def bench_knn(args, world, rank, dev):
     from sfm_mvs_amd import ops
     nq, nt = args.nq, args.nt
-    q = torch.rand((nq, 128), generator=torch.Generator().manual_seed(2 * rank)).to(dev)
-    t = torch.rand((nt, 128), generator=torch.Generator().manual_seed(2 * rank + 1)).to(dev)
+    depth = max(1, args.pipe_depth)
+    pbatch = max(1, min(8, args.pair_batch))
+    # DISTINCT pairs: a launch set matches `pbatch` different (query, train) images (seeds 2 (pbatch (N_SETS rank + s) + b)
+    # and + 1), and N_SETS such sets rotate over the steps — the caches, the arithmetic-mode decision and the rescan counts
+    # see different images in every slot of a launch set and in consecutive steps.  (Round 2 matched ONE pair eight times.)
+    def image(seed, n):
+        return torch.rand((n, 128), generator=torch.Generator().manual_seed(seed)).to(dev)
+    sets = [[(image(2 * (pbatch * (N_SETS * rank + s) + b), nq), image(2 * (pbatch * (N_SETS * rank + s) + b) + 1, nt)) for b in range(pbatch)]
+            for s in range(N_SETS)]
+    q, t = sets[0][0]
     # Pairs are independent units.  A step = one pair; the pairs of consecutive steps are issued PAIR_BATCH per
     # launch set (one prep / filter / refine / scatter launch for the batch: a filter workgroup pays its prologue once per
     # batch, and there are PAIR_BATCH times fewer kernel boundaries), and launch sets are pipelined over PIPE_DEPTH streams
     # so that the low-occupancy tail of one (rescans, ordered scatter) and the prep pass of the next overlap a filter kernel.
-    depth = max(1, args.pipe_depth)
-    pbatch = max(1, min(8, args.pair_batch))
     pipe = ops.BatchPipeline(nq, nt, dev, ratio=0.70, depth=depth, batch=pbatch)
     pm = pipe.matchers[0]
     import torch.distributed as dist
@@ -186,16 +193,20 @@ def bench_knn(args, world, rank, dev):
         from sfm_mvs_amd import sharded
         ex = sharded.BatchedExchange((2, nq, 2), torch.int32, dev, batch=EXCH_BATCH, nbuf=depth + 1)   # a launch set waits for the gather `depth + 1` sets back: all `depth` streams stay busy
 
+    step_no = [0]
+
     def step():
-        """One launch set: `pbatch` independent pairs through sfm_match_batch_l2_f32 on the next stream of the pipeline
-        (+ at N > 1 the all-gather of their match records)."""
+        """One launch set: `pbatch` independent, distinct pairs through sfm_match_batch_l2_f32 on the next stream of the
+        pipeline (+ at N > 1 the all-gather of their match records); consecutive steps take the next set of images."""
+        pairs = sets[step_no[0] % N_SETS]
+        step_no[0] += 1
         if ex is None:
-            for _ in range(pbatch):
-                pipe.submit(q, t, after=False)               # static inputs, nothing to wait for; the last one launches
+            for qb, tb in pairs:
+                pipe.submit(qb, tb, after=False)             # static inputs, nothing to wait for; the last one launches
             return
-        for _ in range(pbatch):
+        for qb, tb in pairs:
             slot, free_ev = ex.next_slot()
-            pipe.submit(q, t, after=free_ev if free_ev is not None else False, result=slot)
+            pipe.submit(qb, tb, after=free_ev if free_ev is not None else False, result=slot)
             if ex.commit():
                 pipe.flush()
                 ex.flush(pipe.streams)
@@ -212,9 +223,19 @@ def bench_knn(args, world, rank, dev):
     # the steady state is what is measured.  CLOCK_WARMUP_STEPS untimed steps (~60 ms of load), then the W warm-up steps.
     for st, pmx in zip(pipe.streams, pipe.matchers):
         with torch.cuda.stream(st):
-            pmx.run([(q, t)] * pbatch)
-            pmx.run([(q, t)])
+            pmx.run(sets[0])
+            pmx.run(sets[0][:1])
     torch.cuda.synchronize()
+    # COLD figure: the same K steps right after an idle period, before the clock ramp (kernels and streams are loaded, the
+    # device is not at its sustained clock) — what a caller that matches one batch now and then sees.
+    time.sleep(0.5)
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step()
+    drain()
+    barrier_sync(world)
+    cold_elapsed = max_over_ranks(time.perf_counter() - t0, world, dev)
     for i in range(CLOCK_WARMUP_STEPS):                      # (a fixed count: every rank issues the same collectives)
         step()
         if i % 16 == 15:
@@ -245,7 +266,7 @@ def bench_knn(args, world, rank, dev):
     pipe.synchronize()
     for i in range(PROF_SAMPLES):                           # one launch set (a whole pair batch) alone on the device
         ops.profile_enable(PROF_REPEAT)
-        pm.run([(q, t)] * pbatch)
+        pm.run(sets[i % N_SETS])
         ops.profile_enable(False)
         torch.cuda.synchronize()
     drain()
@@ -268,25 +289,30 @@ def bench_knn(args, world, rank, dev):
     value = world * pbatch * nq * nt * args.steps / elapsed      # every step matches pbatch pairs per GPU
     filt_avg_ms = filt_ms / max(filt_n, 1)
     algo_flop = pbatch * nq * nt * FLOP_PER_DISTANCE        # one filter launch covers the whole pair batch
+    pair_flop = nq * nt * FLOP_PER_DISTANCE                 # ... a single-pair launch (the variant legs below) one pair
     achieved = algo_flop / (filt_avg_ms * 1e-3) / 1e12
     # MFMA work actually issued by the filter arithmetic the device chose (stats[3]): one fp16 product per fp32 product
     # (8 MFMAs per 32x32x128 tile) or the 3-product bf16 split (24)
     mode = stats[3]
     mfma_per_tile = {0: 8, 1: 8, 2: SPLIT_MFMA_PER_TILE}.get(mode, 8)
-    issued = pbatch * (nq / 32.0) * (nt / 32.0) * mfma_per_tile * 2 * 32 * 32 * 16 / (filt_avg_ms * 1e-3) / 1e12
+    # (+ the accumulator-init MFMA of every tile, v_mfma_f32_32x32x8_bf16: half the flops of a product MFMA)
+    issued = pbatch * (nq / 32.0) * (nt / 32.0) * (mfma_per_tile + 0.5) * 2 * 32 * 32 * 16 / (filt_avg_ms * 1e-3) / 1e12
     mode_name = {0: "fp16 single product (inputs exact in fp16)", 1: "fp16 single product", 2: "bf16 hi+mid split (3 products)",
                  3: "fp32 MFMA"}.get(mode, str(mode))
     out = {
         "metric": "descriptor-pair distances/sec (BF-KNN k=2 + Lowe ratio)", "value": value, "unit": "distances/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "ms_per_pair": elapsed / (args.steps * pbatch) * 1e3, "host_enqueue_ms_per_step": t_enq / args.steps * 1e3,
+        "cold_value": world * pbatch * nq * nt * args.steps / cold_elapsed, "cold_ms_per_step": cold_elapsed / args.steps * 1e3,
+        "cold_note": "the same K steps timed after 0.5 s of idle, BEFORE the clock-ramp steps (kernels and streams loaded): `value` is the sustained rate, this the rate a cold device gives",
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": f"f32 results (bit-identical to the direct-form f32 reference); filter arithmetic on MFMA: {mode_name}; "
                  "f32 exact refine",
         "data": "synthetic",
         "config": {"workload": f"BASELINE configs[1]: 10k x 10k uniform[0,1) float32 128-D descriptors, BF-KNN k=2 + "
-                               f"Lowe ratio 0.70; a step = one launch set = a batch of {pbatch} independent image pairs of that shape per GPU "
-                               f"({pbatch}e8 distances)", "nq": nq, "nt": nt, "dim": 128, "pairs_per_step": pbatch,
+                               f"Lowe ratio 0.70; a step = one launch set = a batch of {pbatch} distinct pairs of that shape per GPU "
+                               f"({pbatch}e8 distances; {pbatch} distinct pairs per launch set, {N_SETS} sets of images rotating over the steps)",
+                   "nq": nq, "nt": nt, "dim": 128, "pairs_per_step": pbatch, "distinct_pairs_per_launch_set": pbatch, "image_sets": N_SETS,
                    "parallelism": f"pair-sharded x{world}" + (f" + one RCCL all-gather of the match records per {EXCH_BATCH} pairs" if world > 1 else "")
                                   + f"; independent pairs issued {pbatch} per launch set (sfm_match_batch_l2_f32), {depth} launch sets in flight per GPU (one HIP stream each)",
                    "pairs_per_launch": pbatch,
@@ -295,7 +321,7 @@ def bench_knn(args, world, rank, dev):
                      "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": traffic,
                      "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_note,
                      "algorithmic_bytes_per_launch": pbatch * (4 * 128 * (nq + nt) + 16 * nq),
-                     "kernel": "knn_filter_split2_kernel<0, 4>", "avg_launch_ms": filt_avg_ms, "launches": filt_n, "pairs_per_launch": pbatch,
+                     "kernel": "knn_filter_q4_kernel<0>", "avg_launch_ms": filt_avg_ms, "launches": filt_n, "pairs_per_launch": pbatch,
                      "algorithmic_flop_per_launch": algo_flop,
                      "issued_mfma_tflops": issued, "issued_frac_of_peak": issued / BF16_MFMA_PEAK_TFLOPS,
                      "launch_sampling": f"HIP events around the filter kernel on {PROF_SAMPLES} launch sets run alone AFTER the timed region "
@@ -325,10 +351,14 @@ def bench_knn(args, world, rank, dev):
     bm0 = pipe.matchers[0]
     t0 = time.perf_counter()
     for _ in range(20):
-        bm0.run([(q, t)] * pbatch)
+        bm0.run(sets[0])
     torch.cuda.synchronize()
     out["batch_latency_ms_single_stream"] = (time.perf_counter() - t0) / 20 * 1e3
-    same_as_single = all(bool(torch.equal(bm0.idx[b], pm1.idx) and torch.equal(bm0.dist[b], pm1.dist)) for b in range(pbatch))
+    same_as_single = True                                   # every pair of the batch against its own single-pair call
+    for b, (qb, tb) in enumerate(sets[0]):
+        pm1.run(qb, tb)
+        same_as_single = same_as_single and bool(torch.equal(bm0.idx[b], pm1.idx) and torch.equal(bm0.dist[b], pm1.dist))
+    pm1.run(q, t)
     out["batched_results_identical_to_single_pair_call"] = same_as_single
     if world == 1 and not args.no_extras:
         # SURVEY 8d's second input distribution at the same shape: SIFT-like integer descriptors (0..255, norm 512) with 30 %
@@ -386,8 +416,8 @@ def bench_knn(args, world, rank, dev):
         same = bool(torch.equal(pm32.idx, pm.idx) and torch.equal(pm32.dist, pm.dist))
         f32_avg = f32_ms / max(f32_n, 1)
         out["fp32_filter_variant"] = {"kernel": "knn_filter_kernel (v_mfma_f32_32x32x2_f32)", "avg_launch_ms": f32_avg,
-                                      "achieved_tflops": algo_flop / (f32_avg * 1e-3) / 1e12, "peak_tflops": FP32_MFMA_PEAK_TFLOPS,
-                                      "frac": algo_flop / (f32_avg * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                                      "achieved_tflops": pair_flop / (f32_avg * 1e-3) / 1e12, "peak_tflops": FP32_MFMA_PEAK_TFLOPS,
+                                      "frac": pair_flop / (f32_avg * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, "pairs_per_launch": 1,
                                       "results_identical_to_default": same}
         # ... and the 3-product bf16 split pinned (what the device picks for data outside fp16's comfortable range)
         pms = ops.PairMatcher(nq, nt, dev, ratio=0.70, filter="split")
@@ -401,9 +431,10 @@ def bench_knn(args, world, rank, dev):
         ops.profile_read(1)
         ops.profile_enable(False)
         sp_avg = sp_ms / max(sp_n, 1)
-        out["bf16_split_variant"] = {"kernel": "knn_filter_split2_kernel<0, 4> (3 x v_mfma_f32_32x32x16_bf16 per product)",
-                                     "avg_launch_ms": sp_avg, "achieved_tflops": algo_flop / (sp_avg * 1e-3) / 1e12,
-                                     "issued_mfma_tflops": 3 * algo_flop / (sp_avg * 1e-3) / 1e12,
+        out["bf16_split_variant"] = {"kernel": "knn_filter_q4_kernel<0>, split body (3 x v_mfma_f32_32x32x16_bf16 per product)",
+                                     "avg_launch_ms": sp_avg, "achieved_tflops": pair_flop / (sp_avg * 1e-3) / 1e12,
+                                     "frac": pair_flop / (sp_avg * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, "pairs_per_launch": 1,
+                                     "issued_mfma_tflops": 3 * pair_flop / (sp_avg * 1e-3) / 1e12,
                                      "results_identical_to_default": bool(torch.equal(pms.idx, pm.idx) and torch.equal(pms.dist, pm.dist))}
     return out
 
@@ -564,25 +595,93 @@ def bench_tri(args, world, rank, dev):
     return out
 
 
-def bench_ba(args, world, rank, dev):
+def c4_problem(dev, seed, ncam=500, npt=200_000):
+    """BASELINE configs[3]: cameras on a ring, points in the unit ball, dense visibility, sigma 0.5 px, 1 % perturbed
+    cameras.  Observations are synthesised on the device with the library's own projection."""
     from sfm_mvs_amd import ops
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from datagen import load_pose_csv, ring_cameras
-    ncam, npt = 500, 200_000
     K, _ = load_pose_csv()
-    g = torch.Generator(device="cpu").manual_seed(3 + rank)
+    g = torch.Generator(device="cpu").manual_seed(seed)
     cams = torch.from_numpy(ring_cameras(ncam)).to(dev)
     X = torch.randn((npt, 3), generator=g)
     X = (X / X.norm(dim=1, keepdim=True).clamp(min=1.0) * torch.rand((npt, 1), generator=g).clamp(min=0.2)).to(dev)
     obs = torch.empty((ncam, npt, 2), dtype=torch.float32, device=dev)
-    # synthesise observations on device with the library's own projection (proj output), + noise
-    idx_pts = torch.arange(npt, device=dev, dtype=torch.int32)
+    zero = torch.zeros((npt, 2), device=dev)
     for c in range(ncam):
-        o = ops.project_residual(cams[c:c + 1], K, X, torch.zeros((npt, 2), device=dev), want_proj=True)
-        obs[c] = o["proj"]
+        obs[c] = ops.project_residual(cams[c:c + 1], K, X, zero, want_proj=True)["proj"]
     obs += 0.5 * torch.randn(obs.shape, device=dev)
     cams_p = cams * (1 + 0.01 * torch.randn(cams.shape, device=dev, dtype=torch.float64))
-    del idx_pts
+    return K, cams_p, X, obs
+
+
+def c4_cpu_baseline(K, cams_p, X, obs, ns):
+    """The oracle's sweep (sequential C, one thread: its accumulation order is the reference order) on a bounded slice of
+    the same problem: all cameras x the first `ns` points, residual + all four block sets."""
+    from oracle import oracle as O
+    ncam = cams_p.shape[0]
+    cam_idx = np.repeat(np.arange(ncam, dtype=np.int32), ns)
+    pt_idx = np.tile(np.arange(ns, dtype=np.int32), ncam)
+    ch, Xh, oh = cams_p.cpu().numpy(), X[:ns].cpu().numpy(), obs[:, :ns].reshape(-1, 2).cpu().numpy()
+    t1 = time.perf_counter()
+    O.project_residual(ch, K, Xh, oh, cam_idx, pt_idx)
+    dt = time.perf_counter() - t1
+    return {"value": ncam * ns / dt, "unit": "observations/s", "cores": 1, "kind": "port",
+            "sample": f"all {ncam} cameras x the first {ns} points of the same problem ({ncam * ns} observations), once, oracle "
+                      f"orc_project_residual (sequential C, 1 thread), {dt:.1f} s"}
+
+
+def extra_c4(dev):
+    """configs[3] inside the default run (so that the driver's own bench record carries it): 3 timed sweeps of the 500 x 200k
+    dense residual / J^T J sweep with its roofline and the 1-thread oracle beside it, and the reprojection-error operator
+    (A5, sfm.py:79-100) at 10^6 points."""
+    from sfm_mvs_amd import ops
+    K, cams_p, X, obs = c4_problem(dev, 3)
+    ncam, npt = cams_p.shape[0], X.shape[0]
+    nobs = ncam * npt
+    ops.ba_dense_sweep(cams_p, K, X, obs)
+    torch.cuda.synchronize()
+    ops.profile_read(3)
+    ops.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        ops.ba_dense_sweep(cams_p, K, X, obs)
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / 3
+    ms, cnt = ops.profile_read(3)
+    ops.profile_enable(False)
+    k_ms = ms / cnt
+    gbs = 8.2 * nobs / (k_ms * 1e-3) / 1e9
+    out = {"workload": "BASELINE configs[3]: 500 cameras x 200k points dense (1e8 observations), sigma 0.5 px; 3 sweeps",
+           "value": nobs / wall, "unit": "observations/s", "ms_per_sweep": wall * 1e3,
+           "roofline": {"bound": "fp64-valu", "achieved": 420.0 * nobs / (k_ms * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": 420.0 * nobs / (k_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS, "kernel": "ba_dense_kernel", "avg_launch_ms": k_ms,
+                        "flop_per_observation": 420, "hbm_GBs_at_8.2_B_per_obs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS, "traffic": None},
+           "cpu_baseline": c4_cpu_baseline(K, cams_p, X, obs, 8000)}
+    del obs
+    # A5 at scale: ReprojectionError of 10^6 points in one camera (projection + f32 diff + fixed-shape fp64 reduction)
+    n = 1_000_000
+    g = torch.Generator(device="cpu").manual_seed(5)
+    Xb = (torch.randn((n, 3), generator=g) * 0.3).to(dev)
+    ob = ops.project_residual(cams_p[:1], K, Xb, torch.zeros((n, 2), device=dev), want_proj=True)["proj"] + 0.5 * torch.randn((n, 2), device=dev)
+    for _ in range(3):
+        ops.project_residual(cams_p[:1], K, Xb, ob, want_proj=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        r = ops.project_residual(cams_p[:1], K, Xb, ob, want_proj=True)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 20
+    out["reprojection_error_1e6"] = {"points_per_sec": n / dt, "ms_per_call": dt * 1e3, "hbm_GBs_at_28_B_per_point": 28.0 * n / dt / 1e9,
+                                     "error": float(np.sqrt(r["sumsq"].item()) / n),
+                                     "note": "sfm_project_residual, single camera: cam table + residual kernel + two-level fixed-shape fold (12 B X + 8 B obs in, 8 B proj out)"}
+    return out
+
+
+def bench_ba(args, world, rank, dev):
+    from sfm_mvs_amd import ops
+    ncam, npt = 500, 200_000
+    K, cams_p, X, obs = c4_problem(dev, 3 + rank, ncam, npt)
     for _ in range(max(args.warmup, 1)):
         ops.ba_dense_sweep(cams_p, K, X, obs)
     barrier_sync(world)
@@ -618,21 +717,7 @@ def bench_ba(args, world, rank, dev):
               "cost_noise_floor": 2.0 * nobs * 0.25,
               "note": "Schur-complement LM (sfm_mvs_amd.ba.bundle_adjust_schur): PCG on the reduced camera system, "
                       "S x = B x - W C^-1 W^T x with W never formed (sfm_ba_schur_wt / sfm_ba_schur_w)"}
-    cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
-        # the oracle's sweep (sequential C, one thread: its accumulation order is the reference order) on a bounded slice of
-        # the same problem: all 500 cameras x the first 4 000 points = 2e6 observations, residual + all four block sets
-        from oracle import oracle as O
-        ns = 40000
-        cam_idx = np.repeat(np.arange(ncam, dtype=np.int32), ns)
-        pt_idx = np.tile(np.arange(ns, dtype=np.int32), ncam)
-        ch, Xh, oh = cams_p.cpu().numpy(), X[:ns].cpu().numpy(), obs[:, :ns].reshape(-1, 2).cpu().numpy()
-        t1 = time.perf_counter()
-        O.project_residual(ch, K, Xh, oh, cam_idx, pt_idx)
-        dt = time.perf_counter() - t1
-        cpu = {"value": ncam * ns / dt, "unit": "observations/s", "cores": 1, "kind": "port",
-               "sample": f"all {ncam} cameras x the first {ns} points of the same problem ({ncam * ns} observations), once, oracle "
-                         f"orc_project_residual (sequential C, 1 thread), {dt:.1f} s"}
+    cpu = c4_cpu_baseline(K, cams_p, X, obs, 40000) if rank == 0 and not args.no_cpu_baseline else None
     return {"solver": solver, "cpu_baseline": cpu,
             "metric": "BA observations/sec (residual + J^T J sweep)", "value": world * nobs * steps / elapsed,
             "unit": "observations/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
@@ -809,6 +894,7 @@ def main():
         if rank == 0 and world == 1:
             if not args.no_extras:
                 out["extra"] = extras(dev)
+                out["extra"]["config4"] = extra_c4(dev)
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_knn_baseline(args.nq, args.nt, 0, 1)
     elif args.workload == "tri":

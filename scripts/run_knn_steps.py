@@ -28,12 +28,15 @@ if B > 1:      # one launch set per step for B pairs (what bench.py drives): the
         for _ in range(10):
             wa @ wa
         torch.cuda.synchronize()
-    for _ in range(3):
-        bm.run([(q, t)] * B)
+    # B DISTINCT pairs per launch set, two sets alternating (as bench.py drives it)
+    gen = lambda seed, m: torch.rand((m, 128), generator=torch.Generator().manual_seed(seed)).cuda()
+    sets = [[(gen(2 * (B * s + b), nq), gen(2 * (B * s + b) + 1, nt)) for b in range(B)] for s in range(2)] if kind != "sift" else [[(q, t)] * B] * 2
+    for i in range(3):
+        bm.run(sets[i % 2])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(n):
-        bm.run([(q, t)] * B)
+    for i in range(n):
+        bm.run(sets[i % 2])
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / (n * B)
     print(f"done {kind} {nq}x{nt}: batch {B}: {dt*1e3:.4f} ms per pair  {nq*nt/dt:.3e} dist/s  stats", bm.stats[0].cpu().tolist())

@@ -41,7 +41,7 @@ for k, v in agg.items():
 # it only while csrc/knn.hip is unchanged)
 import hashlib, json
 for k, v in agg.items():
-    if k.startswith("knn_filter_split2_kernel") and "FETCH_SIZE" in v:
+    if k.startswith("knn_filter_q4_kernel") and "FETCH_SIZE" in v:
         m = {c: sum(x) / len(x) for c, x in v.items()}
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
         out = {"kernel": k, "pairs_per_launch": pairs, "bytes_per_launch": 2 * m["FETCH_SIZE"] * 1024 + m.get("WRITE_SIZE", 0) * 1024,
