@@ -130,13 +130,19 @@ int sfm_match_batch_l2_f32(int batch, const float* const* q_dev, int64_t nq, int
                            int32_t* const* out_t_dev, int32_t* const* out_count_dev, uint8_t* const* mask_dev,
                            int32_t* const* stats_dev, void* ws_dev, size_t ws_bytes, void* stream);
 
-/* Self-test of the hardware property the KNN certificate's "MFMA chain" term rests on: how far one
- * v_mfma_f32_32x32x16_{f16,bf16} is from the exact c + sum a_k b_k, in units of 2^-24 (|c| + sum |a_k b_k|), maximum over
- * 4096 waves x trials_per_wave MFMAs x 1024 outputs, for seven operand regimes (equal exponents ... 2^16 spread with
- * cancellation; the last one is the filter's own).  The certificate assumes 16 units per MFMA.
- * regime_max_host: 7 doubles; ws: 32 KiB + 256 B of device memory. */
-int sfm_selftest_mfma_accumulation(int use_bf16, int trials_per_wave, double* regime_max_host, void* ws_dev, size_t ws_bytes,
+/* Self-test of the hardware property the KNN certificate's "MFMA chain" term rests on: how far one MFMA is from the exact
+ * c + sum a_k b_k, in units of 2^-24 (|c| + sum |a_k b_k|), maximum over 4096 waves x trials_per_wave MFMAs x 1024 outputs, for
+ * seven operand regimes (equal exponents ... 2^16 spread with cancellation; the last one is the filter's own).
+ * kind: 0 v_mfma_f32_32x32x16_f16, 1 v_mfma_f32_32x32x16_bf16, 2 v_mfma_f32_32x32x8_bf16 (the accumulator-init MFMA).
+ * regime_max_host: 7 doubles; ws: 32 KiB + 512 B of device memory.  Synchronises `stream`. */
+int sfm_selftest_mfma_accumulation(int kind, int trials_per_wave, double* regime_max_host, void* ws_dev, size_t ws_bytes,
                                    void* stream);
+
+/* What the library measured on the CURRENT device the first time a 16-bit KNN filter ran there (it runs the self-test above
+ * once per device and process: a few ms and one synchronisation of a private stream, inside that first call): the largest E
+ * over the three MFMA kinds and seven regimes, and the factor applied to the certificate's chain term — 1 while E <= 8 (the
+ * certificate assumes 16), E / 8 above: an unknown matrix pipe costs speed (more rescans), never exactness. */
+int sfm_knn_mfma_selftest_result(double* worst_units_host, float* chain_scale_host);
 
 /* Gather keypoint coordinates of the survivors: pts0 = kp0[out_q], pts1 = kp1[out_t]
  * (sfm.py:267-268).  kp*_dev are [n x 2] float32 (KeyPoint.pt); count_dev is the

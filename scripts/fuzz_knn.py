@@ -1,7 +1,28 @@
-"""Randomised parity sweep: sfm_match_l2_f32 (through PairMatcher) against the CPU oracle on random shapes and data
-families, including the degenerate ones that force rescans.  Usage: python scripts/fuzz_knn.py [seconds] [seed]"""
-import os, sys, time
-import numpy as np, torch
+"""Randomised parity sweep of the KNN path (sfm_match_l2_f32 / sfm_match_batch_l2_f32 through ops.PairMatcher /
+ops.BatchMatcher) against the CPU oracle: indices, float32 distances (bit patterns), Lowe survivors.
+
+  python scripts/fuzz_knn.py [seconds] [seed] [big]
+
+Data families: the ordinary ones (uniform, scaled normals, SIFT-like integers, planted twins, duplicates, near-ties, unit
+vectors, mixed magnitudes) and a second group aimed at the margins of the exactness certificate:
+  cancel     operands that maximise |c| + sum |a b| while the score itself cancels to almost nothing (alternating signs,
+             large common offset): the regime in which the matrix pipe's accumulation error is largest (7.1 units measured)
+  tie23      every query has its 2nd and 3rd neighbour at distances that differ by 0 .. a few float32 ulps (and the 1st / 2nd
+             likewise for a third of them): a mis-ranked pair flips an index or a Lowe decision
+  pow2       squared distances within a few ulps of a power of two (sqrtf / key-truncation boundaries)
+  fp16edge   values on fp16 rounding midpoints, at the top of its range (~6e4) and around its smallest normals (6.1e-5)
+  normspread query norms spread over 10^3 inside one pair (the slack is relative to each query's own norm)
+Most cases are small (the oracle dominates the wall time); one in eight is large, `big` adds 20k-70k train rows.
+The log ends with the sha256 of csrc/knn.hip: profiles/r03_fuzz_knn_*.log are checked against the tree by tests/test_gpu_knn.py.
+"""
+import hashlib
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from sfm_mvs_amd import ops
@@ -12,91 +33,154 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 big = len(sys.argv) > 3 and sys.argv[3] == "big"       # also long train sets (many substreams / candidate records per query)
 rng = np.random.default_rng(seed)
+NTH = os.cpu_count() or 8
+f32 = np.float32
+
+
+def unit_rows(n):
+    v = rng.standard_normal((n, 128))
+    return v / np.linalg.norm(v, axis=1, keepdims=True)
 
 
 def make(kind, nq, nt):
     if kind == "uniform":
-        return rng.random((nq, 128), dtype=np.float32), rng.random((nt, 128), dtype=np.float32)
+        return rng.random((nq, 128), dtype=f32), rng.random((nt, 128), dtype=f32)
     if kind == "normal_scaled":
-        s = np.float32(10.0 ** rng.uniform(-4, 4))
-        return (rng.standard_normal((nq, 128)) * s).astype(np.float32), (rng.standard_normal((nt, 128)) * s + s).astype(np.float32)
+        s = f32(10.0 ** rng.uniform(-4, 4))
+        return (rng.standard_normal((nq, 128)) * s).astype(f32), (rng.standard_normal((nt, 128)) * s + s).astype(f32)
     if kind == "sift":
         return sift_like(rng, nq), sift_like(rng, nt)
     if kind == "planted":
         q, t, _ = planted_pair(rng, nq, max(nt, 2), 0.3)
         return q, t
     if kind == "duplicates":
-        base = rng.random((max(1, nt // 7), 128), dtype=np.float32)
+        base = rng.random((max(1, nt // 7), 128), dtype=f32)
         t = np.tile(base, (8, 1))[:nt]
-        q = base[rng.integers(0, len(base), nq)] + np.float32(1e-3) * rng.standard_normal((nq, 128)).astype(np.float32)
-        return q.astype(np.float32), t
+        q = base[rng.integers(0, len(base), nq)] + f32(1e-3) * rng.standard_normal((nq, 128)).astype(f32)
+        return q.astype(f32), t
     if kind == "near_ties":
-        base = rng.random((1, 128), dtype=np.float32)
-        t = (base * (1 + np.float32(1e-6) * rng.standard_normal((nt, 1)).astype(np.float32))).astype(np.float32)
-        return rng.random((nq, 128), dtype=np.float32), t
+        base = rng.random((1, 128), dtype=f32)
+        t = (base * (1 + f32(1e-6) * rng.standard_normal((nt, 1)).astype(f32))).astype(f32)
+        return rng.random((nq, 128), dtype=f32), t
     if kind == "unit":
-        q = rng.standard_normal((nq, 128)); t = rng.standard_normal((nt, 128))
-        return (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32), (t / np.linalg.norm(t, axis=1, keepdims=True)).astype(np.float32)
+        return unit_rows(nq).astype(f32), unit_rows(nt).astype(f32)
     if kind == "mixed_magnitude":
-        q = rng.random((nq, 128), dtype=np.float32); t = rng.random((nt, 128), dtype=np.float32)
-        t[:: max(1, nt // 9)] *= np.float32(1e-4); q[::3] *= np.float32(100.0)
+        q = rng.random((nq, 128), dtype=f32); t = rng.random((nt, 128), dtype=f32)
+        t[:: max(1, nt // 9)] *= f32(1e-4); q[::3] *= f32(100.0)
         return q, t
+    # ---- aimed at the certificate's margins
+    if kind == "cancel":
+        # alternating-sign pattern on a large common offset: |q.t| terms are ~offset^2 each and cancel pairwise
+        off = 10.0 ** rng.uniform(0, 3)
+        sign = np.where(np.arange(128) % 2 == 0, 1.0, -1.0)
+        q = (off * sign + rng.standard_normal((nq, 128))) * rng.choice([1.0, -1.0], (nq, 1))
+        t = (off * sign[::-1] * rng.choice([1.0, -1.0], (nt, 1)) + rng.standard_normal((nt, 128)))
+        return q.astype(f32), t.astype(f32)
+    if kind in ("tie23", "pow2"):
+        nt = max(nt, 8)
+        q = (rng.random((nq, 128)) * 10.0 ** rng.uniform(-1, 2)).astype(f32)
+        t = (rng.random((nt, 128)) * 10.0 ** rng.uniform(-1, 2)).astype(f32)
+        m = min(nq, nt // 3)
+        rows = rng.permutation(nt)[: 3 * m].reshape(m, 3)
+        u, v, w = unit_rows(m), unit_rows(m), unit_rows(m)
+        for i in range(m):
+            qi = q[i].astype(np.float64)
+            r = (0.02 + 0.2 * rng.random()) * (np.linalg.norm(qi) + 1e-3)
+            if kind == "pow2":
+                r = np.sqrt(2.0 ** np.round(np.log2(r * r)))                 # d^2 at a power of two (up to rounding of t)
+            eta = rng.choice([0.0, 1e-7, 3e-7, 1e-6, 1e-5]) * rng.choice([1, -1])
+            r1 = r * (1 + (rng.choice([0.0, 1e-7, 1e-6]) if i % 3 == 0 else -0.2))
+            t[rows[i, 0]] = (qi + r1 * u[i]).astype(f32)
+            t[rows[i, 1]] = (qi + r * v[i]).astype(f32)
+            t[rows[i, 2]] = (qi + r * (1 + eta) * w[i]).astype(f32)
+        return q, t
+    if kind == "fp16edge":
+        pick = rng.integers(0, 3)
+        if pick == 0:      # midpoints between adjacent fp16 values (ties of the round-to-nearest-even)
+            base = (rng.integers(1024, 2048, (nq + nt, 128)).astype(np.float64) + 0.5) * 2.0 ** rng.integers(-12, 4)
+        elif pick == 1:    # top of fp16's range: |-2 q| must stay <= 60000
+            base = rng.uniform(2.0e4, 2.9e4, (nq + nt, 128)) * rng.choice([1.0, -1.0], (nq + nt, 128))
+        else:              # around fp16's smallest normals (6.1e-5): the matrix pipe may flush what is below
+            base = rng.uniform(2e-5, 2.5e-4, (nq + nt, 128)) * rng.choice([1.0, -1.0], (nq + nt, 128)) + (rng.random((nq + nt, 128)) < 0.02) * 0.7
+        return base[:nq].astype(f32), base[nq:].astype(f32)
+    if kind == "normspread":
+        q = rng.random((nq, 128)) * 10.0 ** rng.uniform(-1.5, 1.5, (nq, 1))
+        t = rng.random((nt, 128)) * 10.0 ** rng.uniform(-1.5, 1.5, (nt, 1))
+        return q.astype(f32), t.astype(f32)
     raise ValueError(kind)
 
 
-kinds = ["uniform", "normal_scaled", "sift", "planted", "duplicates", "near_ties", "unit", "mixed_magnitude"]
-t_end = time.time() + budget
+kinds = ["uniform", "normal_scaled", "sift", "planted", "duplicates", "near_ties", "unit", "mixed_magnitude",
+         "cancel", "tie23", "pow2", "fp16edge", "normspread", "tie23", "cancel"]
+variants = ["auto"] * 6 + ["split", "f32", "lds", "lds_split", "split"]
+t_start = time.time()
+t_end = t_start + budget
 cases = fails = batched = 0
-modes = {}
+modes, per_kind, per_variant, rescans = {}, {}, {}, 0
+
+
+def check(q, t, idx, dist, oq, ot, m):
+    wi, wd = O.knn2(q, t, nthreads=NTH)
+    wq, wt, _ = O.ratio_filter(wi, wd, 0.70)
+    return (np.array_equal(idx, wi) and np.array_equal(dist.view(np.uint32), wd.view(np.uint32)) and m == len(wq)
+            and np.array_equal(oq[:m], wq) and np.array_equal(ot[:m], wt))
+
+
 while time.time() < t_end:
     kind = kinds[cases % len(kinds)]
-    nq = int(rng.choice([1, 3, 17, 64, 255, 257, 1000, 2049, 5000]) if rng.random() < 0.5 else rng.integers(1, 6000))
-    nt = int(rng.choice([1, 2, 31, 33, 512, 1023, 4097, 9000]) if rng.random() < 0.5 else rng.integers(1, 12000))
-    if big and cases % 3 == 0:
+    variant = variants[(cases // 3) % len(variants)]
+    if cases % 8 == 7:       # the large shapes (several row blocks, many substreams)
+        nq = int(rng.choice([1000, 2049, 5000]) if rng.random() < 0.5 else rng.integers(600, 6000))
+        nt = int(rng.choice([4097, 9000]) if rng.random() < 0.5 else rng.integers(3000, 12000))
+    else:
+        nq = int(rng.choice([1, 3, 17, 64, 255, 257, 511, 513]) if rng.random() < 0.4 else rng.integers(1, 600))
+        nt = int(rng.choice([1, 2, 31, 33, 512, 1023, 2049]) if rng.random() < 0.4 else rng.integers(1, 2600))
+    if big and cases % 24 == 5:
         nq, nt = int(rng.integers(1, 700)), int(rng.integers(20000, 70000))
     if kind in ("duplicates", "near_ties"):
         nq, nt = min(nq, 600), min(nt, 3000)             # every stream is rescanned: keep the exact work bounded
     q, t = make(kind, nq, nt)
     nq, nt = len(q), len(t)
-    variant = ["auto", "auto", "auto", "split", "f32", "auto", "lds"][cases % 7]
+    per_kind[kind] = per_kind.get(kind, 0) + 1
+    per_variant[variant] = per_variant.get(variant, 0) + 1
     if variant != "f32" and cases % 4 == 1:
         # a batch of 2..8 pairs of this shape in ONE launch set (sfm_match_batch_l2_f32), data families mixed: the batch runs
         # the most general arithmetic mode any pair needs, every pair must still equal the oracle
         B = int(rng.integers(2, 9))
         nqb, ntb = min(nq, 1500), min(nt, 4000)
         pairs = [make(kinds[(cases + 3 * b) % len(kinds)] if b else kind, nqb, ntb) for b in range(B)]
-        pairs = [(q[:nqb], t[:ntb]) for q, t in pairs if len(q) >= nqb and len(t) >= ntb]
+        pairs = [(a, b) for a, b in pairs if len(a) >= nqb and len(b) >= ntb]
         nqb, ntb = min(len(p[0]) for p in pairs), min(len(p[1]) for p in pairs)
-        pairs = [(np.ascontiguousarray(q[:nqb]), np.ascontiguousarray(t[:ntb])) for q, t in pairs]
+        pairs = [(np.ascontiguousarray(a[:nqb]), np.ascontiguousarray(b[:ntb])) for a, b in pairs]
         bm = ops.BatchMatcher(nqb, ntb, "cuda", ratio=0.70, batch=len(pairs), filter=variant)
-        bm.run([(torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda()) for q, t in pairs])
+        bm.run([(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()) for a, b in pairs])
         ok = True
-        for b, (q, t) in enumerate(pairs):
-            wi, wd = O.knn2(q, t, nthreads=os.cpu_count() or 8)
-            wq, wt, _ = O.ratio_filter(wi, wd, 0.70)
-            m = int(bm.count[b].item())
-            ok = ok and np.array_equal(bm.idx[b].cpu().numpy(), wi) and np.array_equal(bm.dist[b].cpu().numpy().view(np.uint32), wd.view(np.uint32)) \
-                and m == len(wq) and np.array_equal(bm.out_q[b, :m].cpu().numpy(), wq) and np.array_equal(bm.out_t[b, :m].cpu().numpy(), wt)
+        idx, dist, oq, ot, cnt = bm.idx.cpu().numpy(), bm.dist.cpu().numpy(), bm.out_q.cpu().numpy(), bm.out_t.cpu().numpy(), bm.count.cpu().numpy()
+        for b, (a, c) in enumerate(pairs):
+            ok = ok and check(a, c, idx[b], dist[b], oq[b], ot[b], int(cnt[b, 0]))
         st = bm.stats[0].cpu().tolist()
-        modes[st[3]] = modes.get(st[3], 0) + 1
-        cases += 1
         batched += 1
-        if not ok:
-            fails += 1
-            print(f"MISMATCH case {cases}: BATCH of {len(pairs)} kind={kind} nq={nqb} nt={ntb} variant={variant} stats={st}", flush=True)
-        continue
-    pm = ops.PairMatcher(nq, nt, "cuda", ratio=0.70, filter=variant)
-    idx, dist, oq, ot, cnt = pm.run(torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda())
-    gi, gd, m = idx.cpu().numpy(), dist.cpu().numpy(), int(cnt.item())
-    wi, wd = O.knn2(q, t, nthreads=os.cpu_count() or 8)
-    wq, wt, _ = O.ratio_filter(wi, wd, 0.70)
-    ok = np.array_equal(gi, wi) and np.array_equal(gd.view(np.uint32), wd.view(np.uint32)) and m == len(wq) \
-        and np.array_equal(oq[:m].cpu().numpy(), wq) and np.array_equal(ot[:m].cpu().numpy(), wt)
-    st = pm.stats.cpu().tolist()
+        desc = f"BATCH of {len(pairs)} kind={kind} nq={nqb} nt={ntb}"
+    else:
+        pm = ops.PairMatcher(nq, nt, "cuda", ratio=0.70, filter=variant)
+        idx, dist, oq, ot, cnt = pm.run(torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda())
+        ok = check(q, t, idx.cpu().numpy(), dist.cpu().numpy(), oq.cpu().numpy(), ot.cpu().numpy(), int(cnt.item()))
+        st = pm.stats.cpu().tolist()
+        desc = f"kind={kind} nq={nq} nt={nt}"
     modes[st[3]] = modes.get(st[3], 0) + 1
+    rescans += st[0]
     cases += 1
     if not ok:
         fails += 1
-        print(f"MISMATCH case {cases}: kind={kind} nq={nq} nt={nt} variant={variant} stats={st} rows differing={(gi != wi).any(1).sum()}", flush=True)
-print(f"fuzz: {cases} cases ({batched} of them batches of 2..8 pairs), {fails} mismatches, filter modes used {modes} (seed {seed})")
+        print(f"MISMATCH case {cases}: {desc} variant={variant} stats={st}", flush=True)
+    if cases % 2000 == 0:
+        print(f"  ... {cases} cases, {fails} mismatches, {time.time() - t_start:.0f} s", flush=True)
+
+worst, scale = ops.knn_mfma_selftest_result()
+sha = hashlib.sha256(open(os.path.join(ROOT, "sfm_mvs_amd", "csrc", "knn.hip"), "rb").read()).hexdigest()
+print(f"fuzz: {cases} cases ({batched} of them batches of 2..8 pairs), {fails} mismatches, seed {seed}, {time.time() - t_start:.0f} s")
+print(f"  filter arithmetic modes that ran {dict(sorted(modes.items()))}; variants {per_variant}; rescanned queries in total {rescans}")
+print(f"  families {per_kind}")
+print(f"  runtime MFMA self-test on this device: worst E = {worst:.2f} units, chain scale {scale}")
+print(f"knn_hip_sha256 {sha}")
 sys.exit(1 if fails else 0)

@@ -53,6 +53,7 @@ SIGNATURES = {
     "sfm_norm_l2": (_int, [_vp, _vp, _i64, _int, _vp, _vp, _sz, _vp]),
     "sfm_host_epnp": (_int, [_vp, _vp, _vp, _int, _vp, _vp]),
     "sfm_selftest_mfma_accumulation": (_int, [_int, _int, _vp, _vp, _sz, _vp]),
+    "sfm_knn_mfma_selftest_result": (_int, [_c.POINTER(_f64), _c.POINTER(_f32)]),
     "sfm_host_p3p": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "sfm_host_five_point": (_int, [_vp, _vp, _vp, _vp]),
     "sfm_host_decompose_essential": (_int, [_vp, _vp, _vp, _vp]),

@@ -1655,9 +1655,10 @@ constexpr float kU = 5.9604645e-8f;
 constexpr float kEpsF32 = 600.f * kU;
 static_assert(kKeyBits == 8, "kKeyTrunc = 2^(kKeyBits-23)");
 constexpr float kKeyTrunc = 3.0517578e-5f * 1.002f;
-constexpr float kEpsExact = 200.f * kU + 256.f * kU;
-constexpr float kEpsSplit = 200.f * kU + 640.f * kU + 2.33e-5f;
-constexpr float kEpsHalf = kEpsExact + 4.8840e-4f;
+constexpr float kEpsRound = 200.f * kU;                      // fp32 rounding around the product (budget: DESIGN.md 4.1 "error budget")
+constexpr float kChainHalf = 256.f * kU, kChainSplit = 640.f * kU;   // MFMA chain at E = 16 units per MFMA; x chain_scale (mfma_chain_scale)
+constexpr float kEpsSplitOp = 2.33e-5f;
+constexpr float kEpsHalfOp = 4.8840e-4f;
 constexpr float kEpsHalfAbs = 1.3811e-3f;
 constexpr int kModeF32 = 3;   // fp32-MFMA filter (host-selected)
 
@@ -1767,7 +1768,7 @@ __global__ __launch_bounds__(256, 4) void knn_refine_kernel(
     const unsigned short* __restrict__ thalf /*fp16 image of T, or null*/, const float* __restrict__ tn,
     const int64_t* __restrict__ wg_begin, const int* __restrict__ rb_first, const int* __restrict__ rb_last,
     int n_rb1, int64_t s_cand, int64_t s_tsplit, int64_t s_tn, double ratio,
-    int* __restrict__ ratio_counts /*null unless fused with the Lowe ratio*/, int ratio_stride, long long* __restrict__ trace) {
+    int* __restrict__ ratio_counts /*null unless fused with the Lowe ratio*/, int ratio_stride, float chain_scale, long long* __restrict__ trace) {
     // XCD-aware order (see the filter): physical workgroup b takes query block (b % 8) * chunk + b / 8, so the queries an
     // XCD refines are (roughly) those whose candidate records its own filter workgroups wrote.  Batched: the query
     // blocks of all pairs form one sequence, pair after pair.
@@ -1831,7 +1832,9 @@ __global__ __launch_bounds__(256, 4) void knn_refine_kernel(
         if (B > 1) mode = knn_batch_mode(midflag0, bmax0, B, lane);
     }
     if (force_mode >= 0) mode = force_mode;
-    const float eps_coef = mode == kModeHalfExact ? kEpsExact : mode == kModeHalf ? kEpsHalf : mode == kModeSplit ? kEpsSplit : kEpsF32;
+    const float kEpsExact = kEpsRound + kChainHalf * chain_scale;      // (chain_scale: 1 unless this device's MFMA self-test exceeded E = 8)
+    const float eps_coef = mode == kModeHalfExact ? kEpsExact : mode == kModeHalf ? kEpsExact + kEpsHalfOp
+                           : mode == kModeSplit ? kEpsRound + kChainSplit * chain_scale + kEpsSplitOp : kEpsF32;
 
     // streams of this workgroup's query row block = filter blocks that touched it (contiguous slots from 0);
     // the queries of a workgroup share the row block (rows_per_block is a multiple of 16)
@@ -2502,22 +2505,30 @@ __device__ inline float st_gen(uint32_t h, int e0, int span, bool sg, int mant_b
     return ldexpf(m, e) * ((sg && (h >> 31)) ? -1.f : 1.f);
 }
 
-template <bool BF16>
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+template <int KIND>       // 0: v_mfma_f32_32x32x16_f16, 1: ..._32x32x16_bf16, 2: v_mfma_f32_32x32x8_bf16 (the accumulator-init MFMA)
 __global__ __launch_bounds__(256) void mfma_selftest_kernel(MfmaRegime rg, int trials, uint32_t seed, double* __restrict__ maxerr) {
     const int lane = threadIdx.x & 63, wid = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int rc = lane & 31, h = lane >> 5;
+    constexpr bool BF16 = KIND != 0;
+    constexpr int KK = KIND == 2 ? 8 : 16, PER = KK / 2;      // k-slots of the instruction, per lane
     constexpr int kMant = BF16 ? 7 : 10;
     double worst = 0;
     for (int t = 0; t < trials; ++t) {
         const uint32_t s = seed + 7919u * (uint32_t)(wid * trials + t);
         float av[8], bv[8];
-        for (int e = 0; e < 8; ++e) {
-            av[e] = st_gen(st_hash(s, rc, 8 * h + e), rg.ea, rg.sa, rg.signed_, kMant);               // A[row rc][k = 8 h + e]
-            bv[e] = st_gen(st_hash(s ^ 0xABCDu, rc, 8 * h + e), rg.eb, rg.sb, rg.signed_, kMant);     // B[k][col rc]
+        for (int e = 0; e < PER; ++e) {
+            av[e] = st_gen(st_hash(s, rc, PER * h + e), rg.ea, rg.sa, rg.signed_, kMant);               // A[row rc][k = PER h + e]
+            bv[e] = st_gen(st_hash(s ^ 0xABCDu, rc, PER * h + e), rg.eb, rg.sb, rg.signed_, kMant);     // B[k][col rc]
         }
         f32x16 C, D;
         for (int r = 0; r < 16; ++r) C[r] = st_gen(st_hash(s ^ 0x1234u, 8 * (r >> 2) + 4 * h + (r & 3), rc), rg.ec, rg.sc, rg.signed_, 23);
-        if constexpr (BF16) {
+        if constexpr (KIND == 2) {
+            typedef short s16x4 __attribute__((ext_vector_type(4)));
+            bf16x4 A, B;
+            for (int e = 0; e < 4; ++e) { A[e] = (__bf16)av[e]; B[e] = (__bf16)bv[e]; }
+            D = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(s16x4, A), __builtin_bit_cast(s16x4, B), C, 0, 0, 0);
+        } else if constexpr (KIND == 1) {
             bf16x8 A, B;
             for (int e = 0; e < 8; ++e) { A[e] = (__bf16)av[e]; B[e] = (__bf16)bv[e]; }
             D = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, 0, 0, 0);
@@ -2529,7 +2540,7 @@ __global__ __launch_bounds__(256) void mfma_selftest_kernel(MfmaRegime rg, int t
         for (int r = 0; r < 16; ++r) {
             const int row = 8 * (r >> 2) + 4 * h + (r & 3);
             double ref = (double)C[r], mag = fabs((double)C[r]);
-            for (int kk = 0; kk < 16; ++kk) {
+            for (int kk = 0; kk < KK; ++kk) {
                 const double a = (double)st_gen(st_hash(s, row, kk), rg.ea, rg.sa, rg.signed_, kMant);
                 const double b = (double)st_gen(st_hash(s ^ 0xABCDu, rc, kk), rg.eb, rg.sb, rg.signed_, kMant);
                 ref += a * b;
@@ -2568,8 +2579,9 @@ extern "C" int sfm_selftest_mfma_accumulation(int use_bf16, int trials_per_wave,
     };
     std::vector<double> host((size_t)kBlocks * 4);
     for (int r = 0; r < 7; ++r) {
-        if (use_bf16) hipLaunchKernelGGL(mfma_selftest_kernel<true>, dim3(kBlocks), dim3(256), 0, stream, regs[r], trials_per_wave, 17u + 4096u * r, d);
-        else hipLaunchKernelGGL(mfma_selftest_kernel<false>, dim3(kBlocks), dim3(256), 0, stream, regs[r], trials_per_wave, 17u + 4096u * r, d);
+        if (use_bf16 == 2) hipLaunchKernelGGL(mfma_selftest_kernel<2>, dim3(kBlocks), dim3(256), 0, stream, regs[r], trials_per_wave, 17u + 4096u * r, d);
+        else if (use_bf16) hipLaunchKernelGGL(mfma_selftest_kernel<1>, dim3(kBlocks), dim3(256), 0, stream, regs[r], trials_per_wave, 17u + 4096u * r, d);
+        else hipLaunchKernelGGL(mfma_selftest_kernel<0>, dim3(kBlocks), dim3(256), 0, stream, regs[r], trials_per_wave, 17u + 4096u * r, d);
         SFM_CHECK_LAUNCH();
         SFM_CHECK_HIP(hipMemcpyAsync(host.data(), d, sizeof(double) * host.size(), hipMemcpyDeviceToHost, stream));
         SFM_CHECK_HIP(hipStreamSynchronize(stream));
@@ -2577,6 +2589,65 @@ extern "C" int sfm_selftest_mfma_accumulation(int use_bf16, int trials_per_wave,
         for (double v : host) w = std::max(w, v);
         regime_max_host[r] = w;
     }
+    return SFM_OK;
+}
+
+// ---------------------------------------------------------------- once per device: is the certificate's MFMA assumption met HERE?
+// The chain term of the certificate assumes E = 16 units per MFMA, twice the E <= 8 this library requires of a device (measured
+// on gfx950: <= 2.0 in the filter's regime, <= 7.1 adversarially).  The first 16-bit KNN call on a device runs the self-test
+// (three MFMA kinds x seven regimes, a few ms, ONE synchronisation of a private stream) and keeps the largest E: if it exceeds
+// 8, the chain term of every later call is scaled by E_measured / 8 — the certificate widens, results stay exact, rescans get
+// more frequent — so an unknown matrix pipe (other silicon, firmware) degrades speed, never correctness.
+namespace {
+struct ChainCal {
+    std::once_flag once;
+    float scale = -1.f;
+    double worst = 0;
+};
+ChainCal g_chain_cal[16];
+}  // namespace
+
+static float mfma_chain_scale() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) {
+        sfm::set_error("sfm_knn2_l2_f32: no usable HIP device");
+        return -1.f;
+    }
+    ChainCal& c = g_chain_cal[dev];
+    std::call_once(c.once, [&] {
+        const char* skip = getenv("SFM_KNN_ASSUME_E");           // dev/test: pretend the self-test measured this E
+        double worst = skip ? atof(skip) : 0.0;
+        if (!skip) {
+            void* ws = nullptr;
+            hipStream_t st = nullptr;
+            if (hipMalloc(&ws, 32768 + 512) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+                if (ws) (void)hipFree(ws);
+                return;                                           // scale stays -1: the call fails loudly
+            }
+            bool ok = true;
+            for (int kind = 0; kind < 3 && ok; ++kind) {
+                double r[7];
+                ok = sfm_selftest_mfma_accumulation(kind, 4, r, ws, 32768 + 512, st) == SFM_OK;
+                for (double v : r) worst = std::max(worst, v);
+            }
+            (void)hipStreamDestroy(st);
+            (void)hipFree(ws);
+            if (!ok || !(worst < 1e6)) return;
+        }
+        c.worst = worst;
+        c.scale = worst <= 8.0 ? 1.f : (float)(worst / 8.0);
+    });
+    if (c.scale < 0.f) sfm::set_error("sfm_knn2_l2_f32: the MFMA accumulation self-test could not run on device %d", dev);
+    return c.scale;
+}
+
+extern "C" int sfm_knn_mfma_selftest_result(double* worst_units, float* chain_scale) {
+    const float s = mfma_chain_scale();
+    if (s < 0.f) return SFM_ERR_DEVICE;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (worst_units) *worst_units = g_chain_cal[dev].worst;
+    if (chain_scale) *chain_scale = s;
     return SFM_OK;
 }
 
@@ -2710,13 +2781,18 @@ int knn_batch_impl(int B, const BatchPtrs& P, int64_t nq, int64_t ldq, int64_t n
     sfm::prof_end(sfm::kProfKnnFilter, stream, prof_reps);
     SFM_CHECK_LAUNCH();
     const int force_mode = !p.split ? kModeF32 : p.force_mode;
+    float chain_scale = 1.f;
+    if (p.split) {
+        chain_scale = mfma_chain_scale();
+        if (chain_scale < 0.f) return SFM_ERR_DEVICE;
+    }
     const int64_t refine_wgs = (int64_t)B * ((nq + kRefQ - 1) / kRefQ), refine_grid = refine_wgs >= 64 ? 8 * ((refine_wgs + 7) / 8) : refine_wgs;
     sfm::prof_begin(sfm::kProfKnnRefine, stream);
 #define SFM_LAUNCH_REFINE(FRAG, THALF, S_THALF)                                                                                          \
     hipLaunchKernelGGL(knn_refine_kernel<FRAG>, dim3((unsigned)refine_grid), dim3(256), 0, stream, P, B, ldq, (int)nq, ldt, (int)nt, w.cand_s,    \
                        w.cand_i, p.rows_per_block, p.tiles, p.units, p.G, p.smax * p.nsub, p.nsub, force_mode, w.midflag, w.bmax,               \
                        p.split ? w.minfo : nullptr, p.split ? w.qerr : nullptr, w.s_qn, THALF, w.tn, w.wg_begin, w.rb_first, w.rb_last, p.n_rb1, \
-                       w.s_cand, S_THALF, w.s_tn, ratio, ratio_counts, ratio_stride, g_trace ? g_trace + 16384 : nullptr)
+                       w.s_cand, S_THALF, w.s_tn, ratio, ratio_counts, ratio_stride, chain_scale, g_trace ? g_trace + 16384 : nullptr)
     if (p.q4) SFM_LAUNCH_REFINE(true, reinterpret_cast<const unsigned short*>(w.tfrag), w.s_tfrag / 2);      // (stride in 16-bit elements)
     else SFM_LAUNCH_REFINE(false, p.split ? w.tsplit + (size_t)2 * p.tiles * kTileT * kDim : nullptr, w.s_tsplit);
 #undef SFM_LAUNCH_REFINE

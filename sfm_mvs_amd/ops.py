@@ -601,16 +601,26 @@ class BatchPipeline:
             st.synchronize()
 
 
-def selftest_mfma_accumulation(bf16=False, trials_per_wave=50, device="cuda"):
-    """Largest error of one v_mfma_f32_32x32x16_{f16,bf16} against the exact c + sum a_k b_k, in units of
-    2^-24 (|c| + sum |a_k b_k|), for seven operand regimes (sfm_selftest_mfma_accumulation): the hardware property the KNN
-    certificate's chain term assumes to be <= 16."""
+def selftest_mfma_accumulation(kind=0, trials_per_wave=50, device="cuda", bf16=None):
+    """Largest error of one MFMA against the exact c + sum a_k b_k, in units of 2^-24 (|c| + sum |a_k b_k|), for seven
+    operand regimes (sfm_selftest_mfma_accumulation): the hardware property the KNN certificate's chain term assumes to be
+    <= 16.  kind: 0 v_mfma_f32_32x32x16_f16, 1 ..._32x32x16_bf16, 2 v_mfma_f32_32x32x8_bf16 (the accumulator init)."""
+    if bf16 is not None:
+        kind = 1 if bf16 else 0
     ws = torch.empty(32768 + 512, dtype=torch.uint8, device=device)
     out = (ctypes.c_double * 7)()
     with on_device(ws.device):
-        check(_lib.lib().sfm_selftest_mfma_accumulation(int(bool(bf16)), int(trials_per_wave), out, ptr(ws), ws.numel(), stream_ptr()),
+        check(_lib.lib().sfm_selftest_mfma_accumulation(int(kind), int(trials_per_wave), out, ptr(ws), ws.numel(), stream_ptr()),
               "sfm_selftest_mfma_accumulation")
     return list(out)
+
+
+def knn_mfma_selftest_result(device="cuda"):
+    """(worst E measured, chain-term scale) of the once-per-device self-test the first 16-bit KNN call runs."""
+    worst, scale = ctypes.c_double(0), ctypes.c_float(0)
+    with on_device(torch.device(device)):
+        check(_lib.lib().sfm_knn_mfma_selftest_result(ctypes.byref(worst), ctypes.byref(scale)), "sfm_knn_mfma_selftest_result")
+    return worst.value, scale.value
 
 
 def profile_enable(on=True):

@@ -322,7 +322,27 @@ def test_mfma_accumulation_error_is_within_what_the_certificate_assumes(hip):
     """The certificate's chain term assumes that one 16-bit MFMA returns c + sum a_k b_k within 16 * 2^-24 (|c| + sum |a b|)
     (knn.hip: kEps*).  No manual states how the matrix pipe adds, so the device at hand is measured: 4096 waves x 50 MFMAs
     x 1024 outputs per regime, from equal exponents to a 2^16 spread with cancellation — and held to HALF the assumption."""
-    for bf16 in (False, True):
-        worst = hip.selftest_mfma_accumulation(bf16=bf16, trials_per_wave=50)
-        assert len(worst) == 7 and all(0.0 < w <= 8.0 for w in worst), (bf16, worst)
+    for kind in (0, 1, 2):                     # f16 K=16, bf16 K=16, bf16 K=8 (the accumulator-init MFMA)
+        worst = hip.selftest_mfma_accumulation(kind=kind, trials_per_wave=50)
+        assert len(worst) == 7 and all(0.0 < w <= 8.0 for w in worst), (kind, worst)
         assert worst[6] <= 4.0, worst          # the filter's own operand regime
+
+
+@pytest.mark.gpu
+def test_runtime_selftest_gates_the_certificate(hip, oracle):
+    """The library runs the self-test itself, once per device, inside the first 16-bit KNN call, and scales the certificate's
+    chain term when the device exceeds E = 8.  On gfx950 the scale must be 1; with a pretended E = 64 (fresh process,
+    SFM_KNN_ASSUME_E) results must still be bit-identical — only the rescans grow."""
+    rng = np.random.default_rng(91)
+    q, t = rng.random((700, 128), dtype=np.float32), rng.random((2500, 128), dtype=np.float32)
+    assert_bit_equal(run(hip, q, t), oracle.knn2(q, t, nthreads=8))
+    worst, scale = hip.knn_mfma_selftest_result()
+    assert 0.0 < worst <= 8.0 and scale == 1.0, (worst, scale)
+    import os, subprocess, sys
+    code = ("import numpy as np, torch, sys; sys.path.insert(0, %r); from sfm_mvs_amd import ops; from oracle import oracle as O;"
+            "rng = np.random.default_rng(91); q, t = rng.random((700, 128), dtype=np.float32), rng.random((2500, 128), dtype=np.float32);"
+            "i, d, st = ops.knn2(torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda(), return_stats=True); wi, wd = O.knn2(q, t, nthreads=8);"
+            "assert np.array_equal(i.cpu().numpy(), wi) and np.array_equal(d.cpu().numpy().view(np.uint32), wd.view(np.uint32));"
+            "w, s = ops.knn_mfma_selftest_result(); assert w == 64.0 and s == 8.0, (w, s); print('rescans', int(st[0]))") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SFM_KNN_ASSUME_E="64"), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "rescans" in out.stdout, out.stderr[-2000:]
