@@ -20,6 +20,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")      # (the oracle's OpenMP team and torch's must not spin against each other)
+
 import numpy as np
 import torch
 
@@ -120,7 +122,7 @@ modes, per_kind, per_variant, rescans = {}, {}, {}, 0
 
 
 def check(q, t, idx, dist, oq, ot, m):
-    wi, wd = O.knn2(q, t, nthreads=NTH)
+    wi, wd = O.knn2(q, t, nthreads=max(1, min(NTH // 2, len(q) * len(t) // 400000)))     # (a 256-thread team costs more than a small case)
     wq, wt, _ = O.ratio_filter(wi, wd, 0.70)
     return (np.array_equal(idx, wi) and np.array_equal(dist.view(np.uint32), wd.view(np.uint32)) and m == len(wq)
             and np.array_equal(oq[:m], wq) and np.array_equal(ot[:m], wt))

@@ -346,3 +346,23 @@ def test_runtime_selftest_gates_the_certificate(hip, oracle):
             "w, s = ops.knn_mfma_selftest_result(); assert w == 64.0 and s == 8.0, (w, s); print('rescans', int(st[0]))") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SFM_KNN_ASSUME_E="64"), capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "rescans" in out.stdout, out.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_committed_fuzz_logs_are_those_of_this_kernel_source():
+    """The long randomised parity sweeps (scripts/fuzz_knn.py: >= 20 000 cases per round incl. the margin-aimed families)
+    are committed under profiles/ with the sha256 of csrc/knn.hip they ran on.  A log of another source proves nothing about
+    this binary: the sweep has to be re-run after the last edit of the kernel file."""
+    import glob, hashlib, os, re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sha = hashlib.sha256(open(os.path.join(root, "sfm_mvs_amd", "csrc", "knn.hip"), "rb").read()).hexdigest()
+    logs = sorted(glob.glob(os.path.join(root, "profiles", "r03_fuzz_knn_*.log")))
+    assert logs, "no profiles/r03_fuzz_knn_*.log"
+    total = 0
+    for path in logs:
+        text = open(path).read()
+        m = re.search(r"fuzz: (\d+) cases .*?, (\d+) mismatches", text)
+        assert m and int(m.group(2)) == 0, f"{path}: no clean summary line"
+        assert f"knn_hip_sha256 {sha}" in text, f"{path} was produced by another csrc/knn.hip (stale): re-run scripts/fuzz_knn.py"
+        total += int(m.group(1))
+    assert total >= 20000, f"only {total} fuzz cases on this source"
