@@ -269,6 +269,20 @@ int sfm_ba_schur_indexed(const double* cams_dev, int64_t ncam, const double* K_h
                          const double* in_dev, double* out_dev,
                          void* ws_dev, size_t ws_bytes, void* stream);
 
+/* One damped Gauss-Newton (Levenberg-Marquardt) step of the DENSE problem, solved on the device: the reduced camera system
+ *     S dc = g_c - W Cd^-1 g_p,   S = Bd - W Cd^-1 W^T,   dp = Cd^-1 (g_p - W^T dc),   Bd / Cd = blocks with diagonals x (1 + lam)
+ * by block-Jacobi-preconditioned conjugate gradients; S is applied matrix-free (the two products above), the CG vectors and
+ * scalars stay on the device, the host reads the residual norm every fifth iteration.  Inputs: the blocks
+ * sfm_ba_dense_sweep returned at (cams, X).  Outputs: dc_dev [ncam x 6], dp_dev [npt x 3] (update = parameters - step);
+ * iters_host = CG iterations run; status_host bit 0 = a singular camera block was met (its preconditioner block is the
+ * identity), bit 1 = a singular point block.  Synchronises `stream`.  Replaces the reference's
+ * scipy.optimize.least_squares call (sfm.py:146), which differentiates the dense problem by finite differences. */
+size_t sfm_ba_schur_solve_ws_bytes(int64_t ncam, int64_t npt);
+int sfm_ba_schur_solve(const double* cams_dev, int64_t ncam, const double* K_host, const float* X_dev, int64_t npt, int64_t ldx,
+                       const double* JtJ_cam_dev, const double* Jtr_cam_dev, const double* JtJ_pt_dev, const double* Jtr_pt_dev,
+                       double lam, int fix_first_camera, double cg_tol, int cg_iters, double* dc_dev, double* dp_dev,
+                       int32_t* iters_host, int32_t* status_host, void* ws_dev, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------
  * Small batched block kernels of the Schur-complement solver (row f-3; the reference hands the
  * problem to SciPy's dense least_squares, sfm.py:146) and cv2.norm of the metric (sfm.py:93,95).

@@ -45,6 +45,9 @@ SIGNATURES = {
     "sfm_ba_schur_ws_bytes": (_sz, [_i64, _i64]),
     "sfm_ba_schur_wt": (_int, [_vp, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
     "sfm_ba_schur_w": (_int, [_vp, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "sfm_ba_schur_solve_ws_bytes": (_sz, [_i64, _i64]),
+    "sfm_ba_schur_solve": (_int, [_vp, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _f64, _int, _f64, _int, _vp, _vp,
+                                  _c.POINTER(_i32), _c.POINTER(_i32), _vp, _sz, _vp]),
     "sfm_ba_schur_indexed_ws_bytes": (_sz, [_i64]),
     "sfm_ba_schur_indexed": (_int, [_vp, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _int, _vp, _vp, _vp, _sz, _vp]),
     "sfm_block_inverse": (_int, [_vp, _i64, _int, _vp, _vp]),

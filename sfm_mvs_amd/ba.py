@@ -99,7 +99,7 @@ def _bmv(A, x, n):
     return ops.block_matvec(A, x, n)
 
 
-def schur_step(cams, K, X, blocks, lam, fix_first_camera=True, cg_tol=1e-10, cg_iters=200, cam_idx=None, pt_idx=None):
+def schur_step(cams, K, X, blocks, lam, fix_first_camera=True, cg_tol=1e-10, cg_iters=200, cam_idx=None, pt_idx=None, device_pcg=True):
     """One damped Gauss-Newton step of the dense problem through the reduced camera system.
 
         [ B+lam*diag(B)    W           ] [dc]   [g_c]        S dc = g_c - W Cd^-1 g_p,    S = Bd - W Cd^-1 W^T
@@ -108,7 +108,14 @@ def schur_step(cams, K, X, blocks, lam, fix_first_camera=True, cg_tol=1e-10, cg_
     S is never formed: preconditioned conjugate gradients with S x = Bd x - W (Cd^-1 (W^T x)) (two device sweeps per
     iteration, ops.ba_schur_wt / ops.ba_schur_w), block-Jacobi preconditioner Bd^-1.  `blocks` = the dict returned by
     ops.ba_dense_sweep at (cams, X).  Returns (dc [ncam,6], dp [npt,3], number of CG iterations); the update is
-    params - step (the sweep's gradient is J^T r)."""
+    params - step (the sweep's gradient is J^T r).
+    Dense visibility: the whole recurrence runs on the device (ops.ba_schur_solve: one C-ABI call, the CG vectors and
+    scalars never leave HBM); the torch loop below is the sparse-window form and the cross-check of the device solver."""
+    if device_pcg and cam_idx is None:
+        dc, dp, it, status = ops.ba_schur_solve(cams, K, X, blocks, lam, fix_first_camera, cg_tol, cg_iters)
+        if status & 1:
+            raise ops.SfmHipError("schur_step: a camera block is singular (a camera without observations?)")
+        return dc, dp, it
     dev = X.device
     B = blocks["JtJ_cam"].clone().view(-1, 6, 6)
     C = blocks["JtJ_pt"].clone()

@@ -374,6 +374,24 @@ def ba_schur_w(cams, K, X, v_pt, cam_idx=None, pt_idx=None):
     return w
 
 
+def ba_schur_solve(cams, K, X, blocks, lam, fix_first_camera=True, cg_tol=1e-10, cg_iters=200):
+    """One damped Schur-complement step of the dense problem, PCG on the device (sfm_ba_schur_solve).  `blocks`: the dict
+    ops.ba_dense_sweep returned at (cams, X).  Returns (dc [ncam,6], dp [npt,3] float64 CUDA, CG iterations, status bits)."""
+    cams, k, X = _schur_args(cams, K, X)
+    ncam, npt, dev = cams.shape[0], X.shape[0], X.device
+    B, gc, C, gp = (blocks[n].contiguous() for n in ("JtJ_cam", "Jtr_cam", "JtJ_pt", "Jtr_pt"))
+    dc = torch.empty((ncam, 6), dtype=torch.float64, device=dev)
+    dp = torch.empty((npt, 3), dtype=torch.float64, device=dev)
+    lib = _lib.lib()
+    ws = _workspace(dev, lib.sfm_ba_schur_solve_ws_bytes(ncam, npt))
+    it, st = ctypes.c_int32(0), ctypes.c_int32(0)
+    with on_device(dev):
+        check(lib.sfm_ba_schur_solve(ptr(cams), ncam, k.ctypes.data_as(ctypes.c_void_p), ptr(X), npt, X.stride(0), ptr(B), ptr(gc), ptr(C), ptr(gp),
+                                     float(lam), int(bool(fix_first_camera)), float(cg_tol), int(cg_iters), ptr(dc), ptr(dp),
+                                     ctypes.byref(it), ctypes.byref(st), ptr(ws), ws.numel(), stream_ptr()), "sfm_ba_schur_solve")
+    return dc, dp, it.value, st.value
+
+
 def score_essential(E, x1n, x2n, thr2, want_mask=False):
     """Sampson-distance inlier counts for h candidate essential matrices (sfm.py:307 RANSAC scoring)."""
     require_cuda(E, x1n, x2n)

@@ -139,7 +139,9 @@ class HipMatchEngine:
         if pipe is None:
             pipe = self.pipes[(nq, nt)] = ops.PairPipeline(nq, nt, self.device, ratio=self.ratio, depth=self.depth)
         direct = block.shape[1] == nq and block.is_contiguous()
-        slot, st, out = pipe.submit(des0, des1, after=after if after is not None else False, result=block if direct else None)
+        # after = None (no free-event yet: the first rounds): the pair waits for everything already enqueued on the caller's
+        # current stream — descriptors still being produced there (an asynchronous SIFT or upload) are safe to pass in
+        slot, st, out = pipe.submit(des0, des1, after=after, result=block if direct else None)
         if not direct:
             with torch.cuda.stream(st):
                 block[0, :nq].copy_(out[0], non_blocking=True)

@@ -271,6 +271,36 @@ def test_schur_step_equals_dense_normal_equation_solve(hip):
     assert np.abs(dp.cpu().numpy().ravel() - sol[6 * ncam:]).max() <= 2e-5 * np.abs(sol[6 * ncam:]).max()
 
 
+def test_device_pcg_equals_the_host_driven_recurrence(hip):
+    """sfm_ba_schur_solve (the whole PCG recurrence on the device) against the same recurrence driven from torch ops: same
+    iteration count, steps equal to CG rounding, identical Levenberg-Marquardt cost histories; a singular camera block is
+    reported instead of silently producing inf / NaN."""
+    from sfm_mvs_amd import ba
+    ncam, npt, lam = 9, 2500, 3e-3
+    K, cams, X, obs = ba_problem(ncam, npt, 0.5, seed=35, perturb=0.01)
+    blocks = hip.ba_dense_sweep(cu(cams), K, cu(X), cu(obs))
+    d1 = ba.schur_step(cu(cams), K, cu(X), blocks, lam, device_pcg=True)
+    d2 = ba.schur_step(cu(cams), K, cu(X), blocks, lam, device_pcg=False)
+    assert d1[2] == d2[2] and d1[2] > 0
+    for a, b in zip(d1[:2], d2[:2]):
+        assert float((a - b).abs().max()) <= 1e-8 * float(b.abs().max())
+    assert torch.equal(d1[0], ba.schur_step(cu(cams), K, cu(X), blocks, lam)[0])          # fixed-order reductions: deterministic
+    real = ba.schur_step
+    h_dev = ba.bundle_adjust_schur(cu(cams), K, cu(X), cu(obs), iters=6)[2]
+    try:
+        ba.schur_step = lambda *a, **k: real(*a, **dict(k, device_pcg=False))
+        h_host = ba.bundle_adjust_schur(cu(cams), K, cu(X), cu(obs), iters=6)[2]
+    finally:
+        ba.schur_step = real
+    assert len(h_dev) == len(h_host) and np.allclose(h_dev, h_host, rtol=1e-7)
+    dead = {k: v.clone() for k, v in blocks.items()}
+    dead["JtJ_cam"][3] = 0
+    dc, dp, it, status = hip.ba_schur_solve(cu(cams), K, cu(X), dead, 0.0)
+    assert status & 1
+    with pytest.raises(hip.SfmHipError):
+        ba.schur_step(cu(cams), K, cu(X), dead, 0.0)
+
+
 def test_schur_lm_converges_to_the_noise_floor(hip):
     """Joint Schur-complement LM vs the alternating block updates on the same problem and iteration budget."""
     from sfm_mvs_amd import ba

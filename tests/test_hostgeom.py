@@ -78,3 +78,23 @@ def test_scene_generator_is_consistent():
     assert len(feats) == 4 and all(f[0].dtype == np.float32 and f[1].shape[1] == 128 for f in feats)
     common = np.intersect1d(ids[1][ids[1] >= 0], ids[2][ids[2] >= 0])
     assert len(common) > 100
+
+
+def test_save_pose_csv_reproduces_the_reference_file_byte_for_byte(tmp_path):
+    """sfm.py:423 `np.savetxt('pose.csv', posearr, delimiter='\\n')`: one '%.18e' value per line, K (9 numbers) then the 57
+    projection matrices.  The reference's own pose.csv (tests/golden/pose.csv, 693 lines) read back and written through
+    pipeline.save_pose_csv must come out identical to the byte."""
+    import os
+    from sfm_mvs_amd import pipeline
+    src = os.path.join(GOLDEN, "pose.csv")
+    posearr = np.loadtxt(src)
+    assert posearr.shape == (9 + 57 * 12,)
+    out = tmp_path / "pose.csv"
+    pipeline.save_pose_csv(str(out), posearr)
+    assert out.read_bytes() == open(src, "rb").read()
+    # ... and in the driver's own accumulation form: K.ravel() followed by one 12-vector per camera (sfm.py:296-300, 398)
+    arr = posearr[:9]
+    for k in range(57):
+        arr = np.hstack((arr, posearr[9 + 12 * k: 21 + 12 * k]))
+    pipeline.save_pose_csv(str(out), arr)
+    assert out.read_bytes() == open(src, "rb").read()
