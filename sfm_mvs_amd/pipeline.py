@@ -268,227 +268,265 @@ def to_ply(path, point_cloud, colors, densify=False):
     return len(verts)
 
 
-def run_sfm(features, K, images=None, log=None, be=None, device_resident=None):
-    """The reference's driver, sfm.py:274-423 (bundle_adjustment=False, its default).
-    features: list of (kp (n,2) float32, des (n,128) float32) per image, in sequence order.
-    images:   optional list of HxWx3 uint8 arrays for the colour lookup (sfm.py:393-394).
-    Returns dict(posearr (9+12*n_cam,), Xtot (m,3), colorstot (m,3), errors [per-frame], first_error).
-    On the HIP back-end (be=None) the driver keeps every per-frame array in HBM between the operators
-    (`_run_sfm_device`: same kernels, same results bit for bit, a handful of host synchronisations per frame instead of
-    an upload and a download around every operator); device_resident=False forces the array-in / array-out form below,
-    which is also what a substituted backend (the tests' CPU twin) runs."""
+# ---------------------------------------------------------------------------------------------------------------------
+# The incremental driver (sfm.py:274-423, bundle_adjustment=False: the reference's default), written ONCE over a small
+# engine interface.  An engine owns the array type the per-frame state lives in and supplies the operators:
+#     match(i, j)            matched keypoints of images i, j                       (find_features, sfm.py:347)
+#     essential(a, b)        essential matrix + rows of its {0,1} mask              (sfm.py:307-309)
+#     recover_pose(E, a, b)  R, t + rows of the {0,255} cheirality mask             (sfm.py:311-313)
+#     triangulate(Pa, Pb, a, b)   (n,3) float32 cloud, w normalised as sfm.py:54    (Triangulation + convertPointsFromHomogeneous)
+#     error(X, obs, Rt)      handle of ||proj - obs||_F / n                         (ReprojectionError)
+#     pnp(X, p, p0)          R, t and the inlier rows of p, X, p0                   (PnP)
+#     associate(pts1, pts_)  indx1, indx2, rows of pts_ not associated              (common_points)
+#     take(x, rows), host(x), errors(handles)
+# `_HipEngine` keeps everything in HBM (device tensors from kernel to kernel, a handful of host synchronisations per
+# frame); `_ArrayEngine` runs the NumPy helper mirrors above over a Backend — the HIP one, or the CPU twin the tests build
+# on the oracle.  One frame is one call of register_next(): the tests drive it frame by frame with the other engine's
+# state (teacher forcing) to separate per-frame parity from the drift of the free-running chain.
+# ---------------------------------------------------------------------------------------------------------------------
+class FrameState:
+    """What the driver carries from frame to frame (sfm.py:404-409: only the last two cameras, quirk 7): the two projection
+    matrices (host, float64), the matches of the last pair in the engine's array type, and — for the very first
+    registration only — the bootstrap pair's PnP-filtered cloud and points (afterwards the cloud is re-triangulated from
+    ALL ratio matches, quirk 6)."""
+    __slots__ = ("P1", "P2", "pts0", "pts1", "cloud0")
+
+    def __init__(self, P1, P2, pts0, pts1, cloud0=None):
+        self.P1, self.P2, self.pts0, self.pts1, self.cloud0 = P1, P2, pts0, pts1, cloud0
+
+    def on(self, engine):
+        """The same state in another engine's array type."""
+        c = engine.array
+        return FrameState(self.P1.copy(), self.P2.copy(), c(self.pts0), c(self.pts1), None if self.cloud0 is None else c(self.cloud0))
+
+
+def _np(x):
+    return x.detach().cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
+
+
+class _ArrayEngine:
+    """NumPy arrays in, NumPy arrays out, through the helper mirrors (Triangulation, PnP, ReprojectionError, common_points)
+    of a Backend."""
+
+    def __init__(self, features, K, be=None):
+        self.features, self.K, self.be = features, np.asarray(K, np.float64), _be(be)
+
+    def array(self, x):
+        return np.ascontiguousarray(_np(x))
+
+    host = staticmethod(_np)
+
+    def match(self, i, j):
+        return match_features(self.features[i], self.features[j], self.be)
+
+    def essential(self, a, b):
+        cv = self.be.cv
+        E, mask = cv.findEssentialMat(a, b, self.K, method=cv.RANSAC, prob=0.999, threshold=0.4, mask=None)
+        return E, np.flatnonzero(mask.ravel() == 1)              # quirk 4: {0,1} mask
+
+    def recover_pose(self, E, a, b):
+        _, R, t, mask = self.be.cv.recoverPose(E, a, b, self.K)
+        return R, t, np.flatnonzero(mask.ravel() > 0)            # quirk 4: {0,255} mask
+
+    def take(self, x, rows):
+        return x[rows]
+
+    def triangulate(self, Pa, Pb, a, b):
+        _, _, cloud = Triangulation(Pa, Pb, a, b, self.K, repeat=False, be=self.be)
+        return self.be.cv.convertPointsFromHomogeneous(cloud.T)[:, 0, :]
+
+    def error(self, X, obs, Rt):
+        return ReprojectionError(X, obs, Rt, self.K, homogenity=0, be=self.be)[0]
+
+    def pnp(self, X, p, p0):
+        return PnP(X, p, self.K, np.zeros((5, 1), dtype=np.float32), p0, initial=0, be=self.be)
+
+    def associate(self, pts1, pts_):
+        indx1, indx2, _, _ = common_points(pts1, pts_, pts_)
+        keep = np.ones(len(pts_), bool)
+        keep[indx2] = False
+        return indx1, indx2, np.flatnonzero(keep)
+
+    def errors(self, handles):
+        return [float(h) for h in handles]
+
+
+class _HipEngine:
+    """Device tensors from kernel to kernel.  What crosses to the host per frame: one survivor count, one association count
+    and the few scalars solvePnPRansac returns; error sums, clouds and colour-lookup points come back once, at the end."""
+
+    def __init__(self, features, K):
+        self.features, self.K = features, np.asarray(K, np.float64)
+        self.dev = torch.device("cuda")
+        self.cache, self.pre, self.pre_m = {}, {}, []
+        # The matches of consecutive frames do not depend on the pose chain: pairs of equal shape are matched up front, 8 per
+        # launch set (sfm_match_batch_l2_f32: bit-identical to per-pair calls), their survivor counts come back in ONE
+        # download; pairs of a shape that occurs once are matched when the driver asks for them.
+        shapes = {}
+        for k in range(len(features) - 1):
+            shapes.setdefault((len(features[k][0]), len(features[k + 1][0])), []).append(k)
+        self.keep_all = set()
+        for plist in shapes.values():
+            if len(plist) >= 2:
+                self.keep_all.update(plist)
+                self.keep_all.update(k + 1 for k in plist)
+        counts = []
+        for (nq, nt), plist in shapes.items():
+            if len(plist) < 2 or nq == 0 or nt == 0:
+                continue
+            bm = ops.BatchMatcher(nq, nt, self.dev, ratio=RATIO, batch=min(8, len(plist)))
+            for c0 in range(0, len(plist), 8):
+                chunk = plist[c0:c0 + 8]
+                bm.run([(self._feat(k)[1], self._feat(k + 1)[1]) for k in chunk])
+                oq, ot, cn = bm.out_q[:len(chunk)].clone(), bm.out_t[:len(chunk)].clone(), bm.count[:len(chunk)].clone()
+                for b, k in enumerate(chunk):
+                    self.pre[k] = (oq[b], ot[b], cn[b], len(counts) + b)
+                counts.extend([cn[b] for b in range(len(chunk))])
+        self.pre_m = torch.cat(counts).cpu().tolist() if counts else []
+
+    def array(self, x):
+        return x.to(self.dev).contiguous() if torch.is_tensor(x) else torch.as_tensor(np.ascontiguousarray(x)).to(self.dev)
+
+    host = staticmethod(_np)
+
+    def _feat(self, i):   # every image's features are uploaded once
+        if i not in self.cache:
+            kp, des = self.features[i]
+            up = lambda a: a.to(self.dev, torch.float32).contiguous() if torch.is_tensor(a) else torch.as_tensor(np.ascontiguousarray(a, np.float32)).to(self.dev)
+            self.cache[i] = (up(kp), up(des))
+            if i - 2 not in self.keep_all:
+                self.cache.pop(i - 2, None)
+        return self.cache[i]
+
+    def match(self, i, j):
+        (kp0, d0), (kp1, d1) = self._feat(i), self._feat(j)
+        if i in self.pre and j == i + 1:
+            out_q, out_t, count, slot = self.pre[i]
+            m = int(self.pre_m[slot])
+        else:
+            idx, dist = ops.knn2(d0, d1)
+            out_q, out_t, count = ops.ratio_compact(idx, dist, RATIO)
+            m = int(count.item())
+        p0, p1 = ops.gather_matches(kp0, kp1, out_q, out_t, count)
+        return p0[:m], p1[:m]
+
+    def essential(self, a, b):
+        from . import ransac
+        E, mask = ransac.find_essential_mat(a, b, self.K, 0.999, 0.4, return_device_mask=True)
+        return E, torch.nonzero(mask.ravel() == 1).ravel()
+
+    def recover_pose(self, E, a, b):
+        from . import ransac
+        _, R, t, mask = ransac.recover_pose(E, a, b, self.K, return_device_mask=True)
+        return R, t, torch.nonzero(mask.ravel() > 0).ravel()
+
+    def take(self, x, rows):
+        return x[rows.long() if torch.is_tensor(rows) else rows]
+
+    def triangulate(self, Pa, Pb, a, b):
+        return ops.triangulate(Pa, Pb, a.t(), b.t(), rows=cv2.TRIANGULATE_ROWS, normalise_w=True)[:3].t().contiguous()
+
+    def error(self, X, obs, Rt):
+        from . import hostgeom as hg
+        cams = torch.as_tensor(np.hstack([hg.rodrigues_mat2vec(Rt[:3, :3]), Rt[:3, 3]])[None]).to(self.dev)
+        return ops.project_residual(cams, self.K, X, obs.contiguous(), want_proj=False)["sumsq"], len(obs)
+
+    def pnp(self, X, p, p0):
+        from . import hostgeom as hg
+        from . import ransac
+        ok, rvec, t, inl = ransac.solve_pnp_ransac(X, p, self.K, return_device_inliers=True)
+        if inl is not None:
+            sel = inl[:, 0].long()
+            p, X, p0 = p[sel], X[sel], p0[sel]
+        return hg.rodrigues_vec2mat(rvec), t, p, X, p0
+
+    def associate(self, pts1, pts_):
+        indx1, indx2, keep = ops.common_points(pts1, pts_)
+        return indx1, indx2, torch.nonzero(keep).ravel()
+
+    def errors(self, handles):
+        if not handles:
+            return []
+        sv = torch.cat([h for h, _ in handles]).cpu().numpy()         # one download for the whole sequence
+        return [float(np.sqrt(v)) / n for v, (_, n) in zip(sv, handles)]
+
+
+def make_engine(features, K, be=None, device_resident=None):
+    """The engine run_sfm would use: HBM-resident on the HIP back-end (be=None) unless device_resident=False, NumPy arrays
+    over `be` otherwise."""
     if device_resident is None:
         device_resident = be is None
     if device_resident:
         if be is not None:
             raise ops.SfmHipError("run_sfm: device_resident needs the HIP back-end")
-        return _run_sfm_device(features, K, images, log)
-    K = np.asarray(K, np.float64)
-    be = _be(be)
-    cv2 = be.cv
+        return _HipEngine(features, K)
+    return _ArrayEngine(features, K, be)
+
+
+def bootstrap_pair(eng):
+    """Images 0 and 1 (sfm.py:304-339): essential matrix, pose, first cloud, its error, and the PnP call whose inlier
+    filtering of the points survives.  Returns (state, first error handle, P1, P2)."""
+    K = eng.K
+    Rt0 = np.hstack([np.eye(3), np.zeros((3, 1))])
+    P1 = K @ Rt0
+    a, b = eng.match(0, 1)
+    E, rows = eng.essential(a, b)
+    a, b = eng.take(a, rows), eng.take(b, rows)
+    R, t, rows = eng.recover_pose(E, a, b)
+    a, b = eng.take(a, rows), eng.take(b, rows)
+    Rt1 = np.empty((3, 4))
+    Rt1[:, :3] = R @ Rt0[:, :3]
+    Rt1[:, 3] = Rt0[:, 3] + Rt0[:, :3] @ np.asarray(t, np.float64).ravel()
+    P2 = K @ Rt1
+    X = eng.triangulate(P1, P2, a, b)
+    first = eng.error(X, b, Rt1)
+    _, _, b_in, X_in, _ = eng.pnp(X, b, a)                      # (its pose is discarded, sfm.py:326)
+    return FrameState(P1, P2, a, b_in, X_in), first
+
+
+def register_next(eng, state, i):
+    """One iteration of sfm.py:341-409: register image i + 2 against the cloud of images i, i + 1.  Returns
+    (next state, dict(P, error handle, cloud (n,3), lookup (n,2) points of the new cloud in image i + 2, pnp inlier count))."""
+    K = eng.K
+    pts_, pts2 = eng.match(i + 1, i + 2)
+    cloud = state.cloud0 if state.cloud0 is not None else eng.triangulate(state.P1, state.P2, state.pts0, state.pts1)
+    indx1, indx2, rest = eng.associate(state.pts1, pts_)
+    new1, new2 = eng.take(pts_, rest), eng.take(pts2, rest)
+    R, t, p_in, _, _ = eng.pnp(eng.take(cloud, indx1), eng.take(pts2, indx2), eng.take(pts_, indx2))
+    Rt = np.hstack((np.asarray(R, np.float64), np.asarray(t, np.float64).reshape(3, 1)))
+    P = K @ Rt
+    X = eng.triangulate(state.P2, P, new1, new2)
+    out = dict(P=P, error=eng.error(X, new2, Rt), cloud=X, lookup=new2, pnp_inliers=len(p_in))
+    return FrameState(state.P2.copy(), P.copy(), pts_, pts2), out
+
+
+def run_sfm(features, K, images=None, log=None, be=None, device_resident=None):
+    """The reference's driver, sfm.py:274-423 (bundle_adjustment=False, its default).
+    features: list of (kp (n,2) float32, des (n,128) float32) per image, in sequence order.
+    images:   optional list of HxWx3 uint8 arrays for the colour lookup (sfm.py:393-394).
+    Returns dict(posearr (9+12*n_cam,), Xtot (m,3), colorstot (m,3), errors [per-frame], first_error).
+    On the HIP back-end (be=None) the per-frame state stays in HBM (`_HipEngine`); device_resident=False, or a substituted
+    backend (the tests' CPU twin), runs the same driver over NumPy arrays (`_ArrayEngine`): same operators, same results."""
+    eng = make_engine(features, K, be, device_resident)
     say = log or (lambda *a: None)
-    posearr = K.ravel()
-    R_t_0 = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0]], np.float64)
-    R_t_1 = np.empty((3, 4))
-    P1 = np.matmul(K, R_t_0)
-    Xtot = np.zeros((1, 3))               # quirk 8: leading zero row
-    colorstot = np.zeros((1, 3))
-
-    pts0, pts1 = match_features(features[0], features[1], be)
-    E, mask = cv2.findEssentialMat(pts0, pts1, K, method=cv2.RANSAC, prob=0.999, threshold=0.4, mask=None)
-    pts0 = pts0[mask.ravel() == 1]        # quirk 4: {0,1} mask
-    pts1 = pts1[mask.ravel() == 1]
-    _, R, t, mask = cv2.recoverPose(E, pts0, pts1, K)
-    pts0 = pts0[mask.ravel() > 0]         # quirk 4: {0,255} mask
-    pts1 = pts1[mask.ravel() > 0]
-    R_t_1[:3, :3] = np.matmul(R, R_t_0[:3, :3])
-    R_t_1[:3, 3] = R_t_0[:3, 3] + np.matmul(R_t_0[:3, :3], t.ravel())
-    P2 = np.matmul(K, R_t_1)
-
-    pts0, pts1, points_3d = Triangulation(P1, P2, pts0, pts1, K, repeat=False, be=be)
-    first_error, points_3d, _ = ReprojectionError(points_3d, pts1, R_t_1, K, homogenity=1, be=be)
-    say("REPROJECTION ERROR: ", first_error)
-    Rot, trans, pts1, points_3d, pts0t = PnP(points_3d, pts1, K, np.zeros((5, 1), dtype=np.float32), pts0, initial=1, be=be)
-    posearr = np.hstack((posearr, P1.ravel(), P2.ravel()))
-
-    errors = []
+    state, first = bootstrap_pair(eng)
+    poses = [eng.K.ravel(), state.P1.ravel(), state.P2.ravel()]
+    handles, clouds, lookups = [first], [], []
     for i in range(len(features) - 2):
-        pts_, pts2 = match_features(features[i + 1], features[i + 2], be)
-        if i != 0:
-            pts0, pts1, points_3d = Triangulation(P1, P2, pts0, pts1, K, repeat=False, be=be)   # quirk 6: all ratio matches
-            pts1 = pts1.T
-            points_3d = cv2.convertPointsFromHomogeneous(points_3d.T)[:, 0, :]
-        indx1, indx2, temp1, temp2 = common_points(pts1, pts_, pts2)
-        com_pts2 = pts2[indx2]
-        com_pts_ = pts_[indx2]
-        com_pts0 = pts0.T[indx1]          # quirk 5: unused, mis-indexed at i == 0 in the reference too
-        del com_pts0
-        Rot, trans, com_pts2, points_3d, com_pts_ = PnP(points_3d[indx1], com_pts2, K,
-                                                        np.zeros((5, 1), dtype=np.float32), com_pts_, initial=0, be=be)
-        Rtnew = np.hstack((Rot, trans))
-        Pnew = np.matmul(K, Rtnew)
-        error, points_3d, _ = ReprojectionError(points_3d, com_pts2, Rtnew, K, homogenity=0, be=be)
-        temp1, temp2, points_3d = Triangulation(P2, Pnew, temp1, temp2, K, repeat=False, be=be)
-        error, points_3d, _ = ReprojectionError(points_3d, temp2, Rtnew, K, homogenity=1, be=be)
-        say("Reprojection Error: ", error)
-        errors.append(error)
-        posearr = np.hstack((posearr, Pnew.ravel()))
-
-        Xtot = np.vstack((Xtot, points_3d[:, 0, :]))
-        pts1_reg = np.array(temp2, dtype=np.int32)         # quirk 10: truncation toward zero
-        if images is not None:
-            img2 = images[i + 2]
-            colors = np.array([img2[l[1], l[0]] for l in pts1_reg.T]).reshape(-1, 3)
-        else:
-            colors = np.zeros((pts1_reg.shape[1], 3))
-        colorstot = np.vstack((colorstot, colors))
-
-        R_t_0 = np.copy(R_t_1)            # quirk 7: only the last two cameras are kept
-        P1 = np.copy(P2)
-        pts0 = np.copy(pts_)
-        pts1 = np.copy(pts2)
-        P2 = np.copy(Pnew)
-    return dict(posearr=posearr, Xtot=Xtot, colorstot=colorstot, errors=errors, first_error=first_error)
-
-
-def _run_sfm_device(features, K, images=None, log=None):
-    """run_sfm with the per-frame state resident in HBM: matched points, clouds, association indices, masks and inlier
-    lists are device tensors handed from kernel to kernel; what crosses to the host per frame is one survivor count, one
-    association count, the few scalars solvePnPRansac returns, and (at the very end) the clouds, the points of the colour
-    lookup and the per-frame squared error sums.  The arithmetic is that of the array form, call for call."""
-    from . import hostgeom as hg
-    from . import ransac
-    dev = torch.device("cuda")
-    K = np.asarray(K, np.float64)
-    say = log or (lambda *a: None)
-    cache = {}
-
-    # The matches of consecutive frames (sfm.py:347: find_features(img_k, img_k+1)) do not depend on the pose chain, so the
-    # pairs of equal shape are matched up front, 8 per launch set (sfm_match_batch_l2_f32: bit-identical to per-pair
-    # calls), and their survivor counts come back in ONE download; pairs of a shape that occurs once are matched in the loop.
-    pre = {}
-    shapes = {}
-    for k in range(len(features) - 1):
-        shapes.setdefault((len(features[k][0]), len(features[k + 1][0])), []).append(k)
-    keep_all = set()
-    for plist in shapes.values():
-        if len(plist) >= 2:
-            keep_all.update(plist)
-            keep_all.update(k + 1 for k in plist)
-
-    def feat(i):          # every image's features are uploaded once (the array form uploads them for both of its pairs)
-        if i not in cache:
-            kp, des = features[i]
-            up = lambda a: a.to(dev, torch.float32).contiguous() if torch.is_tensor(a) else torch.as_tensor(np.ascontiguousarray(a, np.float32)).to(dev)
-            cache[i] = (up(kp), up(des))
-            if i - 2 not in keep_all:
-                cache.pop(i - 2, None)
-        return cache[i]
-
-    pre_counts = []
-    for (nq, nt), plist in shapes.items():
-        if len(plist) < 2 or nq == 0 or nt == 0:
-            continue
-        bm = ops.BatchMatcher(nq, nt, dev, ratio=RATIO, batch=min(8, len(plist)))
-        for c0 in range(0, len(plist), 8):
-            chunk = plist[c0:c0 + 8]
-            bm.run([(feat(k)[1], feat(k + 1)[1]) for k in chunk])
-            oq, ot, cn = bm.out_q[:len(chunk)].clone(), bm.out_t[:len(chunk)].clone(), bm.count[:len(chunk)].clone()
-            for b, k in enumerate(chunk):
-                pre[k] = (oq[b], ot[b], cn[b], len(pre_counts) + b)
-            pre_counts.extend([cn[b] for b in range(len(chunk))])
-    pre_m = torch.cat(pre_counts).cpu().tolist() if pre_counts else []
-
-    def match(i, j):      # find_features' matcher half (sfm.py:259-268)
-        (kp0, d0), (kp1, d1) = feat(i), feat(j)
-        if i in pre and j == i + 1:
-            out_q, out_t, count, slot = pre[i]
-            p0, p1 = ops.gather_matches(kp0, kp1, out_q, out_t, count)
-            m = int(pre_m[slot])
-            return p0[:m], p1[:m]
-        idx, dist = ops.knn2(d0, d1)
-        out_q, out_t, count = ops.ratio_compact(idx, dist, RATIO)
-        p0, p1 = ops.gather_matches(kp0, kp1, out_q, out_t, count)
-        m = int(count.item())
-        return p0[:m], p1[:m]
-
-    def triangulate(Pa, Pb, a, b):      # Triangulation (sfm.py:45-56) on (M,2) device points -> (4,M), w == 1
-        return ops.triangulate(Pa, Pb, a.t(), b.t(), rows=cv2.TRIANGULATE_ROWS, normalise_w=True)
-
-    def reproj_sumsq(X4, obs, Rt):      # ReprojectionError (sfm.py:79-100): the squared error sum stays on the device
-        r = hg.rodrigues_mat2vec(Rt[:3, :3])
-        cams = torch.as_tensor(np.hstack([r, Rt[:3, 3]])[None]).to(dev)
-        Xf = X4[:3].t().contiguous()
-        return ops.project_residual(cams, K, Xf, obs.contiguous(), want_proj=False)["sumsq"], Xf
-
-    def pnp(X, p, p_0):                 # PnP (sfm.py:60-76)
-        ok, rvec, t, inl = ransac.solve_pnp_ransac(X, p, K, return_device_inliers=True)
-        R = hg.rodrigues_vec2mat(rvec)
-        if inl is not None:
-            sel = inl[:, 0].long()
-            p, X, p_0 = p[sel], X[sel], p_0[sel]
-        return R, t, p, X, p_0
-
-    posearr = K.ravel()
-    R_t_0 = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0]], np.float64)
-    R_t_1 = np.empty((3, 4))
-    P1 = np.matmul(K, R_t_0)
-    pts0, pts1 = match(0, 1)
-    E, mask = ransac.find_essential_mat(pts0, pts1, K, 0.999, 0.4, return_device_mask=True)
-    sel = torch.nonzero(mask.ravel() == 1).ravel()            # quirk 4: {0,1} mask
-    pts0, pts1 = pts0[sel], pts1[sel]
-    _, R, t, mask = ransac.recover_pose(E, pts0, pts1, K, return_device_mask=True)
-    sel = torch.nonzero(mask.ravel() > 0).ravel()             # quirk 4: {0,255} mask
-    pts0, pts1 = pts0[sel], pts1[sel]
-    R_t_1[:3, :3] = np.matmul(R, R_t_0[:3, :3])
-    R_t_1[:3, 3] = R_t_0[:3, 3] + np.matmul(R_t_0[:3, :3], t.ravel())
-    P2 = np.matmul(K, R_t_1)
-    X4 = triangulate(P1, P2, pts0, pts1)
-    ss, Xf = reproj_sumsq(X4, pts1, R_t_1)
-    first_error = float(np.sqrt(ss.item())) / len(pts1)
-    say("REPROJECTION ERROR: ", first_error)
-    Rot, trans, pts1, points_3d, _ = pnp(Xf, pts1, pts0)      # only its inlier filtering of pts1 / points_3d survives
-    posearr = np.hstack((posearr, P1.ravel(), P2.ravel()))
-
-    sums, counts, clouds, lookups = [], [], [], []
-    for i in range(len(features) - 2):
-        pts_, pts2 = match(i + 1, i + 2)
-        if i != 0:
-            points_3d = triangulate(P1, P2, pts0, pts1)[:3].t().contiguous()       # quirk 6: all ratio matches
-        indx1, indx2, keep = ops.common_points(pts1, pts_)
-        i1, i2 = indx1.long(), indx2.long()
-        rest = torch.nonzero(keep).ravel()
-        temp1, temp2 = pts_[rest], pts2[rest]
-        Rot, trans, com_pts2, points_3d, com_pts_ = pnp(points_3d[i1], pts2[i2], pts_[i2])
-        Rtnew = np.hstack((Rot, trans))
-        Pnew = np.matmul(K, Rtnew)
-        X4 = triangulate(P2, Pnew, temp1, temp2)
-        ss, Xf = reproj_sumsq(X4, temp2, Rtnew)
-        sums.append(ss)
-        counts.append(len(temp2))
+        state, out = register_next(eng, state, i)
+        poses.append(out["P"].ravel())
+        handles.append(out["error"])
+        clouds.append(out["cloud"])
+        lookups.append(out["lookup"])
         if log is not None:
-            say("Reprojection Error: ", float(np.sqrt(ss.item())) / len(temp2))
-        posearr = np.hstack((posearr, Pnew.ravel()))
-        clouds.append(Xf)
-        lookups.append(temp2)
-        P1, P2 = np.copy(P2), np.copy(Pnew)
-        pts0, pts1 = pts_, pts2
-    # one download at the end: error sums, clouds, colour-lookup coordinates
-    if sums:
-        sv = torch.cat(sums).cpu().numpy()
-        errors = [float(np.sqrt(v)) / n for v, n in zip(sv, counts)]
-        Xtot = np.vstack([np.zeros((1, 3))] + [c.cpu().numpy() for c in clouds])      # quirk 8: leading zero row
-    else:
-        errors, Xtot = [], np.zeros((1, 3))
+            say("Reprojection Error: ", eng.errors([out["error"]])[0])
+    errs = eng.errors(handles)
+    Xtot = np.vstack([np.zeros((1, 3))] + [eng.host(c) for c in clouds])             # quirk 8: leading zero row
     cols = [np.zeros((1, 3))]
-    for i, t2 in enumerate(lookups):
-        reg = np.array(t2.cpu().numpy().T, dtype=np.int32)                            # quirk 10: truncation toward zero
-        if images is not None:
-            img2 = images[i + 2]
-            cols.append(np.array([img2[l[1], l[0]] for l in reg.T]).reshape(-1, 3))
-        else:
-            cols.append(np.zeros((reg.shape[1], 3)))
-    return dict(posearr=posearr, Xtot=Xtot, colorstot=np.vstack(cols), errors=errors, first_error=first_error)
+    for i, pts in enumerate(lookups):
+        reg = np.array(eng.host(pts), dtype=np.int32)                                # quirk 10: truncation toward zero
+        cols.append(images[i + 2][reg[:, 1], reg[:, 0]].reshape(-1, 3) if images is not None else np.zeros((len(reg), 3)))
+    return dict(posearr=np.hstack(poses), Xtot=Xtot, colorstot=np.vstack(cols), errors=errs[1:], first_error=errs[0])
 
 
 def save_pose_csv(path, posearr):
