@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--workload", default="knn", choices=["knn", "tri", "ba", "sfm", "c5", "sift"])
     ap.add_argument("--nq", type=int, default=10000)
     ap.add_argument("--nt", type=int, default=10000)
-    ap.add_argument("--images", type=int, default=32, help="workload c5: images in the sequence (BASELINE config 5 has 256)")
+    ap.add_argument("--images", type=int, default=256, help="workload c5: images in the sequence IN TOTAL (BASELINE config 5: 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--pipe-depth", type=int, default=PIPE_DEPTH, help="launch sets in flight per GPU (1 = one stream)")
@@ -731,55 +731,84 @@ def bench_ba(args, world, rank, dev):
 
 
 def bench_c5(args, world, rank, dev):
-    """BASELINE configs[4] shape on this rank's share: a sequence of images with 50 000 SIFT-like descriptors each,
-    image k+1 containing 30 % planted matches of image k; sequential pairs (k, k+1) as in sfm.py:347, all descriptors
-    resident in HBM, pairs pipelined over streams.  Checks that the planted matches are what survives the ratio test."""
-    from sfm_mvs_amd import ops
-    n_img, n_desc = max(2, args.images), 50_000
-    g = torch.Generator(device=dev).manual_seed(100 + rank)
+    """BASELINE configs[4] as written: `--images` (256) images x 50 000 SIFT-like descriptors in TOTAL, sequential pairs
+    (k, k+1) as in sfm.py:347 sharded over the ranks through the package's one multi-GPU code path —
+    sharded.match_pairs_sharded (halo partition: a rank generates and holds only its block's images + one halo image;
+    the KNN blocks of 8 pairs per RCCL all-gather, inside the timed region) followed by sharded.triangulate_pairs_sharded
+    (DLT of every Lowe survivor on the owning rank, all-gather of the float32 x 4 points).  STRONG scaling: the job is the
+    same 255 pairs whatever N.  Image k + 1 carries 30 % planted twins of image k; they must come back as nearest neighbours."""
+    from sfm_mvs_amd import sharded
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from datagen import load_pose_csv
+    n_img, n_desc, n_plant = max(2, args.images), 50_000, 15_000
+    pairs = sharded.sequential_pairs(n_img)
 
-    def sift_like(n):
-        d = torch.randn((n, 128), generator=g, device=dev).abs_().square_()
+    def base(k):          # image k before its planted rows: a function of k alone, so every rank generates the same image
+        g = torch.Generator(device=dev).manual_seed(100 + k)
+        d = torch.randn((n_desc, 128), generator=g, device=dev).abs_().square_()
         d /= d.norm(dim=1, keepdim=True)
         d = torch.minimum(d, torch.tensor(0.2, device=dev))
         d /= d.norm(dim=1, keepdim=True)
-        return (d * 512).round_().clamp_(0, 255)
+        return (d * 512).round_().clamp_(0, 255), g
 
-    imgs, planted = [sift_like(n_desc)], []
-    for k in range(1, n_img):
-        nxt = sift_like(n_desc)
-        src = torch.randperm(n_desc, generator=g, device=dev)[: int(0.3 * n_desc)]
-        dst = torch.randperm(n_desc, generator=g, device=dev)[: int(0.3 * n_desc)]
-        nxt[dst] = (imgs[-1][src] + torch.randn((len(src), 128), generator=g, device=dev).mul_(2).round_()).clamp_(0, 255)
-        imgs.append(nxt)
-        planted.append((2 * src, dst.to(torch.int32)))            # position of trainIdx[src][0] in the flat [nq][2] result
-    pipe = ops.PairPipeline(n_desc, n_desc, dev, ratio=0.70, depth=PIPE_DEPTH)
-    for k in range(min(3, n_img - 1)):                       # warm-up
-        pipe.submit(imgs[k], imgs[k + 1], after=False)
+    def image(k):         # rows [0, n_plant) = noisy twins of rows >= n_plant of image k - 1 (rows no image overwrites)
+        d, g = base(k)
+        if k == 0:
+            return d, None
+        src = n_plant + torch.randperm(n_desc - n_plant, generator=g, device=dev)[:n_plant]
+        d[:n_plant] = (base(k - 1)[0][src] + torch.randn((n_plant, 128), generator=g, device=dev).mul_(2).round_()).clamp_(0, 255)
+        return d, src
+
+    mine = sharded.halo_images(pairs, world, rank)
+    imgs, planted = [None] * n_img, [None] * n_img
+    for k in mine:
+        imgs[k], planted[k] = image(k)
+    g = torch.Generator(device="cpu").manual_seed(7)
+    kps = [torch.rand((n_desc, 2), generator=g).mul_(900.0).to(dev) if k in mine else None for k in range(n_img)]
+    _, P = load_pose_csv()
+    proj = [P[k % len(P)] for k in range(n_img)]
+    eng = sharded.HipMatchEngine(dev, 0.70, depth=PIPE_DEPTH)
+    warm = [(mine[0], mine[1])] * 3 if len(mine) >= 2 else []
+    if warm:                                                 # warm-up: streams, kernels, the collective
+        wd = [imgs[k] if k in (mine[0], mine[1]) else None for k in range(n_img)]
+        wpairs = [(mine[0], mine[1])] * world * 3
+        wstore, wnq = sharded.match_pairs_sharded(wd, wpairs, n_desc=[n_desc] * n_img, engine=eng, device=dev, batch=EXCH_BATCH)
+        sharded.triangulate_pairs_sharded(wstore, wnq, wpairs, kps, proj, batch=EXCH_BATCH)
+        del wstore
     barrier_sync(world)
-    pairs = n_img - 1
-    counts = torch.zeros(pairs, dtype=torch.int32, device=dev)
-    nn1 = torch.empty((pairs, n_desc, 2), dtype=torch.int32, device=dev)     # every pair's trainIdx block, kept for the check
+    st_m, st_t = {}, {}
     t0 = time.perf_counter()
-    for k in range(pairs):
-        slot, st, (idx, dist, oq, ot, cnt) = pipe.submit(imgs[k], imgs[k + 1], after=False)
-        with torch.cuda.stream(st):                          # consume the result on the pair's own stream, before the slot is
-            counts[k].copy_(cnt[0], non_blocking=True)       # reused (plain copies into preallocated buffers: no allocator traffic)
-            nn1[k].copy_(idx, non_blocking=True)
+    store, nq = sharded.match_pairs_sharded(imgs, pairs, n_desc=[n_desc] * n_img, engine=eng, device=dev, batch=EXCH_BATCH, stats=st_m)
+    torch.cuda.synchronize()
+    t_match = time.perf_counter() - t0
+    pts, counts = sharded.triangulate_pairs_sharded(store, nq, pairs, kps, proj, batch=EXCH_BATCH, stats=st_t)
     barrier_sync(world)
     elapsed = max_over_ranks(time.perf_counter() - t0, world, dev)
-    hits = sum(int((nn1[k].reshape(-1).index_select(0, planted[k][0]) == planted[k][1]).sum().item()) for k in range(pairs))
-    frac_hit = hits / (pairs * int(0.3 * n_desc))
-    return {"metric": "descriptor-pair distances/sec over an image sequence (BF-KNN k=2 + Lowe ratio)",
-            "value": world * pairs * n_desc * n_desc / elapsed, "unit": "distances/s", "n_gpus": world, "steps": pairs, "warmup": 3,
-            "ms_per_step": elapsed / pairs * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+    t_match = max_over_ranks(t_match, world, dev)
+    # every rank holds every pair's block: planted twins recovered as nearest neighbours (checked for the pairs whose source
+    # rows this rank knows, i.e. whose train image it generated)
+    hits = tot = 0
+    for p, (i, j) in enumerate(pairs):
+        if planted[j] is not None:
+            # query = image i rows `src`, train = image j rows [0, n_plant): twin of query row src[r] is train row r
+            hits += int((store[p, 0, :, 0].index_select(0, planted[j]) == torch.arange(n_plant, device=dev, dtype=torch.int32)).sum().item())
+            tot += n_plant
+    n_pairs = len(pairs)
+    return {"metric": "descriptor-pair distances/sec over an image sequence (BF-KNN k=2 + Lowe ratio), pair-sharded with the match-record and 3-D point all-gathers",
+            "value": n_pairs * n_desc * n_desc / elapsed, "unit": "distances/s", "n_gpus": world, "steps": n_pairs, "warmup": 3,
+            "ms_per_step": elapsed / n_pairs * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32 results; filter arithmetic fp16 single product (exact for integer descriptors)", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[4] shape: {n_img} images x 50k SIFT-like descriptors per GPU, sequential pairs, "
-                                   "30 % planted matches", "images": n_img, "descriptors": n_desc,
-                       "parallelism": f"pair-sharded x{world}; {PIPE_DEPTH} pairs in flight per GPU"},
-            "planted_matches_recovered_as_nearest_neighbour": frac_hit,
-            "ratio_survivors_per_pair_mean": float(counts.float().mean().item()),
-            "seconds_for_256_images_at_this_rate": 255 * n_desc * n_desc / (world * pairs * n_desc * n_desc / elapsed)}
+            "config": {"workload": f"BASELINE configs[4]: {n_img} images x 50k SIFT-like descriptors in total, {n_pairs} sequential pairs sharded "
+                                   f"{world}-way (halo partition), RCCL all-gather of the KNN blocks ({EXCH_BATCH} pairs per collective) and of the "
+                                   "triangulated points, 30 % planted matches", "images": n_img, "descriptors": n_desc,
+                       "parallelism": f"pair-sharded x{world} (sharded.match_pairs_sharded + triangulate_pairs_sharded); {PIPE_DEPTH} pairs in flight per GPU"},
+            "job_seconds": elapsed, "match_seconds": t_match, "triangulate_and_gather_seconds": elapsed - t_match,
+            "images_resident_on_this_rank": len(mine),
+            "exchange": {"match_records": st_m, "points": st_t,
+                         "note": "device time between the events bracketing each all_gather_into_tensor (includes waiting for the batch's producers)"},
+            "triangulated_points_total": int(counts.sum().item()),
+            "planted_matches_recovered_as_nearest_neighbour": hits / max(tot, 1),
+            "ratio_survivors_per_pair_mean": float(counts.float().mean().item())}
 
 
 def bench_sift(args, world, rank, dev):

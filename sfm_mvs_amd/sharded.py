@@ -39,10 +39,48 @@ def all_pairs(n_images):
     return [(j, i) for i in range(n_images) for j in range(i)]
 
 
-def halo_images(pairs, world, rank):
-    """Images rank `rank` must hold to match its block of `pairs`: for sequential pairs its own images + one halo image."""
-    lo, hi = shard_range(len(pairs), world, rank)
-    return sorted({i for p in pairs[lo:hi] for i in p})
+def contiguous_partition(n_pairs, world):
+    """The default split: rank r owns the contiguous block shard_range(n_pairs, world, r) of the pair list."""
+    return [np.arange(*shard_range(n_pairs, world, r)) for r in range(world)]
+
+
+def process_grid(world):
+    """pr x pc with pr the largest divisor of `world` not above its square root (8 -> 2 x 4)."""
+    pr = max(d for d in range(1, int(world ** 0.5) + 1) if world % d == 0)
+    return pr, world // pr
+
+
+def block_cyclic_partition(pairs, n_images, world, block=None):
+    """SURVEY 8e's split for EXHAUSTIVE matching (isfm.py:56-71: every j < i): the (j, i) pair grid is cut into
+    block x block tiles of images and tile (bj, bi) goes to rank (bj mod pr) * pc + (bi mod pc) of a pr x pc process grid.
+    A rank then touches only the image blocks of its grid row and grid column — about n / pr + n / pc images instead of
+    nearly all n with a contiguous split of the pair list (the halo does not depend on the tile size) — and the cyclic deal
+    balances the triangular pair region: the heaviest rank carries 1 + O(pc block / n) of the mean (256 images over 2 x 4:
+    1.67 x the lightest at block 16, 1.13 x at 4, 1.06 x at 2); block defaults to n / (32 pc), at least 1.  Returns the list over ranks of pair-index
+    arrays (indices into `pairs`, ascending), usable as `partition=` below."""
+    pr, pc = process_grid(world)
+    if block is None:
+        block = max(1, n_images // (32 * pc))
+    owner = [[] for _ in range(world)]
+    for p, (j, i) in enumerate(pairs):
+        owner[((j // block) % pr) * pc + ((i // block) % pc)].append(p)
+    return [np.asarray(o, dtype=np.int64) for o in owner]
+
+
+def halo_images(pairs, world, rank, partition=None):
+    """Images rank `rank` must hold to match its pairs: for sequential pairs (contiguous split) its own images + one halo
+    image; for a block-cyclic split of all pairs the image blocks of its process-grid row and column."""
+    mine = (partition or contiguous_partition(len(pairs), world))[rank]
+    return sorted({i for p in mine for i in pairs[int(p)]})
+
+
+def _round_targets(partition, rd, batch, dump):
+    """Destination pair index of every (rank, slot) of round `rd` (unused slots go to the dump row)."""
+    dst = torch.full((len(partition), batch), dump, dtype=torch.int64)
+    for r, part in enumerate(partition):
+        k = part[rd * batch:(rd + 1) * batch]
+        dst[r, :len(k)] = torch.from_numpy(np.asarray(k, dtype=np.int64))
+    return dst
 
 
 def _world_rank(group):
@@ -158,11 +196,12 @@ def ratio_survivors(block, nq, ratio=0.70):
     return q, idx[q, 0].long()
 
 
-def match_pairs_sharded(descriptors, pairs, n_desc=None, engine=None, group=None, device=None, batch=8, ratio=0.70):
+def match_pairs_sharded(descriptors, pairs, n_desc=None, engine=None, group=None, device=None, batch=8, ratio=0.70, partition=None, stats=None):
     """descriptors: list over images of [n_i,128] float32 tensors — None for images this rank never touches
     (`halo_images`); pairs: list of (i, j); n_desc: descriptor count of EVERY image (needed for images held elsewhere;
     taken from `descriptors` when all are present).  Every rank matches its block of pairs and the KNN blocks are
-    all-gathered `batch` pairs at a time.  Returns, on every rank, (store, n_query): store int32 [n_pairs][2][cap][2]
+    all-gathered `batch` pairs at a time.  partition: list over ranks of pair-index arrays (default: contiguous blocks;
+    `block_cyclic_partition` for exhaustive pair lists).  Returns, on every rank, (store, n_query): store int32 [n_pairs][2][cap][2]
     with store[p][0] = trainIdx x2 and store[p][1] = float32 distance bits x2 of pair p's n_query[p] queries."""
     world, rank = _world_rank(group)
     if n_desc is None:
@@ -172,29 +211,27 @@ def match_pairs_sharded(descriptors, pairs, n_desc=None, engine=None, group=None
     cap = max((n_desc[i] for i, _ in pairs), default=0)
     engine = engine or HipMatchEngine(dev, ratio)
     ex = BatchedExchange((2, cap, 2), torch.int32, dev, batch, group)
-    spans = [shard_range(n_pairs, world, r) for r in range(world)]
-    lo, hi = spans[rank]
-    per = max((h - l for l, h in spans), default=0)
+    partition = partition or contiguous_partition(n_pairs, world)
+    mine = partition[rank]
+    per = max((len(part) for part in partition), default=0)
     store = torch.zeros((n_pairs + 1, 2, cap, 2), dtype=torch.int32, device=dev)      # [+1]: dump row for unused slots
     for rd in range(-(-per // batch) if per else 0):
-        for b in range(batch):
-            p = lo + rd * batch + b
-            if p < hi:
-                i, j = pairs[p]
-                slot, ev = ex.next_slot()
-                engine.match(descriptors[i], descriptors[j], slot, after=ev)
-                ex.commit()
+        for p in mine[rd * batch:(rd + 1) * batch]:
+            i, j = pairs[int(p)]
+            slot, ev = ex.next_slot()
+            engine.match(descriptors[i], descriptors[j], slot, after=ev)
+            ex.commit()
         gathered, _ = ex.flush(getattr(engine, "streams", ()))
         # scatter the round's blocks to their pairs in ONE indexed copy (unused slots go to the dump row)
-        dst = torch.full((world, batch), n_pairs, dtype=torch.int64)
-        for r, (l, h) in enumerate(spans):
-            k = np.arange(batch) + l + rd * batch
-            dst[r] = torch.from_numpy(np.where(k < h, k, n_pairs))
+        dst = _round_targets(partition, rd, batch, n_pairs)
         store.index_copy_(0, dst.reshape(-1).to(dev), gathered.reshape((world * batch,) + gathered.shape[2:]))
+    if stats is not None:                                  # (bench.py: device time inside the collectives, their number and size)
+        stats.update(exchange_ms=ex.exchange_ms() if ex.cuda else 0.0, collectives=ex.collectives,
+                     bytes_per_rank_per_collective=batch * 2 * cap * 2 * 4)
     return store[:n_pairs], [n_desc[i] for i, _ in pairs]
 
 
-def triangulate_pairs_sharded(store, n_query, pairs, keypoints, proj, triangulate=None, group=None, batch=8, ratio=0.70):
+def triangulate_pairs_sharded(store, n_query, pairs, keypoints, proj, triangulate=None, group=None, batch=8, ratio=0.70, partition=None, stats=None):
     """The path's second exchange (north_star: "all-gather of 3D points"): every rank triangulates the Lowe survivors of
     ITS pairs (sfm.py:349,371: cv2.triangulatePoints + division by w) and the float32 x 4 points are all-gathered.
     keypoints: list over images of [n_i,2] float32 (None where not held: a rank needs its block + halo, as for the
@@ -210,33 +247,40 @@ def triangulate_pairs_sharded(store, n_query, pairs, keypoints, proj, triangulat
         def triangulate(P1, P2, x1, x2):
             return ops.triangulate(P1, P2, x1, x2, normalise_w=True)
     ex = BatchedExchange((4, cap), torch.float32, dev, batch, group)
-    spans = [shard_range(n_pairs, world, r) for r in range(world)]
-    lo, hi = spans[rank]
-    per = max((h - l for l, h in spans), default=0)
+    partition = partition or contiguous_partition(n_pairs, world)
+    mine = partition[rank]
+    per = max((len(part) for part in partition), default=0)
     points = torch.zeros((n_pairs + 1, 4, cap), dtype=torch.float32, device=dev)
-    # the survivor counts are a function of the gathered KNN blocks: every rank derives all of them, no collective
-    counts = torch.tensor([len(ratio_survivors(store[p], n_query[p], ratio)[0]) for p in range(n_pairs)], dtype=torch.int64)
+    # The Lowe survivors are a function of the gathered KNN blocks: every rank derives the mask of EVERY pair in one
+    # vectorised pass (sfm.py:262-265: float32 distances promoted to double, strict <), the counts come back in ONE download,
+    # and a pair's ascending survivor list is the head of a stable sort of its mask — no per-pair host synchronisation.
+    nqv = torch.as_tensor(np.asarray(n_query, dtype=np.int64), device=dev)
+    d = store[:, 1].view(torch.float32).to(torch.float64)
+    keep = (store[:, 0, :, 1] >= 0) & (d[:, :, 0] < ratio * d[:, :, 1]) & (torch.arange(cap, device=dev)[None, :] < nqv[:, None])
+    del d
+    counts = keep.sum(1).cpu()
+    mine_t = torch.as_tensor(np.asarray(mine, dtype=np.int64), device=dev)
+    order = torch.sort((~keep[mine_t]).to(torch.uint8), dim=1, stable=True).indices if len(mine) else None
     for rd in range(-(-per // batch) if per else 0):
-        for b in range(batch):
-            p = lo + rd * batch + b
-            if p < hi:
-                i, j = pairs[p]
-                q, t = ratio_survivors(store[p], n_query[p], ratio)
-                slot, ev = ex.next_slot()
-                if ev is not None:
-                    torch.cuda.current_stream(dev).wait_event(ev)
-                slot.zero_()                                     # (the buffer still holds the points of two rounds ago)
-                if len(q):
-                    x1 = keypoints[i].to(dev)[q].t().contiguous()
-                    x2 = keypoints[j].to(dev)[t].t().contiguous()
-                    slot[:, :len(q)].copy_(triangulate(proj[i], proj[j], x1, x2))
-                ex.commit()
+        for k, p in enumerate(mine[rd * batch:(rd + 1) * batch]):
+            p = int(p)
+            i, j = pairs[p]
+            m = int(counts[p])
+            q = order[rd * batch + k, :m]
+            slot, ev = ex.next_slot()
+            if ev is not None:
+                torch.cuda.current_stream(dev).wait_event(ev)
+            slot.zero_()                                     # (the buffer still holds the points of two rounds ago)
+            if m:
+                x1 = keypoints[i].to(dev)[q].t().contiguous()
+                x2 = keypoints[j].to(dev)[store[p, 0, q, 0].long()].t().contiguous()
+                slot[:, :m].copy_(triangulate(proj[i], proj[j], x1, x2))
+            ex.commit()
         gathered, _ = ex.flush()
-        dst = torch.full((world, batch), n_pairs, dtype=torch.int64)
-        for r, (l, h) in enumerate(spans):
-            k = np.arange(batch) + l + rd * batch
-            dst[r] = torch.from_numpy(np.where(k < h, k, n_pairs))
+        dst = _round_targets(partition, rd, batch, n_pairs)
         points.index_copy_(0, dst.reshape(-1).to(dev), gathered.reshape((world * batch,) + gathered.shape[2:]))
+    if stats is not None:
+        stats.update(exchange_ms=ex.exchange_ms() if ex.cuda else 0.0, collectives=ex.collectives, bytes_per_rank_per_collective=batch * 4 * cap * 4)
     return points[:n_pairs], counts
 
 

@@ -39,7 +39,7 @@ def _scene(n_images, seed):
     return des, kps
 
 
-def _worker(rank, world, port, n_images, batch, ret, all_pairs=False):
+def _worker(rank, world, port, n_images, batch, ret, all_pairs=False, cyclic=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -52,12 +52,13 @@ def _worker(rank, world, port, n_images, batch, ret, all_pairs=False):
     des, kps = _scene(n_images, 0)
     n_desc = [len(d) for d in des]
     pairs = sharded.all_pairs(n_images) if all_pairs else sharded.sequential_pairs(n_images)    # isfm.py:56-71 / sfm.py:347
-    mine = sharded.halo_images(pairs, world, rank)
-    lo, hi = sharded.shard_range(len(pairs), world, rank)
+    part = sharded.block_cyclic_partition(pairs, n_images, world, block=2) if cyclic else None
+    mine = sharded.halo_images(pairs, world, rank, part)
+    lo, hi = (0, len(part[rank])) if cyclic else sharded.shard_range(len(pairs), world, rank)
     held = [d if i in mine else None for i, d in enumerate(des)]        # the halo partition: nothing else is resident
     held_kp = [k if i in mine else None for i, k in enumerate(kps)]
     eng = OracleEngine(O)
-    store, nq = sharded.match_pairs_sharded(held, pairs, n_desc=n_desc, engine=eng, device=torch.device("cpu"), batch=batch)
+    store, nq = sharded.match_pairs_sharded(held, pairs, n_desc=n_desc, engine=eng, device=torch.device("cpu"), batch=batch, partition=part)
     ok = eng.calls == hi - lo and (all_pairs or len(mine) == (hi - lo + 1 if hi > lo else 0))
     total = 0
     for p, (i, j) in enumerate(pairs):                                  # every pair's block, on every rank, = the oracle's
@@ -73,7 +74,7 @@ def _worker(rank, world, port, n_images, batch, ret, all_pairs=False):
     def tri(P1, P2, x1, x2):
         return torch.from_numpy(O.triangulate(P1, P2, x1.numpy(), x2.numpy(), normalise_w=True))
 
-    pts, counts = sharded.triangulate_pairs_sharded(store, nq, pairs, held_kp, list(P[:n_images]), triangulate=tri, batch=batch)
+    pts, counts = sharded.triangulate_pairs_sharded(store, nq, pairs, held_kp, list(P[:n_images]), triangulate=tri, batch=batch, partition=part)
     for p, (i, j) in enumerate(pairs):
         q, t = sharded.ratio_survivors(store[p], nq[p])
         m = int(counts[p])
@@ -103,6 +104,38 @@ def test_two_rank_all_pairs():
     ret = mp.Manager().dict()
     mp.spawn(_worker, args=(2, 29523, 5, 4, ret, True), nprocs=2, join=True)
     assert ret[0][0] and ret[1][0] and ret[0][1] + ret[1][1] == 10 and ret[0][2] == ret[1][2]
+
+
+def test_two_rank_all_pairs_block_cyclic():
+    """The exhaustive pair list under SURVEY 8e's 2-D block-cyclic split (2 x 2-image tiles dealt to a 1 x 2 process grid):
+    7 images -> 21 pairs; every pair's block and points still arrive on every rank, a rank holds only the images its
+    tiles name."""
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(2, 29525, 7, 4, ret, True, True), nprocs=2, join=True)
+    assert ret[0][0] and ret[1][0] and ret[0][1] + ret[1][1] == 21 and ret[0][2] == ret[1][2]
+
+
+def test_block_cyclic_partition_covers_all_pairs_with_small_halos():
+    """isfm.py:56-71 at config-5 scale: 256 images -> 32 640 pairs over 8 ranks (2 x 4 grid, 16-image tiles).  Every pair
+    is owned exactly once, the loads are balanced, and a rank touches the image blocks of one grid row and one grid
+    column: at most n / pr + n / pc = 192 images — a contiguous split of the pair list needs all 256 on its last rank (the
+    resident set is sized by the worst rank)."""
+    from sfm_mvs_amd.sharded import all_pairs, block_cyclic_partition, contiguous_partition, halo_images, process_grid
+    assert process_grid(8) == (2, 4) and process_grid(4) == (2, 2) and process_grid(2) == (1, 2) and process_grid(1) == (1, 1)
+    n, world = 256, 8
+    pairs = all_pairs(n)
+    part = block_cyclic_partition(pairs, n, world)
+    allp = np.sort(np.concatenate(part))
+    assert np.array_equal(allp, np.arange(len(pairs)))
+    sizes = [len(x) for x in part]
+    assert max(sizes) <= 1.15 * min(sizes), sizes
+    halos = [len(halo_images(pairs, world, r, part)) for r in range(world)]
+    assert max(halos) <= n // 2 + n // 4, halos
+    cont = [len(halo_images(pairs, world, r, contiguous_partition(len(pairs), world))) for r in range(world)]
+    assert max(cont) == n and max(halos) <= 0.75 * n, (cont, halos)
+    for w in (1, 2, 3, 4, 6):                                # any world size: a partition, nothing lost
+        pt = block_cyclic_partition(all_pairs(37), 37, w)
+        assert np.array_equal(np.sort(np.concatenate(pt)), np.arange(37 * 36 // 2))
 
 
 def _train_split_worker(rank, world, port, ret):
