@@ -182,6 +182,11 @@ int sfm_common_points(const float* pts1_dev, int64_t n1, const float* pts2_dev, 
  *   points, within 1 float32 ulp otherwise; lanes that do not converge (degenerate geometry)
  *   run the Jacobi sweeps.  The un-normalised vector (normalise_w = 0) has OpenCV's sign and
  *   is only offered by the faithful path.
+ * normalise_w = 3 (rows = 4 only) is the GUARDED fast path: the result of 2 is kept only where every component of the unit
+ *   vector keeps a margin of max(2^-40, 16 eps lambda1/lambda3) from the nearest float32 rounding boundary (the distance
+ *   two backward-stable solutions of this point can have; lambda1/lambda3 is read off the iteration), the other points —
+ *   a fraction of a percent on well-conditioned geometry, all of them when the baseline vanishes — are redone by the
+ *   Jacobi sweeps in a second, compacted pass: bit-identical to normalise_w = 1 on every point.
  *
  *   P1, P2        HOST pointers, 12 doubles each, row-major 3x4
  *   x1_dev,x2_dev float32; point i has x at [i*stride_pt] and y at

@@ -1,0 +1,31 @@
+import sys, numpy as np, torch
+sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+from sfm_mvs_amd import ops
+from datagen import load_pose_csv
+K, P = load_pose_csv()
+n = 400_000
+rng = np.random.default_rng(5)
+X = np.stack([rng.uniform(-6.3, 3.6, n), rng.uniform(-2.6, 5.0, n), rng.uniform(3.2, 13.0, n)], 1)
+Xh = np.c_[X, np.ones(n)].T
+def obs(Pm, s): 
+    x = Pm @ Xh
+    return torch.from_numpy(((x[:2] / x[2]).T + rng.normal(0, s, (n, 2))).astype(np.float32)).cuda().t()
+for name, Pa, Pb in [("pose1-2", P[1], P[2]), ("pose1-5", P[1], P[5]), ("pose10-40", P[10], P[40])] + [(f"baseline {b:g}", P[1], None) for b in (1.0, 1e-1, 1e-2, 1e-3, 1e-4)]:
+    if Pb is None:
+        b = float(name.split()[1]); Pb = P[1].copy(); Pb[:, 3] += P[1][:, :3] @ np.array([b, 0.0, 0.0])
+    for s in (0.0, 0.3, 3.0):
+        a, c = obs(Pa, s), obs(Pb, s)
+        f = ops.triangulate(Pa, Pb, a, c, normalise_w=True)
+        g = ops.triangulate(Pa, Pb, a, c, normalise_w="guarded")
+        fast = ops.triangulate(Pa, Pb, a, c, normalise_w="fast")
+        bad = int((f.view(torch.int32) != g.view(torch.int32)).any(0).sum())
+        badf = int((f.view(torch.int32) != fast.view(torch.int32)).any(0).sum())
+        print(f"{name:16s} sigma {s:3.1f}: guarded mismatches {bad:6d}  (plain fast path: {badf})")
+
+import time
+a, c = obs(P[1], 0.3), obs(P[2], 0.3)
+for mode in (True, "guarded", "fast"):
+    for _ in range(3): ops.triangulate(P[1], P[2], a, c, normalise_w=mode)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(20): r = ops.triangulate(P[1], P[2], a, c, normalise_w=mode)
+    torch.cuda.synchronize(); print(mode, f"{n * 20 / (time.perf_counter() - t0):.3e} pts/s")

@@ -12,6 +12,7 @@
 // lane owns a point and a wave solves 64 points in lockstep.
 #include "common.h"
 #include <cfloat>
+#include <cstdlib>
 
 namespace {
 
@@ -155,7 +156,7 @@ __device__ __forceinline__ void dlt_build(double (&At)[4][M], const double* __re
 // orthogonal to the solution, lambda3 ~ lambda4: degenerate geometry) runs the Jacobi path instead.  Returns false then.
 constexpr int kFastIters = 12;
 
-__device__ __forceinline__ bool dlt_nullvec_fast(const double (&At)[4][4], double (&X)[4]) {
+__device__ __forceinline__ bool dlt_nullvec_fast(const double (&At)[4][4], double (&X)[4], double* sens = nullptr) {
     // M = A^T A (At[k] is column k of A)
     double m[4][4];
 #pragma unroll
@@ -180,6 +181,7 @@ __device__ __forceinline__ bool dlt_nullvec_fast(const double (&At)[4][4], doubl
     if (!(d0 > 0 && d1 > 0 && d2 > 0 && d3 > 0)) return false;
     double v0 = 0.5, v1 = 0.5, v2 = 0.5, v3 = 0.5;
     bool done = false;
+    double diff_prev = 0.0, rho = 0.0, growth = 0.0;
     for (int it = 0; it < kFastIters && !done; ++it) {
         // L y = v
         const double y0 = v0;
@@ -198,26 +200,47 @@ __device__ __forceinline__ bool dlt_nullvec_fast(const double (&At)[4][4], doubl
         const double diff = fmax(fmax(fabs(n0 - v0), fabs(n1 - v1)), fmax(fabs(n2 - v2), fabs(n3 - v3)));
         v0 = n0; v1 = n1; v2 = n2; v3 = n3;
         done = diff < 1e-13;
+        // contraction of this step, taken only while the step is still well above the rounding floor (a floored step would
+        // overstate it by orders of magnitude); the first step's "ratio" is against the arbitrary start vector and is skipped
+        if (it >= 1 && (diff >= 1e-14 || rho == 0.0)) rho = fmax(diff, 1e-16) / fmax(diff_prev, 1e-300);
+        diff_prev = diff;
+        growth = sqrt(nn);                                              // -> 1 / (lambda4 + mu) as v converges
     }
     X[0] = v0; X[1] = v1; X[2] = v2; X[3] = v3;
+    // How far can this vector be from the one another backward-stable algorithm returns?  ~ eps * lambda1 / lambda3: with
+    // rho = (lambda4 + mu) / (lambda3 + mu) the contraction the iteration showed (ratio of consecutive steps) and
+    // lambda1 <= trace, lambda1 / lambda3 ~ trace * rho * growth.  Measured over well- and ill-conditioned geometries
+    // (scripts/dev_tri_calib.py, 4e6 points): |fast - Jacobi| <= 2.5 sens, 3.5e-15 at the rounding floor.
+    if (sens) *sens = 2.220446049250313e-16 * (m[0][0] + m[1][1] + m[2][2] + m[3][3]) * fmin(1.0, rho == 0.0 ? 1.0 : rho) * growth;
     return done;
 }
 
+// Guarded fast path (normalise_w = 3): the inverse-iteration vector and the Jacobi vector are the same unit vector up to
+// ~1e-11 (fp64 rounding of two different algorithms), so their float32 casts — and with them the whole float32 result —
+// are identical unless a component sits within that distance of a float32 ROUNDING BOUNDARY (the midpoint of two adjacent
+// floats).  The distance between two backward-stable solutions grows with the conditioning of the null vector, ~ eps
+// lambda1 / lambda3 of A^T A, which the iteration itself reveals (dlt_nullvec_fast: `sens`).  A lane whose four components
+// all keep a margin of max(2^-40, 16 sens) — in units of the unit vector's norm — from the nearest midpoint keeps the fast
+// result; the others (a fraction of a percent on well-conditioned geometry, all of them when the baseline vanishes) and the
+// lanes whose iteration did not converge are marked and redone by triangulate_fixup_kernel with the Jacobi sweeps,
+// compacted so that no wave runs the slow path for a single lane.
+constexpr double kCastGuard = 9.094947017729282e-13;    // 2^-40: 300 x the rounding floor of the two vectors' difference (<= 3.5e-15 measured)
+constexpr double kSensFactor = 16.0;                    // margin = max(kCastGuard, kSensFactor * sens); measured |fast - Jacobi| <= 2.5 sens
+constexpr unsigned kRedoMark = 0x7FC0DEADu;             // quiet-NaN payload written to all four outputs of a point to redo
+
+__device__ __forceinline__ bool cast_margin_ok(double x, double margin) {
+    const double ax = fabs(x);
+    const float af = (float)ax;                                        // round to nearest even
+    const unsigned bits = __float_as_uint(af);
+    if (bits == 0u) return true;                                       // |x| < 2^-150: zero on both paths
+    if (bits >= 0x7F7FFFFFu) return false;
+    const double lo = 0.5 * ((double)af + (double)__uint_as_float(bits - 1u));   // midpoint to the float below
+    const double hi = 0.5 * ((double)af + (double)__uint_as_float(bits + 1u));   // ... and above
+    return ax - lo > margin && hi - ax > margin;                    // (absolute: the vector has unit norm)
+}
+
 template <int M>
-__global__ __launch_bounds__(256) void triangulate_kernel(ProjPair P, const float* __restrict__ x1,
-                                                          const float* __restrict__ x2, int64_t n, int64_t spt,
-                                                          int64_t sxy, int normalise_w, float* __restrict__ X4) {
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double At[4][M];   // At[k][row]: column k of the DLT matrix
-    dlt_build<M>(At, P.p[0], P.p[1], (double)x1[i * spt], (double)x1[i * spt + sxy], (double)x2[i * spt],
-                 (double)x2[i * spt + sxy]);
-    double Xd[4];
-    bool have = false;
-    if constexpr (M == 4) {
-        if (normalise_w == 2) have = dlt_nullvec_fast(At, Xd);
-    }
-    if (!have) dlt_nullvec<M>(At, Xd);
+__device__ __forceinline__ void store_point(const double (&Xd)[4], int normalise_w, int64_t n, int64_t i, float* __restrict__ X4) {
     float X[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) X[k] = (float)Xd[k];
@@ -228,6 +251,77 @@ __global__ __launch_bounds__(256) void triangulate_kernel(ProjPair P, const floa
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) X4[k * n + i] = X[k];
+}
+
+// Second pass of the guarded fast path: every workgroup scans kFixChunk points for the redo mark, queues their indices in
+// LDS, and runs the OpenCV-faithful Jacobi path on the queue, 256 points at a time.
+constexpr int kFixChunk = 4096;
+__global__ __launch_bounds__(256) void triangulate_fixup_kernel(ProjPair P, const float* __restrict__ x1, const float* __restrict__ x2, int64_t n,
+                                                               int64_t spt, int64_t sxy, float* __restrict__ X4) {
+    __shared__ int queue[kFixChunk];
+    __shared__ int qn;
+    if (threadIdx.x == 0) qn = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * kFixChunk;
+    for (int o = threadIdx.x; o < kFixChunk; o += 256) {
+        const int64_t i = base + o;
+        if (i < n && __float_as_uint(X4[3 * n + i]) == kRedoMark && __float_as_uint(X4[i]) == kRedoMark) queue[atomicAdd(&qn, 1)] = o;
+    }
+    __syncthreads();
+    const int total = qn;
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int64_t i = base + queue[e];
+        double At[4][4], Xd[4];
+        dlt_build<4>(At, P.p[0], P.p[1], (double)x1[i * spt], (double)x1[i * spt + sxy], (double)x2[i * spt], (double)x2[i * spt + sxy]);
+        dlt_nullvec<4>(At, Xd);
+        store_point<4>(Xd, 1, n, i, X4);
+    }
+}
+
+template <int M>
+__global__ __launch_bounds__(256) void triangulate_kernel(ProjPair P, const float* __restrict__ x1,
+                                                          const float* __restrict__ x2, int64_t n, int64_t spt,
+                                                          int64_t sxy, int normalise_w, double sens_factor, double base_guard,
+                                                          float* __restrict__ X4) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double At[4][M];   // At[k][row]: column k of the DLT matrix
+    dlt_build<M>(At, P.p[0], P.p[1], (double)x1[i * spt], (double)x1[i * spt + sxy], (double)x2[i * spt],
+                 (double)x2[i * spt + sxy]);
+    double Xd[4];
+    bool have = false;
+    if constexpr (M == 4) {
+        double sens = 0;
+        if (normalise_w >= 2) have = dlt_nullvec_fast(At, Xd, &sens);
+        if (normalise_w == 4) {      // dev calibration: X4[0] = max |fast - jacobi| over the components (sign-aligned), X4[1] = sens
+            double Xj[4];
+            dlt_nullvec<M>(At, Xj);
+            const double sg = (Xj[0] * Xd[0] + Xj[1] * Xd[1] + Xj[2] * Xd[2] + Xj[3] * Xd[3]) < 0 ? -1.0 : 1.0;
+            double d = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) d = fmax(d, fabs(Xd[k] - sg * Xj[k]));
+            X4[i] = have ? (float)d : -1.f;
+            X4[n + i] = (float)sens;
+            X4[2 * n + i] = 0.f;
+            X4[3 * n + i] = 0.f;
+            return;
+        }
+        if (normalise_w == 3) {
+            // guarded: keep the fast result only where its float32 casts cannot differ from the Jacobi path's; mark the rest
+            // (the components are relative to a UNIT vector: a perturbation of the vector moves a small component by the same
+            // absolute amount, so the margin is taken relative to 1, not to the component)
+            const double margin = fmax(base_guard, sens_factor * sens);
+            const bool keep = have && margin < 1e-3 && cast_margin_ok(Xd[0], margin) && cast_margin_ok(Xd[1], margin) &&
+                              cast_margin_ok(Xd[2], margin) && cast_margin_ok(Xd[3], margin);
+            if (!keep) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) X4[k * n + i] = __uint_as_float(kRedoMark);
+                return;
+            }
+        }
+    }
+    if (!have) dlt_nullvec<M>(At, Xd);
+    store_point<M>(Xd, normalise_w, n, i, X4);
 }
 
 // cv2.recoverPose's cheirality vote (sfm.py:311): for pose candidate m = blockIdx.y triangulate every
@@ -269,8 +363,8 @@ extern "C" int sfm_triangulate_dlt(const double* P1, const double* P2, const flo
                                    int64_t stride_pt, int64_t stride_xy, int rows, int normalise_w, float* X4,
                                    void* stream_) {
     SFM_CHECK_ARG(rows == 4 || rows == 6, "sfm_triangulate_dlt: rows must be 4 or 6 (got %d)", rows);
-    SFM_CHECK_ARG(normalise_w >= 0 && normalise_w <= 2 && (normalise_w != 2 || rows == 4),
-                  "sfm_triangulate_dlt: normalise_w must be 0, 1 or 2 (2 = fast path, rows = 4 only)");
+    SFM_CHECK_ARG(normalise_w >= 0 && normalise_w <= 4 && (normalise_w < 2 || rows == 4),
+                  "sfm_triangulate_dlt: normalise_w must be 0, 1, 2 (fast path) or 3 (guarded fast path); 2 and 3 need rows = 4");
     SFM_CHECK_ARG(n >= 0, "sfm_triangulate_dlt: negative n");
     if (n == 0) return SFM_OK;
     SFM_CHECK_ARG(P1 && P2 && x1 && x2 && X4, "sfm_triangulate_dlt: null pointer");
@@ -280,13 +374,18 @@ extern "C" int sfm_triangulate_dlt(const double* P1, const double* P2, const flo
         P.p[1][k] = P2[k];
     }
     const dim3 grid((unsigned)((n + 255) / 256));
+    static const double sens_factor = [] { const char* e = getenv("SFM_TRI_SENS"); return e ? atof(e) : kSensFactor; }();   // dev overrides
+    static const double base_guard = [] { const char* e = getenv("SFM_TRI_GUARD"); return e ? atof(e) : kCastGuard; }();
     sfm::prof_begin(sfm::kProfTriangulate, sfm::as_stream(stream_));
     if (rows == 4)
         hipLaunchKernelGGL(triangulate_kernel<4>, grid, dim3(256), 0, sfm::as_stream(stream_), P, x1, x2, n, stride_pt,
-                           stride_xy, normalise_w, X4);
+                           stride_xy, normalise_w, sens_factor, base_guard, X4);
     else
         hipLaunchKernelGGL(triangulate_kernel<6>, grid, dim3(256), 0, sfm::as_stream(stream_), P, x1, x2, n, stride_pt,
-                           stride_xy, normalise_w, X4);
+                           stride_xy, normalise_w, sens_factor, base_guard, X4);
+    if (normalise_w == 3)
+        hipLaunchKernelGGL(triangulate_fixup_kernel, dim3((unsigned)((n + kFixChunk - 1) / kFixChunk)), dim3(256), 0, sfm::as_stream(stream_), P, x1,
+                           x2, n, stride_pt, stride_xy, X4);
     sfm::prof_end(sfm::kProfTriangulate, sfm::as_stream(stream_));
     SFM_CHECK_LAUNCH();
     return SFM_OK;

@@ -245,7 +245,7 @@ def triangulate_pairs_sharded(store, n_query, pairs, keypoints, proj, triangulat
         from . import ops
 
         def triangulate(P1, P2, x1, x2):
-            return ops.triangulate(P1, P2, x1, x2, normalise_w=True)
+            return ops.triangulate(P1, P2, x1, x2, normalise_w="guarded")     # bit-identical to normalise_w=True
     ex = BatchedExchange((4, cap), torch.float32, dev, batch, group)
     partition = partition or contiguous_partition(n_pairs, world)
     mine = partition[rank]

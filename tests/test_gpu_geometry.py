@@ -366,6 +366,20 @@ def test_triangulation_one_million_distinct_points_vs_oracle(hip, oracle):
     fast = hip.triangulate(P[1], P[2], a, b, normalise_w="fast").cpu().numpy()
     assert (fast == got).all(0).mean() >= 0.995
     assert (np.abs(fast - got).max(0) / scale).max() <= 3e-7
+    # the guarded fast path (what the driver uses): the fast result where its float32 casts cannot differ, the Jacobi sweeps
+    # (second, compacted pass) elsewhere — EVERY point equal to the faithful path, bit for bit
+    guarded = hip.triangulate(P[1], P[2], a, b, normalise_w="guarded").cpu().numpy()
+    assert np.array_equal(guarded.view(np.uint32), got.view(np.uint32))
+    # ... also where the geometry is nearly degenerate (baseline 1e-4 of the depth: the inverse iteration converges slowly or
+    # not at all and most points take the fallback) and on strided (N, 2) inputs
+    P2n = P[1].copy()
+    P2n[:, 3] += P[1][:, :3] @ np.array([1e-3, 0.0, 0.0])
+    xb = (P2n @ Xh)
+    xb = ((xb[:2] / xb[2]).T + rng.normal(0, 0.3, (n, 2))).astype(np.float32)
+    m = 200_000
+    a2, b2 = cu(xs[0][:m]).t(), cu(xb[:m]).t()
+    assert np.array_equal(hip.triangulate(P[1], P2n, a2, b2, normalise_w="guarded").cpu().numpy().view(np.uint32),
+                          hip.triangulate(P[1], P2n, a2, b2, normalise_w=True).cpu().numpy().view(np.uint32))
 
 
 def test_block_kernels_and_norm(hip):
