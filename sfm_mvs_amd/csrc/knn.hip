@@ -621,7 +621,8 @@ __device__ __forceinline__ uint2 frag_init_operand(float x, bool query_side, int
 // arithmetic (values outside fp16's range) and are written by knn_split_images_kernel, which runs when the flags say so:
 // the common case moves 15 MB per 10k x 10k pair instead of 25.
 // Batched: grid = (blocks + 1, B); column b works on pair b (its workspace arrays sit at b * stride).
-__global__ __launch_bounds__(1024) void knn_prep_kernel(BatchPtrs P, int64_t ldq, int nq, int nq_pad,
+constexpr int kPrepThreads = 256;      // one wave per SIMD, 56 registers: a prep workgroup of the NEXT launch set fits beside the q4 filter's waves
+__global__ __launch_bounds__(kPrepThreads) void knn_prep_kernel(BatchPtrs P, int64_t ldq, int nq, int nq_pad,
                                                        int64_t ldt, int nt, int nt_pad,
                                                        unsigned short* __restrict__ qsplit, float* __restrict__ qn,
                                                        unsigned short* __restrict__ tsplit, float* __restrict__ tn,
@@ -634,7 +635,8 @@ __global__ __launch_bounds__(1024) void knn_prep_kernel(BatchPtrs P, int64_t ldq
                                                        int64_t units, int tiles, int G, int seg_cost, int n_rb,
                                                        int64_t* __restrict__ wg_begin, int* __restrict__ rb_first,
                                                        int* __restrict__ rb_last) {
-    __shared__ float wmax[16];
+    constexpr int kPrepWaves = kPrepThreads / 64, kPrepRows = kPrepThreads / 16;
+    __shared__ float wmax[kPrepWaves];
     const int pb = blockIdx.y;
     if (blockIdx.x == gridDim.x - 1) {                     // the extra workgroup (of column 0): partition tables, nothing else
         if (pb == 0) fill_partition_tables(make_partition(units, tiles, G, seg_cost), n_rb, wg_begin, rb_first, rb_last);
@@ -650,7 +652,7 @@ __global__ __launch_bounds__(1024) void knn_prep_kernel(BatchPtrs P, int64_t ldq
     const bool frag = qfrag != nullptr;
     if (frag) { qfrag += pb * s_qfrag; tfrag += pb * s_tfrag; }
     const int nblk = gridDim.x - 1;
-    __shared__ int wmid[16];
+    __shared__ int wmid[kPrepWaves];
     // SIXTEEN lanes per row, one 16-byte chunk (8 elements) each: a lane reads 32 contiguous bytes of its row (a wave = 4
     // rows x 512 B) and its eight fp16 values ARE one chunk of the images — row-major: 16 B at row * 256 + 16 c; fragment
     // order: 16 B at fragment c >> 1, lane 32 (c & 1) + row % 32 of the row's tile, so the four adjacent rows of a wave
@@ -660,10 +662,10 @@ __global__ __launch_bounds__(1024) void knn_prep_kernel(BatchPtrs P, int64_t ldq
     float mx = 0.f, mxe = 0.f;
     unsigned flags = 0;
     const int rows = nq_pad + nt_pad;
-    // A workgroup takes 64 consecutive rows per trip; the rows of up to kPrepAhead trips are requested before the first is
-    // worked on (the body is a dependent chain and a workgroup has only 1-2 trips).
-    constexpr int kPrepAhead = 2;
-    const int row0 = blockIdx.x * 64 + (threadIdx.x >> 4), rstep = nblk * 64;
+    // A workgroup takes kPrepRows consecutive rows per trip; the rows of up to kPrepAhead trips are requested before the first
+    // is worked on (the body is a dependent chain and a workgroup has only a few trips).
+    constexpr int kPrepAhead = 3;
+    const int row0 = blockIdx.x * kPrepRows + (threadIdx.x >> 4), rstep = nblk * kPrepRows;
     for (int rbase = row0; rbase < rows; rbase += kPrepAhead * rstep) {
     float4 vin[kPrepAhead][2];
 #pragma unroll
@@ -736,7 +738,7 @@ __global__ __launch_bounds__(1024) void knn_prep_kernel(BatchPtrs P, int64_t ldq
     int wfl = 0;
 #pragma unroll
     for (int b = 1; b <= 4; b <<= 1) wfl |= __any((flags & b) != 0) ? b : 0;
-    __shared__ float wmaxe[16];
+    __shared__ float wmaxe[kPrepWaves];
     if ((threadIdx.x & 63) == 0) {
         wmax[threadIdx.x >> 6] = mx;
         wmaxe[threadIdx.x >> 6] = mxe;
@@ -746,7 +748,7 @@ __global__ __launch_bounds__(1024) void knn_prep_kernel(BatchPtrs P, int64_t ldq
     if (threadIdx.x == 0) {
         float bm = wmax[0], bme = wmaxe[0];
         int fl = wmid[0];
-        for (int w = 1; w < 16; ++w) {
+        for (int w = 1; w < kPrepWaves; ++w) {
             bm = fmaxf(bm, wmax[w]);
             bme = fmaxf(bme, wmaxe[w]);
             fl |= wmid[w];
@@ -1429,10 +1431,16 @@ __device__ __forceinline__ void filter_q4_body(
             for (int g = 0; g < NG; ++g) k0[g] = k1[g] = k2[g] = kKeyInf;
             int sub = 0, sub_t0 = t_begin;
             auto flush = [&](int sb, int st0) {
+                // (cold: once per 64 tiles.  The record addresses are formed HERE from an opaque copy of the query row: left to
+                // the optimiser their loop-invariant parts are hoisted and pin registers across the tile loop — the kernel must
+                // stay within 240 VGPRs + 144 AGPRs = 384 registers so that a 128-register refine wave of another launch set
+                // fits beside a filter wave on the same SIMD)
+                int qr = qrow0;
+                asm volatile("" : "+v"(qr));
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
                     if (qok[g]) {
-                        const int64_t ob = ((int64_t)(qrow0 + 32 * g) * (2 * smax * nsub) + (int64_t)slot * nsub * 2 + h) * 3 + 6 * sb;
+                        const int64_t ob = ((int64_t)(qr + 32 * g) * (2 * smax * nsub) + (int64_t)slot * nsub * 2 + h) * 3 + 6 * sb;
                         flush_keys<true>(k0[g], k1[g], k2[g], st0, h, cand_s + ob, cand_i + ob);
                     }
                     k0[g] = k1[g] = k2[g] = kKeyInf;
@@ -2711,7 +2719,7 @@ int knn_batch_impl(int B, const BatchPtrs& P, int64_t nq, int64_t ldq, int64_t n
     const int prof_reps = p.split ? sfm::prof_repeat() : 1;
     static const int abl = [] { const char* e = getenv("SFM_KNN_ABL"); return e ? atoi(e) : 0; }();   // dev only
     if (p.split) {
-        hipLaunchKernelGGL(knn_prep_kernel, dim3(kNormBlocks + 1, (unsigned)B), dim3(1024), 0, stream, P, ldq, (int)nq, p.nq_pad, ldt, (int)nt,
+        hipLaunchKernelGGL(knn_prep_kernel, dim3(kNormBlocks + 1, (unsigned)B), dim3(kPrepThreads), 0, stream, P, ldq, (int)nq, p.nq_pad, ldt, (int)nt,
                            p.tiles * kTileT, w.qsplit, w.qn, w.tsplit, w.tn, w.bmax, w.midflag, w.qerr, w.bmaxerr, w.s_qsplit, w.s_tsplit, w.s_qn, w.s_tn,
                            p.q4 ? w.qfrag : nullptr, w.tfrag, w.s_qfrag, w.s_tfrag,
                            ratio_counts, ratio_counts ? ratio_stride : 0,
