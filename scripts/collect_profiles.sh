@@ -36,4 +36,16 @@ cp $OUT/trace_sift1/sift1_kernel_stats.csv $OUT/${TAG}_sift_depth1_kernel_stats.
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_sift -o sift -- python $R/bench.py --workload sift --steps 30 --warmup 5 --no-cpu-baseline > $OUT/bench_sift_under_rocprof.json 2>> $OUT/trace.log
 cp $OUT/trace_sift/sift_kernel_stats.csv $OUT/${TAG}_sift_kernel_stats.csv
 rm -rf $OUT/trace $OUT/traceb $OUT/trace1 $OUT/trace_tri $OUT/trace_ba $OUT/trace_sift $OUT/trace_sift1
+# the bench lines themselves, un-profiled (a profiled run clocks 2-5 % lower): the driver's flags, config 5 through a
+# one-rank RCCL group, the 57-camera driver
+cd $R
+python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_knn.json 2>> $OUT/trace.log
+SFM_BENCH_EXCHANGE=1 python bench.py --workload c5 > $OUT/${TAG}_bench_c5.json 2>> $OUT/trace.log
+python bench.py --workload sfm --steps 3 > $OUT/${TAG}_bench_sfm.json 2>> $OUT/trace.log
+python bench.py --workload tri --steps 5 --warmup 1 > $OUT/${TAG}_bench_tri.json 2>> $OUT/trace.log
+python bench.py --workload ba --steps 5 --warmup 1 > $OUT/${TAG}_bench_ba.json 2>> $OUT/trace.log
+python bench.py --workload sift --steps 30 --warmup 5 > $OUT/${TAG}_bench_sift.json 2>> $OUT/trace.log
+# PMC passes of the non-KNN legs (triangulation, BA, SIFT)
+bash $R/scripts/collect_pmc_other.sh $TAG > $OUT/pmc_other.log 2>&1
+python $R/scripts/summarize_pmc_other.py $TAG > $OUT/${TAG}_other_pmc.md
 ls $OUT
