@@ -584,7 +584,7 @@ __device__ __forceinline__ int knn_filter_mode(const int* __restrict__ flags, co
 // The arithmetic mode of a BATCH of pairs (one launch, one body): the most general mode any of its pairs needs — the
 // modes are nested (fp16-exact data are fp16-representable data are split-representable data), and the refine kernel
 // prices its slack with the same batch mode, so every pair is certified against the arithmetic that actually ran.
-constexpr int kMinfoPairMode = 0, kMinfoBatchMode = kMaxBatch, kMinfoTmax = 16, kMinfoTerr = 24, kMinfoWords = 32;   // written by knn_split_images_kernel (block 0)
+constexpr int kMinfoPairMode = 0, kMinfoBatchMode = kMaxBatch, kMinfoTmax = 16, kMinfoTerr = 24, kMinfoQmax = 32, kMinfoWords = 40;   // written by knn_split_images_kernel (block 0)
 __device__ __forceinline__ int knn_batch_mode(const int* __restrict__ flags, const float* __restrict__ bmax, int n_pairs, int lane) {
     int mode = kModeHalfExact;
     for (int b = 0; b < n_pairs; ++b) mode = max(mode, knn_filter_mode(flags + b * kNormBlocks, bmax + b * kNormBlocks, lane));
@@ -628,6 +628,7 @@ __global__ __launch_bounds__(kPrepThreads) void knn_prep_kernel(BatchPtrs P, int
                                                        unsigned short* __restrict__ tsplit, float* __restrict__ tn,
                                                        float* __restrict__ bmax, int* __restrict__ midflag,
                                                        float* __restrict__ qerr /*[s_qn] per pair*/, float* __restrict__ bmaxerr /*[kNormBlocks] per pair*/,
+                                                       float* __restrict__ bqmax /*[kNormBlocks] per pair: per-block max of ||q||^2*/,
                                                        int64_t s_qsplit, int64_t s_tsplit, int64_t s_qn, int64_t s_tn,
                                                        unsigned char* __restrict__ qfrag /*null: row-major images only (LDS-ring filter)*/,
                                                        unsigned char* __restrict__ tfrag, int64_t s_qfrag, int64_t s_tfrag,
@@ -647,7 +648,7 @@ __global__ __launch_bounds__(kPrepThreads) void knn_prep_kernel(BatchPtrs P, int
     int* __restrict__ stats = P.stats[pb];
     qsplit += pb * s_qsplit; tsplit += pb * s_tsplit; qn += pb * s_qn; tn += pb * s_tn;
     bmax += pb * kNormBlocks; midflag += pb * kNormBlocks;
-    qerr += pb * s_qn; bmaxerr += pb * kNormBlocks;
+    qerr += pb * s_qn; bmaxerr += pb * kNormBlocks; bqmax += pb * kNormBlocks;
     zero += pb * nzero;
     const bool frag = qfrag != nullptr;
     if (frag) { qfrag += pb * s_qfrag; tfrag += pb * s_tfrag; }
@@ -659,7 +660,7 @@ __global__ __launch_bounds__(kPrepThreads) void knn_prep_kernel(BatchPtrs P, int
     // store 64 contiguous bytes per chunk.  No transposition pass (through LDS, between two barriers, it cost 7 us of a
     // 46 us launch), no shared memory in the loop.
     const int c = threadIdx.x & 15;
-    float mx = 0.f, mxe = 0.f;
+    float mx = 0.f, mxe = 0.f, mxq = 0.f;
     unsigned flags = 0;
     const int rows = nq_pad + nt_pad;
     // A workgroup takes kPrepRows consecutive rows per trip; the rows of up to kPrepAhead trips are requested before the first
@@ -717,13 +718,16 @@ __global__ __launch_bounds__(kPrepThreads) void knn_prep_kernel(BatchPtrs P, int
             // then the 512-byte accumulator-init fragment (frag_init_operand: 8 B per lane)
             unsigned char* fimg = (isq ? qfrag : tfrag) + (int64_t)(r >> 5) * kTileFragBytes;
             *reinterpret_cast<uint4*>(fimg + (((c >> 1) * 64 + (c & 1) * 32 + (r & 31)) << 4)) = packed;
-            if (c < 2) *reinterpret_cast<uint2*>(fimg + 8 * kFragBytes + ((c * 32 + (r & 31)) << 3)) = frag_init_operand(nrm, isq, c);
+            // (train image only: the query side of the init product is the same for every query of the pair — ||q||^2max,
+            // see knn_filter_q4_kernel — and is formed by the filter itself)
+            if (c < 2 && !isq) *reinterpret_cast<uint2*>(fimg + 8 * kFragBytes + ((c * 32 + (r & 31)) << 3)) = frag_init_operand(nrm, false, c);
         } else {
             *reinterpret_cast<uint4*>((isq ? qsplit : tsplit) + (2 * (int64_t)npad + r) * kDim + 8 * c) = packed;   // row-major fp16 plane (LDS-ring filter, its refine screens)
         }
         if (c == 0) (isq ? qn : tn)[r] = nrm;
         if (isq) {
             if (c == 0) qerr[r] = err2;
+            mxq = fmaxf(mxq, s);
         } else {
             mx = fmaxf(mx, s);
             mxe = fmaxf(mxe, err2);
@@ -734,27 +738,31 @@ __global__ __launch_bounds__(kPrepThreads) void knn_prep_kernel(BatchPtrs P, int
     for (int m = 32; m >= 1; m >>= 1) {
         mx = fmaxf(mx, __shfl_xor(mx, m, 64));
         mxe = fmaxf(mxe, __shfl_xor(mxe, m, 64));
+        mxq = fmaxf(mxq, __shfl_xor(mxq, m, 64));
     }
     int wfl = 0;
 #pragma unroll
     for (int b = 1; b <= 4; b <<= 1) wfl |= __any((flags & b) != 0) ? b : 0;
-    __shared__ float wmaxe[kPrepWaves];
+    __shared__ float wmaxe[kPrepWaves], wmaxq[kPrepWaves];
     if ((threadIdx.x & 63) == 0) {
         wmax[threadIdx.x >> 6] = mx;
         wmaxe[threadIdx.x >> 6] = mxe;
+        wmaxq[threadIdx.x >> 6] = mxq;
         wmid[threadIdx.x >> 6] = wfl;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        float bm = wmax[0], bme = wmaxe[0];
+        float bm = wmax[0], bme = wmaxe[0], bmq = wmaxq[0];
         int fl = wmid[0];
         for (int w = 1; w < kPrepWaves; ++w) {
             bm = fmaxf(bm, wmax[w]);
             bme = fmaxf(bme, wmaxe[w]);
+            bmq = fmaxf(bmq, wmaxq[w]);
             fl |= wmid[w];
         }
         bmax[blockIdx.x] = bm;
         bmaxerr[blockIdx.x] = bme;
+        bqmax[blockIdx.x] = bmq;
         midflag[blockIdx.x] = fl;
         if (blockIdx.x == 0 && stats) stats[0] = 0;   // rescanned-query counter (refine kernel)
         if (blockIdx.x == 1 || nblk == 1)
@@ -773,7 +781,7 @@ __global__ __launch_bounds__(kSplitThreads) void knn_split_images_kernel(BatchPt
                                                                         const int* __restrict__ midflag, const float* __restrict__ bmax,
                                                                         int force_mode, unsigned char* __restrict__ qhm0 /*null: row-major planes*/,
                                                                         unsigned char* __restrict__ thm0, int64_t s_qhm, int64_t s_thm,
-                                                                        const float* __restrict__ bmaxerr, int* __restrict__ minfo) {
+                                                                        const float* __restrict__ bmaxerr, const float* __restrict__ bqmax, int* __restrict__ minfo) {
     // The batch's arithmetic mode, reduced ONCE for the launch set: wave b of every workgroup reduces pair b's 2 x 256 flag
     // words (the eight pairs in parallel: one round trip; as a loop over the pairs inside every filter workgroup this was
     // 8-10 us of dependent loads at the head of the filter launch), workgroup 0 leaves the result — per pair the mode,
@@ -786,15 +794,21 @@ __global__ __launch_bounds__(kSplitThreads) void knn_split_images_kernel(BatchPt
             float tmax;
             const int m = knn_filter_mode(midflag + wave * kNormBlocks, bmax + wave * kNormBlocks, lane, &tmax);
             const float* be = bmaxerr + wave * kNormBlocks;
+            const float* bq = bqmax + wave * kNormBlocks;
             float te = fmaxf(fmaxf(be[lane], be[lane + 64]), fmaxf(be[lane + 128], be[lane + 192]));
+            float qm = fmaxf(fmaxf(bq[lane], bq[lane + 64]), fmaxf(bq[lane + 128], bq[lane + 192]));
 #pragma unroll
-            for (int sh = 32; sh >= 1; sh >>= 1) te = fmaxf(te, __shfl_xor(te, sh, 64));
+            for (int sh = 32; sh >= 1; sh >>= 1) {
+                te = fmaxf(te, __shfl_xor(te, sh, 64));
+                qm = fmaxf(qm, __shfl_xor(qm, sh, 64));
+            }
             if (lane == 0) {
                 smode[wave] = m;
                 if (blockIdx.x == 0) {
                     minfo[kMinfoPairMode + wave] = m;
                     minfo[kMinfoTmax + wave] = __float_as_int(tmax);
                     minfo[kMinfoTerr + wave] = __float_as_int(te);
+                    minfo[kMinfoQmax + wave] = __float_as_int(qm);
                 }
             }
         }
@@ -1303,6 +1317,10 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #define SFM_MFMA_F16(acc, a, b) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b))
 #define SFM_MFMA_BF16(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b))
 #define SFM_MFMA_BF16_INIT(acc, a, b) asm volatile("v_mfma_f32_32x32x8_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "a"(b))
+// first product of a chain: D = A B + C with C a DIFFERENT register block (the tile's shared init values); D is early-clobber —
+// an MFMA's D may coincide with its C exactly or not at all
+#define SFM_MFMA_F16_C(acc, a, b, c) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(acc) : "v"(a), "a"(b), "v"(c))
+#define SFM_MFMA_BF16_C(acc, a, b, c) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(acc) : "v"(a), "a"(b), "v"(c))
 
 __device__ __forceinline__ void key_insert_quad(const f32x16& a, int r, int seq /*wave-uniform*/, int vmask, int& k0, int& k1, int& k2) {
     const int m = min(min(__float_as_int(a[r]), __float_as_int(a[r + 1])), min(__float_as_int(a[r + 2]), __float_as_int(a[r + 3])));
@@ -1337,7 +1355,7 @@ __device__ __forceinline__ void filter_q4_body(
     const unsigned char* __restrict__ qfrag, const unsigned char* __restrict__ tfrag, const unsigned char* __restrict__ qhm,
     const unsigned char* __restrict__ thm, int nq, int nq_pad, int tiles, int smax, int nsub, float* __restrict__ cand_s0,
     int* __restrict__ cand_i0, const int64_t* __restrict__ wg_begin, const int* __restrict__ rb_first, int n_rb1, int64_t s_qfrag,
-    int64_t s_tfrag, int64_t s_qhm, int64_t s_thm, int64_t s_cand) {
+    int64_t s_tfrag, int64_t s_qhm, int64_t s_thm, int64_t s_cand, const int* __restrict__ minfo) {
     constexpr int NG = KMID ? 2 : 4;                          // groups per pass
     constexpr int NPASS = KMID ? 2 : 1;
     constexpr int P = NG / 2;                                 // groups per phase
@@ -1404,25 +1422,24 @@ __device__ __forceinline__ void filter_q4_body(
             // the query fragments go straight into accumulation registers (hipcc makes the loads' destinations the AGPRs the
             // tied "a" constraints below ask for); ALL of them are requested before the first is waited for
             u32x4 bq[NG][KMID ? 16 : 8];
-            u32x2 bi[NG];
+            u32x2 bi;                                                          // the init product's query side: ||q||^2max of the pair
             {
                 i32x4 tmp[NG][KMID ? 16 : 8];
-                i32x2 tmpi[NG];
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
 #pragma unroll
                     for (int f = 0; f < (KMID ? 16 : 8); ++f)
                         tmp[g][f] = KMID ? __builtin_amdgcn_raw_buffer_load_b128(qhrs, voff, __builtin_amdgcn_readfirstlane((qg0 + g) * (16 * kFragBytes) + f * kFragBytes), 0)
                                          : __builtin_amdgcn_raw_buffer_load_b128(qrs, voff, __builtin_amdgcn_readfirstlane((qg0 + g) * kTileFragBytes + f * kFragBytes), 0);
-                    tmpi[g] = __builtin_amdgcn_raw_buffer_load_b64(qrs, voffi, __builtin_amdgcn_readfirstlane((qg0 + g) * kTileFragBytes + 8 * kFragBytes), 0);
                 }
+                const uint2 qm = frag_init_operand(__int_as_float(minfo[kMinfoQmax + pb]), true, h);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
 #pragma unroll
                     for (int f = 0; f < (KMID ? 16 : 8); ++f) asm volatile("" : "=a"(bq[g][f]) : "0"(__builtin_bit_cast(u32x4, tmp[g][f])));
-                    asm volatile("" : "=a"(bi[g]) : "0"(__builtin_bit_cast(u32x2, tmpi[g])));
                 }
+                asm volatile("" : "=a"(bi) : "0"(u32x2{qm.x, qm.y}));
             }
             asm volatile("s_nop 4");                                           // v_accvgpr_write -> MFMA operand
 
@@ -1453,6 +1470,12 @@ __device__ __forceinline__ void filter_q4_body(
             for (int g = P; g < NG; ++g)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[g][r] = kInf;
+            // ||t||^2 + ||q||^2max of the tile about to run: ONE init MFMA per tile, shared by all groups as the C operand of
+            // their chains' first products.  It is issued a phase ahead (right after the last chain of the previous tile
+            // has read the previous values), so nothing ever waits for it; the segment's first one is followed by nops.
+            f32x16 cinit;
+            SFM_MFMA_BF16_INIT(cinit, __builtin_bit_cast(u32x2, fri[0]), bi);
+            asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
 
             // k-step st of group g: one fp16 product, or the three bf16 products hi.hi + hi.mid + mid.hi
             auto tile = [&](int t, auto slot_c) {
@@ -1460,18 +1483,14 @@ __device__ __forceinline__ void filter_q4_body(
                 const bool more = t + D < t_end;
                 const int seq_prev = __builtin_amdgcn_readfirstlane(max((t - 1) - sub_t0, 0) << 2);
                 // ---- phase A: chains of the first half's groups; epilogue of the second half's groups (previous tile)
-                {
-                    const u32x2 ai = __builtin_bit_cast(u32x2, fri[S]);
-#pragma unroll
-                    for (int g = 0; g < P; ++g) SFM_MFMA_BF16_INIT(acc[g], ai, bi[g]);
-                }
 #pragma unroll
                 for (int st = 0; st < 8; ++st) {
                     __builtin_amdgcn_sched_barrier(0);
                     const u32x4 a = __builtin_bit_cast(u32x4, fr[S][st]);
                     if constexpr (KMID) {
                         const u32x4 am = __builtin_bit_cast(u32x4, fr[S][8 + st]);
-                        SFM_MFMA_BF16(acc[0], a, bq[0][st]);
+                        if (st == 0) SFM_MFMA_BF16_C(acc[0], a, bq[0][st], cinit);
+                        else SFM_MFMA_BF16(acc[0], a, bq[0][st]);
                         SFM_MFMA_BF16(acc[0], a, bq[0][8 + st]);
                         SFM_MFMA_BF16(acc[0], am, bq[0][st]);
                         if (st & 1) key_insert_quad(acc[1], 4 * (st >> 1), seq_prev + (st >> 1), vmask, k0[1], k1[1], k2[1]);
@@ -1479,11 +1498,13 @@ __device__ __forceinline__ void filter_q4_body(
                         // the epilogue's six VALU per quad are dealt to BOTH gaps (three after each MFMA): a wave alone on its SIMD
                         // hides ~5 single-issue instructions per 32-cycle MFMA, and none behind an MFMA it is still waiting to issue
                         const int g = 2 + (st >> 2);
-                        SFM_MFMA_F16(acc[0], a, bq[0][st]);
+                        if (st == 0) SFM_MFMA_F16_C(acc[0], a, bq[0][st], cinit);
+                        else SFM_MFMA_F16(acc[0], a, bq[0][st]);
                         int key = 0;
                         if (!(ABL & 2)) key = key_make(acc[g], 4 * (st & 3), seq_prev + (st & 3), vmask);
                         __builtin_amdgcn_sched_barrier(0);
-                        SFM_MFMA_F16(acc[1], a, bq[1][st]);
+                        if (st == 0) SFM_MFMA_F16_C(acc[1], a, bq[1][st], cinit);
+                        else SFM_MFMA_F16(acc[1], a, bq[1][st]);
                         if (ABL & 2) {
                             if (st == 0) k0[2] = min(k0[2], __float_as_int(acc[2][0]) + __float_as_int(acc[3][5]));
                         } else
@@ -1500,11 +1521,6 @@ __device__ __forceinline__ void filter_q4_body(
                 const int seq_cur = __builtin_amdgcn_readfirstlane((t - sub_t0) << 2);
                 // ---- phase B: chains of the second half's groups; epilogue of the first half's (this tile); the fragments die
                 // one by one and are refilled for tile t + D
-                {
-                    const u32x2 ai = __builtin_bit_cast(u32x2, fri[S]);
-#pragma unroll
-                    for (int g = P; g < NG; ++g) SFM_MFMA_BF16_INIT(acc[g], ai, bi[g]);
-                }
                 __builtin_amdgcn_sched_barrier(0);
                 load_frag(S, NF, t + D, more, true);
 #pragma unroll
@@ -1513,16 +1529,21 @@ __device__ __forceinline__ void filter_q4_body(
                     const u32x4 a = __builtin_bit_cast(u32x4, fr[S][st]);
                     if constexpr (KMID) {
                         const u32x4 am = __builtin_bit_cast(u32x4, fr[S][8 + st]);
-                        SFM_MFMA_BF16(acc[1], a, bq[1][st]);
+                        if (st == 0) SFM_MFMA_BF16_C(acc[1], a, bq[1][st], cinit);
+                        else SFM_MFMA_BF16(acc[1], a, bq[1][st]);
                         SFM_MFMA_BF16(acc[1], a, bq[1][8 + st]);
                         SFM_MFMA_BF16(acc[1], am, bq[1][st]);
+                        if (st == 1) SFM_MFMA_BF16_INIT(cinit, __builtin_bit_cast(u32x2, fri[(S + 1) % D]), bi);   // the NEXT tile's
                     } else {
                         const int g = st >> 2;
-                        SFM_MFMA_F16(acc[2], a, bq[2][st]);
+                        if (st == 0) SFM_MFMA_F16_C(acc[2], a, bq[2][st], cinit);
+                        else SFM_MFMA_F16(acc[2], a, bq[2][st]);
                         int key = 0;
                         if (!(ABL & 2)) key = key_make(acc[g], 4 * (st & 3), seq_cur + (st & 3), vmask);
                         __builtin_amdgcn_sched_barrier(0);
-                        SFM_MFMA_F16(acc[3], a, bq[3][st]);
+                        if (st == 0) SFM_MFMA_F16_C(acc[3], a, bq[3][st], cinit);
+                        else SFM_MFMA_F16(acc[3], a, bq[3][st]);
+                        if (st == 1) SFM_MFMA_BF16_INIT(cinit, __builtin_bit_cast(u32x2, fri[(S + 1) % D]), bi);   // the NEXT tile's (two MFMAs after the last reader)
                         __builtin_amdgcn_sched_barrier(0);
                         load_frag(S, st, t + D, more, true);
                         if (ABL & 2) {
@@ -1596,10 +1617,10 @@ __global__ __launch_bounds__(256, 1) void knn_filter_q4_kernel(
     const bool need_mid = (force_mode >= 0 ? force_mode : minfo[kMinfoBatchMode]) == kModeSplit;   // (reduced by knn_split_images_kernel)
     if (need_mid)
         filter_q4_body<true, 0>(qfrag, tfrag, qhm, thm, nq, nq_pad, tiles, smax, nsub, cand_s, cand_i, wg_begin, rb_first, n_rb1, s_qfrag, s_tfrag, s_qhm,
-                             s_thm, s_cand);
+                             s_thm, s_cand, minfo);
     else
         filter_q4_body<false, ABL>(qfrag, tfrag, qhm, thm, nq, nq_pad, tiles, smax, nsub, cand_s, cand_i, wg_begin, rb_first, n_rb1, s_qfrag, s_tfrag, s_qhm,
-                              s_thm, s_cand);
+                              s_thm, s_cand, minfo);
     if (trace && threadIdx.x == 0) {
         trace[4 * blockIdx.x + 1] = wall_clock64();
         trace[8192 + 4 * blockIdx.x + 3] = clock64();
@@ -1776,7 +1797,8 @@ __global__ __launch_bounds__(256, 4) void knn_refine_kernel(
     const unsigned short* __restrict__ thalf /*fp16 image of T, or null*/, const float* __restrict__ tn,
     const int64_t* __restrict__ wg_begin, const int* __restrict__ rb_first, const int* __restrict__ rb_last,
     int n_rb1, int64_t s_cand, int64_t s_tsplit, int64_t s_tn, double ratio,
-    int* __restrict__ ratio_counts /*null unless fused with the Lowe ratio*/, int ratio_stride, float chain_scale, long long* __restrict__ trace) {
+    int* __restrict__ ratio_counts /*null unless fused with the Lowe ratio*/, int ratio_stride, float chain_scale,
+    int qoff /*1: the filter's scores carry ||q||^2max of the pair instead of the query's own ||q||^2 (q4 filter)*/, long long* __restrict__ trace) {
     // XCD-aware order (see the filter): physical workgroup b takes query block (b % 8) * chunk + b / 8, so the queries an
     // XCD refines are (roughly) those whose candidate records its own filter workgroups wrote.  Batched: the query
     // blocks of all pairs form one sequence, pair after pair.
@@ -1882,8 +1904,14 @@ __global__ __launch_bounds__(256, 4) void knn_refine_kernel(
         qq = a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w + c4.x * c4.x + c4.y * c4.y + c4.z * c4.z + c4.w * c4.w;
     }
     qq += lane_xor<8>(qq); qq += lane_xor<4>(qq); qq += lane_xor<2>(qq); qq += lane_xor<1>(qq);
-    const float nsum = sqrtf(qq) + sqrtf(tmax);
-    if (sl == 0) q_qq[ql] = qq;                           // (the rescan's operand)
+    // The q4 filter scores with s = ||t||^2 + ||q||^2max - 2 q.t — the same offset for every query of the pair, so that ONE
+    // init MFMA serves all the query groups of a wave.  Everything below that compares filter scores with each other is
+    // untouched (a query's records all carry the same offset); the screens add the same number the filter did (qadd), the
+    // certificate moves the exact d2^2 into the scores' frame (qadd - qq, in double), and the slack is priced on the
+    // magnitudes the filter's accumulators actually held: N = ||q||max + ||t||max.
+    const float qadd = (qoff && minfo) ? __int_as_float(minfo[kMinfoQmax + pb]) : qq;
+    const float nsum = sqrtf(qadd) + sqrtf(tmax);
+    if (sl == 0) q_qq[ql] = qadd;                         // (the rescan's operand)
     // Operand rounding of the fp16 single product, bounded from the data instead of the worst case 2^-10 (|q|+|t|)^2 / 2:
     // the filter scores with Q' = fp16(-2 q) and T' = fp16(t), so its product is off by at most
     // |dQ'| |t| + |Q'| |dT| + |dQ'| |dT| (Cauchy-Schwarz) with the residual norms |dQ'| of THIS query and max |dT| of the
@@ -2017,7 +2045,7 @@ __global__ __launch_bounds__(256, 4) void knn_refine_kernel(
                         d[k & 3] = dot8_f16(hv[k], *reinterpret_cast<const uint4*>(&qhalf[ql][8 * (8 * hf + k)]), d[k & 3]);
                 }
                 asm volatile("" : "+v"(tnv));
-                const float sp = (tnv + qq) + ((d[0] + d[2]) + (d[1] + d[3]));
+                const float sp = (tnv + qadd) + ((d[0] + d[2]) + (d[1] + d[3]));
                 if (live && !(thr < sp)) qual[ql][atomicAdd(&cnt_lds[ql], 1)] = row;
             }
         } else {
@@ -2062,7 +2090,7 @@ __global__ __launch_bounds__(256, 4) void knn_refine_kernel(
                 float mine = dot[0];
     #pragma unroll
                 for (int r = 1; r < kHotPre; ++r) mine = (jq & (kHotPre - 1)) == r ? dot[r] : mine;
-                const float sp = (tnv + qq) + mine;
+                const float sp = (tnv + qadd) + mine;
                 if (jq < kHotPre && live && !(thr < sp)) qual[ql][atomicAdd(&cnt_lds[ql], 1)] = row0 + jq;
             }
         }
@@ -2129,7 +2157,7 @@ __global__ __launch_bounds__(256, 4) void knn_refine_kernel(
         if (trace && threadIdx.x == 0 && round == 0) trace[16 * bidt + 3] = wall_clock64();
         if (round == 1) break;
         // Certificate.  (s3 < 0 can only be rounding noise: such a stream never certifies.)
-        lim = b.i[1] != INT_MAX ? dsq_upper(b.d[1]) + (double)eps : (double)kInf;
+        lim = b.i[1] != INT_MAX ? dsq_upper(b.d[1]) + (double)eps + ((double)qadd - (double)qq) : (double)kInf;   // (in the scores' frame)
         const bool open = valid && tau < kInf && !(lim < (double)tau);    // some stream could not be certified
         if (!__syncthreads_or(open ? 1 : 0)) break;
 
@@ -2440,6 +2468,7 @@ struct KnnWs {
     float* bmax;                  // [B][kNormBlocks]
     float* qerr;                  // [B][s_qn]: ||fp16(-2 q) - (-2 q)||^2 per query; bmaxerr [B][kNormBlocks]: per-block max of ||fp16(t) - t||^2
     float* bmaxerr;
+    float* bqmax;                 // [B][kNormBlocks]: per-block max of ||q||^2 (the q4 filter's common score offset)
     int* midflag;
     int* minfo;                   // [kMinfoWords] modes / ||t||max reduced by filter block 0 for the refine kernel
     int64_t* wg_begin;            // partition tables over the whole batch (filled by the prep / norms launch)
@@ -2475,6 +2504,7 @@ KnnWs carve_ws(void* ws, int64_t nq, int64_t nt, const Plan& p) {
     w.qn = c.take<float>(B * (size_t)w.s_qn);
     w.qerr = c.take<float>(B * (size_t)w.s_qn);
     w.bmaxerr = c.take<float>(B * kNormBlocks);
+    w.bqmax = c.take<float>(B * kNormBlocks);
     w.qsplit = c.take<unsigned short>(B * (size_t)w.s_qsplit);
     w.tsplit = c.take<unsigned short>(B * (size_t)w.s_tsplit);
     w.cand_s = c.take<float>(B * (size_t)w.s_cand);
@@ -2720,14 +2750,14 @@ int knn_batch_impl(int B, const BatchPtrs& P, int64_t nq, int64_t ldq, int64_t n
     static const int abl = [] { const char* e = getenv("SFM_KNN_ABL"); return e ? atoi(e) : 0; }();   // dev only
     if (p.split) {
         hipLaunchKernelGGL(knn_prep_kernel, dim3(kNormBlocks + 1, (unsigned)B), dim3(kPrepThreads), 0, stream, P, ldq, (int)nq, p.nq_pad, ldt, (int)nt,
-                           p.tiles * kTileT, w.qsplit, w.qn, w.tsplit, w.tn, w.bmax, w.midflag, w.qerr, w.bmaxerr, w.s_qsplit, w.s_tsplit, w.s_qn, w.s_tn,
+                           p.tiles * kTileT, w.qsplit, w.qn, w.tsplit, w.tn, w.bmax, w.midflag, w.qerr, w.bmaxerr, w.bqmax, w.s_qsplit, w.s_tsplit, w.s_qn, w.s_tn,
                            p.q4 ? w.qfrag : nullptr, w.tfrag, w.s_qfrag, w.s_tfrag,
                            ratio_counts, ratio_counts ? ratio_stride : 0,
                            p.units, p.tiles, p.G, p.seg_cost, p.n_rb, w.wg_begin, w.rb_first, w.rb_last);
         SFM_CHECK_LAUNCH();
         hipLaunchKernelGGL(knn_split_images_kernel, dim3(kNormBlocks), dim3(kSplitThreads), 0, stream, P, B, ldq, (int)nq, p.nq_pad, ldt, (int)nt,
                            p.tiles * kTileT, w.qsplit, w.tsplit, w.s_qsplit, w.s_tsplit, w.midflag, w.bmax, p.force_mode,
-                           p.q4 ? w.qhm : nullptr, w.thm, w.s_qhm, w.s_thm, w.bmaxerr, w.minfo);
+                           p.q4 ? w.qhm : nullptr, w.thm, w.s_qhm, w.s_thm, w.bmaxerr, w.bqmax, w.minfo);
         SFM_CHECK_LAUNCH();
         sfm::prof_begin(sfm::kProfKnnFilter, stream);
 #define SFM_LAUNCH_SPLIT2(A, WV)                                                                                        \
@@ -2800,7 +2830,7 @@ int knn_batch_impl(int B, const BatchPtrs& P, int64_t nq, int64_t ldq, int64_t n
     hipLaunchKernelGGL(knn_refine_kernel<FRAG>, dim3((unsigned)refine_grid), dim3(256), 0, stream, P, B, ldq, (int)nq, ldt, (int)nt, w.cand_s,    \
                        w.cand_i, p.rows_per_block, p.tiles, p.units, p.G, p.smax * p.nsub, p.nsub, force_mode, w.midflag, w.bmax,               \
                        p.split ? w.minfo : nullptr, p.split ? w.qerr : nullptr, w.s_qn, THALF, w.tn, w.wg_begin, w.rb_first, w.rb_last, p.n_rb1, \
-                       w.s_cand, S_THALF, w.s_tn, ratio, ratio_counts, ratio_stride, chain_scale, g_trace ? g_trace + 16384 : nullptr)
+                       w.s_cand, S_THALF, w.s_tn, ratio, ratio_counts, ratio_stride, chain_scale, p.q4 ? 1 : 0, g_trace ? g_trace + 16384 : nullptr)
     if (p.q4) SFM_LAUNCH_REFINE(true, reinterpret_cast<const unsigned short*>(w.tfrag), w.s_tfrag / 2);      // (stride in 16-bit elements)
     else SFM_LAUNCH_REFINE(false, p.split ? w.tsplit + (size_t)2 * p.tiles * kTileT * kDim : nullptr, w.s_tsplit);
 #undef SFM_LAUNCH_REFINE
