@@ -137,8 +137,12 @@ int g_seg_cost_q4 = [] { const char* e = getenv("SFM_KNN_SEGCOST_Q4"); return e 
 // One workgroup fills the partition tables the filter / refine kernels read: begin[G+1], and per query row block the
 // first and last block that touches it.
 constexpr int kPartLds = 1025;                                  // blocks whose table fits the LDS copy used for the searches
+// Compact candidate streams (q4 filter): a workgroup's segment of L tiles in a row block is ceil(L / kSubTiles) substreams;
+// the substreams of a row block are numbered densely in workgroup order — rb_last[n_rb + rb] = their count, wg_sbase[b] = the
+// number of the first substream of block b's FIRST segment (a later segment of a block opens its row block: number 0) — so
+// the records a query owns are a dense prefix of its slot array and nothing is written for substreams that do not exist.
 __device__ inline void fill_partition_tables(const Partition pt, int n_rb, int64_t* __restrict__ begin, int* __restrict__ rb_first,
-                                             int* __restrict__ rb_last) {
+                                             int* __restrict__ rb_last, int* __restrict__ wg_sbase = nullptr) {
     // the binary searches below are 9-10 DEPENDENT reads each: from global memory that was 6-7 us and made this one
     // workgroup the critical path of the whole prep launch, so they run on an LDS copy of the table
     __shared__ int64_t tab[kPartLds];
@@ -166,6 +170,15 @@ __device__ inline void fill_partition_tables(const Partition pt, int n_rb, int64
             if (look[mid + 1] > u1) hi = mid; else lo = mid + 1;
         }
         rb_last[rb] = lo;
+        if (wg_sbase) {
+            int acc = 0;
+            for (int b = rb_first[rb]; b <= lo; ++b) {
+                const int64_t s0 = look[b] > u0 ? look[b] : u0, s1 = look[b + 1] < u1 + 1 ? look[b + 1] : u1 + 1;
+                if (look[b] >= u0) wg_sbase[b] = acc;              // (block b's range begins in this row block)
+                acc += (int)((s1 - s0 + kSubTilesHost - 1) / kSubTilesHost);
+            }
+            rb_last[n_rb + rb] = acc;
+        }
     }
 }
 
@@ -635,12 +648,12 @@ __global__ __launch_bounds__(kPrepThreads) void knn_prep_kernel(BatchPtrs P, int
                                                        int* __restrict__ zero, int nzero,
                                                        int64_t units, int tiles, int G, int seg_cost, int n_rb,
                                                        int64_t* __restrict__ wg_begin, int* __restrict__ rb_first,
-                                                       int* __restrict__ rb_last) {
+                                                       int* __restrict__ rb_last, int* __restrict__ wg_sbase) {
     constexpr int kPrepWaves = kPrepThreads / 64, kPrepRows = kPrepThreads / 16;
     __shared__ float wmax[kPrepWaves];
     const int pb = blockIdx.y;
     if (blockIdx.x == gridDim.x - 1) {                     // the extra workgroup (of column 0): partition tables, nothing else
-        if (pb == 0) fill_partition_tables(make_partition(units, tiles, G, seg_cost), n_rb, wg_begin, rb_first, rb_last);
+        if (pb == 0) fill_partition_tables(make_partition(units, tiles, G, seg_cost), n_rb, wg_begin, rb_first, rb_last, wg_sbase);
         return;
     }
     const float* __restrict__ Q = P.q[pb];
@@ -1355,7 +1368,7 @@ __device__ __forceinline__ void filter_q4_body(
     const unsigned char* __restrict__ qfrag, const unsigned char* __restrict__ tfrag, const unsigned char* __restrict__ qhm,
     const unsigned char* __restrict__ thm, int nq, int nq_pad, int tiles, int smax, int nsub, float* __restrict__ cand_s0,
     int* __restrict__ cand_i0, const int64_t* __restrict__ wg_begin, const int* __restrict__ rb_first, int n_rb1, int64_t s_qfrag,
-    int64_t s_tfrag, int64_t s_qhm, int64_t s_thm, int64_t s_cand, const int* __restrict__ minfo) {
+    int64_t s_tfrag, int64_t s_qhm, int64_t s_thm, int64_t s_cand, const int* __restrict__ minfo, const int* __restrict__ wg_sbase) {
     constexpr int NG = KMID ? 2 : 4;                          // groups per pass
     constexpr int NPASS = KMID ? 2 : 1;
     constexpr int P = NG / 2;                                 // groups per phase
@@ -1374,11 +1387,11 @@ __device__ __forceinline__ void filter_q4_body(
     asm volatile("v_mov_b32 %0, %1" : "=v"(vmask) : "s"(~kKeyMask));
 
     while (u < u_end) {
-        const int rb = (int)(u / tiles);
-        const int t_begin = (int)(u - (int64_t)rb * tiles);
-        const int t_end = (int)min((int64_t)tiles, t_begin + (u_end - u));
-        const int slot = bid - rb_first[rb];
-        const int pb = n_rb1 > 0 ? rb / n_rb1 : 0;
+        const int rb = __builtin_amdgcn_readfirstlane((int)(u / tiles));      // (the 64-bit division runs on the vector ALU: say that it is uniform)
+        const int t_begin = __builtin_amdgcn_readfirstlane((int)(u - (int64_t)rb * tiles));
+        const int t_end = __builtin_amdgcn_readfirstlane((int)min((int64_t)tiles, t_begin + (u_end - u)));
+        const int sbase = __builtin_amdgcn_readfirstlane(u == wg_begin[bid] ? wg_sbase[bid] : 0);   // number of this segment's first substream in its row block (compact streams)
+        const int pb = __builtin_amdgcn_readfirstlane(n_rb1 > 0 ? rb / n_rb1 : 0);
         const int rbl = rb - pb * n_rb1;
         float* __restrict__ cand_s = cand_s0 + pb * s_cand;
         int* __restrict__ cand_i = cand_i0 + pb * s_cand;
@@ -1457,7 +1470,7 @@ __device__ __forceinline__ void filter_q4_body(
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
                     if (qok[g]) {
-                        const int64_t ob = ((int64_t)(qr + 32 * g) * (2 * smax * nsub) + (int64_t)slot * nsub * 2 + h) * 3 + 6 * sb;
+                        const int64_t ob = ((int64_t)(qr + 32 * g) * (2 * smax * nsub) + (int64_t)(sbase + sb) * 2 + h) * 3;
                         flush_keys<true>(k0[g], k1[g], k2[g], st0, h, cand_s + ob, cand_i + ob);
                     }
                     k0[g] = k1[g] = k2[g] = kKeyInf;
@@ -1584,17 +1597,6 @@ __device__ __forceinline__ void filter_q4_body(
                     for (int r = 0; r < 16; r += 4) key_insert_quad(acc[g], r, seq + (r >> 2), vmask, k0[g], k1[g], k2[g]);
             }
             flush(sub, sub_t0);
-#pragma unroll
-            for (int g = 0; g < NG; ++g)
-                if (qok[g]) {
-                    const int64_t ob = ((int64_t)(qrow0 + 32 * g) * (2 * smax * nsub) + (int64_t)slot * nsub * 2 + h) * 3;
-                    for (int e = sub + 1; e < nsub; ++e)
-#pragma unroll
-                        for (int r = 0; r < 3; ++r) {
-                            cand_s[ob + 6 * e + r] = kInf;
-                            cand_i[ob + 6 * e + r] = -1;
-                        }
-                }
         }
         u += t_end - t_begin;
     }
@@ -1607,7 +1609,7 @@ __global__ __launch_bounds__(256, 1) void knn_filter_q4_kernel(
     const float* __restrict__ bmax, int force_mode, float* __restrict__ cand_s, int* __restrict__ cand_i,
     const int64_t* __restrict__ wg_begin, const int* __restrict__ rb_first, int n_rb1, int n_pairs, int64_t s_qfrag, int64_t s_tfrag,
     int64_t s_qhm, int64_t s_thm, int64_t s_cand, int* __restrict__ minfo, const float* __restrict__ bmaxerr,
-    long long* __restrict__ trace) {
+    const int* __restrict__ wg_sbase, long long* __restrict__ trace) {
     if (trace && threadIdx.x == 0) {
         trace[4 * blockIdx.x + 0] = wall_clock64();
         trace[4 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg(0xF804);
@@ -1617,10 +1619,10 @@ __global__ __launch_bounds__(256, 1) void knn_filter_q4_kernel(
     const bool need_mid = (force_mode >= 0 ? force_mode : minfo[kMinfoBatchMode]) == kModeSplit;   // (reduced by knn_split_images_kernel)
     if (need_mid)
         filter_q4_body<true, 0>(qfrag, tfrag, qhm, thm, nq, nq_pad, tiles, smax, nsub, cand_s, cand_i, wg_begin, rb_first, n_rb1, s_qfrag, s_tfrag, s_qhm,
-                             s_thm, s_cand, minfo);
+                             s_thm, s_cand, minfo, wg_sbase);
     else
         filter_q4_body<false, ABL>(qfrag, tfrag, qhm, thm, nq, nq_pad, tiles, smax, nsub, cand_s, cand_i, wg_begin, rb_first, n_rb1, s_qfrag, s_tfrag, s_qhm,
-                              s_thm, s_cand, minfo);
+                              s_thm, s_cand, minfo, wg_sbase);
     if (trace && threadIdx.x == 0) {
         trace[4 * blockIdx.x + 1] = wall_clock64();
         trace[8192 + 4 * blockIdx.x + 3] = clock64();
@@ -1839,6 +1841,13 @@ __global__ __launch_bounds__(256, 4) void knn_refine_kernel(
     const int q = bid * kRefQ + ql;
     const bool valid = q < nq;
 
+    // streams of this workgroup's query row block = filter blocks that touched it (contiguous slots from 0);
+    // the queries of a workgroup share the row block (rows_per_block is a multiple of 16)
+    const int rb = pb * n_rb1 + (bid * kRefQ) / rows_per_block;      // GLOBAL row block (the partition tables span the batch)
+    const int fb = rb_first[rb];
+    const int lb = rb_last[rb];
+    // (q4 filter: compact streams — the row block's live substreams, numbered densely; else every slot's nsub substreams)
+    const int NC = qoff ? 2 * rb_last[B * n_rb1 + rb] * 3 : 2 * (lb - fb + 1) * nsub * 3;
     for (int e = threadIdx.x; e < kRefQ * 32; e += 256) {
         const int row = bid * kRefQ + (e >> 5);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1866,9 +1875,6 @@ __global__ __launch_bounds__(256, 4) void knn_refine_kernel(
     const float eps_coef = mode == kModeHalfExact ? kEpsExact : mode == kModeHalf ? kEpsExact + kEpsHalfOp
                            : mode == kModeSplit ? kEpsRound + kChainSplit * chain_scale + kEpsSplitOp : kEpsF32;
 
-    // streams of this workgroup's query row block = filter blocks that touched it (contiguous slots from 0);
-    // the queries of a workgroup share the row block (rows_per_block is a multiple of 16)
-    const int rb = pb * n_rb1 + (bid * kRefQ) / rows_per_block;      // GLOBAL row block (the partition tables span the batch)
     const float* cs = cand_s + (int64_t)(valid ? q : 0) * (2 * smax * 3);
     const int* ci = cand_i + (int64_t)(valid ? q : 0) * (2 * smax * 3);
     if (bid == 0 && threadIdx.x == 0 && stats) {
@@ -1881,21 +1887,12 @@ __global__ __launch_bounds__(256, 4) void knn_refine_kernel(
     float s1v[kS1];
     int i1v[kS1];                                        // the records' row ids ride along: sweep 2 takes its first 16 * kS1
 #pragma unroll                                           // records from these registers instead of a second, dependent round trip
-    for (int k = 0; k < kS1; ++k) {                      // (issued before NC is known: one dependent round trip less; slots
-        const int c = min(sl + 16 * k, 2 * smax * 3 - 1);   // past NC hold stale records and are masked below)
-        s1v[k] = valid ? cs[c] : kInf;
-        i1v[k] = valid ? ci[c] : -1;
+    for (int k = 0; k < kS1; ++k) {                      // (NC: three scalar loads issued at the top of the kernel, behind the
+        const int c = sl + 16 * k;                       // query rows' vector loads; slots past NC were never written by this
+        s1v[k] = (valid && c < NC) ? cs[c] : kInf;       // launch — reading them would be HBM traffic for nothing)
+        i1v[k] = (valid && c < NC) ? ci[c] : -1;
     }
     const float qe2 = (qerr && valid) ? qerr[pb * s_qn + q] : 0.f;   // (issued with the record loads: not a round trip of its own)
-    const int fb = rb_first[rb];
-    const int lb = rb_last[rb];
-    const int NC = 2 * (lb - fb + 1) * nsub * 3;
-#pragma unroll
-    for (int k = 0; k < kS1; ++k)
-        if (sl + 16 * k >= NC) {
-            s1v[k] = kInf;
-            i1v[k] = -1;
-        }
     __syncthreads();                                     // query rows in LDS
     if (trace && threadIdx.x == 0) trace[16 * bidt + 1] = wall_clock64();
     float qq;
@@ -2196,7 +2193,17 @@ __global__ __launch_bounds__(256, 4) void knn_refine_kernel(
             const int n_it = min(nitem, kRefItems);
             for (int it = 0; it < n_it; ++it) {
                 const int w = items[it] >> 20, sid = items[it] & 0xFFFFF;
-                const int slot = sid / (2 * nsub), sb = (sid % (2 * nsub)) >> 1, h = sid & 1;
+                int slot = sid / (2 * nsub), sb = (sid % (2 * nsub)) >> 1;
+                const int h = sid & 1;
+                if (qoff) {                                   // compact streams: walk the row block's blocks to the one that owns substream sid >> 1
+                    sb = sid >> 1;
+                    for (slot = 0; fb + slot < lb; ++slot) {
+                        const int64_t a0 = max(wg_begin[fb + slot], (int64_t)rb * tiles), a1 = min(wg_begin[fb + slot + 1], (int64_t)(rb + 1) * tiles);
+                        const int nl = (int)((a1 - a0 + kSubTiles - 1) / kSubTiles);
+                        if (sb < nl) break;
+                        sb -= nl;
+                    }
+                }
                 const int wg = fb + slot;
                 const int64_t u0 = max(wg_begin[wg], (int64_t)rb * tiles);
                 const int64_t u1 = min(wg_begin[wg + 1], (int64_t)(rb + 1) * tiles);
@@ -2474,6 +2481,7 @@ struct KnnWs {
     int64_t* wg_begin;            // partition tables over the whole batch (filled by the prep / norms launch)
     int* rb_first;
     int* rb_last;
+    int* wg_sbase;                // [G] number of the first substream of a block's first segment (compact streams, q4)
     float* cand_s;
     int* cand_i;
     unsigned char* qfrag;         // q4 filter: fragment-order fp16 images (+ init fragments), kTileFragBytes per 32 rows
@@ -2499,7 +2507,8 @@ KnnWs carve_ws(void* ws, int64_t nq, int64_t nt, const Plan& p) {
     w.minfo = c.take<int>(kMinfoWords);
     w.wg_begin = c.take<int64_t>((size_t)p.G + 1);
     w.rb_first = c.take<int>((size_t)p.n_rb);
-    w.rb_last = c.take<int>((size_t)p.n_rb);
+    w.rb_last = c.take<int>(2 * (size_t)p.n_rb);          // [n_rb] last block, then [n_rb] live substreams of the row block
+    w.wg_sbase = c.take<int>((size_t)p.G + 1);
     w.tn = c.take<float>(B * (size_t)w.s_tn);
     w.qn = c.take<float>(B * (size_t)w.s_qn);
     w.qerr = c.take<float>(B * (size_t)w.s_qn);
@@ -2753,7 +2762,7 @@ int knn_batch_impl(int B, const BatchPtrs& P, int64_t nq, int64_t ldq, int64_t n
                            p.tiles * kTileT, w.qsplit, w.qn, w.tsplit, w.tn, w.bmax, w.midflag, w.qerr, w.bmaxerr, w.bqmax, w.s_qsplit, w.s_tsplit, w.s_qn, w.s_tn,
                            p.q4 ? w.qfrag : nullptr, w.tfrag, w.s_qfrag, w.s_tfrag,
                            ratio_counts, ratio_counts ? ratio_stride : 0,
-                           p.units, p.tiles, p.G, p.seg_cost, p.n_rb, w.wg_begin, w.rb_first, w.rb_last);
+                           p.units, p.tiles, p.G, p.seg_cost, p.n_rb, w.wg_begin, w.rb_first, w.rb_last, p.q4 ? w.wg_sbase : nullptr);
         SFM_CHECK_LAUNCH();
         hipLaunchKernelGGL(knn_split_images_kernel, dim3(kNormBlocks), dim3(kSplitThreads), 0, stream, P, B, ldq, (int)nq, p.nq_pad, ldt, (int)nt,
                            p.tiles * kTileT, w.qsplit, w.tsplit, w.s_qsplit, w.s_tsplit, w.midflag, w.bmax, p.force_mode,
@@ -2772,7 +2781,7 @@ int knn_batch_impl(int B, const BatchPtrs& P, int64_t nq, int64_t ldq, int64_t n
 #define SFM_LAUNCH_Q4(A)                                                                                                                         \
     hipLaunchKernelGGL(knn_filter_q4_kernel<A>, grid, dim3(256), 0, stream, w.qfrag, w.tfrag, w.qhm, w.thm, (int)nq, p.nq_pad, p.tiles, p.smax, p.nsub, \
                        w.midflag, w.bmax, p.force_mode, w.cand_s, w.cand_i, w.wg_begin, w.rb_first, p.n_rb1, B, w.s_qfrag, w.s_tfrag, w.s_qhm,         \
-                       w.s_thm, w.s_cand, w.minfo, w.bmaxerr, g_trace)
+                       w.s_thm, w.s_cand, w.minfo, w.bmaxerr, w.wg_sbase, g_trace)
             if (abl == 1) SFM_LAUNCH_Q4(1); else if (abl == 2) SFM_LAUNCH_Q4(2); else if (abl == 3) SFM_LAUNCH_Q4(3); else if (abl == 4) SFM_LAUNCH_Q4(4); else SFM_LAUNCH_Q4(0);
 #undef SFM_LAUNCH_Q4
         } else if (p.waves == 4) {
