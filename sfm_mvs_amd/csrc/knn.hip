@@ -4,15 +4,18 @@
 //   1. knn_prep_kernel    one pass over Q and T: the fp16 operand image, fp32 ||.||^2, exactness / range flags, the
 //                         work-partition tables (knn_norms_kernel for the fp32-MFMA variant);
 //      knn_split_images_kernel  the bf16 hi/mid planes, only when the flags ask for the split arithmetic.
-//   2. knn_filter_*       s(q,t) = ||t||^2 + ||q||^2 - 2 q.t on the matrix pipe with the OPERANDS SWAPPED
-//                         (A = train tile from LDS, B = query fragments resident in VGPRs) so that a lane
-//                         owns ONE query column and the running top-3 per lane needs no cross-lane traffic.
-//                         Default: knn_filter_split2_kernel — v_mfma_f32_32x32x16_{f16,bf16}, one fp16 product
-//                         or three bf16 hi/mid products, chosen on the device from the data; train tiles stream
-//                         L2 -> LDS by buffer_load ... lds into a 3-slot ring (XOR-swizzled image); 2 x 32 queries
-//                         per wave, two 4-wave workgroups per CU, cost-weighted stream-K split over batch x row blocks
-//                         x tiles.  Every (workgroup segment, 64-tile substream, half-wave) triple is an independent
-//                         "stream" that emits its 3 best records (a record = a quad of adjacent trains).
+//   2. knn_filter_*       s(q,t) = ||t||^2 + c - 2 q.t on the matrix pipe with the OPERANDS SWAPPED (A = train tile, B = query
+//                         fragments resident in registers) so that a lane owns ONE query column and the running top-3
+//                         per lane needs no cross-lane traffic.
+//                         Default: knn_filter_q4_kernel — v_mfma_f32_32x32x16_{f16,bf16}, one fp16 product or three bf16
+//                         hi/mid products, chosen on the device from the data; ONE wave per SIMD owning 4 x 32 queries
+//                         whose fragments sit in accumulation registers; train tiles stream from a FRAGMENT-ORDER image
+//                         straight into the MFMA's A registers (no LDS); c = the pair's largest ||q||^2, so that one
+//                         init MFMA per tile serves all four groups; cost-weighted stream-K split over batch x row blocks
+//                         x tiles.  (knn_filter_split2_kernel: the round-2 LDS-ring kernel, c = the query's own
+//                         ||q||^2, kept as the `lds` variants; knn_filter_kernel: fp32 MFMA.)
+//                         Every (workgroup segment, 64-tile substream, half-wave) triple is an independent "stream" that
+//                         emits its 3 best records (a record = a quad of adjacent trains).
 //   3. knn_refine_kernel  16 lanes per query: screens the rows of the records that can still matter against the fp16
 //                         image, re-evaluates the survivors with the reference's direct-form float32 arithmetic (sub,
 //                         mul, add — no FMA — in OpenCV's 2x4-lane accumulation order, then sqrtf), orders them by
@@ -1768,6 +1771,16 @@ __device__ __forceinline__ void exact_l2sq_quad_rows(const float* __restrict__ q
     }
 }
 
+// The refine kernel's merge over a query's 16 lanes: only lane 2 of every quad ever inserts evaluated rows (the other lanes
+// hold what all 16 agreed on earlier, a subset of lane 2's), so the two in-quad exchange steps are one broadcast of lane 2.
+__device__ __forceinline__ void best2_reduce16_from_quad_lane2(Best2& b) {
+    auto bc = [](int v) { return __builtin_amdgcn_update_dpp(0, v, 0xAA /*quad_perm [2,2,2,2]*/, 0xF, 0xF, false); };
+    b.d[0] = __int_as_float(bc(__float_as_int(b.d[0]))); b.i[0] = bc(b.i[0]);
+    b.d[1] = __int_as_float(bc(__float_as_int(b.d[1]))); b.i[1] = bc(b.i[1]);
+    best2_exchange_step<8>(b);
+    best2_exchange_step<4>(b);
+}
+
 constexpr int kRatioBlock = 1024; // queries per ratio workgroup (256 threads x 4 consecutive queries)
 constexpr int kRefQ = 16;        // queries per refine workgroup: 16 lanes each
 constexpr int kS1 = 6;           // candidate records per lane fetched up front by sweep 1 (96 per query)
@@ -2150,7 +2163,7 @@ __global__ __launch_bounds__(256, 4) void knn_refine_kernel(
     bool rescanned = false;
     for (int round = 0;; ++round) {
         if (round == 1) evaluate(std::false_type{});      // rescan survivors (cold site)
-        best2_group_reduce<16>(b);
+        best2_reduce16_from_quad_lane2(b);
         if (trace && threadIdx.x == 0 && round == 0) trace[16 * bidt + 3] = wall_clock64();
         if (round == 1) break;
         // Certificate.  (s3 < 0 can only be rounding noise: such a stream never certifies.)
