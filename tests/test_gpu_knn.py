@@ -104,6 +104,32 @@ def test_dynamic_range(hip, oracle, scale):
     assert_bit_equal(run(hip, q, t), oracle.knn2(q, t, nthreads=8))
 
 
+@pytest.mark.parametrize("boost", [30.0, 300.0, 1e4])
+def test_query_norm_outliers_share_the_pairs_score_offset(hip, oracle, boost):
+    """The q4 filter scores with ||t||^2 + ||q||^2max - 2 q.t (one init MFMA per tile for all query groups): a few queries of
+    huge norm raise the common offset — and the slack — of every other query of the pair.  That may cost rescans, never
+    exactness; and the rescans stay the exception."""
+    rng = np.random.default_rng(int(boost))
+    q, t = rng.random((3000, 128), dtype=np.float32), rng.random((2600, 128), dtype=np.float32)
+    q[[5, 1500, 2999]] *= np.float32(boost)          # (boost 1e4: -2q leaves fp16's range -> the bf16 split runs)
+    q[7] *= np.float32(1e-3)
+    for filt in ("auto", "split", "lds"):
+        gi, gd, st = run(hip, q, t, stats=True, filter=filt)
+        assert_bit_equal((gi, gd), oracle.knn2(q, t, nthreads=8))
+    # batched: the offset is per PAIR — the outliers of pair 0 must not leak into pair 1's slack or results
+    q1, t1 = rng.random((3000, 128), dtype=np.float32), rng.random((2600, 128), dtype=np.float32)
+    bm = hip.BatchMatcher(3000, 2600, torch.device("cuda"), ratio=0.70, batch=2)
+    bm.run([(torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda()), (torch.from_numpy(q1).cuda(), torch.from_numpy(t1).cuda())])
+    torch.cuda.synchronize()
+    for b, (qq, tt) in enumerate(((q, t), (q1, t1))):
+        assert_bit_equal((bm.idx[b].cpu().numpy(), bm.dist[b].cpu().numpy()), oracle.knn2(qq, tt, nthreads=8))
+    alone = hip.BatchMatcher(3000, 2600, torch.device("cuda"), ratio=0.70, batch=1)
+    alone.run([(torch.from_numpy(q1).cuda(), torch.from_numpy(t1).cuda())])
+    torch.cuda.synchronize()
+    if boost < 1e3:                                   # (same arithmetic mode alone and in the batch)
+        assert int(bm.stats[1][0]) == int(alone.stats[0][0]), "pair 1 rescans as often beside the outlier pair as alone"
+
+
 def test_duplicated_train_set(hip, oracle):
     rng = np.random.default_rng(8)
     base = rng.random((100, 128), dtype=np.float32)
