@@ -703,6 +703,27 @@ def extra_c4(dev):
     return out
 
 
+def extra_other_workloads(args, dev):
+    """Short runs of the other workloads inside the default run, so that the driver's own bench record carries them
+    (each is the `--workload X` leg with fewer steps; a leg that fails is reported, it never takes the headline line down):
+    configs[4] (the full 255-pair job on this one GPU), SIFT frames/s, the 57-camera driver."""
+    import copy
+    out = {}
+    for key, fn, over in (("config5", bench_c5, {}), ("sift", bench_sift, {"steps": 30, "warmup": 5}), ("sfm57", bench_sfm, {"steps": 2, "warmup": 1})):
+        a = copy.copy(args)
+        for k, v in over.items():
+            setattr(a, k, v)
+        try:
+            r = fn(a, 1, 0, dev)
+            keep = ("metric", "value", "unit", "ms_per_step", "config", "roofline", "cpu_baseline", "parity", "frame_latency_ms_single_stream",
+                    "job_seconds", "match_seconds", "triangulated_points_total", "planted_matches_recovered_as_nearest_neighbour", "scaling")
+            out[key] = {k: r[k] for k in keep if k in r}
+        except Exception as e:      # noqa: BLE001 — an extra, not the measurement
+            out[key] = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.synchronize()
+    return out
+
+
 def bench_ba(args, world, rank, dev):
     from sfm_mvs_amd import ops
     ncam, npt = 500, 200_000
@@ -949,6 +970,7 @@ def main():
             if not args.no_extras:
                 out["extra"] = extras(dev)
                 out["extra"]["config4"] = extra_c4(dev)
+                out["extra"].update(extra_other_workloads(args, dev))
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_knn_baseline(args.nq, args.nt, 0, 1)
     elif args.workload == "tri":
