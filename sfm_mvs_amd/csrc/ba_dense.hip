@@ -122,54 +122,90 @@ __global__ __launch_bounds__(256) void ba_dense_kernel(const double* __restrict_
             double x = e[0] * Xw[pp] + e[1] * Yw[pp] + e[2] * Zw[pp] + e[9];
             double y = e[3] * Xw[pp] + e[4] * Yw[pp] + e[5] * Zw[pp] + e[10];
             double z = e[6] * Xw[pp] + e[7] * Yw[pp] + e[8] * Zw[pp] + e[11];
-            z = z != 0.0 ? 1. / z : 1.;
+            // 1 / z: the hardware estimate (~26 bits) + two Newton steps — a third of the IEEE division's instructions,
+            // full double accuracy up to the last bit or two (the sums are checked to 1e-10)
+            if (z != 0.0) {
+                double r = __builtin_amdgcn_rcp(z);
+                r = fma(fma(-z, r, 1.0), r, r);
+                r = fma(fma(-z, r, 1.0), r, r);
+                z = r;
+            } else {
+                z = 1.;
+            }
             x *= z;
             y *= z;
             const double u = x * K.fx + K.cx, v = y * K.fy + K.cy;
             const float dxf = (float)u - ob[pp].x, dyf = (float)v - ob[pp].y;
             cacc[27] += (double)dxf * (double)dxf + (double)dyf * (double)dyf;
             const double ru = u - (double)ob[pp].x, rv = v - (double)ob[pp].y;
-            double Ju[6], Jv[6];
+            const double fxz = K.fx * z, fyz = K.fy * z;
+            // camera-side Jacobian rows: Ju = (Ju0, Ju1, Ju2, fx z, 0, -fx x z), Jv = (Jv0, Jv1, Jv2, 0, fy z, -fy y z)
+            double Ju[3], Jv[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const double* d = e + 12 + 9 * j;
                 const double dx0 = Xw[pp] * d[0] + Yw[pp] * d[1] + Zw[pp] * d[2];
                 const double dy0 = Xw[pp] * d[3] + Yw[pp] * d[4] + Zw[pp] * d[5];
                 const double dz0 = Xw[pp] * d[6] + Yw[pp] * d[7] + Zw[pp] * d[8];
-                Ju[j] = K.fx * (z * (dx0 - x * dz0));
-                Jv[j] = K.fy * (z * (dy0 - y * dz0));
+                Ju[j] = fxz * (dx0 - x * dz0);
+                Jv[j] = fyz * (dy0 - y * dz0);
             }
-            Ju[3] = K.fx * z; Ju[4] = 0;        Ju[5] = K.fx * (-x * z);
-            Jv[3] = 0;        Jv[4] = K.fy * z; Jv[5] = K.fy * (-y * z);
+            const double Ju5 = -x * fxz, Jv5 = -y * fyz;
+            // J^T J (upper triangle, row-major q = 0..20) and J^T r as one fused multiply-add per NONZERO product: the
+            // structural zeros of the translation columns (Ju[4] = Jv[3] = 0) are never multiplied
             {
+                // rows 0..2
                 int q = 0;
 #pragma unroll
-                for (int a = 0; a < 6; ++a)
+                for (int a = 0; a < 3; ++a) {
 #pragma unroll
-                    for (int b = a; b < 6; ++b) {
-                        cacc[q] += Ju[a] * Ju[b] + Jv[a] * Jv[b];
+                    for (int b2 = a; b2 < 3; ++b2) {
+                        cacc[q] = fma(Ju[a], Ju[b2], cacc[q]);
+                        cacc[q] = fma(Jv[a], Jv[b2], cacc[q]);
                         ++q;
                     }
+                    cacc[q] = fma(Ju[a], fxz, cacc[q]); ++q;                    // (a, 3)
+                    cacc[q] = fma(Jv[a], fyz, cacc[q]); ++q;                    // (a, 4)
+                    cacc[q] = fma(Ju[a], Ju5, cacc[q]);
+                    cacc[q] = fma(Jv[a], Jv5, cacc[q]); ++q;                    // (a, 5)
+                }
+                cacc[15] = fma(fxz, fxz, cacc[15]);                             // (3, 3); (3, 4) = cacc[16] stays 0
+                cacc[17] = fma(fxz, Ju5, cacc[17]);                             // (3, 5)
+                cacc[18] = fma(fyz, fyz, cacc[18]);                             // (4, 4)
+                cacc[19] = fma(fyz, Jv5, cacc[19]);                             // (4, 5)
+                cacc[20] = fma(Ju5, Ju5, cacc[20]);
+                cacc[20] = fma(Jv5, Jv5, cacc[20]);                             // (5, 5)
 #pragma unroll
-                for (int a = 0; a < 6; ++a) cacc[21 + a] += Ju[a] * ru + Jv[a] * rv;
+                for (int a = 0; a < 3; ++a) {
+                    cacc[21 + a] = fma(Ju[a], ru, cacc[21 + a]);
+                    cacc[21 + a] = fma(Jv[a], rv, cacc[21 + a]);
+                }
+                cacc[24] = fma(fxz, ru, cacc[24]);
+                cacc[25] = fma(fyz, rv, cacc[25]);
+                cacc[26] = fma(Ju5, ru, cacc[26]);
+                cacc[26] = fma(Jv5, rv, cacc[26]);
             }
             double Pu[3], Pv[3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                Pu[k] = K.fx * (z * (e[k] - x * e[6 + k]));
-                Pv[k] = K.fy * (z * (e[3 + k] - y * e[6 + k]));
+                Pu[k] = fxz * (e[k] - x * e[6 + k]);
+                Pv[k] = fyz * (e[3 + k] - y * e[6 + k]);
             }
             {
                 int q = 0;
 #pragma unroll
                 for (int a = 0; a < 3; ++a)
 #pragma unroll
-                    for (int b = a; b < 3; ++b) {
-                        pacc[pp][q] += Pu[a] * Pu[b] + Pv[a] * Pv[b];
+                    for (int b2 = a; b2 < 3; ++b2) {
+                        pacc[pp][q] = fma(Pu[a], Pu[b2], pacc[pp][q]);
+                        pacc[pp][q] = fma(Pv[a], Pv[b2], pacc[pp][q]);
                         ++q;
                     }
 #pragma unroll
-                for (int a = 0; a < 3; ++a) pacc[pp][6 + a] += Pu[a] * ru + Pv[a] * rv;
+                for (int a = 0; a < 3; ++a) {
+                    pacc[pp][6 + a] = fma(Pu[a], ru, pacc[pp][6 + a]);
+                    pacc[pp][6 + a] = fma(Pv[a], rv, pacc[pp][6 + a]);
+                }
             }
         }
         // fixed-order block reduction of the 28 camera-side sums

@@ -103,6 +103,48 @@ __device__ __forceinline__ void pair_jacobians(const double* __restrict__ e, con
     }
 }
 
+// The same Jacobians with the structure of the translation columns spelled out — Ju = (Ju[0..2], fxz, 0, Ju5),
+// Jv = (Jv[0..2], 0, fyz, Jv5) — for the dense products below, which never multiply the structural zeros and take 1 / z
+// from the hardware estimate + two Newton steps (as ba_dense_kernel; the sums are checked to 1e-10).
+struct PairJ {
+    double Ju[3], Jv[3], fxz, fyz, Ju5, Jv5, Pu[3], Pv[3];
+};
+__device__ __forceinline__ PairJ pair_jacobians_structured(const double* __restrict__ e, const Intrin& K, double Xw, double Yw, double Zw) {
+    PairJ J;
+    double x = e[0] * Xw + e[1] * Yw + e[2] * Zw + e[9];
+    double y = e[3] * Xw + e[4] * Yw + e[5] * Zw + e[10];
+    double z = e[6] * Xw + e[7] * Yw + e[8] * Zw + e[11];
+    if (z != 0.0) {
+        double r = __builtin_amdgcn_rcp(z);
+        r = fma(fma(-z, r, 1.0), r, r);
+        r = fma(fma(-z, r, 1.0), r, r);
+        z = r;
+    } else {
+        z = 1.;
+    }
+    x *= z;
+    y *= z;
+    J.fxz = K.fx * z;
+    J.fyz = K.fy * z;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double* d = e + 12 + 9 * j;
+        const double dx0 = Xw * d[0] + Yw * d[1] + Zw * d[2];
+        const double dy0 = Xw * d[3] + Yw * d[4] + Zw * d[5];
+        const double dz0 = Xw * d[6] + Yw * d[7] + Zw * d[8];
+        J.Ju[j] = J.fxz * (dx0 - x * dz0);
+        J.Jv[j] = J.fyz * (dy0 - y * dz0);
+    }
+    J.Ju5 = -x * J.fxz;
+    J.Jv5 = -y * J.fyz;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        J.Pu[k] = J.fxz * (e[k] - x * e[6 + k]);
+        J.Pv[k] = J.fyz * (e[3 + k] - y * e[6 + k]);
+    }
+    return J;
+}
+
 // u_j (partial over a camera chunk) = sum_i Jp_ij^T (Jc_ij x_i)
 template <int PP>
 __global__ __launch_bounds__(256) void schur_wt_kernel(const double* __restrict__ table, Intrin K, int ncam,
@@ -131,16 +173,20 @@ __global__ __launch_bounds__(256) void schur_wt_kernel(const double* __restrict_
 #pragma unroll
         for (int pp = 0; pp < PP; ++pp) {
             if (!live[pp]) continue;
-            double Ju[6], Jv[6], Pu[3], Pv[3];
-            pair_jacobians(e, K, Xw[pp], Yw[pp], Zw[pp], Ju, Jv, Pu, Pv);
-            double tu = 0, tv = 0;
+            const PairJ J = pair_jacobians_structured(e, K, Xw[pp], Yw[pp], Zw[pp]);
+            double tu = J.fxz * xi[3], tv = J.fyz * xi[4];
+            tu = fma(J.Ju5, xi[5], tu);
+            tv = fma(J.Jv5, xi[5], tv);
 #pragma unroll
-            for (int a = 0; a < 6; ++a) {
-                tu += Ju[a] * xi[a];
-                tv += Jv[a] * xi[a];
+            for (int a = 0; a < 3; ++a) {
+                tu = fma(J.Ju[a], xi[a], tu);
+                tv = fma(J.Jv[a], xi[a], tv);
             }
 #pragma unroll
-            for (int k = 0; k < 3; ++k) acc[pp][k] += Pu[k] * tu + Pv[k] * tv;
+            for (int k = 0; k < 3; ++k) {
+                acc[pp][k] = fma(J.Pu[k], tu, acc[pp][k]);
+                acc[pp][k] = fma(J.Pv[k], tv, acc[pp][k]);
+            }
         }
     }
 #pragma unroll
@@ -196,12 +242,18 @@ __global__ __launch_bounds__(256) void schur_w_kernel(const double* __restrict__
 #pragma unroll
         for (int pp = 0; pp < PP; ++pp) {
             if (!live[pp]) continue;
-            double Ju[6], Jv[6], Pu[3], Pv[3];
-            pair_jacobians(e, K, Xw[pp], Yw[pp], Zw[pp], Ju, Jv, Pu, Pv);
-            const double su = Pu[0] * vj[pp][0] + Pu[1] * vj[pp][1] + Pu[2] * vj[pp][2];
-            const double sv = Pv[0] * vj[pp][0] + Pv[1] * vj[pp][1] + Pv[2] * vj[pp][2];
+            const PairJ J = pair_jacobians_structured(e, K, Xw[pp], Yw[pp], Zw[pp]);
+            const double su = J.Pu[0] * vj[pp][0] + J.Pu[1] * vj[pp][1] + J.Pu[2] * vj[pp][2];
+            const double sv = J.Pv[0] * vj[pp][0] + J.Pv[1] * vj[pp][1] + J.Pv[2] * vj[pp][2];
 #pragma unroll
-            for (int a = 0; a < 6; ++a) cacc[a] += Ju[a] * su + Jv[a] * sv;
+            for (int a = 0; a < 3; ++a) {
+                cacc[a] = fma(J.Ju[a], su, cacc[a]);
+                cacc[a] = fma(J.Jv[a], sv, cacc[a]);
+            }
+            cacc[3] = fma(J.fxz, su, cacc[3]);
+            cacc[4] = fma(J.fyz, sv, cacc[4]);
+            cacc[5] = fma(J.Ju5, su, cacc[5]);
+            cacc[5] = fma(J.Jv5, sv, cacc[5]);
         }
         __syncthreads();   // previous camera's readers are done
 #pragma unroll
