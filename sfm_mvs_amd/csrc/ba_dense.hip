@@ -316,11 +316,7 @@ DensePlan dense_plan(int64_t ncam, int64_t npt) {
     DensePlan d;
     d.pp = npt >= 64 * 1024 ? 4 : 2;
     d.tiles = (int)((npt + 256 * d.pp - 1) / (256 * d.pp));
-    int nch = d.tiles > 0 ? (1024 + d.tiles - 1) / d.tiles : 1;
-    if (nch > ncam / 16) nch = (int)(ncam / 16);
-    if (nch < 1) nch = 1;
-    if (nch > 64) nch = 64;
-    d.nch = nch;
+    d.nch = sfm::pick_camera_chunks(d.tiles, ncam, 512);      // (two workgroups per CU: 202 VGPRs, 59 KB of LDS)
     return d;
 }
 

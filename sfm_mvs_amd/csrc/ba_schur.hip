@@ -331,12 +331,7 @@ SchurPlan schur_plan(int64_t ncam, int64_t npt, bool cam_side) {
     SchurPlan d;
     d.pp = npt >= 64 * 1024 ? 4 : 2;
     d.tiles = (int)((npt + 256 * d.pp - 1) / (256 * d.pp));
-    int nch = d.tiles > 0 ? (1024 + d.tiles - 1) / d.tiles : 1;
-    if (nch > ncam / 16) nch = (int)(ncam / 16);
-    if (nch < 1) nch = 1;
-    if (nch > 64) nch = 64;
-    d.nch = nch;
-    (void)cam_side;
+    d.nch = sfm::pick_camera_chunks(d.tiles, ncam, cam_side ? 1024 : 1280);      // (schur_w: 4 waves per SIMD, schur_wt: 5)
     return d;
 }
 
@@ -699,7 +694,8 @@ extern "C" int sfm_ba_schur_solve(const double* cams, int64_t ncam, const double
     SFM_CHECK_LAUNCH();
     // rhs = g_c - W Cd^-1 g_p
     hipLaunchKernelGGL(schur_pt_apply_kernel, dim3(pblocks), dim3(256), 0, stream, w.Cinv, Jtr_pt, (const double*)nullptr, 1.0, npt, w.v);
-    launch_w(stream, d, w.prod, K, ncam, X, npt, ldx, w.v, w.wv);
+    const SchurPlan dw = schur_plan(ncam, npt, true);                // (the camera-side product has its own occupancy, hence its own chunking)
+    launch_w(stream, dw, w.prod, K, ncam, X, npt, ldx, w.v, w.wv);
     hipLaunchKernelGGL(schur_cg_init_kernel, dim3(1), dim3(kCgThreads), 0, stream, Jtr_cam, w.wv, w.Minv, n, fix_first_camera ? 1 : 0,
                        cg_tol * cg_tol, dc_dev, w.r, w.p, w.scal);
     SFM_CHECK_LAUNCH();
@@ -714,7 +710,7 @@ extern "C" int sfm_ba_schur_solve(const double* cams, int64_t ncam, const double
         sfm::prof_begin(sfm::kProfBaSchur, stream);
         launch_wt(stream, d, w.prod, K, ncam, X, npt, ldx, w.p, w.u);                                   // u = W^T p
         hipLaunchKernelGGL(schur_pt_apply_kernel, dim3(pblocks), dim3(256), 0, stream, w.Cinv, w.u, (const double*)nullptr, 1.0, npt, w.v);
-        launch_w(stream, d, w.prod, K, ncam, X, npt, ldx, w.v, w.wv);                                   // w = W Cd^-1 u
+        launch_w(stream, dw, w.prod, K, ncam, X, npt, ldx, w.v, w.wv);                                   // w = W Cd^-1 u
         sfm::prof_end(sfm::kProfBaSchur, stream, 2);
         hipLaunchKernelGGL(schur_cg_step_kernel, dim3(1), dim3(kCgThreads), 0, stream, w.Bd, w.Minv, w.wv, n, fix_first_camera ? 1 : 0, dc_dev,
                            w.r, w.p, w.tmp, w.scal);

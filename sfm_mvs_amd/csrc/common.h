@@ -20,6 +20,25 @@ int prof_repeat();   // launches per event pair requested with sfm_profile_enabl
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Camera chunks of the dense BA kernels (grid = point tiles x chunks, a workgroup walks ncam / chunks cameras for its tile
+// of points): the launch takes ceil(tiles * chunks / slots) rounds of ceil(ncam / chunks) cameras each, `slots` = the
+// workgroups the chip holds at once for that kernel (256 CUs x its occupancy).  Round 2 aimed at ">= 1024 workgroups" and
+// got 1176 for config 4 — 2.3 rounds on 512 slots, i.e. three: a quarter of the sweep was a third round a third full.
+// Every chunk also costs a partial row per point (written, then folded): ~0.6 % of a sweep each.
+inline int pick_camera_chunks(int tiles, long long ncam, int slots, int max_chunks = 64) {
+    long long cap = ncam / 16;
+    if (cap > max_chunks) cap = max_chunks;
+    if (cap < 1) cap = 1;
+    int best = 1;
+    double best_cost = 1e300;
+    for (int n = 1; n <= (int)cap; ++n) {
+        const long long rounds = ((long long)tiles * n + slots - 1) / slots, cams = (ncam + n - 1) / n;
+        const double cost = (double)(rounds * cams) * (1.0 + 0.006 * n);
+        if (cost < best_cost) { best_cost = cost; best = n; }
+    }
+    return best;
+}
+
 // Carve aligned sub-buffers out of the caller's workspace.
 struct Carver {
     char* base;
