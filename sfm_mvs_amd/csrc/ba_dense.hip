@@ -28,7 +28,7 @@ namespace {
 constexpr int kCamStride = 40;
 constexpr int kNAcc = 28;          // 21 upper JtJ + 6 Jtr + 1 sumsq
 constexpr int kSegStride = 33;     // doubles; 32 lanes + 1 pad
-constexpr int kValStride = 8 * kSegStride + 1;
+constexpr int kValStride = 2 * kSegStride + 1;   // a wave's slab: [value][half][32 lanes + pad] + pad
 
 struct Intrin {
     double fx, fy, cx, cy;
@@ -79,9 +79,9 @@ template <int PP>
 __global__ __launch_bounds__(256) void ba_dense_kernel(const double* __restrict__ table, Intrin K, int ncam,
                                                        const float* __restrict__ X, int64_t npt, int64_t ldx,
                                                        const float* __restrict__ obs, int nch,
-                                                       double* __restrict__ cam_part /*[tiles][ncam][28]*/,
+                                                       double* __restrict__ cam_part /*[4 * tiles][ncam][28]: a row per WAVE*/,
                                                        double* __restrict__ pt_part /*[nch][npt][9]*/) {
-    extern __shared__ __attribute__((aligned(16))) double red[];   // kNAcc * kValStride doubles
+    extern __shared__ __attribute__((aligned(16))) double red[];   // 4 waves x kNAcc * kValStride doubles
     const int tid = threadIdx.x;
     const int tile = blockIdx.x, ch = blockIdx.y;
     const int c_begin = (int)((int64_t)ncam * ch / nch), c_end = (int)((int64_t)ncam * (ch + 1) / nch);
@@ -102,9 +102,17 @@ __global__ __launch_bounds__(256) void ba_dense_kernel(const double* __restrict_
         for (int k = 0; k < 9; ++k) pacc[pp][k] = 0;
     }
 
-    const int wseg = tid >> 5, wlane = tid & 31;   // LDS slot of this lane's contribution
-    const int rk = tid >> 3, rseg = tid & 7;       // reducer role: value rk (<28), segment rseg
+    const int lane = tid & 63, wave = tid >> 6;
+    const int whalf = lane >> 5, wlane = lane & 31;   // LDS slot of this lane's contribution inside the wave's slab
+    double* const wred = red + wave * (kNAcc * kValStride);
 
+    // the observations of camera c + 1 are requested while camera c is worked on
+    float2 ob_next[PP];
+#pragma unroll
+    for (int pp = 0; pp < PP; ++pp) {
+        const int64_t p = p0 + 256 * pp;
+        ob_next[pp] = (live[pp] && c_begin < c_end) ? *reinterpret_cast<const float2*>(obs + ((int64_t)c_begin * npt + p) * 2) : make_float2(0.f, 0.f);
+    }
     for (int c = c_begin; c < c_end; ++c) {
         const double* __restrict__ e = table + (int64_t)c * kCamStride;
         double cacc[kNAcc];
@@ -114,7 +122,8 @@ __global__ __launch_bounds__(256) void ba_dense_kernel(const double* __restrict_
 #pragma unroll
         for (int pp = 0; pp < PP; ++pp) {
             const int64_t p = p0 + 256 * pp;
-            ob[pp] = live[pp] ? *reinterpret_cast<const float2*>(obs + ((int64_t)c * npt + p) * 2) : make_float2(0.f, 0.f);
+            ob[pp] = ob_next[pp];
+            if (live[pp] && c + 1 < c_end) ob_next[pp] = *reinterpret_cast<const float2*>(obs + ((int64_t)(c + 1) * npt + p) * 2);
         }
 #pragma unroll
         for (int pp = 0; pp < PP; ++pp) {
@@ -208,21 +217,33 @@ __global__ __launch_bounds__(256) void ba_dense_kernel(const double* __restrict_
                 }
             }
         }
-        // fixed-order block reduction of the 28 camera-side sums
-        __syncthreads();   // previous camera's readers are done
+        // Fixed-order reduction of the 28 camera-side sums, PER WAVE and without a workgroup barrier: the wave's 64 partials
+        // of a value sit in its own LDS slab ([value][half][32 lanes], odd strides); lane 2k + h adds the 32 partials of
+        // half h of value k in ascending order, one exchange joins the halves, and the wave writes ITS partial row
+        // (4 rows per tile and camera: the fold kernel adds them).  A wave's LDS operations execute in issue order, so
+        // neither the readers of this camera nor the writers of the next need more than a wave barrier — and the four
+        // waves drift apart, which is the point: with two __syncthreads per camera around a workgroup-wide fold this
+        // step cost 38 % of the kernel (ablation), all of it LDS time nobody overlapped.
 #pragma unroll
-        for (int k = 0; k < kNAcc; ++k) red[k * kValStride + wseg * kSegStride + wlane] = cacc[k];
-        __syncthreads();
-        if (rk < kNAcc) {
-            const double* src = red + rk * kValStride + rseg * kSegStride;
-            double s = 0;
-#pragma unroll 8
-            for (int i = 0; i < 32; ++i) s += src[i];
+        for (int k = 0; k < kNAcc; ++k) wred[k * kValStride + whalf * kSegStride + wlane] = cacc[k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 2 * kNAcc) {
+            const double* src = wred + (lane >> 1) * kValStride + (lane & 1) * kSegStride;
+            // (four interleaved chains of eight, then a fixed tree: one chain of 32 dependent adds is 32 add latencies)
+            double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+            for (int i = 0; i < 32; i += 4) {
+                s0 += src[i];
+                s1 += src[i + 1];
+                s2 += src[i + 2];
+                s3 += src[i + 3];
+            }
+            double s = (s0 + s1) + (s2 + s3);
             s += __shfl_xor(s, 1, 64);
-            s += __shfl_xor(s, 2, 64);
-            s += __shfl_xor(s, 4, 64);
-            if (rseg == 0) cam_part[((int64_t)tile * ncam + c) * kNAcc + rk] = s;
+            if ((lane & 1) == 0) cam_part[(((int64_t)tile * 4 + wave) * ncam + c) * kNAcc + (lane >> 1)] = s;
         }
+        __builtin_amdgcn_wave_barrier();
     }
 
 #pragma unroll
@@ -330,7 +351,7 @@ DenseWs dense_carve(void* base, int64_t ncam, int64_t npt, const DensePlan& d) {
     DenseWs w;
     w.table = c.take<double>((size_t)ncam * kCamStride);
     w.cam_sumsq = c.take<double>((size_t)ncam);
-    w.cam_part = c.take<double>((size_t)d.tiles * ncam * kNAcc);
+    w.cam_part = c.take<double>((size_t)4 * d.tiles * ncam * kNAcc);
     w.pt_part = c.take<double>((size_t)d.nch * npt * 9);
     w.bytes = c.used();
     return w;
@@ -360,7 +381,7 @@ extern "C" int sfm_ba_dense_sweep(const double* cams, int64_t ncam, const double
     const Intrin K{K_host[0], K_host[4], K_host[2], K_host[5]};
     hipLaunchKernelGGL(dense_cam_prepare_kernel, dim3((unsigned)((ncam + 63) / 64)), dim3(64), 0, stream, cams, ncam, w.table);
     SFM_CHECK_LAUNCH();
-    const size_t lds = (size_t)kNAcc * kValStride * sizeof(double);
+    const size_t lds = (size_t)4 * kNAcc * kValStride * sizeof(double);
     const dim3 grid((unsigned)d.tiles, (unsigned)d.nch);
     sfm::prof_begin(sfm::kProfBaDense, stream);
     if (d.pp == 4)
@@ -371,7 +392,7 @@ extern "C" int sfm_ba_dense_sweep(const double* cams, int64_t ncam, const double
                            w.cam_part, w.pt_part);
     sfm::prof_end(sfm::kProfBaDense, stream);
     SFM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(dense_cam_reduce_kernel, dim3((unsigned)ncam), dim3(1024), 0, stream, w.cam_part, d.tiles, (int)ncam,
+    hipLaunchKernelGGL(dense_cam_reduce_kernel, dim3((unsigned)ncam), dim3(1024), 0, stream, w.cam_part, 4 * d.tiles, (int)ncam,
                        JtJ_cam, Jtr_cam, w.cam_sumsq);
     SFM_CHECK_LAUNCH();
     if (sumsq) {
