@@ -712,17 +712,38 @@ __global__ __launch_bounds__(kPrepThreads) void knn_prep_kernel(BatchPtrs P, int
         const float sc = isq ? -2.f : 1.f;
         unsigned fb[8];
         float err2 = 0.f;                                                // ||fp16(row) - row||^2: the certificate's operand-rounding term
+        // The per-element tests — range (also NaN / inf), fp16-exactness, below fp16's normal range — are folded over the
+        // lane's eight elements on bit patterns (the kernel is bound by its vector-ALU instruction count, not by the bytes):
+        //   amax = max |e| bits;   umin = min (|e| bits - 1)  (0 wraps to 0xFFFFFFFF: "nonzero and below 2^-14" is ONE unsigned
+        //   compare);   dor = OR of the residuals' bits (any bit but the sign: inexact)
+        unsigned amax = 0u, umin = 0xFFFFFFFFu, dor = 0u;
+        float evs[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float ev = sc * in[e], ae = fabsf(ev);
+            const float ev = sc * in[e];
             const _Float16 hv = (_Float16)ev;                            // round to nearest even
             fb[e] = (unsigned)__builtin_bit_cast(unsigned short, hv);
-            if (!(ae <= 60000.f)) flags |= kFlagRangeBad;                // also catches NaN / inf
-            if ((float)hv != ev || (ae != 0.f && ae < 6.103515625e-5f)) flags |= kFlagHalfInexact;
-            // below fp16's normal range the matrix pipe may flush the operand to zero: the whole element is the error then
-            // (|e - hv| <= |e| holds for the rounded subnormal too, so this bounds both behaviours)
-            const float dv = ae < 6.103515625e-5f ? ev : ev - (float)hv;
+            const float dv = ev - (float)hv;
             err2 = fmaf(dv, dv, err2);
+            const unsigned ab = __float_as_uint(ev) & 0x7FFFFFFFu;
+            amax = max(amax, ab);
+            umin = min(umin, ab - 1u);
+            dor |= __float_as_uint(dv);
+            evs[e] = ev;
+        }
+        if (amax > 0x476A6000u /*60000.f*/) flags |= kFlagRangeBad;      // (NaN and inf patterns are larger still)
+        const bool has_sub = umin < 0x38800000u - 1u;                     // some element is nonzero and below 2^-14
+        if ((dor & 0x7FFFFFFFu) != 0u || has_sub) flags |= kFlagHalfInexact;
+        if (has_sub) {
+            // below fp16's normal range the matrix pipe may flush the operand to zero: the whole element is the error then
+            // (|e - hv| <= |e| holds for the rounded subnormal too, so this bounds both behaviours).  Rare: redo the sum.
+            err2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float ev = evs[e];
+                const float dv = fabsf(ev) < 6.103515625e-5f ? ev : ev - (float)__builtin_bit_cast(_Float16, (unsigned short)fb[e]);
+                err2 = fmaf(dv, dv, err2);
+            }
         }
         err2 += lane_xor<8>(err2); err2 += lane_xor<4>(err2); err2 += lane_xor<2>(err2); err2 += lane_xor<1>(err2);
         if (!(err2 < kInf)) err2 = 0.f;                                  // (out-of-range data: the split arithmetic runs, this term is unused)
@@ -1300,9 +1321,10 @@ __global__ __launch_bounds__(64 * W, 2) void knn_filter_split2_kernel(
 // (which then contend for the one pipe), and pays a 5 us prologue per segment for the LDS transposition of the query
 // fragments.  This kernel removes all of that:
 //   * ONE wave per SIMD (a 256-thread workgroup per CU, 512 registers per lane): a wave owns FOUR 32-query groups whose B
-//     fragments (4 x 8 k-steps x 4 registers + 4 init fragments = 144 registers) live in ACCUMULATION registers — MFMA
+//     fragments (4 x 8 k-steps x 4 registers + the init operand = 130 registers) live in ACCUMULATION registers — MFMA
 //     A/B operands may be AGPRs on gfx950, the vector ALU never touches them — while the four accumulators (64), the
-//     packed keys (12) and the train fragments sit in VGPRs.  Every train fragment feeds four MFMAs.
+//     tile's shared init values (16), the packed keys (12) and the train fragments sit in VGPRs.  Every train fragment
+//     feeds four MFMAs.
 //   * NO LDS, no barrier, no LDS-DMA: the prep pass stores both images in FRAGMENT ORDER ([32-row tile][9][64 lanes][16 B]),
 //     so an MFMA A operand of a whole tile is ONE coalesced 1 KiB buffer_load_dwordx4 straight into the registers the MFMA
 //     reads.  A ring of kQ4Ring tiles of fragments (27 loads in flight per wave) replaces the LDS ring; a fragment's
@@ -1310,16 +1332,19 @@ __global__ __launch_bounds__(64 * W, 2) void knn_filter_split2_kernel(
 //     the same tiles (L1 / L2 hits) but nothing synchronises them.  (An LDS-DMA piece costs its wave 60-185 issue cycles
 //     and there is no partner wave to hide them behind: the same loop fed through the LDS ring runs 10 % slower —
 //     scripts/ubench/filter_q4.hip, V = 3 against V = 4.)
-//   * accumulator init ||t||^2 + ||q||^2 as one bf16 MFMA on exact bf16 triples (frag_init_operand): 32 pipe cycles per
-//     group and tile instead of 64, no LDS read, no v_cndmask.
+//   * accumulator init as ONE K = 8 bf16 MFMA per TILE on exact bf16 triples (frag_init_operand): the scores carry the
+//     pair's largest ||q||^2 instead of the query's own (same offset for all of a query's records: rankings, thresholds and
+//     third-best bounds are untouched; the refine kernel works in that frame), so the init value depends on the train
+//     row only and the four groups' chains take it as the C operand of their first product: 33 MFMAs per tile, not 36.
 //   * the accumulators are single-buffered: a tile is two phases — the chains of groups 0, 1 with the packed-key epilogue
 //     of groups 2, 3 (previous tile) as fillers between the MFMAs, then the chains of 2, 3 with the epilogue of 0, 1 —
 //     ~3 VALU per MFMA gap, below the ~5 a wave alone on its SIMD can hide per 32-cycle MFMA.
 // In isolation (scripts/ubench/filter_q4.hip) the loop sustains 1520-1560 algorithmic TFLOP/s against 1610 for the same
 // MFMA stream with operands in registers and 1220 for the LDS-ring loop: what is left is the power-limited clock
-// (~1.75 GHz under a dense MFMA stream) and the init MFMAs (4 of 36).
-// Candidate records, streams and the partition tables are exactly those of the LDS-ring kernel (a row block is 512
-// queries, 256 workgroups), so the refine kernel is shared.
+// (~1.75 GHz under a dense MFMA stream).
+// Candidate records and the partition are those of the LDS-ring kernel (a row block is 512 queries, 256 workgroups) except
+// that the streams of a row block are numbered DENSELY (fill_partition_tables: nothing is written for substreams that do
+// not exist); the refine kernel is shared, a flag tells it the score frame and the stream numbering.
 // MFMAs are inline asm (B operands constrained to "a"): hipcc pads nothing around them.  The hazards that matter —
 // an MFMA's D read by a VALU (8-pass: 12 wait states) — are covered by construction: an accumulator is first read by the
 // epilogue at least two later MFMAs (>= 16 passes) after the MFMA that completed it, and the segment tail carries explicit
