@@ -26,8 +26,7 @@
 namespace {
 
 constexpr int kCamStride = 40;
-constexpr int kSegStride = 33;     // doubles; 32 lanes + 1 pad
-constexpr int kValStride = 8 * kSegStride + 1;
+constexpr int kWaveValStride = 8 * 9 + 1;   // a wave's slab of schur_w_kernel: [value][8 groups x (8 + pad)] + pad
 
 struct Intrin {
     double fx, fy, cx, cy;
@@ -216,8 +215,8 @@ template <int PP>
 __global__ __launch_bounds__(256) void schur_w_kernel(const double* __restrict__ table, Intrin K, int ncam,
                                                       const float* __restrict__ X, int64_t npt, int64_t ldx,
                                                       const double* __restrict__ v /*[npt][3]*/, int nch,
-                                                      double* __restrict__ cam_part /*[tiles][ncam][6]*/) {
-    extern __shared__ __attribute__((aligned(16))) double red[];   // 6 * kValStride doubles
+                                                      double* __restrict__ cam_part /*[4 * tiles][ncam][6]: a row per wave*/) {
+    extern __shared__ __attribute__((aligned(16))) double red[];   // 4 waves x 6 * kWaveValStride doubles
     const int tid = threadIdx.x;
     const int tile = blockIdx.x, ch = blockIdx.y;
     const int c_begin = (int)((int64_t)ncam * ch / nch), c_end = (int)((int64_t)ncam * (ch + 1) / nch);
@@ -234,8 +233,12 @@ __global__ __launch_bounds__(256) void schur_w_kernel(const double* __restrict__
         Zw[pp] = X[ps * ldx + 2];
         vj[pp][0] = v[ps * 3]; vj[pp][1] = v[ps * 3 + 1]; vj[pp][2] = v[ps * 3 + 2];
     }
-    const int wseg = tid >> 5, wlane = tid & 31;   // LDS slot of this lane's contribution
-    const int rk = tid >> 3, rseg = tid & 7;       // reducer role: value rk (< 6), segment rseg
+    // The six camera-side sums are folded PER WAVE (as in ba_dense_kernel: a wave's own LDS slab, a wave barrier, a partial
+    // row per wave — no __syncthreads in the camera loop): lane 8k + g adds partials 8g .. 8g + 7 of value k in order, three
+    // exchanges join the eight groups.
+    const int lane = tid & 63, wave = tid >> 6;
+    double* const wred = red + wave * (6 * kWaveValStride);
+    const int rk = lane >> 3, rseg = lane & 7;     // reducer role: value rk (< 6), group rseg
     for (int c = c_begin; c < c_end; ++c) {
         const double* __restrict__ e = table + (int64_t)c * kCamStride;
         double cacc[6] = {0, 0, 0, 0, 0, 0};
@@ -255,20 +258,21 @@ __global__ __launch_bounds__(256) void schur_w_kernel(const double* __restrict__
             cacc[5] = fma(J.Ju5, su, cacc[5]);
             cacc[5] = fma(J.Jv5, sv, cacc[5]);
         }
-        __syncthreads();   // previous camera's readers are done
 #pragma unroll
-        for (int k = 0; k < 6; ++k) red[k * kValStride + wseg * kSegStride + wlane] = cacc[k];
-        __syncthreads();
+        for (int k = 0; k < 6; ++k) wred[k * kWaveValStride + (lane >> 3) * 9 + (lane & 7)] = cacc[k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         if (rk < 6) {
-            const double* src = red + rk * kValStride + rseg * kSegStride;
+            const double* src = wred + rk * kWaveValStride + rseg * 9;
             double s = 0;
-#pragma unroll 8
-            for (int i = 0; i < 32; ++i) s += src[i];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += src[i];
             s += __shfl_xor(s, 1, 64);
             s += __shfl_xor(s, 2, 64);
             s += __shfl_xor(s, 4, 64);
-            if (rseg == 0) cam_part[((int64_t)tile * ncam + c) * 6 + rk] = s;
+            if (rseg == 0) cam_part[(((int64_t)tile * 4 + wave) * ncam + c) * 6 + rk] = s;
         }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -344,7 +348,7 @@ SchurWs schur_carve(void* base, int64_t ncam, int64_t npt, const SchurPlan& d) {
     sfm::Carver c(base);
     SchurWs w;
     w.table = c.take<double>((size_t)ncam * kCamStride);
-    const size_t pt = (size_t)d.nch * npt * 3, cam = (size_t)d.tiles * ncam * 6;
+    const size_t pt = (size_t)d.nch * npt * 3, cam = (size_t)4 * d.tiles * ncam * 6;
     w.part = c.take<double>(pt > cam ? pt : cam);
     w.bytes = c.used();
     return w;
@@ -402,7 +406,7 @@ extern "C" int sfm_ba_schur_w(const double* cams, int64_t ncam, const double* K_
     const Intrin K{K_host[0], K_host[4], K_host[2], K_host[5]};
     hipLaunchKernelGGL(schur_cam_prepare_kernel, dim3((unsigned)((ncam + 63) / 64)), dim3(64), 0, stream, cams, ncam, w.table);
     SFM_CHECK_LAUNCH();
-    const size_t lds = (size_t)6 * kValStride * sizeof(double);
+    const size_t lds = (size_t)4 * 6 * kWaveValStride * sizeof(double);
     const dim3 grid((unsigned)d.tiles, (unsigned)d.nch);
     sfm::prof_begin(sfm::kProfBaSchur, stream);
     if (d.pp == 4)
@@ -411,7 +415,7 @@ extern "C" int sfm_ba_schur_w(const double* cams, int64_t ncam, const double* K_
         hipLaunchKernelGGL(schur_w_kernel<2>, grid, dim3(256), lds, stream, w.table, K, (int)ncam, X, npt, ldx, v_pt, d.nch, w.part);
     sfm::prof_end(sfm::kProfBaSchur, stream);
     SFM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(schur_cam_fold_kernel, dim3((unsigned)ncam), dim3(256), 0, stream, w.part, d.tiles, (int)ncam, w_cam);
+    hipLaunchKernelGGL(schur_cam_fold_kernel, dim3((unsigned)ncam), dim3(256), 0, stream, w.part, 4 * d.tiles, (int)ncam, w_cam);
     SFM_CHECK_LAUNCH();
     return SFM_OK;
 }
@@ -650,13 +654,13 @@ void launch_wt(hipStream_t stream, const SchurPlan& d, const SchurWs& w, const I
 
 void launch_w(hipStream_t stream, const SchurPlan& d, const SchurWs& w, const Intrin& K, int64_t ncam, const float* X, int64_t npt, int64_t ldx,
               const double* v_pt, double* w_cam) {
-    const size_t lds = (size_t)6 * kValStride * sizeof(double);
+    const size_t lds = (size_t)4 * 6 * kWaveValStride * sizeof(double);
     const dim3 grid((unsigned)d.tiles, (unsigned)d.nch);
     if (d.pp == 4)
         hipLaunchKernelGGL(schur_w_kernel<4>, grid, dim3(256), lds, stream, w.table, K, (int)ncam, X, npt, ldx, v_pt, d.nch, w.part);
     else
         hipLaunchKernelGGL(schur_w_kernel<2>, grid, dim3(256), lds, stream, w.table, K, (int)ncam, X, npt, ldx, v_pt, d.nch, w.part);
-    hipLaunchKernelGGL(schur_cam_fold_kernel, dim3((unsigned)ncam), dim3(256), 0, stream, w.part, d.tiles, (int)ncam, w_cam);
+    hipLaunchKernelGGL(schur_cam_fold_kernel, dim3((unsigned)ncam), dim3(256), 0, stream, w.part, 4 * d.tiles, (int)ncam, w_cam);
 }
 
 }  // namespace
