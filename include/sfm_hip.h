@@ -153,6 +153,18 @@ int sfm_gather_matches(const float* kp0_dev, const float* kp1_dev,
                        float* pts0_dev, float* pts1_dev, void* stream);
 
 /* ------------------------------------------------------------------------
+ * A2, train set split over `shards` devices (SURVEY 8e's fallback for one pair
+ * whose train descriptors do not fit one device): merge of the shards' partial
+ * knnMatch(k=2) results into the result of a single scan (sfm.py:259-260).
+ *   cand_dev [shards][2][nq][2] int32: per shard the (GLOBAL) trainIdx plane and
+ *   the distance-bits plane of its partial result (idx < 0: no neighbour) — the
+ *   layout one all-gather of the shards' result blocks produces;
+ *   out_idx_dev [nq][2] int32 (-1: none), out_dist_dev [nq][2] float32 (0: none).
+ * Order: (distance, trainIdx) — the lower index wins ties, as BFMatcher's scan.
+ * ---------------------------------------------------------------------- */
+int sfm_knn_merge_top2(const int32_t* cand_dev, int shards, int64_t nq, int32_t* out_idx_dev, float* out_dist_dev, void* stream);
+
+/* ------------------------------------------------------------------------
  * A9  common_points(pts1, pts2, pts3)                       sfm.py:215-239
  *
  * For every row i of pts1 ([n1 x 2] float32) the FIRST row of pts2 ([n2 x 2])

@@ -80,7 +80,48 @@ __global__ __launch_bounds__(1024) void assoc_compact_kernel(const int* __restri
     if (threadIdx.x == 0) *count = base_s;
 }
 
+// Merge of partial 2-NN lists (train set split over S ranks / shards): one lane per query walks the 2 S candidates in shard
+// order and keeps the two smallest by (distance, global train index) — the order a single scan of the whole train set
+// produces (cv2.BFMatcher keeps the earlier row on a tie).  Missing neighbours are idx < 0.
+__global__ __launch_bounds__(256) void knn_merge_top2_kernel(const int* __restrict__ cand /*[S][2][nq][2]: idx plane, dist-bits plane*/, int S,
+                                                             int64_t nq, int* __restrict__ out_idx, float* __restrict__ out_dist) {
+    const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    float d0 = __builtin_huge_valf(), d1 = __builtin_huge_valf();
+    int i0 = -1, i1 = -1;
+    auto less = [](float da, int ia, float db, int ib) { return ib < 0 || da < db || (da == db && ia < ib); };
+    for (int s = 0; s < S; ++s) {
+        const int2 ci = *reinterpret_cast<const int2*>(cand + ((int64_t)(2 * s) * nq + q) * 2);
+        const int2 cd = *reinterpret_cast<const int2*>(cand + ((int64_t)(2 * s + 1) * nq + q) * 2);
+        const int ids[2] = {ci.x, ci.y};
+        const float ds[2] = {__int_as_float(cd.x), __int_as_float(cd.y)};
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            if (ids[r] < 0) continue;
+            if (less(ds[r], ids[r], d0, i0)) {
+                d1 = d0; i1 = i0;
+                d0 = ds[r]; i0 = ids[r];
+            } else if (less(ds[r], ids[r], d1, i1)) {
+                d1 = ds[r]; i1 = ids[r];
+            }
+        }
+    }
+    *reinterpret_cast<int2*>(out_idx + 2 * q) = make_int2(i0, i1);
+    *reinterpret_cast<float2*>(out_dist + 2 * q) = make_float2(i0 >= 0 ? d0 : 0.f, i1 >= 0 ? d1 : 0.f);
+}
+
 }  // namespace
+
+extern "C" int sfm_knn_merge_top2(const int32_t* cand, int shards, int64_t nq, int32_t* out_idx, float* out_dist, void* stream_) {
+    SFM_CHECK_ARG(shards >= 1 && nq >= 0 && nq < ((int64_t)1 << 31), "sfm_knn_merge_top2: bad sizes");
+    if (nq == 0) return SFM_OK;
+    SFM_CHECK_ARG(cand && out_idx && out_dist, "sfm_knn_merge_top2: null pointer");
+    SFM_CHECK_ARG(((uintptr_t)cand & 7) == 0 && ((uintptr_t)out_idx & 7) == 0 && ((uintptr_t)out_dist & 7) == 0, "sfm_knn_merge_top2: 8-byte alignment");
+    hipStream_t stream = sfm::as_stream(stream_);
+    hipLaunchKernelGGL(knn_merge_top2_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream, cand, shards, nq, out_idx, out_dist);
+    SFM_CHECK_LAUNCH();
+    return SFM_OK;
+}
 
 extern "C" int sfm_common_points(const float* pts1, int64_t n1, const float* pts2, int64_t n2, int32_t* first_ws,
                                  int32_t* idx1, int32_t* idx2, int32_t* count, uint8_t* keep2, void* stream_) {

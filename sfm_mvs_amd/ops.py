@@ -136,6 +136,22 @@ def common_points(pts1, pts2):
     return idx1[:m], idx2[:m], keep2[:n2].bool()
 
 
+def knn_merge_top2(cand):
+    """Merge the shards' partial 2-NN results (train set split over devices): cand [S][2][nq][2] int32 CUDA tensor — per
+    shard the global trainIdx plane and the distance-bits plane — -> (idx [nq,2] int32, dist [nq,2] float32), ordered by
+    (distance, trainIdx) as a single scan would (sfm_knn_merge_top2)."""
+    require_cuda(cand)
+    if cand.dtype != torch.int32 or cand.dim() != 4 or cand.shape[1] != 2 or cand.shape[3] != 2:
+        raise SfmHipError("knn_merge_top2: cand must be int32 [S][2][nq][2]")
+    cand = cand.contiguous()
+    S, nq = int(cand.shape[0]), int(cand.shape[2])
+    idx = torch.empty((nq, 2), dtype=torch.int32, device=cand.device)
+    dist = torch.empty((nq, 2), dtype=torch.float32, device=cand.device)
+    with on_device(cand.device):
+        check(_lib.lib().sfm_knn_merge_top2(ptr(cand), S, nq, ptr(idx), ptr(dist), stream_ptr()), "sfm_knn_merge_top2")
+    return idx, dist
+
+
 def match_pair(des0, des1, ratio=0.70, filter="auto"):
     """KNN + ratio for one image pair; returns (query_idx, train_idx, dist1) trimmed to the survivors.
 

@@ -309,6 +309,10 @@ def knn2_train_split(des0, des1_shard, train_offset, knn2=None, group=None):
         dist.all_gather_into_tensor(gathered.view(world * 2, nq, 2), local, group=group)
     else:
         gathered[0].copy_(local)
+    if dev.type == "cuda":                                  # the product path: one kernel, a lane per query
+        from . import ops
+        return ops.knn_merge_top2(gathered)
+    # host tensors (the gloo tests' array engine): the same merge with stable sorts
     cand_i = gathered[:, 0].permute(1, 0, 2).reshape(nq, 2 * world)                       # [nq][2 world]
     cand_d = gathered[:, 1].permute(1, 0, 2).reshape(nq, 2 * world).contiguous().view(torch.float32)
     cand_d = torch.where(cand_i >= 0, cand_d, torch.full_like(cand_d, float("inf")))

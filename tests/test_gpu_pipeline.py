@@ -339,6 +339,41 @@ def test_sharded_path_on_one_gpu(hip, oracle):
     assert np.array_equal(gi.cpu().numpy(), wi) and np.array_equal(gd.cpu().numpy(), wd)
 
 
+def test_train_split_merge_kernel_equals_a_single_scan(hip, oracle):
+    """sfm_knn_merge_top2 (SURVEY 8e's train-split fallback): partial 2-NN results of S shards of the train set, merged by
+    (distance, global trainIdx), equal the single scan — including exact ties across shards (duplicated train rows: the
+    lower index must win), shards that contribute one or no neighbour, and queries with fewer than two neighbours at all."""
+    import torch
+    rng = np.random.default_rng(17)
+    q = rng.integers(0, 60, (700, 128)).astype(np.float32)
+    t = rng.integers(0, 60, (901, 128)).astype(np.float32)
+    t[400:420] = t[100:120]                              # exact duplicates in different shards
+    t[650] = q[3]                                        # a zero distance ...
+    t[20] = q[3]                                         # ... twice
+    bounds = [0, 1, 300, 300, 600, 901]                  # shards of 1, 299, 0, 300 and 301 rows
+    S = len(bounds) - 1
+    cand = torch.empty((S, 2, 700, 2), dtype=torch.int32, device="cuda")
+    dq = torch.from_numpy(q).cuda()
+    for s in range(S):
+        lo, hi = bounds[s], bounds[s + 1]
+        if hi > lo:
+            idx, d = hip.knn2(dq, torch.from_numpy(t[lo:hi]).cuda())
+            cand[s, 0] = torch.where(idx >= 0, idx + lo, idx)
+            cand[s, 1] = d.contiguous().view(torch.int32)
+        else:
+            cand[s, 0].fill_(-1)
+            cand[s, 1].zero_()
+    gi, gd = hip.knn_merge_top2(cand)
+    wi, wd = oracle.knn2(q, t)
+    assert np.array_equal(gi.cpu().numpy(), wi) and np.array_equal(gd.cpu().numpy().view(np.uint32), wd.view(np.uint32))
+    # a single one-row shard: the second neighbour is missing
+    one = torch.empty((1, 2, 700, 2), dtype=torch.int32, device="cuda")
+    idx, d = hip.knn2(dq, torch.from_numpy(t[:1]).cuda())
+    one[0, 0], one[0, 1] = idx, d.contiguous().view(torch.int32)
+    gi, gd = hip.knn_merge_top2(one)
+    assert (gi[:, 0] == 0).all() and (gi[:, 1] == -1).all() and float(gd[:, 1].abs().sum()) == 0.0
+
+
 def test_device_resident_driver_equals_the_array_form(hip):
     """run_sfm's HBM-resident form (the default on the HIP back-end) against its array-in / array-out form: the same
     kernels in the same order, so every output is identical — poses, cloud, per-frame errors, colours."""
