@@ -11,7 +11,8 @@ vectors, mixed magnitudes) and a second group aimed at the margins of the exactn
              likewise for a third of them): a mis-ranked pair flips an index or a Lowe decision
   pow2       squared distances within a few ulps of a power of two (sqrtf / key-truncation boundaries)
   fp16edge   values on fp16 rounding midpoints, at the top of its range (~6e4) and around its smallest normals (6.1e-5)
-  normspread query norms spread over 10^3 inside one pair (the slack is relative to each query's own norm)
+  normspread query norms spread over 10^3 inside one pair (the q4 filter's scores carry the pair's LARGEST ||q||^2 and its slack is
+             relative to that: small-norm queries of such a pair rescan more, and must stay exact)
 Most cases are small (the oracle dominates the wall time); one in eight is large, `big` adds 20k-70k train rows.
 The log ends with the sha256 of csrc/knn.hip: profiles/r03_fuzz_knn_*.log are checked against the tree by tests/test_gpu_knn.py.
 """

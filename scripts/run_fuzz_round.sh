@@ -1,11 +1,11 @@
 #!/bin/bash
 # The round's long KNN parity sweep on the FINAL binary (run via gpurun; logs land in gpurun_out/, copy them to profiles/).
-# usage: bash scripts/run_fuzz_round.sh rNN [seconds per seed]
-TAG=${1:-r03}; SEC=${2:-150}
+# usage: bash scripts/run_fuzz_round.sh rNN [seconds per seed] [seed base: seeds base+1 .. base+5, default 100]
+TAG=${1:-r03}; SEC=${2:-150}; BASE=${3:-100}
 R=${GRAFT_REPO_ROOT:-/root/repo}
-for seed in 101 102 103 104; do
+for seed in $((BASE+1)) $((BASE+2)) $((BASE+3)) $((BASE+4)); do
   python $R/scripts/fuzz_knn.py $SEC $seed 2>&1 | grep -v amdgpu.ids > $R/gpurun_out/${TAG}_fuzz_knn_seed$seed.log
   tail -3 $R/gpurun_out/${TAG}_fuzz_knn_seed$seed.log | head -1
 done
-python $R/scripts/fuzz_knn.py $SEC 105 big 2>&1 | grep -v amdgpu.ids > $R/gpurun_out/${TAG}_fuzz_knn_seed105_big.log
+python $R/scripts/fuzz_knn.py $SEC $((BASE+5)) big 2>&1 | grep -v amdgpu.ids > $R/gpurun_out/${TAG}_fuzz_knn_seed$((BASE+5))_big.log
 grep "^fuzz:" $R/gpurun_out/${TAG}_fuzz_knn_seed*.log
