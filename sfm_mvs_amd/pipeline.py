@@ -448,8 +448,9 @@ class _HipEngine:
     def errors(self, handles):
         if not handles:
             return []
-        sv = torch.cat([h for h, _ in handles]).cpu().numpy()         # one download for the whole sequence
-        return [float(np.sqrt(v)) / n for v, (_, n) in zip(sv, handles)]
+        dev_h = [h for h in handles if isinstance(h, tuple)]           # (a bundle-adjusted frame's error is already a float)
+        sv = iter(torch.cat([h for h, _ in dev_h]).cpu().numpy() if dev_h else [])   # one download for the whole sequence
+        return [float(np.sqrt(next(sv))) / h[1] if isinstance(h, tuple) else float(h) for h in handles]
 
 
 def make_engine(features, K, be=None, device_resident=None):
@@ -485,9 +486,14 @@ def bootstrap_pair(eng):
     return FrameState(P1, P2, a, b_in, X_in), first
 
 
-def register_next(eng, state, i):
+def register_next(eng, state, i, bundle_adjustment=False, gtol_thresh=0.5):
     """One iteration of sfm.py:341-409: register image i + 2 against the cloud of images i, i + 1.  Returns
-    (next state, dict(P, error handle, cloud (n,3), lookup (n,2) points of the new cloud in image i + 2, pnp inlier count))."""
+    (next state, dict(P, error handle, cloud (n,3), lookup (n,2) points of the new cloud in image i + 2, pnp inlier count)).
+    bundle_adjustment=True is the reference's `if bundle_adjustment:` branch (sfm.py:378-388, off by default, sfm.py:33):
+    SciPy's least_squares over [Rt | K | 2-D points | 3-D points] of the NEW cloud with the device's fp64 projection as
+    residual (BundleAdjustment above), then the refined Rt, points and observations replace the frame's — P for the next
+    frame, the cloud, the colour-lookup points and the error (ReprojectionError with homogenity = 0 on the float64
+    results, as sfm.py:384) — exactly where the reference replaces them."""
     K = eng.K
     pts_, pts2 = eng.match(i + 1, i + 2)
     cloud = state.cloud0 if state.cloud0 is not None else eng.triangulate(state.P1, state.P2, state.pts0, state.pts1)
@@ -498,11 +504,20 @@ def register_next(eng, state, i):
     P = K @ Rt
     X = eng.triangulate(state.P2, P, new1, new2)
     out = dict(P=P, error=eng.error(X, new2, Rt), cloud=X, lookup=new2, pnp_inliers=len(p_in))
+    if bundle_adjustment:
+        be = getattr(eng, "be", None)
+        # sfm.py:380: points_3d is the (N,1,3) float32 cloud ReprojectionError(homogenity=1) handed back, temp2 the (2,N)
+        # transposed view Triangulation returned — raveled, that is all x then all y, which is how sfm.py:110 unpacks them
+        Xb, pb, Rt = BundleAdjustment(np.asarray(eng.host(X))[:, None, :], np.asarray(eng.host(new2)).T, Rt, K, gtol_thresh, be=be)
+        P = K @ Rt                                                                   # sfm.py:381
+        err, _, _ = ReprojectionError(Xb, pb, Rt, K, homogenity=0, be=be)            # sfm.py:384 ("Minimized error")
+        out = dict(P=P, error=err, cloud=Xb, lookup=pb, pnp_inliers=len(p_in), ba_error_before=out["error"])
     return FrameState(state.P2.copy(), P.copy(), pts_, pts2), out
 
 
-def run_sfm(features, K, images=None, log=None, be=None, device_resident=None):
-    """The reference's driver, sfm.py:274-423 (bundle_adjustment=False, its default).
+def run_sfm(features, K, images=None, log=None, be=None, device_resident=None, bundle_adjustment=False, gtol_thresh=0.5):
+    """The reference's driver, sfm.py:274-423; `bundle_adjustment` / `gtol_thresh` are its globals of sfm.py:33,337 (default:
+    no bundle adjustment, as shipped).
     features: list of (kp (n,2) float32, des (n,128) float32) per image, in sequence order.
     images:   optional list of HxWx3 uint8 arrays for the colour lookup (sfm.py:393-394).
     Returns dict(posearr (9+12*n_cam,), Xtot (m,3), colorstot (m,3), errors [per-frame], first_error).
@@ -514,7 +529,7 @@ def run_sfm(features, K, images=None, log=None, be=None, device_resident=None):
     poses = [eng.K.ravel(), state.P1.ravel(), state.P2.ravel()]
     handles, clouds, lookups = [first], [], []
     for i in range(len(features) - 2):
-        state, out = register_next(eng, state, i)
+        state, out = register_next(eng, state, i, bundle_adjustment, gtol_thresh)
         poses.append(out["P"].ravel())
         handles.append(out["error"])
         clouds.append(out["cloud"])

@@ -227,6 +227,38 @@ def test_free_running_chain_drift(hip, oracle):
     print("free-running relative error drift per frame:", ["%.1e" % d for d in drift])
 
 
+def test_driver_with_bundle_adjustment_enabled(hip, oracle):
+    """The `if bundle_adjustment:` branch of the reference's loop (sfm.py:378-388, off as shipped): every registration is
+    followed by SciPy's least_squares over the new cloud, its observations and the camera, and the refined values replace
+    the frame's.  Teacher-forced per frame against the CPU twin (same driver, oracle operators): same integer decisions, P,
+    cloud, lookup points and minimised error within 1e-4; the error really is minimised; and the free-running driver
+    carries the refined P into the pose array."""
+    from sfm_mvs_amd import pipeline as pl
+    K, P, feats, ids = gustav_scene(5, seed=3, pix_noise=0.5)      # (new clouds of 1306, 2 and 20 points: the first is left as it is —
+    # its gradient is below gtol — the other two are moved)
+    ora = pl.make_engine(feats, K, be=oracle_pipeline_backend(oracle))
+    dev = pl.make_engine(feats, K)
+    s_o, _ = pl.bootstrap_pair(ora)
+    for i in range(len(feats) - 2):
+        s_next, want = pl.register_next(ora, s_o, i, bundle_adjustment=True, gtol_thresh=0.5)
+        _, got = pl.register_next(dev, s_o.on(dev), i, bundle_adjustment=True, gtol_thresh=0.5)
+        assert got["pnp_inliers"] == want["pnp_inliers"] and got["cloud"].shape == want["cloud"].shape and len(want["cloud"]) >= 2
+        print(i, len(want["cloud"]), float(np.abs(got["P"] - want["P"]).max() / np.abs(want["P"]).max()), float(np.abs(got["cloud"] - want["cloud"]).max()))
+        assert np.allclose(got["P"], want["P"], rtol=1e-4, atol=1e-4 * np.abs(want["P"]).max()), i
+        assert np.allclose(got["cloud"], want["cloud"], rtol=1e-4, atol=1e-4 * np.abs(want["cloud"]).max()), i
+        assert np.allclose(got["lookup"], want["lookup"], rtol=1e-4, atol=1e-3), i
+        ge, we = dev.errors([got["error"]])[0], ora.errors([want["error"]])[0]
+        assert ge == pytest.approx(we, rel=1e-4, abs=1e-9), i
+        assert ge <= dev.errors([got["ba_error_before"]])[0] * (1 + 1e-9), i      # "Minimized error" (sfm.py:385)
+        s_o = s_next
+    out = pl.run_sfm(feats, K, bundle_adjustment=True)
+    plain = pl.run_sfm(feats, K)
+    assert out["posearr"].shape == plain["posearr"].shape == (9 + 12 * 5,) and out["Xtot"].shape == plain["Xtot"].shape
+    assert np.array_equal(out["posearr"][:9 + 24], plain["posearr"][:9 + 24])            # the bootstrap pair is untouched ...
+    assert not np.array_equal(out["posearr"][9 + 24:], plain["posearr"][9 + 24:])        # ... every later camera is refined
+    assert len(out["errors"]) == 3 and out["errors"][1] < plain["errors"][1] and out["errors"][2] < plain["errors"][2]
+
+
 def test_bundle_adjustment_mirror(hip, oracle):
     """sfm.py:104-157 (off by default in the reference): the residual vector is fp64 end to end — equal to a float64
     NumPy twin to 1e-12 and to the CPU oracle twin — so SciPy's finite-difference Jacobian sees X, Rt and K (a float32
