@@ -128,11 +128,12 @@ def features_from_images(images, depth=3, on_device=False):
     return feats
 
 
-def run_sfm_images(images, K, downscale=2, log=None, be=None):
+def run_sfm_images(images, K, downscale=2, log=None, be=None, bundle_adjustment=False, gtol_thresh=0.5):
     """sfm.py's main loop from pixels: img_downscale (:40), cvtColor + SIFT (:243-252) and the driver (:274-423).
     `images`: BGR uint8 frames in sequence order; K is scaled by the caller as in sfm.py:20-26."""
     small = [img_downscale(im, downscale, be) for im in images]
-    return run_sfm(features_from_images(small, on_device=be is None), K, images=small, log=log, be=be)
+    return run_sfm(features_from_images(small, on_device=be is None), K, images=small, log=log, be=be,
+                   bundle_adjustment=bundle_adjustment, gtol_thresh=gtol_thresh)
 
 def Triangulation(P1, P2, pts1, pts2, K, repeat, be=None):
     """sfm.py:45-56."""
