@@ -24,7 +24,7 @@ import time
 
 # The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); two streams sharing one are serialised by
 # each other's barrier packets.  A rank uses three launch-set streams + the stream that issues the collectives + RCCL's
-# own: with 4 queues the exchange path lost 14 % (scripts/dev_exchange.py).  Must be set before the runtime initialises.
+# own: with 4 queues the exchange path lost 14 % (scripts/dev/dev_exchange.py).  Must be set before the runtime initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np
@@ -218,7 +218,7 @@ def bench_knn(args, world, rank, dev):
 
     # Set-up, not steps.  (1) every stream is created and every matcher's kernels are loaded once (a HIP stream's first
     # launch costs milliseconds).  (2) The device is brought to its sustained clock: after an idle period the MI355X runs the
-    # same launch set ~20 % slower and takes ~25 ms of load to ramp up (scripts/dev_ramp.py: 43 -> 36 us per pair over the
+    # same launch set ~20 % slower and takes ~25 ms of load to ramp up (scripts/dev/dev_ramp.py: 43 -> 36 us per pair over the
     # first 200 launch sets), far longer than W warm-up steps; the path is a throughput path (thousands of pairs per job), so
     # the steady state is what is measured.  CLOCK_WARMUP_STEPS untimed steps (~60 ms of load), then the W warm-up steps.
     for st, pmx in zip(pipe.streams, pipe.matchers):

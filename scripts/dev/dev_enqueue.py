@@ -1,6 +1,6 @@
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from sfm_mvs_amd import ops
 nq = nt = 10000
 q = torch.rand((nq, 128)).cuda(); t = torch.rand((nt, 128)).cuda()

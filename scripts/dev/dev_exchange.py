@@ -1,6 +1,6 @@
 """Dev: where the single-rank exchange path of bench.py loses time: CPU enqueue time per step vs GPU time per step."""
 import os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from sfm_mvs_amd import ops, sharded
 nq = nt = 10000; B = 8; depth = 3
 dev = torch.device("cuda:0")

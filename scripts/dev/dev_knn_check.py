@@ -1,9 +1,9 @@
 """Dev-only: drive the KNN entry points directly through ctypes (no binding table) and diff vs the oracle."""
 import ctypes as C, os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import oracle as O
-L = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sfm_mvs_amd/lib/libsfmhip.so"))
+L = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "sfm_mvs_amd/lib/libsfmhip.so"))
 L.sfm_knn2_l2_f32_ws_bytes.restype = C.c_size_t
 L.sfm_last_error.restype = C.c_char_p
 vp = C.c_void_p

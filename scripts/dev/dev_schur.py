@@ -1,8 +1,8 @@
 """Dev: Schur-complement LM vs alternating block updates on a dense problem; timing of the products at config-4 scale."""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 from datagen import ba_problem
 from sfm_mvs_amd import ba, ops
 cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()

@@ -1,7 +1,7 @@
 """Dev: SIFT timing on a frame with a photograph-like keypoint count (~2-3k at 968x648)."""
 import os, sys, time
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from sfm_mvs_amd import sift
 import datagen

@@ -1,6 +1,6 @@
 """Dev: host-side profile of the 57-camera driver (where do the 0.16 s go?)."""
 import cProfile, pstats, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from datagen import gustav_scene

@@ -1,7 +1,7 @@
 """Dev diagnostics: per-workgroup start/end/placement of the knn filter kernel."""
 import os, sys, ctypes
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from sfm_mvs_amd import ops, _lib
 nq = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 nt = int(sys.argv[2]) if len(sys.argv) > 2 else 10000

@@ -2,7 +2,7 @@
 XCDs finish (equal work per workgroup, unequal clocks)?"""
 import os, sys, ctypes
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from sfm_mvs_amd import ops, _lib
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 nq = nt = 10000

@@ -1,7 +1,7 @@
 """Dev diagnostics: per-workgroup phase timestamps of knn_refine_kernel for one BATCHED launch set."""
 import os, sys, ctypes
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from sfm_mvs_amd import ops, _lib
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 nq = nt = 10000
