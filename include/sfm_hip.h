@@ -56,7 +56,7 @@ const char* sfm_last_error(void);
  *       [0] queries for which at least one filter stream had to be rescanned exactly
  *       [1] filter workgroups launched   [2] candidate streams reserved per query
  *       [3] filter arithmetic that ran: 0 fp16 single product, exact inputs; 1 fp16 single product;
- *           2 bf16 hi/mid split; 3 fp32 MFMA
+ *           2 bf16 hi/mid split; 3 fp32 MFMA; 4 exact-integer i8 MFMA (u8-integer descriptors: real SIFT output)
  *
  * dim must be 128 (SIFT); q_dev/t_dev 16-byte aligned; ldq, ldt multiples of 4; nt <= 4 000 000.
  * The result is bit-identical to the direct-form float32 evaluation for ANY
@@ -64,9 +64,12 @@ const char* sfm_last_error(void);
  *
  * `filter` — the candidate filter that runs before the exact refine.  A per-call argument (ABI 1 had
  * a process-global switch); results are bit-identical whichever runs, the _ws_bytes twin takes the same value:
- *   SFM_KNN_FILTER_AUTO       16-bit MFMA filter, fragments streamed L2 -> registers (knn_filter_q4_kernel); its
- *                             arithmetic is chosen ON THE DEVICE from the data: one fp16 product when the values fit
- *                             fp16's range (exact for integer descriptors), else the three-product bf16 hi/mid split
+ *   SFM_KNN_FILTER_AUTO       MFMA filter, fragments streamed L2 -> registers (knn_filter_q4_kernel); its
+ *                             arithmetic is chosen ON THE DEVICE from the data: the exact-integer body
+ *                             (v_mfma_i32_32x32x32_i8, i32 scores, integer certificate) when every value of the batch is an
+ *                             integer 0 .. 255 — what cv2 SIFT emits (sfm.py:246-252) —, else one fp16 product when the
+ *                             values fit fp16's range, else the three-product bf16 hi/mid split
+ *   SFM_KNN_FILTER_HALF       as AUTO without the exact-integer body (16-bit arithmetic whatever the data)
  *   SFM_KNN_FILTER_F32        fp32 MFMA filter (single pair only)
  *   SFM_KNN_FILTER_SPLIT      as AUTO but pinned to the bf16 split
  *   SFM_KNN_FILTER_LDS, SFM_KNN_FILTER_LDS_SPLIT   round 2's LDS-ring kernel (knn_filter_split2_kernel), auto / pinned
@@ -76,6 +79,7 @@ const char* sfm_last_error(void);
 #define SFM_KNN_FILTER_SPLIT     2
 #define SFM_KNN_FILTER_LDS       3
 #define SFM_KNN_FILTER_LDS_SPLIT 4
+#define SFM_KNN_FILTER_HALF      5
 size_t sfm_knn2_l2_f32_ws_bytes(int64_t nq, int64_t nt, int dim, int filter);
 int    sfm_knn2_l2_f32(const float* q_dev, int64_t nq, int64_t ldq,
                        const float* t_dev, int64_t nt, int64_t ldt, int dim, int filter,

@@ -73,7 +73,8 @@ struct BatchPtrs {
 };
 
 // Filter variants (the `filter` argument of the entry points, include/sfm_hip.h): results are bit-identical whichever runs.
-constexpr int kFilterAuto = 0, kFilterF32 = 1, kFilterSplit = 2, kFilterLds = 3, kFilterLdsSplit = 4;
+constexpr int kFilterAuto = 0, kFilterF32 = 1, kFilterSplit = 2, kFilterLds = 3, kFilterLdsSplit = 4, kFilterHalf = 5;
+constexpr int kFilterI8Plan = 100;     // internal: the plan of the exact-integer body that kFilterAuto carries beside its fp16 plan
 
 struct Plan {
     int split;         // 1: 16-bit MFMA filter (default), 0: fp32-MFMA filter
@@ -92,6 +93,8 @@ struct Plan {
     int smax;          // candidate slots reserved per row block (>= blocks touching it)
     int nsub;          // substreams (32 tiles each) per slot
     int seg_cost;      // partition weight of a segment in tile-steps (0: plain equal-units split)
+    int sub_tiles;     // tiles per substream (64: the 16-bit filters' key holds 6 bits of tile + 2 of quad; 256: the i8 body's key holds 8 bits of tile)
+    int i8;            // 1: kFilterAuto — the launch set also carries the exact-integer (i8 MFMA) body, chosen on the device for u8-integer data
 };
 
 __host__ __device__ inline int64_t unit_begin(int64_t units, int G, int b) { return units * b / G; }
@@ -145,7 +148,7 @@ constexpr int kPartLds = 1025;                                  // blocks whose 
 // number of the first substream of block b's FIRST segment (a later segment of a block opens its row block: number 0) — so
 // the records a query owns are a dense prefix of its slot array and nothing is written for substreams that do not exist.
 __device__ inline void fill_partition_tables(const Partition pt, int n_rb, int64_t* __restrict__ begin, int* __restrict__ rb_first,
-                                             int* __restrict__ rb_last, int* __restrict__ wg_sbase = nullptr) {
+                                             int* __restrict__ rb_last, int* __restrict__ wg_sbase = nullptr, int sub_tiles = kSubTilesHost) {
     // the binary searches below are 9-10 DEPENDENT reads each: from global memory that was 6-7 us and made this one
     // workgroup the critical path of the whole prep launch, so they run on an LDS copy of the table
     __shared__ int64_t tab[kPartLds];
@@ -178,7 +181,7 @@ __device__ inline void fill_partition_tables(const Partition pt, int n_rb, int64
             for (int b = rb_first[rb]; b <= lo; ++b) {
                 const int64_t s0 = look[b] > u0 ? look[b] : u0, s1 = look[b + 1] < u1 + 1 ? look[b + 1] : u1 + 1;
                 if (look[b] >= u0) wg_sbase[b] = acc;              // (block b's range begins in this row block)
-                acc += (int)((s1 - s0 + kSubTilesHost - 1) / kSubTilesHost);
+                acc += (int)((s1 - s0 + sub_tiles - 1) / sub_tiles);
             }
             rb_last[n_rb + rb] = acc;
         }
@@ -222,17 +225,22 @@ Plan make_plan_uncached(int64_t nq, int64_t nt, int B, int filter) {
     p.split = filter == kFilterF32 ? 0 : 1;
     p.q4 = (filter == kFilterLds || filter == kFilterLdsSplit || filter == kFilterF32) ? 0 : 1;
     p.force_mode = (filter == kFilterSplit || filter == kFilterLdsSplit) ? 2 /*kModeSplit*/ : -1;
-    p.qg = p.q4 ? 4 : p.split ? 2 : 1;
+    p.i8 = filter == kFilterAuto ? 1 : 0;
+    const bool i8plan = filter == kFilterI8Plan;   // the partition of the i8 body: 8 query groups per wave, 1024-query row blocks
+    p.sub_tiles = i8plan ? 256 : kSubTilesHost;
+    p.qg = i8plan ? 8 : p.q4 ? 4 : p.split ? 2 : 1;
     if (p.q4) p.waves = 4;                     // one 4-wave workgroup per CU: one wave per SIMD, 512 registers each
     else if (p.split && !(env_w == 4 || env_w == 8 || env_w == 16)) p.waves = p.qg == 2 ? 4 : 16;   // split2: two 4-wave workgroups per CU (their barrier stalls interleave; ~3 % over one 8-wave group)
     p.rows_per_block = p.waves * 32 * p.qg;
     p.n_rb1 = (int)((nq + p.rows_per_block - 1) / p.rows_per_block);
     p.n_rb = B * p.n_rb1;
     p.nq_pad = p.n_rb1 * p.rows_per_block;
+    if (p.i8) p.nq_pad = (int)((nq + 1023) / 1024) * 1024;      // (the query images serve the i8 body's 1024-query row blocks too)
     p.tiles = (int)((nt + kTileT - 1) / kTileT);
     p.units = (int64_t)p.n_rb * p.tiles;
     static const int env_res = [] { const char* e = getenv("SFM_KNN_RESIDENT"); return e ? atoi(e) : 0; }();   // dev override
     int64_t g = (env_res > 0 ? env_res : kResidentWaves / p.qg) / p.waves;
+    if (i8plan) g = 256;                       // (one workgroup per CU, as the q4 bodies: they are bodies of one kernel)
     if (g > p.units) g = p.units;
     if (g > (int64_t)p.n_rb * (kMaxSlots - 2)) g = (int64_t)p.n_rb * (kMaxSlots - 2);
     if (g < 1) g = 1;
@@ -253,7 +261,7 @@ Plan make_plan_uncached(int64_t nq, int64_t nt, int B, int filter) {
         }
         p.smax = touch;
         if (maxseg > p.tiles) maxseg = p.tiles;
-        p.nsub = (int)((maxseg + kSubTilesHost - 1) / kSubTilesHost);
+        p.nsub = (int)((maxseg + p.sub_tiles - 1) / p.sub_tiles);
         if (p.nsub < 1) p.nsub = 1;
     }
     return p;
@@ -571,7 +579,7 @@ __device__ __forceinline__ unsigned bf16_rn_bits(float x) {
 //                   range, which the matrix pipe may flush) — the refine kernel's slack (kEpsHalf*) covers it.
 //   kModeSplit      anything else (huge / tiny magnitudes): bf16 hi+mid split, three products, full fp32 range.
 constexpr int kModeHalfExact = 0, kModeHalf = 1, kModeSplit = 2;
-constexpr int kFlagHalfInexact = 2, kFlagRangeBad = 4;
+constexpr int kFlagHalfInexact = 2, kFlagRangeBad = 4, kFlagNotU8 = 8;   // (NotU8: some value is not an integer 0 .. 255)
 
 // Lane exchanges without an address register: lane ^ M by DPP quad_perm (M = 1, 2) or ds_swizzle bit mode
 // (M = 4, 8, 16); __shfl_xor compiles to ds_bpermute and keeps one address VGPR alive per distinct pattern.
@@ -600,7 +608,8 @@ __device__ __forceinline__ int knn_filter_mode(const int* __restrict__ flags, co
 // The arithmetic mode of a BATCH of pairs (one launch, one body): the most general mode any of its pairs needs — the
 // modes are nested (fp16-exact data are fp16-representable data are split-representable data), and the refine kernel
 // prices its slack with the same batch mode, so every pair is certified against the arithmetic that actually ran.
-constexpr int kMinfoPairMode = 0, kMinfoBatchMode = kMaxBatch, kMinfoTmax = 16, kMinfoTerr = 24, kMinfoQmax = 32, kMinfoWords = 40;   // written by knn_split_images_kernel (block 0)
+constexpr int kMinfoPairMode = 0, kMinfoBatchMode = kMaxBatch, kMinfoTmax = 16, kMinfoTerr = 24, kMinfoQmax = 32, kMinfoBase = 40, kMinfoI8 = 48,
+              kMinfoWords = 56;   // written by knn_split_images_kernel (block 0); kMinfoI8: 1 = the exact-integer body runs, kMinfoBase: its per-pair score offset
 __device__ __forceinline__ int knn_batch_mode(const int* __restrict__ flags, const float* __restrict__ bmax, int n_pairs, int lane) {
     int mode = kModeHalfExact;
     for (int b = 0; b < n_pairs; ++b) mode = max(mode, knn_filter_mode(flags + b * kNormBlocks, bmax + b * kNormBlocks, lane));
@@ -631,6 +640,28 @@ __device__ __forceinline__ uint2 frag_init_operand(float x, bool query_side, int
     return h == 0 ? make_uint2(hi | (mid << 16), lo | (one << 16)) : make_uint2(one | (one << 16), 0u);
 }
 
+// ---- exact-integer (i8 MFMA) body: images and scores
+// Real SIFT descriptors are integers 0 .. 255 (sfm.py:246-252 -> :259-260).  For such data the filter runs on
+// v_mfma_i32_32x32x32_i8 — half the MFMAs per distance of the fp16 product — with i32 accumulation, i.e. EXACT scores:
+//     stored bytes   train  a = t - 128  (= t ^ 0x80)      query  b = 127 - q  (= q ^ 0x7F),   both in [-128, 127]
+//     q - t = -(a + b + 1)   =>   d^2 = sum (a + b + 1)^2 = w_t + c_q - 128 + 2 sum a b,   w_t = sum (a + 1)^2 = |t - 127|^2,
+//                                                                                       c_q = sum (b + 1)^2 = |q - 128|^2
+// The factor 2 cannot ride on an i8 operand, so the accumulator holds HALF the score:  acc = C_t + sum a b  with
+// C_t = floor(w_t / 2) - base  (base: the pair's mid-range of floor(w_t / 2), so that C_t fits the init product below), and
+//     d^2 = c_q - 128 + (w_t & 1) + 2 (acc + base):   the filter ranks by acc, which is the exact order up to the parity bit.
+// The refine kernel's certificate is therefore an INTEGER one with slack 1 (+ 2 for float32 square roots that collide):
+// no epsilon, no error budget, no assumption about the matrix pipe's rounding.
+// Init product (one MFMA per tile, K = 32): query side {1, -128 x 31}, train side {C & 127, digits d_k} with
+// sum d_k = -(C >> 7), d_k in [-128, 127]:  C in [-503 936, 508 031].  Pairs whose floor(w_t / 2) spread exceeds that range
+// (possible only when all-127 and all-0 / all-255 rows meet in one image) fall back to the fp16 body, as do non-u8 data.
+constexpr int kI8Groups = 8;                                // 32-query groups per wave
+constexpr int kI8Rows = 4 * kI8Groups * 32;                 // 1024 queries per workgroup (row block of the i8 partition)
+constexpr int kI8SubTiles = 256;                            // tiles per substream: the key's low 8 bits are the tile inside it
+constexpr int kI8TileBytes = 5 * 1024;                      // train image per 32 rows: 4 k-steps of 32 ([64 lanes][16 B]) + the init fragment
+constexpr int kI8QTileBytes = 4 * 1024;                     // query image per 32 rows
+constexpr int kI8CMax = 508031, kI8CMin = -503936;          // range of the init product
+constexpr int kKeyEmptyI = 0x7FFFFF00;                      // i8 keys >= this are empty slots / the first tile's pretend "previous tile"
+
 // One pass over Q and T: rows → the fp16 image (Q pre-scaled by -2, exact), fp32 squared norms, per-block max of
 // ||t||^2 and exactness / range flags, zero the rescan counter.  Rows >= n of the padded images are zero-filled.
 // Image layout: [3][n_pad][128] 16-bit: bf16 hi, bf16 mid, fp16; the two bf16 planes are only needed by the split
@@ -651,14 +682,26 @@ __global__ __launch_bounds__(kPrepThreads) void knn_prep_kernel(BatchPtrs P, int
                                                        int* __restrict__ zero, int nzero,
                                                        int64_t units, int tiles, int G, int seg_cost, int n_rb,
                                                        int64_t* __restrict__ wg_begin, int* __restrict__ rb_first,
-                                                       int* __restrict__ rb_last, int* __restrict__ wg_sbase) {
+                                                       int* __restrict__ rb_last, int* __restrict__ wg_sbase,
+                                                       // the exact-integer body (null / 0 when not planned): byte images, integer norms, its partition
+                                                       unsigned char* __restrict__ qi8, unsigned char* __restrict__ ti8, int64_t s_qi8, int64_t s_ti8,
+                                                       int* __restrict__ wq /*[s_qn] per pair: |q - 128|^2*/, int* __restrict__ wt /*[s_tn] per pair: |t - 127|^2*/,
+                                                       int* __restrict__ bwmin /*[kNormBlocks] per pair*/, int* __restrict__ bwmax,
+                                                       int64_t units8, int G8, int n_rb8, int64_t* __restrict__ wg_begin8,
+                                                       int* __restrict__ rb_first8, int* __restrict__ rb_last8, int* __restrict__ wg_sbase8) {
     constexpr int kPrepWaves = kPrepThreads / 64, kPrepRows = kPrepThreads / 16;
     __shared__ float wmax[kPrepWaves];
     const int pb = blockIdx.y;
-    if (blockIdx.x == gridDim.x - 1) {                     // the extra workgroup (of column 0): partition tables, nothing else
-        if (pb == 0) fill_partition_tables(make_partition(units, tiles, G, seg_cost), n_rb, wg_begin, rb_first, rb_last, wg_sbase);
+    if (blockIdx.x >= gridDim.x - 2) {                     // the two extra workgroups (of column 0): partition tables, nothing else
+        if (pb == 0) {
+            if (blockIdx.x == gridDim.x - 2) fill_partition_tables(make_partition(units, tiles, G, seg_cost), n_rb, wg_begin, rb_first, rb_last, wg_sbase);
+            else if (qi8) fill_partition_tables(make_partition(units8, tiles, G8, seg_cost), n_rb8, wg_begin8, rb_first8, rb_last8, wg_sbase8, kI8SubTiles);
+        }
         return;
     }
+    const bool do8 = qi8 != nullptr;
+    if (do8) { qi8 += pb * s_qi8; ti8 += pb * s_ti8; wq += pb * s_qn; wt += pb * s_tn; bwmin += pb * kNormBlocks; bwmax += pb * kNormBlocks; }
+    int w8min = INT_MAX, w8max = INT_MIN;
     const float* __restrict__ Q = P.q[pb];
     const float* __restrict__ T = P.t[pb];
     int* __restrict__ stats = P.stats[pb];
@@ -668,7 +711,7 @@ __global__ __launch_bounds__(kPrepThreads) void knn_prep_kernel(BatchPtrs P, int
     zero += pb * nzero;
     const bool frag = qfrag != nullptr;
     if (frag) { qfrag += pb * s_qfrag; tfrag += pb * s_tfrag; }
-    const int nblk = gridDim.x - 1;
+    const int nblk = gridDim.x - 2;
     __shared__ int wmid[kPrepWaves];
     // SIXTEEN lanes per row, one 16-byte chunk (8 elements) each: a lane reads 32 contiguous bytes of its row (a wave = 4
     // rows x 512 B) and its eight fp16 values ARE one chunk of the images — row-major: 16 B at row * 256 + 16 c; fragment
@@ -762,6 +805,38 @@ __global__ __launch_bounds__(kPrepThreads) void knn_prep_kernel(BatchPtrs P, int
             *reinterpret_cast<uint4*>((isq ? qsplit : tsplit) + (2 * (int64_t)npad + r) * kDim + 8 * c) = packed;   // row-major fp16 plane (LDS-ring filter, its refine screens)
         }
         if (c == 0) (isq ? qn : tn)[r] = nrm;
+        if (do8) {
+            // the byte image of the exact-integer body: saturating conversion, then "is every value an integer 0 .. 255" = the
+            // conversion was exact (-0 counts as 0; NaN / inf / fractions / out-of-range leave a nonzero difference)
+            unsigned lo = 0u, hi = 0u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                lo = __builtin_amdgcn_cvt_pk_u8_f32(in[e], e, lo);
+                hi = __builtin_amdgcn_cvt_pk_u8_f32(in[4 + e], e, hi);
+            }
+            unsigned nu = 0u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                nu |= __float_as_uint(in[e] - (float)((lo >> (8 * e)) & 0xFFu));
+                nu |= __float_as_uint(in[4 + e] - (float)((hi >> (8 * e)) & 0xFFu));
+            }
+            if ((nu & 0x7FFFFFFFu) != 0u) flags |= kFlagNotU8;
+            const unsigned flip = isq ? 0x7F7F7F7Fu : 0x80808080u;      // b = 127 - q,  a = t - 128
+            const bool real = r < n;
+            const unsigned x0 = real ? lo ^ flip : 0u, x1 = real ? hi ^ flip : 0u;   // rows past the end: zero bytes (a padded train row scores C_max + 0)
+            // sum (x + 1)^2 over the row = |t - 127|^2 resp. |q - 128|^2
+            int w8 = __builtin_amdgcn_sdot4((int)x0, (int)x0, 8, false);
+            w8 = __builtin_amdgcn_sdot4((int)x1, (int)x1, w8, false);
+            w8 = __builtin_amdgcn_sdot4((int)x0, 0x02020202, w8, false);
+            w8 = __builtin_amdgcn_sdot4((int)x1, 0x02020202, w8, false);
+            w8 += lane_xor<8>(w8); w8 += lane_xor<4>(w8); w8 += lane_xor<2>(w8); w8 += lane_xor<1>(w8);
+            // fragment order: [32-row tile][k-step f = element / 32][lane 32 h + row % 32][16 B], h = (element / 16) & 1; this lane's
+            // eight elements 8 c .. 8 c + 7 are half of the chunk of lane 32 ((c >> 1) & 1) + row % 32 in fragment c >> 2
+            unsigned char* img = isq ? qi8 + (int64_t)(r >> 5) * kI8QTileBytes : ti8 + (int64_t)(r >> 5) * kI8TileBytes;
+            *reinterpret_cast<uint2*>(img + (c >> 2) * 1024 + ((((c >> 1) & 1) * 32 + (r & 31)) << 4) + ((c & 1) << 3)) = make_uint2(x0, x1);
+            if (c == 0) (isq ? wq : wt)[r] = w8;
+            if (!isq && real) { w8min = min(w8min, w8); w8max = max(w8max, w8); }
+        }
         if (isq) {
             if (c == 0) qerr[r] = err2;
             mxq = fmaxf(mxq, s);
@@ -779,32 +854,61 @@ __global__ __launch_bounds__(kPrepThreads) void knn_prep_kernel(BatchPtrs P, int
     }
     int wfl = 0;
 #pragma unroll
-    for (int b = 1; b <= 4; b <<= 1) wfl |= __any((flags & b) != 0) ? b : 0;
+    for (int b = 1; b <= 8; b <<= 1) wfl |= __any((flags & b) != 0) ? b : 0;
     __shared__ float wmaxe[kPrepWaves], wmaxq[kPrepWaves];
+    __shared__ int w8lo[kPrepWaves], w8hi[kPrepWaves];
+    if (do8) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            w8min = min(w8min, __shfl_xor(w8min, m, 64));
+            w8max = max(w8max, __shfl_xor(w8max, m, 64));
+        }
+    }
     if ((threadIdx.x & 63) == 0) {
         wmax[threadIdx.x >> 6] = mx;
         wmaxe[threadIdx.x >> 6] = mxe;
         wmaxq[threadIdx.x >> 6] = mxq;
         wmid[threadIdx.x >> 6] = wfl;
+        w8lo[threadIdx.x >> 6] = w8min;
+        w8hi[threadIdx.x >> 6] = w8max;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         float bm = wmax[0], bme = wmaxe[0], bmq = wmaxq[0];
-        int fl = wmid[0];
+        int fl = wmid[0], lo8 = w8lo[0], hi8 = w8hi[0];
         for (int w = 1; w < kPrepWaves; ++w) {
             bm = fmaxf(bm, wmax[w]);
             bme = fmaxf(bme, wmaxe[w]);
             bmq = fmaxf(bmq, wmaxq[w]);
             fl |= wmid[w];
+            lo8 = min(lo8, w8lo[w]);
+            hi8 = max(hi8, w8hi[w]);
         }
         bmax[blockIdx.x] = bm;
         bmaxerr[blockIdx.x] = bme;
         bqmax[blockIdx.x] = bmq;
         midflag[blockIdx.x] = fl;
+        if (do8) { bwmin[blockIdx.x] = lo8; bwmax[blockIdx.x] = hi8; }
         if (blockIdx.x == 0 && stats) stats[0] = 0;   // rescanned-query counter (refine kernel)
         if (blockIdx.x == 1 || nblk == 1)
             for (int i = 0; i < nzero; ++i) zero[i] = 0;   // Lowe-ratio survivor counters of the fused match call
     }
+}
+
+// Train side of the i8 init product for C in [kI8CMin, kI8CMax]: slot 0 (byte 0 of the h = 0 lanes; query side 1) holds C & 127,
+// the other 31 slots (query side -128) hold digits d_k in [-128, 127] with sum d_k = -(C >> 7), dealt greedily in slot order.
+__device__ __forceinline__ uint4 frag_init_i8(int C, int h) {
+    int S = -(C >> 7);                                         // what slots 1 .. 31 must add up to
+    if (h == 1) S -= max(-15 * 128, min(15 * 127, S));         // (slots 1 .. 15 live in the h = 0 lanes)
+    unsigned wds[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        int d;
+        if (h == 0 && k == 0) d = C & 127;
+        else { d = max(-128, min(127, S)); S -= d; }
+        wds[k >> 2] |= (unsigned)(d & 0xFF) << (8 * (k & 3));
+    }
+    return make_uint4(wds[0], wds[1], wds[2], wds[3]);
 }
 
 // The bf16 (hi, mid) planes of the images, for the split arithmetic only: every workgroup derives the batch's mode from
@@ -818,18 +922,41 @@ __global__ __launch_bounds__(kSplitThreads) void knn_split_images_kernel(BatchPt
                                                                         const int* __restrict__ midflag, const float* __restrict__ bmax,
                                                                         int force_mode, unsigned char* __restrict__ qhm0 /*null: row-major planes*/,
                                                                         unsigned char* __restrict__ thm0, int64_t s_qhm, int64_t s_thm,
-                                                                        const float* __restrict__ bmaxerr, const float* __restrict__ bqmax, int* __restrict__ minfo) {
+                                                                        const float* __restrict__ bmaxerr, const float* __restrict__ bqmax, int* __restrict__ minfo,
+                                                                        // exact-integer body (ti8 == null: not planned)
+                                                                        unsigned char* __restrict__ ti8, int64_t s_ti8, const int* __restrict__ wt, int64_t s_tn,
+                                                                        const int* __restrict__ bwmin, const int* __restrict__ bwmax) {
     // The batch's arithmetic mode, reduced ONCE for the launch set: wave b of every workgroup reduces pair b's 2 x 256 flag
     // words (the eight pairs in parallel: one round trip; as a loop over the pairs inside every filter workgroup this was
     // 8-10 us of dependent loads at the head of the filter launch), workgroup 0 leaves the result — per pair the mode,
     // ||t||max and the largest fp16 residual, and the batch's mode — in `minfo` for the filter and refine kernels.
-    __shared__ int smode[kMaxBatch];
+    __shared__ int smode[kMaxBatch], s8ok[kMaxBatch], s8base[kMaxBatch];
     {
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
         static_assert(kSplitThreads / 64 >= kMaxBatch, "one wave per pair");
         if (wave < B) {
             float tmax;
             const int m = knn_filter_mode(midflag + wave * kNormBlocks, bmax + wave * kNormBlocks, lane, &tmax);
+            if (ti8) {
+                // exact-integer body: every value a u8 integer, and floor(w_t / 2) of the pair's train rows within the init product's range
+                const int* fl = midflag + wave * kNormBlocks;
+                const int* lo = bwmin + wave * kNormBlocks;
+                const int* hi = bwmax + wave * kNormBlocks;
+                const bool u8 = !__any(((fl[lane] | fl[lane + 64] | fl[lane + 128] | fl[lane + 192]) & kFlagNotU8) != 0);
+                int wl = min(min(lo[lane], lo[lane + 64]), min(lo[lane + 128], lo[lane + 192]));
+                int wh = max(max(hi[lane], hi[lane + 64]), max(hi[lane + 128], hi[lane + 192]));
+#pragma unroll
+                for (int sh = 32; sh >= 1; sh >>= 1) {
+                    wl = min(wl, __shfl_xor(wl, sh, 64));
+                    wh = max(wh, __shfl_xor(wh, sh, 64));
+                }
+                const int cl = wl >> 1, ch = wh >> 1;                      // (wl <= wh: nt >= 1 here)
+                const int base = max(ch - kI8CMax, min(cl + (ch - cl) / 2, cl - kI8CMin));   // mid-range, nudged so that both ends fit when they can
+                if (lane == 0) {
+                    s8ok[wave] = (u8 && wl <= wh && ch - base <= kI8CMax && cl - base >= kI8CMin) ? 1 : 0;
+                    s8base[wave] = base;
+                }
+            }
             const float* be = bmaxerr + wave * kNormBlocks;
             const float* bq = bqmax + wave * kNormBlocks;
             float te = fmaxf(fmaxf(be[lane], be[lane + 64]), fmaxf(be[lane + 128], be[lane + 192]));
@@ -854,6 +981,26 @@ __global__ __launch_bounds__(kSplitThreads) void knn_split_images_kernel(BatchPt
     int mode = kModeHalfExact;
     for (int b = 0; b < B; ++b) mode = max(mode, smode[b]);
     if (blockIdx.x == 0 && threadIdx.x == 0) minfo[kMinfoBatchMode] = mode;
+    // The exact-integer body runs iff EVERY pair of the batch qualifies (one launch, one body).  Its init fragments
+    // (frag_init_i8: the digits of floor(w_t / 2) - base) need the pair's base, so they are written here, not by the prep pass.
+    bool i8 = ti8 != nullptr;
+    for (int b = 0; b < B && i8; ++b) i8 = s8ok[b] != 0;
+    if (blockIdx.x == 0 && threadIdx.x < kMaxBatch + 1) {
+        if (threadIdx.x == kMaxBatch) minfo[kMinfoI8] = i8 ? 1 : 0;
+        else if (threadIdx.x < B && ti8) minfo[kMinfoBase + threadIdx.x] = s8base[threadIdx.x];
+    }
+    if (i8) {
+        for (int pb = 0; pb < B; ++pb) {
+            const int base = s8base[pb];
+            const int* __restrict__ w = wt + pb * s_tn;
+            unsigned char* __restrict__ img = ti8 + pb * s_ti8;
+            for (int e = blockIdx.x * kSplitThreads + threadIdx.x; e < 2 * nt_pad; e += gridDim.x * kSplitThreads) {
+                const int r = e >> 1, h = e & 1;
+                *reinterpret_cast<uint4*>(img + (int64_t)(r >> 5) * kI8TileBytes + 4 * 1024 + ((h * 32 + (r & 31)) << 4)) = frag_init_i8(r < nt ? (w[r] >> 1) - base : kI8CMax, h);
+            }
+        }
+        return;
+    }
     if (force_mode >= 0) mode = force_mode;
     if (mode != kModeSplit) return;
     const bool frag = qhm0 != nullptr;
@@ -1358,6 +1505,7 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #define SFM_MFMA_F16(acc, a, b) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b))
 #define SFM_MFMA_BF16(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b))
 #define SFM_MFMA_BF16_INIT(acc, a, b) asm volatile("v_mfma_f32_32x32x8_bf16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "a"(b))
+#define SFM_MFMA_BF16_REINIT(acc, a, b) asm volatile("v_mfma_f32_32x32x8_bf16 %0, %1, %2, 0" : "+v"(acc) : "v"(a), "a"(b))   // in-loop: pins the register block (see SFM_MFMA_I8_REINIT)
 // first product of a chain: D = A B + C with C a DIFFERENT register block (the tile's shared init values); D is early-clobber —
 // an MFMA's D may coincide with its C exactly or not at all
 #define SFM_MFMA_F16_C(acc, a, b, c) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(acc) : "v"(a), "a"(b), "v"(c))
@@ -1574,7 +1722,7 @@ __device__ __forceinline__ void filter_q4_body(
                         else SFM_MFMA_BF16(acc[1], a, bq[1][st]);
                         SFM_MFMA_BF16(acc[1], a, bq[1][8 + st]);
                         SFM_MFMA_BF16(acc[1], am, bq[1][st]);
-                        if (st == 1) SFM_MFMA_BF16_INIT(cinit, __builtin_bit_cast(u32x2, fri[(S + 1) % D]), bi);   // the NEXT tile's
+                        if (st == 1) SFM_MFMA_BF16_REINIT(cinit, __builtin_bit_cast(u32x2, fri[(S + 1) % D]), bi);   // the NEXT tile's
                     } else {
                         const int g = st >> 2;
                         if (st == 0) SFM_MFMA_F16_C(acc[2], a, bq[2][st], cinit);
@@ -1584,7 +1732,7 @@ __device__ __forceinline__ void filter_q4_body(
                         __builtin_amdgcn_sched_barrier(0);
                         if (st == 0) SFM_MFMA_F16_C(acc[3], a, bq[3][st], cinit);
                         else SFM_MFMA_F16(acc[3], a, bq[3][st]);
-                        if (st == 1) SFM_MFMA_BF16_INIT(cinit, __builtin_bit_cast(u32x2, fri[(S + 1) % D]), bi);   // the NEXT tile's (two MFMAs after the last reader)
+                        if (st == 1) SFM_MFMA_BF16_REINIT(cinit, __builtin_bit_cast(u32x2, fri[(S + 1) % D]), bi);   // the NEXT tile's (two MFMAs after the last reader)
                         __builtin_amdgcn_sched_barrier(0);
                         load_frag(S, st, t + D, more, true);
                         if (ABL & 2) {
@@ -1630,6 +1778,217 @@ __device__ __forceinline__ void filter_q4_body(
     }
 }
 
+
+// ---------------------------------------------------------------- exact-integer body: v_mfma_i32_32x32x32_i8
+// The third body of the q4 kernel (same launch: 256 workgroups of 4 waves, one wave per SIMD), chosen on the device when
+// every value of the batch is a u8 integer (minfo[kMinfoI8]).  Differences from the fp16 body:
+//   * 4 product MFMAs per 32 x 32 tile and group instead of 8, so the loop would be bound by everything that is NOT an MFMA:
+//     a wave owns EIGHT 32-query groups (B fragments: 8 x 4 x 4 = 128 AGPRs), every train fragment (one 1 KiB load) feeds 8
+//     MFMAs — with 4 groups the four waves' fragment loads (20 KiB per tile through the CU's 64 B/clk L1 path) cost 34 of a
+//     tile-group's 128 pipe cycles (scripts/ubench/filter_i8.hip, profiles/r04_ubench_filter_i8_skeleton.txt);
+//   * a candidate record is all 16 accumulator registers of a lane — the 16 train rows 8 m + 4 h + i of a tile — so the
+//     epilogue is 8 min3 / min + 1 pack + 3 insert = 12 VALU per group and tile, THREE per MFMA gap (quads: six, more than a
+//     wave alone on its SIMD hides); the key's low 8 bits are the tile inside a 256-tile substream;
+//   * i32 accumulation: scores are exact (up to the parity bit, see the images' comment), keys hold the whole score
+//     (acc << 8 | tile), the accumulator init is one i8 MFMA per tile shared by the 8 groups (C operand of their first products);
+//   * records are the three packed keys per stream, stored transposed ([row block][stream][h][k][1024 queries]: every store
+//     instruction writes 128 contiguous bytes per half-wave) — 12 B per stream and query instead of 24.
+// Row blocks are 1024 queries; the partition tables are those of the i8 plan (wg_begin8 ...).
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+#define SFM_MFMA_I8(acc, a, b) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b))
+#define SFM_MFMA_I8_C(acc, a, b, c) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %3" : "=&v"(acc) : "v"(a), "a"(b), "v"(c))
+#define SFM_MFMA_I8_INIT(acc, a, b) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "a"(b))
+// The in-loop form declares the old values read ("+v") although the instruction does not read them: the tile's init values
+// must keep ONE register block for the whole loop.  With "=v" the old block is dead after the last chain's first MFMA has
+// been ISSUED, and hipcc hands its registers to the epilogue's temporaries — written by the vector ALU while that MFMA is still
+// reading them as SrcC (no hardware interlock: results of a whole query group went wrong, found by tests/test_gpu_knn_i8.py).
+#define SFM_MFMA_I8_REINIT(acc, a, b) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, 0" : "+v"(acc) : "v"(a), "a"(b))
+
+__device__ __forceinline__ int key_pack_i8(int m, int seq /*wave-uniform*/) {
+    int key;
+    asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(key) : "v"(m), "s"(seq));
+    return key;
+}
+__device__ __forceinline__ int imin3(int a, int b, int c) { return min(min(a, b), c); }   // v_min3_i32
+
+template <int ABL>
+__device__ __forceinline__ void filter_i8_body(
+    const unsigned char* __restrict__ qi8, const unsigned char* __restrict__ ti8, int nq, int nq_pad, int nt, int tiles, int nstr /*stream slots per row block*/,
+    int* __restrict__ keys0, int* __restrict__ sttab0, const int64_t* __restrict__ wg_begin, int n_rb1, int64_t s_qi8, int64_t s_ti8, int64_t s_keys,
+    const int* __restrict__ wg_sbase, int G) {
+    constexpr int NG = kI8Groups, P = NG / 2, D = 2;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int bid = (G & 7) == 0 ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;   // XCD-aware order
+    const int64_t u_end = wg_begin[bid + 1];
+    int64_t u = wg_begin[bid];
+    const int voff = lane * 16;
+    const int qtiles = nq_pad >> 5;
+
+    while (u < u_end) {
+        const int rb = __builtin_amdgcn_readfirstlane((int)(u / tiles));
+        const int t_begin = __builtin_amdgcn_readfirstlane((int)(u - (int64_t)rb * tiles));
+        const int t_end = __builtin_amdgcn_readfirstlane((int)min((int64_t)tiles, t_begin + (u_end - u)));
+        const int sbase = __builtin_amdgcn_readfirstlane(u == wg_begin[bid] ? wg_sbase[bid] : 0);
+        const int pb = __builtin_amdgcn_readfirstlane(n_rb1 > 0 ? rb / n_rb1 : 0);
+        const int rbl = rb - pb * n_rb1;
+        int* __restrict__ keys = keys0 + pb * s_keys;
+        int* __restrict__ sttab = sttab0 + (int64_t)rb * nstr * 2;               // (global row block: the table spans the batch)
+        const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc((void*)(ti8 + pb * s_ti8), 0, tiles * kI8TileBytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc((void*)(qi8 + pb * s_qi8), 0, qtiles * kI8QTileBytes, 0x00020000);
+        const int qg0 = rbl * (kI8Rows / 32) + wave * NG;                      // first 32-query tile of this wave
+        const int qloc0 = wave * NG * 32 + j;                                  // query inside the row block; group g adds 32 g
+        bool qok[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) qok[g] = qg0 * 32 + j + 32 * g < nq;
+
+        // ---- train fragments of the first D tiles (init fragment first: it is consumed first), then the query fragments
+        i32x4 fr[D][5];
+        auto load_frag = [&](int s_, int f, int tile_, bool live, bool in_loop = false) {
+            if ((ABL & 1) && in_loop) return;
+            const int tile = live ? tile_ : t_end - 1;
+            fr[s_][f] = __builtin_amdgcn_raw_buffer_load_b128(trs, voff, __builtin_amdgcn_readfirstlane(tile * kI8TileBytes + f * 1024), 0);
+        };
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            load_frag(d, 4, t_begin + d, t_begin + d < t_end);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) load_frag(d, f, t_begin + d, t_begin + d < t_end);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        u32x4 bq[NG][4], bi;
+        {
+            i32x4 tmp[NG][4];
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+                    tmp[g][f] = __builtin_amdgcn_raw_buffer_load_b128(qrs, voff, __builtin_amdgcn_readfirstlane((qg0 + g) * kI8QTileBytes + f * 1024), 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int f = 0; f < 4; ++f) asm volatile("" : "=a"(bq[g][f]) : "0"(__builtin_bit_cast(u32x4, tmp[g][f])));
+            // query side of the init product: slot 0 (byte 0 of the h = 0 lanes) = 1, the other 31 slots = -128
+            asm volatile("" : "=a"(bi) : "0"(u32x4{h ? 0x80808080u : 0x80808001u, 0x80808080u, 0x80808080u, 0x80808080u}));
+        }
+        asm volatile("s_nop 4");                                               // v_accvgpr_write -> MFMA operand
+
+        int k0[NG], k1[NG], k2[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) k0[g] = k1[g] = k2[g] = INT_MAX;
+        int sub = 0, sub_t0 = t_begin;
+        auto flush = [&](int sb, int st0, int st1) {
+            // cold: once per 256 tiles.  keys[(((rbl * nstr + stream) * 2 + h) * 3 + k) * 1024 + query-in-block]
+            int ql = qloc0;
+            asm volatile("" : "+v"(ql));
+            const int64_t ob = ((int64_t)(rbl * nstr + sbase + sb) * 2 + h) * 3 * kI8Rows;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (qok[g]) {
+                    int* o = keys + ob + ql + 32 * g;
+                    o[0] = k0[g]; o[kI8Rows] = k1[g]; o[2 * kI8Rows] = k2[g];
+                }
+                k0[g] = k1[g] = k2[g] = INT_MAX;
+            }
+            if (threadIdx.x == 0) {                                            // the stream's tile range, for the refine kernel's decode / rescan
+                sttab[2 * (sbase + sb)] = st0;
+                sttab[2 * (sbase + sb) + 1] = st1 - st0;
+            }
+        };
+        i32x16 acc[NG], cinit;
+        // the first tile's "previous tile" (phase A runs the epilogue of groups P .. NG-1): values whose keys are >= kKeyEmptyI
+#pragma unroll
+        for (int g = P; g < NG; ++g)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[g][r] = 0x7FFFFF;
+        SFM_MFMA_I8_INIT(cinit, __builtin_bit_cast(u32x4, fr[0][4]), bi);
+        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+
+        // Rows past the last train (the train image is padded to whole tiles) must never make a key: a record's score has to be
+        // the score of a REAL row of the record (the refine kernel's selection argument counts distinct real rows).  The last,
+        // partial tile's accumulators are masked before their epilogue — a wave-uniform branch taken once per segment at most.
+        const int nrem = nt & 31;                                             // real rows of the partial tile (0: none is partial)
+        auto mask_tail = [&](i32x16& a) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a[r] = 8 * (r >> 2) + 4 * h + (r & 3) >= nrem ? 0x7FFFFF : a[r];
+        };
+        // one group's epilogue (12 VALU) in four pieces of three, one per MFMA gap of a k-step
+        int m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, key = 0;
+        auto epi = [&](int piece, i32x16& a, int seq, int& e0, int& e1, int& e2, bool partial) {
+            if (ABL & 2) { if (piece == 0) e0 = min(e0, a[0] + a[15]); return; }
+            if (piece == 0 && partial) mask_tail(a);
+            if (piece == 0) { m0 = imin3(a[0], a[1], a[2]); m1 = imin3(a[3], a[4], a[5]); m2 = imin3(a[6], a[7], a[8]); }
+            else if (piece == 1) { m3 = imin3(a[9], a[10], a[11]); m4 = imin3(a[12], a[13], a[14]); m0 = imin3(m0, m1, a[15]); }
+            else if (piece == 2) { m0 = imin3(m0, m2, m3); m0 = min(m0, m4); key = key_pack_i8(m0, seq); }
+            else key_put(key, e0, e1, e2);
+        };
+        auto tile = [&](int t, auto slot_c) {
+            constexpr int S = decltype(slot_c)::value;
+            const bool more = t + D < t_end;
+            const int seq_prev = __builtin_amdgcn_readfirstlane(max((t - 1) - sub_t0, 0));
+            const bool part_cur = nrem != 0 && t + 1 == tiles;      // (wave-uniform) t is the train image's last, partial tile; its second-half groups' epilogue is the tail's
+            // ---- phase A: chains of groups 0 .. 3; k-step st carries the epilogue of group P + st (previous tile)
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const u32x4 a = __builtin_bit_cast(u32x4, fr[S][st]);
+#pragma unroll
+                for (int g = 0; g < P; ++g) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (st == 0) SFM_MFMA_I8_C(acc[g], a, bq[g][st], cinit);
+                    else SFM_MFMA_I8(acc[g], a, bq[g][st]);
+                    epi(g, acc[P + st], seq_prev, k0[P + st], k1[P + st], k2[P + st], false);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // ---- substream boundary: every group's keys now cover exactly the tiles before t
+            if (t - sub_t0 == kI8SubTiles) {
+                flush(sub, sub_t0, t);
+                ++sub;
+                sub_t0 = t;
+            }
+            const int seq_cur = __builtin_amdgcn_readfirstlane(t - sub_t0);
+            // ---- phase B: chains of groups 4 .. 7; epilogue of groups 0 .. 3 (this tile); the fragments die one by one and are
+            // refilled for tile t + D; the NEXT tile's init MFMA two MFMAs after the last reader of the current values
+            __builtin_amdgcn_sched_barrier(0);
+            load_frag(S, 4, t + D, more, true);
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const u32x4 a = __builtin_bit_cast(u32x4, fr[S][st]);
+#pragma unroll
+                for (int g = 0; g < P; ++g) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (st == 0) SFM_MFMA_I8_C(acc[P + g], a, bq[P + g][st], cinit);
+                    else SFM_MFMA_I8(acc[P + g], a, bq[P + g][st]);
+                    if (st == 1 && g == 1) SFM_MFMA_I8_REINIT(cinit, __builtin_bit_cast(u32x4, fr[(S + 1) % D][4]), bi);
+                    epi(g, acc[st], seq_cur, k0[st], k1[st], k2[st], part_cur);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                load_frag(S, st, t + D, more, true);
+            }
+        };
+        // whole rounds of D tiles, the remainder after the loop (see the fp16 body: hipcc's waitcnt merge at the back edge)
+        int t = t_begin;
+        for (; t + D <= t_end; t += D) {
+            tile(t, std::integral_constant<int, 0>{});
+            tile(t + 1, std::integral_constant<int, 1>{});
+        }
+        if (t < t_end) tile(t, std::integral_constant<int, 0>{});
+        // epilogue of the last tile's groups P .. NG-1 (the MFMAs that completed them were the last instructions issued)
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        if (t_end > t_begin) {
+            const int seq = __builtin_amdgcn_readfirstlane((t_end - 1) - sub_t0);
+#pragma unroll
+            for (int g = P; g < NG; ++g)
+#pragma unroll
+                for (int piece = 0; piece < 4; ++piece) epi(piece, acc[g], seq, k0[g], k1[g], k2[g], nrem != 0 && t_end == tiles);
+        }
+        flush(sub, sub_t0, t_end);
+        u += t_end - t_begin;
+    }
+}
+
 template <int ABL>
 __global__ __launch_bounds__(256, 1) void knn_filter_q4_kernel(
     const unsigned char* __restrict__ qfrag, const unsigned char* __restrict__ tfrag, const unsigned char* __restrict__ qhm,
@@ -1637,12 +1996,24 @@ __global__ __launch_bounds__(256, 1) void knn_filter_q4_kernel(
     const float* __restrict__ bmax, int force_mode, float* __restrict__ cand_s, int* __restrict__ cand_i,
     const int64_t* __restrict__ wg_begin, const int* __restrict__ rb_first, int n_rb1, int n_pairs, int64_t s_qfrag, int64_t s_tfrag,
     int64_t s_qhm, int64_t s_thm, int64_t s_cand, int* __restrict__ minfo, const float* __restrict__ bmaxerr,
-    const int* __restrict__ wg_sbase, long long* __restrict__ trace) {
+    const int* __restrict__ wg_sbase, long long* __restrict__ trace,
+    // the exact-integer body (qi8 == null: not planned): byte images, key records, its own partition (1024-query row blocks)
+    const unsigned char* __restrict__ qi8, const unsigned char* __restrict__ ti8, int64_t s_qi8, int64_t s_ti8, int* __restrict__ keys8,
+    int* __restrict__ sttab8, int64_t s_keys8, int nstr8, const int64_t* __restrict__ wg_begin8, int n_rb1_8, const int* __restrict__ wg_sbase8, int G8,
+    int nt8) {
     if (trace && threadIdx.x == 0) {
         trace[4 * blockIdx.x + 0] = wall_clock64();
         trace[4 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg(0xF804);
         trace[4 * blockIdx.x + 3] = __builtin_amdgcn_s_getreg(0xF814);
         trace[8192 + 4 * blockIdx.x + 2] = clock64();
+    }
+    if (qi8 && minfo[kMinfoI8]) {                          // (uniform: one scalar load)
+        if ((int)blockIdx.x < G8) filter_i8_body<ABL>(qi8, ti8, nq, nq_pad, nt8, tiles, nstr8, keys8, sttab8, wg_begin8, n_rb1_8, s_qi8, s_ti8, s_keys8, wg_sbase8, G8);
+        if (trace && threadIdx.x == 0) {
+            trace[4 * blockIdx.x + 1] = wall_clock64();
+            trace[8192 + 4 * blockIdx.x + 3] = clock64();
+        }
+        return;
     }
     const bool need_mid = (force_mode >= 0 ? force_mode : minfo[kMinfoBatchMode]) == kModeSplit;   // (reduced by knn_split_images_kernel)
     if (need_mid)
@@ -1816,6 +2187,236 @@ constexpr int kHotPre = 2;       // rows a lane quad has in flight in the hot-pa
 constexpr int kRecCap = 112;     // record list per query
 constexpr int kQualCap = 144;    // exact-evaluation list per query (a chunk of 16 records adds up to 64 rows)
 
+
+// ---------------------------------------------------------------- refine, exact-integer body
+// Sixteen lanes per query as above, but everything is integer and every wave is on its own (no workgroup barrier):
+//   records   three packed keys (acc << 8 | tile-in-substream) per stream; a record = the 16 train rows 8 m + 4 h + i of a tile
+//   select    a(2) = the second smallest record score; a row of the exact top-2 (ties and float32 square roots that collide
+//             included) sits in a record with score <= a(2) + 1:  two distinct rows with d^2 <= U = c_q - 128 + 2 (a(2) + base) + 1
+//             exist, so d2^2 <= U, and a row with d^2 <= d2^2 + 2 has acc <= a(2) + 1.5
+//   evaluate  the listed records' rows exactly: d^2 = c_q - 128 + w_t + 2 sum a b (v_dot4_i32_i8 on the byte images), a lane per row;
+//             ordered by (sqrtf((float) d^2), index) — the reference compares float32 distances, lower index wins ties
+//   certify   a stream discards only rows with acc >= its third key's: d^2 >= c_q - 128 + 2 (a3 + base); a stream with that
+//             bound > d2^2 + 2 hides nothing (d^2 < 2^23: at most two consecutive integers share a float32 square root)
+//   rescan    any other full stream: its rows are evaluated by the query's 16 lanes (duplicates / exact ties only)
+struct Best2I {
+    float d[2];
+    int i[2];
+    int s[2];      // exact d^2
+};
+__device__ __forceinline__ void best2i_insert_unique(Best2I& b, float d, int i, int s) {
+    if (i == b.i[0] || i == b.i[1]) return;
+    if (key_less(d, i, b.d[0], b.i[0])) {
+        b.d[1] = b.d[0]; b.i[1] = b.i[0]; b.s[1] = b.s[0];
+        b.d[0] = d; b.i[0] = i; b.s[0] = s;
+    } else if (key_less(d, i, b.d[1], b.i[1])) {
+        b.d[1] = d; b.i[1] = i; b.s[1] = s;
+    }
+}
+template <int M>
+__device__ __forceinline__ void best2i_exchange_step(Best2I& b) {
+    const float d0 = lane_xor<M>(b.d[0]), d1 = lane_xor<M>(b.d[1]);
+    const int i0 = lane_xor<M>(b.i[0]), i1 = lane_xor<M>(b.i[1]), s0 = lane_xor<M>(b.s[0]), s1 = lane_xor<M>(b.s[1]);
+    best2i_insert_unique(b, d0, i0, s0);
+    best2i_insert_unique(b, d1, i1, s1);
+}
+constexpr int kRecCapI8 = 56;      // (key, slot) pairs per query in the record list (the `rec` array: 112 ints per query)
+
+__device__ __forceinline__ void refine_i8_body(
+    const BatchPtrs& P, int B, int nq, int nt, int tiles, const int* __restrict__ minfo, const unsigned char* __restrict__ qi8, const unsigned char* __restrict__ ti8,
+    int64_t s_qi8, int64_t s_ti8, const int* __restrict__ wq, const int* __restrict__ wt, int64_t s_qn, int64_t s_tn, const int* __restrict__ keys,
+    const int* __restrict__ sttab, int64_t s_keys, int nstr, const int* __restrict__ rb_last8, int n_rb1, int G8, double ratio,
+    int* __restrict__ ratio_counts, int ratio_stride, unsigned char* __restrict__ qb /*LDS [kRefQ][128]*/, int* __restrict__ recl /*LDS [kRefQ][2 * kRecCapI8]*/) {
+    const int n_wg = (nq + kRefQ - 1) / kRefQ, n_tot = B * n_wg, wg_chunk = (n_tot + 7) >> 3;
+    const int bidt = n_tot >= 64 ? (int)(blockIdx.x & 7) * wg_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (bidt >= n_tot) return;
+    const int pb = bidt / n_wg, bid = bidt - pb * n_wg;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane >> 4, sl = lane & 15;
+    const int ql = wave * 4 + sub;
+    const int q = bid * kRefQ + ql;
+    const bool valid = q < nq;
+    const int qc = valid ? q : 0;
+    const int rbl = (bid * kRefQ) / kI8Rows, rb = pb * n_rb1 + rbl;
+    const int qloc = qc - rbl * kI8Rows;
+    const int NC = rb_last8[B * n_rb1 + rb] * 6;              // live key slots of the row block: streams x 2 half-waves x 3
+    const int base = minfo[kMinfoBase + pb];
+    qi8 += pb * s_qi8; ti8 += pb * s_ti8; wq += pb * s_qn; wt += pb * s_tn; keys += pb * s_keys;
+    const int* __restrict__ kq = keys + (int64_t)rbl * nstr * 6 * kI8Rows + qloc;      // slot c of this query: kq[c * kI8Rows]
+    const int* __restrict__ stt = sttab + (int64_t)rb * nstr * 2;
+    int* __restrict__ stats = P.stats[pb];
+    if (bid == 0 && threadIdx.x == 0 && stats) { stats[1] = G8; stats[2] = 2 * nstr; stats[3] = 4; }
+
+    // the query's bytes -> LDS in element order (chunk 2 f + h of the fragment image = elements 32 f + 16 h .. + 15); wave-local
+    if (sl < 8) *reinterpret_cast<uint4*>(qb + ql * kDim + 16 * sl) =
+        *reinterpret_cast<const uint4*>(qi8 + (int64_t)(qc >> 5) * kI8QTileBytes + (sl >> 1) * 1024 + (((sl & 1) * 32 + (qc & 31)) << 4));
+    const int cq = wq[qc] - 128;
+    int kv[kS1];
+#pragma unroll
+    for (int k = 0; k < kS1; ++k) {
+        const int c = sl + 16 * k;
+        kv[k] = (valid && c < NC) ? kq[(int64_t)c * kI8Rows] : INT_MAX;
+    }
+    int a1 = INT_MAX, a2 = INT_MAX, atau = INT_MAX;
+#pragma unroll
+    for (int k = 0; k < kS1; ++k) {
+        a2 = imed3(a1, a2, kv[k]);
+        a1 = min(a1, kv[k]);
+        if ((sl + 16 * k) % 3 == 2) atau = min(atau, kv[k]);
+    }
+    if (valid)
+        for (int c = sl + 16 * kS1; c < NC; c += 16) {
+            const int x = kq[(int64_t)c * kI8Rows];
+            if (c % 3 == 2) atau = min(atau, x);
+            a2 = imed3(a1, a2, x);
+            a1 = min(a1, x);
+        }
+    auto fold = [&](int o1, int o2, int ot) {
+        const int hi = max(a1, o1);
+        a1 = min(a1, o1);
+        a2 = min(hi, min(a2, o2));
+        atau = min(atau, ot);
+    };
+    fold(lane_xor<8>(a1), lane_xor<8>(a2), lane_xor<8>(atau));
+    fold(lane_xor<4>(a1), lane_xor<4>(a2), lane_xor<4>(atau));
+    fold(lane_xor<2>(a1), lane_xor<2>(a2), lane_xor<2>(atau));
+    fold(lane_xor<1>(a1), lane_xor<1>(a2), lane_xor<1>(atau));
+    // records with score <= a(2) + 1 (every record when there are fewer than two)
+    const int thr = a2 >= kKeyEmptyI ? kKeyEmptyI - 1 : (int)((((unsigned)(a2 >> 8) + 1u) << 8) | 0xFFu);
+
+    Best2I b;
+    b.d[0] = b.d[1] = kInf; b.i[0] = b.i[1] = INT_MAX; b.s[0] = b.s[1] = INT_MAX;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // one tile's 16 rows of half-wave h, a lane per row: exact d^2, inserted under (sqrtf, index)
+    auto eval_tile = [&](int tile, int hh, bool live) {
+        const int jr = 8 * (sl >> 2) + 4 * hh + (sl & 3);
+        const int row = tile * kTileT + jr;
+        const unsigned char* tp = ti8 + (int64_t)tile * kI8TileBytes + (jr << 4);
+        uint4 tv[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) tv[c] = *reinterpret_cast<const uint4*>(tp + (c >> 1) * 1024 + (c & 1) * 512);
+        const int w = wt[row];
+        int s0 = 0, s1 = 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const uint4 qv = *reinterpret_cast<const uint4*>(qb + ql * kDim + 16 * c);
+            s0 = __builtin_amdgcn_sdot4((int)tv[c].x, (int)qv.x, s0, false);
+            s1 = __builtin_amdgcn_sdot4((int)tv[c].y, (int)qv.y, s1, false);
+            s0 = __builtin_amdgcn_sdot4((int)tv[c].z, (int)qv.z, s0, false);
+            s1 = __builtin_amdgcn_sdot4((int)tv[c].w, (int)qv.w, s1, false);
+        }
+        const int d2 = cq + w + 2 * (s0 + s1);
+        if (live && row < nt) best2i_insert_unique(b, sqrtf((float)d2), row, d2);
+    };
+    auto row_scan = [&](int v, int& total) {
+        v += __builtin_amdgcn_update_dpp(0, v, 0x111 /*row_shr:1*/, 0xF, 0xF, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x112 /*row_shr:2*/, 0xF, 0xF, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x114 /*row_shr:4*/, 0xF, 0xF, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x118 /*row_shr:8*/, 0xF, 0xF, true);
+        total = __builtin_amdgcn_ds_swizzle(v, 0x10 | (0x0F << 5));
+        return v;
+    };
+    auto wave_max = [&](int v) {
+        v = max(v, lane_xor<16>(v));
+        return max(v, __shfl_xor(v, 32, 64));
+    };
+    int* __restrict__ myrec = recl + ql * (2 * kRecCapI8);
+    int nrec = 0;
+    auto process = [&]() {                                       // evaluate the listed records (wave-uniform trip count)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int nmax = wave_max(nrec);
+#pragma unroll 1
+        for (int e = 0; e < nmax; ++e) {
+            const bool live = e < nrec;
+            const int key = live ? myrec[2 * e] : 0, c = live ? myrec[2 * e + 1] : 0;
+            const int tile = min(stt[2 * (c / 6)] + (key & 0xFF), tiles - 1);      // (idle lanes: slot 0 -> a real tile, result unused)
+            eval_tile(tile, (c / 3) & 1, live);
+        }
+        __builtin_amdgcn_wave_barrier();
+        nrec = 0;
+    };
+    {   // the chunks still in registers: one prefix sum when the list holds them all (always, but for exact ties en masse)
+        bool take[kS1];
+        int mine = 0;
+#pragma unroll
+        for (int k = 0; k < kS1; ++k) {
+            take[k] = kv[k] <= thr;                              // (empty / invalid slots: INT_MAX or >= kKeyEmptyI > thr)
+            mine += take[k] ? 1 : 0;
+        }
+        int total;
+        int at = row_scan(mine, total) - mine;
+        if (!__any(total > kRecCapI8)) {
+#pragma unroll
+            for (int k = 0; k < kS1; ++k)
+                if (take[k]) { myrec[2 * at] = kv[k]; myrec[2 * at + 1] = sl + 16 * k; ++at; }
+            nrec = total;
+        } else {
+#pragma unroll 1
+            for (int k = 0; k < kS1; ++k) {
+                if (__any(nrec > kRecCapI8 - 16)) process();
+                int kvk = kv[0];
+#pragma unroll
+                for (int kk = 1; kk < kS1; ++kk) kvk = k == kk ? kv[kk] : kvk;
+                const bool tk = kvk <= thr;
+                int tot;
+                const int a0 = row_scan(tk ? 1 : 0, tot) - (tk ? 1 : 0);
+                if (tk) { myrec[2 * (nrec + a0)] = kvk; myrec[2 * (nrec + a0) + 1] = sl + 16 * k; }
+                nrec += tot;
+            }
+        }
+    }
+    for (int k0 = kS1; k0 * 16 < NC; ++k0) {                     // (wave-uniform) more than 96 key slots per query
+        if (__any(nrec > kRecCapI8 - 16)) process();
+        const int c = sl + 16 * k0;
+        const int x = (valid && c < NC) ? kq[(int64_t)c * kI8Rows] : INT_MAX;
+        const bool take = x <= thr;
+        int total;
+        const int at = row_scan(take ? 1 : 0, total) - (take ? 1 : 0);
+        if (take) { myrec[2 * (nrec + at)] = x; myrec[2 * (nrec + at) + 1] = c; }
+        nrec += total;
+    }
+    process();
+    auto reduce16 = [&]() {
+        best2i_exchange_step<8>(b);
+        best2i_exchange_step<4>(b);
+        best2i_exchange_step<2>(b);
+        best2i_exchange_step<1>(b);
+    };
+    reduce16();
+    // certificate (all-integer); rescans are wave-local: the query's 16 lanes walk the uncertified streams' tiles
+    const long long lim = b.i[1] != INT_MAX ? (long long)b.s[1] + 2 : LLONG_MAX;
+    auto hides = [&](int key3) {                                 // could the stream behind this third key hide a row that matters?
+        return key3 < kKeyEmptyI && (long long)cq + 2 * ((long long)(key3 >> 8) + base) <= lim;
+    };
+    const bool open = valid && hides(atau);
+    if (open) {
+        for (int c3 = 2; c3 < NC; c3 += 3) {
+            const int key3 = kq[(int64_t)c3 * kI8Rows];
+            if (!hides(key3)) continue;
+            const int t0 = stt[2 * (c3 / 6)], len = stt[2 * (c3 / 6) + 1];
+            for (int tt = 0; tt < len; ++tt) eval_tile(t0 + tt, (c3 / 3) & 1, true);
+        }
+        reduce16();
+    }
+
+    int* __restrict__ idx_out = P.idx[pb];
+    float* __restrict__ dist_out = P.dist[pb];
+    unsigned char* __restrict__ ratio_mask = P.mask[pb];
+    if (valid && sl == 0) {
+        *reinterpret_cast<int2*>(idx_out + 2 * (int64_t)q) = make_int2(b.i[0] == INT_MAX ? -1 : b.i[0], b.i[1] == INT_MAX ? -1 : b.i[1]);
+        *reinterpret_cast<float2*>(dist_out + 2 * (int64_t)q) = make_float2(b.d[0], b.d[1]);
+        if (open && stats) atomicAdd(stats, 1);
+    }
+    if (ratio_counts) {                                          // (already offset to this pair by the caller)
+        const bool pass = valid && sl == 0 && b.i[1] != INT_MAX && (double)b.d[0] < ratio * (double)b.d[1];
+        if (ratio_mask && valid && sl == 0) ratio_mask[q] = pass ? 1 : 0;
+        const int n = __popcll(__ballot(pass));
+        if (lane == 0 && n) atomicAdd(ratio_counts + (bid * kRefQ) / kRatioBlock, n);
+    }
+}
+
 // Sixteen lanes per query, sixteen queries per workgroup (one resident round for 10^4 queries).
 //   sweep 1  two smallest filter scores over the query's candidate records and each stream's 3rd best
 //   sweep 2  candidates within 4*eps of the 2nd smallest score are compacted and evaluated exactly → (d1, d2)
@@ -1838,7 +2439,11 @@ __global__ __launch_bounds__(256, 4) void knn_refine_kernel(
     const int64_t* __restrict__ wg_begin, const int* __restrict__ rb_first, const int* __restrict__ rb_last,
     int n_rb1, int64_t s_cand, int64_t s_tsplit, int64_t s_tn, double ratio,
     int* __restrict__ ratio_counts /*null unless fused with the Lowe ratio*/, int ratio_stride, float chain_scale,
-    int qoff /*1: the filter's scores carry ||q||^2max of the pair instead of the query's own ||q||^2 (q4 filter)*/, long long* __restrict__ trace) {
+    int qoff /*1: the filter's scores carry ||q||^2max of the pair instead of the query's own ||q||^2 (q4 filter)*/, long long* __restrict__ trace,
+    // the exact-integer body (qi8 == null: not planned)
+    const unsigned char* __restrict__ qi8, const unsigned char* __restrict__ ti8, int64_t s_qi8, int64_t s_ti8, const int* __restrict__ wq8,
+    const int* __restrict__ wt8, const int* __restrict__ keys8, const int* __restrict__ sttab8, int64_t s_keys8, int nstr8,
+    const int* __restrict__ rb_last8, int n_rb1_8, int G8) {
     // XCD-aware order (see the filter): physical workgroup b takes query block (b % 8) * chunk + b / 8, so the queries an
     // XCD refines are (roughly) those whose candidate records its own filter workgroups wrote.  Batched: the query
     // blocks of all pairs form one sequence, pair after pair.
@@ -1871,6 +2476,12 @@ __global__ __launch_bounds__(256, 4) void knn_refine_kernel(
     __shared__ int surv[kSubTiles * 16];
     __shared__ int nitem, nsurv;
     __shared__ Best2 wbest[4];
+    if constexpr (FRAG)
+    if (qi8 && minfo && minfo[kMinfoI8]) {                 // (uniform) the exact-integer body ran: its records, its certificate
+        refine_i8_body(P, B, nq, nt, tiles, minfo, qi8, ti8, s_qi8, s_ti8, wq8, wt8, s_qn, s_tn, keys8, sttab8, s_keys8, nstr8, rb_last8, n_rb1_8, G8, ratio,
+                       ratio_counts, ratio_stride, reinterpret_cast<unsigned char*>(&qrows[0][0]), &rec[0][0]);
+        return;
+    }
     if (trace && threadIdx.x == 0) trace[16 * bidt + 0] = wall_clock64();   // dev diagnostics
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -2527,13 +3138,27 @@ struct KnnWs {
     unsigned char* qhm;           // ... and the bf16 hi / mid planes in fragment order (split arithmetic only), 16 KiB per 32 rows
     unsigned char* thm;
     int64_t s_qsplit, s_tsplit, s_qn, s_tn, s_cand, s_qfrag, s_tfrag, s_qhm, s_thm;
+    // exact-integer body (kFilterAuto): byte images, integer norms, key records, its partition tables
+    unsigned char* qi8;
+    unsigned char* ti8;
+    int* wq;                      // [B][s_qn]  |q - 128|^2
+    int* wt;                      // [B][s_tn]  |t - 127|^2
+    int* bwmin;                   // [B][kNormBlocks] per-block min / max of wt over the real train rows
+    int* bwmax;
+    int* keys8;                   // [B][row blocks][stream slots][2][3][1024] packed keys
+    int* sttab8;                  // [row blocks of the batch][stream slots][2]: first tile, tile count of a stream
+    int64_t* wg_begin8;
+    int* rb_first8;
+    int* rb_last8;
+    int* wg_sbase8;
+    int64_t s_qi8, s_ti8, s_keys8;
     size_t bytes;
 };
 
-KnnWs carve_ws(void* ws, int64_t nq, int64_t nt, const Plan& p) {
+KnnWs carve_ws(void* ws, int64_t nq, int64_t nt, const Plan& p, const Plan* p8) {
     (void)nt;
     sfm::Carver c(ws);
-    KnnWs w;
+    KnnWs w{};
     const size_t B = (size_t)p.B;
     w.s_tn = (int64_t)p.tiles * kTileT;
     w.s_qn = p.nq_pad;
@@ -2564,6 +3189,23 @@ KnnWs carve_ws(void* ws, int64_t nq, int64_t nt, const Plan& p) {
     w.tfrag = c.take<unsigned char>(B * (size_t)w.s_tfrag);
     w.qhm = c.take<unsigned char>(B * (size_t)w.s_qhm);
     w.thm = c.take<unsigned char>(B * (size_t)w.s_thm);
+    if (p8) {
+        w.s_qi8 = (int64_t)(p.nq_pad / 32) * kI8QTileBytes;
+        w.s_ti8 = (int64_t)p.tiles * kI8TileBytes;
+        w.s_keys8 = (int64_t)p8->n_rb1 * p8->smax * p8->nsub * 6 * kI8Rows;
+        w.qi8 = c.take<unsigned char>(B * (size_t)w.s_qi8);
+        w.ti8 = c.take<unsigned char>(B * (size_t)w.s_ti8);
+        w.wq = c.take<int>(B * (size_t)w.s_qn);
+        w.wt = c.take<int>(B * (size_t)w.s_tn);
+        w.bwmin = c.take<int>(B * kNormBlocks);
+        w.bwmax = c.take<int>(B * kNormBlocks);
+        w.keys8 = c.take<int>(B * (size_t)w.s_keys8);
+        w.sttab8 = c.take<int>((size_t)p8->n_rb * p8->smax * p8->nsub * 2);
+        w.wg_begin8 = c.take<int64_t>((size_t)p8->G + 1);
+        w.rb_first8 = c.take<int>((size_t)p8->n_rb);
+        w.rb_last8 = c.take<int>(2 * (size_t)p8->n_rb);
+        w.wg_sbase8 = c.take<int>((size_t)p8->G + 1);
+    }
     w.bytes = c.used();
     return w;
 }
@@ -2744,13 +3386,15 @@ extern "C" int sfm_debug_set_trace(void* dev_buf) {
 namespace {
 constexpr int64_t kMaxTrainRows = 4000000;                     // fragment offsets are 32-bit: 16 KiB per 32 rows in the split images
 
-bool filter_ok(int filter) { return filter >= kFilterAuto && filter <= kFilterLdsSplit; }
+bool filter_ok(int filter) { return filter >= kFilterAuto && filter <= kFilterHalf; }
 
 size_t knn_ws_bytes(int64_t nq, int64_t nt, int dim, int B, int filter) {
     if (nq < 0 || nt < 0 || nt > kMaxTrainRows || dim != kDim || B < 1 || B > kMaxBatch || !filter_ok(filter)) return 0;
     if (B > 1 && filter == kFilterF32) return 0;               // the fp32-MFMA variant is single-pair
     const Plan p = make_plan(nq, nt, B, filter);
-    return carve_ws(nullptr, nq, nt, p).bytes + 256;
+    if (!p.i8) return carve_ws(nullptr, nq, nt, p, nullptr).bytes + 256;
+    const Plan p8 = make_plan(nq, nt, B, kFilterI8Plan);
+    return carve_ws(nullptr, nq, nt, p, &p8).bytes + 256;
 }
 
 size_t ratio_ws_bytes(int64_t nq, int B) {
@@ -2764,7 +3408,7 @@ int knn_batch_impl(int B, const BatchPtrs& P, int64_t nq, int64_t ldq, int64_t n
     const int ratio_blocks = ratio_counts ? (int)((nq + kRatioBlock - 1) / kRatioBlock) : 0;
     SFM_CHECK_ARG(dim == kDim, "sfm_knn2_l2_f32: dim must be 128 (got %d)", dim);
     SFM_CHECK_ARG(B >= 1 && B <= kMaxBatch, "sfm_match_batch_l2_f32: 1 <= batch <= %d (got %d)", kMaxBatch, B);
-    SFM_CHECK_ARG(filter_ok(filter), "sfm_knn2_l2_f32: filter must be 0 (auto), 1 (fp32 MFMA), 2 (bf16 split pinned), 3 / 4 (LDS-ring kernel, auto / split) (got %d)", filter);
+    SFM_CHECK_ARG(filter_ok(filter), "sfm_knn2_l2_f32: filter must be 0 (auto), 1 (fp32 MFMA), 2 (bf16 split pinned), 3 / 4 (LDS-ring kernel, auto / split), 5 (16-bit only) (got %d)", filter);
     SFM_CHECK_ARG(nq >= 0 && nt >= 0 && nq < INT_MAX / 256 && nt <= kMaxTrainRows, "sfm_knn2_l2_f32: bad sizes nq=%lld nt=%lld (nt <= %lld)",
                   (long long)nq, (long long)nt, (long long)kMaxTrainRows);
     if (nq == 0) return SFM_OK;
@@ -2783,6 +3427,8 @@ int knn_batch_impl(int B, const BatchPtrs& P, int64_t nq, int64_t ldq, int64_t n
     }
     SFM_CHECK_ARG(B == 1 || filter != kFilterF32, "sfm_match_batch_l2_f32: the fp32-MFMA filter variant is single-pair");
     const Plan p = make_plan(nq, nt, B, filter);
+    Plan p8{};
+    if (p.i8) p8 = make_plan(nq, nt, B, kFilterI8Plan);
     const size_t need = knn_ws_bytes(nq, nt, dim, B, filter);
     if (!ws || ws_bytes < need) {
         sfm::set_error("sfm_knn2_l2_f32: workspace too small (%zu < %zu)", ws_bytes, need);
@@ -2790,21 +3436,24 @@ int knn_batch_impl(int B, const BatchPtrs& P, int64_t nq, int64_t ldq, int64_t n
     }
     // carve from a 256-aligned base inside the caller's buffer
     char* base = reinterpret_cast<char*>(sfm::align_up((size_t)(uintptr_t)ws, 256));
-    const KnnWs w = carve_ws(base, nq, nt, p);
+    const KnnWs w = carve_ws(base, nq, nt, p, p.i8 ? &p8 : nullptr);
+    const int nstr8 = p.i8 ? p8.smax * p8.nsub : 0;
 
     const dim3 grid((unsigned)p.G);
     const int prof_reps = p.split ? sfm::prof_repeat() : 1;
     static const int abl = [] { const char* e = getenv("SFM_KNN_ABL"); return e ? atoi(e) : 0; }();   // dev only
     if (p.split) {
-        hipLaunchKernelGGL(knn_prep_kernel, dim3(kNormBlocks + 1, (unsigned)B), dim3(kPrepThreads), 0, stream, P, ldq, (int)nq, p.nq_pad, ldt, (int)nt,
+        hipLaunchKernelGGL(knn_prep_kernel, dim3(kNormBlocks + 2, (unsigned)B), dim3(kPrepThreads), 0, stream, P, ldq, (int)nq, p.nq_pad, ldt, (int)nt,
                            p.tiles * kTileT, w.qsplit, w.qn, w.tsplit, w.tn, w.bmax, w.midflag, w.qerr, w.bmaxerr, w.bqmax, w.s_qsplit, w.s_tsplit, w.s_qn, w.s_tn,
                            p.q4 ? w.qfrag : nullptr, w.tfrag, w.s_qfrag, w.s_tfrag,
                            ratio_counts, ratio_counts ? ratio_stride : 0,
-                           p.units, p.tiles, p.G, p.seg_cost, p.n_rb, w.wg_begin, w.rb_first, w.rb_last, p.q4 ? w.wg_sbase : nullptr);
+                           p.units, p.tiles, p.G, p.seg_cost, p.n_rb, w.wg_begin, w.rb_first, w.rb_last, p.q4 ? w.wg_sbase : nullptr,
+                           w.qi8, w.ti8, w.s_qi8, w.s_ti8, w.wq, w.wt, w.bwmin, w.bwmax, p8.units, p8.G, p8.n_rb, w.wg_begin8, w.rb_first8, w.rb_last8,
+                           w.wg_sbase8);
         SFM_CHECK_LAUNCH();
         hipLaunchKernelGGL(knn_split_images_kernel, dim3(kNormBlocks), dim3(kSplitThreads), 0, stream, P, B, ldq, (int)nq, p.nq_pad, ldt, (int)nt,
                            p.tiles * kTileT, w.qsplit, w.tsplit, w.s_qsplit, w.s_tsplit, w.midflag, w.bmax, p.force_mode,
-                           p.q4 ? w.qhm : nullptr, w.thm, w.s_qhm, w.s_thm, w.bmaxerr, w.bqmax, w.minfo);
+                           p.q4 ? w.qhm : nullptr, w.thm, w.s_qhm, w.s_thm, w.bmaxerr, w.bqmax, w.minfo, w.ti8, w.s_ti8, w.wt, w.s_tn, w.bwmin, w.bwmax);
         SFM_CHECK_LAUNCH();
         sfm::prof_begin(sfm::kProfKnnFilter, stream);
 #define SFM_LAUNCH_SPLIT2(A, WV)                                                                                        \
@@ -2819,7 +3468,8 @@ int knn_batch_impl(int B, const BatchPtrs& P, int64_t nq, int64_t ldq, int64_t n
 #define SFM_LAUNCH_Q4(A)                                                                                                                         \
     hipLaunchKernelGGL(knn_filter_q4_kernel<A>, grid, dim3(256), 0, stream, w.qfrag, w.tfrag, w.qhm, w.thm, (int)nq, p.nq_pad, p.tiles, p.smax, p.nsub, \
                        w.midflag, w.bmax, p.force_mode, w.cand_s, w.cand_i, w.wg_begin, w.rb_first, p.n_rb1, B, w.s_qfrag, w.s_tfrag, w.s_qhm,         \
-                       w.s_thm, w.s_cand, w.minfo, w.bmaxerr, w.wg_sbase, g_trace)
+                       w.s_thm, w.s_cand, w.minfo, w.bmaxerr, w.wg_sbase, g_trace, w.qi8, w.ti8, w.s_qi8, w.s_ti8, w.keys8, w.sttab8, w.s_keys8, nstr8,         \
+                       w.wg_begin8, p8.n_rb1, w.wg_sbase8, p8.G, (int)nt)
             if (abl == 1) SFM_LAUNCH_Q4(1); else if (abl == 2) SFM_LAUNCH_Q4(2); else if (abl == 3) SFM_LAUNCH_Q4(3); else if (abl == 4) SFM_LAUNCH_Q4(4); else SFM_LAUNCH_Q4(0);
 #undef SFM_LAUNCH_Q4
         } else if (p.waves == 4) {
@@ -2877,7 +3527,8 @@ int knn_batch_impl(int B, const BatchPtrs& P, int64_t nq, int64_t ldq, int64_t n
     hipLaunchKernelGGL(knn_refine_kernel<FRAG>, dim3((unsigned)refine_grid), dim3(256), 0, stream, P, B, ldq, (int)nq, ldt, (int)nt, w.cand_s,    \
                        w.cand_i, p.rows_per_block, p.tiles, p.units, p.G, p.smax * p.nsub, p.nsub, force_mode, w.midflag, w.bmax,               \
                        p.split ? w.minfo : nullptr, p.split ? w.qerr : nullptr, w.s_qn, THALF, w.tn, w.wg_begin, w.rb_first, w.rb_last, p.n_rb1, \
-                       w.s_cand, S_THALF, w.s_tn, ratio, ratio_counts, ratio_stride, chain_scale, p.q4 ? 1 : 0, g_trace ? g_trace + 16384 : nullptr)
+                       w.s_cand, S_THALF, w.s_tn, ratio, ratio_counts, ratio_stride, chain_scale, p.q4 ? 1 : 0, g_trace ? g_trace + 16384 : nullptr,    \
+                       w.qi8, w.ti8, w.s_qi8, w.s_ti8, w.wq, w.wt, w.keys8, w.sttab8, w.s_keys8, nstr8, w.rb_last8, p8.n_rb1, p8.G)
     if (p.q4) SFM_LAUNCH_REFINE(true, reinterpret_cast<const unsigned short*>(w.tfrag), w.s_tfrag / 2);      // (stride in 16-bit elements)
     else SFM_LAUNCH_REFINE(false, p.split ? w.tsplit + (size_t)2 * p.tiles * kTileT * kDim : nullptr, w.s_tsplit);
 #undef SFM_LAUNCH_REFINE

@@ -69,10 +69,15 @@ def test_exact_ties_resolve_to_lower_index_via_fallback(hip, oracle):
         base = 32 * (k // 3)
         for r in (1, 9, 17, 25):
             t[base + r] = q[k]
-    gi, gd, stats = run(hip, q, t, stats=True)
+    # (these are u8 integers: 'auto' runs the exact-integer body, whose 16-row records hold all four twins — no fallback needed
+    # there; 'half' is the 16-bit filter this case was written for)
+    gi, gd, stats = run(hip, q, t, stats=True, filter="half")
     assert_bit_equal((gi, gd), oracle.knn2(q, t, nthreads=4))
     assert stats[0] >= 32                     # fallback exercised
     assert np.all(gd[::3, :] == 0) and np.all(gi[::3, 0] % 32 == 1) and np.all(gi[::3, 1] % 32 == 9)
+    gi8, gd8, stats8 = run(hip, q, t, stats=True)
+    assert stats8[3] == 4
+    assert_bit_equal((gi8, gd8), (gi, gd))
 
 
 def test_near_ties_below_filter_resolution(hip, oracle):
@@ -214,7 +219,9 @@ def test_filter_modes_all_agree_with_oracle(hip, oracle, name):
     q, t, expect_mode = _mode_cases()[name]
     want = oracle.knn2(q, t, nthreads=8)
     # the filter variant is a per-call argument (ABI 2): q4 kernel auto / split, fp32 MFMA, and round 2's LDS-ring kernel
-    for variant, mode in (("auto", expect_mode), ("split", 2), ("f32", 3), ("lds", expect_mode), ("lds_split", 2)):
+    # (ABI 2 + SFM_KNN_FILTER_HALF): 'auto' takes the exact-integer i8 body (mode 4) for u8-integer data, 'half' never does
+    auto_mode = 4 if name == "sift_integers" else expect_mode
+    for variant, mode in (("auto", auto_mode), ("half", expect_mode), ("split", 2), ("f32", 3), ("lds", expect_mode), ("lds_split", 2)):
         gi, gd, stats = run(hip, q, t, stats=True, filter=variant)
         assert stats[3] == mode, f"{name}/{variant}: filter mode {stats[3]}, expected {mode}"
         assert_bit_equal((gi, gd), want)
