@@ -381,7 +381,7 @@ def bench_knn(args, world, rank, dev):
         m = int(bm_s.count[0].item())
         got = dict(zip(bm_s.out_q[0, :m].cpu().tolist(), bm_s.out_t[0, :m].cpu().tolist()))
         out["sift_like"] = {"distances_per_sec": n_sets * pbatch * nq * nt / dt, "ms_per_pair": dt / (n_sets * pbatch) * 1e3,
-                            "filter_mode": {0: "fp16 single product (inputs exact in fp16)", 1: "fp16 single product", 2: "bf16 split"}.get(int(bm_s.stats[0, 3].item())),
+                            "filter_mode": {0: "fp16 single product (inputs exact in fp16)", 1: "fp16 single product", 2: "bf16 split", 4: "exact-integer i8 MFMA (v_mfma_i32_32x32x32_i8)"}.get(int(bm_s.stats[0, 3].item())),
                             "ratio_survivors": m, "planted_matches": int(len(planted)),
                             "planted_matches_among_survivors": int(sum(1 for a, b in planted.tolist() if got.get(a) == b)),
                             "note": "SIFT-like descriptors (SURVEY 8d (ii)), 30 % planted twins with N(0, 2) integer noise; survivors = Lowe ratio 0.70"}

@@ -52,6 +52,7 @@ constexpr int kResidentWaves = 4096;   // 256 CUs x 16 waves (4 per SIMD at <= 1
 constexpr int kMaxSlots = 258;         // cap on filter blocks that may touch one query row block (all 256 CUs on one)
 constexpr float kInf = __builtin_huge_valf();
 constexpr int kSubTilesHost = 64;      // = kSubTiles (tiles per substream), needed by make_plan before its definition
+constexpr int kI8SubTilesHost = 128;   // = kI8SubTiles (exact-integer body)
 
 // Work decomposition ("stream-K" over the flattened (query row block, train tile) unit space):
 // block b owns units [units*b/G, units*(b+1)/G).  Every block gets the same number of units (+-1),
@@ -227,7 +228,7 @@ Plan make_plan_uncached(int64_t nq, int64_t nt, int B, int filter) {
     p.force_mode = (filter == kFilterSplit || filter == kFilterLdsSplit) ? 2 /*kModeSplit*/ : -1;
     p.i8 = filter == kFilterAuto ? 1 : 0;
     const bool i8plan = filter == kFilterI8Plan;   // the partition of the i8 body: 8 query groups per wave, 1024-query row blocks
-    p.sub_tiles = i8plan ? 256 : kSubTilesHost;
+    p.sub_tiles = i8plan ? kI8SubTilesHost : kSubTilesHost;
     p.qg = i8plan ? 8 : p.q4 ? 4 : p.split ? 2 : 1;
     if (p.q4) p.waves = 4;                     // one 4-wave workgroup per CU: one wave per SIMD, 512 registers each
     else if (p.split && !(env_w == 4 || env_w == 8 || env_w == 16)) p.waves = p.qg == 2 ? 4 : 16;   // split2: two 4-wave workgroups per CU (their barrier stalls interleave; ~3 % over one 8-wave group)
@@ -656,10 +657,11 @@ __device__ __forceinline__ uint2 frag_init_operand(float x, bool query_side, int
 // (possible only when all-127 and all-0 / all-255 rows meet in one image) fall back to the fp16 body, as do non-u8 data.
 constexpr int kI8Groups = 8;                                // 32-query groups per wave
 constexpr int kI8Rows = 4 * kI8Groups * 32;                 // 1024 queries per workgroup (row block of the i8 partition)
-constexpr int kI8SubTiles = 256;                            // tiles per substream: the key's low 8 bits are the tile inside it
+constexpr int kI8SubTiles = 128;                            // tiles per substream: the key's low 8 bits are (tile inside it) << 1 | register half
 constexpr int kI8TileBytes = 5 * 1024;                      // train image per 32 rows: 4 k-steps of 32 ([64 lanes][16 B]) + the init fragment
 constexpr int kI8QTileBytes = 4 * 1024;                     // query image per 32 rows
 constexpr int kI8CMax = 508031, kI8CMin = -503936;          // range of the init product
+static_assert(kI8SubTiles == kI8SubTilesHost, "make_plan's copy");
 constexpr int kKeyEmptyI = 0x7FFFFF00;                      // i8 keys >= this are empty slots / the first tile's pretend "previous tile"
 
 // One pass over Q and T: rows → the fp16 image (Q pre-scaled by -2, exact), fp32 squared norms, per-block max of
@@ -1786,9 +1788,11 @@ __device__ __forceinline__ void filter_q4_body(
 //     a wave owns EIGHT 32-query groups (B fragments: 8 x 4 x 4 = 128 AGPRs), every train fragment (one 1 KiB load) feeds 8
 //     MFMAs — with 4 groups the four waves' fragment loads (20 KiB per tile through the CU's 64 B/clk L1 path) cost 34 of a
 //     tile-group's 128 pipe cycles (scripts/ubench/filter_i8.hip, profiles/r04_ubench_filter_i8_skeleton.txt);
-//   * a candidate record is all 16 accumulator registers of a lane — the 16 train rows 8 m + 4 h + i of a tile — so the
-//     epilogue is 8 min3 / min + 1 pack + 3 insert = 12 VALU per group and tile, THREE per MFMA gap (quads: six, more than a
-//     wave alone on its SIMD hides); the key's low 8 bits are the tile inside a 256-tile substream;
+//   * a candidate record is HALF of a lane's 16 accumulator registers — registers 8 e .. 8 e + 7 = the 8 train rows
+//     16 e + 8 (r >> 2) + 4 h + (r & 3) of a tile — so the epilogue is 2 x (4 min3 / min + 1 pack + 3 insert) = 16 VALU per group
+//     and tile, FOUR per MFMA gap (quads: six, more than a wave alone on its SIMD hides; whole-lane records: three, but the
+//     refine kernel then reads 16 rows per record — its L1 traffic doubled and it lost more than the filter gained);
+//     the key's low 8 bits are (tile inside a 128-tile substream) << 1 | e;
 //   * i32 accumulation: scores are exact (up to the parity bit, see the images' comment), keys hold the whole score
 //     (acc << 8 | tile), the accumulator init is one i8 MFMA per tile shared by the 8 groups (C operand of their first products);
 //   * records are the three packed keys per stream, stored transposed ([row block][stream][h][k][1024 queries]: every store
@@ -1914,20 +1918,20 @@ __device__ __forceinline__ void filter_i8_body(
 #pragma unroll
             for (int r = 0; r < 16; ++r) a[r] = 8 * (r >> 2) + 4 * h + (r & 3) >= nrem ? 0x7FFFFF : a[r];
         };
-        // one group's epilogue (12 VALU) in four pieces of three, one per MFMA gap of a k-step
-        int m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, key = 0;
-        auto epi = [&](int piece, i32x16& a, int seq, int& e0, int& e1, int& e2, bool partial) {
+        // one group's epilogue (16 VALU) in four pieces of four, one per MFMA gap of a k-step: the two 8-register records
+        int m0 = 0, m1 = 0, key = 0;
+        auto epi = [&](int piece, i32x16& a, int seq /*(tile in substream) << 1*/, int& e0, int& e1, int& e2, bool partial) {
             if (ABL & 2) { if (piece == 0) e0 = min(e0, a[0] + a[15]); return; }
             if (piece == 0 && partial) mask_tail(a);
-            if (piece == 0) { m0 = imin3(a[0], a[1], a[2]); m1 = imin3(a[3], a[4], a[5]); m2 = imin3(a[6], a[7], a[8]); }
-            else if (piece == 1) { m3 = imin3(a[9], a[10], a[11]); m4 = imin3(a[12], a[13], a[14]); m0 = imin3(m0, m1, a[15]); }
-            else if (piece == 2) { m0 = imin3(m0, m2, m3); m0 = min(m0, m4); key = key_pack_i8(m0, seq); }
-            else key_put(key, e0, e1, e2);
+            if (piece == 0) { m0 = imin3(a[0], a[1], a[2]); m1 = imin3(a[3], a[4], a[5]); m0 = imin3(m0, m1, a[6]); m0 = min(m0, a[7]); }
+            else if (piece == 1) { key = key_pack_i8(m0, seq); key_put(key, e0, e1, e2); }
+            else if (piece == 2) { m0 = imin3(a[8], a[9], a[10]); m1 = imin3(a[11], a[12], a[13]); m0 = imin3(m0, m1, a[14]); m0 = min(m0, a[15]); }
+            else { key = key_pack_i8(m0, seq | 1); key_put(key, e0, e1, e2); }
         };
         auto tile = [&](int t, auto slot_c) {
             constexpr int S = decltype(slot_c)::value;
             const bool more = t + D < t_end;
-            const int seq_prev = __builtin_amdgcn_readfirstlane(max((t - 1) - sub_t0, 0));
+            const int seq_prev = __builtin_amdgcn_readfirstlane(max((t - 1) - sub_t0, 0) << 1);
             const bool part_cur = nrem != 0 && t + 1 == tiles;      // (wave-uniform) t is the train image's last, partial tile; its second-half groups' epilogue is the tail's
             // ---- phase A: chains of groups 0 .. 3; k-step st carries the epilogue of group P + st (previous tile)
 #pragma unroll
@@ -1948,7 +1952,7 @@ __device__ __forceinline__ void filter_i8_body(
                 ++sub;
                 sub_t0 = t;
             }
-            const int seq_cur = __builtin_amdgcn_readfirstlane(t - sub_t0);
+            const int seq_cur = __builtin_amdgcn_readfirstlane((t - sub_t0) << 1);
             // ---- phase B: chains of groups 4 .. 7; epilogue of groups 0 .. 3 (this tile); the fragments die one by one and are
             // refilled for tile t + D; the NEXT tile's init MFMA two MFMAs after the last reader of the current values
             __builtin_amdgcn_sched_barrier(0);
@@ -1978,7 +1982,7 @@ __device__ __forceinline__ void filter_i8_body(
         // epilogue of the last tile's groups P .. NG-1 (the MFMAs that completed them were the last instructions issued)
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
         if (t_end > t_begin) {
-            const int seq = __builtin_amdgcn_readfirstlane((t_end - 1) - sub_t0);
+            const int seq = __builtin_amdgcn_readfirstlane(((t_end - 1) - sub_t0) << 1);
 #pragma unroll
             for (int g = P; g < NG; ++g)
 #pragma unroll
@@ -2190,7 +2194,8 @@ constexpr int kQualCap = 144;    // exact-evaluation list per query (a chunk of 
 
 // ---------------------------------------------------------------- refine, exact-integer body
 // Sixteen lanes per query as above, but everything is integer and every wave is on its own (no workgroup barrier):
-//   records   three packed keys (acc << 8 | tile-in-substream) per stream; a record = the 16 train rows 8 m + 4 h + i of a tile
+//   records   three packed keys (acc << 8 | tile-in-substream << 1 | e) per stream; a record = the 8 train rows
+//             16 e + 8 (r >> 2) + 4 h + (r & 3), r = 0 .. 7, of a tile (half of a lane's accumulator registers in the filter)
 //   select    a(2) = the second smallest record score; a row of the exact top-2 (ties and float32 square roots that collide
 //             included) sits in a record with score <= a(2) + 1:  two distinct rows with d^2 <= U = c_q - 128 + 2 (a(2) + base) + 1
 //             exist, so d2^2 <= U, and a row with d^2 <= d2^2 + 2 has acc <= a(2) + 1.5
@@ -2226,7 +2231,8 @@ __device__ __forceinline__ void refine_i8_body(
     const BatchPtrs& P, int B, int nq, int nt, int tiles, const int* __restrict__ minfo, const unsigned char* __restrict__ qi8, const unsigned char* __restrict__ ti8,
     int64_t s_qi8, int64_t s_ti8, const int* __restrict__ wq, const int* __restrict__ wt, int64_t s_qn, int64_t s_tn, const int* __restrict__ keys,
     const int* __restrict__ sttab, int64_t s_keys, int nstr, const int* __restrict__ rb_last8, int n_rb1, int G8, double ratio,
-    int* __restrict__ ratio_counts, int ratio_stride, unsigned char* __restrict__ qb /*LDS [kRefQ][128]*/, int* __restrict__ recl /*LDS [kRefQ][2 * kRecCapI8]*/) {
+    int* __restrict__ ratio_counts, int ratio_stride, unsigned char* __restrict__ qb /*LDS [kRefQ][128]*/, int* __restrict__ recl /*LDS [kRefQ][2 * kRecCapI8]*/,
+    int* __restrict__ scratch /*LDS [512]: the rescan's hand-over*/) {
     const int n_wg = (nq + kRefQ - 1) / kRefQ, n_tot = B * n_wg, wg_chunk = (n_tot + 7) >> 3;
     const int bidt = n_tot >= 64 ? (int)(blockIdx.x & 7) * wg_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     if (bidt >= n_tot) return;
@@ -2245,7 +2251,11 @@ __device__ __forceinline__ void refine_i8_body(
     const int* __restrict__ kq = keys + (int64_t)rbl * nstr * 6 * kI8Rows + qloc;      // slot c of this query: kq[c * kI8Rows]
     const int* __restrict__ stt = sttab + (int64_t)rb * nstr * 2;
     int* __restrict__ stats = P.stats[pb];
+#ifdef SFM_DEBUG_NREC
+    if (bid == 0 && threadIdx.x == 0 && stats) { stats[3] = 4; }
+#else
     if (bid == 0 && threadIdx.x == 0 && stats) { stats[1] = G8; stats[2] = 2 * nstr; stats[3] = 4; }
+#endif
 
     // the query's bytes -> LDS in element order (chunk 2 f + h of the fragment image = elements 32 f + 16 h .. + 15); wave-local
     if (sl < 8) *reinterpret_cast<uint4*>(qb + ql * kDim + 16 * sl) =
@@ -2288,9 +2298,10 @@ __device__ __forceinline__ void refine_i8_body(
     b.d[0] = b.d[1] = kInf; b.i[0] = b.i[1] = INT_MAX; b.s[0] = b.s[1] = INT_MAX;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    // one tile's 16 rows of half-wave h, a lane per row: exact d^2, inserted under (sqrtf, index)
-    auto eval_tile = [&](int tile, int hh, bool live) {
-        const int jr = 8 * (sl >> 2) + 4 * hh + (sl & 3);
+    // one row per lane: register r = sl & 7 of record (tile, half-wave hh, register half e) -> exact d^2, inserted under (sqrtf, index)
+    auto eval_row = [&](int tile, int hh, int e, bool live, int qslot, int cqv, Best2I& acc2) {
+        const int r = sl & 7;
+        const int jr = 16 * e + 8 * (r >> 2) + 4 * hh + (r & 3);
         const int row = tile * kTileT + jr;
         const unsigned char* tp = ti8 + (int64_t)tile * kI8TileBytes + (jr << 4);
         uint4 tv[8];
@@ -2300,14 +2311,14 @@ __device__ __forceinline__ void refine_i8_body(
         int s0 = 0, s1 = 0;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            const uint4 qv = *reinterpret_cast<const uint4*>(qb + ql * kDim + 16 * c);
+            const uint4 qv = *reinterpret_cast<const uint4*>(qb + qslot * kDim + 16 * c);
             s0 = __builtin_amdgcn_sdot4((int)tv[c].x, (int)qv.x, s0, false);
             s1 = __builtin_amdgcn_sdot4((int)tv[c].y, (int)qv.y, s1, false);
             s0 = __builtin_amdgcn_sdot4((int)tv[c].z, (int)qv.z, s0, false);
             s1 = __builtin_amdgcn_sdot4((int)tv[c].w, (int)qv.w, s1, false);
         }
-        const int d2 = cq + w + 2 * (s0 + s1);
-        if (live && row < nt) best2i_insert_unique(b, sqrtf((float)d2), row, d2);
+        const int d2 = cqv + w + 2 * (s0 + s1);
+        if (live && row < nt) best2i_insert_unique(acc2, sqrtf((float)d2), row, d2);
     };
     auto row_scan = [&](int v, int& total) {
         v += __builtin_amdgcn_update_dpp(0, v, 0x111 /*row_shr:1*/, 0xF, 0xF, true);
@@ -2328,11 +2339,12 @@ __device__ __forceinline__ void refine_i8_body(
         __builtin_amdgcn_wave_barrier();
         const int nmax = wave_max(nrec);
 #pragma unroll 1
-        for (int e = 0; e < nmax; ++e) {
+        for (int e0 = 0; e0 < nmax; e0 += 2) {                   // two 8-row records per pass: lanes 0-7 / 8-15 of the query
+            const int e = e0 + (sl >> 3);
             const bool live = e < nrec;
             const int key = live ? myrec[2 * e] : 0, c = live ? myrec[2 * e + 1] : 0;
-            const int tile = min(stt[2 * (c / 6)] + (key & 0xFF), tiles - 1);      // (idle lanes: slot 0 -> a real tile, result unused)
-            eval_tile(tile, (c / 3) & 1, live);
+            const int tile = min(stt[2 * (c / 6)] + ((key & 0xFF) >> 1), tiles - 1);      // (idle lanes: slot 0 -> a real tile, result unused)
+            eval_row(tile, (c / 3) & 1, key & 1, live, ql, cq, b);
         }
         __builtin_amdgcn_wave_barrier();
         nrec = 0;
@@ -2377,6 +2389,9 @@ __device__ __forceinline__ void refine_i8_body(
         if (take) { myrec[2 * (nrec + at)] = x; myrec[2 * (nrec + at) + 1] = c; }
         nrec += total;
     }
+#ifdef SFM_DEBUG_NREC
+    if (sl == 0 && stats && valid) { atomicAdd(stats + 1, nrec); atomicAdd(stats + 2, NC); }
+#endif
     process();
     auto reduce16 = [&]() {
         best2i_exchange_step<8>(b);
@@ -2385,20 +2400,54 @@ __device__ __forceinline__ void refine_i8_body(
         best2i_exchange_step<1>(b);
     };
     reduce16();
-    // certificate (all-integer); rescans are wave-local: the query's 16 lanes walk the uncertified streams' tiles
+    // certificate (all-integer)
     const long long lim = b.i[1] != INT_MAX ? (long long)b.s[1] + 2 : LLONG_MAX;
-    auto hides = [&](int key3) {                                 // could the stream behind this third key hide a row that matters?
-        return key3 < kKeyEmptyI && (long long)cq + 2 * ((long long)(key3 >> 8) + base) <= lim;
-    };
-    const bool open = valid && hides(atau);
-    if (open) {
-        for (int c3 = 2; c3 < NC; c3 += 3) {
-            const int key3 = kq[(int64_t)c3 * kI8Rows];
-            if (!hides(key3)) continue;
-            const int t0 = stt[2 * (c3 / 6)], len = stt[2 * (c3 / 6) + 1];
-            for (int tt = 0; tt < len; ++tt) eval_tile(t0 + tt, (c3 / 3) & 1, true);
+    const bool open = valid && atau < kKeyEmptyI && (long long)cq + 2 * ((long long)(atau >> 8) + base) <= lim;
+    // Rescan (rare: exact ties / a third record within 2 of the second neighbour): the WORKGROUP works for one open query at a
+    // time — its 256 lanes take sixteen tiles of an uncertified stream per trip.  (A lone query's 16 lanes walking 128 tiles one
+    // by one, a dependent load round trip each, was the kernel's tail: 48 us for one query in 10^4.)  Everything before this
+    // point is wave-local; this barrier is the kernel's only one.
+    if (__syncthreads_or(open ? 1 : 0)) {
+        // scratch: [0 .. 15] open flag, [16 ..] per query {cq, lim lo, lim hi, qloc}, [128 ..] the waves' partial results
+        if (sl == 0) {
+            scratch[ql] = open ? 1 : 0;
+            scratch[16 + 4 * ql + 0] = cq;
+            scratch[16 + 4 * ql + 1] = (int)(unsigned)lim;
+            scratch[16 + 4 * ql + 2] = (int)(lim >> 32);
+            scratch[16 + 4 * ql + 3] = qloc;
         }
-        reduce16();
+        __syncthreads();
+        for (int w = 0; w < kRefQ; ++w) {                          // (uniform)
+            if (!scratch[w]) continue;
+            const int cq_w = scratch[16 + 4 * w];
+            const long long lim_w = (long long)(((unsigned long long)(unsigned)scratch[16 + 4 * w + 2] << 32) | (unsigned)scratch[16 + 4 * w + 1]);
+            const int* __restrict__ kw = kq + (scratch[16 + 4 * w + 3] - qloc);      // the open query's key column
+            Best2I pbst;
+            pbst.d[0] = pbst.d[1] = kInf; pbst.i[0] = pbst.i[1] = INT_MAX; pbst.s[0] = pbst.s[1] = INT_MAX;
+            for (int c3 = 2; c3 < NC; c3 += 3) {
+                const int key3 = kw[(int64_t)c3 * kI8Rows];         // (uniform)
+                if (!(key3 < kKeyEmptyI && (long long)cq_w + 2 * ((long long)(key3 >> 8) + base) <= lim_w)) continue;
+                const int t0 = stt[2 * (c3 / 6)], len = stt[2 * (c3 / 6) + 1];
+                for (int tt = ql; tt < len; tt += kRefQ) eval_row(t0 + tt, (c3 / 3) & 1, sl >> 3, true, w, cq_w, pbst);   // a tile's 16 rows of this half-wave per 16 lanes
+            }
+            best2i_exchange_step<32>(pbst);
+            best2i_exchange_step<16>(pbst);
+            if (sub == 0) {                                        // lanes 0 .. 15 of every wave: the wave's partial for lane sl
+                int* o = scratch + 128 + (wave * 16 + sl) * 6;
+                o[0] = __float_as_int(pbst.d[0]); o[1] = pbst.i[0]; o[2] = pbst.s[0];
+                o[3] = __float_as_int(pbst.d[1]); o[4] = pbst.i[1]; o[5] = pbst.s[1];
+            }
+            __syncthreads();
+            if (ql == w) {                                         // the owner merges (rows evaluated twice are skipped by index)
+                for (int x = 0; x < 4; ++x) {
+                    const int* o = scratch + 128 + (x * 16 + sl) * 6;
+                    best2i_insert_unique(b, __int_as_float(o[0]), o[1], o[2]);
+                    best2i_insert_unique(b, __int_as_float(o[3]), o[4], o[5]);
+                }
+            }
+            __syncthreads();
+        }
+        if (__ballot(open)) reduce16();
     }
 
     int* __restrict__ idx_out = P.idx[pb];
@@ -2413,7 +2462,7 @@ __device__ __forceinline__ void refine_i8_body(
         const bool pass = valid && sl == 0 && b.i[1] != INT_MAX && (double)b.d[0] < ratio * (double)b.d[1];
         if (ratio_mask && valid && sl == 0) ratio_mask[q] = pass ? 1 : 0;
         const int n = __popcll(__ballot(pass));
-        if (lane == 0 && n) atomicAdd(ratio_counts + (bid * kRefQ) / kRatioBlock, n);
+        if (lane == 0) ratio_counts[bid * 4 + wave] = n;           // one plain store per wave (see kRatioSub)
     }
 }
 
@@ -2479,7 +2528,8 @@ __global__ __launch_bounds__(256, 4) void knn_refine_kernel(
     if constexpr (FRAG)
     if (qi8 && minfo && minfo[kMinfoI8]) {                 // (uniform) the exact-integer body ran: its records, its certificate
         refine_i8_body(P, B, nq, nt, tiles, minfo, qi8, ti8, s_qi8, s_ti8, wq8, wt8, s_qn, s_tn, keys8, sttab8, s_keys8, nstr8, rb_last8, n_rb1_8, G8, ratio,
-                       ratio_counts, ratio_stride, reinterpret_cast<unsigned char*>(&qrows[0][0]), &rec[0][0]);
+                       ratio_counts, ratio_stride, reinterpret_cast<unsigned char*>(&qrows[0][0]), &rec[0][0], items);
+        static_assert(kRefItems >= 128 + 64 * 6, "the i8 body's rescan scratch");
         return;
     }
     if (trace && threadIdx.x == 0) trace[16 * bidt + 0] = wall_clock64();   // dev diagnostics
@@ -2979,12 +3029,14 @@ __global__ __launch_bounds__(256, 4) void knn_refine_kernel(
         if (rescanned && stats) atomicAdd(stats, 1);
     }
     if (ratio_counts) {
-        // fused sfm_match_l2_f32: the Lowe test of sfm.py:264 here, survivors counted per 1024-query block (integer
-        // atomics: order-independent), so the match list needs the ordered scatter pass only
+        // fused sfm_match_l2_f32: the Lowe test of sfm.py:264 here, survivors counted per WAVE (4 queries) with one plain
+        // store each, so the match list needs the ordered scatter pass only.  (Round 3 added them to one counter per 1024
+        // queries with atomics: on data with survivors — 30 % of the queries of a SIFT-like pair — the ~14 000 atomics of a batch
+        // landed on half a dozen cache lines and took 45 us, more than the rest of the kernel.)
         const bool pass = valid && sl == 0 && b.i[1] != INT_MAX && (double)b.d[0] < ratio * (double)b.d[1];
         if (ratio_mask && valid && sl == 0) ratio_mask[qo] = pass ? 1 : 0;
         const int n = __popcll(__ballot(pass));
-        if (lane == 0 && n) atomicAdd(ratio_counts + (bid * kRefQ) / kRatioBlock, n);
+        if (lane == 0) ratio_counts[bid * 4 + (threadIdx.x >> 6)] = n;
     }
     if (trace && threadIdx.x == 0) {
         trace[16 * bidt + 4] = wall_clock64();
@@ -3035,16 +3087,17 @@ __global__ __launch_bounds__(256) void ratio_count_kernel(const int* __restrict_
     if (threadIdx.x == 0) block_count[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
+constexpr int kRatioSub = 4 * (kRatioBlock / kRefQ);     // survivor counts per 1024 queries when the refine kernel wrote them: one per wave (4 queries)
 __device__ __forceinline__ void ratio_scatter_body(const int* __restrict__ idx, const float* __restrict__ dist, int nq,
                                                    double ratio, const int* __restrict__ block_count,
                                                    int* __restrict__ out_q, int* __restrict__ out_t,
-                                                   int* __restrict__ out_count) {
+                                                   int* __restrict__ out_count, int per_block = 1) {
     __shared__ int wsum[4];
     __shared__ int base_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // exclusive prefix of the preceding workgroups' counts
     int part = 0;
-    for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) part += block_count[b];
+    for (int b = threadIdx.x; b < (int)blockIdx.x * per_block; b += 256) part += block_count[b];
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) part += __shfl_xor(part, m, 64);
     if (lane == 0) wsum[wave] = part;
@@ -3090,7 +3143,7 @@ __global__ __launch_bounds__(256) void ratio_scatter_kernel(const int* __restric
 __global__ __launch_bounds__(256) void ratio_scatter_batch_kernel(BatchPtrs P, int nq, double ratio, const int* __restrict__ block_count,
                                                                   int count_stride) {
     const int pb = blockIdx.y;
-    ratio_scatter_body(P.idx[pb], P.dist[pb], nq, ratio, block_count + pb * count_stride, P.out_q[pb], P.out_t[pb], P.out_count[pb]);
+    ratio_scatter_body(P.idx[pb], P.dist[pb], nq, ratio, block_count + pb * count_stride, P.out_q[pb], P.out_t[pb], P.out_count[pb], kRatioSub);
 }
 
 __global__ __launch_bounds__(256) void gather_matches_kernel(const float2* __restrict__ kp0, const float2* __restrict__ kp1,
@@ -3398,14 +3451,13 @@ size_t knn_ws_bytes(int64_t nq, int64_t nt, int dim, int B, int filter) {
 }
 
 size_t ratio_ws_bytes(int64_t nq, int B) {
-    return sfm::align_up((size_t)B * (size_t)((nq + kRatioBlock - 1) / kRatioBlock + 1) * sizeof(int), 256) + 256;
+    return sfm::align_up((size_t)B * (size_t)((nq + kRatioBlock - 1) / kRatioBlock * kRatioSub + 1) * sizeof(int), 256) + 256;
 }
 
 // KNN of B equally shaped pairs in ONE set of launches (prep, filter, refine), optionally fused with the Lowe-ratio
 // survivor count (ratio_counts != null: ratio_stride ints per pair, one per 1024 queries).
 int knn_batch_impl(int B, const BatchPtrs& P, int64_t nq, int64_t ldq, int64_t nt, int64_t ldt, int dim, int filter, void* ws, size_t ws_bytes,
                    void* stream_, double ratio, int* ratio_counts, int ratio_stride) {
-    const int ratio_blocks = ratio_counts ? (int)((nq + kRatioBlock - 1) / kRatioBlock) : 0;
     SFM_CHECK_ARG(dim == kDim, "sfm_knn2_l2_f32: dim must be 128 (got %d)", dim);
     SFM_CHECK_ARG(B >= 1 && B <= kMaxBatch, "sfm_match_batch_l2_f32: 1 <= batch <= %d (got %d)", kMaxBatch, B);
     SFM_CHECK_ARG(filter_ok(filter), "sfm_knn2_l2_f32: filter must be 0 (auto), 1 (fp32 MFMA), 2 (bf16 split pinned), 3 / 4 (LDS-ring kernel, auto / split), 5 (16-bit only) (got %d)", filter);
@@ -3446,7 +3498,7 @@ int knn_batch_impl(int B, const BatchPtrs& P, int64_t nq, int64_t ldq, int64_t n
         hipLaunchKernelGGL(knn_prep_kernel, dim3(kNormBlocks + 2, (unsigned)B), dim3(kPrepThreads), 0, stream, P, ldq, (int)nq, p.nq_pad, ldt, (int)nt,
                            p.tiles * kTileT, w.qsplit, w.qn, w.tsplit, w.tn, w.bmax, w.midflag, w.qerr, w.bmaxerr, w.bqmax, w.s_qsplit, w.s_tsplit, w.s_qn, w.s_tn,
                            p.q4 ? w.qfrag : nullptr, w.tfrag, w.s_qfrag, w.s_tfrag,
-                           ratio_counts, ratio_counts ? ratio_stride : 0,
+                           ratio_counts, 0 /*(the refine kernel writes every count: nothing to zero)*/,
                            p.units, p.tiles, p.G, p.seg_cost, p.n_rb, w.wg_begin, w.rb_first, w.rb_last, p.q4 ? w.wg_sbase : nullptr,
                            w.qi8, w.ti8, w.s_qi8, w.s_ti8, w.wq, w.wt, w.bwmin, w.bwmax, p8.units, p8.G, p8.n_rb, w.wg_begin8, w.rb_first8, w.rb_last8,
                            w.wg_sbase8);
@@ -3486,7 +3538,7 @@ int knn_batch_impl(int B, const BatchPtrs& P, int64_t nq, int64_t ldq, int64_t n
     const float* q = P.q[0];
     const float* t = P.t[0];
     hipLaunchKernelGGL(knn_norms_kernel, dim3(kNormBlocks + 1), dim3(256), 0, stream, t, ldt, (int)nt, w.tn, w.bmax,
-                       P.stats[0], ratio_counts, ratio_blocks, p.units, p.tiles, p.G, p.seg_cost, p.n_rb, w.wg_begin, w.rb_first, w.rb_last);
+                       P.stats[0], ratio_counts, 0, p.units, p.tiles, p.G, p.seg_cost, p.n_rb, w.wg_begin, w.rb_first, w.rb_last);
     SFM_CHECK_LAUNCH();
     sfm::prof_begin(sfm::kProfKnnFilter, stream);
 #define SFM_LAUNCH_FILTER(A, WV)                                                                                     \
@@ -3618,7 +3670,7 @@ int match_batch_impl(int B, const BatchPtrs& P, int64_t nq, int64_t ldq, int64_t
     }
     int* counts = reinterpret_cast<int*>(sfm::align_up((size_t)(uintptr_t)ws, 256));
     const unsigned blocks = (unsigned)((nq + kRatioBlock - 1) / kRatioBlock);
-    const int stride = (int)blocks + 1;
+    const int stride = (int)blocks * kRatioSub + 1;            // per-wave survivor counts, written (every one of them) by the refine kernel
     const int rc = knn_batch_impl(B, P, nq, ldq, nt, ldt, dim, filter, static_cast<char*>(ws) + rbytes, ws_bytes - rbytes, stream_, ratio, counts, stride);
     if (rc != SFM_OK) return rc;
     hipLaunchKernelGGL(ratio_scatter_batch_kernel, dim3(blocks, (unsigned)B), dim3(256), 0, stream, P, (int)nq, ratio, counts, stride);
