@@ -35,6 +35,8 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf16, dense (no sparsity)
+I8_MFMA_PEAK_TOPS = 5000.0        # dense int8 MFMA (v_mfma_i32_32x32x32_i8: 2x the bf16 rate; the guide measured 4 404 TOPS for 32x32)
+F16_MFMA_SUSTAINED_TFLOPS, I8_MFMA_SUSTAINED_TOPS = 1691.0, 3619.0   # pure MFMA stream on RANDOM operands, measured: profiles/r04_mfma_ceiling.md
 PROF_SAMPLES = 6                   # profiled steps, run alone AFTER the timed region
 PIPE_DEPTH = 3                     # launch sets in flight (one stream + workspace each)
 N_SETS = 2                         # sets of PAIR_BATCH distinct image pairs rotating over the steps
@@ -316,9 +318,13 @@ def bench_knn(args, world, rank, dev):
                    "parallelism": f"pair-sharded x{world}" + (f" + one RCCL all-gather of the match records per {EXCH_BATCH} pairs" if world > 1 else "")
                                   + f"; independent pairs issued {pbatch} per launch set (sfm_match_batch_l2_f32), {depth} launch sets in flight per GPU (one HIP stream each)",
                    "pairs_per_launch": pbatch,
+                   "cold_value": world * pbatch * nq * nt * args.steps / cold_elapsed, "cold_ms_per_step": cold_elapsed / args.steps * 1e3,
+                   "cold_note": "`value` is the sustained rate; cold_value = the same K steps after 0.5 s of idle, before the clock ramp",
                    "setup": f"streams and kernels loaded, then {CLOCK_WARMUP_STEPS} untimed steps of the same workload (~60 ms: the device reaches its sustained clock) before the W warm-up steps"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                     "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "frac_of_sustained": achieved / F16_MFMA_SUSTAINED_TFLOPS,
+                     "sustained_note": "a pure fp16 MFMA stream on random operands holds 1 691 TFLOP/s on this part (clock 1.66 GHz: power-limited), profiles/r04_mfma_ceiling.md",
+                     "traffic": traffic,
                      "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_note,
                      "algorithmic_bytes_per_launch": pbatch * (4 * 128 * (nq + nt) + 16 * nq),
                      "kernel": "knn_filter_q4_kernel<0>", "avg_launch_ms": filt_avg_ms, "launches": filt_n, "pairs_per_launch": pbatch,
@@ -366,25 +372,61 @@ def bench_knn(args, world, rank, dev):
         # the filter takes its exact single-product path.  Same pipeline, untimed w.r.t. the headline value.
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from datagen import planted_pair
-        qs_h, ts_h, planted = planted_pair(np.random.default_rng(0), nq, nt, 0.3)
-        qs, ts = torch.from_numpy(qs_h).to(dev), torch.from_numpy(ts_h).to(dev)
-        for _ in range(6 * pbatch):
-            pipe.submit(qs, ts, after=False)
-        pipe.flush(); pipe.synchronize()
-        n_sets = 40
+        # DISTINCT pairs here too: N_SETS launch sets of `pbatch` different planted pairs rotate over the steps.  Integer 0..255
+        # data: filter="auto" takes the exact-integer body (v_mfma_i32_32x32x32_i8, stats[3] = 4) — the reference's real data
+        # (cv2 SIFT output, sfm.py:246-252) — so this leg carries its own roofline against the i8 peak.
+        rng_s = np.random.default_rng(0)
+        sets_s, planted0 = [], None
+        for s_ in range(N_SETS):
+            cur = []
+            for b_ in range(pbatch):
+                qh_, th_, pl_ = planted_pair(rng_s, nq, nt, 0.3)
+                if planted0 is None:
+                    planted0 = pl_
+                cur.append((torch.from_numpy(qh_).to(dev), torch.from_numpy(th_).to(dev)))
+            sets_s.append(cur)
+
+        def run_sets(n):
+            for i in range(n):
+                for qb, tb in sets_s[i % N_SETS]:
+                    pipe.submit(qb, tb, after=False)
+            pipe.flush(); pipe.synchronize()
+        run_sets(CLOCK_WARMUP_STEPS // 2)                      # (the device is at its sustained clock already; kernels of this mode loaded)
+        n_sets = 60
         t0 = time.perf_counter()
-        for _ in range(n_sets * pbatch):
-            pipe.submit(qs, ts, after=False)
-        pipe.flush(); pipe.synchronize()
+        run_sets(n_sets)
         dt = time.perf_counter() - t0
+        ops.profile_read(0), ops.profile_read(1)
+        for i in range(PROF_SAMPLES):
+            ops.profile_enable(PROF_REPEAT)
+            pipe.matchers[0].run(sets_s[i % N_SETS])
+            ops.profile_enable(False)
+            torch.cuda.synchronize()
+        f8_ms, f8_n = ops.profile_read(0)
+        r8_ms, r8_n = ops.profile_read(1)
+        f8_avg = f8_ms / max(f8_n, 1)
         bm_s = pipe.matchers[0]
+        bm_s.run(sets_s[0]); torch.cuda.synchronize()
         m = int(bm_s.count[0].item())
         got = dict(zip(bm_s.out_q[0, :m].cpu().tolist(), bm_s.out_t[0, :m].cpu().tolist()))
-        out["sift_like"] = {"distances_per_sec": n_sets * pbatch * nq * nt / dt, "ms_per_pair": dt / (n_sets * pbatch) * 1e3,
-                            "filter_mode": {0: "fp16 single product (inputs exact in fp16)", 1: "fp16 single product", 2: "bf16 split", 4: "exact-integer i8 MFMA (v_mfma_i32_32x32x32_i8)"}.get(int(bm_s.stats[0, 3].item())),
-                            "ratio_survivors": m, "planted_matches": int(len(planted)),
-                            "planted_matches_among_survivors": int(sum(1 for a, b in planted.tolist() if got.get(a) == b)),
-                            "note": "SIFT-like descriptors (SURVEY 8d (ii)), 30 % planted twins with N(0, 2) integer noise; survivors = Lowe ratio 0.70"}
+        mode_s = int(bm_s.stats[0, 3].item())
+        ach8 = algo_flop / (f8_avg * 1e-3) / 1e12
+        peak8 = I8_MFMA_PEAK_TOPS if mode_s == 4 else BF16_MFMA_PEAK_TFLOPS
+        out["sift_like"] = {"distances_per_sec": n_sets * pbatch * nq * nt / dt, "ms_per_pair": dt / (n_sets * pbatch) * 1e3, "ms_per_step": dt / n_sets * 1e3,
+                            "filter_mode": {0: "fp16 single product (inputs exact in fp16)", 1: "fp16 single product", 2: "bf16 split",
+                                            4: "exact-integer i8 MFMA (v_mfma_i32_32x32x32_i8, i32 scores)"}.get(mode_s),
+                            "distinct_pairs_per_launch_set": pbatch, "image_sets": N_SETS,
+                            "roofline": {"bound": "mfma", "achieved": ach8, "peak": peak8, "unit": "TOP/s" if mode_s == 4 else "TFLOP/s", "frac": ach8 / peak8,
+                                         "frac_of_sustained": ach8 / (I8_MFMA_SUSTAINED_TOPS if mode_s == 4 else F16_MFMA_SUSTAINED_TFLOPS),
+                                         "sustained_note": "a pure MFMA stream on random operands holds 3 619 TOPS (i8) / 1 691 TFLOP/s (fp16) on this part: the clock drops to 1.66-1.78 GHz (profiles/r04_mfma_ceiling.md)",
+                                         "kernel": "knn_filter_q4_kernel<0> (filter_i8_body)" if mode_s == 4 else "knn_filter_q4_kernel<0>",
+                                         "avg_launch_ms": f8_avg, "launches": f8_n, "pairs_per_launch": pbatch, "algorithmic_flop_per_launch": algo_flop, "traffic": None,
+                                         "note": "algorithmic = 256 integer ops per distance (SURVEY 8d, GEMM form 2 D); peak = dense int8 MFMA (MI355X_MICROARCH.md: ~5 P dense, 4 404 TOPS measured for 32x32)"},
+                            "kernels_ms": {"knn_filter": f8_avg, "knn_refine": r8_ms / max(r8_n, 1)},
+                            "rescanned_queries_pair0": int(bm_s.stats[0, 0].item()),
+                            "ratio_survivors": m, "planted_matches": int(len(planted0)),
+                            "planted_matches_among_survivors": int(sum(1 for a, b in planted0.tolist() if got.get(a) == b)),
+                            "note": "SIFT-like descriptors (SURVEY 8d (ii)), 30 % planted twins with N(0, 2) integer noise; survivors = Lowe ratio 0.70; same pipeline as the headline value"}
         # boundary handing over HOST buffers: pinned H2D of both descriptor sets + the step + D2H of the results
         qh, th = q.cpu().pin_memory(), t.cpu().pin_memory()
         qd, td = torch.empty_like(q), torch.empty_like(t)

@@ -580,7 +580,7 @@ __device__ __forceinline__ unsigned bf16_rn_bits(float x) {
 //                   range, which the matrix pipe may flush) — the refine kernel's slack (kEpsHalf*) covers it.
 //   kModeSplit      anything else (huge / tiny magnitudes): bf16 hi+mid split, three products, full fp32 range.
 constexpr int kModeHalfExact = 0, kModeHalf = 1, kModeSplit = 2;
-constexpr int kFlagHalfInexact = 2, kFlagRangeBad = 4, kFlagNotU8 = 8;   // (NotU8: some value is not an integer 0 .. 255)
+constexpr int kFlagHalfInexact = 2, kFlagRangeBad = 4, kFlagNotU8 = 8, kFlagSomeU8 = 16;   // (NotU8: some value is not an integer 0 .. 255; SomeU8: some chunk of a real row exists in the byte image only)
 
 // Lane exchanges without an address register: lane ^ M by DPP quad_perm (M = 1, 2) or ds_swizzle bit mode
 // (M = 4, 8, 16); __shfl_xor compiles to ds_bpermute and keeps one address VGPR alive per distinct pattern.
@@ -689,6 +689,8 @@ __global__ __launch_bounds__(kPrepThreads) void knn_prep_kernel(BatchPtrs P, int
                                                        unsigned char* __restrict__ qi8, unsigned char* __restrict__ ti8, int64_t s_qi8, int64_t s_ti8,
                                                        int* __restrict__ wq /*[s_qn] per pair: |q - 128|^2*/, int* __restrict__ wt /*[s_tn] per pair: |t - 127|^2*/,
                                                        int* __restrict__ bwmin /*[kNormBlocks] per pair*/, int* __restrict__ bwmax,
+                                                       unsigned short* __restrict__ rmq /*[s_qn] per pair: chunks of a row that exist in the byte image only*/,
+                                                       unsigned short* __restrict__ rmt /*[s_tn]*/,
                                                        int64_t units8, int G8, int n_rb8, int64_t* __restrict__ wg_begin8,
                                                        int* __restrict__ rb_first8, int* __restrict__ rb_last8, int* __restrict__ wg_sbase8) {
     constexpr int kPrepWaves = kPrepThreads / 64, kPrepRows = kPrepThreads / 16;
@@ -702,7 +704,7 @@ __global__ __launch_bounds__(kPrepThreads) void knn_prep_kernel(BatchPtrs P, int
         return;
     }
     const bool do8 = qi8 != nullptr;
-    if (do8) { qi8 += pb * s_qi8; ti8 += pb * s_ti8; wq += pb * s_qn; wt += pb * s_tn; bwmin += pb * kNormBlocks; bwmax += pb * kNormBlocks; }
+    if (do8) { qi8 += pb * s_qi8; ti8 += pb * s_ti8; wq += pb * s_qn; wt += pb * s_tn; bwmin += pb * kNormBlocks; bwmax += pb * kNormBlocks; rmq += pb * s_qn; rmt += pb * s_tn; }
     int w8min = INT_MAX, w8max = INT_MIN;
     const float* __restrict__ Q = P.q[pb];
     const float* __restrict__ T = P.t[pb];
@@ -755,26 +757,56 @@ __global__ __launch_bounds__(kPrepThreads) void knn_prep_kernel(BatchPtrs P, int
         float s = ((in[0] * in[0] + in[1] * in[1]) + (in[2] * in[2] + in[3] * in[3])) + ((in[4] * in[4] + in[5] * in[5]) + (in[6] * in[6] + in[7] * in[7]));
         s += lane_xor<8>(s); s += lane_xor<4>(s); s += lane_xor<2>(s); s += lane_xor<1>(s);
         const float sc = isq ? -2.f : 1.f;
-        unsigned fb[8];
+        const bool real = r < n;
+        // Which image does this lane's chunk (8 elements) need?  u8 integers -> the byte image of the exact-integer body (8 B);
+        // anything else -> the fp16 image (16 B).  Only that one is written: u8 data costs 2.8 MB of image per 10k x 10k pair
+        // instead of 8.1, float data 5.3.  A batch that mixes both kinds runs the 16-bit bodies and needs the fp16 image of its
+        // u8 chunks after all: knn_split_images_kernel converts those from the byte image (`rowmask`: one bit per chunk of a row).
+        // Rows past the end are zero in BOTH images.
+        bool chunk8 = false;
+        unsigned lo = 0u, hi = 0u;
+        if (do8) {
+            // saturating conversion; "every value an integer 0 .. 255" = the conversion was exact (-0 counts as 0; NaN / inf /
+            // fractions / out-of-range values leave a nonzero difference)
+            // (float data: the first element of a chunk settles it for the whole wave — three instructions instead of thirty)
+            lo = __builtin_amdgcn_cvt_pk_u8_f32(in[0], 0, 0u);
+            if (__any(((__float_as_uint(in[0] - (float)(lo & 0xFFu))) & 0x7FFFFFFFu) == 0u)) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (e) lo = __builtin_amdgcn_cvt_pk_u8_f32(in[e], e, lo);
+                    hi = __builtin_amdgcn_cvt_pk_u8_f32(in[4 + e], e, hi);
+                }
+                unsigned nu = 0u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    nu |= __float_as_uint(in[e] - (float)((lo >> (8 * e)) & 0xFFu));
+                    nu |= __float_as_uint(in[4 + e] - (float)((hi >> (8 * e)) & 0xFFu));
+                }
+                chunk8 = (nu & 0x7FFFFFFFu) == 0u;
+            }
+            if (!chunk8) flags |= kFlagNotU8;
+            else if (real) flags |= kFlagSomeU8;
+        }
         float err2 = 0.f;                                                // ||fp16(row) - row||^2: the certificate's operand-rounding term
+        const float nrm = (isq || real) ? s : kInf;                      // padded train rows can never be candidates
+        if (!__all(chunk8 && real)) {                                    // (wave-uniform: four rows of all-u8 chunks skip the 16-bit work)
+        unsigned fw[4] = {0u, 0u, 0u, 0u};                               // the eight fp16 values, packed as they are made
         // The per-element tests — range (also NaN / inf), fp16-exactness, below fp16's normal range — are folded over the
         // lane's eight elements on bit patterns (the kernel is bound by its vector-ALU instruction count, not by the bytes):
         //   amax = max |e| bits;   umin = min (|e| bits - 1)  (0 wraps to 0xFFFFFFFF: "nonzero and below 2^-14" is ONE unsigned
         //   compare);   dor = OR of the residuals' bits (any bit but the sign: inexact)
         unsigned amax = 0u, umin = 0xFFFFFFFFu, dor = 0u;
-        float evs[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float ev = sc * in[e];
             const _Float16 hv = (_Float16)ev;                            // round to nearest even
-            fb[e] = (unsigned)__builtin_bit_cast(unsigned short, hv);
+            fw[e >> 1] |= (unsigned)__builtin_bit_cast(unsigned short, hv) << (16 * (e & 1));
             const float dv = ev - (float)hv;
             err2 = fmaf(dv, dv, err2);
             const unsigned ab = __float_as_uint(ev) & 0x7FFFFFFFu;
             amax = max(amax, ab);
             umin = min(umin, ab - 1u);
             dor |= __float_as_uint(dv);
-            evs[e] = ev;
         }
         if (amax > 0x476A6000u /*60000.f*/) flags |= kFlagRangeBad;      // (NaN and inf patterns are larger still)
         const bool has_sub = umin < 0x38800000u - 1u;                     // some element is nonzero and below 2^-14
@@ -785,48 +817,36 @@ __global__ __launch_bounds__(kPrepThreads) void knn_prep_kernel(BatchPtrs P, int
             err2 = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float ev = evs[e];
-                const float dv = fabsf(ev) < 6.103515625e-5f ? ev : ev - (float)__builtin_bit_cast(_Float16, (unsigned short)fb[e]);
+                const float ev = sc * in[e];
+                const float dv = fabsf(ev) < 6.103515625e-5f ? ev : ev - (float)__builtin_bit_cast(_Float16, (unsigned short)(fw[e >> 1] >> (16 * (e & 1))));
                 err2 = fmaf(dv, dv, err2);
             }
         }
         err2 += lane_xor<8>(err2); err2 += lane_xor<4>(err2); err2 += lane_xor<2>(err2); err2 += lane_xor<1>(err2);
         if (!(err2 < kInf)) err2 = 0.f;                                  // (out-of-range data: the split arithmetic runs, this term is unused)
-        const uint4 packed = make_uint4(fb[0] | (fb[1] << 16), fb[2] | (fb[3] << 16), fb[4] | (fb[5] << 16), fb[6] | (fb[7] << 16));
-        const float nrm = (isq || r < n) ? s : kInf;                     // padded train rows can never be candidates
+        const uint4 packed = make_uint4(fw[0], fw[1], fw[2], fw[3]);
         if (frag) {
             // FRAGMENT ORDER (knn_filter_q4_kernel): [32-row tile][9 fragments][64 lanes][16 B]; fragment f < 8 is k-step f of
             // v_mfma_f32_32x32x16_f16 (lane 32 h + j holds elements 16 f + 8 h .. + 7 of row j of the tile: chunk c = 2 f + h),
             // then the 512-byte accumulator-init fragment (frag_init_operand: 8 B per lane)
-            unsigned char* fimg = (isq ? qfrag : tfrag) + (int64_t)(r >> 5) * kTileFragBytes;
-            *reinterpret_cast<uint4*>(fimg + (((c >> 1) * 64 + (c & 1) * 32 + (r & 31)) << 4)) = packed;
-            // (train image only: the query side of the init product is the same for every query of the pair — ||q||^2max,
-            // see knn_filter_q4_kernel — and is formed by the filter itself)
-            if (c < 2 && !isq) *reinterpret_cast<uint2*>(fimg + 8 * kFragBytes + ((c * 32 + (r & 31)) << 3)) = frag_init_operand(nrm, false, c);
+            if (!(chunk8 && real))
+                *reinterpret_cast<uint4*>((isq ? qfrag : tfrag) + (int64_t)(r >> 5) * kTileFragBytes + (((c >> 1) * 64 + (c & 1) * 32 + (r & 31)) << 4)) = packed;
         } else {
             *reinterpret_cast<uint4*>((isq ? qsplit : tsplit) + (2 * (int64_t)npad + r) * kDim + 8 * c) = packed;   // row-major fp16 plane (LDS-ring filter, its refine screens)
         }
+        }
+        // (train image only: the query side of the init product is the same for every query of the pair — ||q||^2max, see
+        // knn_filter_q4_kernel — and is formed by the filter itself)
+        if (frag && c < 2 && !isq) *reinterpret_cast<uint2*>(tfrag + (int64_t)(r >> 5) * kTileFragBytes + 8 * kFragBytes + ((c * 32 + (r & 31)) << 3)) = frag_init_operand(nrm, false, c);
         if (c == 0) (isq ? qn : tn)[r] = nrm;
         if (do8) {
-            // the byte image of the exact-integer body: saturating conversion, then "is every value an integer 0 .. 255" = the
-            // conversion was exact (-0 counts as 0; NaN / inf / fractions / out-of-range leave a nonzero difference)
-            unsigned lo = 0u, hi = 0u;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                lo = __builtin_amdgcn_cvt_pk_u8_f32(in[e], e, lo);
-                hi = __builtin_amdgcn_cvt_pk_u8_f32(in[4 + e], e, hi);
-            }
-            unsigned nu = 0u;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                nu |= __float_as_uint(in[e] - (float)((lo >> (8 * e)) & 0xFFu));
-                nu |= __float_as_uint(in[4 + e] - (float)((hi >> (8 * e)) & 0xFFu));
-            }
-            if ((nu & 0x7FFFFFFFu) != 0u) flags |= kFlagNotU8;
+            const unsigned long long m8 = __ballot(chunk8 && real);      // bit 16 k + c: chunk c of the wave's row k is in the byte image only
+            if (c == 0) (isq ? rmq : rmt)[r] = (unsigned short)(m8 >> (threadIdx.x & 48));
+        }
+        if (do8 && __any(chunk8)) {
             const unsigned flip = isq ? 0x7F7F7F7Fu : 0x80808080u;      // b = 127 - q,  a = t - 128
-            const bool real = r < n;
-            const unsigned x0 = real ? lo ^ flip : 0u, x1 = real ? hi ^ flip : 0u;   // rows past the end: zero bytes (a padded train row scores C_max + 0)
-            // sum (x + 1)^2 over the row = |t - 127|^2 resp. |q - 128|^2
+            const unsigned x0 = real ? lo ^ flip : 0u, x1 = real ? hi ^ flip : 0u;   // rows past the end: zero bytes (masked in the filter: they never make a key)
+            // sum (x + 1)^2 over the row = |t - 127|^2 resp. |q - 128|^2 (meaningful only if the whole row is u8: otherwise the pair never runs the integer body)
             int w8 = __builtin_amdgcn_sdot4((int)x0, (int)x0, 8, false);
             w8 = __builtin_amdgcn_sdot4((int)x1, (int)x1, w8, false);
             w8 = __builtin_amdgcn_sdot4((int)x0, 0x02020202, w8, false);
@@ -834,8 +854,10 @@ __global__ __launch_bounds__(kPrepThreads) void knn_prep_kernel(BatchPtrs P, int
             w8 += lane_xor<8>(w8); w8 += lane_xor<4>(w8); w8 += lane_xor<2>(w8); w8 += lane_xor<1>(w8);
             // fragment order: [32-row tile][k-step f = element / 32][lane 32 h + row % 32][16 B], h = (element / 16) & 1; this lane's
             // eight elements 8 c .. 8 c + 7 are half of the chunk of lane 32 ((c >> 1) & 1) + row % 32 in fragment c >> 2
-            unsigned char* img = isq ? qi8 + (int64_t)(r >> 5) * kI8QTileBytes : ti8 + (int64_t)(r >> 5) * kI8TileBytes;
-            *reinterpret_cast<uint2*>(img + (c >> 2) * 1024 + ((((c >> 1) & 1) * 32 + (r & 31)) << 4) + ((c & 1) << 3)) = make_uint2(x0, x1);
+            if (chunk8) {
+                unsigned char* img = isq ? qi8 + (int64_t)(r >> 5) * kI8QTileBytes : ti8 + (int64_t)(r >> 5) * kI8TileBytes;
+                *reinterpret_cast<uint2*>(img + (c >> 2) * 1024 + ((((c >> 1) & 1) * 32 + (r & 31)) << 4) + ((c & 1) << 3)) = make_uint2(x0, x1);
+            }
             if (c == 0) (isq ? wq : wt)[r] = w8;
             if (!isq && real) { w8min = min(w8min, w8); w8max = max(w8max, w8); }
         }
@@ -856,7 +878,7 @@ __global__ __launch_bounds__(kPrepThreads) void knn_prep_kernel(BatchPtrs P, int
     }
     int wfl = 0;
 #pragma unroll
-    for (int b = 1; b <= 8; b <<= 1) wfl |= __any((flags & b) != 0) ? b : 0;
+    for (int b = 1; b <= 16; b <<= 1) wfl |= __any((flags & b) != 0) ? b : 0;
     __shared__ float wmaxe[kPrepWaves], wmaxq[kPrepWaves];
     __shared__ int w8lo[kPrepWaves], w8hi[kPrepWaves];
     if (do8) {
@@ -927,12 +949,16 @@ __global__ __launch_bounds__(kSplitThreads) void knn_split_images_kernel(BatchPt
                                                                         const float* __restrict__ bmaxerr, const float* __restrict__ bqmax, int* __restrict__ minfo,
                                                                         // exact-integer body (ti8 == null: not planned)
                                                                         unsigned char* __restrict__ ti8, int64_t s_ti8, const int* __restrict__ wt, int64_t s_tn,
-                                                                        const int* __restrict__ bwmin, const int* __restrict__ bwmax) {
+                                                                        const int* __restrict__ bwmin, const int* __restrict__ bwmax,
+                                                                        // ... and what the repair of a mixed batch needs (see below)
+                                                                        const unsigned char* __restrict__ qi8, int64_t s_qi8, int64_t s_qn,
+                                                                        const unsigned short* __restrict__ rmq, const unsigned short* __restrict__ rmt,
+                                                                        unsigned char* __restrict__ qfrag, unsigned char* __restrict__ tfrag, int64_t s_qfrag, int64_t s_tfrag) {
     // The batch's arithmetic mode, reduced ONCE for the launch set: wave b of every workgroup reduces pair b's 2 x 256 flag
     // words (the eight pairs in parallel: one round trip; as a loop over the pairs inside every filter workgroup this was
     // 8-10 us of dependent loads at the head of the filter launch), workgroup 0 leaves the result — per pair the mode,
     // ||t||max and the largest fp16 residual, and the batch's mode — in `minfo` for the filter and refine kernels.
-    __shared__ int smode[kMaxBatch], s8ok[kMaxBatch], s8base[kMaxBatch];
+    __shared__ int smode[kMaxBatch], s8ok[kMaxBatch], s8base[kMaxBatch], s8some[kMaxBatch];
     {
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
         static_assert(kSplitThreads / 64 >= kMaxBatch, "one wave per pair");
@@ -944,7 +970,9 @@ __global__ __launch_bounds__(kSplitThreads) void knn_split_images_kernel(BatchPt
                 const int* fl = midflag + wave * kNormBlocks;
                 const int* lo = bwmin + wave * kNormBlocks;
                 const int* hi = bwmax + wave * kNormBlocks;
-                const bool u8 = !__any(((fl[lane] | fl[lane + 64] | fl[lane + 128] | fl[lane + 192]) & kFlagNotU8) != 0);
+                const int fl4 = fl[lane] | fl[lane + 64] | fl[lane + 128] | fl[lane + 192];
+                const bool u8 = !__any((fl4 & kFlagNotU8) != 0);
+                const bool some = __any((fl4 & kFlagSomeU8) != 0);
                 int wl = min(min(lo[lane], lo[lane + 64]), min(lo[lane + 128], lo[lane + 192]));
                 int wh = max(max(hi[lane], hi[lane + 64]), max(hi[lane + 128], hi[lane + 192]));
 #pragma unroll
@@ -957,6 +985,7 @@ __global__ __launch_bounds__(kSplitThreads) void knn_split_images_kernel(BatchPt
                 if (lane == 0) {
                     s8ok[wave] = (u8 && wl <= wh && ch - base <= kI8CMax && cl - base >= kI8CMin) ? 1 : 0;
                     s8base[wave] = base;
+                    s8some[wave] = some ? 1 : 0;
                 }
             }
             const float* be = bmaxerr + wave * kNormBlocks;
@@ -992,16 +1021,48 @@ __global__ __launch_bounds__(kSplitThreads) void knn_split_images_kernel(BatchPt
         else if (threadIdx.x < B && ti8) minfo[kMinfoBase + threadIdx.x] = s8base[threadIdx.x];
     }
     if (i8) {
-        for (int pb = 0; pb < B; ++pb) {
-            const int base = s8base[pb];
-            const int* __restrict__ w = wt + pb * s_tn;
-            unsigned char* __restrict__ img = ti8 + pb * s_ti8;
-            for (int e = blockIdx.x * kSplitThreads + threadIdx.x; e < 2 * nt_pad; e += gridDim.x * kSplitThreads) {
-                const int r = e >> 1, h = e & 1;
-                *reinterpret_cast<uint4*>(img + (int64_t)(r >> 5) * kI8TileBytes + 4 * 1024 + ((h * 32 + (r & 31)) << 4)) = frag_init_i8(r < nt ? (w[r] >> 1) - base : kI8CMax, h);
-            }
+        // one flat loop over (pair, row, half-wave): every load of the launch is in flight at once (a loop over the pairs was a
+        // dependent round trip per pair: 9 us for a batch of 8)
+        const int per_pair = 2 * nt_pad;
+        for (int e = blockIdx.x * kSplitThreads + threadIdx.x; e < B * per_pair; e += gridDim.x * kSplitThreads) {
+            const int pb = e / per_pair, x = e - pb * per_pair;
+            const int r = x >> 1, h = x & 1;
+            const int wv = r < nt ? wt[pb * s_tn + r] : 0;
+            *reinterpret_cast<uint4*>(ti8 + pb * s_ti8 + (int64_t)(r >> 5) * kI8TileBytes + 4 * 1024 + ((h * 32 + (r & 31)) << 4)) =
+                frag_init_i8(r < nt ? (wv >> 1) - s8base[pb] : kI8CMax, h);
         }
         return;
+    }
+    if (ti8) {
+        // A 16-bit body runs although the integer body was planned: chunks the prep pass found to be u8 integers exist in the
+        // byte image only (rmq / rmt: one bit per 8-element chunk of a row).  Convert them: t = a ^ 0x80, q = b ^ 0x7F are exact in
+        // fp16, and so is -2 q.  Nothing to do for pure float data (no such chunk: one flag word per pair says so).
+        bool some = false;
+        for (int b = 0; b < B; ++b) some = some || s8some[b] != 0;
+        if (some) {
+            const int rows = nq_pad + nt_pad;
+            for (int64_t e = (int64_t)blockIdx.x * kSplitThreads + threadIdx.x; e < (int64_t)B * rows * 16; e += (int64_t)gridDim.x * kSplitThreads) {
+                const int c = (int)(e & 15);
+                const int64_t rr = e >> 4;
+                const int pb = (int)(rr / rows), row = (int)(rr - (int64_t)pb * rows);
+                const bool isq = row < nq_pad;
+                const int r = isq ? row : row - nq_pad;
+                const unsigned m = isq ? rmq[pb * s_qn + r] : rmt[pb * s_tn + r];
+                if (!((m >> c) & 1u)) continue;
+                const unsigned char* src = (isq ? qi8 + pb * s_qi8 + (int64_t)(r >> 5) * kI8QTileBytes : ti8 + pb * s_ti8 + (int64_t)(r >> 5) * kI8TileBytes) +
+                                           (c >> 2) * 1024 + ((((c >> 1) & 1) * 32 + (r & 31)) << 4) + ((c & 1) << 3);
+                const uint2 x = *reinterpret_cast<const uint2*>(src);
+                unsigned fb[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const unsigned byte = ((k < 4 ? x.x : x.y) >> (8 * (k & 3))) & 0xFFu;
+                    const float v = isq ? -2.f * (float)(byte ^ 0x7Fu) : (float)(byte ^ 0x80u);
+                    fb[k] = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)v);
+                }
+                unsigned char* dst = (isq ? qfrag + pb * s_qfrag : tfrag + pb * s_tfrag) + (int64_t)(r >> 5) * kTileFragBytes + (((c >> 1) * 64 + (c & 1) * 32 + (r & 31)) << 4);
+                *reinterpret_cast<uint4*>(dst) = make_uint4(fb[0] | (fb[1] << 16), fb[2] | (fb[3] << 16), fb[4] | (fb[5] << 16), fb[6] | (fb[7] << 16));
+            }
+        }
     }
     if (force_mode >= 0) mode = force_mode;
     if (mode != kModeSplit) return;
@@ -1918,15 +1979,16 @@ __device__ __forceinline__ void filter_i8_body(
 #pragma unroll
             for (int r = 0; r < 16; ++r) a[r] = 8 * (r >> 2) + 4 * h + (r & 3) >= nrem ? 0x7FFFFF : a[r];
         };
-        // one group's epilogue (16 VALU) in four pieces of four, one per MFMA gap of a k-step: the two 8-register records
-        int m0 = 0, m1 = 0, key = 0;
+        // one group's epilogue (16 VALU) in four pieces, one per MFMA gap of a k-step.  The two 8-register records' min trees are
+        // interleaved (a wave alone on its SIMD stalls on every dependent vector-ALU pair: independent neighbours fill the slots)
+        int m0 = 0, m1 = 0, n0 = 0, n1 = 0, key = 0, key2 = 0;
         auto epi = [&](int piece, i32x16& a, int seq /*(tile in substream) << 1*/, int& e0, int& e1, int& e2, bool partial) {
             if (ABL & 2) { if (piece == 0) e0 = min(e0, a[0] + a[15]); return; }
             if (piece == 0 && partial) mask_tail(a);
-            if (piece == 0) { m0 = imin3(a[0], a[1], a[2]); m1 = imin3(a[3], a[4], a[5]); m0 = imin3(m0, m1, a[6]); m0 = min(m0, a[7]); }
-            else if (piece == 1) { key = key_pack_i8(m0, seq); key_put(key, e0, e1, e2); }
-            else if (piece == 2) { m0 = imin3(a[8], a[9], a[10]); m1 = imin3(a[11], a[12], a[13]); m0 = imin3(m0, m1, a[14]); m0 = min(m0, a[15]); }
-            else { key = key_pack_i8(m0, seq | 1); key_put(key, e0, e1, e2); }
+            if (piece == 0) { m0 = imin3(a[0], a[1], a[2]); n0 = imin3(a[8], a[9], a[10]); m1 = imin3(a[3], a[4], a[5]); n1 = imin3(a[11], a[12], a[13]); }
+            else if (piece == 1) { m0 = imin3(m0, m1, a[6]); n0 = imin3(n0, n1, a[14]); m0 = min(m0, a[7]); n0 = min(n0, a[15]); }
+            else if (piece == 2) { key = key_pack_i8(m0, seq); key2 = key_pack_i8(n0, seq | 1); key_put(key, e0, e1, e2); }
+            else key_put(key2, e0, e1, e2);
         };
         auto tile = [&](int t, auto slot_c) {
             constexpr int S = decltype(slot_c)::value;
@@ -3198,6 +3260,8 @@ struct KnnWs {
     int* wt;                      // [B][s_tn]  |t - 127|^2
     int* bwmin;                   // [B][kNormBlocks] per-block min / max of wt over the real train rows
     int* bwmax;
+    unsigned short* rmq;          // [B][s_qn] / [B][s_tn]: bit c = chunk c (8 elements) of the row exists in the byte image only
+    unsigned short* rmt;
     int* keys8;                   // [B][row blocks][stream slots][2][3][1024] packed keys
     int* sttab8;                  // [row blocks of the batch][stream slots][2]: first tile, tile count of a stream
     int64_t* wg_begin8;
@@ -3252,6 +3316,8 @@ KnnWs carve_ws(void* ws, int64_t nq, int64_t nt, const Plan& p, const Plan* p8) 
         w.wt = c.take<int>(B * (size_t)w.s_tn);
         w.bwmin = c.take<int>(B * kNormBlocks);
         w.bwmax = c.take<int>(B * kNormBlocks);
+        w.rmq = c.take<unsigned short>(B * (size_t)w.s_qn);
+        w.rmt = c.take<unsigned short>(B * (size_t)w.s_tn);
         w.keys8 = c.take<int>(B * (size_t)w.s_keys8);
         w.sttab8 = c.take<int>((size_t)p8->n_rb * p8->smax * p8->nsub * 2);
         w.wg_begin8 = c.take<int64_t>((size_t)p8->G + 1);
@@ -3500,12 +3566,13 @@ int knn_batch_impl(int B, const BatchPtrs& P, int64_t nq, int64_t ldq, int64_t n
                            p.q4 ? w.qfrag : nullptr, w.tfrag, w.s_qfrag, w.s_tfrag,
                            ratio_counts, 0 /*(the refine kernel writes every count: nothing to zero)*/,
                            p.units, p.tiles, p.G, p.seg_cost, p.n_rb, w.wg_begin, w.rb_first, w.rb_last, p.q4 ? w.wg_sbase : nullptr,
-                           w.qi8, w.ti8, w.s_qi8, w.s_ti8, w.wq, w.wt, w.bwmin, w.bwmax, p8.units, p8.G, p8.n_rb, w.wg_begin8, w.rb_first8, w.rb_last8,
-                           w.wg_sbase8);
+                           w.qi8, w.ti8, w.s_qi8, w.s_ti8, w.wq, w.wt, w.bwmin, w.bwmax, w.rmq, w.rmt, p8.units, p8.G, p8.n_rb, w.wg_begin8, w.rb_first8,
+                           w.rb_last8, w.wg_sbase8);
         SFM_CHECK_LAUNCH();
         hipLaunchKernelGGL(knn_split_images_kernel, dim3(kNormBlocks), dim3(kSplitThreads), 0, stream, P, B, ldq, (int)nq, p.nq_pad, ldt, (int)nt,
                            p.tiles * kTileT, w.qsplit, w.tsplit, w.s_qsplit, w.s_tsplit, w.midflag, w.bmax, p.force_mode,
-                           p.q4 ? w.qhm : nullptr, w.thm, w.s_qhm, w.s_thm, w.bmaxerr, w.bqmax, w.minfo, w.ti8, w.s_ti8, w.wt, w.s_tn, w.bwmin, w.bwmax);
+                           p.q4 ? w.qhm : nullptr, w.thm, w.s_qhm, w.s_thm, w.bmaxerr, w.bqmax, w.minfo, w.ti8, w.s_ti8, w.wt, w.s_tn, w.bwmin, w.bwmax,
+                           w.qi8, w.s_qi8, w.s_qn, w.rmq, w.rmt, w.qfrag, w.tfrag, w.s_qfrag, w.s_tfrag);
         SFM_CHECK_LAUNCH();
         sfm::prof_begin(sfm::kProfKnnFilter, stream);
 #define SFM_LAUNCH_SPLIT2(A, WV)                                                                                        \
