@@ -314,6 +314,9 @@ int sfm_ba_schur_solve(const double* cams_dev, int64_t ncam, const double* K_hos
  *                      order; b_dev may be NULL (norm of a).  out_dev: one double (device).
  * ---------------------------------------------------------------------- */
 int sfm_block_inverse(const double* A_dev, int64_t n, int k, double* Ainv_dev, void* stream);
+/* ... with a device status word: *bad_count_dev = number of blocks whose Gauss-Jordan met a zero or non-finite pivot (their
+ * inverse is non-finite); the caller decides (sfm_mvs_amd.ops.block_inverse raises unless told otherwise). */
+int sfm_block_inverse_checked(const double* A_dev, int64_t n, int k, double* Ainv_dev, int32_t* bad_count_dev, void* stream);
 int sfm_block_matvec(const double* A_dev, const double* x_dev, int64_t n, int k, double* y_dev, void* stream);
 size_t sfm_norm_l2_ws_bytes(void);
 int sfm_norm_l2(const void* a_dev, const void* b_dev, int64_t n, int is_f64, double* out_dev,

@@ -1,4 +1,5 @@
 """Dev: distribution of |inverse-iteration vector - Jacobi vector| and of its estimate `sens` (triangulate.hip), per geometry."""
+# (needs a dev build of the library: make -C sfm_mvs_amd/csrc CXXFLAGS+=-DSFM_DEV_BUILD — release builds reject normalise_w = 4 and ignore SFM_TRI_*)
 import sys, numpy as np, torch
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 from sfm_mvs_amd import ops

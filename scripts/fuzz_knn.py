@@ -13,8 +13,13 @@ vectors, mixed magnitudes) and a second group aimed at the margins of the exactn
   fp16edge   values on fp16 rounding midpoints, at the top of its range (~6e4) and around its smallest normals (6.1e-5)
   normspread query norms spread over 10^3 inside one pair (the q4 filter's scores carry the pair's LARGEST ||q||^2 and its slack is
              relative to that: small-norm queries of such a pair rescan more, and must stay exact)
+and a third group of u8-integer data — what cv2 SIFT emits and what filter="auto" sends through the exact-integer i8 body:
+  u8_uniform arbitrary bytes (ranges 2 .. 256);  u8_ties  trains one or two units apart (parity bit, exact ties inside a record);
+  u8_far     d^2 in (2^22, 2^23): float32 square roots of neighbouring integers collide;  u8_extreme  rows at the ends of the init
+  product's range (all-0 / all-127 / all-255 / four saturated bins: some pairs fall back to the 16-bit body);  u8_dups  duplicates.
+Batches mix the families: a u8 pair next to a float pair exercises the conversion of byte-image chunks to fp16 (mixed batch).
 Most cases are small (the oracle dominates the wall time); one in eight is large, `big` adds 20k-70k train rows.
-The log ends with the sha256 of csrc/knn.hip: profiles/r03_fuzz_knn_*.log are checked against the tree by tests/test_gpu_knn.py.
+The log ends with the sha256 of csrc/knn.hip: profiles/r04_fuzz_knn_*.log are checked against the tree by tests/test_gpu_knn.py.
 """
 import hashlib
 import os
@@ -106,6 +111,52 @@ def make(kind, nq, nt):
         else:              # around fp16's smallest normals (6.1e-5): the matrix pipe may flush what is below
             base = rng.uniform(2e-5, 2.5e-4, (nq + nt, 128)) * rng.choice([1.0, -1.0], (nq + nt, 128)) + (rng.random((nq + nt, 128)) < 0.02) * 0.7
         return base[:nq].astype(f32), base[nq:].astype(f32)
+    # ---- u8 integers: the exact-integer body (v_mfma_i32_32x32x32_i8; filter="auto" picks it on the device) and its margins
+    if kind == "u8_uniform":
+        hi_q, hi_t = int(rng.choice([2, 16, 120, 256])), int(rng.choice([2, 16, 120, 256]))
+        return rng.integers(0, hi_q, (nq, 128)).astype(f32), rng.integers(0, hi_t, (nt, 128)).astype(f32)
+    if kind == "u8_ties":
+        # trains = one base row with a few +-1 tweaks: squared distances to any query differ by 0, 1, 2, ... (the filter's
+        # accumulator holds floor(score / 2): the parity bit and exact ties are the refine kernel's), many per 8-row record
+        base = sift_like(rng, 1)[0] if rng.random() < 0.5 else rng.integers(0, 256, 128).astype(f32)
+        t = np.tile(base, (nt, 1))
+        for r in range(nt):
+            cols = rng.choice(128, int(rng.integers(0, 4)), replace=False)
+            t[r, cols] = np.clip(t[r, cols] + rng.choice([-1.0, 1.0], len(cols)), 0, 255)
+        q = np.clip(np.tile(base, (nq, 1)) + np.rint(rng.normal(0, rng.choice([0.0, 1.0, 20.0]), (nq, 128))), 0, 255).astype(f32)
+        return q, t.astype(f32)
+    if kind == "u8_far":
+        # queries near 0, trains near 255: d^2 in (2^22, 2^23), where two consecutive integers can share a float32 square root and
+        # the reference's float compare (ties -> lower index) decides
+        v = int(rng.integers(182, 256))
+        t = np.full((nt, 128), float(v), f32)
+        k = int(rng.integers(1, 4))
+        t[:, :k] = rng.integers(0, 3, (nt, k)).astype(f32)
+        q = np.zeros((nq, 128), f32)
+        q[:, 100:] = rng.integers(0, 2, (nq, 28)).astype(f32)
+        return q, t
+    if kind == "u8_extreme":
+        # rows at the ends of the init product's range: all-zero, all-127, all-255, four saturated bins; with both ends present
+        # the pair falls back to the 16-bit body (stats[3] = 0) — results must not change
+        q, t = sift_like(rng, nq), sift_like(rng, nt)
+        for arr in (q, t):
+            for r in rng.integers(0, len(arr), max(1, len(arr) // 50)):
+                pick = rng.integers(0, 5)
+                if pick == 0: arr[r] = 0.0
+                elif pick == 1: arr[r] = 255.0 if rng.random() < 0.5 else 254.0
+                elif pick == 2: arr[r] = 127.0
+                elif pick == 3:
+                    arr[r] = 0.0
+                    arr[r, rng.choice(128, 4, replace=False)] = 255.0
+                else: arr[r] = float(rng.integers(0, 256))
+        if rng.random() < 0.5:
+            t[t == 127.0] = 126.0                                 # (keep floor(w / 2) inside the range: the integer body runs)
+        return q, t
+    if kind == "u8_dups":
+        base = sift_like(rng, max(1, nt // 9))
+        t = np.tile(base, (10, 1))[:nt]
+        q = np.clip(base[rng.integers(0, len(base), nq)] + np.rint(rng.normal(0, 1.0, (nq, 128))), 0, 255).astype(f32)
+        return q, t.astype(f32)
     if kind == "normspread":
         q = rng.random((nq, 128)) * 10.0 ** rng.uniform(-1.5, 1.5, (nq, 1))
         t = rng.random((nt, 128)) * 10.0 ** rng.uniform(-1.5, 1.5, (nt, 1))
@@ -114,8 +165,9 @@ def make(kind, nq, nt):
 
 
 kinds = ["uniform", "normal_scaled", "sift", "planted", "duplicates", "near_ties", "unit", "mixed_magnitude",
-         "cancel", "tie23", "pow2", "fp16edge", "normspread", "tie23", "cancel"]
-variants = ["auto"] * 6 + ["split", "f32", "lds", "lds_split", "split"]
+         "cancel", "tie23", "pow2", "fp16edge", "normspread", "tie23", "cancel",
+         "u8_uniform", "u8_ties", "u8_far", "u8_extreme", "u8_dups", "planted", "u8_ties"]
+variants = ["auto"] * 7 + ["half", "split", "f32", "lds", "lds_split", "half"]
 t_start = time.time()
 t_end = t_start + budget
 cases = fails = batched = 0
@@ -140,7 +192,7 @@ while time.time() < t_end:
         nt = int(rng.choice([1, 2, 31, 33, 512, 1023, 2049]) if rng.random() < 0.4 else rng.integers(1, 2600))
     if big and cases % 24 == 5:
         nq, nt = int(rng.integers(1, 700)), int(rng.integers(20000, 70000))
-    if kind in ("duplicates", "near_ties"):
+    if kind in ("duplicates", "near_ties", "u8_dups", "u8_ties", "u8_far"):
         nq, nt = min(nq, 600), min(nt, 3000)             # every stream is rescanned: keep the exact work bounded
     q, t = make(kind, nq, nt)
     nq, nt = len(q), len(t)

@@ -2,6 +2,11 @@
 
 The HIP library is the ONLY implementation of the hot path: if it is missing or a call
 fails this module raises — there is no CPU or PyTorch fallback.
+
+One piece of host-only GLUE exists beside it and is not a fallback of a kernel: `pipeline.common_points` keeps the
+reference's NumPy definition (sfm.py:215-239) for callers WITHOUT a GPU (file tooling, the CPU test of the golden vectors
+the reference's own function produced); with a GPU present the same function runs `sfm_common_points` on the device, and
+the driver (`pipeline.run_sfm`) only ever uses the device operator.  It never touches the oracle.
 """
 import ctypes
 import os
@@ -52,6 +57,7 @@ SIGNATURES = {
     "sfm_ba_schur_indexed_ws_bytes": (_sz, [_i64]),
     "sfm_ba_schur_indexed": (_int, [_vp, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _int, _vp, _vp, _vp, _sz, _vp]),
     "sfm_block_inverse": (_int, [_vp, _i64, _int, _vp, _vp]),
+    "sfm_block_inverse_checked": (_int, [_vp, _i64, _int, _vp, _vp, _vp]),
     "sfm_block_matvec": (_int, [_vp, _vp, _i64, _int, _vp, _vp]),
     "sfm_norm_l2_ws_bytes": (_sz, []),
     "sfm_norm_l2": (_int, [_vp, _vp, _i64, _int, _vp, _vp, _sz, _vp]),

@@ -11,10 +11,12 @@
 namespace {
 
 template <int K>
-__global__ __launch_bounds__(256) void block_inverse_kernel(const double* __restrict__ A, int64_t n, double* __restrict__ out) {
+__global__ __launch_bounds__(256) void block_inverse_kernel(const double* __restrict__ A, int64_t n, double* __restrict__ out,
+                                                            int* __restrict__ bad /*optional: number of singular / non-finite blocks*/) {
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i >= n) return;
     double a[K][K], b[K][K];
+    bool singular = false;
 #pragma unroll
     for (int r = 0; r < K; ++r)
 #pragma unroll
@@ -37,6 +39,9 @@ __global__ __launch_bounds__(256) void block_inverse_kernel(const double* __rest
                 b[r][c] = sw ? tb : b[r][c];
             }
         }
+        // a zero or non-finite pivot (after partial pivoting: the block is singular, or holds inf / NaN) is REPORTED: the
+        // inverse of that block comes out non-finite as before, and the status word lets the caller refuse it
+        singular = singular || !(fabs(a[col][col]) > 0.0) || !(fabs(a[col][col]) < __builtin_huge_val());
         const double d = 1.0 / a[col][col];
 #pragma unroll
         for (int c = 0; c < K; ++c) {
@@ -58,6 +63,7 @@ __global__ __launch_bounds__(256) void block_inverse_kernel(const double* __rest
     for (int r = 0; r < K; ++r)
 #pragma unroll
         for (int c = 0; c < K; ++c) out[i * K * K + r * K + c] = b[r][c];
+    if (bad && singular) atomicAdd(bad, 1);                       // (rare path: integer count, order-independent)
 }
 
 template <int K>
@@ -103,17 +109,22 @@ __global__ void norm_final_kernel(const double* __restrict__ partial, int blocks
 
 }  // namespace
 
-extern "C" int sfm_block_inverse(const double* A, int64_t n, int k, double* Ainv, void* stream_) {
+extern "C" int sfm_block_inverse_checked(const double* A, int64_t n, int k, double* Ainv, int32_t* bad_count_dev, void* stream_) {
     SFM_CHECK_ARG(n >= 0 && (k == 3 || k == 6), "sfm_block_inverse: k must be 3 or 6 (got %d)", k);
+    if (bad_count_dev) SFM_CHECK_HIP(hipMemsetAsync(bad_count_dev, 0, sizeof(int32_t), sfm::as_stream(stream_)));
     if (n == 0) return SFM_OK;
     SFM_CHECK_ARG(A && Ainv, "sfm_block_inverse: null pointer");
     const dim3 grid((unsigned)((n + 255) / 256));
     if (k == 3)
-        hipLaunchKernelGGL(block_inverse_kernel<3>, grid, dim3(256), 0, sfm::as_stream(stream_), A, n, Ainv);
+        hipLaunchKernelGGL(block_inverse_kernel<3>, grid, dim3(256), 0, sfm::as_stream(stream_), A, n, Ainv, bad_count_dev);
     else
-        hipLaunchKernelGGL(block_inverse_kernel<6>, grid, dim3(256), 0, sfm::as_stream(stream_), A, n, Ainv);
+        hipLaunchKernelGGL(block_inverse_kernel<6>, grid, dim3(256), 0, sfm::as_stream(stream_), A, n, Ainv, bad_count_dev);
     SFM_CHECK_LAUNCH();
     return SFM_OK;
+}
+
+extern "C" int sfm_block_inverse(const double* A, int64_t n, int k, double* Ainv, void* stream_) {
+    return sfm_block_inverse_checked(A, n, k, Ainv, nullptr, stream_);
 }
 
 extern "C" int sfm_block_matvec(const double* A, const double* x, int64_t n, int k, double* y, void* stream_) {

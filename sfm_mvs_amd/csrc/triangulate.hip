@@ -293,7 +293,8 @@ __global__ __launch_bounds__(256) void triangulate_kernel(ProjPair P, const floa
     if constexpr (M == 4) {
         double sens = 0;
         if (normalise_w >= 2) have = dlt_nullvec_fast(At, Xd, &sens);
-        if (normalise_w == 4) {      // dev calibration: X4[0] = max |fast - jacobi| over the components (sign-aligned), X4[1] = sens
+#ifdef SFM_DEV_BUILD
+        if (normalise_w == 4) {      // dev calibration (scripts/dev/dev_tri_calib.py; not in release builds): X4[0] = max |fast - jacobi| over the components (sign-aligned), X4[1] = sens
             double Xj[4];
             dlt_nullvec<M>(At, Xj);
             const double sg = (Xj[0] * Xd[0] + Xj[1] * Xd[1] + Xj[2] * Xd[2] + Xj[3] * Xd[3]) < 0 ? -1.0 : 1.0;
@@ -306,6 +307,7 @@ __global__ __launch_bounds__(256) void triangulate_kernel(ProjPair P, const floa
             X4[3 * n + i] = 0.f;
             return;
         }
+#endif
         if (normalise_w == 3) {
             // guarded: keep the fast result only where its float32 casts cannot differ from the Jacobi path's; mark the rest
             // (the components are relative to a UNIT vector: a perturbation of the vector moves a small component by the same
@@ -363,7 +365,12 @@ extern "C" int sfm_triangulate_dlt(const double* P1, const double* P2, const flo
                                    int64_t stride_pt, int64_t stride_xy, int rows, int normalise_w, float* X4,
                                    void* stream_) {
     SFM_CHECK_ARG(rows == 4 || rows == 6, "sfm_triangulate_dlt: rows must be 4 or 6 (got %d)", rows);
-    SFM_CHECK_ARG(normalise_w >= 0 && normalise_w <= 4 && (normalise_w < 2 || rows == 4),
+#ifdef SFM_DEV_BUILD
+    constexpr int kMaxMode = 4;     // + the calibration mode of scripts/dev/dev_tri_calib.py
+#else
+    constexpr int kMaxMode = 3;
+#endif
+    SFM_CHECK_ARG(normalise_w >= 0 && normalise_w <= kMaxMode && (normalise_w < 2 || rows == 4),
                   "sfm_triangulate_dlt: normalise_w must be 0, 1, 2 (fast path) or 3 (guarded fast path); 2 and 3 need rows = 4");
     SFM_CHECK_ARG(n >= 0, "sfm_triangulate_dlt: negative n");
     if (n == 0) return SFM_OK;
@@ -374,8 +381,14 @@ extern "C" int sfm_triangulate_dlt(const double* P1, const double* P2, const flo
         P.p[1][k] = P2[k];
     }
     const dim3 grid((unsigned)((n + 255) / 256));
-    static const double sens_factor = [] { const char* e = getenv("SFM_TRI_SENS"); return e ? atof(e) : kSensFactor; }();   // dev overrides
+    // The guard's constants are part of the bit-identity claim (an EMPIRICAL bound, see the kernel's comment): a release build
+    // takes no override from the environment.
+#ifdef SFM_DEV_BUILD
+    static const double sens_factor = [] { const char* e = getenv("SFM_TRI_SENS"); return e ? atof(e) : kSensFactor; }();
     static const double base_guard = [] { const char* e = getenv("SFM_TRI_GUARD"); return e ? atof(e) : kCastGuard; }();
+#else
+    constexpr double sens_factor = kSensFactor, base_guard = kCastGuard;
+#endif
     sfm::prof_begin(sfm::kProfTriangulate, sfm::as_stream(stream_));
     if (rows == 4)
         hipLaunchKernelGGL(triangulate_kernel<4>, grid, dim3(256), 0, sfm::as_stream(stream_), P, x1, x2, n, stride_pt,

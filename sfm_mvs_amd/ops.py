@@ -177,7 +177,7 @@ def triangulate(P1, P2, pts1, pts2, rows=4, normalise_w=False):
     Returns X4 (4,N) float32 CUDA tensor.  normalise_w: False (raw singular vector, OpenCV's sign), True (divided by
     w in float32), "fast" (the same normalised result via inverse iteration on A^T A instead of Jacobi sweeps:
     bit-identical on > 99.9 % of points, 1 ulp otherwise; rows = 4 only) or "guarded" (the fast path where its float32
-    casts provably equal the faithful path's, the Jacobi sweeps — compacted — for the ~2 % of points near a rounding
+    casts equal the faithful path's under an EMPIRICAL bound (|fast - Jacobi| <= 2.5 sens measured on 4e6 points, guard at 16 sens; bench.py and tests/test_gpu_geometry.py bit-compare against normalise_w = 1), the Jacobi sweeps — compacted — for the ~2 % of points near a rounding
     boundary: bit-identical to True, ~8x faster; what the driver uses).
     """
     require_cuda(pts1, pts2)
@@ -277,16 +277,24 @@ def ba_dense_sweep(cams, K, X, obs, want_cam=True, want_pt=True):
     return out
 
 
-def block_inverse(A, k):
-    """Inverse of n independent k x k float64 blocks ([n, k*k] or [n, k, k]; k = 3 or 6) on the device (sfm_block_inverse)."""
+def block_inverse(A, k, check_singular=True):
+    """Inverse of n independent k x k float64 blocks ([n, k*k] or [n, k, k]; k = 3 or 6) on the device
+    (sfm_block_inverse_checked).  check_singular=True (default) reads the device status word — one synchronisation — and
+    raises if any block met a zero / non-finite pivot; False returns (inverse, bad-count tensor) without synchronising."""
     require_cuda(A)
     if A.dtype != torch.float64:
         raise SfmHipError("block_inverse: float64 blocks")
     a = A.contiguous()
     out = torch.empty_like(a)
     n = a.numel() // (k * k)
+    bad = torch.zeros(1, dtype=torch.int32, device=a.device)
     with on_device(a.device):
-        check(_lib.lib().sfm_block_inverse(ptr(a), n, int(k), ptr(out), stream_ptr()), "sfm_block_inverse")
+        check(_lib.lib().sfm_block_inverse_checked(ptr(a), n, int(k), ptr(out), ptr(bad), stream_ptr()), "sfm_block_inverse_checked")
+    if not check_singular:
+        return out, bad
+    nb = int(bad.item())
+    if nb:
+        raise SfmHipError(f"block_inverse: {nb} of {n} {k}x{k} blocks are singular or non-finite")
     return out
 
 

@@ -181,8 +181,20 @@ def ReprojectionError(X, pts, Rt, K, homogenity, be=None):
     r, _ = cv2.Rodrigues(R)
     if homogenity == 1:
         X = cv2.convertPointsFromHomogeneous(X.T)
-    Xf = np.ascontiguousarray(np.asarray(X, np.float32).reshape(-1, 3))
     obs = np.float32(pts.T if homogenity == 1 else pts)
+    if np.asarray(X).dtype == np.float64:
+        # float64 object points (the bundle-adjusted cloud, sfm.py:384): cv2.projectPoints works in double and returns double;
+        # only then are p and pts cast to float32 (sfm.py:90-91) — a float32 round trip of X would be as large as the
+        # "Minimized error" itself
+        Xd = np.ascontiguousarray(np.asarray(X, np.float64).reshape(-1, 3))
+        if b.reproj is _reproj_hip:
+            p64 = ops.project_points_f64(r, t, K, torch.as_tensor(Xd).to("cuda")).cpu().numpy()
+        else:
+            p64, _ = cv2.projectPoints(Xd, r, t, K, distCoeffs=None)
+        p = np.float32(np.asarray(p64, np.float64).reshape(-1, 2))
+        d = p.astype(np.float64) - obs.reshape(-1, 2).astype(np.float64)             # cv2.norm(float32, float32, NORM_L2): double accumulation
+        return float(np.sqrt(np.sum(d * d))) / len(p), X, p
+    Xf = np.ascontiguousarray(np.asarray(X, np.float32).reshape(-1, 3))
     sumsq, p = b.reproj(r, t, K, Xf, obs)
     tot_error = float(np.sqrt(sumsq)) / len(p)                     # quirk 3: Frobenius norm / N
     return tot_error, X, p
@@ -494,7 +506,9 @@ def register_next(eng, state, i, bundle_adjustment=False, gtol_thresh=0.5):
     SciPy's least_squares over [Rt | K | 2-D points | 3-D points] of the NEW cloud with the device's fp64 projection as
     residual (BundleAdjustment above), then the refined Rt, points and observations replace the frame's — P for the next
     frame, the cloud, the colour-lookup points and the error (ReprojectionError with homogenity = 0 on the float64
-    results, as sfm.py:384) — exactly where the reference replaces them."""
+    results, projected in float64 as sfm.py:384 does) — exactly where the reference replaces them.  The pose ARRAY keeps
+    the camera as PnP found it: sfm.py:375 appends Pnew to posearr BEFORE the `if bundle_adjustment:` branch, so pose.csv
+    holds the pre-adjustment matrices (out["P_pose"]); out["P"] is what the next frame triangulates with."""
     K = eng.K
     pts_, pts2 = eng.match(i + 1, i + 2)
     cloud = state.cloud0 if state.cloud0 is not None else eng.triangulate(state.P1, state.P2, state.pts0, state.pts1)
@@ -504,7 +518,7 @@ def register_next(eng, state, i, bundle_adjustment=False, gtol_thresh=0.5):
     Rt = np.hstack((np.asarray(R, np.float64), np.asarray(t, np.float64).reshape(3, 1)))
     P = K @ Rt
     X = eng.triangulate(state.P2, P, new1, new2)
-    out = dict(P=P, error=eng.error(X, new2, Rt), cloud=X, lookup=new2, pnp_inliers=len(p_in))
+    out = dict(P=P, P_pose=P, error=eng.error(X, new2, Rt), cloud=X, lookup=new2, pnp_inliers=len(p_in))
     if bundle_adjustment:
         be = getattr(eng, "be", None)
         # sfm.py:380: points_3d is the (N,1,3) float32 cloud ReprojectionError(homogenity=1) handed back, temp2 the (2,N)
@@ -512,7 +526,7 @@ def register_next(eng, state, i, bundle_adjustment=False, gtol_thresh=0.5):
         Xb, pb, Rt = BundleAdjustment(np.asarray(eng.host(X))[:, None, :], np.asarray(eng.host(new2)).T, Rt, K, gtol_thresh, be=be)
         P = K @ Rt                                                                   # sfm.py:381
         err, _, _ = ReprojectionError(Xb, pb, Rt, K, homogenity=0, be=be)            # sfm.py:384 ("Minimized error")
-        out = dict(P=P, error=err, cloud=Xb, lookup=pb, pnp_inliers=len(p_in), ba_error_before=out["error"])
+        out = dict(P=P, P_pose=out["P_pose"], error=err, cloud=Xb, lookup=pb, pnp_inliers=len(p_in), ba_error_before=out["error"])
     return FrameState(state.P2.copy(), P.copy(), pts_, pts2), out
 
 
@@ -531,7 +545,7 @@ def run_sfm(features, K, images=None, log=None, be=None, device_resident=None, b
     handles, clouds, lookups = [first], [], []
     for i in range(len(features) - 2):
         state, out = register_next(eng, state, i, bundle_adjustment, gtol_thresh)
-        poses.append(out["P"].ravel())
+        poses.append(out["P_pose"].ravel())                                          # sfm.py:375: before the bundle-adjustment branch
         handles.append(out["error"])
         clouds.append(out["cloud"])
         lookups.append(out["lookup"])

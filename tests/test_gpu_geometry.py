@@ -399,6 +399,17 @@ def test_block_kernels_and_norm(hip):
     general[:, 0, 0] = 0
     inv = hip.block_inverse(cu64(general.reshape(100, 36)), 6).cpu().numpy().reshape(100, 6, 6)
     assert np.abs(inv @ general - np.eye(6)).max() < 1e-8
+    # singular / non-finite blocks are REPORTED through the device status word (sfm_block_inverse_checked): the wrapper raises
+    bad = general.copy()
+    bad[7] = 0.0                                                          # a camera without observations
+    bad[11, :, 2] = bad[11, :, 1]                                         # rank 5
+    bad[13, 2, 2] = np.nan
+    with pytest.raises(hip.SfmHipError, match="singular or non-finite"):
+        hip.block_inverse(cu64(bad.reshape(100, 36)), 6)
+    inv_b, cnt = hip.block_inverse(cu64(bad.reshape(100, 36)), 6, check_singular=False)
+    assert int(cnt.item()) >= 2                                           # (the rank-5 block may escape by rounding; zeros and NaNs never do)
+    ok = np.ones(100, bool); ok[[7, 11, 13]] = False
+    assert np.abs(inv_b.cpu().numpy().reshape(100, 6, 6)[ok] @ general[ok] - np.eye(6)).max() < 1e-8
     for dt in (np.float32, np.float64):
         a, b = rng.normal(0, 30, 100_003).astype(dt), rng.normal(0, 30, 100_003).astype(dt)
         want = np.sqrt(np.sum(np.float64(a - b) ** 2))

@@ -389,8 +389,8 @@ def test_committed_fuzz_logs_are_those_of_this_kernel_source():
     import glob, hashlib, os, re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sha = hashlib.sha256(open(os.path.join(root, "sfm_mvs_amd", "csrc", "knn.hip"), "rb").read()).hexdigest()
-    logs = sorted(glob.glob(os.path.join(root, "profiles", "r03_fuzz_knn_*.log")))
-    assert logs, "no profiles/r03_fuzz_knn_*.log"
+    logs = sorted(glob.glob(os.path.join(root, "profiles", "r04_fuzz_knn_*.log")))
+    assert logs, "no profiles/r04_fuzz_knn_*.log"
     total = 0
     for path in logs:
         text = open(path).read()

@@ -232,7 +232,8 @@ def test_driver_with_bundle_adjustment_enabled(hip, oracle):
     followed by SciPy's least_squares over the new cloud, its observations and the camera, and the refined values replace
     the frame's.  Teacher-forced per frame against the CPU twin (same driver, oracle operators): same integer decisions, P,
     cloud, lookup points and minimised error within 1e-4; the error really is minimised; and the free-running driver
-    carries the refined P into the pose array."""
+    keeps the PRE-adjustment camera in the pose array (sfm.py:375 appends Pnew before the `if bundle_adjustment:` branch) while
+    the refined one drives the next frame."""
     from sfm_mvs_amd import pipeline as pl
     K, P, feats, ids = gustav_scene(5, seed=3, pix_noise=0.5)      # (new clouds of 1306, 2 and 20 points: the first is left as it is —
     # its gradient is below gtol — the other two are moved)
@@ -254,8 +255,11 @@ def test_driver_with_bundle_adjustment_enabled(hip, oracle):
     out = pl.run_sfm(feats, K, bundle_adjustment=True)
     plain = pl.run_sfm(feats, K)
     assert out["posearr"].shape == plain["posearr"].shape == (9 + 12 * 5,) and out["Xtot"].shape == plain["Xtot"].shape
-    assert np.array_equal(out["posearr"][:9 + 24], plain["posearr"][:9 + 24])            # the bootstrap pair is untouched ...
-    assert not np.array_equal(out["posearr"][9 + 24:], plain["posearr"][9 + 24:])        # ... every later camera is refined
+    # posearr holds what PnP found.  Frames 2 and 3 are registered from clouds no adjustment has touched yet (frame 2's own
+    # adjustment leaves it as it is: gradient below gtol), so their entries equal the plain run's; frame 3's adjustment moves its
+    # camera, and frame 4 — triangulated from that refined P — is registered differently
+    assert np.array_equal(out["posearr"][:9 + 48], plain["posearr"][:9 + 48])
+    assert not np.array_equal(out["posearr"][9 + 48:], plain["posearr"][9 + 48:])
     assert len(out["errors"]) == 3 and out["errors"][1] < plain["errors"][1] and out["errors"][2] < plain["errors"][2]
 
 
