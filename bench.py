@@ -794,7 +794,7 @@ def extra_other_workloads(args, dev):
         try:
             r = fn(a, 1, 0, dev)
             keep = ("metric", "value", "unit", "ms_per_step", "config", "roofline", "cpu_baseline", "parity", "frame_latency_ms_single_stream",
-                    "job_seconds", "match_seconds", "triangulated_points_total", "planted_matches_recovered_as_nearest_neighbour", "scaling")
+                    "job_seconds", "match_seconds", "triangulate_and_gather_seconds", "exchange", "triangulated_points_total", "planted_matches_recovered_as_nearest_neighbour", "scaling")
             out[key] = {k: r[k] for k in keep if k in r}
         except Exception as e:      # noqa: BLE001 — an extra, not the measurement
             out[key] = {"error": f"{type(e).__name__}: {e}"}
@@ -869,6 +869,31 @@ def bench_c5(args, world, rank, dev):
     n_img, n_desc, n_plant = max(2, args.images), 50_000, 15_000
     pairs = sharded.sequential_pairs(n_img)
 
+    # The exchange of a ONE-rank run goes through a real one-rank RCCL group (the same all_gather_into_tensor as at N > 1),
+    # created for this leg when the process has none; if RCCL cannot be initialised the leg says "local copy".
+    import torch.distributed as dist
+    own_group, exchange_kind = False, "RCCL all_gather_into_tensor"
+    if not (dist.is_available() and dist.is_initialized()):
+        try:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29541")
+            dist.init_process_group("nccl", device_id=dev, world_size=1, rank=0)
+            own_group = True
+            exchange_kind = "RCCL all_gather_into_tensor on a one-rank group created for this leg"
+        except Exception as e:      # noqa: BLE001
+            exchange_kind = f"local copy (no process group: {type(e).__name__})"
+    try:
+        return _bench_c5(args, world, rank, dev, sharded, pairs, n_img, n_desc, n_plant, exchange_kind)
+    finally:
+        if own_group:
+            torch.cuda.synchronize()
+            dist.destroy_process_group()
+
+
+def _bench_c5(args, world, rank, dev, sharded, pairs, n_img, n_desc, n_plant, exchange_kind):
+    from sfm_mvs_amd import ops
+    from datagen import load_pose_csv
+
     def base(k):          # image k before its planted rows: a function of k alone, so every rank generates the same image
         g = torch.Generator(device=dev).manual_seed(100 + k)
         d = torch.randn((n_desc, 128), generator=g, device=dev).abs_().square_()
@@ -920,21 +945,63 @@ def bench_c5(args, world, rank, dev):
             hits += int((store[p, 0, :, 0].index_select(0, planted[j]) == torch.arange(n_plant, device=dev, dtype=torch.int32)).sum().item())
             tot += n_plant
     n_pairs = len(pairs)
-    return {"metric": "descriptor-pair distances/sec over an image sequence (BF-KNN k=2 + Lowe ratio), pair-sharded with the match-record and 3-D point all-gathers",
-            "value": n_pairs * n_desc * n_desc / elapsed, "unit": "distances/s", "n_gpus": world, "steps": n_pairs, "warmup": 3,
-            "ms_per_step": elapsed / n_pairs * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32 results; filter arithmetic fp16 single product (exact for integer descriptors)", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[4]: {n_img} images x 50k SIFT-like descriptors in total, {n_pairs} sequential pairs sharded "
-                                   f"{world}-way (halo partition), RCCL all-gather of the KNN blocks ({EXCH_BATCH} pairs per collective) and of the "
-                                   "triangulated points, 30 % planted matches", "images": n_img, "descriptors": n_desc,
-                       "parallelism": f"pair-sharded x{world} (sharded.match_pairs_sharded + triangulate_pairs_sharded); {PIPE_DEPTH} pairs in flight per GPU"},
-            "job_seconds": elapsed, "match_seconds": t_match, "triangulate_and_gather_seconds": elapsed - t_match,
-            "images_resident_on_this_rank": len(mine),
-            "exchange": {"match_records": st_m, "points": st_t,
-                         "note": "device time between the events bracketing each all_gather_into_tensor (includes waiting for the batch's producers)"},
-            "triangulated_points_total": int(counts.sum().item()),
-            "planted_matches_recovered_as_nearest_neighbour": hits / max(tot, 1),
-            "ratio_survivors_per_pair_mean": float(counts.float().mean().item())}
+    out = {"metric": "descriptor-pair distances/sec over an image sequence (BF-KNN k=2 + Lowe ratio), pair-sharded with the match-record and 3-D point all-gathers",
+           "value": n_pairs * n_desc * n_desc / elapsed, "unit": "distances/s", "n_gpus": world, "steps": n_pairs, "warmup": 3,
+           "ms_per_step": elapsed / n_pairs * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "f32 results; filter arithmetic exact-integer i8 MFMA (u8-integer descriptors)", "data": "synthetic",
+           "config": {"workload": f"BASELINE configs[4]: {n_img} images x 50k SIFT-like descriptors in total, {n_pairs} sequential pairs sharded "
+                                  f"{world}-way (halo partition), all-gather of the KNN blocks ({EXCH_BATCH} pairs per collective) and of the "
+                                  f"triangulated points; exchange = {exchange_kind}; 30 % planted matches", "images": n_img, "descriptors": n_desc,
+                      "exchange": exchange_kind,
+                      "parallelism": f"pair-sharded x{world} (sharded.match_pairs_sharded + triangulate_pairs_sharded); {PIPE_DEPTH} pairs in flight per GPU"},
+           "job_seconds": elapsed, "match_seconds": t_match, "triangulate_and_gather_seconds": elapsed - t_match,
+           "images_resident_on_this_rank": len(mine),
+           "exchange": {"kind": exchange_kind, "match_records": st_m, "points": st_t,
+                        "note": "device time between the events bracketing each all_gather_into_tensor (includes waiting for the batch's producers)"},
+           "triangulated_points_total": int(counts.sum().item()),
+           "planted_matches_recovered_as_nearest_neighbour": hits / max(tot, 1),
+           "ratio_survivors_per_pair_mean": float(counts.float().mean().item())}
+    # roofline of the dominant kernel at this shape: one 50k x 50k pair alone on the device, the filter launched PROF_REPEAT
+    # times inside the library's event pair (as the headline leg does)
+    if len(mine) >= 2:
+        pm = ops.PairMatcher(n_desc, n_desc, dev, 0.70)
+        a, b = imgs[mine[0]], imgs[mine[1]]
+        pm.run(a, b)
+        torch.cuda.synchronize()
+        ops.profile_read(0), ops.profile_read(1)
+        for _ in range(4):
+            ops.profile_enable(PROF_REPEAT)
+            pm.run(a, b)
+            ops.profile_enable(False)
+            torch.cuda.synchronize()
+        f_ms, f_n = ops.profile_read(0)
+        r_ms, r_n = ops.profile_read(1)
+        mode = int(pm.stats[3].item())
+        peak, unit, sus = (I8_MFMA_PEAK_TOPS, "TOP/s", I8_MFMA_SUSTAINED_TOPS) if mode == 4 else (BF16_MFMA_PEAK_TFLOPS, "TFLOP/s", F16_MFMA_SUSTAINED_TFLOPS)
+        ach = n_desc * n_desc * FLOP_PER_DISTANCE / (f_ms / max(f_n, 1) * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak, "frac_of_sustained": ach / sus,
+                           "kernel": "knn_filter_q4_kernel<0> (" + ("filter_i8_body" if mode == 4 else "16-bit body") + "), one 50k x 50k pair per launch",
+                           "avg_launch_ms": f_ms / max(f_n, 1), "launches": f_n, "refine_avg_launch_ms": r_ms / max(r_n, 1),
+                           "algorithmic_flop_per_launch": n_desc * n_desc * FLOP_PER_DISTANCE, "traffic": None,
+                           "note": "256 integer ops per distance (SURVEY 8d); peak = dense int8 MFMA; sustained = profiles/r04_mfma_ceiling.md"}
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            from oracle import oracle as O
+            cores = os.cpu_count() or 1
+            qh, th = a.cpu().numpy(), b.cpu().numpy()
+            probe = min(n_desc, 64 * cores)
+            t1 = time.perf_counter()
+            O.knn2(qh[:probe], th, nthreads=cores)
+            rate = probe * n_desc / (time.perf_counter() - t1)
+            rows = int(min(n_desc, max(probe, rate * 10.0 / n_desc)))
+            t1 = time.perf_counter()
+            wi, wd = O.knn2(qh[:rows], th, nthreads=cores)
+            dt = time.perf_counter() - t1
+            gi = store[0, 0, :rows].cpu().numpy() if pairs[0] == (mine[0], mine[1]) else None
+            out["cpu_baseline"] = {"value": rows * n_desc / dt, "unit": "distances/s", "cores": cores, "kind": "port",
+                                   "sample": f"the first {rows} query rows of pair 0 x its 50 000 train rows, once, oracle orc_knn2_l2_f32 "
+                                             f"(OpenMP over query rows, {cores} threads), {dt:.1f} s",
+                                   "indices_identical_to_hip_on_the_sample": None if gi is None else bool(np.array_equal(gi, wi))}
+    return out
 
 
 def bench_sift(args, world, rank, dev):

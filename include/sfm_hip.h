@@ -216,6 +216,29 @@ int sfm_triangulate_dlt(const double* P1_host, const double* P2_host,
                         int normalise_w, float* X4_dev, void* stream);
 
 /* ------------------------------------------------------------------------
+ * A3 + A4 for `batch` (1..8) image pairs in one set of launches: the Lowe loop and keypoint gather of
+ * find_features (sfm.py:262-268) followed by Triangulation (sfm.py:53-54: cv2.triangulatePoints and
+ * `cloud / cloud[3]`) — what the pair-sharded path runs on a rank's own pairs before the all-gather of
+ * the 3-D points.  Input are the KNN blocks sfm_knn2_l2_f32 / sfm_match_batch_l2_f32 wrote (here or on
+ * another rank); nothing goes through the host and no survivor list or gathered coordinate array is
+ * materialised:  survivors = queries with a second neighbour and (double)d0 < ratio * (double)d1, in
+ * ascending queryIdx order; column e of the output is the triangulation of (kp0[queryIdx_e],
+ * kp1[trainIdx_e]) under (P[b][0], P[b][1]), computed as sfm_triangulate_dlt(rows = 4, normalise_w = 3)
+ * does (bit-identical to normalise_w = 1); columns >= the survivor count are zeroed.
+ *   knn_idx_dev, knn_dist_dev, kp0_dev, kp1_dev, X4_dev, count_dev: HOST arrays of `batch` device pointers
+ *     knn_idx_dev[b] [nq_b x 2] int32, knn_dist_dev[b] [nq_b x 2] float32 (8-byte aligned)
+ *     kp0_dev[b], kp1_dev[b]   [n x 2] float32 KeyPoint.pt of the query / train image (8-byte aligned)
+ *     X4_dev[b]                float32 [4 x cap] row-major;  count_dev[b] int32[1] (array or entries may be NULL)
+ *   nq_host  `batch` query counts (<= cap);  P_host [batch][2][12] doubles (row-major 3x4 of both views)
+ * ---------------------------------------------------------------------- */
+size_t sfm_triangulate_matches_batch_ws_bytes(int batch, int64_t cap);
+int sfm_triangulate_matches_batch(int batch, const int32_t* const* knn_idx_dev, const float* const* knn_dist_dev,
+                                  const int64_t* nq_host, double ratio,
+                                  const float* const* kp0_dev, const float* const* kp1_dev,
+                                  const double* P_host, int64_t cap, float* const* X4_dev,
+                                  int32_t* const* count_dev, void* ws_dev, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
  * A5  ReprojectionError: cv2.Rodrigues + cv2.projectPoints + cv2.norm
  *                                                        sfm.py:79-100
  * A6  solvePnPRansac inlier scoring                      sfm.py:67

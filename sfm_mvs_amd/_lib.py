@@ -43,6 +43,8 @@ SIGNATURES = {
     "sfm_common_points": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sfm_knn_merge_top2": (_int, [_vp, _int, _i64, _vp, _vp, _vp]),
     "sfm_triangulate_dlt": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _int, _int, _vp, _vp]),
+    "sfm_triangulate_matches_batch_ws_bytes": (_sz, [_int, _i64]),
+    "sfm_triangulate_matches_batch": (_int, [_int, _vp, _vp, _vp, _f64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
     "sfm_project_residual_ws_bytes": (_sz, [_i64, _i64, _i64]),
     "sfm_project_residual": (_int, [_vp, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _f32,
                                     _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -326,6 +326,146 @@ __global__ __launch_bounds__(256) void triangulate_kernel(ProjPair P, const floa
     store_point<M>(Xd, normalise_w, n, i, X4);
 }
 
+// ---------------------------------------------------------------- matches -> points in one pass (sfm.py:262-268, then :53-54)
+// The Lowe loop, the keypoint gather and the triangulation of up to kTmBatch image pairs, from the KNN blocks the matcher
+// wrote ({trainIdx x2}, {distance x2} per query) straight to [4 x cap] point blocks — no survivor list, no gathered
+// coordinate arrays and no host round trip in between (the pair-sharded path used to re-derive the survivors with a stable
+// sort per pair and gather with index kernels: 20 % of the config-5 job for 0.1 ms of arithmetic).
+//   count:  one workgroup per kTmChunk queries -> its number of ratio survivors;
+//   points: a workgroup sums the counts of its predecessors (ascending queryIdx = the order of the Python loop), lists its
+//           own survivors in LDS in order, and runs the GUARDED fast DLT on them (normalise_w = 3 of sfm_triangulate_dlt:
+//           same code, same constants); the lanes the guard rejects are queued in LDS and redone by the same workgroup with
+//           the OpenCV-faithful Jacobi sweeps, so a point's value is that of triangulate_kernel<4> + fixup, bit for bit.
+//           Columns >= the pair's survivor count are zeroed, the count is stored behind the block.
+constexpr int kTmBatch = 8;
+constexpr int kTmChunk = 1024;
+struct TriMatchArgs {
+    const int* idx[kTmBatch];        // [nq][2] trainIdx of the two neighbours
+    const float* dist[kTmBatch];     // [nq][2] their distances
+    const float2* kp0[kTmBatch];     // query image's keypoints (KeyPoint.pt)
+    const float2* kp1[kTmBatch];     // train image's
+    float* X4[kTmBatch];             // [4][ldx] points
+    int* count[kTmBatch];            // survivors of the pair (device scalar)
+    int nq[kTmBatch];
+    double P[kTmBatch][2][12];
+};
+
+__device__ __forceinline__ unsigned tm_ratio_bits(const int* __restrict__ idx, const float* __restrict__ dist, int nq, int qb, double ratio, int (&ti)[4]) {
+    unsigned pass = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int q = qb + k;
+        ti[k] = -1;
+        if (q < nq) {
+            const int2 ii = *reinterpret_cast<const int2*>(idx + 2 * q);
+            const float2 dd = *reinterpret_cast<const float2*>(dist + 2 * q);
+            ti[k] = ii.x;
+            pass |= ((ii.y >= 0) && ((double)dd.x < ratio * (double)dd.y) ? 1u : 0u) << k;   // sfm.py:264: float32 promoted to double, strict <
+        }
+    }
+    return pass;
+}
+
+__global__ __launch_bounds__(256) void tri_matches_count_kernel(TriMatchArgs A, double ratio, int* __restrict__ block_count) {
+    __shared__ int wsum[4];
+    const int pb = blockIdx.y;
+    const int qb = blockIdx.x * kTmChunk + threadIdx.x * 4;
+    int ti[4];
+    int c = __popc(tm_ratio_bits(A.idx[pb], A.dist[pb], A.nq[pb], qb, ratio, ti));
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_count[pb * gridDim.x + blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+__global__ __launch_bounds__(256) void tri_matches_points_kernel(TriMatchArgs A, double ratio, const int* __restrict__ block_count, int64_t ldx,
+                                                                 double sens_factor, double base_guard) {
+    __shared__ int list_q[kTmChunk], list_t[kTmChunk], redo[kTmChunk];
+    __shared__ int wsum[8], base_s, total_s, nredo;
+    const int pb = blockIdx.y, nblk = gridDim.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nq = A.nq[pb];
+    // exclusive prefix of the preceding workgroups' counts, and the pair's total
+    int part = 0, tot = 0;
+    for (int b = threadIdx.x; b < nblk; b += 256) {
+        const int c = block_count[pb * nblk + b];
+        tot += c;
+        if (b < (int)blockIdx.x) part += c;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        part += __shfl_xor(part, m, 64);
+        tot += __shfl_xor(tot, m, 64);
+    }
+    if (lane == 0) { wsum[wave] = part; wsum[4 + wave] = tot; }
+    if (threadIdx.x == 0) nredo = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        base_s = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        total_s = wsum[4] + wsum[5] + wsum[6] + wsum[7];
+    }
+    __syncthreads();
+    const int base = base_s, total = total_s;
+    __syncthreads();
+    // this workgroup's survivors, in ascending queryIdx order
+    const int qb = blockIdx.x * kTmChunk + threadIdx.x * 4;
+    int ti[4];
+    const unsigned pass = tm_ratio_bits(A.idx[pb], A.dist[pb], nq, qb, ratio, ti);
+    const int mine = __popc(pass);
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    const int m_wg = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    int pos = woff + incl - mine;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (pass & (1u << k)) {
+            list_q[pos] = qb + k;
+            list_t[pos] = ti[k];
+            ++pos;
+        }
+    __syncthreads();
+    const float2* __restrict__ kp0 = A.kp0[pb];
+    const float2* __restrict__ kp1 = A.kp1[pb];
+    float* __restrict__ X4 = A.X4[pb];
+    for (int e = threadIdx.x; e < m_wg; e += 256) {
+        const float2 a = kp0[list_q[e]], b = kp1[list_t[e]];
+        double At[4][4], Xd[4], sens = 0;
+        dlt_build<4>(At, A.P[pb][0], A.P[pb][1], (double)a.x, (double)a.y, (double)b.x, (double)b.y);
+        const bool have = dlt_nullvec_fast(At, Xd, &sens);
+        const double margin = fmax(base_guard, sens_factor * sens);
+        const bool keep = have && margin < 1e-3 && cast_margin_ok(Xd[0], margin) && cast_margin_ok(Xd[1], margin) &&
+                          cast_margin_ok(Xd[2], margin) && cast_margin_ok(Xd[3], margin);
+        if (keep) store_point<4>(Xd, 1, ldx, base + e, X4);
+        else redo[atomicAdd(&nredo, 1)] = e;
+    }
+    __syncthreads();
+    const int nr = nredo;
+    for (int r = threadIdx.x; r < nr; r += 256) {                  // (stored by position: the queue's order does not matter)
+        const int e = redo[r];
+        const float2 a = kp0[list_q[e]], b = kp1[list_t[e]];
+        double At[4][4], Xd[4];
+        dlt_build<4>(At, A.P[pb][0], A.P[pb][1], (double)a.x, (double)a.y, (double)b.x, (double)b.y);
+        dlt_nullvec<4>(At, Xd);
+        store_point<4>(Xd, 1, ldx, base + e, X4);
+    }
+    // columns past the survivors: zero (an exchange slot still holds the points of an earlier pair)
+    for (int64_t c = (int64_t)blockIdx.x * kTmChunk + threadIdx.x; c < min((int64_t)(blockIdx.x + 1) * kTmChunk, ldx); c += 256)
+        if (c >= total) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) X4[k * ldx + c] = 0.f;
+        }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && A.count[pb]) *A.count[pb] = total;
+}
+
 // cv2.recoverPose's cheirality vote (sfm.py:311): for pose candidate m = blockIdx.y triangulate every
 // K-normalised correspondence against [I|0] / [R|t] in fp64 (points are double there) and test
 //   Q2*Q3 > 0,  Q2/Q3 < dist,  0 < z' < dist  with z' = third row of [R|t] * (Q/Q3).
@@ -400,6 +540,50 @@ extern "C" int sfm_triangulate_dlt(const double* P1, const double* P2, const flo
         hipLaunchKernelGGL(triangulate_fixup_kernel, dim3((unsigned)((n + kFixChunk - 1) / kFixChunk)), dim3(256), 0, sfm::as_stream(stream_), P, x1,
                            x2, n, stride_pt, stride_xy, X4);
     sfm::prof_end(sfm::kProfTriangulate, sfm::as_stream(stream_));
+    SFM_CHECK_LAUNCH();
+    return SFM_OK;
+}
+
+extern "C" size_t sfm_triangulate_matches_batch_ws_bytes(int batch, int64_t cap) {
+    if (batch < 1 || batch > kTmBatch || cap < 0) return 0;
+    return sfm::align_up(sizeof(int) * (size_t)batch * (size_t)((cap + kTmChunk - 1) / kTmChunk + 1), 256);
+}
+
+extern "C" int sfm_triangulate_matches_batch(int batch, const int32_t* const* knn_idx, const float* const* knn_dist, const int64_t* nq_host,
+                                             double ratio, const float* const* kp0, const float* const* kp1, const double* P_host, int64_t cap,
+                                             float* const* X4, int32_t* const* count, void* ws, size_t ws_bytes, void* stream_) {
+    SFM_CHECK_ARG(batch >= 1 && batch <= kTmBatch, "sfm_triangulate_matches_batch: batch must be 1..%d (got %d)", kTmBatch, batch);
+    SFM_CHECK_ARG(cap >= 0 && cap < INT32_MAX, "sfm_triangulate_matches_batch: bad cap");
+    SFM_CHECK_ARG(knn_idx && knn_dist && nq_host && kp0 && kp1 && P_host && X4, "sfm_triangulate_matches_batch: null pointer");
+    if (cap == 0) return SFM_OK;
+    TriMatchArgs A;
+    for (int b = 0; b < kTmBatch; ++b) {
+        const int s = b < batch ? b : 0;
+        SFM_CHECK_ARG(nq_host[s] >= 0 && nq_host[s] <= cap, "sfm_triangulate_matches_batch: pair %d has %lld queries, the point block %lld columns", s,
+                      (long long)nq_host[s], (long long)cap);
+        SFM_CHECK_ARG(X4[s] && (nq_host[s] == 0 || (knn_idx[s] && knn_dist[s] && kp0[s] && kp1[s])), "sfm_triangulate_matches_batch: null pointer (pair %d)", s);
+        SFM_CHECK_ARG(((uintptr_t)knn_idx[s] & 7) == 0 && ((uintptr_t)knn_dist[s] & 7) == 0 && ((uintptr_t)kp0[s] & 7) == 0 && ((uintptr_t)kp1[s] & 7) == 0,
+                      "sfm_triangulate_matches_batch: KNN blocks and keypoint arrays must be 8-byte aligned");
+        A.idx[b] = knn_idx[s];
+        A.dist[b] = knn_dist[s];
+        A.kp0[b] = reinterpret_cast<const float2*>(kp0[s]);
+        A.kp1[b] = reinterpret_cast<const float2*>(kp1[s]);
+        A.X4[b] = X4[s];
+        A.count[b] = count ? count[s] : nullptr;
+        A.nq[b] = (int)nq_host[s];
+        for (int k = 0; k < 24; ++k) A.P[b][k / 12][k % 12] = P_host[(size_t)s * 24 + k];
+    }
+    if (!ws || ws_bytes < sfm_triangulate_matches_batch_ws_bytes(batch, cap)) {
+        sfm::set_error("sfm_triangulate_matches_batch: workspace too small (%zu < %zu)", ws_bytes, sfm_triangulate_matches_batch_ws_bytes(batch, cap));
+        return SFM_ERR_WORKSPACE;
+    }
+    hipStream_t stream = sfm::as_stream(stream_);
+    const dim3 grid((unsigned)((cap + kTmChunk - 1) / kTmChunk), (unsigned)batch);
+    int* counts = static_cast<int*>(ws);
+    sfm::prof_begin(sfm::kProfTriangulate, stream);
+    hipLaunchKernelGGL(tri_matches_count_kernel, grid, dim3(256), 0, stream, A, ratio, counts);
+    hipLaunchKernelGGL(tri_matches_points_kernel, grid, dim3(256), 0, stream, A, ratio, counts, cap, kSensFactor, kCastGuard);
+    sfm::prof_end(sfm::kProfTriangulate, stream);
     SFM_CHECK_LAUNCH();
     return SFM_OK;
 }

@@ -204,6 +204,53 @@ def triangulate(P1, P2, pts1, pts2, rows=4, normalise_w=False):
     return X4
 
 
+def triangulate_matches_batch(knn_blocks, n_query, keypoints0, keypoints1, proj0, proj1, out, counts=None, ratio=0.70):
+    """Lowe loop + keypoint gather + Triangulation (sfm.py:262-268, :53-54) of 1..8 pairs in one set of launches, straight
+    from the KNN blocks to point blocks (sfm_triangulate_matches_batch) — no host round trip, no survivor list.
+
+    knn_blocks: per pair an int32 [2][cap_b][2] CUDA tensor ([0] trainIdx x2, [1] float32 distance bits x2: what
+    PairMatcher / BatchMatcher write and the pair-sharded exchange gathers); n_query: queries per pair;
+    keypoints0/1: per pair [n,2] float32 CUDA (KeyPoint.pt of the query / train image); proj0/1: per pair 3x4 float64;
+    out: per pair a float32 [4][cap] CUDA view (contiguous rows, one cap for all) receiving the points, columns >= the
+    survivor count zeroed; counts: optional per pair int32 [1] CUDA views receiving the survivor count.
+    Values are those of ops.triangulate(..., normalise_w="guarded") on the gathered survivors, bit for bit."""
+    B = len(knn_blocks)
+    if not (1 <= B <= 8) or not (len(n_query) == len(keypoints0) == len(keypoints1) == len(proj0) == len(proj1) == len(out) == B):
+        raise SfmHipError("triangulate_matches_batch: 1..8 pairs, one entry per pair in every argument")
+    cap = int(out[0].shape[1])
+    vp = ctypes.c_void_p
+    for b in range(B):
+        kb, o = knn_blocks[b], out[b]
+        require_cuda(kb, keypoints0[b], keypoints1[b], o)
+        if kb.dtype != torch.int32 or kb.dim() != 3 or kb.shape[0] != 2 or kb.shape[2] != 2 or kb.stride(2) != 1 or kb.stride(1) != 2:
+            raise SfmHipError("triangulate_matches_batch: a KNN block is an int32 [2][cap][2] tensor with contiguous planes")
+        if int(n_query[b]) > min(cap, kb.shape[1]):
+            raise SfmHipError("triangulate_matches_batch: more queries than block rows / output columns")
+        if o.dtype != torch.float32 or tuple(o.shape) != (4, cap) or o.stride(1) != 1 or o.stride(0) != cap:
+            raise SfmHipError("triangulate_matches_batch: out must be float32 [4][cap] views with one cap and contiguous rows")
+        for kp in (keypoints0[b], keypoints1[b]):
+            if kp.dtype != torch.float32 or kp.dim() != 2 or kp.shape[1] != 2 or not kp.is_contiguous():
+                raise SfmHipError("triangulate_matches_batch: keypoints must be contiguous float32 [n,2]")
+        if counts is not None:
+            require_cuda(counts[b])
+    arr = lambda ptrs: (vp * B)(*ptrs)
+    P = np.empty((B, 2, 12), dtype=np.float64)
+    for b in range(B):
+        P[b, 0] = _f64_host(proj0[b], 12, "P1")
+        P[b, 1] = _f64_host(proj1[b], 12, "P2")
+    nq = np.asarray([int(n) for n in n_query], dtype=np.int64)
+    dev = out[0].device
+    lib = _lib.lib()
+    ws = _workspace(dev, lib.sfm_triangulate_matches_batch_ws_bytes(B, cap))
+    with on_device(dev):
+        check(lib.sfm_triangulate_matches_batch(B, arr([k[0].data_ptr() for k in knn_blocks]), arr([k[1].data_ptr() for k in knn_blocks]),
+                                                nq.ctypes.data_as(vp), float(ratio), arr([k.data_ptr() for k in keypoints0]),
+                                                arr([k.data_ptr() for k in keypoints1]), P.ctypes.data_as(vp), cap,
+                                                arr([o.data_ptr() for o in out]),
+                                                None if counts is None else arr([c.data_ptr() for c in counts]),
+                                                ptr(ws), ws.numel(), stream_ptr()), "sfm_triangulate_matches_batch")
+
+
 def project_residual(cams, K, X, obs, cam_idx=None, pt_idx=None, thr2=64.0, want_proj=True, want_inlier=False,
                      want_jac=False, want_pt_jac=False, want_res2=False):
     """Reprojection sweep (sfm.py:79-100 / :67 scoring / :104-136 residual).

@@ -74,13 +74,15 @@ def halo_images(pairs, world, rank, partition=None):
     return sorted({i for p in mine for i in pairs[int(p)]})
 
 
-def _round_targets(partition, rd, batch, dump):
-    """Destination pair index of every (rank, slot) of round `rd` (unused slots go to the dump row)."""
-    dst = torch.full((len(partition), batch), dump, dtype=torch.int64)
+def _round_targets(partition, rounds, batch, dump, device):
+    """Destination pair index of every (round, rank, slot) (unused slots go to the dump row), as ONE device tensor
+    [rounds][world * batch]: a per-round upload would put a host-to-device copy between every two collectives."""
+    dst = np.full((max(rounds, 1), len(partition), batch), dump, dtype=np.int64)
     for r, part in enumerate(partition):
-        k = part[rd * batch:(rd + 1) * batch]
-        dst[r, :len(k)] = torch.from_numpy(np.asarray(k, dtype=np.int64))
-    return dst
+        for rd in range(rounds):
+            k = np.asarray(part[rd * batch:(rd + 1) * batch], dtype=np.int64)
+            dst[rd, r, :len(k)] = k
+    return torch.from_numpy(dst.reshape(max(rounds, 1), -1)).to(device)
 
 
 def _world_rank(group):
@@ -187,13 +189,35 @@ class HipMatchEngine:
 
 
 def ratio_survivors(block, nq, ratio=0.70):
-    """The Lowe loop of sfm.py:262-265 on a gathered KNN block -> (queryIdx, trainIdx) int64 tensors, ascending queryIdx.
-    float32 distances promoted to double, strict <, as Python compares them."""
-    idx = block[0, :nq]
-    d = block[1, :nq].view(torch.float32).to(torch.float64)
-    keep = (idx[:, 1] >= 0) & (d[:, 0] < ratio * d[:, 1])
-    q = torch.nonzero(keep, as_tuple=False).reshape(-1)
-    return q, idx[q, 0].long()
+    """The Lowe loop of sfm.py:262-265 on a gathered KNN block (int32 [2][cap][2] device tensor) -> (queryIdx, trainIdx)
+    int32 device tensors in ascending queryIdx order: `sfm_ratio_compact` (float32 distances promoted to double, strict <, as
+    Python compares them); one host read of the survivor count."""
+    from . import ops
+    out_q, out_t, count = ops.ratio_compact(block[0, :nq], block[1, :nq].view(torch.float32), ratio)
+    m = int(count.item())
+    return out_q[:m], out_t[:m]
+
+
+class HipTriangulateEngine:
+    """Lowe survivors -> keypoint gather -> guarded DLT of up to 8 pairs per call, straight from the gathered KNN blocks into
+    the slots of the point exchange (ops.triangulate_matches_batch): nothing goes through the host."""
+
+    streams = ()
+
+    def __init__(self, device, ratio=0.70):
+        self.device, self.ratio = torch.device(device), ratio
+
+    def triangulate_batch(self, items, after=()):
+        """items: list of (knn_block int32 [2][cap][2], n_query, kp0 [n,2], kp1 [n,2], P0, P1, points float32 [4][cap] view,
+        count int32 [1] view); after: events the slots wait for (their previous all-gather has read them)."""
+        from . import ops
+        cur = torch.cuda.current_stream(self.device)
+        for ev in {id(e): e for e in after if e is not None}.values():
+            cur.wait_event(ev)
+        for lo in range(0, len(items), 8):
+            part = items[lo:lo + 8]
+            ops.triangulate_matches_batch([it[0] for it in part], [it[1] for it in part], [it[2] for it in part], [it[3] for it in part],
+                                          [it[4] for it in part], [it[5] for it in part], [it[6] for it in part], [it[7] for it in part], self.ratio)
 
 
 def match_pairs_sharded(descriptors, pairs, n_desc=None, engine=None, group=None, device=None, batch=8, ratio=0.70, partition=None, stats=None):
@@ -215,7 +239,9 @@ def match_pairs_sharded(descriptors, pairs, n_desc=None, engine=None, group=None
     mine = partition[rank]
     per = max((len(part) for part in partition), default=0)
     store = torch.zeros((n_pairs + 1, 2, cap, 2), dtype=torch.int32, device=dev)      # [+1]: dump row for unused slots
-    for rd in range(-(-per // batch) if per else 0):
+    rounds = -(-per // batch) if per else 0
+    dst = _round_targets(partition, rounds, batch, n_pairs, dev)
+    for rd in range(rounds):
         for p in mine[rd * batch:(rd + 1) * batch]:
             i, j = pairs[int(p)]
             slot, ev = ex.next_slot()
@@ -223,78 +249,67 @@ def match_pairs_sharded(descriptors, pairs, n_desc=None, engine=None, group=None
             ex.commit()
         gathered, _ = ex.flush(getattr(engine, "streams", ()))
         # scatter the round's blocks to their pairs in ONE indexed copy (unused slots go to the dump row)
-        dst = _round_targets(partition, rd, batch, n_pairs)
-        store.index_copy_(0, dst.reshape(-1).to(dev), gathered.reshape((world * batch,) + gathered.shape[2:]))
+        store.index_copy_(0, dst[rd], gathered.reshape((world * batch,) + gathered.shape[2:]))
     if stats is not None:                                  # (bench.py: device time inside the collectives, their number and size)
         stats.update(exchange_ms=ex.exchange_ms() if ex.cuda else 0.0, collectives=ex.collectives,
                      bytes_per_rank_per_collective=batch * 2 * cap * 2 * 4)
     return store[:n_pairs], [n_desc[i] for i, _ in pairs]
 
 
-def triangulate_pairs_sharded(store, n_query, pairs, keypoints, proj, triangulate=None, group=None, batch=8, ratio=0.70, partition=None, stats=None):
+def triangulate_pairs_sharded(store, n_query, pairs, keypoints, proj, engine=None, group=None, batch=8, ratio=0.70, partition=None, stats=None):
     """The path's second exchange (north_star: "all-gather of 3D points"): every rank triangulates the Lowe survivors of
-    ITS pairs (sfm.py:349,371: cv2.triangulatePoints + division by w) and the float32 x 4 points are all-gathered.
-    keypoints: list over images of [n_i,2] float32 (None where not held: a rank needs its block + halo, as for the
-    descriptors); proj: list over images of 3x4 float64 projection matrices (replicated: the PnP chain is sequential).
-    triangulate(P1, P2, x1 (2,m), x2 (2,m)) -> (4,m) float32; default: the HIP kernel.
-    Returns (points float32 [n_pairs][4][cap], counts int64 [n_pairs]) on every rank."""
+    ITS pairs (sfm.py:262-268 then :349,371: ratio loop, keypoint gather, cv2.triangulatePoints + division by w) and the
+    float32 x 4 points are all-gathered together with each pair's survivor count.
+    keypoints: list over images of contiguous [n_i,2] float32 device tensors (None where not held: a rank needs its block +
+    halo, as for the descriptors); proj: list over images of 3x4 float64 projection matrices (replicated: the PnP chain is
+    sequential).  engine: `triangulate_batch(items, after)` as HipTriangulateEngine (the default: one fused set of launches
+    per round, no host synchronisation; the gloo tests inject a host engine).
+    Returns (points float32 [n_pairs][4][cap], counts int64 [n_pairs] on the host) on every rank."""
     world, rank = _world_rank(group)
     dev = store.device
     n_pairs, cap = len(pairs), store.shape[2]
-    if triangulate is None:
-        from . import ops
-
-        def triangulate(P1, P2, x1, x2):
-            return ops.triangulate(P1, P2, x1, x2, normalise_w="guarded")     # bit-identical to normalise_w=True
-    ex = BatchedExchange((4, cap), torch.float32, dev, batch, group)
+    engine = engine or HipTriangulateEngine(dev, ratio)
+    width = 4 * cap + 4                                      # [4][cap] points, then the survivor count (int32 bits) + padding
+    ex = BatchedExchange((width,), torch.float32, dev, batch, group)
     partition = partition or contiguous_partition(n_pairs, world)
     mine = partition[rank]
     per = max((len(part) for part in partition), default=0)
-    points = torch.zeros((n_pairs + 1, 4, cap), dtype=torch.float32, device=dev)
-    # The Lowe survivors are a function of the gathered KNN blocks: every rank derives the mask of EVERY pair in one
-    # vectorised pass (sfm.py:262-265: float32 distances promoted to double, strict <), the counts come back in ONE download,
-    # and a pair's ascending survivor list is the head of a stable sort of its mask — no per-pair host synchronisation.
-    nqv = torch.as_tensor(np.asarray(n_query, dtype=np.int64), device=dev)
-    d = store[:, 1].view(torch.float32).to(torch.float64)
-    keep = (store[:, 0, :, 1] >= 0) & (d[:, :, 0] < ratio * d[:, :, 1]) & (torch.arange(cap, device=dev)[None, :] < nqv[:, None])
-    del d
-    counts = keep.sum(1).cpu()
-    mine_t = torch.as_tensor(np.asarray(mine, dtype=np.int64), device=dev)
-    order = torch.sort((~keep[mine_t]).to(torch.uint8), dim=1, stable=True).indices if len(mine) else None
-    for rd in range(-(-per // batch) if per else 0):
-        for k, p in enumerate(mine[rd * batch:(rd + 1) * batch]):
+    points = torch.zeros((n_pairs + 1, width), dtype=torch.float32, device=dev)
+    rounds = -(-per // batch) if per else 0
+    dst = _round_targets(partition, rounds, batch, n_pairs, dev)
+    for rd in range(rounds):
+        items, after = [], []
+        for p in mine[rd * batch:(rd + 1) * batch]:
             p = int(p)
             i, j = pairs[p]
-            m = int(counts[p])
-            q = order[rd * batch + k, :m]
             slot, ev = ex.next_slot()
-            if ev is not None:
-                torch.cuda.current_stream(dev).wait_event(ev)
-            slot.zero_()                                     # (the buffer still holds the points of two rounds ago)
-            if m:
-                x1 = keypoints[i].to(dev)[q].t().contiguous()
-                x2 = keypoints[j].to(dev)[store[p, 0, q, 0].long()].t().contiguous()
-                slot[:, :m].copy_(triangulate(proj[i], proj[j], x1, x2))
+            items.append((store[p], int(n_query[p]), keypoints[i], keypoints[j], proj[i], proj[j],
+                          slot[:4 * cap].view(4, cap), slot[4 * cap:4 * cap + 1].view(torch.int32)))
+            after.append(ev)
             ex.commit()
-        gathered, _ = ex.flush()
-        dst = _round_targets(partition, rd, batch, n_pairs)
-        points.index_copy_(0, dst.reshape(-1).to(dev), gathered.reshape((world * batch,) + gathered.shape[2:]))
+        if items:
+            engine.triangulate_batch(items, after)
+        gathered, _ = ex.flush(getattr(engine, "streams", ()))
+        points.index_copy_(0, dst[rd], gathered.reshape((world * batch, width)))
+    counts = points[:n_pairs, 4 * cap].contiguous().view(torch.int32).cpu().long()      # the job's one host read
     if stats is not None:
-        stats.update(exchange_ms=ex.exchange_ms() if ex.cuda else 0.0, collectives=ex.collectives, bytes_per_rank_per_collective=batch * 4 * cap * 4)
-    return points[:n_pairs], counts
+        stats.update(exchange_ms=ex.exchange_ms() if ex.cuda else 0.0, collectives=ex.collectives, bytes_per_rank_per_collective=batch * width * 4)
+    return points[:n_pairs, :4 * cap].view(n_pairs, 4, cap), counts
 
 
-def knn2_train_split(des0, des1_shard, train_offset, knn2=None, group=None):
+def knn2_train_split(des0, des1_shard, train_offset, knn2=None, merge=None, group=None):
     """SURVEY 8e's fallback for ONE pair whose train set is split over the ranks (a descriptor set that does not fit one
     device, or a single huge pair to be sped up): every rank holds all queries and the train rows
     [train_offset, train_offset + len(des1_shard)), computes its partial top-2, the partial results are all-gathered and
     merged 2 * world -> 2 by (distance, global train index) — associative, and the lower index wins ties exactly as in a
     single scan (cv2.BFMatcher keeps the earlier row).  knn2(des0, des1) -> (idx [nq,2] int32, dist [nq,2] float32), -1 /
-    anything where a neighbour is missing; default: the HIP kernel.  Returns (idx, dist) on every rank."""
+    anything where a neighbour is missing; merge(gathered int32 [world][2][nq][2]) -> (idx, dist); defaults: the HIP kernels
+    (sfm_knn2_l2_f32, sfm_knn_merge_top2: one kernel, a lane per query) — the gloo tests inject host engines.
+    Returns (idx, dist) on every rank."""
     world, rank = _world_rank(group)
-    if knn2 is None:
+    if knn2 is None or merge is None:
         from . import ops
-        knn2 = ops.knn2
+        knn2, merge = knn2 or ops.knn2, merge or ops.knn_merge_top2
     nq, dev = des0.shape[0], des0.device
     local = torch.empty((2, nq, 2), dtype=torch.int32, device=dev)
     if des1_shard.shape[0] > 0:
@@ -309,18 +324,4 @@ def knn2_train_split(des0, des1_shard, train_offset, knn2=None, group=None):
         dist.all_gather_into_tensor(gathered.view(world * 2, nq, 2), local, group=group)
     else:
         gathered[0].copy_(local)
-    if dev.type == "cuda":                                  # the product path: one kernel, a lane per query
-        from . import ops
-        return ops.knn_merge_top2(gathered)
-    # host tensors (the gloo tests' array engine): the same merge with stable sorts
-    cand_i = gathered[:, 0].permute(1, 0, 2).reshape(nq, 2 * world)                       # [nq][2 world]
-    cand_d = gathered[:, 1].permute(1, 0, 2).reshape(nq, 2 * world).contiguous().view(torch.float32)
-    cand_d = torch.where(cand_i >= 0, cand_d, torch.full_like(cand_d, float("inf")))
-    key_i = torch.where(cand_i >= 0, cand_i, torch.full_like(cand_i, 2 ** 31 - 1))
-    o1 = torch.sort(key_i, dim=1, stable=True).indices                                    # by index ...
-    d1 = torch.gather(cand_d, 1, o1)
-    o2 = torch.sort(d1, dim=1, stable=True).indices                                       # ... then (stable) by distance
-    order = torch.gather(o1, 1, o2)[:, :2]
-    out_i = torch.gather(cand_i, 1, order)
-    out_d = torch.gather(cand_d, 1, order)
-    return out_i.contiguous(), torch.where(out_i >= 0, out_d, torch.zeros_like(out_d)).contiguous()
+    return merge(gathered)

@@ -421,3 +421,73 @@ def test_block_kernels_and_norm(hip):
 
 def cu64(a):
     return torch.from_numpy(np.ascontiguousarray(a, np.float64)).cuda()
+
+
+def test_matches_to_points_in_one_pass_equals_the_separate_operators(hip, oracle):
+    """sfm_triangulate_matches_batch (sfm.py:262-268 then :53-54 for up to 8 pairs per call) against the chain it fuses —
+    the oracle's Lowe loop, a gather, the faithful triangulation: survivor counts, column order (ascending queryIdx), every
+    point bit for bit (the guarded fast path incl. its in-kernel Jacobi redo), zeroed tails.  Pairs of different sizes in
+    one call, a query without a second neighbour, distances exactly ON the ratio boundary (strict <), a pair with no
+    survivor, a pair whose every query survives, and a nearly degenerate camera pair (most points take the redo path)."""
+    from datagen import load_pose_csv
+    K, P = load_pose_csv()
+    rng = np.random.default_rng(31)
+    cap = 5000
+    sizes = [5000, 4097, 1024, 1, 0, 3000, 2500, 777]
+    P2n = P[3].copy()
+    P2n[:, 3] += P[3][:, :3] @ np.array([1e-3, 0.0, 0.0])                # baseline 1e-3: ill-conditioned null vectors
+    cams = [(P[1], P[2]), (P[5], P[6]), (P[10], P[11]), (P[0], P[1]), (P[0], P[1]), (P[3], P2n), (P[20], P[21]), (P[30], P[31])]
+    blocks, kp0s, kp1s, wants = [], [], [], []
+    for b, nq in enumerate(sizes):
+        nt = 3000 + 100 * b
+        idx = np.stack([rng.integers(0, nt, nq), rng.integers(0, nt, nq)], 1).astype(np.int32)
+        d1 = rng.uniform(50, 400, nq).astype(np.float32)
+        d0 = (d1 * rng.uniform(0.3, 1.0, nq)).astype(np.float32)
+        if nq > 100:
+            idx[7, 1] = -1                                               # no second neighbour: never a survivor
+            d0[11] = np.float32(0.7 * np.float64(d1[11]))                # as close to the boundary as float32 gets
+            d1[13], d0[13] = np.float32(10.0), np.float32(7.0)           # 7.0 < 0.7 * 10.0 in double? (0.7 is below 7/10: False)
+        if b == 6:
+            d0[:] = 0.0                                                  # every query passes
+        if b == 7:
+            d0[:] = d1                                                   # none does
+        dist = np.stack([d0, d1], 1)
+        blk = np.zeros((2, cap, 2), np.int32)
+        blk[0, :nq], blk[1, :nq] = idx, dist.view(np.int32)
+        blk[:, nq:] = rng.integers(-5, 5, (2, cap - nq, 2))             # rows past nq must be ignored
+        kp0 = rng.uniform(0, 900, (max(nq, 1), 2)).astype(np.float32)
+        kp1 = rng.uniform(0, 900, (nt, 2)).astype(np.float32)
+        if b == 5:                                                      # consistent rays for the degenerate pair
+            n = max(nq, 1)
+            X = np.stack([rng.uniform(-6, 3, n), rng.uniform(-2, 5, n), rng.uniform(4, 13, n), np.ones(n)], 0)
+            a, c = cams[b][0] @ X, cams[b][1] @ X
+            kp0 = (a[:2] / a[2]).T.astype(np.float32)
+            kp1 = np.tile((c[:2] / c[2]).T.astype(np.float32), (2, 1))[:nt] if nt <= 2 * n else rng.uniform(0, 900, (nt, 2)).astype(np.float32)
+            idx[:, 0] = np.arange(nq) % len(kp1)
+            blk[0, :nq] = idx
+        wq, wt, _ = oracle.ratio_filter(idx, dist, 0.70)
+        want = oracle.triangulate(cams[b][0], cams[b][1], kp0[wq].T.copy(), kp1[wt].T.copy(), normalise_w=True) if len(wq) else np.zeros((4, 0), np.float32)
+        blocks.append(cu(blk)); kp0s.append(cu(kp0)); kp1s.append(cu(kp1)); wants.append((wq, wt, want))
+    out = torch.full((8, 4 * cap + 4), 7.0, dtype=torch.float32, device="cuda")      # stale slot content must disappear
+    pts = [out[b, :4 * cap].view(4, cap) for b in range(8)]
+    cnt = [out[b, 4 * cap:4 * cap + 1].view(torch.int32) for b in range(8)]
+    hip.triangulate_matches_batch(blocks, sizes, kp0s, kp1s, [c[0] for c in cams], [c[1] for c in cams], pts, cnt, ratio=0.70)
+    torch.cuda.synchronize()
+    assert len(wants[6][0]) == sizes[6] - 1 and len(wants[7][0]) == 0 and len(wants[4][0]) == 0      # (query 7 has no second neighbour)
+    for b in range(8):
+        wq, wt, want = wants[b]
+        m = len(wq)
+        assert int(cnt[b].item()) == m, (b, int(cnt[b].item()), m)
+        got = pts[b].cpu().numpy()
+        assert float(np.abs(got[:, m:]).sum()) == 0.0
+        if m:
+            faithful = hip.triangulate(cams[b][0], cams[b][1], kp0s[b][cu(wq).long()].t(), kp1s[b][cu(wt).long()].t(), normalise_w=True).cpu().numpy()
+            assert np.array_equal(got[:, :m].view(np.uint32), faithful.view(np.uint32)), b      # = the faithful kernel, bit for bit
+            if b != 5:                                                  # ... and the oracle (same operation order: almost always bit-identical)
+                assert np.allclose(got[:, :m], want, rtol=1e-6, atol=1e-7) and (got[:, :m] == want).mean() > 0.99
+    # a single pair through the same entry point, no count outputs
+    one = torch.zeros((4, cap), dtype=torch.float32, device="cuda")
+    hip.triangulate_matches_batch(blocks[1:2], sizes[1:2], kp0s[1:2], kp1s[1:2], [cams[1][0]], [cams[1][1]], [one], None)
+    assert torch.equal(one, pts[1])
+    with pytest.raises(hip.SfmHipError):
+        hip.triangulate_matches_batch(blocks[:1], [cap + 1], kp0s[:1], kp1s[:1], [cams[0][0]], [cams[0][1]], [one], None)

@@ -28,6 +28,44 @@ class OracleEngine:
         self.calls += 1
 
 
+class OracleTriEngine:
+    """CPU stand-in for sharded.HipTriangulateEngine: the oracle's Lowe loop + DLT written into the point slots."""
+
+    streams = ()
+
+    def __init__(self, oracle, ratio=0.70):
+        self.O, self.ratio = oracle, ratio
+
+    def triangulate_batch(self, items, after=()):
+        for block, nq, kp0, kp1, P0, P1, pts, count in items:
+            q, t = host_survivors(self.O, block, nq, self.ratio)
+            pts.zero_()
+            if len(q):
+                pts[:, :len(q)] = torch.from_numpy(self.O.triangulate(P0, P1, kp0.numpy()[q].T.copy(), kp1.numpy()[t].T.copy(), normalise_w=True))
+            count[0] = len(q)
+
+
+def host_survivors(O, block, nq, ratio=0.70):
+    """sfm.py:262-265 on a gathered KNN block, by the oracle."""
+    q, t, _ = O.ratio_filter(block[0, :nq].numpy(), block[1, :nq].numpy().view(np.float32), ratio)
+    return q, t
+
+
+def host_merge_top2(gathered):
+    """sfm_knn_merge_top2 on host tensors: order by (distance, global trainIdx) with two stable sorts."""
+    world, _, nq, _ = gathered.shape
+    cand_i = gathered[:, 0].permute(1, 0, 2).reshape(nq, 2 * world)
+    cand_d = gathered[:, 1].permute(1, 0, 2).reshape(nq, 2 * world).contiguous().view(torch.float32)
+    cand_d = torch.where(cand_i >= 0, cand_d, torch.full_like(cand_d, float("inf")))
+    key_i = torch.where(cand_i >= 0, cand_i, torch.full_like(cand_i, 2 ** 31 - 1))
+    o1 = torch.sort(key_i, dim=1, stable=True).indices
+    o2 = torch.sort(torch.gather(cand_d, 1, o1), dim=1, stable=True).indices
+    order = torch.gather(o1, 1, o2)[:, :2]
+    out_i = torch.gather(cand_i, 1, order)
+    out_d = torch.gather(cand_d, 1, order)
+    return out_i.contiguous(), torch.where(out_i >= 0, out_d, torch.zeros_like(out_d)).contiguous()
+
+
 def _scene(n_images, seed):
     from datagen import planted_pair
     rng = np.random.default_rng(seed)          # same data on every rank
@@ -64,23 +102,18 @@ def _worker(rank, world, port, n_images, batch, ret, all_pairs=False, cyclic=Fal
     for p, (i, j) in enumerate(pairs):                                  # every pair's block, on every rank, = the oracle's
         wi, wd = O.knn2(des[i].numpy(), des[j].numpy())
         ok = ok and np.array_equal(store[p, 0, :nq[p]].numpy(), wi) and np.array_equal(store[p, 1, :nq[p]].numpy().view(np.float32), wd)
-        q, t = sharded.ratio_survivors(store[p], nq[p])
-        wq, wt, _ = O.ratio_filter(wi, wd, 0.70)
-        ok = ok and np.array_equal(q.numpy(), wq) and np.array_equal(t.numpy(), wt)
+        q, t = host_survivors(O, store[p], nq[p])
         total += len(q)
     # second exchange: triangulated points of the survivors (cameras replicated)
     K, P = load_pose_csv()
 
-    def tri(P1, P2, x1, x2):
-        return torch.from_numpy(O.triangulate(P1, P2, x1.numpy(), x2.numpy(), normalise_w=True))
-
-    pts, counts = sharded.triangulate_pairs_sharded(store, nq, pairs, held_kp, list(P[:n_images]), triangulate=tri, batch=batch, partition=part)
+    pts, counts = sharded.triangulate_pairs_sharded(store, nq, pairs, held_kp, list(P[:n_images]), engine=OracleTriEngine(O), batch=batch, partition=part)
     for p, (i, j) in enumerate(pairs):
-        q, t = sharded.ratio_survivors(store[p], nq[p])
+        q, t = host_survivors(O, store[p], nq[p])
         m = int(counts[p])
         ok = ok and m == len(q)
         if m:
-            want = O.triangulate(P[i], P[j], kps[i][q].numpy().T.copy(), kps[j][t].numpy().T.copy(), normalise_w=True)
+            want = O.triangulate(P[i], P[j], kps[i].numpy()[q].T.copy(), kps[j].numpy()[t].T.copy(), normalise_w=True)
             ok = ok and np.array_equal(pts[p, :, :m].numpy(), want) and float(pts[p, :, m:].abs().sum()) == 0.0
     ret[rank] = (bool(ok), hi - lo, total)
     dist.destroy_process_group()
@@ -158,7 +191,7 @@ def _train_split_worker(rank, world, port, ret):
         wi, wd = O.knn2(q, t)
         lo, hi = (0, cut) if rank == 0 else (cut, nt)
         knn = lambda a, b: tuple(torch.from_numpy(x) for x in O.knn2(a.numpy(), b.numpy()))
-        gi, gd = sharded.knn2_train_split(torch.from_numpy(q), torch.from_numpy(t[lo:hi]), lo, knn2=knn)
+        gi, gd = sharded.knn2_train_split(torch.from_numpy(q), torch.from_numpy(t[lo:hi]), lo, knn2=knn, merge=host_merge_top2)
         valid = wi >= 0
         ok = ok and np.array_equal(gi.numpy(), wi) and np.array_equal(gd.numpy()[valid], wd[valid])
     ret[rank] = bool(ok)
