@@ -55,10 +55,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="knn", choices=["knn", "tri", "ba", "sfm", "c5", "sift"])
+    ap.add_argument("--workload", default="knn", choices=["knn", "tri", "ba", "sfm", "c5", "sift", "allpairs"])
     ap.add_argument("--nq", type=int, default=10000)
     ap.add_argument("--nt", type=int, default=10000)
-    ap.add_argument("--images", type=int, default=256, help="workload c5: images in the sequence IN TOTAL (BASELINE config 5: 256)")
+    ap.add_argument("--images", type=int, default=None, help="workload c5: images in the sequence IN TOTAL (default 256 = BASELINE config 5); workload allpairs: images (default 64)")
+    ap.add_argument("--verify-images", type=int, default=6, help="workload allpairs: essential-matrix RANSAC + recoverPose (isfm.py:80-94) on the pairs among the first N images")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--pipe-depth", type=int, default=PIPE_DEPTH, help="launch sets in flight per GPU (1 = one stream)")
@@ -866,7 +867,7 @@ def bench_c5(args, world, rank, dev):
     from sfm_mvs_amd import sharded
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from datagen import load_pose_csv
-    n_img, n_desc, n_plant = max(2, args.images), 50_000, 15_000
+    n_img, n_desc, n_plant = max(2, args.images or 256), 50_000, 15_000
     pairs = sharded.sequential_pairs(n_img)
 
     # The exchange of a ONE-rank run goes through a real one-rank RCCL group (the same all_gather_into_tensor as at N > 1),
@@ -1004,6 +1005,101 @@ def _bench_c5(args, world, rank, dev, sharded, pairs, n_img, n_desc, n_plant, ex
     return out
 
 
+def bench_allpairs(args, world, rank, dev):
+    """isfm.py:56-94 — EXHAUSTIVE matching: every image against every earlier one (`--images` 64 -> 2 016 pairs of 10 000
+    x 10 000 SIFT-like descriptors), the pair grid dealt to the ranks by SURVEY 8e's 2-D block-cyclic split
+    (sharded.block_cyclic_partition: a rank holds the image blocks of one process-grid row and column only), KNN + ratio
+    through sharded.match_pairs_sharded with the all-gather of the KNN blocks inside the timed region.  STRONG scaling.
+    Then isfm.py:80-94 (findEssentialMat RANSAC + recoverPose, the printed inlier count) on the pairs among the first
+    `--verify-images` images through sharded.verify_pairs_sharded, with the oracle's counts beside them."""
+    from sfm_mvs_amd import sharded
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from datagen import ring_scene
+    import torch.distributed as dist
+    n_img, n_desc, n_scene = max(2, args.images or 64), 10_000, 7_000
+    xb = 4 * EXCH_BATCH                                          # pairs per collective: 5 MB blocks (a 10k-query pair is 160 KB; few, large collectives)
+    pairs = sharded.all_pairs(n_img)
+    part = sharded.block_cyclic_partition(pairs, n_img, world)
+    mine = sharded.halo_images(pairs, world, rank, part)
+    K, P, image = ring_scene(n_img, n_desc, n_scene, seed=11)
+    kps, des = [None] * n_img, [None] * n_img
+    for k in mine:
+        kp, d, _ = image(k)
+        kps[k], des[k] = torch.from_numpy(kp).to(dev), torch.from_numpy(d).to(dev)
+    own_group, exchange_kind = False, "RCCL all_gather_into_tensor"
+    if not (dist.is_available() and dist.is_initialized()):
+        try:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29542")
+            dist.init_process_group("nccl", device_id=dev, world_size=1, rank=0)
+            own_group, exchange_kind = True, "RCCL all_gather_into_tensor on a one-rank group created for this leg"
+        except Exception as e:      # noqa: BLE001
+            exchange_kind = f"local copy (no process group: {type(e).__name__})"
+    try:
+        eng = sharded.HipMatchEngine(dev, 0.70, depth=PIPE_DEPTH)
+        if len(mine) >= 2:                                       # warm-up: streams, kernels, the collective
+            wp = [(mine[0], mine[1])] * (world * xb)
+            sharded.match_pairs_sharded(des, wp, n_desc=[n_desc] * n_img, engine=eng, device=dev, batch=xb)
+        barrier_sync(world)
+        st = {}
+        t0 = time.perf_counter()
+        store, nq = sharded.match_pairs_sharded(des, pairs, n_desc=[n_desc] * n_img, engine=eng, device=dev, batch=xb, partition=part, stats=st)
+        barrier_sync(world)
+        elapsed = max_over_ranks(time.perf_counter() - t0, world, dev)
+        # geometric verification (isfm.py:80-94) of the pairs among the first images: every rank verifies the ones it owns
+        nv = min(n_img, max(2, args.verify_images))
+        only = {p for p, (j, i) in enumerate(pairs) if i < nv and j < nv}
+        need = sorted({i for p in only for i in pairs[p]})
+        for k in need:                                           # (a rank verifies only pairs it owns: their images are resident)
+            if kps[k] is None and any(int(p) in only for p in part[rank]):
+                kp, _, _ = image(k)
+                kps[k] = torch.from_numpy(kp).to(dev)
+        t1 = time.perf_counter()
+        counts = sharded.verify_pairs_sharded(store, nq, pairs, kps, K, partition=part, only=only)
+        t_verify = time.perf_counter() - t1
+    finally:
+        if own_group:
+            torch.cuda.synchronize()
+            dist.destroy_process_group()
+    n_pairs = len(pairs)
+    loads = [len(x) for x in part]
+    out = {"metric": "descriptor-pair distances/sec over an exhaustive pair list (BF-KNN k=2 + Lowe ratio), 2-D block-cyclic pair sharding",
+           "value": n_pairs * n_desc * n_desc / elapsed, "unit": "distances/s", "n_gpus": world, "steps": n_pairs, "warmup": xb,
+           "ms_per_step": elapsed / n_pairs * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": "f32 results; filter arithmetic exact-integer i8 MFMA (u8-integer descriptors)", "data": "synthetic",
+           "config": {"workload": f"isfm.py:56-94 exhaustive matching: {n_img} images x {n_desc} SIFT-like descriptors ({n_scene} scene points seen by every "
+                                  f"camera of a ring + clutter), all {n_pairs} pairs (j < i), block-cyclic over a {sharded.process_grid(world)[0]} x {sharded.process_grid(world)[1]} "
+                                  f"process grid; exchange = {exchange_kind}", "images": n_img, "descriptors": n_desc, "pairs": n_pairs,
+                      "parallelism": f"pair-sharded x{world} (sharded.block_cyclic_partition + match_pairs_sharded, 8 pairs per launch set, {xb} per collective)"},
+           "job_seconds": elapsed, "images_resident_on_this_rank": len(mine), "pairs_per_rank": loads,
+           "exchange": {"kind": exchange_kind, "match_records": st},
+           "verification": {"what": f"isfm.py:80-94 on the {len(only)} pairs among the first {nv} images: findEssentialMat(RANSAC, 0.999, 0.4) + recoverPose; inliers left per pair",
+                            "seconds": t_verify, "inliers": {f"{pairs[p][0]}-{pairs[p][1]}": int(counts[p]) for p in sorted(only)}}}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as O
+        t1 = time.perf_counter()
+        want, same_knn = {}, True
+        for p in sorted(only):
+            j, i = pairs[p]
+            (kj, dj, _), (ki, di, _) = image(j), image(i)
+            wi, wd = O.knn2(dj, di, nthreads=os.cpu_count() or 1)
+            same_knn = same_knn and np.array_equal(store[p, 0].cpu().numpy(), wi) and np.array_equal(store[p, 1].cpu().numpy().view(np.float32), wd)
+            q, t, _ = O.ratio_filter(wi, wd, 0.70)
+            E, m = O.find_essential_mat(kj[q], ki[t], K, 0.999, 0.4)
+            if E is None:
+                want[p] = -1
+                continue
+            keep = m.ravel() == 1
+            _, _, _, m2 = O.recover_pose(E, kj[q][keep], ki[t][keep], K)
+            want[p] = int((m2.ravel() > 0).sum())
+        dt = time.perf_counter() - t1
+        out["verification"]["oracle_inliers_identical"] = all(int(counts[p]) == want[p] for p in only)
+        out["verification"]["knn_blocks_identical_to_oracle"] = bool(same_knn)
+        out["cpu_baseline"] = {"value": len(only) * n_desc * n_desc / dt, "unit": "distances/s", "cores": os.cpu_count() or 1, "kind": "port",
+                               "sample": f"the same {len(only)} pairs end to end (KNN on all cores + sequential ratio / E-RANSAC / recoverPose), oracle, {dt:.1f} s"}
+    return out
+
+
 def bench_sift(args, world, rank, dev):
     """cv2 SIFT detectAndCompute on frames of the reference's working size (sfm.py:40 halves the
     1936 x 1296 photographs to 968 x 648).  No dataset on the box: procedural frames (tests/datagen.scene_image), a
@@ -1128,6 +1224,8 @@ def main():
         out = bench_c5(args, world, rank, dev)
     elif args.workload == "sift":
         out = bench_sift(args, world, rank, dev)
+    elif args.workload == "allpairs":
+        out = bench_allpairs(args, world, rank, dev)
     else:
         out = bench_ba(args, world, rank, dev)
     if rank == 0:

@@ -161,31 +161,52 @@ class BatchedExchange:
 
 
 class HipMatchEngine:
-    """KNN + ratio of one pair into a caller-provided KNN block, pipelined over HIP streams (ops.PairPipeline)."""
+    """KNN + ratio of image pairs into caller-provided KNN blocks: pairs of one shape are issued up to 8 per launch set
+    (ops.BatchPipeline -> sfm_match_batch_l2_f32: one prep / filter / refine / scatter launch for the batch), launch sets
+    pipelined over `depth` HIP streams.  `flush()` launches what is queued (the exchange calls it before a collective)."""
 
-    def __init__(self, device, ratio=0.70, depth=3):
-        self.device, self.ratio, self.depth = torch.device(device), ratio, depth
+    def __init__(self, device, ratio=0.70, depth=3, batch=8):
+        self.device, self.ratio, self.depth, self.batch = torch.device(device), ratio, depth, batch
         self.pipes = {}
+        self._padded = {}                                  # per pipe: (block, nq) of queued pairs whose block is wider than nq
 
     @property
     def streams(self):
         return [st for p in self.pipes.values() for st in p.streams]
 
     def match(self, des0, des1, block, after=None):
-        """block: int32 [2][cap][2] view (cap >= nq) receiving (trainIdx x2, distance bits x2) of the nq queries."""
+        """block: int32 [2][cap][2] view (cap >= nq) receiving (trainIdx x2, distance bits x2) of the nq queries.
+        after = None (no free-event yet: the first rounds): the pair waits for everything already enqueued on the caller's
+        current stream — descriptors still being produced there (an asynchronous SIFT or upload) are safe to pass in."""
         from . import ops
         nq, nt = des0.shape[0], des1.shape[0]
-        pipe = self.pipes.get((nq, nt))
+        key = (nq, nt)
+        pipe = self.pipes.get(key)
         if pipe is None:
-            pipe = self.pipes[(nq, nt)] = ops.PairPipeline(nq, nt, self.device, ratio=self.ratio, depth=self.depth)
+            pipe = self.pipes[key] = ops.BatchPipeline(nq, nt, self.device, ratio=self.ratio, depth=self.depth, batch=self.batch)
+            self._padded[key] = []
         direct = block.shape[1] == nq and block.is_contiguous()
-        # after = None (no free-event yet: the first rounds): the pair waits for everything already enqueued on the caller's
-        # current stream — descriptors still being produced there (an asynchronous SIFT or upload) are safe to pass in
-        slot, st, out = pipe.submit(des0, des1, after=after, result=block if direct else None)
+        if pipe._pairs and direct != (not self._padded[key]):      # a launch set writes either into blocks or into its own result
+            self._launch(key, pipe.flush())
         if not direct:
-            with torch.cuda.stream(st):
-                block[0, :nq].copy_(out[0], non_blocking=True)
-                block[1, :nq].copy_(out[1].view(torch.int32), non_blocking=True)
+            self._padded[key].append(block)
+        self._launch(key, pipe.submit(des0, des1, after=after, result=block if direct else None))
+
+    def _launch(self, key, rec):
+        """rec: BatchPipeline's launch record (or None: the batch is still filling).  Padded blocks get their rows copied
+        behind the launch set, on its stream."""
+        if rec is None or not self._padded[key]:
+            return
+        _, st, bm, n = rec
+        nq = key[0]
+        with torch.cuda.stream(st):
+            for b, block in enumerate(self._padded[key][:n]):
+                block[:, :nq].copy_(bm.result[b], non_blocking=True)
+        self._padded[key] = self._padded[key][n:]
+
+    def flush(self):
+        for key, pipe in self.pipes.items():
+            self._launch(key, pipe.flush())
 
 
 def ratio_survivors(block, nq, ratio=0.70):
@@ -247,6 +268,7 @@ def match_pairs_sharded(descriptors, pairs, n_desc=None, engine=None, group=None
             slot, ev = ex.next_slot()
             engine.match(descriptors[i], descriptors[j], slot, after=ev)
             ex.commit()
+        getattr(engine, "flush", lambda: None)()           # (engines that batch their launches: issue what is queued)
         gathered, _ = ex.flush(getattr(engine, "streams", ()))
         # scatter the round's blocks to their pairs in ONE indexed copy (unused slots go to the dump row)
         store.index_copy_(0, dst[rd], gathered.reshape((world * batch,) + gathered.shape[2:]))
@@ -295,6 +317,61 @@ def triangulate_pairs_sharded(store, n_query, pairs, keypoints, proj, engine=Non
     if stats is not None:
         stats.update(exchange_ms=ex.exchange_ms() if ex.cuda else 0.0, collectives=ex.collectives, bytes_per_rank_per_collective=batch * width * 4)
     return points[:n_pairs, :4 * cap].view(n_pairs, 4, cap), counts
+
+
+class HipVerifyEngine:
+    """isfm.py:73-94 for one matched pair on the device: Lowe survivors -> keypoint gather -> cv2.findEssentialMat(RANSAC,
+    prob 0.999, threshold 0.4) -> rows with mask == 1 -> cv2.recoverPose -> rows with mask > 0; returns how many correspondences
+    are left (the number isfm.py prints) or -1 when no essential matrix was found / fewer than five survivors."""
+
+    def __init__(self, K, ratio=0.70):
+        self.K, self.ratio = K, ratio
+
+    def verify(self, block, nq, kp0, kp1):
+        from . import ops, ransac
+        out_q, out_t, count = ops.ratio_compact(block[0, :nq], block[1, :nq].view(torch.float32), self.ratio)
+        pts0, pts1 = ops.gather_matches(kp0, kp1, out_q, out_t, count)
+        m = int(count.item())
+        if m < 5:
+            return -1
+        pts0, pts1 = pts0[:m], pts1[:m]
+        E, mask = ransac.find_essential_mat(pts0, pts1, self.K, 0.999, 0.4, return_device_mask=True)
+        if E is None:
+            return -1
+        keep = mask.ravel() == 1                               # isfm.py:81-82 (OpenCV's {0,1} mask)
+        pts0, pts1 = pts0[keep], pts1[keep]
+        _, _, _, mask = ransac.recover_pose(E[:3], pts0, pts1, self.K, return_device_mask=True)
+        return int((mask.ravel() > 0).sum().item())            # isfm.py:84-86 ({0,255} mask)
+
+
+def verify_pairs_sharded(store, n_query, pairs, keypoints, K, engine=None, group=None, ratio=0.70, partition=None, only=None):
+    """isfm.py:73-94 over a matched pair list: every rank verifies ITS pairs (essential-matrix RANSAC + cheirality vote on
+    the Lowe survivors of the gathered KNN blocks), the per-pair inlier counts — one integer per pair — are exchanged in one
+    all-gather.  only: optional set of pair indices to verify (others report -2).  engine: `verify(block, nq, kp0, kp1) ->
+    int` as HipVerifyEngine (the default).  Returns int64 [n_pairs] on every rank."""
+    world, rank = _world_rank(group)
+    n_pairs = len(pairs)
+    engine = engine or HipVerifyEngine(K, ratio)
+    partition = partition or contiguous_partition(n_pairs, world)
+    per = max((len(part) for part in partition), default=0)
+    local = torch.full((max(per, 1),), -2, dtype=torch.int64)
+    for k, p in enumerate(partition[rank]):
+        p = int(p)
+        if only is None or p in only:
+            i, j = pairs[p]
+            local[k] = engine.verify(store[p], int(n_query[p]), keypoints[i], keypoints[j])
+    dev = store.device
+    gathered = torch.empty((world, max(per, 1)), dtype=torch.int64, device=dev)
+    if dist.is_available() and dist.is_initialized():
+        dist.all_gather_into_tensor(gathered.view(-1), local.to(dev), group=group)
+    else:
+        gathered[0].copy_(local)
+    gathered = gathered.cpu()
+    out = torch.full((n_pairs,), -2, dtype=torch.int64)
+    for r, part in enumerate(partition):
+        if len(part):
+            out[torch.from_numpy(np.asarray(part, dtype=np.int64))] = gathered[r, :len(part)]
+    return out
 
 
 def knn2_train_split(des0, des1_shard, train_offset, knn2=None, merge=None, group=None):

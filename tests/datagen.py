@@ -200,3 +200,38 @@ def layered_views(n_views, w, h, seed, f=None, baseline=0.25, depths=(10.0, 6.0,
         Rt = np.hstack([np.eye(3), np.array([[-b], [0.0], [0.0]])])
         P.append(K @ Rt)
     return images, K, P
+
+
+def ring_scene(n_images, n_desc, n_scene, seed=0, desc_noise=1.5, pix_noise=0.3):
+    """An exhaustive-matching scene (isfm.py:56-94): `n_images` cameras on a ring (K of pose.csv) look at `n_scene` points of
+    the unit ball; every image holds the projections of ALL scene points (+ pixel noise) with a persistent SIFT-like
+    descriptor (+ integer noise per view) and n_desc - n_scene clutter features, shuffled per image.  Every image has exactly
+    n_desc features, so the pairs share one shape.  Image k is a function of (seed, k) alone: every rank of a sharded run
+    generates identical images without communicating.  Returns K, P [n,3,4], image(k) -> (kp (n_desc,2) f32, des (n_desc,128)
+    f32, ids (n_desc,) scene-point id or -1)."""
+    K, _ = load_pose_csv()
+    cams = ring_cameras(n_images)
+    rng = np.random.default_rng(seed)
+    X = rng.normal(size=(n_scene, 3))
+    X = X / np.maximum(np.linalg.norm(X, axis=1, keepdims=True), 1.0) * rng.uniform(0.2, 1.0, (n_scene, 1))
+    base = sift_like(rng, n_scene)
+    P = np.empty((n_images, 3, 4))
+    for k in range(n_images):
+        th = np.linalg.norm(cams[k, :3])
+        kx = cams[k, :3] / th if th > 0 else np.zeros(3)
+        Kx = np.array([[0, -kx[2], kx[1]], [kx[2], 0, -kx[0]], [-kx[1], kx[0], 0]])
+        R = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * (Kx @ Kx)
+        P[k] = K @ np.c_[R, cams[k, 3:]]
+
+    def image(k):
+        r = np.random.default_rng([seed, 1000 + k])
+        x, _ = project(P[k], X)
+        kp = (x + r.normal(0, pix_noise, x.shape)).astype(np.float32)
+        des = np.clip(base + np.rint(r.normal(0, desc_noise, base.shape)), 0, 255).astype(np.float32)
+        nc = n_desc - n_scene
+        ckp = r.uniform([1, 1], [967, 647], (nc, 2)).astype(np.float32)
+        cdes = sift_like(r, nc)
+        order = r.permutation(n_desc)
+        return np.vstack([kp, ckp])[order], np.vstack([des, cdes])[order], np.hstack([np.arange(n_scene), -np.ones(nc, int)])[order]
+
+    return K, P, image

@@ -375,6 +375,45 @@ def test_sharded_path_on_one_gpu(hip, oracle):
     assert np.array_equal(gi.cpu().numpy(), wi) and np.array_equal(gd.cpu().numpy(), wd)
 
 
+def test_batched_match_engine_padded_blocks_and_exhaustive_verification(hip, oracle):
+    """(1) sharded.HipMatchEngine issues pairs of one shape up to 8 per launch set: a sequence whose shapes repeat with fewer
+    queries than the block has rows (padded blocks, copied behind the launch set) and with exactly as many (written in place),
+    batches of 3.  (2) isfm.py:56-94 on a 5-image ring scene: all 10 pairs matched, then findEssentialMat + recoverPose per
+    pair through sharded.verify_pairs_sharded — the printed inlier counts equal the oracle twin's."""
+    import torch
+    from datagen import ring_scene
+    from sfm_mvs_amd import sharded
+    rng = np.random.default_rng(9)
+    sizes = [512, 512, 512, 700, 700, 700, 300]
+    des = [planted_pair(rng, n, 10, 0.0)[0] for n in sizes]
+    for k in range(len(sizes) - 1):
+        m = min(sizes[k], sizes[k + 1]) // 2
+        des[k + 1][:m] = des[k][rng.permutation(sizes[k])[:m]]
+    pairs = sharded.sequential_pairs(len(sizes))
+    store, nq = sharded.match_pairs_sharded([torch.from_numpy(d).cuda() for d in des], pairs, batch=3)
+    torch.cuda.synchronize()
+    for p, (i, j) in enumerate(pairs):
+        wi, wd = oracle.knn2(des[i], des[j])
+        assert np.array_equal(store[p, 0, :nq[p]].cpu().numpy(), wi), p
+        assert np.array_equal(store[p, 1, :nq[p]].cpu().numpy().view(np.float32), wd), p
+    K, P, image = ring_scene(5, 1500, 1000, seed=4)
+    imgs = [image(k) for k in range(5)]
+    pairs = sharded.all_pairs(5)
+    store, nq = sharded.match_pairs_sharded([torch.from_numpy(im[1]).cuda() for im in imgs], pairs, batch=4)
+    kps = [torch.from_numpy(im[0]).cuda() for im in imgs]
+    got = sharded.verify_pairs_sharded(store, nq, pairs, kps, K)
+    for p, (j, i) in enumerate(pairs):
+        wi, wd = oracle.knn2(imgs[j][1], imgs[i][1])
+        assert np.array_equal(store[p, 0].cpu().numpy(), wi) and np.array_equal(store[p, 1].cpu().numpy().view(np.float32), wd)
+        q, t, _ = oracle.ratio_filter(wi, wd, 0.70)
+        assert len(q) > 900
+        a, b = imgs[j][0][q], imgs[i][0][t]
+        E, m = oracle.find_essential_mat(a, b, K, 0.999, 0.4)
+        keep = m.ravel() == 1
+        want = int((oracle.recover_pose(E, a[keep], b[keep], K)[3].ravel() > 0).sum())
+        assert int(got[p]) == want and want > 100, (p, int(got[p]), want)
+
+
 def test_train_split_merge_kernel_equals_a_single_scan(hip, oracle):
     """sfm_knn_merge_top2 (SURVEY 8e's train-split fallback): partial 2-NN results of S shards of the train set, merged by
     (distance, global trainIdx), equal the single scan — including exact ties across shards (duplicated train rows: the

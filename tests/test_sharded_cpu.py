@@ -45,6 +45,24 @@ class OracleTriEngine:
             count[0] = len(q)
 
 
+class OracleVerifyEngine:
+    """CPU stand-in for sharded.HipVerifyEngine: isfm.py:73-94 by the oracle."""
+
+    def __init__(self, oracle, K, ratio=0.70):
+        self.O, self.K, self.ratio = oracle, K, ratio
+
+    def verify(self, block, nq, kp0, kp1):
+        q, t = host_survivors(self.O, block, nq, self.ratio)
+        if len(q) < 5:
+            return -1
+        a, b = kp0.numpy()[q], kp1.numpy()[t]
+        E, m = self.O.find_essential_mat(a, b, self.K, 0.999, 0.4)
+        if E is None:
+            return -1
+        keep = m.ravel() == 1
+        return int((self.O.recover_pose(E, a[keep], b[keep], self.K)[3].ravel() > 0).sum())
+
+
 def host_survivors(O, block, nq, ratio=0.70):
     """sfm.py:262-265 on a gathered KNN block, by the oracle."""
     q, t, _ = O.ratio_filter(block[0, :nq].numpy(), block[1, :nq].numpy().view(np.float32), ratio)
@@ -115,6 +133,15 @@ def _worker(rank, world, port, n_images, batch, ret, all_pairs=False, cyclic=Fal
         if m:
             want = O.triangulate(P[i], P[j], kps[i].numpy()[q].T.copy(), kps[j].numpy()[t].T.copy(), normalise_w=True)
             ok = ok and np.array_equal(pts[p, :, :m].numpy(), want) and float(pts[p, :, m:].abs().sum()) == 0.0
+    if all_pairs:
+        # isfm.py:80-94 on every pair, sharded: each rank verifies its own pairs, one all-gather of the counts
+        eng_v = OracleVerifyEngine(O, K)
+        got = sharded.verify_pairs_sharded(store, nq, pairs, held_kp, K, engine=eng_v, partition=part)
+        only = {0, len(pairs) - 1}
+        part_got = sharded.verify_pairs_sharded(store, nq, pairs, held_kp, K, engine=eng_v, partition=part, only=only)
+        for p, (i, j) in enumerate(pairs):
+            want = eng_v.verify(store[p], nq[p], kps[i], kps[j])
+            ok = ok and int(got[p]) == want and int(part_got[p]) == (want if p in only else -2)
     ret[rank] = (bool(ok), hi - lo, total)
     dist.destroy_process_group()
 
@@ -146,6 +173,15 @@ def test_two_rank_all_pairs_block_cyclic():
     ret = mp.Manager().dict()
     mp.spawn(_worker, args=(2, 29525, 7, 4, ret, True, True), nprocs=2, join=True)
     assert ret[0][0] and ret[1][0] and ret[0][1] + ret[1][1] == 21 and ret[0][2] == ret[1][2]
+
+
+def test_three_rank_all_pairs_block_cyclic_uneven_grid():
+    """Three ranks (a 1 x 3 process grid: the tiles of the pair triangle do not divide evenly), 7 images -> 21 pairs dealt
+    9 / 6 / 6 or similar: blocks, points and the isfm.py:80-94 inlier counts arrive on every rank."""
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(3, 29527, 7, 4, ret, True, True), nprocs=3, join=True)
+    assert all(ret[r][0] for r in range(3)) and sum(ret[r][1] for r in range(3)) == 21 and len({ret[r][2] for r in range(3)}) == 1
+    assert len({ret[r][1] for r in range(3)}) > 1          # uneven loads
 
 
 def test_block_cyclic_partition_covers_all_pairs_with_small_halos():
