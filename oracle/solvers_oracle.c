@@ -1014,10 +1014,64 @@ int orc_pnp_dlt_init(const double* X, const double* uv, int64_t n, const double*
     return 0;
 }
 
+/* The 28 sums of one Levenberg-Marquardt sweep — upper triangle of J^T J (21), J^T e (6), |e|^2 — in ONE FIXED TREE, the same
+ * in this file and in csrc/ransac.hip (pnp_sweep_kernel / pnp_sweep_fold_kernel).  OpenCV forms them with cvMulTransposed /
+ * cvGEMM / cvNorm, whose SIMD summation order is not pinned by anything in the reference; a plain sequential sum here and a
+ * parallel one on the device would differ in the last bits, LM's accept / reject test (errNorm > prevErrNorm) would now and
+ * then go the other way, and because every camera is registered against points triangulated from the earlier ones the two
+ * 57-camera chains would drift apart by a factor ~2.5 per frame.  With one tree both sides are bit-identical:
+ *   term of point o:   Ju[a] Ju[b] + Jv[a] Jv[b]   |   Ju[a] ru + Jv[a] rv   |   ru ru + rv rv      (u-row product first)
+ *   slots:             G = min(ceil(n / 1024), 64) groups of 1024 slots; point o goes to slot o mod 1024 G and a slot adds its
+ *                      points in increasing o, starting from 0
+ *   a group:           16 runs of 64 consecutive slots; a run is folded by the butterfly  v[l] += v[l ^ s], s = 32, 16, .. 1
+ *                      (all 64 values at once; the result is read at l = 0); the group's sum = 0 + run 0 + run 1 + ... + run 15
+ *   total:             G = 1: the group's sum;  G > 1: 0 + group 0 + group 1 + ...                                          */
+#define LM_SLOTS 1024
+#define LM_MAXG 64
+static void lm_tree_sums(const double* J /*2n x 6 or NULL*/, const double* err /*2n*/, int64_t n, double* out /*28*/) {
+    int64_t G = (n + LM_SLOTS - 1) / LM_SLOTS;
+    if (G > LM_MAXG) G = LM_MAXG;
+    if (G < 1) G = 1;
+    const int first = J ? 0 : 27;
+    double* acc = (double*)calloc((size_t)(G * LM_SLOTS) * 28, sizeof(double));
+    for (int64_t o = 0; o < n; ++o) {
+        double* a = acc + 28 * (o % (G * LM_SLOTS));
+        const double ru = err[2 * o], rv = err[2 * o + 1];
+        a[27] += ru * ru + rv * rv;
+        if (J) {
+            const double* ju = J + 12 * o;
+            const double* jv = ju + 6;
+            int q = 0;
+            for (int i = 0; i < 6; ++i)
+                for (int j = i; j < 6; ++j) a[q++] += ju[i] * ju[j] + jv[i] * jv[j];
+            for (int i = 0; i < 6; ++i) a[21 + i] += ju[i] * ru + jv[i] * rv;
+        }
+    }
+    for (int k = first; k < 28; ++k) {
+        double total = 0;
+        for (int64_t g = 0; g < G; ++g) {
+            double grp = 0;
+            for (int w = 0; w < LM_SLOTS / 64; ++w) {
+                double v[64], t[64];
+                for (int l = 0; l < 64; ++l) v[l] = acc[28 * (g * LM_SLOTS + 64 * w + l) + k];
+                for (int sft = 32; sft >= 1; sft >>= 1) {
+                    for (int l = 0; l < 64; ++l) t[l] = v[l] + v[l ^ sft];
+                    memcpy(v, t, sizeof(v));
+                }
+                grp += v[0];
+            }
+            if (G == 1) total = grp;
+            else total += grp;
+        }
+        out[k] = total;
+    }
+    free(acc);
+}
+
 int orc_levmarq_pose(const double* X, const double* uv, int64_t n, const double* K, double* rvec, double* tvec, int* iters_out) {
     const int max_iter = 20;
     const double epsilon = FLT_EPSILON, LOG10 = log(10.);
-    double param[6], prev[6], JtJ[36], JtErr[6];
+    double param[6], prev[6], JtJ[36], JtErr[6], sums[28];
     double* J = (double*)malloc(sizeof(double) * 12 * (size_t)n);
     double* err = (double*)malloc(sizeof(double) * 2 * (size_t)n);
     memcpy(param, rvec, 3 * sizeof(double));
@@ -1038,28 +1092,26 @@ int orc_levmarq_pose(const double* X, const double* uv, int64_t n, const double*
     do {                                                                             \
         project_jac(param, param + 3, K, X, n, err, NULL);                           \
         for (int64_t i_ = 0; i_ < 2 * n; ++i_) err[i_] = err[i_] - uv[i_];           \
+        lm_tree_sums(NULL, err, n, sums);                                            \
     } while (0)
     for (;;) {
         /* STARTED / CALC_J: Jacobian and error at `param` */
         project_jac(param, param + 3, K, X, n, err, J);
         for (int64_t i = 0; i < 2 * n; ++i) err[i] = err[i] - uv[i];
-        for (int a = 0; a < 6; ++a) {
-            for (int b = 0; b < 6; ++b) {
-                double s = 0;
-                for (int64_t r = 0; r < 2 * n; ++r) s += J[6 * r + a] * J[6 * r + b];
-                JtJ[6 * a + b] = s;
-            }
-            double s = 0;
-            for (int64_t r = 0; r < 2 * n; ++r) s += J[6 * r + a] * err[r];
-            JtErr[a] = s;
+        lm_tree_sums(J, err, n, sums);
+        {
+            int q = 0;
+            for (int a = 0; a < 6; ++a)
+                for (int b = a; b < 6; ++b) JtJ[6 * a + b] = JtJ[6 * b + a] = sums[q++];
+            for (int a = 0; a < 6; ++a) JtErr[a] = sums[21 + a];
         }
         memcpy(prev, param, sizeof(prev));
+        if (iters == 0) prevErrNorm = sqrt(sums[27]);
         LM_STEP();
-        if (iters == 0) prevErrNorm = norm_l2(err, (int)(2 * n));
         LM_ERR();
         /* CHECK_ERR */
         for (;;) {
-            errNorm = norm_l2(err, (int)(2 * n));
+            errNorm = sqrt(sums[27]);
             if (errNorm > prevErrNorm) {
                 if (++lambdaLg10 <= 16) {
                     LM_STEP();

@@ -50,7 +50,15 @@ __global__ __launch_bounds__(256) void k_normalise_kernel(const float* __restric
 // (R, t, K) in fp64, residual against the float32 observation, and — mode 1 — the 2x6 Jacobian rows of OpenCV's
 // projectPoints (dp/drvec through dR/drvec, dp/dtvec) folded into the upper triangle of J^T J (21), J^T e (6) and
 // |e|^2.  R, t and dR/dr arrive as kernel arguments (computed on the host, so the sweep has no transcendental math).
-// Sums are reduced in a fixed order (lane tree -> waves -> workgroups): deterministic, no atomics.
+// Sums are reduced in ONE FIXED TREE — the same tree oracle/solvers_oracle.c (lm_tree_sums) walks, so that Levenberg-Marquardt's
+// accept / reject tests, hence the refined pose, hence the whole camera chain, are bit-reproducible between the two:
+//   term of point o:  Ju[a] Ju[b] + Jv[a] Jv[b]  |  Ju[a] ru + Jv[a] rv  |  ru ru + rv rv
+//   slots:            G = min(ceil(m / 1024), 64) workgroups of 1024 lanes; point o -> lane o mod 1024 G, a lane adds its points
+//                     in increasing o starting from 0
+//   workgroup:        each wave folds its 64 lanes by the butterfly v[l] += v[l ^ s], s = 32 .. 1; the workgroup's sum is
+//                     0 + wave 0 + ... + wave 15
+//   total:            G = 1: the workgroup's sum;  G > 1: 0 + workgroup 0 + workgroup 1 + ...   (pnp_sweep_fold_kernel)
+// (OpenCV's own order — cvMulTransposed / cvGEMM / cvNorm SIMD loops — is not pinned by anything in the reference.)
 struct PnpCam {
     double R[9], t[3], dR[27], fx, fy, cx, cy;
 };

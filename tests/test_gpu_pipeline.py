@@ -207,24 +207,29 @@ def test_every_frame_of_the_57_camera_chain_teacher_forced(hip, oracle):
 
 
 def test_free_running_chain_drift(hip, oracle):
-    """The two drivers running FREE on the same sequence: once on the HIP back-end, once with every numeric operator — RANSAC
-    entry points and their minimal solvers included — replaced by the CPU oracle's sequential restatements.  Integer
-    decisions stay identical (array shapes); the numbers drift apart because every camera is registered against float32
-    points triangulated from the earlier ones and the Levenberg-Marquardt accept / reject tests of the two sides compare
-    error norms that differ in the last bits (~1e-10).  north_star's 1e-4 is held over the first 8 frames, 1e-3 over 12;
-    per-frame parity over the whole chain is test_every_frame_of_the_57_camera_chain_teacher_forced."""
+    """Row D at north_star's closing bar: the two drivers running FREE over the WHOLE 57-camera Gustav-geometry sequence
+    (sfm.py:341-409) — once on the HIP back-end, once with every numeric operator, RANSAC entry points and their minimal
+    solvers included, replaced by the CPU oracle's sequential restatements.  Every camera is registered against float32
+    points triangulated from the earlier ones, so any last-bit difference is amplified ~2.5x per frame (rounds 1-3 held
+    1e-4 over 6-8 frames only).  Since round 4 the one floating-point reduction whose order differed between the two sides —
+    the 28 sums of solvePnP's Levenberg-Marquardt sweep — follows ONE fixed tree in csrc/ransac.hip and
+    oracle/solvers_oracle.c, and the chain is reproduced to the bit: identical shapes (integer decisions), poses, cloud and
+    per-frame errors within 1e-4 relative over all 55 registrations (measured differences are printed; expected 0)."""
     from sfm_mvs_amd import pipeline as pl
-    K, P, feats, ids = gustav_scene(12, seed=7, pix_noise=0.2)
-    got = pl.run_sfm(feats, K)
-    want = pl.run_sfm(feats, K, be=oracle_pipeline_backend(oracle))
-    assert got["posearr"].shape == want["posearr"].shape and got["Xtot"].shape == want["Xtot"].shape
-    assert got["first_error"] == pytest.approx(want["first_error"], rel=1e-6)
-    assert np.allclose(got["posearr"][:9 + 12 * 8], want["posearr"][:9 + 12 * 8], rtol=1e-6, atol=1e-4)
-    assert np.allclose(got["errors"][:6], want["errors"][:6], rtol=1e-4, atol=0)
-    assert np.allclose(got["errors"], want["errors"], rtol=1e-3, atol=0)
-    assert np.allclose(got["Xtot"], want["Xtot"], rtol=1e-4, atol=1e-5)
-    drift = [abs(a - b) / b for a, b in zip(got["errors"], want["errors"])]
-    print("free-running relative error drift per frame:", ["%.1e" % d for d in drift])
+    for n, seed, noise in ((57, 3, 0.0), (57, 5, 0.0), (11, 7, 0.2)):      # (with pixel noise the synthetic sequence runs out of new points at frame 12: the reference would divide by len(p) = 0 there too)
+        K, P, feats, ids = gustav_scene(n, seed=seed, pix_noise=noise)
+        got = pl.run_sfm(feats, K)
+        want = pl.run_sfm(feats, K, be=oracle_pipeline_backend(oracle))
+        assert got["posearr"].shape == want["posearr"].shape == (9 + 12 * n,) and got["Xtot"].shape == want["Xtot"].shape
+        assert len(got["errors"]) == len(want["errors"]) == n - 2
+        dP = np.abs(got["posearr"] - want["posearr"]).reshape(-1)[9:].reshape(n, 12).max(1) / np.abs(want["posearr"][9:]).reshape(n, 12).max(1)
+        dE = np.array([abs(a - b) / b for a, b in zip(got["errors"], want["errors"])])
+        dX = np.abs(got["Xtot"] - want["Xtot"]).max() / np.abs(want["Xtot"]).max()
+        print(f"free-running chain, {n} cameras (seed {seed}, pixel noise {noise}): max rel diff P {dP.max():.2e} (frame {int(dP.argmax())}), "
+              f"error {dE.max():.2e} (frame {int(dE.argmax())}), cloud {dX:.2e}; bit-identical poses: {bool(np.array_equal(got['posearr'], want['posearr']))}, "
+              f"cloud: {bool(np.array_equal(got['Xtot'], want['Xtot']))}")
+        assert got["first_error"] == pytest.approx(want["first_error"], rel=1e-6)
+        assert dP.max() <= 1e-4 and dE.max() <= 1e-4 and dX <= 1e-4, (dP.max(), dE.max(), dX)
 
 
 def test_driver_with_bundle_adjustment_enabled(hip, oracle):
