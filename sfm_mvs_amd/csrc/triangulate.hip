@@ -11,6 +11,7 @@
 // spreading it over 64 lanes would leave >90 % of the wave idle and add cross-lane traffic, so a
 // lane owns a point and a wave solves 64 points in lockstep.
 #include "common.h"
+#include <algorithm>
 #include <cfloat>
 #include <cstdlib>
 
@@ -128,7 +129,9 @@ __device__ __forceinline__ void dlt_nullvec(double (&At)[4][M], double (&X)[4]) 
     for (int k = 0; k < 4; ++k) X[k] = id[3] == 0 ? V[0][k] : id[3] == 1 ? V[1][k] : id[3] == 2 ? V[2][k] : V[3][k];
 }
 
-template <int M>
+// FUSED: x * P3 - P1 as one fma (the fast path's own system: its result is only kept where it provably casts like the
+// faithful one's); the faithful path rounds the product and the difference separately, as the reference's arithmetic does.
+template <int M, bool FUSED = false>
 __device__ __forceinline__ void dlt_build(double (&At)[4][M], const double* __restrict__ Pa, const double* __restrict__ Pb,
                                           double xa, double ya, double xb, double yb) {
     constexpr int PER = M / 2;
@@ -138,8 +141,13 @@ __device__ __forceinline__ void dlt_build(double (&At)[4][M], const double* __re
         const double x = v == 0 ? xa : xb, y = v == 0 ? ya : yb;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            At[k][v * PER + 0] = x * P[8 + k] - P[k];
-            At[k][v * PER + 1] = y * P[8 + k] - P[4 + k];
+            if constexpr (FUSED) {
+                At[k][v * PER + 0] = fma(x, P[8 + k], -P[k]);
+                At[k][v * PER + 1] = fma(y, P[8 + k], -P[4 + k]);
+            } else {
+                At[k][v * PER + 0] = x * P[8 + k] - P[k];
+                At[k][v * PER + 1] = y * P[8 + k] - P[4 + k];
+            }
             if (PER == 3) At[k][v * PER + 2] = x * P[4 + k] - y * P[k];
         }
     }
@@ -154,7 +162,29 @@ __device__ __forceinline__ void dlt_build(double (&At)[4][M], const double* __re
 // path + sfm.py:54 do, the result is BIT-IDENTICAL to it on > 99.9 % of points and within 1 ulp otherwise (the two
 // vectors differ by ~1e-10 before the cast).  A lane that has not converged after kFastIters steps (a start vector
 // orthogonal to the solution, lambda3 ~ lambda4: degenerate geometry) runs the Jacobi path instead.  Returns false then.
-constexpr int kFastIters = 12;
+#ifndef SFM_TRI_ITERS
+#define SFM_TRI_ITERS 12
+#endif
+#ifndef SFM_TRI_ABANDON
+#define SFM_TRI_ABANDON 0.0
+#endif
+constexpr int kFastIters = SFM_TRI_ITERS;
+constexpr double kFastAbandon = SFM_TRI_ABANDON;   // > 0: a lane whose step shrinks by less than this factor per iteration gives up (-> Jacobi)
+
+// 1 / d and 1 / sqrt(d) for the fast path (d > 0, far from the ends of the exponent range): the hardware estimate (v_rcp_f64 /
+// v_rsq_f64: ~2^-24 relative) and two Newton steps -> <= 1-2 ulp in 5 / 9 instructions instead of the 12 / 27 of the
+// correctly rounded division and square root.  The fast path does not need correct rounding — its result is compared against
+// float32 rounding boundaries with a margin >= 2^-40, 10^4 x these errors — the OpenCV-faithful Jacobi path keeps `/` and sqrt.
+__device__ __forceinline__ double fast_rcp(double d) {
+    double y = __builtin_amdgcn_rcp(d);
+    y = fma(fma(-d, y, 1.0), y, y);
+    return fma(fma(-d, y, 1.0), y, y);
+}
+__device__ __forceinline__ double fast_rsqrt(double d) {
+    double y = __builtin_amdgcn_rsq(d);
+    y = fma(0.5 * y, fma(-d, y * y, 1.0), y);
+    return fma(0.5 * y, fma(-d, y * y, 1.0), y);
+}
 
 __device__ __forceinline__ bool dlt_nullvec_fast(const double (&At)[4][4], double (&X)[4], double* sens = nullptr) {
     // M = A^T A (At[k] is column k of A)
@@ -170,18 +200,28 @@ __device__ __forceinline__ bool dlt_nullvec_fast(const double (&At)[4][4], doubl
         }
     const double mu = 1e-12 * (m[0][0] + m[1][1] + m[2][2] + m[3][3]);
     // LDL^T of M + mu I
-    const double d0 = m[0][0] + mu, r0 = 1.0 / d0;
+    const double d0 = m[0][0] + mu;
+    if (!(d0 > 0)) return false;
+    const double r0 = fast_rcp(d0);
     const double l10 = m[1][0] * r0, l20 = m[2][0] * r0, l30 = m[3][0] * r0;
-    const double d1 = fma(-l10, m[1][0], m[1][1] + mu), r1 = 1.0 / d1;
+    const double d1 = fma(-l10, m[1][0], m[1][1] + mu);
+    if (!(d1 > 0)) return false;
+    const double r1 = fast_rcp(d1);
     const double l21 = fma(-l20, m[1][0], m[2][1]) * r1, l31 = fma(-l30, m[1][0], m[3][1]) * r1;
     const double t21 = l21 * d1, t31 = l31 * d1;
-    const double d2 = fma(-l21, t21, fma(-l20, m[2][0], m[2][2] + mu)), r2 = 1.0 / d2;
+    const double d2 = fma(-l21, t21, fma(-l20, m[2][0], m[2][2] + mu));
+    if (!(d2 > 0)) return false;
+    const double r2 = fast_rcp(d2);
     const double l32 = fma(-l31, t21, fma(-l30, m[2][0], m[3][2])) * r2;
-    const double d3 = fma(-l32, l32 * d2, fma(-l31, t31, fma(-l30, m[3][0], m[3][3] + mu))), r3 = 1.0 / d3;
-    if (!(d0 > 0 && d1 > 0 && d2 > 0 && d3 > 0)) return false;
+    const double d3 = fma(-l32, l32 * d2, fma(-l31, t31, fma(-l30, m[3][0], m[3][3] + mu)));
+    if (!(d3 > 0)) return false;
+    const double r3 = fast_rcp(d3);
     double v0 = 0.5, v1 = 0.5, v2 = 0.5, v3 = 0.5;
     bool done = false;
-    double diff_prev = 0.0, rho = 0.0, growth = 0.0;
+    // contraction of the iteration = ratio of two consecutive steps, taken while the step is still well above the rounding
+    // floor (a floored step would overstate it by orders of magnitude); the first step's "ratio" is against the arbitrary start
+    // vector and is skipped.  Numerator and denominator are kept and divided ONCE after the loop.
+    double diff_prev = 0.0, rho_num = 0.0, rho_den = 1.0, nn_last = 1.0;
     for (int it = 0; it < kFastIters && !done; ++it) {
         // L y = v
         const double y0 = v0;
@@ -194,24 +234,29 @@ __device__ __forceinline__ bool dlt_nullvec_fast(const double (&At)[4][4], doubl
         const double w1 = fma(-l31, w3, fma(-l21, w2, y1 * r1));
         const double w0 = fma(-l30, w3, fma(-l20, w2, fma(-l10, w1, y0 * r0)));
         const double nn = fma(w0, w0, fma(w1, w1, fma(w2, w2, w3 * w3)));
-        const double inv = 1.0 / sqrt(nn);
+        const double inv = fast_rsqrt(nn);
         const double sgn = (fma(w0, v0, fma(w1, v1, fma(w2, v2, w3 * v3))) < 0) ? -inv : inv;
         const double n0 = w0 * sgn, n1 = w1 * sgn, n2 = w2 * sgn, n3 = w3 * sgn;
         const double diff = fmax(fmax(fabs(n0 - v0), fabs(n1 - v1)), fmax(fabs(n2 - v2), fabs(n3 - v3)));
         v0 = n0; v1 = n1; v2 = n2; v3 = n3;
         done = diff < 1e-13;
-        // contraction of this step, taken only while the step is still well above the rounding floor (a floored step would
-        // overstate it by orders of magnitude); the first step's "ratio" is against the arbitrary start vector and is skipped
-        if (it >= 1 && (diff >= 1e-14 || rho == 0.0)) rho = fmax(diff, 1e-16) / fmax(diff_prev, 1e-300);
+        if (kFastAbandon > 0.0 && it >= 1 && !done && diff > kFastAbandon * diff_prev) return false;
+        if (it >= 1 && (diff >= 1e-14 || rho_num == 0.0)) {
+            rho_num = fmax(diff, 1e-16);
+            rho_den = fmax(diff_prev, 1e-300);
+        }
         diff_prev = diff;
-        growth = sqrt(nn);                                              // -> 1 / (lambda4 + mu) as v converges
+        nn_last = nn;                                                   // sqrt(nn) -> 1 / (lambda4 + mu) as v converges
     }
     X[0] = v0; X[1] = v1; X[2] = v2; X[3] = v3;
     // How far can this vector be from the one another backward-stable algorithm returns?  ~ eps * lambda1 / lambda3: with
     // rho = (lambda4 + mu) / (lambda3 + mu) the contraction the iteration showed (ratio of consecutive steps) and
     // lambda1 <= trace, lambda1 / lambda3 ~ trace * rho * growth.  Measured over well- and ill-conditioned geometries
     // (scripts/dev_tri_calib.py, 4e6 points): |fast - Jacobi| <= 2.5 sens, 3.5e-15 at the rounding floor.
-    if (sens) *sens = 2.220446049250313e-16 * (m[0][0] + m[1][1] + m[2][2] + m[3][3]) * fmin(1.0, rho == 0.0 ? 1.0 : rho) * growth;
+    if (sens) {
+        const double rho = rho_num == 0.0 ? 1.0 : rho_num / rho_den;
+        *sens = 2.220446049250313e-16 * (m[0][0] + m[1][1] + m[2][2] + m[3][3]) * fmin(1.0, rho) * sqrt(nn_last);
+    }
     return done;
 }
 
@@ -253,28 +298,47 @@ __device__ __forceinline__ void store_point(const double (&Xd)[4], int normalise
     for (int k = 0; k < 4; ++k) X4[k * n + i] = X[k];
 }
 
-// Second pass of the guarded fast path: every workgroup scans kFixChunk points for the redo mark, queues their indices in
-// LDS, and runs the OpenCV-faithful Jacobi path on the queue, 256 points at a time.
-constexpr int kFixChunk = 4096;
+// Second pass of the guarded fast path: a workgroup scans chunks of kFixChunk points for the redo mark (row 3 first: one
+// 4-byte read per point; row 0 only where row 3 is marked), queues their indices in LDS, and runs the OpenCV-faithful Jacobi
+// path on the queue, 256 points at a time.  The grid is at most one resident round of the chip (1024 workgroups) walking
+// the chunks, and a chunk is large enough (fixup_chunk: n / 1024 rounded up, 2048 .. 10 240 points) that the ~2 % of points a
+// pass marks fill the workgroup's four waves: a Jacobi solve is ~13 000 fp64 instructions whether one lane of the wave needs
+// it or all 64 (round 3: 4096-point chunks, ~80 marked points each — two waves a third full, in 2.4 rounds of workgroups).
+constexpr int kFixStep = 256 * 8, kFixChunkMax = 5 * kFixStep;       // chunk = a multiple of 2048 points, at most 10 240 (40 KiB of LDS: four workgroups per CU)
+inline int fixup_chunk(int64_t n) {
+    // as few chunks as one resident round of workgroups (256 CUs x 4) can take, so that a workgroup's queue fills its waves
+    const int64_t per = (n + 1023) / 1024;
+    const int64_t c = (per + kFixStep - 1) / kFixStep * kFixStep;
+    return (int)std::min<int64_t>(std::max<int64_t>(c, kFixStep), kFixChunkMax);
+}
 __global__ __launch_bounds__(256) void triangulate_fixup_kernel(ProjPair P, const float* __restrict__ x1, const float* __restrict__ x2, int64_t n,
-                                                               int64_t spt, int64_t sxy, float* __restrict__ X4) {
-    __shared__ int queue[kFixChunk];
+                                                               int64_t spt, int64_t sxy, int chunk, float* __restrict__ X4) {
+    extern __shared__ int queue[];                                  // [chunk]
     __shared__ int qn;
-    if (threadIdx.x == 0) qn = 0;
-    __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * kFixChunk;
-    for (int o = threadIdx.x; o < kFixChunk; o += 256) {
-        const int64_t i = base + o;
-        if (i < n && __float_as_uint(X4[3 * n + i]) == kRedoMark && __float_as_uint(X4[i]) == kRedoMark) queue[atomicAdd(&qn, 1)] = o;
-    }
-    __syncthreads();
-    const int total = qn;
-    for (int e = threadIdx.x; e < total; e += 256) {
-        const int64_t i = base + queue[e];
-        double At[4][4], Xd[4];
-        dlt_build<4>(At, P.p[0], P.p[1], (double)x1[i * spt], (double)x1[i * spt + sxy], (double)x2[i * spt], (double)x2[i * spt + sxy]);
-        dlt_nullvec<4>(At, Xd);
-        store_point<4>(Xd, 1, n, i, X4);
+    for (int64_t base = (int64_t)blockIdx.x * chunk; base < n; base += (int64_t)gridDim.x * chunk) {
+        __syncthreads();                                            // (the previous chunk's queue has been worked off)
+        if (threadIdx.x == 0) qn = 0;
+        __syncthreads();
+        for (int o0 = threadIdx.x; o0 < chunk; o0 += kFixStep) {    // eight independent reads in flight per lane
+            unsigned w[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int64_t i = base + o0 + 256 * k;
+                w[k] = i < n ? __float_as_uint(X4[3 * n + i]) : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (w[k] == kRedoMark && __float_as_uint(X4[base + o0 + 256 * k]) == kRedoMark) queue[atomicAdd(&qn, 1)] = o0 + 256 * k;
+        }
+        __syncthreads();
+        const int total = qn;
+        for (int e = threadIdx.x; e < total; e += 256) {
+            const int64_t i = base + queue[e];
+            double At[4][4], Xd[4];
+            dlt_build<4>(At, P.p[0], P.p[1], (double)x1[i * spt], (double)x1[i * spt + sxy], (double)x2[i * spt], (double)x2[i * spt + sxy]);
+            dlt_nullvec<4>(At, Xd);
+            store_point<4>(Xd, 1, n, i, X4);
+        }
     }
 }
 
@@ -324,6 +388,49 @@ __global__ __launch_bounds__(256) void triangulate_kernel(ProjPair P, const floa
     }
     if (!have) dlt_nullvec<M>(At, Xd);
     store_point<M>(Xd, normalise_w, n, i, X4);
+}
+
+// First pass of the guarded fast path (normalise_w = 3), written for the vector ALU: nothing but the inverse iteration is
+// compiled in (the Jacobi sweeps of the general kernel cost it a fifth of its registers), a lane walks points i, i + T,
+// i + 2T ... of a grid sized to the chip, and the four coordinates of its NEXT point are requested before the current one is
+// solved — the ~2 us a load takes under traffic is covered by the ~640 fp64 instructions of a solve instead of being waited
+// for by a freshly launched workgroup (round 3: 39 000 workgroups of one point per lane at 1e7 points, waitcnt share 0.39).
+// PACKED: the reference's layout — transposed views of (N, 2) arrays, sfm.py:47-48 — is read as one float2 per point.
+template <bool PACKED>
+__global__ __launch_bounds__(256) void triangulate_guarded_kernel(ProjPair P, const float* __restrict__ x1, const float* __restrict__ x2, int64_t n,
+                                                                  int64_t spt, int64_t sxy, double sens_factor, double base_guard,
+                                                                  float* __restrict__ X4) {
+    const int64_t T = (int64_t)gridDim.x * 256;
+    int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x;
+    float xa = 0.f, ya = 0.f, xb = 0.f, yb = 0.f;
+    auto fetch = [&](int64_t k, float& ax, float& ay, float& bx, float& by) {
+        if constexpr (PACKED) {
+            const float2 a = reinterpret_cast<const float2*>(x1)[k], b = reinterpret_cast<const float2*>(x2)[k];
+            ax = a.x; ay = a.y; bx = b.x; by = b.y;
+        } else {
+            ax = x1[k * spt]; ay = x1[k * spt + sxy]; bx = x2[k * spt]; by = x2[k * spt + sxy];
+        }
+    };
+    if (i < n) fetch(i, xa, ya, xb, yb);
+    while (i < n) {
+        const int64_t nx = i + T;
+        float nxa = 0.f, nya = 0.f, nxb = 0.f, nyb = 0.f;
+        if (nx < n) fetch(nx, nxa, nya, nxb, nyb);
+        double At[4][4], Xd[4], sens = 0;
+        dlt_build<4, true>(At, P.p[0], P.p[1], (double)xa, (double)ya, (double)xb, (double)yb);
+        const bool have = dlt_nullvec_fast(At, Xd, &sens);
+        const double margin = fmax(base_guard, sens_factor * sens);
+        const bool keep = have && margin < 1e-3 && cast_margin_ok(Xd[0], margin) && cast_margin_ok(Xd[1], margin) &&
+                          cast_margin_ok(Xd[2], margin) && cast_margin_ok(Xd[3], margin);
+        if (keep) {
+            store_point<4>(Xd, 1, n, i, X4);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) X4[k * n + i] = __uint_as_float(kRedoMark);
+        }
+        xa = nxa; ya = nya; xb = nxb; yb = nyb;
+        i = nx;
+    }
 }
 
 // ---------------------------------------------------------------- matches -> points in one pass (sfm.py:262-268, then :53-54)
@@ -439,7 +546,7 @@ __global__ __launch_bounds__(256) void tri_matches_points_kernel(TriMatchArgs A,
     for (int e = threadIdx.x; e < m_wg; e += 256) {
         const float2 a = kp0[list_q[e]], b = kp1[list_t[e]];
         double At[4][4], Xd[4], sens = 0;
-        dlt_build<4>(At, A.P[pb][0], A.P[pb][1], (double)a.x, (double)a.y, (double)b.x, (double)b.y);
+        dlt_build<4, true>(At, A.P[pb][0], A.P[pb][1], (double)a.x, (double)a.y, (double)b.x, (double)b.y);
         const bool have = dlt_nullvec_fast(At, Xd, &sens);
         const double margin = fmax(base_guard, sens_factor * sens);
         const bool keep = have && margin < 1e-3 && cast_margin_ok(Xd[0], margin) && cast_margin_ok(Xd[1], margin) &&
@@ -530,15 +637,27 @@ extern "C" int sfm_triangulate_dlt(const double* P1, const double* P2, const flo
     constexpr double sens_factor = kSensFactor, base_guard = kCastGuard;
 #endif
     sfm::prof_begin(sfm::kProfTriangulate, sfm::as_stream(stream_));
-    if (rows == 4)
+    if (normalise_w == 3) {
+        // (rows == 4) a grid sized to the chip: 256 CUs x the kernel's resident workgroups, a lane walks its points
+        const dim3 pgrid((unsigned)std::min<int64_t>((n + 255) / 256, 256 * 6));
+        if (stride_pt == 2 && stride_xy == 1 && ((uintptr_t)x1 & 7) == 0 && ((uintptr_t)x2 & 7) == 0)
+            hipLaunchKernelGGL(triangulate_guarded_kernel<true>, pgrid, dim3(256), 0, sfm::as_stream(stream_), P, x1, x2, n, stride_pt, stride_xy,
+                               sens_factor, base_guard, X4);
+        else
+            hipLaunchKernelGGL(triangulate_guarded_kernel<false>, pgrid, dim3(256), 0, sfm::as_stream(stream_), P, x1, x2, n, stride_pt, stride_xy,
+                               sens_factor, base_guard, X4);
+    } else if (rows == 4)
         hipLaunchKernelGGL(triangulate_kernel<4>, grid, dim3(256), 0, sfm::as_stream(stream_), P, x1, x2, n, stride_pt,
                            stride_xy, normalise_w, sens_factor, base_guard, X4);
     else
         hipLaunchKernelGGL(triangulate_kernel<6>, grid, dim3(256), 0, sfm::as_stream(stream_), P, x1, x2, n, stride_pt,
                            stride_xy, normalise_w, sens_factor, base_guard, X4);
     if (normalise_w == 3)
-        hipLaunchKernelGGL(triangulate_fixup_kernel, dim3((unsigned)((n + kFixChunk - 1) / kFixChunk)), dim3(256), 0, sfm::as_stream(stream_), P, x1,
-                           x2, n, stride_pt, stride_xy, X4);
+    {
+        const int chunk = fixup_chunk(n);
+        hipLaunchKernelGGL(triangulate_fixup_kernel, dim3((unsigned)std::min<int64_t>((n + chunk - 1) / chunk, 1024)), dim3(256), sizeof(int) * (size_t)chunk,
+                           sfm::as_stream(stream_), P, x1, x2, n, stride_pt, stride_xy, chunk, X4);
+    }
     sfm::prof_end(sfm::kProfTriangulate, sfm::as_stream(stream_));
     SFM_CHECK_LAUNCH();
     return SFM_OK;
