@@ -687,13 +687,17 @@ def bench_tri(args, world, rank, dev):
     return out
 
 
-# fp64 work of ba_dense_kernel per observation, counted on the ISA of the build (v_fma / v_fmac = 2, v_mul / v_add = 1): 101 fused
-# + 37 plain = 239 FLOP in 160 vector instructions.  (Round 2 quoted 420 FLOP: the count of the UNFUSED formulation that
-# multiplied the Jacobians' structural zeros — 315 instructions; on that count this kernel would read 0.53 of the roof.)
+# fp64 work of the dense sweep per observation.  ALGORITHMIC figure (what `achieved` is computed from, fixed across rounds): the
+# fused form of the reference's Jacobian — cv2.projectPoints' dR/dr . X products — 101 fused + 37 plain = 239 ~ 240 FLOP (the
+# round-3 kernel issued exactly that in 160 vector instructions; SURVEY 8d says ~250; round 2 quoted 420 for the unfused form
+# that multiplied the structural zeros).  ISSUED by the round-4 kernel (counted on its ISA: v_fma / v_fmac = 2, v_mul / v_add = 1):
+# 176 FLOP in 128 vector instructions — the rotation derivative as a cross product with the rotated point (6 instead of 9
+# instructions per axis), the camera table fetched once per camera instead of once per point.
 BA_FLOP_PER_OBS = 240
-BA_VALU_PER_OBS = 160
-BA_FLOP_NOTE = ("FLOP = what the kernel issues (FMA = 2): 240 per observation in 160 vector instructions; r02 quoted 420 for the unfused "
-                "formulation with the Jacobians' structural zeros multiplied (315 instructions)")
+BA_ISSUED_FLOP_PER_OBS = 176
+BA_VALU_PER_OBS = 128
+BA_FLOP_NOTE = ("achieved = ALGORITHMIC FLOP (240 per observation: the fused form of the reference's dR/dr Jacobian, fixed across rounds) / kernel time; "
+                "the round-4 kernel ISSUES 176 FLOP in 128 vector instructions per observation (cross-product form of the rotation derivative)")
 
 
 def c4_problem(dev, seed, ncam=500, npt=200_000):
@@ -757,7 +761,7 @@ def extra_c4(dev):
            "value": nobs / wall, "unit": "observations/s", "ms_per_sweep": wall * 1e3,
            "roofline": {"bound": "fp64-valu", "achieved": BA_FLOP_PER_OBS * nobs / (k_ms * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": BA_FLOP_PER_OBS * nobs / (k_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS, "kernel": "ba_dense_kernel", "avg_launch_ms": k_ms,
-                        "flop_per_observation": BA_FLOP_PER_OBS, "valu_instructions_per_observation": BA_VALU_PER_OBS,
+                        "flop_per_observation": BA_FLOP_PER_OBS, "issued_flop_per_observation": BA_ISSUED_FLOP_PER_OBS, "valu_instructions_per_observation": BA_VALU_PER_OBS,
                         "valu_issue_frac_at_peak_clock": BA_VALU_PER_OBS * nobs / 64 * 4 / (1024 * 2.4e9) / (k_ms * 1e-3),
                         "flop_note": BA_FLOP_NOTE,
                         "hbm_GBs_at_8.2_B_per_obs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS, "traffic": None},
@@ -853,7 +857,7 @@ def bench_ba(args, world, rank, dev):
                          "traffic": None, "kernel": "ba_dense_kernel", "avg_launch_ms": ms / cnt,
                          "fp64_valu_TFLOPs": BA_FLOP_PER_OBS * nobs / (ms / cnt * 1e-3) / 1e12, "flop_per_observation": BA_FLOP_PER_OBS,
                          "fp64_valu_frac": BA_FLOP_PER_OBS * nobs / (ms / cnt * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
-                         "valu_instructions_per_observation": BA_VALU_PER_OBS, "flop_note": BA_FLOP_NOTE,
+                         "issued_flop_per_observation": BA_ISSUED_FLOP_PER_OBS, "valu_instructions_per_observation": BA_VALU_PER_OBS, "flop_note": BA_FLOP_NOTE,
                          "fp64_valu_peak_TFLOPs": FP64_VALU_PEAK_TFLOPS}}
 
 

@@ -25,7 +25,7 @@
 
 namespace {
 
-constexpr int kCamStride = 40;
+constexpr int kCamStride = 24;     // R (9), t (3), the three rotation-derivative axes w_j (9), padding: 42 scalar registers of table per camera
 constexpr int kNAcc = 28;          // 21 upper JtJ + 6 Jtr + 1 sumsq
 constexpr int kSegStride = 33;     // doubles; 32 lanes + 1 pad
 constexpr int kValStride = 2 * kSegStride + 1;   // a wave's slab: [value][half][32 lanes + pad] + pad
@@ -63,6 +63,12 @@ __device__ void rodrigues_dev2(const double* __restrict__ rv, double* __restrict
     }
 }
 
+// Per-camera table.  The derivative of the rotated point with respect to the Rodrigues vector is a cross product:
+//     d(R X)/dr_j = (dR/dr_j) X = [w_j]x (R X),     [w_j]x = (dR/dr_j) R^T  (skew-symmetric: R R^T = I differentiated)
+// so instead of OpenCV's 27-entry dR/dr (cv::Rodrigues' Jacobian, which the oracle multiplies out) the sweep needs the three
+// axes w_j — 9 numbers — and the rotated point it has already computed: 6 instead of 9 instructions per axis and observation,
+// and a table of 21 doubles per camera (42 scalar registers) instead of 39 (78: more than the kernel could keep across the four
+// points of a lane, round 3).  Same value up to rounding (the sums are checked to 1e-10 against the oracle's dR/dr form).
 __global__ void dense_cam_prepare_kernel(const double* __restrict__ cams, int64_t ncam, double* __restrict__ table) {
     const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (c >= ncam) return;
@@ -71,17 +77,25 @@ __global__ void dense_cam_prepare_kernel(const double* __restrict__ cams, int64_
     double* e = table + c * kCamStride;
     for (int k = 0; k < 9; ++k) e[k] = R[k];
     for (int k = 0; k < 3; ++k) e[9 + k] = cams[6 * c + 3 + k];
-    for (int k = 0; k < 27; ++k) e[12 + k] = J[k];
-    e[39] = 0;
+    for (int j = 0; j < 3; ++j) {
+        double S[9];                                       // (dR/dr_j) R^T
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) S[3 * a + b] = J[9 * j + 3 * a] * R[3 * b] + J[9 * j + 3 * a + 1] * R[3 * b + 1] + J[9 * j + 3 * a + 2] * R[3 * b + 2];
+        e[12 + 3 * j + 0] = 0.5 * (S[7] - S[5]);
+        e[12 + 3 * j + 1] = 0.5 * (S[2] - S[6]);
+        e[12 + 3 * j + 2] = 0.5 * (S[3] - S[1]);
+    }
+    e[21] = e[22] = e[23] = 0;
 }
 
-template <int PP>
-__global__ __launch_bounds__(256) void ba_dense_kernel(const double* __restrict__ table, Intrin K, int ncam,
-                                                       const float* __restrict__ X, int64_t npt, int64_t ldx,
-                                                       const float* __restrict__ obs, int nch,
-                                                       double* __restrict__ cam_part /*[4 * tiles][ncam][28]: a row per WAVE*/,
-                                                       double* __restrict__ pt_part /*[nch][npt][9]*/) {
-    extern __shared__ __attribute__((aligned(16))) double red[];   // 4 waves x kNAcc * kValStride doubles
+// FULL: every point of the tile exists (all tiles but the last): no per-point liveness test anywhere, so a camera's four
+// points per lane are ONE basic block — the camera's table is fetched once (scalar loads) instead of once per point section
+// (round 3: four sections, each behind its own s_waitcnt on the scalar loads), and the four independent chains interleave.
+template <int PP, bool FULL>
+__device__ __forceinline__ void ba_dense_body(const double* __restrict__ table, const Intrin& K, int ncam,
+                                              const float* __restrict__ X, int64_t npt, int64_t ldx,
+                                              const float* __restrict__ obs, int nch,
+                                              double* __restrict__ cam_part, double* __restrict__ pt_part, double* __restrict__ red) {
     const int tid = threadIdx.x;
     const int tile = blockIdx.x, ch = blockIdx.y;
     const int c_begin = (int)((int64_t)ncam * ch / nch), c_end = (int)((int64_t)ncam * (ch + 1) / nch);
@@ -93,7 +107,7 @@ __global__ __launch_bounds__(256) void ba_dense_kernel(const double* __restrict_
 #pragma unroll
     for (int pp = 0; pp < PP; ++pp) {
         const int64_t p = p0 + 256 * pp;
-        live[pp] = p < npt;
+        live[pp] = FULL || p < npt;
         const int64_t ps = live[pp] ? p : 0;
         Xw[pp] = X[ps * ldx];
         Yw[pp] = X[ps * ldx + 1];
@@ -106,31 +120,37 @@ __global__ __launch_bounds__(256) void ba_dense_kernel(const double* __restrict_
     const int whalf = lane >> 5, wlane = lane & 31;   // LDS slot of this lane's contribution inside the wave's slab
     double* const wred = red + wave * (kNAcc * kValStride);
 
-    // the observations of camera c + 1 are requested while camera c is worked on
+    // The observations of camera c + 1 are requested while camera c is worked on.  (Tried in round 4 and not kept: a second
+    // buffer with the loop unrolled by two — two cameras of distance, but 16 more registers than the 256 that two waves per SIMD
+    // allow: 15 spills, 1.02 ms; touching camera c + 2's lines with an extra 4-byte load per lane — 0.86 ms against 0.80: the
+    // sweep does not wait for its observations, it waits for the per-camera fold and the scalar table loads.)
     float2 ob_next[PP];
+    const float* const ob0 = obs + p0 * 2;
+    auto ob_ptr = [&](int pp, int64_t cam) -> const float* {
+        if constexpr (FULL) return ob0 + cam * npt * 2 + 512 * pp;   // (one base address, the points' 2 KiB offsets are immediates)
+        else return obs + (cam * npt + (live[pp] ? p0 + 256 * pp : 0)) * 2;
+    };
 #pragma unroll
-    for (int pp = 0; pp < PP; ++pp) {
-        const int64_t p = p0 + 256 * pp;
-        ob_next[pp] = (live[pp] && c_begin < c_end) ? *reinterpret_cast<const float2*>(obs + ((int64_t)c_begin * npt + p) * 2) : make_float2(0.f, 0.f);
-    }
+    for (int pp = 0; pp < PP; ++pp) ob_next[pp] = *reinterpret_cast<const float2*>(ob_ptr(pp, min(c_begin, ncam - 1)));
     for (int c = c_begin; c < c_end; ++c) {
         const double* __restrict__ e = table + (int64_t)c * kCamStride;
         double cacc[kNAcc];
 #pragma unroll
         for (int k = 0; k < kNAcc; ++k) cacc[k] = 0;
         float2 ob[PP];
+        const int64_t c1 = min(c + 1, c_end - 1);                    // (unconditional: a conditional reload is a select at the back edge)
 #pragma unroll
         for (int pp = 0; pp < PP; ++pp) {
-            const int64_t p = p0 + 256 * pp;
             ob[pp] = ob_next[pp];
-            if (live[pp] && c + 1 < c_end) ob_next[pp] = *reinterpret_cast<const float2*>(obs + ((int64_t)(c + 1) * npt + p) * 2);
+            ob_next[pp] = *reinterpret_cast<const float2*>(ob_ptr(pp, c1));
         }
 #pragma unroll
         for (int pp = 0; pp < PP; ++pp) {
-            if (!live[pp]) continue;
-            double x = e[0] * Xw[pp] + e[1] * Yw[pp] + e[2] * Zw[pp] + e[9];
-            double y = e[3] * Xw[pp] + e[4] * Yw[pp] + e[5] * Zw[pp] + e[10];
-            double z = e[6] * Xw[pp] + e[7] * Yw[pp] + e[8] * Zw[pp] + e[11];
+            if (!FULL && !live[pp]) continue;
+            const double x0 = e[0] * Xw[pp] + e[1] * Yw[pp] + e[2] * Zw[pp];      // R X: also the lever arm of the rotation derivatives
+            const double y0 = e[3] * Xw[pp] + e[4] * Yw[pp] + e[5] * Zw[pp];
+            const double z0 = e[6] * Xw[pp] + e[7] * Yw[pp] + e[8] * Zw[pp];
+            double x = x0 + e[9], y = y0 + e[10], z = z0 + e[11];
             // 1 / z: the hardware estimate (~26 bits) + two Newton steps — a third of the IEEE division's instructions,
             // full double accuracy up to the last bit or two (the sums are checked to 1e-10)
             if (z != 0.0) {
@@ -152,10 +172,10 @@ __global__ __launch_bounds__(256) void ba_dense_kernel(const double* __restrict_
             double Ju[3], Jv[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                const double* d = e + 12 + 9 * j;
-                const double dx0 = Xw[pp] * d[0] + Yw[pp] * d[1] + Zw[pp] * d[2];
-                const double dy0 = Xw[pp] * d[3] + Yw[pp] * d[4] + Zw[pp] * d[5];
-                const double dz0 = Xw[pp] * d[6] + Yw[pp] * d[7] + Zw[pp] * d[8];
+                const double* w = e + 12 + 3 * j;                                    // d(R X)/dr_j = w_j x (R X)
+                const double dx0 = w[1] * z0 - w[2] * y0;
+                const double dy0 = w[2] * x0 - w[0] * z0;
+                const double dz0 = w[0] * y0 - w[1] * x0;
                 Ju[j] = fxz * (dx0 - x * dz0);
                 Jv[j] = fyz * (dy0 - y * dz0);
             }
@@ -249,12 +269,25 @@ __global__ __launch_bounds__(256) void ba_dense_kernel(const double* __restrict_
 #pragma unroll
     for (int pp = 0; pp < PP; ++pp) {
         const int64_t p = p0 + 256 * pp;
-        if (live[pp]) {
+        if (FULL || live[pp]) {
             double* dst = pt_part + ((int64_t)ch * npt + p) * 9;
 #pragma unroll
             for (int k = 0; k < 9; ++k) dst[k] = pacc[pp][k];
         }
     }
+}
+
+template <int PP>
+__global__ __launch_bounds__(256) void ba_dense_kernel(const double* __restrict__ table, Intrin K, int ncam,
+                                                       const float* __restrict__ X, int64_t npt, int64_t ldx,
+                                                       const float* __restrict__ obs, int nch,
+                                                       double* __restrict__ cam_part /*[4 * tiles][ncam][28]: a row per WAVE*/,
+                                                       double* __restrict__ pt_part /*[nch][npt][9]*/) {
+    extern __shared__ __attribute__((aligned(16))) double red[];   // 4 waves x kNAcc * kValStride doubles
+    if (((int64_t)blockIdx.x + 1) * (256 * PP) <= npt)              // (uniform) a full tile
+        ba_dense_body<PP, true>(table, K, ncam, X, npt, ldx, obs, nch, cam_part, pt_part, red);
+    else
+        ba_dense_body<PP, false>(table, K, ncam, X, npt, ldx, obs, nch, cam_part, pt_part, red);
 }
 
 // One workgroup per camera folds its `tiles` partial rows (kNAcc doubles each) in a FIXED two-level shape: 1024 threads =
