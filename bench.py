@@ -413,6 +413,14 @@ def bench_knn(args, world, rank, dev):
         mode_s = int(bm_s.stats[0, 3].item())
         ach8 = algo_flop / (f8_avg * 1e-3) / 1e12
         peak8 = I8_MFMA_PEAK_TOPS if mode_s == 4 else BF16_MFMA_PEAK_TFLOPS
+        i8_traffic, i8_traffic_note = None, "no PMC figure for this shape"
+        t8 = os.path.join(ROOT, "profiles", "knn_i8_traffic.json")
+        if os.path.exists(t8) and (nq, nt) == (10000, 10000):
+            tj8 = json.load(open(t8))
+            if tj8.get("knn_hip_sha256") == knn_source_hash() and tj8.get("pairs_per_launch", 1) == pbatch:
+                i8_traffic, i8_traffic_note = tj8.get("bytes_per_launch"), f"profiles/knn_i8_traffic.json ({tj8.get('source')})"
+            else:
+                i8_traffic_note = "profiles/knn_i8_traffic.json is stale (csrc/knn.hip or the pair batch changed since the PMC passes): not reported"
         out["sift_like"] = {"distances_per_sec": n_sets * pbatch * nq * nt / dt, "ms_per_pair": dt / (n_sets * pbatch) * 1e3, "ms_per_step": dt / n_sets * 1e3,
                             "filter_mode": {0: "fp16 single product (inputs exact in fp16)", 1: "fp16 single product", 2: "bf16 split",
                                             4: "exact-integer i8 MFMA (v_mfma_i32_32x32x32_i8, i32 scores)"}.get(mode_s),
@@ -421,7 +429,9 @@ def bench_knn(args, world, rank, dev):
                                          "frac_of_sustained": ach8 / (I8_MFMA_SUSTAINED_TOPS if mode_s == 4 else F16_MFMA_SUSTAINED_TFLOPS),
                                          "sustained_note": "a pure MFMA stream on random operands holds 3 619 TOPS (i8) / 1 691 TFLOP/s (fp16) on this part: the clock drops to 1.66-1.78 GHz (profiles/r04_mfma_ceiling.md)",
                                          "kernel": "knn_filter_q4_kernel<0> (filter_i8_body)" if mode_s == 4 else "knn_filter_q4_kernel<0>",
-                                         "avg_launch_ms": f8_avg, "launches": f8_n, "pairs_per_launch": pbatch, "algorithmic_flop_per_launch": algo_flop, "traffic": None,
+                                         "avg_launch_ms": f8_avg, "launches": f8_n, "pairs_per_launch": pbatch, "algorithmic_flop_per_launch": algo_flop, "traffic": i8_traffic,
+                                         "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": i8_traffic_note,
+                                         "algorithmic_bytes_per_launch": pbatch * (4 * 128 * (nq + nt) + 16 * nq),
                                          "note": "algorithmic = 256 integer ops per distance (SURVEY 8d, GEMM form 2 D); peak = dense int8 MFMA (MI355X_MICROARCH.md: ~5 P dense, 4 404 TOPS measured for 32x32)"},
                             "kernels_ms": {"knn_filter": f8_avg, "knn_refine": r8_ms / max(r8_n, 1)},
                             "rescanned_queries_pair0": int(bm_s.stats[0, 0].item()),

@@ -26,6 +26,15 @@ for P in "$P1" "$P2" "$P3" "$P4"; do
   i=$((i+1))
 done
 python $R/scripts/summarize_pmc.py $OUT/pmc $TAG $BATCH > $OUT/${TAG}_knn_pmc.md
+# the same four passes on SIFT-like u8 descriptors: the exact-integer (i8 MFMA) body and its refine
+i=1
+for P in "$P1" "$P2" "$P3" "$P4"; do
+  SFM_WARM=2 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/pmc_i8 -o pass$i -- python $R/scripts/run_knn_sift.py 6 $BATCH 1 > $OUT/pmc_i8_pass$i.log 2>&1
+  i=$((i+1))
+done
+python $R/scripts/summarize_pmc.py $OUT/pmc_i8 $TAG $BATCH i8 > $OUT/${TAG}_knn_i8_pmc.md
+SFM_WARM=20 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_i8 -o knni8 -- python $R/scripts/run_knn_sift.py 60 $BATCH 1 > $OUT/knn_i8_steps.log 2>> $OUT/trace.log
+cp $OUT/trace_i8/knni8_kernel_stats.csv $OUT/${TAG}_knn_i8_batch_kernel_stats.csv
 for wl in tri ba; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$wl -o $wl -- python $R/bench.py --workload $wl --steps 5 --warmup 1 > $OUT/bench_${wl}_under_rocprof.json 2>> $OUT/trace.log
   cp $OUT/trace_$wl/${wl}_kernel_stats.csv $OUT/${TAG}_${wl}_kernel_stats.csv
@@ -35,12 +44,13 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_sift1 -o sift
 cp $OUT/trace_sift1/sift1_kernel_stats.csv $OUT/${TAG}_sift_depth1_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_sift -o sift -- python $R/bench.py --workload sift --steps 30 --warmup 5 --no-cpu-baseline > $OUT/bench_sift_under_rocprof.json 2>> $OUT/trace.log
 cp $OUT/trace_sift/sift_kernel_stats.csv $OUT/${TAG}_sift_kernel_stats.csv
-rm -rf $OUT/trace $OUT/traceb $OUT/trace1 $OUT/trace_tri $OUT/trace_ba $OUT/trace_sift $OUT/trace_sift1
+rm -rf $OUT/trace_i8 $OUT/trace $OUT/traceb $OUT/trace1 $OUT/trace_tri $OUT/trace_ba $OUT/trace_sift $OUT/trace_sift1
 # the bench lines themselves, un-profiled (a profiled run clocks 2-5 % lower): the driver's flags, config 5 through a
 # one-rank RCCL group, the 57-camera driver
 cd $R
 python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_knn.json 2>> $OUT/trace.log
-SFM_BENCH_EXCHANGE=1 python bench.py --workload c5 > $OUT/${TAG}_bench_c5.json 2>> $OUT/trace.log
+python bench.py --workload c5 > $OUT/${TAG}_bench_c5.json 2>> $OUT/trace.log
+python bench.py --workload allpairs > $OUT/${TAG}_bench_allpairs.json 2>> $OUT/trace.log
 python bench.py --workload sfm --steps 3 > $OUT/${TAG}_bench_sfm.json 2>> $OUT/trace.log
 python bench.py --workload tri --steps 5 --warmup 1 > $OUT/${TAG}_bench_tri.json 2>> $OUT/trace.log
 python bench.py --workload ba --steps 5 --warmup 1 > $OUT/${TAG}_bench_ba.json 2>> $OUT/trace.log

@@ -25,7 +25,7 @@ for s in range(2):
     sets.append([one_pair()] * B if os.environ.get("SFM_SAME") else [one_pair() for _ in range(B)])
 bms = [ops.BatchMatcher(nq, nt, dev, batch=B, filter=filt) for _ in range(S)]
 streams = [torch.cuda.Stream() for _ in range(S)]
-for i in range(60 * S):                                      # load + clock ramp
+for i in range(int(os.environ.get("SFM_WARM", "60")) * S):   # load + clock ramp
     with torch.cuda.stream(streams[i % S]):
         bms[i % S].run(sets[i % 2])
 torch.cuda.synchronize()

@@ -7,13 +7,15 @@ import sys
 
 d, tag = sys.argv[1], sys.argv[2]
 pairs = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+variant = sys.argv[4] if len(sys.argv) > 4 else ""      # "i8": the SIFT-like run (exact-integer body); its traffic stamp goes to knn_i8_traffic.json
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob(os.path.join(d, "pass*_counter_collection.csv"))):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         k = k[k.find("knn_"):].split("(")[0] if "knn_" in k else (k.split("(")[0][-40:])   # keep template arguments
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-print(f"# {tag}: PMC counters of the KNN step (10k x 10k, config 2, {pairs} pair(s) per launch set), mean per launch over 6 launches\n")
+what = "SIFT-like u8 descriptors (SURVEY 8d (ii), 30 % planted twins): the exact-integer i8 body of knn_filter_q4_kernel" if variant == "i8" else "config 2 (uniform float32)"
+print(f"# {tag}: PMC counters of the KNN step (10k x 10k, {what}, {pairs} pair(s) per launch set), mean per launch\n")
 print("Collected with `rocprofv3 --kernel-trace --pmc <group>` in four separate passes (scripts/collect_profiles.sh).")
 print("FETCH_SIZE/WRITE_SIZE are in KiB; per MI355X_MICROARCH.md FETCH_SIZE under-counts wide coalesced reads by 2x on gfx950,")
 print("so `hbm_read_bytes ~= 2 * FETCH_SIZE * 1024` (WRITE_SIZE uncalibrated).\n")
@@ -27,7 +29,7 @@ for k, v in agg.items():
         print(f"| {c} | {m[c]:.4g} |")
     if "SQ_VALU_MFMA_BUSY_CYCLES" in m and m.get("SQ_INSTS_MFMA", 0) > 0:
         print(f"\nMFMA busy cycles / MFMA instruction = {m['SQ_VALU_MFMA_BUSY_CYCLES'] / m['SQ_INSTS_MFMA']:.1f} "
-              f"(32 = v_mfma_f32_32x32x16_bf16, 64 = v_mfma_f32_32x32x2_f32); per-SIMD busy = "
+              f"(32 = v_mfma_f32_32x32x16_{f16,bf16} and v_mfma_i32_32x32x32_i8, 64 = v_mfma_f32_32x32x2_f32); per-SIMD busy = "
               f"{m['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024:.0f} cycles; matrix-pipe busy fraction of CU-busy time = "
               f"{m['SQ_VALU_MFMA_BUSY_CYCLES'] / (4 * m['SQ_BUSY_CU_CYCLES']):.2f}")
     if "FETCH_SIZE" in m:
@@ -48,7 +50,7 @@ for k, v in agg.items():
                "fetch_size_kib": m["FETCH_SIZE"], "write_size_kib": m.get("WRITE_SIZE"),
                "mfma_pipe_busy_frac": (m["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * m["SQ_BUSY_CU_CYCLES"])) if "SQ_BUSY_CU_CYCLES" in m else None,
                "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE doubled per MI355X_MICROARCH.md gfx950 correction; workload 10k x 10k",
-               "source": f"profiles/{tag}_knn_pmc.md",
+               "source": f"profiles/{tag}_knn_i8_pmc.md" if variant == "i8" else f"profiles/{tag}_knn_pmc.md",
                "knn_hip_sha256": hashlib.sha256(open(os.path.join(root, "sfm_mvs_amd", "csrc", "knn.hip"), "rb").read()).hexdigest()}
-        json.dump(out, open(os.path.join(d, "..", "knn_traffic.json"), "w"), indent=1)
+        json.dump(out, open(os.path.join(d, "..", "knn_i8_traffic.json" if variant == "i8" else "knn_traffic.json"), "w"), indent=1)
         break

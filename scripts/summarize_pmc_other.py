@@ -46,9 +46,9 @@ tri = load("tri")
 k = "triangulate_kernel<4>"
 if k in tri:
     n = 10_000_000
-    # launch order of bench.py --workload tri (warmup 1 + 3 steps faithful, 2 + 3 fast, 1 faithful, 2 + 3 guarded)
-    groups = {"faithful (normalise_w = 1, OpenCV's Jacobi sweeps)": {0, 1, 2, 3, 9}, "fast (normalise_w = 2, inverse iteration)": {4, 5, 6, 7, 8},
-              "guarded, first pass (normalise_w = 3)": {10, 11, 12, 13, 14}}
+    # launch order of bench.py --workload tri: triangulate_kernel<4> runs warmup 1 + 3 steps faithful, 2 + 3 fast, 1 faithful; the
+    # guarded path's first pass is its own kernel since round 4 (triangulate_guarded_kernel)
+    groups = {"faithful (normalise_w = 1, OpenCV's Jacobi sweeps)": {0, 1, 2, 3, 9}, "fast (normalise_w = 2, inverse iteration)": {4, 5, 6, 7, 8}}
     print("## triangulation, 10^7 distinct points per launch\n")
     for name, sel in groups.items():
         m = {c: mean(v, sel) for c, v in tri[k].items()}
@@ -62,6 +62,18 @@ if k in tri:
             notes.append(f"HBM traffic ~= {2 * m['FETCH_SIZE'] * 1024 / 1e6:.0f} MB read + {m.get('WRITE_SIZE', 0) * 1024 / 1e6:.0f} MB written per launch "
                          f"= {(2 * m['FETCH_SIZE'] + m.get('WRITE_SIZE', 0)) * 1024 / n:.1f} B per point (algorithmic: 32)")
         table(f"`{k}` — {name}", m, notes)
+    for gk in [x for x in tri if x.startswith("triangulate_guarded_kernel")]:
+        m = {c: mean(v) for c, v in tri[gk].items()}
+        notes = []
+        if "SQ_INSTS_VALU" in m:
+            ipp = m["SQ_INSTS_VALU"] * 64 / n
+            notes.append(f"VALU instructions per point = {ipp:.0f}; at 4 cycles per fp64 wave-instruction on 1024 SIMDs that is {ipp * n / 64 * 4 / 1024 / 2.4e9 * 1e3:.3f} ms "
+                         f"at the 2.4 GHz peak clock (the issue roof of this pass); issue-stall share = {m['SQ_WAIT_INST_ANY'] / m['SQ_WAVE_CYCLES']:.2f}, "
+                         f"waitcnt share = {m['SQ_WAIT_ANY'] / m['SQ_WAVE_CYCLES']:.2f}, VALU busy share = {m['SQ_ACTIVE_INST_VALU'] / m['SQ_WAVE_CYCLES']:.2f}")
+        if "FETCH_SIZE" in m:
+            notes.append(f"HBM traffic ~= {2 * m['FETCH_SIZE'] * 1024 / 1e6:.0f} MB read + {m.get('WRITE_SIZE', 0) * 1024 / 1e6:.0f} MB written per launch "
+                         f"= {(2 * m['FETCH_SIZE'] + m.get('WRITE_SIZE', 0)) * 1024 / n:.1f} B per point (algorithmic: 32)")
+        table(f"`{gk}` — guarded, first pass (normalise_w = 3: fast path only, a lane walks its points, next point prefetched)", m, notes)
     if "triangulate_fixup_kernel" in tri:
         m = {c: mean(v) for c, v in tri["triangulate_fixup_kernel"].items()}
         table("`triangulate_fixup_kernel` (second pass of the guarded path: scan for marks, compacted Jacobi)", m,
@@ -71,7 +83,7 @@ ba = load("ba")
 if ba:
     print("## BASELINE configs[3]: 500 cameras x 200k points (10^8 observations per sweep / product)\n")
     nobs = 1e8
-    for k, what in (("ba_dense_kernel<4>", "dense residual / J^T J sweep"), ("schur_wt_kernel<4>", "Schur product u = W^T x"), ("schur_w_kernel<4>", "Schur product w = W v"),
+    for k, what in (("ba_dense_kernel<4>", "dense residual / J^T J sweep (full tiles + the partial one)"), ("schur_wt_kernel<4>", "Schur product u = W^T x"), ("schur_w_kernel<4>", "Schur product w = W v"),
                     ("schur_cg_step_kernel", "camera-side CG iteration (one workgroup)"), ("dense_cam_reduce_kernel", "per-camera fold (tree)"),
                     ("schur_cam_fold_kernel", "per-camera fold of a product (tree)"), ("final_reduce_kernel", "reprojection-error fold (tree)")):
         if k not in ba:
