@@ -29,7 +29,7 @@ for k, v in agg.items():
         print(f"| {c} | {m[c]:.4g} |")
     if "SQ_VALU_MFMA_BUSY_CYCLES" in m and m.get("SQ_INSTS_MFMA", 0) > 0:
         print(f"\nMFMA busy cycles / MFMA instruction = {m['SQ_VALU_MFMA_BUSY_CYCLES'] / m['SQ_INSTS_MFMA']:.1f} "
-              f"(32 = v_mfma_f32_32x32x16_{f16,bf16} and v_mfma_i32_32x32x32_i8, 64 = v_mfma_f32_32x32x2_f32); per-SIMD busy = "
+              f"(32 = v_mfma_f32_32x32x16_{{f16,bf16}} and v_mfma_i32_32x32x32_i8, 64 = v_mfma_f32_32x32x2_f32); per-SIMD busy = "
               f"{m['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024:.0f} cycles; matrix-pipe busy fraction of CU-busy time = "
               f"{m['SQ_VALU_MFMA_BUSY_CYCLES'] / (4 * m['SQ_BUSY_CU_CYCLES']):.2f}")
     if "FETCH_SIZE" in m:

@@ -301,19 +301,23 @@ __device__ __forceinline__ void store_point(const double (&Xd)[4], int normalise
 // Second pass of the guarded fast path: a workgroup scans chunks of kFixChunk points for the redo mark (row 3 first: one
 // 4-byte read per point; row 0 only where row 3 is marked), queues their indices in LDS, and runs the OpenCV-faithful Jacobi
 // path on the queue, 256 points at a time.  The grid is at most one resident round of the chip (1024 workgroups) walking
-// the chunks, and a chunk is large enough (fixup_chunk: n / 1024 rounded up, 2048 .. 10 240 points) that the ~2 % of points a
-// pass marks fill the workgroup's four waves: a Jacobi solve is ~13 000 fp64 instructions whether one lane of the wave needs
-// it or all 64 (round 3: 4096-point chunks, ~80 marked points each — two waves a third full, in 2.4 rounds of workgroups).
-constexpr int kFixStep = 256 * 8, kFixChunkMax = 5 * kFixStep;       // chunk = a multiple of 2048 points, at most 10 240 (40 KiB of LDS: four workgroups per CU)
+// the chunks, and a chunk is large (fixup_chunk: n / 512 rounded up, 2048 .. 20 480 points) so that the points a pass marks
+// come in few, well-filled waves: a Jacobi solve is ~13 000 fp64 instructions whether one lane of the wave needs it or all 64
+// (round 3: 4096-point chunks, 2 442 workgroups of one or two sparse waves each, in 2.4 rounds).
+constexpr int kFixStep = 256 * 8, kFixChunkMax = 10 * kFixStep;      // chunk = a multiple of 2048 points, at most 20 480 (16-bit queue entries: 40 KiB of LDS)
 inline int fixup_chunk(int64_t n) {
-    // as few chunks as one resident round of workgroups (256 CUs x 4) can take, so that a workgroup's queue fills its waves
-    const int64_t per = (n + 1023) / 1024;
+    // Few, large chunks: a Jacobi solve costs a wave ~13 000 fp64 instructions whether one of its lanes needs it or all 64, and
+    // the waves of the workgroups resident on a SIMD take turns — what counts is the number of (partly filled) waves per SIMD.
+    // With ~0.7 % of the points marked (PMC, profiles/r04_other_pmc.md) 10 240-point chunks gave 72 marked points per workgroup =
+    // a full wave + one of 8 lanes, on 977 workgroups: ~1.9 waves per SIMD; n / 512 rounded up (<= 20 480) gives ~140 = 2.2 waves
+    // on ~490 workgroups: ~1.3 per SIMD.
+    const int64_t per = (n + 511) / 512;
     const int64_t c = (per + kFixStep - 1) / kFixStep * kFixStep;
     return (int)std::min<int64_t>(std::max<int64_t>(c, kFixStep), kFixChunkMax);
 }
 __global__ __launch_bounds__(256) void triangulate_fixup_kernel(ProjPair P, const float* __restrict__ x1, const float* __restrict__ x2, int64_t n,
                                                                int64_t spt, int64_t sxy, int chunk, float* __restrict__ X4) {
-    extern __shared__ int queue[];                                  // [chunk]
+    extern __shared__ unsigned short queue[];                       // [chunk] offsets inside the chunk (< 20 480)
     __shared__ int qn;
     for (int64_t base = (int64_t)blockIdx.x * chunk; base < n; base += (int64_t)gridDim.x * chunk) {
         __syncthreads();                                            // (the previous chunk's queue has been worked off)
@@ -328,7 +332,7 @@ __global__ __launch_bounds__(256) void triangulate_fixup_kernel(ProjPair P, cons
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k)
-                if (w[k] == kRedoMark && __float_as_uint(X4[base + o0 + 256 * k]) == kRedoMark) queue[atomicAdd(&qn, 1)] = o0 + 256 * k;
+                if (w[k] == kRedoMark && __float_as_uint(X4[base + o0 + 256 * k]) == kRedoMark) queue[atomicAdd(&qn, 1)] = (unsigned short)(o0 + 256 * k);
         }
         __syncthreads();
         const int total = qn;
@@ -655,7 +659,7 @@ extern "C" int sfm_triangulate_dlt(const double* P1, const double* P2, const flo
     if (normalise_w == 3)
     {
         const int chunk = fixup_chunk(n);
-        hipLaunchKernelGGL(triangulate_fixup_kernel, dim3((unsigned)std::min<int64_t>((n + chunk - 1) / chunk, 1024)), dim3(256), sizeof(int) * (size_t)chunk,
+        hipLaunchKernelGGL(triangulate_fixup_kernel, dim3((unsigned)std::min<int64_t>((n + chunk - 1) / chunk, 1024)), dim3(256), sizeof(unsigned short) * (size_t)chunk,
                            sfm::as_stream(stream_), P, x1, x2, n, stride_pt, stride_xy, chunk, X4);
     }
     sfm::prof_end(sfm::kProfTriangulate, sfm::as_stream(stream_));
