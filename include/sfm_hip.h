@@ -184,6 +184,17 @@ int sfm_common_points(const float* pts1_dev, int64_t n1, const float* pts2_dev, 
                       int32_t* count_dev, uint8_t* keep2_dev, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Mask -> row indices: `pts0[mask.ravel() == 1]` (sfm.py:309: OpenCV's {0,1} essential-matrix mask),
+ * `pts0[mask.ravel() > 0]` (sfm.py:313: the {0,255} cheirality mask), and the complement rows of
+ * common_points (sfm.py:233-238).  idx_out_dev [n] int32 receives the rows whose mask byte passes —
+ * mode 0: byte == 1, mode 1: byte != 0 — in ascending order, *count_dev their number; the row gather
+ * itself is then an indexed copy.  Deterministic (two passes, no atomics).
+ * ---------------------------------------------------------------------- */
+size_t sfm_mask_indices_ws_bytes(int64_t n);
+int sfm_mask_indices(const uint8_t* mask_dev, int64_t n, int mode, int32_t* idx_out_dev, int32_t* count_dev,
+                     void* ws_dev, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
  * A4  cv2.triangulatePoints(P1, P2, points1, points2)    sfm.py:53
  *     + `cloud = cloud / cloud[3]`                        sfm.py:54
  *

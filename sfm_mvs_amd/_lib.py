@@ -42,6 +42,8 @@ SIGNATURES = {
     "sfm_gather_matches": (_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     "sfm_common_points": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sfm_knn_merge_top2": (_int, [_vp, _int, _i64, _vp, _vp, _vp]),
+    "sfm_mask_indices_ws_bytes": (_sz, [_i64]),
+    "sfm_mask_indices": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _sz, _vp]),
     "sfm_triangulate_dlt": (_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _int, _int, _vp, _vp]),
     "sfm_triangulate_matches_batch_ws_bytes": (_sz, [_int, _i64]),
     "sfm_triangulate_matches_batch": (_int, [_int, _vp, _vp, _vp, _f64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),

@@ -110,7 +110,92 @@ __global__ __launch_bounds__(256) void knn_merge_top2_kernel(const int* __restri
     *reinterpret_cast<float2*>(out_dist + 2 * q) = make_float2(i0 >= 0 ? d0 : 0.f, i1 >= 0 ? d1 : 0.f);
 }
 
+// ---------------------------------------------------------------- mask -> ascending row indices
+// `pts0 = pts0[mask.ravel() == 1]` (sfm.py:309, OpenCV's {0,1} essential-matrix mask), `pts0[mask.ravel() > 0]` (sfm.py:313, the
+// {0,255} cheirality mask) and the complement of common_points (np.ma mask + compress, sfm.py:233-238): the rows whose mask byte
+// passes, in ascending order.  Two multi-workgroup passes like the Lowe compaction (csrc/knn.hip): count per 1024 rows, then
+// every workgroup sums its predecessors' counts and writes its rows at the right offset — deterministic, no atomics.
+constexpr int kMaskBlock = 1024;
+__device__ __forceinline__ unsigned mask_bits(const unsigned char* __restrict__ mask, int64_t n, int64_t r0, int mode) {
+    unsigned pass = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (r0 + k < n) {
+            const unsigned char m = mask[r0 + k];
+            pass |= ((mode == 0 ? m == 1 : m != 0) ? 1u : 0u) << k;
+        }
+    return pass;
+}
+__global__ __launch_bounds__(256) void mask_count_kernel(const unsigned char* __restrict__ mask, int64_t n, int mode, int* __restrict__ block_count) {
+    __shared__ int wsum[4];
+    int c = __popc(mask_bits(mask, n, (int64_t)blockIdx.x * kMaskBlock + threadIdx.x * 4, mode));
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) block_count[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+__global__ __launch_bounds__(256) void mask_scatter_kernel(const unsigned char* __restrict__ mask, int64_t n, int mode, const int* __restrict__ block_count,
+                                                           int* __restrict__ out, int* __restrict__ count) {
+    __shared__ int wsum[4];
+    __shared__ int base_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int part = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) part += block_count[b];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) part += __shfl_xor(part, m, 64);
+    if (lane == 0) wsum[wave] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) base_s = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+    const int base = base_s;
+    __syncthreads();
+    const int64_t r0 = (int64_t)blockIdx.x * kMaskBlock + threadIdx.x * 4;
+    const unsigned pass = mask_bits(mask, n, r0, mode);
+    const int mine = __popc(pass);
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    int pos = base + woff + incl - mine;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (pass & (1u << k)) out[pos++] = (int)(r0 + k);
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) *count = pos;
+}
+
 }  // namespace
+
+extern "C" size_t sfm_mask_indices_ws_bytes(int64_t n) {
+    if (n < 0) return 0;
+    return sfm::align_up(sizeof(int) * (size_t)((n + kMaskBlock - 1) / kMaskBlock + 1), 256);
+}
+
+extern "C" int sfm_mask_indices(const uint8_t* mask, int64_t n, int mode, int32_t* idx_out, int32_t* count, void* ws, size_t ws_bytes, void* stream_) {
+    SFM_CHECK_ARG(n >= 0 && n < ((int64_t)1 << 31) && (mode == 0 || mode == 1), "sfm_mask_indices: bad size or mode (0: byte == 1, 1: byte != 0)");
+    SFM_CHECK_ARG(count && (n == 0 || (mask && idx_out)), "sfm_mask_indices: null pointer");
+    hipStream_t stream = sfm::as_stream(stream_);
+    if (n == 0) {
+        SFM_CHECK_HIP(hipMemsetAsync(count, 0, sizeof(int32_t), stream));
+        return SFM_OK;
+    }
+    if (!ws || ws_bytes < sfm_mask_indices_ws_bytes(n)) {
+        sfm::set_error("sfm_mask_indices: workspace too small (%zu < %zu)", ws_bytes, sfm_mask_indices_ws_bytes(n));
+        return SFM_ERR_WORKSPACE;
+    }
+    const unsigned blocks = (unsigned)((n + kMaskBlock - 1) / kMaskBlock);
+    int* counts = static_cast<int*>(ws);
+    hipLaunchKernelGGL(mask_count_kernel, dim3(blocks), dim3(256), 0, stream, mask, n, mode, counts);
+    hipLaunchKernelGGL(mask_scatter_kernel, dim3(blocks), dim3(256), 0, stream, mask, n, mode, counts, idx_out, count);
+    SFM_CHECK_LAUNCH();
+    return SFM_OK;
+}
 
 extern "C" int sfm_knn_merge_top2(const int32_t* cand, int shards, int64_t nq, int32_t* out_idx, float* out_dist, void* stream_) {
     SFM_CHECK_ARG(shards >= 1 && nq >= 0 && nq < ((int64_t)1 << 31), "sfm_knn_merge_top2: bad sizes");

@@ -136,6 +136,27 @@ def common_points(pts1, pts2):
     return idx1[:m], idx2[:m], keep2[:n2].bool()
 
 
+def mask_indices(mask, nonzero=False):
+    """Rows of a uint8 mask that pass, ascending, as an int32 CUDA tensor (sfm_mask_indices): `mask.ravel() == 1` (OpenCV's
+    {0,1} essential-matrix mask, sfm.py:309) or, nonzero=True, `mask.ravel() > 0` (the {0,255} cheirality mask, sfm.py:313; the
+    complement of common_points).  One host read (the count sizes the result)."""
+    require_cuda(mask)
+    m = mask.reshape(-1)
+    if m.dtype == torch.bool:
+        m = m.view(torch.uint8)
+    if m.dtype != torch.uint8:
+        raise SfmHipError("mask_indices: uint8 / bool mask")
+    m = m.contiguous()
+    n = m.numel()
+    out = torch.empty(max(n, 1), dtype=torch.int32, device=m.device)
+    count = torch.zeros(1, dtype=torch.int32, device=m.device)
+    lib = _lib.lib()
+    ws = _workspace(m.device, lib.sfm_mask_indices_ws_bytes(n))
+    with on_device(m.device):
+        check(lib.sfm_mask_indices(ptr(m), n, 1 if nonzero else 0, ptr(out), ptr(count), ptr(ws), ws.numel(), stream_ptr()), "sfm_mask_indices")
+    return out[:int(count.item())]
+
+
 def knn_merge_top2(cand):
     """Merge the shards' partial 2-NN results (train set split over devices): cand [S][2][nq][2] int32 CUDA tensor — per
     shard the global trainIdx plane and the distance-bits plane — -> (idx [nq,2] int32, dist [nq,2] float32), ordered by

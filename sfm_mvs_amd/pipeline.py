@@ -426,12 +426,12 @@ class _HipEngine:
     def essential(self, a, b):
         from . import ransac
         E, mask = ransac.find_essential_mat(a, b, self.K, 0.999, 0.4, return_device_mask=True)
-        return E, torch.nonzero(mask.ravel() == 1).ravel()
+        return E, ops.mask_indices(mask)                           # quirk 4: rows of the {0,1} mask
 
     def recover_pose(self, E, a, b):
         from . import ransac
         _, R, t, mask = ransac.recover_pose(E, a, b, self.K, return_device_mask=True)
-        return R, t, torch.nonzero(mask.ravel() > 0).ravel()
+        return R, t, ops.mask_indices(mask, nonzero=True)          # quirk 4: rows of the {0,255} mask
 
     def take(self, x, rows):
         return x[rows.long() if torch.is_tensor(rows) else rows]
@@ -456,7 +456,7 @@ class _HipEngine:
 
     def associate(self, pts1, pts_):
         indx1, indx2, keep = ops.common_points(pts1, pts_)
-        return indx1, indx2, torch.nonzero(keep).ravel()
+        return indx1, indx2, ops.mask_indices(keep, nonzero=True)
 
     def errors(self, handles):
         if not handles:

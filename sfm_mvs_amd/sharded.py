@@ -338,10 +338,10 @@ class HipVerifyEngine:
         E, mask = ransac.find_essential_mat(pts0, pts1, self.K, 0.999, 0.4, return_device_mask=True)
         if E is None:
             return -1
-        keep = mask.ravel() == 1                               # isfm.py:81-82 (OpenCV's {0,1} mask)
+        keep = ops.mask_indices(mask).long()                   # isfm.py:81-82 (rows of OpenCV's {0,1} mask)
         pts0, pts1 = pts0[keep], pts1[keep]
         _, _, _, mask = ransac.recover_pose(E[:3], pts0, pts1, self.K, return_device_mask=True)
-        return int((mask.ravel() > 0).sum().item())            # isfm.py:84-86 ({0,255} mask)
+        return int(ops.mask_indices(mask, nonzero=True).numel())   # isfm.py:84-86 (rows of the {0,255} mask)
 
 
 def verify_pairs_sharded(store, n_query, pairs, keypoints, K, engine=None, group=None, ratio=0.70, partition=None, only=None):

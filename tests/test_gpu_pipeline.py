@@ -466,3 +466,19 @@ def test_device_resident_driver_equals_the_array_form(hip):
     for k in ("posearr", "Xtot", "colorstot"):
         assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k]), k
     assert a["errors"] == b["errors"] and a["first_error"] == b["first_error"]
+
+
+def test_mask_indices_kernel(hip):
+    """sfm_mask_indices — `pts[mask.ravel() == 1]` / `pts[mask.ravel() > 0]` (sfm.py:309,313) and the complement rows of
+    common_points — against NumPy on masks with the byte values OpenCV produces (0, 1, 255) and others, at sizes around the
+    1024-row block boundaries, empty and large."""
+    import torch
+    rng = np.random.default_rng(3)
+    for n in (0, 1, 5, 1023, 1024, 1025, 4096, 100_003):
+        m = rng.choice(np.array([0, 0, 1, 255, 7], np.uint8), n)
+        d = torch.from_numpy(m).cuda()
+        assert np.array_equal(hip.mask_indices(d).cpu().numpy(), np.flatnonzero(m == 1))
+        assert np.array_equal(hip.mask_indices(d.reshape(-1, 1), nonzero=True).cpu().numpy(), np.flatnonzero(m > 0))
+        assert np.array_equal(hip.mask_indices(torch.from_numpy(m > 0).cuda(), nonzero=True).cpu().numpy(), np.flatnonzero(m > 0))
+    with pytest.raises(hip.SfmHipError):
+        hip.mask_indices(torch.zeros(4, dtype=torch.float32, device="cuda"))
