@@ -802,14 +802,16 @@ def extra_other_workloads(args, dev):
     configs[4] (the full 255-pair job on this one GPU), SIFT frames/s, the 57-camera driver."""
     import copy
     out = {}
-    for key, fn, over in (("config5", bench_c5, {}), ("sift", bench_sift, {"steps": 30, "warmup": 5}), ("sfm57", bench_sfm, {"steps": 2, "warmup": 1})):
+    for key, fn, over in (("config5", bench_c5, {}), ("allpairs", bench_allpairs, {"images": 32, "verify_images": 4}),
+                          ("sift", bench_sift, {"steps": 30, "warmup": 5}), ("sfm57", bench_sfm, {"steps": 2, "warmup": 1})):
         a = copy.copy(args)
         for k, v in over.items():
             setattr(a, k, v)
         try:
             r = fn(a, 1, 0, dev)
             keep = ("metric", "value", "unit", "ms_per_step", "config", "roofline", "cpu_baseline", "parity", "frame_latency_ms_single_stream",
-                    "job_seconds", "match_seconds", "triangulate_and_gather_seconds", "exchange", "triangulated_points_total", "planted_matches_recovered_as_nearest_neighbour", "scaling")
+                    "job_seconds", "match_seconds", "triangulate_and_gather_seconds", "exchange", "triangulated_points_total", "verification",
+                    "images_resident_on_this_rank", "pairs_per_rank", "planted_matches_recovered_as_nearest_neighbour", "scaling")
             out[key] = {k: r[k] for k in keep if k in r}
         except Exception as e:      # noqa: BLE001 — an extra, not the measurement
             out[key] = {"error": f"{type(e).__name__}: {e}"}

@@ -691,6 +691,11 @@ class BatchPipeline:
         self._after.append(after)
         return self.flush() if len(self._pairs) == self.batch else None
 
+    @property
+    def pending(self):
+        """Pairs queued for the next launch set (not yet launched)."""
+        return len(self._pairs)
+
     def flush(self):
         """Launch the queued pairs (a partial batch is fine).  Returns (slot, stream, matcher, n_pairs) or None."""
         if not self._pairs:

@@ -186,7 +186,7 @@ class HipMatchEngine:
             pipe = self.pipes[key] = ops.BatchPipeline(nq, nt, self.device, ratio=self.ratio, depth=self.depth, batch=self.batch)
             self._padded[key] = []
         direct = block.shape[1] == nq and block.is_contiguous()
-        if pipe._pairs and direct != (not self._padded[key]):      # a launch set writes either into blocks or into its own result
+        if pipe.pending and direct != (not self._padded[key]):     # a launch set writes either into blocks or into its own result
             self._launch(key, pipe.flush())
         if not direct:
             self._padded[key].append(block)
