@@ -698,16 +698,16 @@ def bench_tri(args, world, rank, dev):
 
 
 # fp64 work of the dense sweep per observation.  ALGORITHMIC figure (what `achieved` is computed from, fixed across rounds): the
-# fused form of the reference's Jacobian — cv2.projectPoints' dR/dr . X products — 101 fused + 37 plain = 239 ~ 240 FLOP (the
-# round-3 kernel issued exactly that in 160 vector instructions; SURVEY 8d says ~250; round 2 quoted 420 for the unfused form
-# that multiplied the structural zeros).  ISSUED by the round-4 kernel (counted on its ISA: v_fma / v_fmac = 2, v_mul / v_add = 1):
-# 176 FLOP in 128 vector instructions — the rotation derivative as a cross product with the rotated point (6 instead of 9
-# instructions per axis), the camera table fetched once per camera instead of once per point.
+# fused form of the reference's Jacobian — cv2.projectPoints' dR/dr . X products — 101 fused + 37 plain = 239 ~ 240 FLOP (round 3's
+# ISA count of the observation's own arithmetic; SURVEY 8d says ~250; round 2 quoted 420 for the unfused form that multiplied the
+# structural zeros).  ISSUED by the round-4 kernel, whole camera loop incl. the per-wave fold (ISA count: v_fma / v_fmac = 2,
+# v_mul / v_add = 1; PMC SQ_INSTS_VALU agrees: 161): 230 FLOP in 160 vector instructions per observation (round 3, PMC: 180) — the
+# rotation derivative as a cross product with the rotated point, the camera table fetched once per camera instead of per point.
 BA_FLOP_PER_OBS = 240
-BA_ISSUED_FLOP_PER_OBS = 176
-BA_VALU_PER_OBS = 128
+BA_ISSUED_FLOP_PER_OBS = 230
+BA_VALU_PER_OBS = 160
 BA_FLOP_NOTE = ("achieved = ALGORITHMIC FLOP (240 per observation: the fused form of the reference's dR/dr Jacobian, fixed across rounds) / kernel time; "
-                "the round-4 kernel ISSUES 176 FLOP in 128 vector instructions per observation (cross-product form of the rotation derivative)")
+                "the round-4 kernel ISSUES 230 FLOP in 160 vector instructions per observation, fold included (round 3: 180 instructions, PMC)")
 
 
 def c4_problem(dev, seed, ncam=500, npt=200_000):
