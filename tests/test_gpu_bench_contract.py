@@ -1,0 +1,38 @@
+"""bench.py's output contract, as the driver reads it: exactly ONE JSON line on stdout with the metric of BASELINE.json, the
+whole-job value, the roofline of the dominant kernel measured live, and (default run) the CPU baseline.  Runs the real script
+with a handful of steps and without the extra legs."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_prints_one_json_line_with_the_contract_fields(hip):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--no-extras", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["unit"] == "distances/s" and "distances/sec" in d["metric"] and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "BASELINE configs[1]" in d["config"]["workload"] and "model" not in d["config"]
+    # value = units of all ranks / timed seconds: 8 pairs of 10k x 10k per step
+    assert d["value"] == pytest.approx(8 * 1e8 / (d["ms_per_step"] * 1e-3), rel=1e-6)
+    assert d["value"] > 1e12                                       # (north_star's floor is 1e8; anything below 1e12 means a broken path)
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms"):
+        assert k in r, k
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"]) and 0.2 < r["frac"] < 1.0
+    assert r["achieved"] == pytest.approx(8 * 1e8 * 256 / (r["avg_launch_ms"] * 1e-3) / 1e12, rel=1e-6)     # algorithmic FLOP / live kernel time
+    if "sift_like" in d:                                           # (a leg of the full default run)
+        assert d["sift_like"]["roofline"]["peak"] == 5000.0 and 0.2 < d["sift_like"]["roofline"]["frac"] < 1.0
