@@ -165,10 +165,14 @@ class HipMatchEngine:
     (ops.BatchPipeline -> sfm_match_batch_l2_f32: one prep / filter / refine / scatter launch for the batch), launch sets
     pipelined over `depth` HIP streams.  `flush()` launches what is queued (the exchange calls it before a collective)."""
 
-    def __init__(self, device, ratio=0.70, depth=3, batch=8):
+    def __init__(self, device, ratio=0.70, depth=3, batch=8, max_shapes=4):
         self.device, self.ratio, self.depth, self.batch = torch.device(device), ratio, depth, batch
-        self.pipes = {}
-        self._padded = {}                                  # per pipe: (block, nq) of queued pairs whose block is wider than nq
+        self.pipes = {}                                    # (nq, nt) -> BatchPipeline, most recently used last
+        self._padded = {}                                  # per pipe: blocks of queued pairs that are wider than nq
+        # A pipeline owns depth x (workspace + outputs) for `batch` pairs of its shape (2 GB per launch set at 50k x 50k): a
+        # sequence of real images has a different descriptor count per image, so only the `max_shapes` most recently used shapes
+        # keep theirs (an evicted one is flushed and drained first).
+        self.max_shapes = max(1, int(max_shapes))
 
     @property
     def streams(self):
@@ -181,10 +185,16 @@ class HipMatchEngine:
         from . import ops
         nq, nt = des0.shape[0], des1.shape[0]
         key = (nq, nt)
-        pipe = self.pipes.get(key)
+        pipe = self.pipes.pop(key, None)
         if pipe is None:
-            pipe = self.pipes[key] = ops.BatchPipeline(nq, nt, self.device, ratio=self.ratio, depth=self.depth, batch=self.batch)
+            while len(self.pipes) >= self.max_shapes:       # evict the least recently used shape
+                old = next(iter(self.pipes))
+                self._launch(old, self.pipes[old].flush())
+                self.pipes[old].synchronize()
+                del self.pipes[old], self._padded[old]
+            pipe = ops.BatchPipeline(nq, nt, self.device, ratio=self.ratio, depth=self.depth, batch=self.batch)
             self._padded[key] = []
+        self.pipes[key] = pipe                             # (re-inserted: most recently used)
         direct = block.shape[1] == nq and block.is_contiguous()
         if pipe.pending and direct != (not self._padded[key]):     # a launch set writes either into blocks or into its own result
             self._launch(key, pipe.flush())
