@@ -53,6 +53,7 @@ constexpr int kMaxSlots = 258;         // cap on filter blocks that may touch on
 constexpr float kInf = __builtin_huge_valf();
 constexpr int kSubTilesHost = 64;      // = kSubTiles (tiles per substream), needed by make_plan before its definition
 constexpr int kI8SubTilesHost = 128;   // = kI8SubTiles (exact-integer body)
+constexpr int kQ8SubTilesHost = 32;    // = kQ8SubTiles (the same body on 8-bit QUANTISED float data: shorter streams, see refine_q8_body)
 
 // Work decomposition ("stream-K" over the flattened (query row block, train tile) unit space):
 // block b owns units [units*b/G, units*(b+1)/G).  Every block gets the same number of units (+-1),
@@ -139,6 +140,7 @@ __host__ __device__ inline int64_t part_begin(const Partition& pt, int b) {
 }
 constexpr int kSegCostTiles = 5;
 int g_seg_cost = [] { const char* e = getenv("SFM_KNN_SEGCOST"); return e ? atoi(e) : kSegCostTiles; }();   // dev override
+int g_q8 = [] { const char* e = getenv("SFM_KNN_Q8"); return e ? atoi(e) : 0; }();   // 1: float pairs of a kFilterAuto call are quantised for the integer body
 int g_seg_cost_q4 = [] { const char* e = getenv("SFM_KNN_SEGCOST_Q4"); return e ? atoi(e) : 5; }();              // q4 kernel: a segment's prologue in tile-steps
 
 // One workgroup fills the partition tables the filter / refine kernels read: begin[G+1], and per query row block the
@@ -228,7 +230,7 @@ Plan make_plan_uncached(int64_t nq, int64_t nt, int B, int filter) {
     p.force_mode = (filter == kFilterSplit || filter == kFilterLdsSplit) ? 2 /*kModeSplit*/ : -1;
     p.i8 = filter == kFilterAuto ? 1 : 0;
     const bool i8plan = filter == kFilterI8Plan;   // the partition of the i8 body: 8 query groups per wave, 1024-query row blocks
-    p.sub_tiles = i8plan ? kI8SubTilesHost : kSubTilesHost;
+    p.sub_tiles = i8plan ? (g_q8 ? kQ8SubTilesHost : kI8SubTilesHost) : kSubTilesHost;   // (i8 plan: the SHORTEST substreams the launch set may choose on the device — sizes the slot arrays)
     p.qg = i8plan ? 8 : p.q4 ? 4 : p.split ? 2 : 1;
     if (p.q4) p.waves = 4;                     // one 4-wave workgroup per CU: one wave per SIMD, 512 registers each
     else if (p.split && !(env_w == 4 || env_w == 8 || env_w == 16)) p.waves = p.qg == 2 ? 4 : 16;   // split2: two 4-wave workgroups per CU (their barrier stalls interleave; ~3 % over one 8-wave group)
@@ -581,6 +583,7 @@ __device__ __forceinline__ unsigned bf16_rn_bits(float x) {
 //   kModeSplit      anything else (huge / tiny magnitudes): bf16 hi+mid split, three products, full fp32 range.
 constexpr int kModeHalfExact = 0, kModeHalf = 1, kModeSplit = 2;
 constexpr int kFlagHalfInexact = 2, kFlagRangeBad = 4, kFlagNotU8 = 8, kFlagSomeU8 = 16;   // (NotU8: some value is not an integer 0 .. 255; SomeU8: some chunk of a real row exists in the byte image only)
+constexpr int kFlagQ8 = 32;            // the pair's rows were QUANTISED to 8 bits (float data on the integer body): byte image + residual norms, no fp16 image
 
 // Lane exchanges without an address register: lane ^ M by DPP quad_perm (M = 1, 2) or ds_swizzle bit mode
 // (M = 4, 8, 16); __shfl_xor compiles to ds_bpermute and keeps one address VGPR alive per distinct pattern.
@@ -610,7 +613,10 @@ __device__ __forceinline__ int knn_filter_mode(const int* __restrict__ flags, co
 // modes are nested (fp16-exact data are fp16-representable data are split-representable data), and the refine kernel
 // prices its slack with the same batch mode, so every pair is certified against the arithmetic that actually ran.
 constexpr int kMinfoPairMode = 0, kMinfoBatchMode = kMaxBatch, kMinfoTmax = 16, kMinfoTerr = 24, kMinfoQmax = 32, kMinfoBase = 40, kMinfoI8 = 48,
-              kMinfoWords = 56;   // written by knn_split_images_kernel (block 0); kMinfoI8: 1 = the exact-integer body runs, kMinfoBase: its per-pair score offset
+              kMinfoQ8 = 49,      // 1: the integer body runs on QUANTISED data (some pair of the batch is float data): refine_q8_body certifies
+              kMinfoSub8 = 50,    // tiles per substream of the integer body for this launch set (written by the prep launch's partition workgroup)
+              kMinfoQ8S = 56, kMinfoQ8Lo = 64,   // per pair: the quantisation grid x ~ lo + s k, k = 0 .. 255 (float bits; written by the prep launch)
+              kMinfoWords = 72;   // written by knn_split_images_kernel (block 0); kMinfoI8: 1 = the exact-integer body runs, kMinfoBase: its per-pair score offset
 __device__ __forceinline__ int knn_batch_mode(const int* __restrict__ flags, const float* __restrict__ bmax, int n_pairs, int lane) {
     int mode = kModeHalfExact;
     for (int b = 0; b < n_pairs; ++b) mode = max(mode, knn_filter_mode(flags + b * kNormBlocks, bmax + b * kNormBlocks, lane));
@@ -664,6 +670,69 @@ constexpr int kI8CMax = 508031, kI8CMin = -503936;          // range of the init
 static_assert(kI8SubTiles == kI8SubTilesHost, "make_plan's copy");
 constexpr int kKeyEmptyI = 0x7FFFFF00;                      // i8 keys >= this are empty slots / the first tile's pretend "previous tile"
 
+// ---- 8-bit QUANTISED float data on the integer body ("q8")
+// Float descriptors that are not u8 integers can still be FILTERED on v_mfma_i32_32x32x32_i8: x ~ lo + s k, k = 0 .. 255, one
+// grid (lo, s) per image pair.  With q^ = lo + s k_q, t^ = lo + s k_t the integer body returns D = sum (k_q - k_t)^2 EXACTLY, and
+//     | ||q - t|| - s sqrt(D) |  <=  ||q - q^|| + ||t - t^||                                   (triangle inequality)
+// whatever rounding, clipping or grid produced the bytes: the prep pass MEASURES the residual norms per row, the refine
+// kernel (refine_q8_body) selects / certifies with them and re-evaluates the survivors in the reference's float32 arithmetic.
+// The grid is therefore a matter of speed only.  It comes from a SAMPLE — sixteen rows of Q and sixteen of T, evenly spaced;
+// every workgroup of the pair reads the same 16 KiB (L2 hits) and derives the same grid: no extra pass over the data, no
+// grid-wide reduction.  Values outside the sampled range saturate (their error is part of the measured residual).
+constexpr int kQ8SubTiles = 32;                             // tiles per substream when the launch set runs on quantised data
+static_assert(kQ8SubTiles == kQ8SubTilesHost, "make_plan's copy");
+struct Q8Grid {
+    float lo, s, inv;
+    int kind;        // 0: every sampled value is a u8 integer (exact-integer path, decided per chunk); 1: quantise; 2: not quantisable (16-bit bodies)
+};
+__device__ __forceinline__ Q8Grid q8_sample_grid(const float* __restrict__ Q, int64_t ldq, int nq, const float* __restrict__ T, int64_t ldt, int nt,
+                                                 float* __restrict__ red /*LDS [12]*/) {
+    const int sr = threadIdx.x >> 4, c = threadIdx.x & 15;             // 256 threads: 16 rows x 16 chunks of 8 floats, of Q and of T
+    const float* qs = Q + (int64_t)(((int64_t)sr * nq) >> 4) * ldq + 8 * c;
+    const float* ts = T + (int64_t)(((int64_t)sr * nt) >> 4) * ldt + 8 * c;
+    const float4 v0 = *reinterpret_cast<const float4*>(qs), v1 = *reinterpret_cast<const float4*>(qs + 4);
+    const float4 v2 = *reinterpret_cast<const float4*>(ts), v3 = *reinterpret_cast<const float4*>(ts + 4);
+    const float in[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+    float mn = kInf, mx = -kInf;
+    bool bad = false, nonu8 = false;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        mn = fminf(mn, in[e]);
+        mx = fmaxf(mx, in[e]);
+        bad = bad || !(fabsf(in[e]) < kInf);                            // NaN / inf
+        nonu8 = nonu8 || !(in[e] >= 0.f && in[e] <= 255.f && in[e] == floorf(in[e]));
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, m, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+    }
+    const int fl = (__any(bad) ? 1 : 0) | (__any(nonu8) ? 2 : 0);
+    __syncthreads();                                                    // (a caller may loop: the previous round's reads are done)
+    if ((threadIdx.x & 63) == 0) {
+        red[3 * (threadIdx.x >> 6)] = mn;
+        red[3 * (threadIdx.x >> 6) + 1] = mx;
+        red[3 * (threadIdx.x >> 6) + 2] = __int_as_float(fl);
+    }
+    __syncthreads();
+    int flw = 0;
+    mn = red[0]; mx = red[1];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        mn = fminf(mn, red[3 * w]);
+        mx = fmaxf(mx, red[3 * w + 1]);
+        flw |= __float_as_int(red[3 * w + 2]);
+    }
+    Q8Grid g{0.f, 1.f, 1.f, 0};
+    if (flw & 1) { g.kind = 2; return g; }
+    if (!(flw & 2)) return g;                                           // u8 integers as far as the sample goes
+    const float s = (mx - mn) * (1.f / 255.f), mabs = fmaxf(fabsf(mn), fabsf(mx));
+    // (a range below the float32 spacing of the values, or absurd magnitudes: the 16-bit bodies' business)
+    if (!(s >= 1e-12f && s <= 1e30f && s >= 1.52587890625e-05f * mabs)) { g.kind = 2; return g; }
+    g.lo = mn; g.s = s; g.inv = 1.f / s; g.kind = 1;
+    return g;
+}
+
 // One pass over Q and T: rows → the fp16 image (Q pre-scaled by -2, exact), fp32 squared norms, per-block max of
 // ||t||^2 and exactness / range flags, zero the rescan counter.  Rows >= n of the padded images are zero-filled.
 // Image layout: [3][n_pad][128] 16-bit: bf16 hi, bf16 mid, fp16; the two bf16 planes are only needed by the split
@@ -692,14 +761,25 @@ __global__ __launch_bounds__(kPrepThreads) void knn_prep_kernel(BatchPtrs P, int
                                                        unsigned short* __restrict__ rmq /*[s_qn] per pair: chunks of a row that exist in the byte image only*/,
                                                        unsigned short* __restrict__ rmt /*[s_tn]*/,
                                                        int64_t units8, int G8, int n_rb8, int64_t* __restrict__ wg_begin8,
-                                                       int* __restrict__ rb_first8, int* __restrict__ rb_last8, int* __restrict__ wg_sbase8) {
+                                                       int* __restrict__ rb_first8, int* __restrict__ rb_last8, int* __restrict__ wg_sbase8,
+                                                       int q8 /*1: float pairs are quantised for the integer body*/, int* __restrict__ minfo) {
     constexpr int kPrepWaves = kPrepThreads / 64, kPrepRows = kPrepThreads / 16;
     __shared__ float wmax[kPrepWaves];
+    __shared__ float q8red[12];
     const int pb = blockIdx.y;
     if (blockIdx.x >= gridDim.x - 2) {                     // the two extra workgroups (of column 0): partition tables, nothing else
         if (pb == 0) {
             if (blockIdx.x == gridDim.x - 2) fill_partition_tables(make_partition(units, tiles, G, seg_cost), n_rb, wg_begin, rb_first, rb_last, wg_sbase);
-            else if (qi8) fill_partition_tables(make_partition(units8, tiles, G8, seg_cost), n_rb8, wg_begin8, rb_first8, rb_last8, wg_sbase8, kI8SubTiles);
+            else if (qi8) {
+                // tiles per substream of the integer body: short streams when some pair of the batch will be quantised (the same
+                // sample, the same rule as that pair's own workgroups below)
+                int sub8 = kI8SubTiles;
+                if (q8)
+                    for (int b = 0; b < (int)gridDim.y; ++b)
+                        if (q8_sample_grid(P.q[b], ldq, nq, P.t[b], ldt, nt, q8red).kind == 1) sub8 = kQ8SubTiles;
+                if (threadIdx.x == 0) minfo[kMinfoSub8] = sub8;
+                fill_partition_tables(make_partition(units8, tiles, G8, seg_cost), n_rb8, wg_begin8, rb_first8, rb_last8, wg_sbase8, sub8);
+            }
         }
         return;
     }
@@ -717,6 +797,13 @@ __global__ __launch_bounds__(kPrepThreads) void knn_prep_kernel(BatchPtrs P, int
     if (frag) { qfrag += pb * s_qfrag; tfrag += pb * s_tfrag; }
     const int nblk = gridDim.x - 2;
     __shared__ int wmid[kPrepWaves];
+    Q8Grid g8{0.f, 1.f, 1.f, 0};
+    if (do8 && q8) g8 = q8_sample_grid(Q, ldq, nq, T, ldt, nt, q8red);
+    const bool q8pair = g8.kind == 1;                        // (uniform over the pair's workgroups)
+    if (do8 && blockIdx.x == 0 && threadIdx.x == 0) {
+        minfo[kMinfoQ8S + pb] = __float_as_int(g8.s);
+        minfo[kMinfoQ8Lo + pb] = __float_as_int(g8.lo);
+    }
     // SIXTEEN lanes per row, one 16-byte chunk (8 elements) each: a lane reads 32 contiguous bytes of its row (a wave = 4
     // rows x 512 B) and its eight fp16 values ARE one chunk of the images — row-major: 16 B at row * 256 + 16 c; fragment
     // order: 16 B at fragment c >> 1, lane 32 (c & 1) + row % 32 of the row's tile, so the four adjacent rows of a wave
@@ -765,7 +852,26 @@ __global__ __launch_bounds__(kPrepThreads) void knn_prep_kernel(BatchPtrs P, int
         // Rows past the end are zero in BOTH images.
         bool chunk8 = false;
         unsigned lo = 0u, hi = 0u;
-        if (do8) {
+        float err2q = 0.f;                                               // ||row - (lo + s k)||^2 of a quantised row (this lane's eight elements)
+        if (q8pair) {
+            // k = the saturating, rounding conversion of (x - lo) / s; the residual is measured against lo + s k as the float32
+            // numbers they are (one fma: within 2^-24 max(|lo|, |hi|) of the real value — refine_q8_body's E carries that term)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                lo = __builtin_amdgcn_cvt_pk_u8_f32((in[e] - g8.lo) * g8.inv, e, lo);
+                hi = __builtin_amdgcn_cvt_pk_u8_f32((in[4 + e] - g8.lo) * g8.inv, e, hi);
+            }
+            if (real) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float kf = (float)(((e < 4 ? lo : hi) >> (8 * (e & 3))) & 0xFFu);
+                    const float dv = in[e] - fmaf(g8.s, kf, g8.lo);
+                    err2q = fmaf(dv, dv, err2q);
+                }
+                flags |= kFlagQ8;
+            }
+            chunk8 = true;
+        } else if (do8) {
             // saturating conversion; "every value an integer 0 .. 255" = the conversion was exact (-0 counts as 0; NaN / inf /
             // fractions / out-of-range values leave a nonzero difference)
             // (float data: the first element of a chunk settles it for the whole wave — three instructions instead of thirty)
@@ -835,6 +941,10 @@ __global__ __launch_bounds__(kPrepThreads) void knn_prep_kernel(BatchPtrs P, int
             *reinterpret_cast<uint4*>((isq ? qsplit : tsplit) + (2 * (int64_t)npad + r) * kDim + 8 * c) = packed;   // row-major fp16 plane (LDS-ring filter, its refine screens)
         }
         }
+        if (q8pair) {
+            err2q += lane_xor<8>(err2q); err2q += lane_xor<4>(err2q); err2q += lane_xor<2>(err2q); err2q += lane_xor<1>(err2q);
+            err2 = err2q < kInf ? err2q : kInf;                          // (NaN / inf data: an infinite slack — everything is re-evaluated exactly)
+        }
         // (train image only: the query side of the init product is the same for every query of the pair — ||q||^2max, see
         // knn_filter_q4_kernel — and is formed by the filter itself)
         if (frag && c < 2 && !isq) *reinterpret_cast<uint2*>(tfrag + (int64_t)(r >> 5) * kTileFragBytes + 8 * kFragBytes + ((c * 32 + (r & 31)) << 3)) = frag_init_operand(nrm, false, c);
@@ -878,7 +988,7 @@ __global__ __launch_bounds__(kPrepThreads) void knn_prep_kernel(BatchPtrs P, int
     }
     int wfl = 0;
 #pragma unroll
-    for (int b = 1; b <= 16; b <<= 1) wfl |= __any((flags & b) != 0) ? b : 0;
+    for (int b = 1; b <= kFlagQ8; b <<= 1) wfl |= __any((flags & b) != 0) ? b : 0;
     __shared__ float wmaxe[kPrepWaves], wmaxq[kPrepWaves];
     __shared__ int w8lo[kPrepWaves], w8hi[kPrepWaves];
     if (do8) {
@@ -958,7 +1068,7 @@ __global__ __launch_bounds__(kSplitThreads) void knn_split_images_kernel(BatchPt
     // words (the eight pairs in parallel: one round trip; as a loop over the pairs inside every filter workgroup this was
     // 8-10 us of dependent loads at the head of the filter launch), workgroup 0 leaves the result — per pair the mode,
     // ||t||max and the largest fp16 residual, and the batch's mode — in `minfo` for the filter and refine kernels.
-    __shared__ int smode[kMaxBatch], s8ok[kMaxBatch], s8base[kMaxBatch], s8some[kMaxBatch];
+    __shared__ int smode[kMaxBatch], s8ok[kMaxBatch], s8base[kMaxBatch], s8some[kMaxBatch], sq8[kMaxBatch];
     {
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
         static_assert(kSplitThreads / 64 >= kMaxBatch, "one wave per pair");
@@ -973,6 +1083,7 @@ __global__ __launch_bounds__(kSplitThreads) void knn_split_images_kernel(BatchPt
                 const int fl4 = fl[lane] | fl[lane + 64] | fl[lane + 128] | fl[lane + 192];
                 const bool u8 = !__any((fl4 & kFlagNotU8) != 0);
                 const bool some = __any((fl4 & kFlagSomeU8) != 0);
+                const bool q8p = __any((fl4 & kFlagQ8) != 0);              // the prep pass quantised this pair (float data)
                 int wl = min(min(lo[lane], lo[lane + 64]), min(lo[lane + 128], lo[lane + 192]));
                 int wh = max(max(hi[lane], hi[lane + 64]), max(hi[lane + 128], hi[lane + 192]));
 #pragma unroll
@@ -986,6 +1097,7 @@ __global__ __launch_bounds__(kSplitThreads) void knn_split_images_kernel(BatchPt
                     s8ok[wave] = (u8 && wl <= wh && ch - base <= kI8CMax && cl - base >= kI8CMin) ? 1 : 0;
                     s8base[wave] = base;
                     s8some[wave] = some ? 1 : 0;
+                    sq8[wave] = q8p ? 1 : 0;
                 }
             }
             const float* be = bmaxerr + wave * kNormBlocks;
@@ -1016,8 +1128,10 @@ __global__ __launch_bounds__(kSplitThreads) void knn_split_images_kernel(BatchPt
     // (frag_init_i8: the digits of floor(w_t / 2) - base) need the pair's base, so they are written here, not by the prep pass.
     bool i8 = ti8 != nullptr;
     for (int b = 0; b < B && i8; ++b) i8 = s8ok[b] != 0;
+    bool q8any = false;
+    for (int b = 0; b < B && ti8; ++b) q8any = q8any || sq8[b] != 0;
     if (blockIdx.x == 0 && threadIdx.x < kMaxBatch + 1) {
-        if (threadIdx.x == kMaxBatch) minfo[kMinfoI8] = i8 ? 1 : 0;
+        if (threadIdx.x == kMaxBatch) { minfo[kMinfoI8] = i8 ? 1 : 0; minfo[kMinfoQ8] = (i8 && q8any) ? 1 : 0; }
         else if (threadIdx.x < B && ti8) minfo[kMinfoBase + threadIdx.x] = s8base[threadIdx.x];
     }
     if (i8) {
@@ -1880,7 +1994,7 @@ template <int ABL>
 __device__ __forceinline__ void filter_i8_body(
     const unsigned char* __restrict__ qi8, const unsigned char* __restrict__ ti8, int nq, int nq_pad, int nt, int tiles, int nstr /*stream slots per row block*/,
     int* __restrict__ keys0, int* __restrict__ sttab0, const int64_t* __restrict__ wg_begin, int n_rb1, int64_t s_qi8, int64_t s_ti8, int64_t s_keys,
-    const int* __restrict__ wg_sbase, int G) {
+    const int* __restrict__ wg_sbase, int G, int sub_tiles /*tiles per substream (wave-uniform): kI8SubTiles, or kQ8SubTiles on quantised data*/) {
     constexpr int NG = kI8Groups, P = NG / 2, D = 2;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2009,7 +2123,7 @@ __device__ __forceinline__ void filter_i8_body(
                 }
             }
             // ---- substream boundary: every group's keys now cover exactly the tiles before t
-            if (t - sub_t0 == kI8SubTiles) {
+            if (t - sub_t0 == sub_tiles) {
                 flush(sub, sub_t0, t);
                 ++sub;
                 sub_t0 = t;
@@ -2074,7 +2188,7 @@ __global__ __launch_bounds__(256, 1) void knn_filter_q4_kernel(
         trace[8192 + 4 * blockIdx.x + 2] = clock64();
     }
     if (qi8 && minfo[kMinfoI8]) {                          // (uniform: one scalar load)
-        if ((int)blockIdx.x < G8) filter_i8_body<ABL>(qi8, ti8, nq, nq_pad, nt8, tiles, nstr8, keys8, sttab8, wg_begin8, n_rb1_8, s_qi8, s_ti8, s_keys8, wg_sbase8, G8);
+        if ((int)blockIdx.x < G8) filter_i8_body<ABL>(qi8, ti8, nq, nq_pad, nt8, tiles, nstr8, keys8, sttab8, wg_begin8, n_rb1_8, s_qi8, s_ti8, s_keys8, wg_sbase8, G8, minfo[kMinfoSub8]);
         if (trace && threadIdx.x == 0) {
             trace[4 * blockIdx.x + 1] = wall_clock64();
             trace[8192 + 4 * blockIdx.x + 3] = clock64();
@@ -2528,6 +2642,324 @@ __device__ __forceinline__ void refine_i8_body(
     }
 }
 
+// ---------------------------------------------------------------- refine, integer body on QUANTISED float data ("q8")
+// The records are the integer body's (exact D = sum (k_q - k_t)^2 of the 8-bit images); what they rank is the QUANTISED
+// distance d^ = s sqrt(D).  With E = ||q - q^|| + max_t ||t - t^|| (residual norms measured by the prep pass, rounded up) every
+// row satisfies | d - d^ | <= E for the real distance d = ||q - t||, and the float32 direct-form value the reference returns,
+// dc = sqrtf(fl(sum (q - t)^2)), satisfies | dc - d | <= rho d + eta (rho = 2^-19: <= 14 roundings of 2^-24 in the sum and the
+// square root, generously; eta = 1e-17 for sums that underflow).  In units of s (e = E / s, ...):
+//   select    two distinct real rows have D <= U = cq + 2 (a(2) + base) + 1 (the two smallest record keys), so the second
+//             smallest dc is <= R = (sqrt(U) + e)(1 + rho) + eta; a row of the answer has dc <= R, hence
+//             D <= Dlim(R) = ((R + eta)(1 + 2 rho) + e)^2.  Records whose lower bound of D is above that are skipped.
+//   evaluate  the listed records' rows in integers (a lane per row); those with D <= Dlim(R) in the reference's float32
+//             arithmetic (a lane quad per row, OpenCV's accumulation order), ordered by (dc, index)
+//   certify   a stream discards only rows with acc >= its third key's: D >= Dlow = cq + 2 (a3 + base), so
+//             dc >= (sqrt(Dlow) - e)(1 - rho) - eta; a stream whose bound exceeds the answer's dc2 hides nothing
+//   rescan    any other full stream: the WAVE evaluates its rows in integers, 64 per trip, and the open query's lanes
+//             re-evaluate those with D <= Dlim(dc2) exactly.  No workgroup barrier anywhere.
+// u8 pairs inside a quantised batch are the case s = 1, lo = 0, E ~ 0.
+// Everything below is float32 arithmetic in units of s on numbers <= 2^23; kQ8Rho = 4e-6 carries rho (1.9e-6) AND the roundings
+// of these few operations (each <= 6e-8 relative, a dozen of them): every bound is pushed outwards by it at every use.
+constexpr float kQ8Rho = 4e-6f, kQ8Eta = 1e-17f;
+__device__ __forceinline__ void refine_q8_body(
+    const BatchPtrs& P, int B, int64_t ldq, int nq, int64_t ldt, int nt, int tiles, const int* __restrict__ minfo, const unsigned char* __restrict__ qi8,
+    const unsigned char* __restrict__ ti8, int64_t s_qi8, int64_t s_ti8, const int* __restrict__ wq, const int* __restrict__ wt, int64_t s_qn, int64_t s_tn,
+    const float* __restrict__ qerr, const int* __restrict__ keys, const int* __restrict__ sttab, int64_t s_keys, int nstr, const int* __restrict__ rb_last8,
+    int n_rb1, int G8, double ratio, int* __restrict__ ratio_counts, float* __restrict__ qrows /*LDS [kRefQ][128]*/,
+    unsigned char* __restrict__ qb /*LDS [kRefQ][128]*/, int* __restrict__ recl /*LDS [kRefQ][2 * kRecCapI8]*/, int* __restrict__ quall /*LDS [kRefQ][kQualCap]*/,
+    long long* __restrict__ trace) {
+    const int n_wg = (nq + kRefQ - 1) / kRefQ, n_tot = B * n_wg, wg_chunk = (n_tot + 7) >> 3;
+    const int bidt = n_tot >= 64 ? (int)(blockIdx.x & 7) * wg_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (bidt >= n_tot) return;
+    if (trace && threadIdx.x == 0) trace[16 * bidt + 0] = wall_clock64();   // dev diagnostics
+    const int pb = bidt / n_wg, bid = bidt - pb * n_wg;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane >> 4, sl = lane & 15;
+    const int ql = wave * 4 + sub;
+    const int q = bid * kRefQ + ql;
+    const bool valid = q < nq;
+    const int qc = valid ? q : 0;
+    const int rbl = (bid * kRefQ) / kI8Rows, rb = pb * n_rb1 + rbl;
+    const int qloc = qc - rbl * kI8Rows;
+    const int NC = rb_last8[B * n_rb1 + rb] * 6;              // live key slots of the row block: streams x 2 half-waves x 3
+    const int base = minfo[kMinfoBase + pb];
+    const float* __restrict__ Q = P.q[pb];
+    const float* __restrict__ T = P.t[pb];
+    qi8 += pb * s_qi8; ti8 += pb * s_ti8; wq += pb * s_qn; wt += pb * s_tn; keys += pb * s_keys; qerr += pb * s_qn;
+    const int* __restrict__ kq = keys + (int64_t)rbl * nstr * 6 * kI8Rows + qloc;      // slot c of this query: kq[c * kI8Rows]
+    const int* __restrict__ stt = sttab + (int64_t)rb * nstr * 2;
+    int* __restrict__ stats = P.stats[pb];
+    if (bid == 0 && threadIdx.x == 0 && stats) { stats[1] = G8; stats[2] = 2 * nstr; stats[3] = 5; }
+
+    // the query's bytes (element order) and its float32 row -> LDS; wave-local
+    if (sl < 8) *reinterpret_cast<uint4*>(qb + ql * kDim + 16 * sl) =
+        *reinterpret_cast<const uint4*>(qi8 + (int64_t)(qc >> 5) * kI8QTileBytes + (sl >> 1) * 1024 + (((sl & 1) * 32 + (qc & 31)) << 4));
+    {
+        const float* src = Q + (int64_t)qc * ldq + 8 * sl;
+        *reinterpret_cast<float4*>(qrows + ql * kDim + 8 * sl) = *reinterpret_cast<const float4*>(src);
+        *reinterpret_cast<float4*>(qrows + ql * kDim + 8 * sl + 4) = *reinterpret_cast<const float4*>(src + 4);
+    }
+    const int cq = wq[qc] - 128;
+    const float qe2 = qerr[qc];
+    int kv[kS1], st0[kS1];                                       // keys, and the first tile of each key's stream (requested together:
+#pragma unroll                                                   // a record's tile is then known without a dependent table lookup)
+    for (int k = 0; k < kS1; ++k) {
+        const int c = sl + 16 * k;
+        kv[k] = (valid && c < NC) ? kq[(int64_t)c * kI8Rows] : INT_MAX;
+        st0[k] = (valid && c < NC) ? stt[2 * (c / 6)] : 0;
+    }
+    // the pair's grid and this query's slack, in units of s
+    const float sf = __int_as_float(minfo[kMinfoQ8S + pb]), lof = __int_as_float(minfo[kMinfoQ8Lo + pb]);
+    const float te2 = __int_as_float(minfo[kMinfoTerr + pb]);
+    const float inv_s = 1.f / sf;
+    const float eta_s = kQ8Eta * inv_s;
+    float e_s;
+    {
+        const float mabs = fmaxf(fabsf(lof), fabsf(lof + 255.f * sf));
+        // residual norms: float32 sums (<= 12 roundings) of differences each within 2^-24 mabs of the real one
+        const float E = (sqrtf(qe2) + sqrtf(te2)) * (1.f + 8e-6f) + 24.f * 5.9604645e-08f * mabs * (1.f + 1e-6f);
+        e_s = E * inv_s * (1.f + 1e-6f);
+        if (!(e_s < 1e30f)) e_s = kInf;                          // (NaN / inf residuals: nothing is ever certified or skipped)
+    }
+    // largest D a row whose float32 distance is <= x (in units of s) can have
+    auto dlim_of = [&](float x) -> float {
+        const float r = (x + eta_s) * (1.f + 2.f * kQ8Rho) + e_s;
+        return r * r * (1.f + 1e-6f) + 2.f;
+    };
+    int a1 = INT_MAX, a2 = INT_MAX, atau = INT_MAX;
+#pragma unroll
+    for (int k = 0; k < kS1; ++k) {
+        a2 = imed3(a1, a2, kv[k]);
+        a1 = min(a1, kv[k]);
+        if ((sl + 16 * k) % 3 == 2) atau = min(atau, kv[k]);
+    }
+    if (valid)
+        for (int c = sl + 16 * kS1; c < NC; c += 16) {
+            const int x = kq[(int64_t)c * kI8Rows];
+            if (c % 3 == 2) atau = min(atau, x);
+            a2 = imed3(a1, a2, x);
+            a1 = min(a1, x);
+        }
+    auto fold = [&](int o1, int o2, int ot) {
+        const int hi = max(a1, o1);
+        a1 = min(a1, o1);
+        a2 = min(hi, min(a2, o2));
+        atau = min(atau, ot);
+    };
+    fold(lane_xor<8>(a1), lane_xor<8>(a2), lane_xor<8>(atau));
+    fold(lane_xor<4>(a1), lane_xor<4>(a2), lane_xor<4>(atau));
+    fold(lane_xor<2>(a1), lane_xor<2>(a2), lane_xor<2>(atau));
+    fold(lane_xor<1>(a1), lane_xor<1>(a2), lane_xor<1>(atau));
+    // record threshold (keys) and row threshold (D) from the second smallest record key; every record when there are fewer than two
+    int thr = kKeyEmptyI - 1;
+    int dlim = INT_MAX;                                          // rows with D <= dlim are evaluated in float32
+    if (a2 < kKeyEmptyI) {
+        const long long U = (long long)cq + 2 * ((long long)(a2 >> 8) + base) + 1;
+        const float R = (sqrtf((float)(U > 0 ? U : 0)) * (1.f + 2e-7f) + e_s) * (1.f + kQ8Rho) + eta_s;
+        const float dl = dlim_of(R);
+        if (dl < 1.6e7f) {                                       // (D < 2^23 for every row: a larger bound limits nothing)
+            dlim = (int)dl;
+            // a row with D <= dlim has acc <= al (D >= cq + 2 (acc + base)); integer arithmetic from here on
+            const long long al = (((long long)dlim - cq) >> 1) - base + 1;
+            if (al < 8388606) thr = (int)((((unsigned)(int)al) << 8) | 0xFFu);
+        }
+        if (thr < a2) thr = a2;                                  // (never below the two records the bound came from)
+    }
+    if (trace && threadIdx.x == 0) trace[16 * bidt + 1] = wall_clock64();
+
+    Best2 b;
+    b.d[0] = b.d[1] = kInf; b.i[0] = b.i[1] = INT_MAX;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // exact D of one row per lane: register r of record (tile, half-wave hh, register half e) against the bytes of query slot `qslot`
+    auto int_row = [&](int tile, int hh, int e, int r, int qslot, int cqv, int& row) -> int {
+        const int jr = 16 * e + 8 * (r >> 2) + 4 * hh + (r & 3);
+        row = tile * kTileT + jr;
+        const unsigned char* tp = ti8 + (int64_t)tile * kI8TileBytes + (jr << 4);
+        uint4 tv[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) tv[c] = *reinterpret_cast<const uint4*>(tp + (c >> 1) * 1024 + (c & 1) * 512);
+        const int w = wt[row];
+        int s0 = 0, s1 = 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const uint4 qv = *reinterpret_cast<const uint4*>(qb + qslot * kDim + 16 * c);
+            s0 = __builtin_amdgcn_sdot4((int)tv[c].x, (int)qv.x, s0, false);
+            s1 = __builtin_amdgcn_sdot4((int)tv[c].y, (int)qv.y, s1, false);
+            s0 = __builtin_amdgcn_sdot4((int)tv[c].z, (int)qv.z, s0, false);
+            s1 = __builtin_amdgcn_sdot4((int)tv[c].w, (int)qv.w, s1, false);
+        }
+        return cqv + w + 2 * (s0 + s1);
+    };
+    auto row_scan = [&](int v, int& total) {
+        v += __builtin_amdgcn_update_dpp(0, v, 0x111 /*row_shr:1*/, 0xF, 0xF, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x112 /*row_shr:2*/, 0xF, 0xF, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x114 /*row_shr:4*/, 0xF, 0xF, true);
+        v += __builtin_amdgcn_update_dpp(0, v, 0x118 /*row_shr:8*/, 0xF, 0xF, true);
+        total = __builtin_amdgcn_ds_swizzle(v, 0x10 | (0x0F << 5));
+        return v;
+    };
+    auto wave_max = [&](int v) {
+        v = max(v, lane_xor<16>(v));
+        return max(v, __shfl_xor(v, 32, 64));
+    };
+    int* __restrict__ myrec = recl + ql * (2 * kRecCapI8);
+    int* __restrict__ myqual = quall + ql * kQualCap;
+    auto rec_info = [](int key, int t0, int c) { return ((t0 + ((key & 0xFF) >> 1)) << 1) | ((c / 3) & 1); };   // a record's tile << 1 | half-wave
+    int nrec = 0, nqual = 0;
+    // float32 evaluation of the rows on the query's list: a lane quad per row, four rows per pass (wave-uniform trip count)
+    auto eval_list = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int nmax = wave_max(nqual);
+#pragma unroll 1
+        for (int e0 = 0; e0 < nmax; e0 += 4) {
+            const int e = e0 + (sl >> 2);
+            const int row = e < nqual ? myqual[e] : -1;
+            const float* const trow[1] = {row >= 0 ? T + (int64_t)row * ldt : nullptr};
+            float out[1];
+            exact_l2sq_quad_rows<1, true>(qrows + ql * kDim, trow, sl & 3, out);
+            if ((sl & 3) == 2 && row >= 0) best2_insert_unique(b, sqrtf(out[0]), row);
+        }
+        best2_reduce16_from_quad_lane2(b);
+        __builtin_amdgcn_wave_barrier();
+        nqual = 0;
+    };
+    auto process = [&]() {                                       // integer evaluation of the listed records: two 8-row records per pass
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int nmax = wave_max(nrec);
+#pragma unroll 1
+        for (int e0 = 0; e0 < nmax; e0 += 2) {
+            if (__any(nqual > kQualCap - 16)) eval_list();
+            const int e = e0 + (sl >> 3);
+            const bool live = e < nrec;
+            const int key = live ? myrec[2 * e] : 0, inf = live ? myrec[2 * e + 1] : 0;      // (idle lanes: tile 0, result unused)
+            int row;
+            const int D = int_row(min(inf >> 1, tiles - 1), inf & 1, key & 1, sl & 7, ql, cq, row);
+            const bool take = live && row < nt && D <= dlim;
+            int total;
+            const int at = row_scan(take ? 1 : 0, total) - (take ? 1 : 0);
+            if (take) myqual[nqual + at] = row;
+            nqual += total;
+        }
+        __builtin_amdgcn_wave_barrier();
+        nrec = 0;
+    };
+    {   // the chunks still in registers: one prefix sum when the list holds them all
+        bool take[kS1];
+        int mine = 0;
+#pragma unroll
+        for (int k = 0; k < kS1; ++k) {
+            take[k] = kv[k] <= thr;                              // (empty / invalid slots: INT_MAX or >= kKeyEmptyI > thr)
+            mine += take[k] ? 1 : 0;
+        }
+        int total;
+        int at = row_scan(mine, total) - mine;
+        if (!__any(total > kRecCapI8)) {
+#pragma unroll
+            for (int k = 0; k < kS1; ++k)
+                if (take[k]) { myrec[2 * at] = kv[k]; myrec[2 * at + 1] = rec_info(kv[k], st0[k], sl + 16 * k); ++at; }
+            nrec = total;
+        } else {
+#pragma unroll 1
+            for (int k = 0; k < kS1; ++k) {
+                if (__any(nrec > kRecCapI8 - 16)) process();
+                int kvk = kv[0], stk = st0[0];
+#pragma unroll
+                for (int kk = 1; kk < kS1; ++kk) { kvk = k == kk ? kv[kk] : kvk; stk = k == kk ? st0[kk] : stk; }
+                const bool tk = kvk <= thr;
+                int tot;
+                const int a0 = row_scan(tk ? 1 : 0, tot) - (tk ? 1 : 0);
+                if (tk) { myrec[2 * (nrec + a0)] = kvk; myrec[2 * (nrec + a0) + 1] = rec_info(kvk, stk, sl + 16 * k); }
+                nrec += tot;
+            }
+        }
+    }
+    for (int k0 = kS1; k0 * 16 < NC; ++k0) {                     // (wave-uniform) more than 96 key slots per query
+        if (__any(nrec > kRecCapI8 - 16)) process();
+        const int c = sl + 16 * k0;
+        const bool in = valid && c < NC;
+        const int x = in ? kq[(int64_t)c * kI8Rows] : INT_MAX;
+        const int t0x = in ? stt[2 * (c / 6)] : 0;
+        const bool take = x <= thr;
+        int total;
+        const int at = row_scan(take ? 1 : 0, total) - (take ? 1 : 0);
+        if (take) { myrec[2 * (nrec + at)] = x; myrec[2 * (nrec + at) + 1] = rec_info(x, t0x, c); }
+        nrec += total;
+    }
+    if (trace && threadIdx.x == 0) { trace[16 * bidt + 2] = wall_clock64(); trace[16 * bidt + 13] = nrec; }
+    process();
+    if (trace && threadIdx.x == 0) { trace[16 * bidt + 3] = wall_clock64(); trace[16 * bidt + 14] = nqual; }
+    eval_list();
+    if (trace && threadIdx.x == 0) trace[16 * bidt + 4] = wall_clock64();
+
+    // certificate: does the stream with third key `key3` provably hide nothing closer than the answer's second distance?
+    auto hides_nothing = [&](int key3, float d2c) -> bool {
+        if (key3 >= kKeyEmptyI) return true;                       // fewer than three records: the stream discarded nothing
+        const long long dlow = (long long)cq + 2 * ((long long)(key3 >> 8) + base);
+        const float lowb = (sqrtf((float)(dlow > 0 ? dlow : 0)) * (1.f - 2e-7f) - e_s) * (1.f - kQ8Rho) - eta_s;
+        return lowb > d2c * inv_s * (1.f + 1e-6f);                 // (d2c = +inf while fewer than two rows are known, e_s = +inf: false)
+    };
+    const bool open = valid && !hides_nothing(atau, b.d[1]);
+    // Rescan (rare): the WAVE works for one open query at a time; 64 lanes take four tiles of an uncertified stream per trip
+    // (integer D of one row each), the rows within the bound join the open query's list and are re-evaluated by its own lanes.
+    unsigned long long openm = __ballot(open);
+    if (trace && threadIdx.x == 0) trace[16 * bidt + 6] = openm != 0;
+    while (openm) {                                                // (wave-uniform)
+        const int wl = (int)__builtin_ctzll(openm) >> 4;           // query slot inside the wave
+        openm &= ~(0xFFFFull << (16 * wl));
+        const int src = 16 * wl;
+        const int cq_w = __shfl(cq, src, 64), qloc_w = __shfl(qloc, src, 64);
+        const int* __restrict__ kw = kq + (qloc_w - qloc);         // the open query's key column
+        const bool mine = sub == wl;
+        for (int c3 = 2; c3 < NC; c3 += 3) {
+            const int key3 = kw[(int64_t)c3 * kI8Rows];            // (uniform)
+            // the owner's lanes decide (their slack, their current second distance); everyone follows
+            const bool hid = hides_nothing(key3, b.d[1]);
+            const unsigned long long vote = __ballot(mine && !hid);
+            if (!vote) continue;
+            // D bound of rows that can still enter the answer, from the owner's current second distance
+            int dl_o = INT_MAX;
+            {
+                const float dl = dlim_of(b.d[1] * inv_s * (1.f + 1e-6f));
+                if (dl < 1.6e7f) dl_o = (int)dl;
+            }
+            const int dl_w = __shfl(dl_o, src, 64);
+            const int t0 = stt[2 * (c3 / 6)], len = stt[2 * (c3 / 6) + 1], hh = (c3 / 3) & 1;
+            for (int tt = 0; tt < len; tt += 4) {
+                if (__any(nqual > kQualCap - 64)) eval_list();
+                const int tl = tt + (lane >> 4);
+                const bool live = tl < len;
+                int row;
+                const int D = int_row(live ? t0 + tl : t0, hh, (lane >> 3) & 1, lane & 7, wave * 4 + wl, cq_w, row);
+                const bool take = live && row < nt && D <= dl_w;
+                const unsigned long long tm = __ballot(take);
+                const int nq_w = __shfl(nqual, src, 64);             // (the owner's list length)
+                if (take) quall[(wave * 4 + wl) * kQualCap + nq_w + __popcll(tm & ((1ull << lane) - 1ull))] = row;
+                if (mine) nqual += __popcll(tm);
+            }
+        }
+        eval_list();
+    }
+
+    int* __restrict__ idx_out = P.idx[pb];
+    float* __restrict__ dist_out = P.dist[pb];
+    unsigned char* __restrict__ ratio_mask = P.mask[pb];
+    if (valid && sl == 0) {
+        *reinterpret_cast<int2*>(idx_out + 2 * (int64_t)q) = make_int2(b.i[0] == INT_MAX ? -1 : b.i[0], b.i[1] == INT_MAX ? -1 : b.i[1]);
+        *reinterpret_cast<float2*>(dist_out + 2 * (int64_t)q) = make_float2(b.d[0], b.d[1]);
+        if (open && stats) atomicAdd(stats, 1);
+    }
+    if (ratio_counts) {                                          // (already offset to this pair by the caller)
+        const bool pass = valid && sl == 0 && b.i[1] != INT_MAX && (double)b.d[0] < ratio * (double)b.d[1];
+        if (ratio_mask && valid && sl == 0) ratio_mask[q] = pass ? 1 : 0;
+        const int n = __popcll(__ballot(pass));
+        if (lane == 0) ratio_counts[bid * 4 + wave] = n;           // one plain store per wave (see kRatioSub)
+    }
+    if (trace && threadIdx.x == 0) trace[16 * bidt + 5] = wall_clock64();
+}
+
 // Sixteen lanes per query, sixteen queries per workgroup (one resident round for 10^4 queries).
 //   sweep 1  two smallest filter scores over the query's candidate records and each stream's 3rd best
 //   sweep 2  candidates within 4*eps of the 2nd smallest score are compacted and evaluated exactly → (d1, d2)
@@ -2587,6 +3019,12 @@ __global__ __launch_bounds__(256, 4) void knn_refine_kernel(
     __shared__ int surv[kSubTiles * 16];
     __shared__ int nitem, nsurv;
     __shared__ Best2 wbest[4];
+    if constexpr (FRAG)
+    if (qi8 && minfo && minfo[kMinfoI8] && minfo[kMinfoQ8]) {   // (uniform) the integer body ran on quantised float data
+        refine_q8_body(P, B, ldq, nq, ldt, nt, tiles, minfo, qi8, ti8, s_qi8, s_ti8, wq8, wt8, s_qn, s_tn, qerr, keys8, sttab8, s_keys8, nstr8, rb_last8, n_rb1_8, G8,
+                       ratio, ratio_counts, &qrows[0][0], reinterpret_cast<unsigned char*>(&qhalf[0][0]), &rec[0][0], &qual[0][0], trace);
+        return;
+    }
     if constexpr (FRAG)
     if (qi8 && minfo && minfo[kMinfoI8]) {                 // (uniform) the exact-integer body ran: its records, its certificate
         refine_i8_body(P, B, nq, nt, tiles, minfo, qi8, ti8, s_qi8, s_ti8, wq8, wt8, s_qn, s_tn, keys8, sttab8, s_keys8, nstr8, rb_last8, n_rb1_8, G8, ratio,
@@ -3567,7 +4005,7 @@ int knn_batch_impl(int B, const BatchPtrs& P, int64_t nq, int64_t ldq, int64_t n
                            ratio_counts, 0 /*(the refine kernel writes every count: nothing to zero)*/,
                            p.units, p.tiles, p.G, p.seg_cost, p.n_rb, w.wg_begin, w.rb_first, w.rb_last, p.q4 ? w.wg_sbase : nullptr,
                            w.qi8, w.ti8, w.s_qi8, w.s_ti8, w.wq, w.wt, w.bwmin, w.bwmax, w.rmq, w.rmt, p8.units, p8.G, p8.n_rb, w.wg_begin8, w.rb_first8,
-                           w.rb_last8, w.wg_sbase8);
+                           w.rb_last8, w.wg_sbase8, (p.i8 && g_q8) ? 1 : 0, w.minfo);
         SFM_CHECK_LAUNCH();
         hipLaunchKernelGGL(knn_split_images_kernel, dim3(kNormBlocks), dim3(kSplitThreads), 0, stream, P, B, ldq, (int)nq, p.nq_pad, ldt, (int)nt,
                            p.tiles * kTileT, w.qsplit, w.tsplit, w.s_qsplit, w.s_tsplit, w.midflag, w.bmax, p.force_mode,
