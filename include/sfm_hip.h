@@ -56,7 +56,8 @@ const char* sfm_last_error(void);
  *       [0] queries for which at least one filter stream had to be rescanned exactly
  *       [1] filter workgroups launched   [2] candidate streams reserved per query
  *       [3] filter arithmetic that ran: 0 fp16 single product, exact inputs; 1 fp16 single product;
- *           2 bf16 hi/mid split; 3 fp32 MFMA; 4 exact-integer i8 MFMA (u8-integer descriptors: real SIFT output)
+ *           2 bf16 hi/mid split; 3 fp32 MFMA; 4 exact-integer i8 MFMA (u8-integer descriptors: real SIFT output);
+ *           5 the i8 MFMA body on float descriptors QUANTISED to 8 bits (certified by their measured residual norms)
  *
  * dim must be 128 (SIFT); q_dev/t_dev 16-byte aligned; ldq, ldt multiples of 4; nt <= 4 000 000.
  * The result is bit-identical to the direct-form float32 evaluation for ANY
@@ -67,8 +68,14 @@ const char* sfm_last_error(void);
  *   SFM_KNN_FILTER_AUTO       MFMA filter, fragments streamed L2 -> registers (knn_filter_q4_kernel); its
  *                             arithmetic is chosen ON THE DEVICE from the data: the exact-integer body
  *                             (v_mfma_i32_32x32x32_i8, i32 scores, integer certificate) when every value of the batch is an
- *                             integer 0 .. 255 — what cv2 SIFT emits (sfm.py:246-252) —, else one fp16 product when the
- *                             values fit fp16's range, else the three-product bf16 hi/mid split
+ *                             integer 0 .. 255 — what cv2 SIFT emits (sfm.py:246-252) —; the same body on the pairs'
+ *                             values QUANTISED to 8 bits (x ~ lo + s k, one grid per pair from a sample of its rows, the
+ *                             residual norms measured, | ||q - t|| - s sqrt(D) | <= ||q - q^|| + ||t - t^|| as the
+ *                             certificate, survivors re-evaluated in float32) when the sampled values have compact
+ *                             support (range <= 5 standard deviations: e.g. uniform data) and the grid turns out to
+ *                             fit; else one fp16 product when the values fit fp16's range, else the three-product
+ *                             bf16 hi/mid split
+ *   SFM_KNN_FILTER_NOQUANT    as AUTO, but float data never run quantised (the exact-integer body still serves u8 data)
  *   SFM_KNN_FILTER_HALF       as AUTO without the exact-integer body (16-bit arithmetic whatever the data)
  *   SFM_KNN_FILTER_F32        fp32 MFMA filter (single pair only)
  *   SFM_KNN_FILTER_SPLIT      as AUTO but pinned to the bf16 split
@@ -80,6 +87,7 @@ const char* sfm_last_error(void);
 #define SFM_KNN_FILTER_LDS       3
 #define SFM_KNN_FILTER_LDS_SPLIT 4
 #define SFM_KNN_FILTER_HALF      5
+#define SFM_KNN_FILTER_NOQUANT   6
 size_t sfm_knn2_l2_f32_ws_bytes(int64_t nq, int64_t nt, int dim, int filter);
 int    sfm_knn2_l2_f32(const float* q_dev, int64_t nq, int64_t ldq,
                        const float* t_dev, int64_t nt, int64_t ldt, int dim, int filter,

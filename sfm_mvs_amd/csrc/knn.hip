@@ -75,8 +75,10 @@ struct BatchPtrs {
 };
 
 // Filter variants (the `filter` argument of the entry points, include/sfm_hip.h): results are bit-identical whichever runs.
-constexpr int kFilterAuto = 0, kFilterF32 = 1, kFilterSplit = 2, kFilterLds = 3, kFilterLdsSplit = 4, kFilterHalf = 5;
+constexpr int kFilterAuto = 0, kFilterF32 = 1, kFilterSplit = 2, kFilterLds = 3, kFilterLdsSplit = 4, kFilterHalf = 5,
+              kFilterNoQuant = 6;   // as kFilterAuto, but float data never run QUANTISED on the integer body (exact u8 data still do)
 constexpr int kFilterI8Plan = 100;     // internal: the plan of the exact-integer body that kFilterAuto carries beside its fp16 plan
+constexpr int kFilterI8PlanQ8 = 101;   // internal: the same with the short substreams quantised data run with (sizes the slot arrays)
 
 struct Plan {
     int split;         // 1: 16-bit MFMA filter (default), 0: fp32-MFMA filter
@@ -96,7 +98,8 @@ struct Plan {
     int nsub;          // substreams (32 tiles each) per slot
     int seg_cost;      // partition weight of a segment in tile-steps (0: plain equal-units split)
     int sub_tiles;     // tiles per substream (64: the 16-bit filters' key holds 6 bits of tile + 2 of quad; 256: the i8 body's key holds 8 bits of tile)
-    int i8;            // 1: kFilterAuto — the launch set also carries the exact-integer (i8 MFMA) body, chosen on the device for u8-integer data
+    int i8;            // 1: kFilterAuto / kFilterNoQuant — the launch set also carries the exact-integer (i8 MFMA) body, chosen on the device for u8-integer data
+    int q8;            // 1: kFilterAuto — float pairs whose sampled values have compact support are QUANTISED to 8 bits for that body
 };
 
 __host__ __device__ inline int64_t unit_begin(int64_t units, int G, int b) { return units * b / G; }
@@ -140,7 +143,7 @@ __host__ __device__ inline int64_t part_begin(const Partition& pt, int b) {
 }
 constexpr int kSegCostTiles = 5;
 int g_seg_cost = [] { const char* e = getenv("SFM_KNN_SEGCOST"); return e ? atoi(e) : kSegCostTiles; }();   // dev override
-int g_q8 = [] { const char* e = getenv("SFM_KNN_Q8"); return e ? atoi(e) : 0; }();   // 1: float pairs of a kFilterAuto call are quantised for the integer body
+int g_q8 = [] { const char* e = getenv("SFM_KNN_Q8"); return e ? atoi(e) : 1; }();   // dev override: 0 = kFilterAuto never quantises (= kFilterNoQuant)
 int g_seg_cost_q4 = [] { const char* e = getenv("SFM_KNN_SEGCOST_Q4"); return e ? atoi(e) : 5; }();              // q4 kernel: a segment's prologue in tile-steps
 
 // One workgroup fills the partition tables the filter / refine kernels read: begin[G+1], and per query row block the
@@ -228,9 +231,10 @@ Plan make_plan_uncached(int64_t nq, int64_t nt, int B, int filter) {
     p.split = filter == kFilterF32 ? 0 : 1;
     p.q4 = (filter == kFilterLds || filter == kFilterLdsSplit || filter == kFilterF32) ? 0 : 1;
     p.force_mode = (filter == kFilterSplit || filter == kFilterLdsSplit) ? 2 /*kModeSplit*/ : -1;
-    p.i8 = filter == kFilterAuto ? 1 : 0;
-    const bool i8plan = filter == kFilterI8Plan;   // the partition of the i8 body: 8 query groups per wave, 1024-query row blocks
-    p.sub_tiles = i8plan ? (g_q8 ? kQ8SubTilesHost : kI8SubTilesHost) : kSubTilesHost;   // (i8 plan: the SHORTEST substreams the launch set may choose on the device — sizes the slot arrays)
+    p.i8 = (filter == kFilterAuto || filter == kFilterNoQuant) ? 1 : 0;
+    p.q8 = (filter == kFilterAuto && g_q8) ? 1 : 0;
+    const bool i8plan = filter == kFilterI8Plan || filter == kFilterI8PlanQ8;   // the partition of the i8 body: 8 query groups per wave, 1024-query row blocks
+    p.sub_tiles = i8plan ? (filter == kFilterI8PlanQ8 ? kQ8SubTilesHost : kI8SubTilesHost) : kSubTilesHost;   // (i8 plan: the SHORTEST substreams the launch set may choose on the device — sizes the slot arrays)
     p.qg = i8plan ? 8 : p.q4 ? 4 : p.split ? 2 : 1;
     if (p.q4) p.waves = 4;                     // one 4-wave workgroup per CU: one wave per SIMD, 512 registers each
     else if (p.split && !(env_w == 4 || env_w == 8 || env_w == 16)) p.waves = p.qg == 2 ? 4 : 16;   // split2: two 4-wave workgroups per CU (their barrier stalls interleave; ~3 % over one 8-wave group)
@@ -615,6 +619,7 @@ __device__ __forceinline__ int knn_filter_mode(const int* __restrict__ flags, co
 constexpr int kMinfoPairMode = 0, kMinfoBatchMode = kMaxBatch, kMinfoTmax = 16, kMinfoTerr = 24, kMinfoQmax = 32, kMinfoBase = 40, kMinfoI8 = 48,
               kMinfoQ8 = 49,      // 1: the integer body runs on QUANTISED data (some pair of the batch is float data): refine_q8_body certifies
               kMinfoSub8 = 50,    // tiles per substream of the integer body for this launch set (written by the prep launch's partition workgroup)
+              kMinfoBar = 51,     // arrival counter of the repair's grid barrier in knn_split_images_kernel (zeroed by the prep launch)
               kMinfoQ8S = 56, kMinfoQ8Lo = 64,   // per pair: the quantisation grid x ~ lo + s k, k = 0 .. 255 (float bits; written by the prep launch)
               kMinfoWords = 72;   // written by knn_split_images_kernel (block 0); kMinfoI8: 1 = the exact-integer body runs, kMinfoBase: its per-pair score offset
 __device__ __forceinline__ int knn_batch_mode(const int* __restrict__ flags, const float* __restrict__ bmax, int n_pairs, int lane) {
@@ -686,19 +691,21 @@ struct Q8Grid {
     int kind;        // 0: every sampled value is a u8 integer (exact-integer path, decided per chunk); 1: quantise; 2: not quantisable (16-bit bodies)
 };
 __device__ __forceinline__ Q8Grid q8_sample_grid(const float* __restrict__ Q, int64_t ldq, int nq, const float* __restrict__ T, int64_t ldt, int nt,
-                                                 float* __restrict__ red /*LDS [12]*/) {
+                                                 float* __restrict__ red /*LDS [20]*/) {
     const int sr = threadIdx.x >> 4, c = threadIdx.x & 15;             // 256 threads: 16 rows x 16 chunks of 8 floats, of Q and of T
     const float* qs = Q + (int64_t)(((int64_t)sr * nq) >> 4) * ldq + 8 * c;
     const float* ts = T + (int64_t)(((int64_t)sr * nt) >> 4) * ldt + 8 * c;
     const float4 v0 = *reinterpret_cast<const float4*>(qs), v1 = *reinterpret_cast<const float4*>(qs + 4);
     const float4 v2 = *reinterpret_cast<const float4*>(ts), v3 = *reinterpret_cast<const float4*>(ts + 4);
     const float in[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
-    float mn = kInf, mx = -kInf;
+    float mn = kInf, mx = -kInf, sm = 0.f, sq = 0.f;
     bool bad = false, nonu8 = false;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         mn = fminf(mn, in[e]);
         mx = fmaxf(mx, in[e]);
+        sm += in[e];
+        sq = fmaf(in[e], in[e], sq);
         bad = bad || !(fabsf(in[e]) < kInf);                            // NaN / inf
         nonu8 = nonu8 || !(in[e] >= 0.f && in[e] <= 255.f && in[e] == floorf(in[e]));
     }
@@ -706,22 +713,28 @@ __device__ __forceinline__ Q8Grid q8_sample_grid(const float* __restrict__ Q, in
     for (int m = 32; m >= 1; m >>= 1) {
         mn = fminf(mn, __shfl_xor(mn, m, 64));
         mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+        sm += __shfl_xor(sm, m, 64);
+        sq += __shfl_xor(sq, m, 64);
     }
     const int fl = (__any(bad) ? 1 : 0) | (__any(nonu8) ? 2 : 0);
     __syncthreads();                                                    // (a caller may loop: the previous round's reads are done)
     if ((threadIdx.x & 63) == 0) {
-        red[3 * (threadIdx.x >> 6)] = mn;
-        red[3 * (threadIdx.x >> 6) + 1] = mx;
-        red[3 * (threadIdx.x >> 6) + 2] = __int_as_float(fl);
+        red[5 * (threadIdx.x >> 6)] = mn;
+        red[5 * (threadIdx.x >> 6) + 1] = mx;
+        red[5 * (threadIdx.x >> 6) + 2] = __int_as_float(fl);
+        red[5 * (threadIdx.x >> 6) + 3] = sm;
+        red[5 * (threadIdx.x >> 6) + 4] = sq;
     }
     __syncthreads();
     int flw = 0;
-    mn = red[0]; mx = red[1];
+    mn = red[0]; mx = red[1]; sm = 0.f; sq = 0.f;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-        mn = fminf(mn, red[3 * w]);
-        mx = fmaxf(mx, red[3 * w + 1]);
-        flw |= __float_as_int(red[3 * w + 2]);
+        mn = fminf(mn, red[5 * w]);
+        mx = fmaxf(mx, red[5 * w + 1]);
+        flw |= __float_as_int(red[5 * w + 2]);
+        sm += red[5 * w + 3];
+        sq += red[5 * w + 4];
     }
     Q8Grid g{0.f, 1.f, 1.f, 0};
     if (flw & 1) { g.kind = 2; return g; }
@@ -729,8 +742,55 @@ __device__ __forceinline__ Q8Grid q8_sample_grid(const float* __restrict__ Q, in
     const float s = (mx - mn) * (1.f / 255.f), mabs = fmaxf(fabsf(mn), fabsf(mx));
     // (a range below the float32 spacing of the values, or absurd magnitudes: the 16-bit bodies' business)
     if (!(s >= 1e-12f && s <= 1e30f && s >= 1.52587890625e-05f * mabs)) { g.kind = 2; return g; }
+    // COMPACT SUPPORT only: 256 levels over the range are worth it when the range is a few standard deviations (uniform data:
+    // 3.5; a Gaussian's 4096-value sample: 7 and its tails would clip).  Heavy-tailed data stay with the 16-bit bodies — a
+    // matter of speed; a wrong guess is caught by the measured residuals (knn_split_images_kernel) and repaired.
+    {
+        const float mean = sm * (1.f / 4096.f), var = fmaxf(sq * (1.f / 4096.f) - mean * mean, 0.f);
+        if (!((mx - mn) * (mx - mn) <= 25.f * var)) { g.kind = 2; return g; }
+    }
     g.lo = mn; g.s = s; g.inv = 1.f / s; g.kind = 1;
     return g;
+}
+
+// The fp16 image of one 8-element chunk of a row (sc = -2 for query rows): the packed values, the chunk's share of
+// ||fp16(row) - row||^2 (the certificate's operand-rounding term) and the exactness / range flags.  Shared by the prep pass and
+// by the repair of pairs that were quantised in vain (knn_split_images_kernel).
+__device__ __forceinline__ float fp16_chunk(const float (&in)[8], float sc, unsigned (&fw)[4], unsigned& flags) {
+    fw[0] = fw[1] = fw[2] = fw[3] = 0u;
+    float err2 = 0.f;
+    // The per-element tests — range (also NaN / inf), fp16-exactness, below fp16's normal range — are folded over the
+    // lane's eight elements on bit patterns (the kernel is bound by its vector-ALU instruction count, not by the bytes):
+    //   amax = max |e| bits;   umin = min (|e| bits - 1)  (0 wraps to 0xFFFFFFFF: "nonzero and below 2^-14" is ONE unsigned
+    //   compare);   dor = OR of the residuals' bits (any bit but the sign: inexact)
+    unsigned amax = 0u, umin = 0xFFFFFFFFu, dor = 0u;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float ev = sc * in[e];
+        const _Float16 hv = (_Float16)ev;                            // round to nearest even
+        fw[e >> 1] |= (unsigned)__builtin_bit_cast(unsigned short, hv) << (16 * (e & 1));
+        const float dv = ev - (float)hv;
+        err2 = fmaf(dv, dv, err2);
+        const unsigned ab = __float_as_uint(ev) & 0x7FFFFFFFu;
+        amax = max(amax, ab);
+        umin = min(umin, ab - 1u);
+        dor |= __float_as_uint(dv);
+    }
+    if (amax > 0x476A6000u /*60000.f*/) flags |= kFlagRangeBad;      // (NaN and inf patterns are larger still)
+    const bool has_sub = umin < 0x38800000u - 1u;                     // some element is nonzero and below 2^-14
+    if ((dor & 0x7FFFFFFFu) != 0u || has_sub) flags |= kFlagHalfInexact;
+    if (has_sub) {
+        // below fp16's normal range the matrix pipe may flush the operand to zero: the whole element is the error then
+        // (|e - hv| <= |e| holds for the rounded subnormal too, so this bounds both behaviours).  Rare: redo the sum.
+        err2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float ev = sc * in[e];
+            const float dv = fabsf(ev) < 6.103515625e-5f ? ev : ev - (float)__builtin_bit_cast(_Float16, (unsigned short)(fw[e >> 1] >> (16 * (e & 1))));
+            err2 = fmaf(dv, dv, err2);
+        }
+    }
+    return err2;
 }
 
 // One pass over Q and T: rows → the fp16 image (Q pre-scaled by -2, exact), fp32 squared norms, per-block max of
@@ -765,7 +825,7 @@ __global__ __launch_bounds__(kPrepThreads) void knn_prep_kernel(BatchPtrs P, int
                                                        int q8 /*1: float pairs are quantised for the integer body*/, int* __restrict__ minfo) {
     constexpr int kPrepWaves = kPrepThreads / 64, kPrepRows = kPrepThreads / 16;
     __shared__ float wmax[kPrepWaves];
-    __shared__ float q8red[12];
+    __shared__ float q8red[20];
     const int pb = blockIdx.y;
     if (blockIdx.x >= gridDim.x - 2) {                     // the two extra workgroups (of column 0): partition tables, nothing else
         if (pb == 0) {
@@ -777,7 +837,7 @@ __global__ __launch_bounds__(kPrepThreads) void knn_prep_kernel(BatchPtrs P, int
                 if (q8)
                     for (int b = 0; b < (int)gridDim.y; ++b)
                         if (q8_sample_grid(P.q[b], ldq, nq, P.t[b], ldt, nt, q8red).kind == 1) sub8 = kQ8SubTiles;
-                if (threadIdx.x == 0) minfo[kMinfoSub8] = sub8;
+                if (threadIdx.x == 0) { minfo[kMinfoSub8] = sub8; minfo[kMinfoBar] = 0; }
                 fill_partition_tables(make_partition(units8, tiles, G8, seg_cost), n_rb8, wg_begin8, rb_first8, rb_last8, wg_sbase8, sub8);
             }
         }
@@ -896,38 +956,8 @@ __global__ __launch_bounds__(kPrepThreads) void knn_prep_kernel(BatchPtrs P, int
         float err2 = 0.f;                                                // ||fp16(row) - row||^2: the certificate's operand-rounding term
         const float nrm = (isq || real) ? s : kInf;                      // padded train rows can never be candidates
         if (!__all(chunk8 && real)) {                                    // (wave-uniform: four rows of all-u8 chunks skip the 16-bit work)
-        unsigned fw[4] = {0u, 0u, 0u, 0u};                               // the eight fp16 values, packed as they are made
-        // The per-element tests — range (also NaN / inf), fp16-exactness, below fp16's normal range — are folded over the
-        // lane's eight elements on bit patterns (the kernel is bound by its vector-ALU instruction count, not by the bytes):
-        //   amax = max |e| bits;   umin = min (|e| bits - 1)  (0 wraps to 0xFFFFFFFF: "nonzero and below 2^-14" is ONE unsigned
-        //   compare);   dor = OR of the residuals' bits (any bit but the sign: inexact)
-        unsigned amax = 0u, umin = 0xFFFFFFFFu, dor = 0u;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float ev = sc * in[e];
-            const _Float16 hv = (_Float16)ev;                            // round to nearest even
-            fw[e >> 1] |= (unsigned)__builtin_bit_cast(unsigned short, hv) << (16 * (e & 1));
-            const float dv = ev - (float)hv;
-            err2 = fmaf(dv, dv, err2);
-            const unsigned ab = __float_as_uint(ev) & 0x7FFFFFFFu;
-            amax = max(amax, ab);
-            umin = min(umin, ab - 1u);
-            dor |= __float_as_uint(dv);
-        }
-        if (amax > 0x476A6000u /*60000.f*/) flags |= kFlagRangeBad;      // (NaN and inf patterns are larger still)
-        const bool has_sub = umin < 0x38800000u - 1u;                     // some element is nonzero and below 2^-14
-        if ((dor & 0x7FFFFFFFu) != 0u || has_sub) flags |= kFlagHalfInexact;
-        if (has_sub) {
-            // below fp16's normal range the matrix pipe may flush the operand to zero: the whole element is the error then
-            // (|e - hv| <= |e| holds for the rounded subnormal too, so this bounds both behaviours).  Rare: redo the sum.
-            err2 = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float ev = sc * in[e];
-                const float dv = fabsf(ev) < 6.103515625e-5f ? ev : ev - (float)__builtin_bit_cast(_Float16, (unsigned short)(fw[e >> 1] >> (16 * (e & 1))));
-                err2 = fmaf(dv, dv, err2);
-            }
-        }
+        unsigned fw[4];                                                  // the eight fp16 values
+        err2 = fp16_chunk(in, sc, fw, flags);
         err2 += lane_xor<8>(err2); err2 += lane_xor<4>(err2); err2 += lane_xor<2>(err2); err2 += lane_xor<1>(err2);
         if (!(err2 < kInf)) err2 = 0.f;                                  // (out-of-range data: the split arithmetic runs, this term is unused)
         const uint4 packed = make_uint4(fw[0], fw[1], fw[2], fw[3]);
@@ -1053,28 +1083,38 @@ constexpr int kSplitThreads = 512;
 __global__ __launch_bounds__(kSplitThreads) void knn_split_images_kernel(BatchPtrs P, int B, int64_t ldq, int nq, int nq_pad, int64_t ldt, int nt,
                                                                         int nt_pad, unsigned short* __restrict__ qsplit0,
                                                                         unsigned short* __restrict__ tsplit0, int64_t s_qsplit, int64_t s_tsplit,
-                                                                        const int* __restrict__ midflag, const float* __restrict__ bmax,
+                                                                        int* __restrict__ midflag, const float* __restrict__ bmax,
                                                                         int force_mode, unsigned char* __restrict__ qhm0 /*null: row-major planes*/,
                                                                         unsigned char* __restrict__ thm0, int64_t s_qhm, int64_t s_thm,
-                                                                        const float* __restrict__ bmaxerr, const float* __restrict__ bqmax, int* __restrict__ minfo,
+                                                                        float* __restrict__ bmaxerr, const float* __restrict__ bqmax, int* __restrict__ minfo,
                                                                         // exact-integer body (ti8 == null: not planned)
                                                                         unsigned char* __restrict__ ti8, int64_t s_ti8, const int* __restrict__ wt, int64_t s_tn,
                                                                         const int* __restrict__ bwmin, const int* __restrict__ bwmax,
                                                                         // ... and what the repair of a mixed batch needs (see below)
                                                                         const unsigned char* __restrict__ qi8, int64_t s_qi8, int64_t s_qn,
                                                                         const unsigned short* __restrict__ rmq, const unsigned short* __restrict__ rmt,
-                                                                        unsigned char* __restrict__ qfrag, unsigned char* __restrict__ tfrag, int64_t s_qfrag, int64_t s_tfrag) {
+                                                                        unsigned char* __restrict__ qfrag, unsigned char* __restrict__ tfrag, int64_t s_qfrag, int64_t s_tfrag,
+                                                                        float* __restrict__ qerr /*[B][s_qn]: rewritten for pairs repaired below*/) {
     // The batch's arithmetic mode, reduced ONCE for the launch set: wave b of every workgroup reduces pair b's 2 x 256 flag
     // words (the eight pairs in parallel: one round trip; as a loop over the pairs inside every filter workgroup this was
     // 8-10 us of dependent loads at the head of the filter launch), workgroup 0 leaves the result — per pair the mode,
     // ||t||max and the largest fp16 residual, and the batch's mode — in `minfo` for the filter and refine kernels.
     __shared__ int smode[kMaxBatch], s8ok[kMaxBatch], s8base[kMaxBatch], s8some[kMaxBatch], sq8[kMaxBatch];
-    {
+    auto reduce_modes = [&]() {
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
         static_assert(kSplitThreads / 64 >= kMaxBatch, "one wave per pair");
         if (wave < B) {
             float tmax;
             const int m = knn_filter_mode(midflag + wave * kNormBlocks, bmax + wave * kNormBlocks, lane, &tmax);
+            const float* be = bmaxerr + wave * kNormBlocks;
+            const float* bq = bqmax + wave * kNormBlocks;
+            float te = fmaxf(fmaxf(be[lane], be[lane + 64]), fmaxf(be[lane + 128], be[lane + 192]));
+            float qm = fmaxf(fmaxf(bq[lane], bq[lane + 64]), fmaxf(bq[lane + 128], bq[lane + 192]));
+#pragma unroll
+            for (int sh = 32; sh >= 1; sh >>= 1) {
+                te = fmaxf(te, __shfl_xor(te, sh, 64));
+                qm = fmaxf(qm, __shfl_xor(qm, sh, 64));
+            }
             if (ti8) {
                 // exact-integer body: every value a u8 integer, and floor(w_t / 2) of the pair's train rows within the init product's range
                 const int* fl = midflag + wave * kNormBlocks;
@@ -1093,21 +1133,17 @@ __global__ __launch_bounds__(kSplitThreads) void knn_split_images_kernel(BatchPt
                 }
                 const int cl = wl >> 1, ch = wh >> 1;                      // (wl <= wh: nt >= 1 here)
                 const int base = max(ch - kI8CMax, min(cl + (ch - cl) / 2, cl - kI8CMin));   // mid-range, nudged so that both ends fit when they can
+                // a QUANTISED pair runs the integer body only if the grid fitted: the largest train residual (it enters every query's
+                // slack) within 1.6 x what rounding alone leaves, s sqrt(128 / 12).  Beyond that — clipped tails the sample did not
+                // show — the 16-bit bodies are the faster exact path: the pair is repaired below.
+                const float s8 = __int_as_float(minfo[kMinfoQ8S + wave]);
+                const bool fit = !q8p || te <= 27.4f * s8 * s8;
                 if (lane == 0) {
-                    s8ok[wave] = (u8 && wl <= wh && ch - base <= kI8CMax && cl - base >= kI8CMin) ? 1 : 0;
+                    s8ok[wave] = (u8 && fit && wl <= wh && ch - base <= kI8CMax && cl - base >= kI8CMin) ? 1 : 0;
                     s8base[wave] = base;
                     s8some[wave] = some ? 1 : 0;
                     sq8[wave] = q8p ? 1 : 0;
                 }
-            }
-            const float* be = bmaxerr + wave * kNormBlocks;
-            const float* bq = bqmax + wave * kNormBlocks;
-            float te = fmaxf(fmaxf(be[lane], be[lane + 64]), fmaxf(be[lane + 128], be[lane + 192]));
-            float qm = fmaxf(fmaxf(bq[lane], bq[lane + 64]), fmaxf(bq[lane + 128], bq[lane + 192]));
-#pragma unroll
-            for (int sh = 32; sh >= 1; sh >>= 1) {
-                te = fmaxf(te, __shfl_xor(te, sh, 64));
-                qm = fmaxf(qm, __shfl_xor(qm, sh, 64));
             }
             if (lane == 0) {
                 smode[wave] = m;
@@ -1120,16 +1156,90 @@ __global__ __launch_bounds__(kSplitThreads) void knn_split_images_kernel(BatchPt
             }
         }
         __syncthreads();
-    }
-    int mode = kModeHalfExact;
-    for (int b = 0; b < B; ++b) mode = max(mode, smode[b]);
-    if (blockIdx.x == 0 && threadIdx.x == 0) minfo[kMinfoBatchMode] = mode;
-    // The exact-integer body runs iff EVERY pair of the batch qualifies (one launch, one body).  Its init fragments
-    // (frag_init_i8: the digits of floor(w_t / 2) - base) need the pair's base, so they are written here, not by the prep pass.
+    };
+    reduce_modes();
+    // The exact-integer body runs iff EVERY pair of the batch qualifies (one launch, one body).
     bool i8 = ti8 != nullptr;
     for (int b = 0; b < B && i8; ++b) i8 = s8ok[b] != 0;
     bool q8any = false;
     for (int b = 0; b < B && ti8; ++b) q8any = q8any || sq8[b] != 0;
+    __shared__ int sq8r[kMaxBatch];                                    // pairs repaired below (their byte image must not be read back as values)
+    if (threadIdx.x < kMaxBatch) sq8r[threadIdx.x] = (ti8 && q8any && !i8 && threadIdx.x < B) ? sq8[threadIdx.x] : 0;
+    __syncthreads();
+    if (ti8 && q8any && !i8) {
+        // REPAIR: some pair was quantised by the prep pass (byte image only) but the batch runs a 16-bit body after all — the
+        // grid did not fit, the init product's range is exceeded, or another pair of the batch is not integer-body material.
+        // Those pairs get their fp16 image, residuals and flags now, from the original floats.  Rows are dealt exactly as in the
+        // prep launch (workgroup x of kNormBlocks, sixteen lanes per row), so workgroup x simply REWRITES the pair's per-block
+        // words x; then a grid-wide barrier (kNormBlocks workgroups of 8 waves: always co-resident) and the reduction again.
+        // Rare by construction (the sample rule), so it only has to be right.
+        __shared__ int rfl[kSplitThreads / 64];
+        __shared__ float rme[kSplitThreads / 64];
+        const int c = threadIdx.x & 15, rows = nq_pad + nt_pad;
+        for (int pb = 0; pb < B; ++pb) {
+            if (!sq8[pb]) continue;                                      // (uniform)
+            const float* __restrict__ Q = P.q[pb];
+            const float* __restrict__ T = P.t[pb];
+            unsigned flags = kFlagNotU8;
+            float mxe = 0.f;
+            if (threadIdx.x < kPrepThreads)
+                for (int row = blockIdx.x * (kPrepThreads / 16) + (threadIdx.x >> 4); row < rows; row += kNormBlocks * (kPrepThreads / 16)) {
+                    const bool isq = row < nq_pad;
+                    const int r = isq ? row : row - nq_pad;
+                    const bool real = r < (isq ? nq : nt);
+                    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+                    if (real) {
+                        const float* src = (isq ? Q + (int64_t)r * ldq : T + (int64_t)r * ldt) + 8 * c;
+                        v0 = *reinterpret_cast<const float4*>(src);
+                        v1 = *reinterpret_cast<const float4*>(src + 4);
+                    }
+                    const float in[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                    unsigned fw[4];
+                    float err2 = fp16_chunk(in, isq ? -2.f : 1.f, fw, flags);
+                    err2 += lane_xor<8>(err2); err2 += lane_xor<4>(err2); err2 += lane_xor<2>(err2); err2 += lane_xor<1>(err2);
+                    if (!(err2 < kInf)) err2 = 0.f;
+                    *reinterpret_cast<uint4*>((isq ? qfrag + pb * s_qfrag : tfrag + pb * s_tfrag) + (int64_t)(r >> 5) * kTileFragBytes +
+                                              (((c >> 1) * 64 + (c & 1) * 32 + (r & 31)) << 4)) = make_uint4(fw[0], fw[1], fw[2], fw[3]);
+                    if (isq) { if (c == 0) qerr[pb * s_qn + r] = err2; }
+                    else mxe = fmaxf(mxe, err2);
+                }
+            int wfl = 0;
+#pragma unroll
+            for (int b = 1; b <= kFlagQ8; b <<= 1) wfl |= __any((flags & b) != 0) ? b : 0;
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) mxe = fmaxf(mxe, __shfl_xor(mxe, m, 64));
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) { rfl[threadIdx.x >> 6] = wfl; rme[threadIdx.x >> 6] = mxe; }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int fl = 0;
+                float me = 0.f;
+                for (int w = 0; w < kPrepThreads / 64; ++w) { fl |= rfl[w]; me = fmaxf(me, rme[w]); }
+                midflag[pb * kNormBlocks + blockIdx.x] = fl;             // (kFlagNotU8, no kFlagQ8: a 16-bit pair from here on)
+                bmaxerr[pb * kNormBlocks + blockIdx.x] = me;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            atomicAdd(&minfo[kMinfoBar], 1);
+            long long spins = 0;
+            while (__hip_atomic_load(&minfo[kMinfoBar], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)gridDim.x) {
+                __builtin_amdgcn_s_sleep(16);
+                if (++spins > (1ll << 24)) __builtin_trap();             // (never: fail loudly rather than continue on half-repaired images)
+            }
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");               // the other workgroups' words, not this CU's cached copies
+        reduce_modes();
+        i8 = false;
+        q8any = false;
+    }
+    int mode = kModeHalfExact;
+    for (int b = 0; b < B; ++b) mode = max(mode, smode[b]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) minfo[kMinfoBatchMode] = mode;
+    // The integer body's init fragments (frag_init_i8: the digits of floor(w_t / 2) - base) need the pair's base, so they are
+    // written here, not by the prep pass.
     if (blockIdx.x == 0 && threadIdx.x < kMaxBatch + 1) {
         if (threadIdx.x == kMaxBatch) { minfo[kMinfoI8] = i8 ? 1 : 0; minfo[kMinfoQ8] = (i8 && q8any) ? 1 : 0; }
         else if (threadIdx.x < B && ti8) minfo[kMinfoBase + threadIdx.x] = s8base[threadIdx.x];
@@ -1162,7 +1272,7 @@ __global__ __launch_bounds__(kSplitThreads) void knn_split_images_kernel(BatchPt
                 const bool isq = row < nq_pad;
                 const int r = isq ? row : row - nq_pad;
                 const unsigned m = isq ? rmq[pb * s_qn + r] : rmt[pb * s_tn + r];
-                if (!((m >> c) & 1u)) continue;
+                if (!((m >> c) & 1u) || sq8r[pb]) continue;              // (a quantised pair's bytes are not its values: repaired above)
                 const unsigned char* src = (isq ? qi8 + pb * s_qi8 + (int64_t)(r >> 5) * kI8QTileBytes : ti8 + pb * s_ti8 + (int64_t)(r >> 5) * kI8TileBytes) +
                                            (c >> 2) * 1024 + ((((c >> 1) & 1) * 32 + (r & 31)) << 4) + ((c & 1) << 3);
                 const uint2 x = *reinterpret_cast<const uint2*>(src);
@@ -3943,14 +4053,15 @@ extern "C" int sfm_debug_set_trace(void* dev_buf) {
 namespace {
 constexpr int64_t kMaxTrainRows = 4000000;                     // fragment offsets are 32-bit: 16 KiB per 32 rows in the split images
 
-bool filter_ok(int filter) { return filter >= kFilterAuto && filter <= kFilterHalf; }
+static_assert(kFilterHalf == 5 && kFilterNoQuant == 6, "include/sfm_hip.h SFM_KNN_FILTER_*");
+bool filter_ok(int filter) { return filter >= kFilterAuto && filter <= kFilterNoQuant; }
 
 size_t knn_ws_bytes(int64_t nq, int64_t nt, int dim, int B, int filter) {
     if (nq < 0 || nt < 0 || nt > kMaxTrainRows || dim != kDim || B < 1 || B > kMaxBatch || !filter_ok(filter)) return 0;
     if (B > 1 && filter == kFilterF32) return 0;               // the fp32-MFMA variant is single-pair
     const Plan p = make_plan(nq, nt, B, filter);
     if (!p.i8) return carve_ws(nullptr, nq, nt, p, nullptr).bytes + 256;
-    const Plan p8 = make_plan(nq, nt, B, kFilterI8Plan);
+    const Plan p8 = make_plan(nq, nt, B, p.q8 ? kFilterI8PlanQ8 : kFilterI8Plan);
     return carve_ws(nullptr, nq, nt, p, &p8).bytes + 256;
 }
 
@@ -3964,7 +4075,7 @@ int knn_batch_impl(int B, const BatchPtrs& P, int64_t nq, int64_t ldq, int64_t n
                    void* stream_, double ratio, int* ratio_counts, int ratio_stride) {
     SFM_CHECK_ARG(dim == kDim, "sfm_knn2_l2_f32: dim must be 128 (got %d)", dim);
     SFM_CHECK_ARG(B >= 1 && B <= kMaxBatch, "sfm_match_batch_l2_f32: 1 <= batch <= %d (got %d)", kMaxBatch, B);
-    SFM_CHECK_ARG(filter_ok(filter), "sfm_knn2_l2_f32: filter must be 0 (auto), 1 (fp32 MFMA), 2 (bf16 split pinned), 3 / 4 (LDS-ring kernel, auto / split), 5 (16-bit only) (got %d)", filter);
+    SFM_CHECK_ARG(filter_ok(filter), "sfm_knn2_l2_f32: filter must be 0 (auto), 1 (fp32 MFMA), 2 (bf16 split pinned), 3 / 4 (LDS-ring kernel, auto / split), 5 (16-bit only), 6 (auto, never quantised) (got %d)", filter);
     SFM_CHECK_ARG(nq >= 0 && nt >= 0 && nq < INT_MAX / 256 && nt <= kMaxTrainRows, "sfm_knn2_l2_f32: bad sizes nq=%lld nt=%lld (nt <= %lld)",
                   (long long)nq, (long long)nt, (long long)kMaxTrainRows);
     if (nq == 0) return SFM_OK;
@@ -3984,7 +4095,7 @@ int knn_batch_impl(int B, const BatchPtrs& P, int64_t nq, int64_t ldq, int64_t n
     SFM_CHECK_ARG(B == 1 || filter != kFilterF32, "sfm_match_batch_l2_f32: the fp32-MFMA filter variant is single-pair");
     const Plan p = make_plan(nq, nt, B, filter);
     Plan p8{};
-    if (p.i8) p8 = make_plan(nq, nt, B, kFilterI8Plan);
+    if (p.i8) p8 = make_plan(nq, nt, B, p.q8 ? kFilterI8PlanQ8 : kFilterI8Plan);
     const size_t need = knn_ws_bytes(nq, nt, dim, B, filter);
     if (!ws || ws_bytes < need) {
         sfm::set_error("sfm_knn2_l2_f32: workspace too small (%zu < %zu)", ws_bytes, need);
@@ -4005,12 +4116,12 @@ int knn_batch_impl(int B, const BatchPtrs& P, int64_t nq, int64_t ldq, int64_t n
                            ratio_counts, 0 /*(the refine kernel writes every count: nothing to zero)*/,
                            p.units, p.tiles, p.G, p.seg_cost, p.n_rb, w.wg_begin, w.rb_first, w.rb_last, p.q4 ? w.wg_sbase : nullptr,
                            w.qi8, w.ti8, w.s_qi8, w.s_ti8, w.wq, w.wt, w.bwmin, w.bwmax, w.rmq, w.rmt, p8.units, p8.G, p8.n_rb, w.wg_begin8, w.rb_first8,
-                           w.rb_last8, w.wg_sbase8, (p.i8 && g_q8) ? 1 : 0, w.minfo);
+                           w.rb_last8, w.wg_sbase8, p.q8, w.minfo);
         SFM_CHECK_LAUNCH();
         hipLaunchKernelGGL(knn_split_images_kernel, dim3(kNormBlocks), dim3(kSplitThreads), 0, stream, P, B, ldq, (int)nq, p.nq_pad, ldt, (int)nt,
                            p.tiles * kTileT, w.qsplit, w.tsplit, w.s_qsplit, w.s_tsplit, w.midflag, w.bmax, p.force_mode,
                            p.q4 ? w.qhm : nullptr, w.thm, w.s_qhm, w.s_thm, w.bmaxerr, w.bqmax, w.minfo, w.ti8, w.s_ti8, w.wt, w.s_tn, w.bwmin, w.bwmax,
-                           w.qi8, w.s_qi8, w.s_qn, w.rmq, w.rmt, w.qfrag, w.tfrag, w.s_qfrag, w.s_tfrag);
+                           w.qi8, w.s_qi8, w.s_qn, w.rmq, w.rmt, w.qfrag, w.tfrag, w.s_qfrag, w.s_tfrag, w.qerr);
         SFM_CHECK_LAUNCH();
         sfm::prof_begin(sfm::kProfKnnFilter, stream);
 #define SFM_LAUNCH_SPLIT2(A, WV)                                                                                        \

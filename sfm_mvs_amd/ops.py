@@ -15,7 +15,7 @@ _ws_cache = {}
 
 # `filter` argument of the KNN entry points (include/sfm_hip.h SFM_KNN_FILTER_*): which candidate filter runs before the
 # exact refine.  Results are bit-identical whichever runs.
-KNN_FILTERS = {"auto": 0, "f32": 1, "split": 2, "lds": 3, "lds_split": 4, "half": 5}
+KNN_FILTERS = {"auto": 0, "f32": 1, "split": 2, "lds": 3, "lds_split": 4, "half": 5, "noquant": 6}
 
 
 def _filter_code(name):
@@ -50,7 +50,7 @@ def knn2(des0, des1, return_stats=False, filter="auto"):
 
     des0 [nq,128] / des1 [nt,128] float32 CUDA tensors (rows may be strided).
     Returns idx [nq,2] int32 (trainIdx), dist [nq,2] float32 (DMatch.distance).
-    filter: 'auto' (default) | 'f32' | 'split' | 'lds' | 'lds_split' | 'half' — see KNN_FILTERS; identical results.
+    filter: 'auto' (default) | 'f32' | 'split' | 'lds' | 'lds_split' | 'half' | 'noquant' — see KNN_FILTERS; identical results.
     """
     fcode = _filter_code(filter)
     require_cuda(des0, des1)
