@@ -17,7 +17,14 @@ and a third group of u8-integer data — what cv2 SIFT emits and what filter="au
   u8_uniform arbitrary bytes (ranges 2 .. 256);  u8_ties  trains one or two units apart (parity bit, exact ties inside a record);
   u8_far     d^2 in (2^22, 2^23): float32 square roots of neighbouring integers collide;  u8_extreme  rows at the ends of the init
   product's range (all-0 / all-127 / all-255 / four saturated bins: some pairs fall back to the 16-bit body);  u8_dups  duplicates.
-Batches mix the families: a u8 pair next to a float pair exercises the conversion of byte-image chunks to fp16 (mixed batch).
+and a fourth group of float data with COMPACT support — what filter="auto" QUANTISES to 8 bits for the integer body (stats[3] = 5):
+  q8_uniform uniform values on a random interval (offsets / scales over six decades, either sign);  q8_beta  bounded, non-uniform;
+  q8_twins   planted near-twins and exact duplicates (d far below the quantisation step: the slack dominates the distance);
+  q8_grid    values ON a 256-level grid (residuals ~ 0: exact ties of the quantised distances, the float32 order decides);
+  q8_clip    outliers in rows the grid's sample does not see (clipped: the measured residuals reject the grid, the pair is repaired);
+  q8_const   constant rows at the middle and the ends of the range (init product's range exceeded: repair).
+Batches mix the families: a u8 pair next to a float pair exercises the conversion of byte-image chunks to fp16 (mixed batch),
+a quantised pair next to a Gaussian one the repair of pairs quantised in vain.
 Most cases are small (the oracle dominates the wall time); one in eight is large, `big` adds 20k-70k train rows.
 The log ends with the sha256 of csrc/knn.hip: profiles/r04_fuzz_knn_*.log are checked against the tree by tests/test_gpu_knn.py.
 """
@@ -157,6 +164,31 @@ def make(kind, nq, nt):
         t = np.tile(base, (10, 1))[:nt]
         q = np.clip(base[rng.integers(0, len(base), nq)] + np.rint(rng.normal(0, 1.0, (nq, 128))), 0, 255).astype(f32)
         return q, t.astype(f32)
+    if kind in ("q8_uniform", "q8_beta", "q8_twins", "q8_grid", "q8_clip", "q8_const"):
+        lo = float(rng.choice([0.0, 0.0, -1.0, 1.0]) * 10.0 ** rng.uniform(-3, 3))
+        width = float(10.0 ** rng.uniform(-3, 3))
+        if abs(lo) > 300 * width:
+            lo = 0.0                                               # (keep the range well above the values' float32 spacing)
+        draw = (lambda n: rng.beta(2.0, 2.0, (n, 128))) if kind == "q8_beta" else (lambda n: rng.random((n, 128)))
+        if kind == "q8_grid":
+            draw = lambda n: rng.integers(0, 256, (n, 128)) / 255.0
+        q, t = lo + width * draw(nq), lo + width * draw(nt)
+        if kind == "q8_grid":
+            t[0], q[0] = lo, lo + width                            # (the sample sees both ends)
+        if kind == "q8_twins":
+            m = min(nq, nt) // 2
+            rows = rng.permutation(nt)[:m]
+            noise = rng.choice([0.0, 1e-7, 1e-5, 1e-3]) * width
+            t[rows] = q[rng.permutation(nq)[:m]] + noise * rng.standard_normal((m, 128))
+            if m > 2: t[rows[1]] = t[rows[0]]                      # an exact duplicate
+        if kind == "q8_clip" and nt > 40:
+            rows = np.setdiff1d(np.arange(nt), (np.arange(16) * nt) >> 4)      # not the rows the sample reads
+            hit = rng.choice(rows, max(1, len(rows) // int(rng.choice([3, 50, 500]))), replace=False)
+            t[hit, rng.integers(0, 128, len(hit))] = lo + width * rng.choice([3.0, -2.0, 40.0])
+        if kind == "q8_const" and nt > 8:
+            t[1], t[2], t[3] = lo + 0.5 * width, lo, lo + width
+            if nq > 4: q[1] = lo + 0.5 * width
+        return q.astype(f32), t.astype(f32)
     if kind == "normspread":
         q = rng.random((nq, 128)) * 10.0 ** rng.uniform(-1.5, 1.5, (nq, 1))
         t = rng.random((nt, 128)) * 10.0 ** rng.uniform(-1.5, 1.5, (nt, 1))
@@ -166,8 +198,9 @@ def make(kind, nq, nt):
 
 kinds = ["uniform", "normal_scaled", "sift", "planted", "duplicates", "near_ties", "unit", "mixed_magnitude",
          "cancel", "tie23", "pow2", "fp16edge", "normspread", "tie23", "cancel",
-         "u8_uniform", "u8_ties", "u8_far", "u8_extreme", "u8_dups", "planted", "u8_ties"]
-variants = ["auto"] * 7 + ["half", "split", "f32", "lds", "lds_split", "half"]
+         "u8_uniform", "u8_ties", "u8_far", "u8_extreme", "u8_dups", "planted", "u8_ties",
+         "q8_uniform", "q8_beta", "q8_twins", "q8_grid", "q8_clip", "q8_const", "q8_uniform", "q8_twins"]
+variants = ["auto"] * 8 + ["half", "split", "f32", "lds", "lds_split", "noquant"]
 t_start = time.time()
 t_end = t_start + budget
 cases = fails = batched = 0
@@ -192,7 +225,7 @@ while time.time() < t_end:
         nt = int(rng.choice([1, 2, 31, 33, 512, 1023, 2049]) if rng.random() < 0.4 else rng.integers(1, 2600))
     if big and cases % 24 == 5:
         nq, nt = int(rng.integers(1, 700)), int(rng.integers(20000, 70000))
-    if kind in ("duplicates", "near_ties", "u8_dups", "u8_ties", "u8_far"):
+    if kind in ("duplicates", "near_ties", "u8_dups", "u8_ties", "u8_far", "q8_grid"):
         nq, nt = min(nq, 600), min(nt, 3000)             # every stream is rescanned: keep the exact work bounded
     q, t = make(kind, nq, nt)
     nq, nt = len(q), len(t)

@@ -220,8 +220,10 @@ def test_filter_modes_all_agree_with_oracle(hip, oracle, name):
     want = oracle.knn2(q, t, nthreads=8)
     # the filter variant is a per-call argument (ABI 2): q4 kernel auto / split, fp32 MFMA, and round 2's LDS-ring kernel
     # (ABI 2 + SFM_KNN_FILTER_HALF): 'auto' takes the exact-integer i8 body (mode 4) for u8-integer data, 'half' never does
-    auto_mode = 4 if name == "sift_integers" else expect_mode
-    for variant, mode in (("auto", auto_mode), ("half", expect_mode), ("split", 2), ("f32", 3), ("lds", expect_mode), ("lds_split", 2)):
+    # round 4b: 'auto' QUANTISES float pairs with compact support to 8 bits for the same integer body (mode 5); 'noquant' never does
+    noq_mode = 4 if name == "sift_integers" else expect_mode
+    auto_mode = 5 if name in ("uniform_floats", "fp16_subnormal_elements", "fp16_exact_not_bf16_exact") else noq_mode
+    for variant, mode in (("auto", auto_mode), ("noquant", noq_mode), ("half", expect_mode), ("split", 2), ("f32", 3), ("lds", expect_mode), ("lds_split", 2)):
         gi, gd, stats = run(hip, q, t, stats=True, filter=variant)
         assert stats[3] == mode, f"{name}/{variant}: filter mode {stats[3]}, expected {mode}"
         assert_bit_equal((gi, gd), want)
@@ -234,8 +236,11 @@ def test_fp16_mode_near_ties_and_duplicates(hip, oracle):
     base = rng.random((64, 128), dtype=np.float32)
     t = np.repeat(base, 8, axis=0) * (1 + np.float32(2e-5) * rng.standard_normal((512, 1)).astype(np.float32))
     q = base[:40] + np.float32(1e-3) * rng.standard_normal((40, 128)).astype(np.float32)
-    gi, gd, stats = run(hip, q.astype(np.float32), t.astype(np.float32), stats=True)
+    gi, gd, stats = run(hip, q.astype(np.float32), t.astype(np.float32), stats=True, filter="noquant")
     assert stats[3] == 1
+    assert_bit_equal((gi, gd), oracle.knn2(q.astype(np.float32), t.astype(np.float32), nthreads=4))
+    gi, gd, stats = run(hip, q.astype(np.float32), t.astype(np.float32), stats=True)            # ('auto': the quantised integer body, same answer)
+    assert stats[3] == 5
     assert_bit_equal((gi, gd), oracle.knn2(q.astype(np.float32), t.astype(np.float32), nthreads=4))
 
 

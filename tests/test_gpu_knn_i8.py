@@ -141,7 +141,9 @@ def test_half_variant_never_takes_the_integer_body(hip, oracle):
 
 @pytest.mark.parametrize("batch", [2, 5, 8])
 def test_batched_integer_pairs(hip, oracle, batch):
-    """Batches run ONE body: all pairs u8 -> i8 (mode 4); one float pair in the batch -> the whole batch takes 16-bit arithmetic."""
+    """Batches run ONE body: all pairs u8 -> i8 (mode 4); one heavy-tailed float pair in the batch -> the whole batch takes
+    16-bit arithmetic (the u8 chunks are converted from the byte image); one float pair with compact support -> the batch runs
+    the integer body on quantised data (mode 5), the u8 pairs on the grid s = 1."""
     rng = np.random.default_rng(13 + batch)
     nq, nt = 1500, 2100
     pairs = [planted_pair(rng, nq, nt, 0.3)[:2] for _ in range(batch)]
@@ -156,13 +158,16 @@ def test_batched_integer_pairs(hip, oracle, batch):
         wq, wt, _ = oracle.ratio_filter(wi, wd, 0.70)
         m = int(bm.count[b].item())
         assert m == len(wq) and np.array_equal(bm.out_q[b, :m].cpu().numpy(), wq) and np.array_equal(bm.out_t[b, :m].cpu().numpy(), wt)
-    pairs[batch // 2] = (rng.random((nq, 128), dtype=np.float32), rng.random((nt, 128), dtype=np.float32))
-    bm.run([(torch.from_numpy(q).to(dev), torch.from_numpy(t).to(dev)) for q, t in pairs])
-    torch.cuda.synchronize()
-    for b, (q, t) in enumerate(pairs):
-        wi, wd = oracle.knn2(q, t, nthreads=8)
-        assert int(bm.stats[b, 3]) == 1
-        assert np.array_equal(bm.idx[b].cpu().numpy(), wi) and np.array_equal(bm.dist[b].cpu().numpy().view(np.uint32), wd.view(np.uint32))
+    for other in (((rng.standard_normal((nq, 128)) * 30).astype(np.float32), (rng.standard_normal((nt, 128)) * 30).astype(np.float32), 1),
+                        (rng.random((nq, 128), dtype=np.float32), rng.random((nt, 128), dtype=np.float32), 5)):
+        pairs[batch // 2] = other[:2]
+        mode = other[2]
+        bm.run([(torch.from_numpy(q).to(dev), torch.from_numpy(t).to(dev)) for q, t in pairs])
+        torch.cuda.synchronize()
+        for b, (q, t) in enumerate(pairs):
+            wi, wd = oracle.knn2(q, t, nthreads=8)
+            assert int(bm.stats[b, 3]) == mode
+            assert np.array_equal(bm.idx[b].cpu().numpy(), wi) and np.array_equal(bm.dist[b].cpu().numpy().view(np.uint32), wd.view(np.uint32))
 
 
 def test_config2_size_sift_like(hip, oracle):

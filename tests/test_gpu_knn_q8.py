@@ -1,0 +1,155 @@
+"""The integer MFMA body on 8-bit QUANTISED float descriptors (filter="auto" on data with compact support; stats[3] = 5),
+through the C-ABI: indices and float32 distances bit-identical to the direct-form oracle `orc_knn2_l2_f32`
+(cv2.BFMatcher().knnMatch(k=2), /root/reference/sfm.py:259-260), whatever the grid, the clipping or the fallback."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def run(hip, q, t, filter="auto"):
+    gi, gd, st = hip.knn2(torch.from_numpy(np.ascontiguousarray(q)).cuda(), torch.from_numpy(np.ascontiguousarray(t)).cuda(), return_stats=True, filter=filter)
+    torch.cuda.synchronize()
+    return gi.cpu().numpy(), gd.cpu().numpy(), st.cpu().numpy()
+
+
+def assert_parity(oracle, q, t, gi, gd):
+    wi, wd = oracle.knn2(np.ascontiguousarray(q), np.ascontiguousarray(t), nthreads=8)
+    assert np.array_equal(gi, wi), f"{(gi != wi).any(1).sum()} rows differ"
+    assert np.array_equal(gd.view(np.uint32), wd.view(np.uint32))
+
+
+@pytest.mark.parametrize("nq,nt", [(1, 2), (5, 3), (64, 64), (129, 1000), (777, 1234), (3000, 2500), (100, 20000), (20000, 96)])
+@pytest.mark.parametrize("lo,width", [(0.0, 1.0), (-3.0, 7.0), (250.0, 10.0), (0.0, 1e-5)])
+def test_uniform_floats_run_quantised_and_bit_exact(hip, oracle, nq, nt, lo, width):
+    rng = np.random.default_rng(nq * 31 + nt + int(width * 1000))
+    q = (lo + width * rng.random((nq, 128))).astype(np.float32)
+    t = (lo + width * rng.random((nt, 128))).astype(np.float32)
+    gi, gd, st = run(hip, q, t)
+    assert st[3] == 5, f"filter arithmetic {st[3]}: the quantised integer body was expected"
+    assert_parity(oracle, q, t, gi, gd)
+
+
+def test_bounded_nonuniform_twins_duplicates_and_grid_values(hip, oracle):
+    rng = np.random.default_rng(11)
+    # beta(2, 2): bounded, range = 4.5 sigma
+    q, t = rng.beta(2, 2, (900, 128)).astype(np.float32), rng.beta(2, 2, (1700, 128)).astype(np.float32)
+    gi, gd, st = run(hip, q, t)
+    assert st[3] == 5
+    assert_parity(oracle, q, t, gi, gd)
+    # near-twins far below the quantisation step (1/255), exact duplicates, twins of twins
+    t = rng.random((4000, 128), dtype=np.float32)
+    q = t[rng.integers(0, 4000, 3000)] + (rng.standard_normal((3000, 128)) * 1e-4).astype(np.float32)
+    t[100] = t[7]; t[101] = t[7]
+    gi, gd, st = run(hip, q.astype(np.float32), t)
+    assert st[3] == 5
+    assert_parity(oracle, q.astype(np.float32), t, gi, gd)
+    # a few distinct rows repeated: every stream full of exact ties
+    t = np.repeat(rng.random((50, 128), dtype=np.float32), 40, axis=0)
+    q = rng.random((300, 128), dtype=np.float32)
+    gi, gd, st = run(hip, q, t)
+    assert st[3] == 5
+    assert_parity(oracle, q, t, gi, gd)
+    # values ON the grid: residuals ~ 0, the quantised distances tie exactly and the float32 order has to decide
+    q = (rng.integers(0, 256, (500, 128)) / 255.0).astype(np.float32)
+    t = (rng.integers(0, 256, (900, 128)) / 255.0).astype(np.float32)
+    q[0], t[0] = 0.0, 1.0
+    gi, gd, st = run(hip, q, t)
+    assert st[3] == 5
+    assert_parity(oracle, q, t, gi, gd)
+
+
+def test_heavy_tails_are_not_quantised(hip, oracle):
+    """A Gaussian's 4096-value sample spans 7 sigma: the sample rule (range <= 5 sigma) leaves it to the fp16 body."""
+    rng = np.random.default_rng(12)
+    q, t = rng.standard_normal((800, 128)).astype(np.float32), rng.standard_normal((1300, 128)).astype(np.float32)
+    gi, gd, st = run(hip, q, t)
+    assert st[3] == 1
+    assert_parity(oracle, q, t, gi, gd)
+
+
+def test_grid_that_does_not_fit_is_repaired(hip, oracle):
+    """The grid comes from a sample of 16 + 16 rows.  Outliers in other rows are clipped, the MEASURED train residual rejects the
+    grid and the pair's fp16 image is rebuilt in knn_split_images_kernel (stats[3] = 1); likewise when constant rows at the
+    middle and the ends of the range exceed the init product's range."""
+    rng = np.random.default_rng(13)
+    nq, nt = 1500, 2100
+    q, t = rng.random((nq, 128), dtype=np.float32), rng.random((nt, 128), dtype=np.float32)
+    t[5:900:7, 3] = 9.0                                          # rows 0, nt/16, 2 nt/16, ... are what the sample reads
+    gi, gd, st = run(hip, q, t)
+    assert st[3] == 1
+    assert_parity(oracle, q, t, gi, gd)
+    t = rng.random((nt, 128), dtype=np.float32)
+    t[1], t[2], t[3] = 0.5, 0.0, 1.0
+    gi, gd, st = run(hip, q, t)
+    assert st[3] == 1
+    assert_parity(oracle, q, t, gi, gd)
+    # a few clipped QUERY rows only cost those queries their certificate (they rescan): the pair still runs quantised
+    q2 = q.copy(); q2[5:900:97, 3] = 9.0
+    t = rng.random((nt, 128), dtype=np.float32)
+    gi, gd, st = run(hip, q2, t)
+    assert st[3] == 5 and st[0] >= 9
+    assert_parity(oracle, q2, t, gi, gd)
+
+
+@pytest.mark.parametrize("kinds,mode", [("uuuu", 5), ("usU", 5), ("ugu", 1), ("uou", 1), ("ss", 4), ("gg", 1)])
+def test_batches_mixing_quantised_u8_and_other_pairs(hip, oracle, kinds, mode):
+    """One launch set, one body: u8 pairs ride along in a quantised batch (grid s = 1, lo = 0, no residual); a pair that is not
+    integer-body material (Gaussian, or a grid that did not fit) sends the WHOLE batch to the 16-bit body and the pairs that were
+    quantised in vain are repaired."""
+    rng = np.random.default_rng(len(kinds) * 7 + mode)
+    nq, nt = 1100, 1900
+    pairs = []
+    for k in kinds:
+        if k == "u": q, t = rng.random((nq, 128), dtype=np.float32), rng.random((nt, 128), dtype=np.float32)
+        elif k == "U": q, t = (rng.random((nq, 128)) * 7 - 3).astype(np.float32), (rng.random((nt, 128)) * 7 - 3).astype(np.float32)
+        elif k == "s": q, t = rng.integers(0, 120, (nq, 128)).astype(np.float32), rng.integers(0, 120, (nt, 128)).astype(np.float32)
+        elif k == "g": q, t = rng.standard_normal((nq, 128)).astype(np.float32), rng.standard_normal((nt, 128)).astype(np.float32)
+        else:
+            q, t = rng.random((nq, 128), dtype=np.float32), rng.random((nt, 128), dtype=np.float32)
+            t[5:900:7, 3] = 9.0
+        k3 = nq // 3
+        t[rng.permutation(nt)[:k3]] = q[rng.permutation(nq)[:k3]] * np.float32(1.001) if k != "s" else q[rng.permutation(nq)[:k3]]   # ratio survivors
+        pairs.append((q, t))
+    bm = hip.BatchMatcher(nq, nt, "cuda", ratio=0.70, batch=len(pairs))
+    bm.run([(torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda()) for q, t in pairs])
+    torch.cuda.synchronize()
+    assert int(bm.stats[0, 3].item()) == mode
+    for b, (q, t) in enumerate(pairs):
+        wi, wd = oracle.knn2(q, t, nthreads=8)
+        assert np.array_equal(bm.idx[b].cpu().numpy(), wi) and np.array_equal(bm.dist[b].cpu().numpy().view(np.uint32), wd.view(np.uint32)), (kinds, b)
+        wq, wt, _ = oracle.ratio_filter(wi, wd, 0.70)
+        m = int(bm.count[b].item())
+        assert m == len(wq) and m > 100
+        assert np.array_equal(bm.out_q[b, :m].cpu().numpy(), wq) and np.array_equal(bm.out_t[b, :m].cpu().numpy(), wt)
+
+
+def test_strided_rows_and_the_variants_that_never_quantise(hip, oracle):
+    rng = np.random.default_rng(14)
+    qf, tf = rng.random((700, 160), dtype=np.float32), rng.random((1500, 192), dtype=np.float32)
+    q, t = torch.from_numpy(qf).cuda()[:, :128], torch.from_numpy(tf).cuda()[:, 32:160]
+    want = oracle.knn2(np.ascontiguousarray(qf[:, :128]), np.ascontiguousarray(tf[:, 32:160]), nthreads=8)
+    for variant, mode in (("auto", 5), ("noquant", 1), ("half", 1)):
+        gi, gd, st = hip.knn2(q, t, return_stats=True, filter=variant)
+        assert int(st[3].item()) == mode
+        assert np.array_equal(gi.cpu().numpy(), want[0]) and np.array_equal(gd.cpu().numpy().view(np.uint32), want[1].view(np.uint32))
+
+
+def test_full_size_batch_quantised_equals_noquant(hip):
+    """BASELINE configs[1] at full size, 8 distinct 10k x 10k pairs in one launch set: the quantised body and the fp16 body
+    (filter="noquant") return the same bits (each is tested against the oracle at this size in tests/test_gpu_knn.py)."""
+    gen = lambda seed, n: torch.rand((n, 128), generator=torch.Generator().manual_seed(seed)).cuda()
+    pairs = [(gen(2 * b, 10000), gen(2 * b + 1, 10000)) for b in range(8)]
+    res = {}
+    for variant in ("auto", "noquant"):
+        bm = hip.BatchMatcher(10000, 10000, "cuda", ratio=0.70, batch=8, filter=variant)
+        bm.run(pairs)
+        torch.cuda.synchronize()
+        res[variant] = (bm.result.clone(), bm.count.clone(), bm.out_q.clone(), bm.out_t.clone(), int(bm.stats[0, 3].item()), int(bm.stats[:, 0].sum().item()))
+    assert res["auto"][4] == 5 and res["noquant"][4] == 1
+    assert torch.equal(res["auto"][0], res["noquant"][0]) and torch.equal(res["auto"][1], res["noquant"][1])
+    for b in range(8):
+        m = int(res["auto"][1][b].item())
+        assert torch.equal(res["auto"][2][b, :m], res["noquant"][2][b, :m]) and torch.equal(res["auto"][3][b, :m], res["noquant"][3][b, :m])
+    assert res["auto"][5] < 8 * 10000 // 50, "more than 2 % of the queries rescanned on uniform data"
