@@ -297,11 +297,17 @@ def bench_knn(args, world, rank, dev):
     # MFMA work actually issued by the filter arithmetic the device chose (stats[3]): one fp16 product per fp32 product
     # (8 MFMAs per 32x32x128 tile) or the 3-product bf16 split (24)
     mode = stats[3]
+    int_body = mode in (4, 5)        # v_mfma_i32_32x32x32_i8: exact u8 data (4) or float data QUANTISED to 8 bits (5) — priced against the int8 roof
     mfma_per_tile = {0: 8, 1: 8, 2: SPLIT_MFMA_PER_TILE}.get(mode, 8)
     # (+ the accumulator-init MFMA of every tile, v_mfma_f32_32x32x8_bf16: half the flops of a product MFMA)
     issued = pbatch * (nq / 32.0) * (nt / 32.0) * (mfma_per_tile + 0.5) * 2 * 32 * 32 * 16 / (filt_avg_ms * 1e-3) / 1e12
+    if int_body:                     # 4 product MFMAs of K = 32 per 32 x 32 x 128 tile and group, one init MFMA per tile shared by 8 groups
+        issued = pbatch * (nq / 32.0) * (nt / 32.0) * (4 + 1.0 / 8) * 2 * 32 * 32 * 32 / (filt_avg_ms * 1e-3) / 1e12
+    peak_hl, unit_hl, sus_hl = ((I8_MFMA_PEAK_TOPS, "TOP/s", I8_MFMA_SUSTAINED_TOPS) if int_body
+                                else (BF16_MFMA_PEAK_TFLOPS, "TFLOP/s", F16_MFMA_SUSTAINED_TFLOPS))
     mode_name = {0: "fp16 single product (inputs exact in fp16)", 1: "fp16 single product", 2: "bf16 hi+mid split (3 products)",
-                 3: "fp32 MFMA"}.get(mode, str(mode))
+                 3: "fp32 MFMA", 4: "exact-integer i8 MFMA (u8-integer descriptors)",
+                 5: "i8 MFMA on the descriptors QUANTISED to 8 bits (one grid per pair; the certificate uses the measured residual norms)"}.get(mode, str(mode))
     out = {
         "metric": "descriptor-pair distances/sec (BF-KNN k=2 + Lowe ratio)", "value": value, "unit": "distances/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -322,15 +328,19 @@ def bench_knn(args, world, rank, dev):
                    "cold_value": world * pbatch * nq * nt * args.steps / cold_elapsed, "cold_ms_per_step": cold_elapsed / args.steps * 1e3,
                    "cold_note": "`value` is the sustained rate; cold_value = the same K steps after 0.5 s of idle, before the clock ramp",
                    "setup": f"streams and kernels loaded, then {CLOCK_WARMUP_STEPS} untimed steps of the same workload (~60 ms: the device reaches its sustained clock) before the W warm-up steps"},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "frac_of_sustained": achieved / F16_MFMA_SUSTAINED_TFLOPS,
-                     "sustained_note": "a pure fp16 MFMA stream on random operands holds 1 691 TFLOP/s on this part (clock 1.66 GHz: power-limited), profiles/r04_mfma_ceiling.md",
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak_hl, "unit": unit_hl,
+                     "frac": achieved / peak_hl, "frac_of_sustained": achieved / sus_hl,
+                     "sustained_note": ("a pure i8 MFMA stream on random bytes holds 3 619 TOPS on this part (power-limited clock), profiles/r04_mfma_ceiling.md" if int_body else
+                                        "a pure fp16 MFMA stream on random operands holds 1 691 TFLOP/s on this part (clock 1.66 GHz: power-limited), profiles/r04_mfma_ceiling.md"),
+                     "peak_note": ("dense int8 MFMA peak (the filter ran on v_mfma_i32_32x32x32_i8: 2x the 16-bit rate); against the dense fp16 peak of 2 500 the same figure is "
+                                   f"{achieved / BF16_MFMA_PEAK_TFLOPS:.3f}" if int_body else "dense fp16 / bf16 MFMA peak"),
                      "traffic": traffic,
                      "traffic_unit": "bytes/launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)", "traffic_source": traffic_note,
                      "algorithmic_bytes_per_launch": pbatch * (4 * 128 * (nq + nt) + 16 * nq),
-                     "kernel": "knn_filter_q4_kernel<0>", "avg_launch_ms": filt_avg_ms, "launches": filt_n, "pairs_per_launch": pbatch,
+                     "kernel": "knn_filter_q4_kernel<0>" + (" (filter_i8_body on 8-bit quantised operands)" if mode == 5 else " (filter_i8_body)" if mode == 4 else ""),
+                     "avg_launch_ms": filt_avg_ms, "launches": filt_n, "pairs_per_launch": pbatch,
                      "algorithmic_flop_per_launch": algo_flop,
-                     "issued_mfma_tflops": issued, "issued_frac_of_peak": issued / BF16_MFMA_PEAK_TFLOPS,
+                     "issued_mfma_tflops": issued, "issued_frac_of_peak": issued / peak_hl,
                      "launch_sampling": f"HIP events around the filter kernel on {PROF_SAMPLES} launch sets run alone AFTER the timed region "
                                         f"(pipeline drained); on those the kernel is launched {PROF_REPEAT}x back-to-back inside "
                                         "the event pair (idempotent) so that the event overhead (~7 us per pair) is amortised",
@@ -455,6 +465,39 @@ def bench_knn(args, world, rank, dev):
         torch.cuda.synchronize()
         out["pcie_inclusive"] = {"distances_per_sec": nq * nt * 20 / (time.perf_counter() - t0),
                                  "note": "pinned-host descriptors in, results out, same stream (not the headline value)"}
+        # the 16-bit body on the SAME data, box and pipeline (filter="noquant": what ran by default before the quantised body)
+        pipe16 = ops.BatchPipeline(nq, nt, dev, ratio=0.70, depth=depth, batch=pbatch, filter="noquant")
+        def run16(n):
+            for i in range(n):
+                for qb, tb in sets[i % N_SETS]:
+                    pipe16.submit(qb, tb, after=False)
+            pipe16.flush(); pipe16.synchronize()
+        run16(40)
+        t0 = time.perf_counter()
+        run16(60)
+        dt16 = time.perf_counter() - t0
+        ops.profile_read(0), ops.profile_read(1)
+        for i in range(PROF_SAMPLES):
+            ops.profile_enable(PROF_REPEAT)
+            pipe16.matchers[0].run(sets[i % N_SETS])
+            ops.profile_enable(False)
+            torch.cuda.synchronize()
+        f16_ms, f16_n = ops.profile_read(0)
+        r16_ms, r16_n = ops.profile_read(1)
+        f16_avg = f16_ms / max(f16_n, 1)
+        m16 = pipe16.matchers[0]
+        m16.run(sets[0]); bm0.run(sets[0])
+        torch.cuda.synchronize()
+        same16 = bool(torch.equal(m16.result, bm0.result) and torch.equal(m16.count, bm0.count))
+        out["fp16_body_variant"] = {"filter": "noquant", "distances_per_sec": 60 * pbatch * nq * nt / dt16, "ms_per_step": dt16 / 60 * 1e3,
+                                    "filter_mode": int(m16.stats[0, 3].item()), "filter_avg_launch_ms": f16_avg, "refine_avg_launch_ms": r16_ms / max(r16_n, 1),
+                                    "achieved_tflops": algo_flop / (f16_avg * 1e-3) / 1e12, "peak_tflops": BF16_MFMA_PEAK_TFLOPS,
+                                    "frac": algo_flop / (f16_avg * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+                                    "frac_of_sustained": algo_flop / (f16_avg * 1e-3) / 1e12 / F16_MFMA_SUSTAINED_TFLOPS,
+                                    "results_identical_to_default": same16,
+                                    "note": "the same launch sets through the fp16 single-product body (3 launch sets in flight): the headline value runs the i8 MFMA "
+                                            "body on 8-bit quantised operands instead; bit-identical results (tests/test_gpu_knn_q8.py::test_full_size_batch_quantised_equals_noquant)"}
+        del pipe16
         # the exact-f32-MFMA filter variant on the same inputs (identical results), for the fp32 roofline
         pm32 = ops.PairMatcher(nq, nt, dev, ratio=0.70, filter="f32")
         for _ in range(5):

@@ -24,6 +24,12 @@
 //                         whole workgroup (fp16 screen of the stream's trains, exact evaluation of the few that pass).
 //   4. ratio_scatter_*    Lowe survivors (counted by the refine kernel) written in ascending queryIdx order.
 //
+// filter = auto also carries the INTEGER body of the same filter kernel (v_mfma_i32_32x32x32_i8, half the MFMAs per distance):
+//   * on u8-integer data (what cv2 SIFT emits) the scores are exact and the certificate is an integer one (refine_i8_body);
+//   * on float data with compact support the rows are QUANTISED to 8 bits on one grid per pair (taken from a sample of the
+//     rows, every residual norm measured by the prep pass), the body ranks the quantised distances exactly and
+//     refine_q8_body selects / certifies with | ||q - t|| - s sqrt(D) | <= ||q - q^|| + ||t - t^|| before the same float32
+//     re-evaluation; pairs whose grid turns out not to fit are repaired to the fp16 image (knn_split_images_kernel).
 // Up to 8 equally shaped pairs share one set of launches (sfm_match_batch_l2_f32).
 //
 // The GEMM-form value is therefore never returned: indices and distances are bit-identical
