@@ -26,6 +26,16 @@ for P in "$P1" "$P2" "$P3" "$P4"; do
   i=$((i+1))
 done
 python $R/scripts/summarize_pmc.py $OUT/pmc $TAG $BATCH > $OUT/${TAG}_knn_pmc.md
+# ... and on the same uniform data through filter = noquant: the fp16 body the headline ran before the quantised integer body
+i=1
+for P in "$P1" "$P2" "$P3" "$P4"; do
+  SFM_FILTER=noquant SFM_BATCH=$BATCH rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/pmc_f16 -o pass$i -- python $R/scripts/run_knn_steps.py 6 > $OUT/pmc_f16_pass$i.log 2>&1
+  i=$((i+1))
+done
+python $R/scripts/summarize_pmc.py $OUT/pmc_f16 $TAG $BATCH f16 > $OUT/${TAG}_knn_f16_pmc.md
+SFM_FILTER=noquant SFM_BATCH=$BATCH rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tracef -o knnf -- python $R/scripts/run_knn_steps.py 60 > $OUT/knn_f16_batch_steps.log 2>> $OUT/trace.log
+cp $OUT/tracef/knnf_kernel_stats.csv $OUT/${TAG}_knn_f16_batch_kernel_stats.csv
+rm -rf $OUT/tracef
 # the same four passes on SIFT-like u8 descriptors: the exact-integer (i8 MFMA) body and its refine
 i=1
 for P in "$P1" "$P2" "$P3" "$P4"; do

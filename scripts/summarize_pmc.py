@@ -14,7 +14,9 @@ for f in sorted(glob.glob(os.path.join(d, "pass*_counter_collection.csv"))):
         k = r["Kernel_Name"]
         k = k[k.find("knn_"):].split("(")[0] if "knn_" in k else (k.split("(")[0][-40:])   # keep template arguments
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-what = "SIFT-like u8 descriptors (SURVEY 8d (ii), 30 % planted twins): the exact-integer i8 body of knn_filter_q4_kernel" if variant == "i8" else "config 2 (uniform float32)"
+what = ("SIFT-like u8 descriptors (SURVEY 8d (ii), 30 % planted twins): the exact-integer i8 body of knn_filter_q4_kernel" if variant == "i8" else
+        "config 2 (uniform float32) through filter = noquant: the fp16 single-product body" if variant == "f16" else
+        "config 2 (uniform float32), filter = auto: the i8 MFMA body on 8-bit QUANTISED operands + refine_q8_body")
 print(f"# {tag}: PMC counters of the KNN step (10k x 10k, {what}, {pairs} pair(s) per launch set), mean per launch\n")
 print("Collected with `rocprofv3 --kernel-trace --pmc <group>` in four separate passes (scripts/collect_profiles.sh).")
 print("FETCH_SIZE/WRITE_SIZE are in KiB; per MI355X_MICROARCH.md FETCH_SIZE under-counts wide coalesced reads by 2x on gfx950,")
@@ -50,7 +52,7 @@ for k, v in agg.items():
                "fetch_size_kib": m["FETCH_SIZE"], "write_size_kib": m.get("WRITE_SIZE"),
                "mfma_pipe_busy_frac": (m["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * m["SQ_BUSY_CU_CYCLES"])) if "SQ_BUSY_CU_CYCLES" in m else None,
                "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE doubled per MI355X_MICROARCH.md gfx950 correction; workload 10k x 10k",
-               "source": f"profiles/{tag}_knn_i8_pmc.md" if variant == "i8" else f"profiles/{tag}_knn_pmc.md",
+               "source": f"profiles/{tag}_knn_i8_pmc.md" if variant == "i8" else f"profiles/{tag}_knn_f16_pmc.md" if variant == "f16" else f"profiles/{tag}_knn_pmc.md",
                "knn_hip_sha256": hashlib.sha256(open(os.path.join(root, "sfm_mvs_amd", "csrc", "knn.hip"), "rb").read()).hexdigest()}
-        json.dump(out, open(os.path.join(d, "..", "knn_i8_traffic.json" if variant == "i8" else "knn_traffic.json"), "w"), indent=1)
+        json.dump(out, open(os.path.join(d, "..", "knn_i8_traffic.json" if variant == "i8" else "knn_f16_traffic.json" if variant == "f16" else "knn_traffic.json"), "w"), indent=1)
         break
