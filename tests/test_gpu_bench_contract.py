@@ -31,7 +31,8 @@ def test_bench_prints_one_json_line_with_the_contract_fields(hip):
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms"):
         assert k in r, k
-    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
+    # the headline data (uniform float32) run the i8 MFMA body on 8-bit quantised operands: priced against the dense int8 peak
+    assert "QUANTISED" in d["dtype"] and r["bound"] == "mfma" and r["unit"] == "TOP/s" and r["peak"] == 5000.0
     assert r["frac"] == pytest.approx(r["achieved"] / r["peak"]) and 0.2 < r["frac"] < 1.0
     assert r["achieved"] == pytest.approx(8 * 1e8 * 256 / (r["avg_launch_ms"] * 1e-3) / 1e12, rel=1e-6)     # algorithmic FLOP / live kernel time
     if "sift_like" in d:                                           # (a leg of the full default run)
