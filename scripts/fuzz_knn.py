@@ -1,7 +1,7 @@
 """Randomised parity sweep of the KNN path (sfm_match_l2_f32 / sfm_match_batch_l2_f32 through ops.PairMatcher /
 ops.BatchMatcher) against the CPU oracle: indices, float32 distances (bit patterns), Lowe survivors.
 
-  python scripts/fuzz_knn.py [seconds] [seed] [big]
+  python scripts/fuzz_knn.py [seconds] [seed] [big | q8]
 
 Data families: the ordinary ones (uniform, scaled normals, SIFT-like integers, planted twins, duplicates, near-ties, unit
 vectors, mixed magnitudes) and a second group aimed at the margins of the exactness certificate:
@@ -47,6 +47,7 @@ from datagen import planted_pair, sift_like
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 big = len(sys.argv) > 3 and sys.argv[3] == "big"       # also long train sets (many substreams / candidate records per query)
+q8only = len(sys.argv) > 3 and sys.argv[3] == "q8"     # only the families the quantised integer body runs (and what sits next to them in a batch)
 rng = np.random.default_rng(seed)
 NTH = os.cpu_count() or 8
 f32 = np.float32
@@ -201,6 +202,9 @@ kinds = ["uniform", "normal_scaled", "sift", "planted", "duplicates", "near_ties
          "u8_uniform", "u8_ties", "u8_far", "u8_extreme", "u8_dups", "planted", "u8_ties",
          "q8_uniform", "q8_beta", "q8_twins", "q8_grid", "q8_clip", "q8_const", "q8_uniform", "q8_twins"]
 variants = ["auto"] * 8 + ["half", "split", "f32", "lds", "lds_split", "noquant"]
+if q8only:
+    kinds = ["q8_uniform", "q8_beta", "q8_twins", "q8_grid", "q8_clip", "q8_const", "uniform", "q8_uniform", "sift", "q8_twins", "normal_scaled"]
+    variants = ["auto"] * 6 + ["noquant"]
 t_start = time.time()
 t_end = t_start + budget
 cases = fails = batched = 0
