@@ -60,8 +60,10 @@ const char* sfm_last_error(void);
  *           5 the i8 MFMA body on float descriptors QUANTISED to 8 bits (certified by their measured residual norms)
  *
  * dim must be 128 (SIFT); q_dev/t_dev 16-byte aligned; ldq, ldt multiples of 4; nt <= 4 000 000.
- * The result is bit-identical to the direct-form float32 evaluation for ANY
- * finite input (see DESIGN.md "certified filter + exact refine").
+ * The result is bit-identical to the direct-form float32 evaluation for any finite input whose squared row
+ * norms are finite in float32 (|x| up to ~1e18; see DESIGN.md "certified filter + exact refine").  Beyond that the
+ * filters' scores ||t||^2 + ||q||^2 - 2 q.t are +inf / NaN while some direct-form distances are still finite: measured
+ * wrong at 3e18, right again from 1e19 on, where every distance is +inf and the index order decides (scripts/dev/q8_huge.py).
  *
  * `filter` — the candidate filter that runs before the exact refine.  A per-call argument (ABI 1 had
  * a process-global switch); results are bit-identical whichever runs, the _ws_bytes twin takes the same value:

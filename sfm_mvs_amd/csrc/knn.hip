@@ -33,7 +33,8 @@
 // Up to 8 equally shaped pairs share one set of launches (sfm_match_batch_l2_f32).
 //
 // The GEMM-form value is therefore never returned: indices and distances are bit-identical
-// to the direct-form oracle (oracle/sfm_oracle.c: orc_knn2_l2_f32) for any finite input.
+// to the direct-form oracle (oracle/sfm_oracle.c: orc_knn2_l2_f32) for any finite input whose squared row norms are finite in
+// float32 (|x| up to ~1e18: the filters' scores carry ||t||^2 + ||q||^2).
 #include "common.h"
 #include <cfloat>
 #include <climits>
@@ -1143,7 +1144,9 @@ __global__ __launch_bounds__(kSplitThreads) void knn_split_images_kernel(BatchPt
                 // slack) within 1.6 x what rounding alone leaves, s sqrt(128 / 12).  Beyond that — clipped tails the sample did not
                 // show — the 16-bit bodies are the faster exact path: the pair is repaired below.
                 const float s8 = __int_as_float(minfo[kMinfoQ8S + wave]);
-                const bool fit = !q8p || te <= 27.4f * s8 * s8;
+                // ... and only if no float32 distance of the pair can overflow: sum (q - t)^2 <= (||q|| + ||t||)^2 < FLT_MAX (all
+                // of them +inf would tie by index — the bound R below assumes finite values; the 16-bit bodies' business, as before)
+                const bool fit = !q8p || (te <= 27.4f * s8 * s8 && tmax < 2.5e37f && qm < 2.5e37f);
                 if (lane == 0) {
                     s8ok[wave] = (u8 && fit && wl <= wh && ch - base <= kI8CMax && cl - base >= kI8CMin) ? 1 : 0;
                     s8base[wave] = base;

@@ -125,6 +125,17 @@ def test_batches_mixing_quantised_u8_and_other_pairs(hip, oracle, kinds, mode):
         assert np.array_equal(bm.out_q[b, :m].cpu().numpy(), wq) and np.array_equal(bm.out_t[b, :m].cpu().numpy(), wt)
 
 
+@pytest.mark.parametrize("scale,mode", [(1e12, 5), (1e17, 5), (1e19, 2), (1e25, 2)])
+def test_huge_magnitudes(hip, oracle, scale, mode):
+    """Up to the point where a float32 squared distance can overflow the quantised body runs (its bounds are relative); from
+    there on — (||q|| + ||t||)^2 >= FLT_MAX: distances of +inf that tie by index — the pair is left to the 16-bit bodies."""
+    rng = np.random.default_rng(int(np.log10(scale)))
+    q, t = (rng.random((300, 128)) * scale).astype(np.float32), (rng.random((700, 128)) * scale).astype(np.float32)
+    gi, gd, st = run(hip, q, t)
+    assert st[3] == mode
+    assert_parity(oracle, q, t, gi, gd)
+
+
 def test_strided_rows_and_the_variants_that_never_quantise(hip, oracle):
     rng = np.random.default_rng(14)
     qf, tf = rng.random((700, 160), dtype=np.float32), rng.random((1500, 192), dtype=np.float32)
