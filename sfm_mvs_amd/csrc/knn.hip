@@ -2178,16 +2178,16 @@ __device__ __forceinline__ void filter_i8_body(
         for (int g = 0; g < NG; ++g) k0[g] = k1[g] = k2[g] = INT_MAX;
         int sub = 0, sub_t0 = t_begin;
         auto flush = [&](int sb, int st0, int st1) {
-            // cold: once per 256 tiles.  keys[(((rbl * nstr + stream) * 2 + h) * 3 + k) * 1024 + query-in-block]
+            // cold: once per substream.  keys[((rbl * nstr + stream) * 2 + h) * 1024 + query-in-block][4]: the stream's three keys
+            // of a query as ONE 16-byte store (the fourth word is padding) — a flush is 8 stores per lane instead of 24, and the
+            // fragment wait that follows has to sit their completion out (stores and loads share vmcnt): 87.2 -> 84.0 us per batch
+            // of 8 with 32-tile substreams (measured with a one-store-per-group build before the layout was changed)
             int ql = qloc0;
             asm volatile("" : "+v"(ql));
-            const int64_t ob = ((int64_t)(rbl * nstr + sbase + sb) * 2 + h) * 3 * kI8Rows;
+            const int64_t ob = ((int64_t)(rbl * nstr + sbase + sb) * 2 + h) * kI8Rows * 4;
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
-                if (qok[g]) {
-                    int* o = keys + ob + ql + 32 * g;
-                    o[0] = k0[g]; o[kI8Rows] = k1[g]; o[2 * kI8Rows] = k2[g];
-                }
+                if (qok[g]) *reinterpret_cast<int4*>(keys + ob + (int64_t)(ql + 32 * g) * 4) = make_int4(k0[g], k1[g], k2[g], INT_MAX);
                 k0[g] = k1[g] = k2[g] = INT_MAX;
             }
             if (threadIdx.x == 0) {                                            // the stream's tile range, for the refine kernel's decode / rescan
@@ -2521,6 +2521,12 @@ __device__ __forceinline__ void best2i_exchange_step(Best2I& b) {
     best2i_insert_unique(b, d1, i1, s1);
 }
 constexpr int kRecCapI8 = 56;      // (key, slot) pairs per query in the record list (the `rec` array: 112 ints per query)
+// Key slots of a query (integer bodies): pair p = stream * 2 + half-wave holds the stream's three keys as one int4 at
+// kq[p * kI8Rows * 4 .. + 2] (kq: the row block's array + 4 * query-in-block).  Slot c = 3 p + j names key j of pair p.
+constexpr int kS1P = kS1 / 3;      // pairs per lane fetched up front (kS1 keys)
+static_assert(kS1 % 3 == 0, "whole pairs");
+__device__ __forceinline__ int key_slot(const int* __restrict__ kq, int c) { return kq[(int64_t)(c / 3) * (kI8Rows * 4) + (c % 3)]; }
+
 
 __device__ __forceinline__ void refine_i8_body(
     const BatchPtrs& P, int B, int nq, int nt, int tiles, const int* __restrict__ minfo, const unsigned char* __restrict__ qi8, const unsigned char* __restrict__ ti8,
@@ -2540,10 +2546,10 @@ __device__ __forceinline__ void refine_i8_body(
     const int qc = valid ? q : 0;
     const int rbl = (bid * kRefQ) / kI8Rows, rb = pb * n_rb1 + rbl;
     const int qloc = qc - rbl * kI8Rows;
-    const int NC = rb_last8[B * n_rb1 + rb] * 6;              // live key slots of the row block: streams x 2 half-waves x 3
+    const int NP = rb_last8[B * n_rb1 + rb] * 2, NC = 3 * NP; // live pairs (stream, half-wave) of the row block, key slots
     const int base = minfo[kMinfoBase + pb];
     qi8 += pb * s_qi8; ti8 += pb * s_ti8; wq += pb * s_qn; wt += pb * s_tn; keys += pb * s_keys;
-    const int* __restrict__ kq = keys + (int64_t)rbl * nstr * 6 * kI8Rows + qloc;      // slot c of this query: kq[c * kI8Rows]
+    const int* __restrict__ kq = keys + ((int64_t)rbl * nstr * 2 * kI8Rows + qloc) * 4;  // pair p of this query: the int4 at kq[p * kI8Rows * 4]
     const int* __restrict__ stt = sttab + (int64_t)rb * nstr * 2;
     int* __restrict__ stats = P.stats[pb];
 #ifdef SFM_DEBUG_NREC
@@ -2556,25 +2562,28 @@ __device__ __forceinline__ void refine_i8_body(
     if (sl < 8) *reinterpret_cast<uint4*>(qb + ql * kDim + 16 * sl) =
         *reinterpret_cast<const uint4*>(qi8 + (int64_t)(qc >> 5) * kI8QTileBytes + (sl >> 1) * 1024 + (((sl & 1) * 32 + (qc & 31)) << 4));
     const int cq = wq[qc] - 128;
-    int kv[kS1];
+    int kv[kS1];                                                 // kv[3 m + j]: key j of pair sl + 16 m (slot 3 (sl + 16 m) + j)
 #pragma unroll
-    for (int k = 0; k < kS1; ++k) {
-        const int c = sl + 16 * k;
-        kv[k] = (valid && c < NC) ? kq[(int64_t)c * kI8Rows] : INT_MAX;
+    for (int m = 0; m < kS1P; ++m) {
+        const int pp = sl + 16 * m;
+        const int4 x = (valid && pp < NP) ? *reinterpret_cast<const int4*>(kq + (int64_t)pp * (kI8Rows * 4)) : make_int4(INT_MAX, INT_MAX, INT_MAX, INT_MAX);
+        kv[3 * m] = x.x; kv[3 * m + 1] = x.y; kv[3 * m + 2] = x.z;
     }
+    auto slot_of = [&](int k) { return 3 * (sl + 16 * (k / 3)) + k % 3; };
     int a1 = INT_MAX, a2 = INT_MAX, atau = INT_MAX;
 #pragma unroll
     for (int k = 0; k < kS1; ++k) {
         a2 = imed3(a1, a2, kv[k]);
         a1 = min(a1, kv[k]);
-        if ((sl + 16 * k) % 3 == 2) atau = min(atau, kv[k]);
+        if (k % 3 == 2) atau = min(atau, kv[k]);
     }
     if (valid)
-        for (int c = sl + 16 * kS1; c < NC; c += 16) {
-            const int x = kq[(int64_t)c * kI8Rows];
-            if (c % 3 == 2) atau = min(atau, x);
-            a2 = imed3(a1, a2, x);
-            a1 = min(a1, x);
+        for (int pp = sl + 16 * kS1P; pp < NP; pp += 16) {
+            const int4 x = *reinterpret_cast<const int4*>(kq + (int64_t)pp * (kI8Rows * 4));
+            atau = min(atau, x.z);
+            a2 = imed3(a1, a2, x.x); a1 = min(a1, x.x);
+            a2 = imed3(a1, a2, x.y); a1 = min(a1, x.y);
+            a2 = imed3(a1, a2, x.z); a1 = min(a1, x.z);
         }
     auto fold = [&](int o1, int o2, int ot) {
         const int hi = max(a1, o1);
@@ -2657,7 +2666,7 @@ __device__ __forceinline__ void refine_i8_body(
         if (!__any(total > kRecCapI8)) {
 #pragma unroll
             for (int k = 0; k < kS1; ++k)
-                if (take[k]) { myrec[2 * at] = kv[k]; myrec[2 * at + 1] = sl + 16 * k; ++at; }
+                if (take[k]) { myrec[2 * at] = kv[k]; myrec[2 * at + 1] = slot_of(k); ++at; }
             nrec = total;
         } else {
 #pragma unroll 1
@@ -2669,20 +2678,23 @@ __device__ __forceinline__ void refine_i8_body(
                 const bool tk = kvk <= thr;
                 int tot;
                 const int a0 = row_scan(tk ? 1 : 0, tot) - (tk ? 1 : 0);
-                if (tk) { myrec[2 * (nrec + a0)] = kvk; myrec[2 * (nrec + a0) + 1] = sl + 16 * k; }
+                if (tk) { myrec[2 * (nrec + a0)] = kvk; myrec[2 * (nrec + a0) + 1] = slot_of(k); }
                 nrec += tot;
             }
         }
     }
-    for (int k0 = kS1; k0 * 16 < NC; ++k0) {                     // (wave-uniform) more than 96 key slots per query
-        if (__any(nrec > kRecCapI8 - 16)) process();
-        const int c = sl + 16 * k0;
-        const int x = (valid && c < NC) ? kq[(int64_t)c * kI8Rows] : INT_MAX;
-        const bool take = x <= thr;
-        int total;
-        const int at = row_scan(take ? 1 : 0, total) - (take ? 1 : 0);
-        if (take) { myrec[2 * (nrec + at)] = x; myrec[2 * (nrec + at) + 1] = c; }
-        nrec += total;
+    for (int p0 = 16 * kS1P; p0 < NP; p0 += 16) {                // (wave-uniform) more than 32 pairs (96 key slots) per query
+#pragma unroll 1
+        for (int j = 0; j < 3; ++j) {
+            if (__any(nrec > kRecCapI8 - 16)) process();
+            const int pp = p0 + sl;
+            const int x = (valid && pp < NP) ? kq[(int64_t)pp * (kI8Rows * 4) + j] : INT_MAX;
+            const bool take = x <= thr;
+            int total;
+            const int at = row_scan(take ? 1 : 0, total) - (take ? 1 : 0);
+            if (take) { myrec[2 * (nrec + at)] = x; myrec[2 * (nrec + at) + 1] = 3 * pp + j; }
+            nrec += total;
+        }
     }
 #ifdef SFM_DEBUG_NREC
     if (sl == 0 && stats && valid) { atomicAdd(stats + 1, nrec); atomicAdd(stats + 2, NC); }
@@ -2716,11 +2728,11 @@ __device__ __forceinline__ void refine_i8_body(
             if (!scratch[w]) continue;
             const int cq_w = scratch[16 + 4 * w];
             const long long lim_w = (long long)(((unsigned long long)(unsigned)scratch[16 + 4 * w + 2] << 32) | (unsigned)scratch[16 + 4 * w + 1]);
-            const int* __restrict__ kw = kq + (scratch[16 + 4 * w + 3] - qloc);      // the open query's key column
+            const int* __restrict__ kw = kq + 4 * (scratch[16 + 4 * w + 3] - qloc);  // the open query's key slots
             Best2I pbst;
             pbst.d[0] = pbst.d[1] = kInf; pbst.i[0] = pbst.i[1] = INT_MAX; pbst.s[0] = pbst.s[1] = INT_MAX;
             for (int c3 = 2; c3 < NC; c3 += 3) {
-                const int key3 = kw[(int64_t)c3 * kI8Rows];         // (uniform)
+                const int key3 = key_slot(kw, c3);                   // (uniform)
                 if (!(key3 < kKeyEmptyI && (long long)cq_w + 2 * ((long long)(key3 >> 8) + base) <= lim_w)) continue;
                 const int t0 = stt[2 * (c3 / 6)], len = stt[2 * (c3 / 6) + 1];
                 for (int tt = ql; tt < len; tt += kRefQ) eval_row(t0 + tt, (c3 / 3) & 1, sl >> 3, true, w, cq_w, pbst);   // a tile's 16 rows of this half-wave per 16 lanes
@@ -2800,12 +2812,12 @@ __device__ __forceinline__ void refine_q8_body(
     const int qc = valid ? q : 0;
     const int rbl = (bid * kRefQ) / kI8Rows, rb = pb * n_rb1 + rbl;
     const int qloc = qc - rbl * kI8Rows;
-    const int NC = rb_last8[B * n_rb1 + rb] * 6;              // live key slots of the row block: streams x 2 half-waves x 3
+    const int NP = rb_last8[B * n_rb1 + rb] * 2, NC = 3 * NP; // live pairs (stream, half-wave) of the row block, key slots
     const int base = minfo[kMinfoBase + pb];
     const float* __restrict__ Q = P.q[pb];
     const float* __restrict__ T = P.t[pb];
     qi8 += pb * s_qi8; ti8 += pb * s_ti8; wq += pb * s_qn; wt += pb * s_tn; keys += pb * s_keys; qerr += pb * s_qn;
-    const int* __restrict__ kq = keys + (int64_t)rbl * nstr * 6 * kI8Rows + qloc;      // slot c of this query: kq[c * kI8Rows]
+    const int* __restrict__ kq = keys + ((int64_t)rbl * nstr * 2 * kI8Rows + qloc) * 4;  // pair p of this query: the int4 at kq[p * kI8Rows * 4]
     const int* __restrict__ stt = sttab + (int64_t)rb * nstr * 2;
     int* __restrict__ stats = P.stats[pb];
     if (bid == 0 && threadIdx.x == 0 && stats) { stats[1] = G8; stats[2] = 2 * nstr; stats[3] = 5; }
@@ -2820,13 +2832,16 @@ __device__ __forceinline__ void refine_q8_body(
     }
     const int cq = wq[qc] - 128;
     const float qe2 = qerr[qc];
-    int kv[kS1], st0[kS1];                                       // keys, and the first tile of each key's stream (requested together:
-#pragma unroll                                                   // a record's tile is then known without a dependent table lookup)
-    for (int k = 0; k < kS1; ++k) {
-        const int c = sl + 16 * k;
-        kv[k] = (valid && c < NC) ? kq[(int64_t)c * kI8Rows] : INT_MAX;
-        st0[k] = (valid && c < NC) ? stt[2 * (c / 6)] : 0;
+    int kv[kS1], st0[kS1P];                                      // kv[3 m + j]: key j of pair sl + 16 m; st0[m]: the first tile of that pair's
+#pragma unroll                                                   // stream (requested together: a record's tile needs no dependent table lookup)
+    for (int m = 0; m < kS1P; ++m) {
+        const int pp = sl + 16 * m;
+        const bool in = valid && pp < NP;
+        const int4 x = in ? *reinterpret_cast<const int4*>(kq + (int64_t)pp * (kI8Rows * 4)) : make_int4(INT_MAX, INT_MAX, INT_MAX, INT_MAX);
+        kv[3 * m] = x.x; kv[3 * m + 1] = x.y; kv[3 * m + 2] = x.z;
+        st0[m] = in ? stt[2 * (pp >> 1)] : 0;
     }
+    auto slot_of = [&](int k) { return 3 * (sl + 16 * (k / 3)) + k % 3; };
     // the pair's grid and this query's slack, in units of s
     const float sf = __int_as_float(minfo[kMinfoQ8S + pb]), lof = __int_as_float(minfo[kMinfoQ8Lo + pb]);
     const float te2 = __int_as_float(minfo[kMinfoTerr + pb]);
@@ -2850,14 +2865,15 @@ __device__ __forceinline__ void refine_q8_body(
     for (int k = 0; k < kS1; ++k) {
         a2 = imed3(a1, a2, kv[k]);
         a1 = min(a1, kv[k]);
-        if ((sl + 16 * k) % 3 == 2) atau = min(atau, kv[k]);
+        if (k % 3 == 2) atau = min(atau, kv[k]);
     }
     if (valid)
-        for (int c = sl + 16 * kS1; c < NC; c += 16) {
-            const int x = kq[(int64_t)c * kI8Rows];
-            if (c % 3 == 2) atau = min(atau, x);
-            a2 = imed3(a1, a2, x);
-            a1 = min(a1, x);
+        for (int pp = sl + 16 * kS1P; pp < NP; pp += 16) {
+            const int4 x = *reinterpret_cast<const int4*>(kq + (int64_t)pp * (kI8Rows * 4));
+            atau = min(atau, x.z);
+            a2 = imed3(a1, a2, x.x); a1 = min(a1, x.x);
+            a2 = imed3(a1, a2, x.y); a1 = min(a1, x.y);
+            a2 = imed3(a1, a2, x.z); a1 = min(a1, x.z);
         }
     auto fold = [&](int o1, int o2, int ot) {
         const int hi = max(a1, o1);
@@ -2978,7 +2994,7 @@ __device__ __forceinline__ void refine_q8_body(
         if (!__any(total > kRecCapI8)) {
 #pragma unroll
             for (int k = 0; k < kS1; ++k)
-                if (take[k]) { myrec[2 * at] = kv[k]; myrec[2 * at + 1] = rec_info(kv[k], st0[k], sl + 16 * k); ++at; }
+                if (take[k]) { myrec[2 * at] = kv[k]; myrec[2 * at + 1] = rec_info(kv[k], st0[k / 3], slot_of(k)); ++at; }
             nrec = total;
         } else {
 #pragma unroll 1
@@ -2986,26 +3002,29 @@ __device__ __forceinline__ void refine_q8_body(
                 if (__any(nrec > kRecCapI8 - 16)) process();
                 int kvk = kv[0], stk = st0[0];
 #pragma unroll
-                for (int kk = 1; kk < kS1; ++kk) { kvk = k == kk ? kv[kk] : kvk; stk = k == kk ? st0[kk] : stk; }
+                for (int kk = 1; kk < kS1; ++kk) { kvk = k == kk ? kv[kk] : kvk; stk = k == kk ? st0[kk / 3] : stk; }
                 const bool tk = kvk <= thr;
                 int tot;
                 const int a0 = row_scan(tk ? 1 : 0, tot) - (tk ? 1 : 0);
-                if (tk) { myrec[2 * (nrec + a0)] = kvk; myrec[2 * (nrec + a0) + 1] = rec_info(kvk, stk, sl + 16 * k); }
+                if (tk) { myrec[2 * (nrec + a0)] = kvk; myrec[2 * (nrec + a0) + 1] = rec_info(kvk, stk, slot_of(k)); }
                 nrec += tot;
             }
         }
     }
-    for (int k0 = kS1; k0 * 16 < NC; ++k0) {                     // (wave-uniform) more than 96 key slots per query
-        if (__any(nrec > kRecCapI8 - 16)) process();
-        const int c = sl + 16 * k0;
-        const bool in = valid && c < NC;
-        const int x = in ? kq[(int64_t)c * kI8Rows] : INT_MAX;
-        const int t0x = in ? stt[2 * (c / 6)] : 0;
-        const bool take = x <= thr;
-        int total;
-        const int at = row_scan(take ? 1 : 0, total) - (take ? 1 : 0);
-        if (take) { myrec[2 * (nrec + at)] = x; myrec[2 * (nrec + at) + 1] = rec_info(x, t0x, c); }
-        nrec += total;
+    for (int p0 = 16 * kS1P; p0 < NP; p0 += 16) {                // (wave-uniform) more than 32 pairs (96 key slots) per query
+        const int pp = p0 + sl;
+        const bool in = valid && pp < NP;
+        const int t0x = in ? stt[2 * (pp >> 1)] : 0;
+#pragma unroll 1
+        for (int j = 0; j < 3; ++j) {
+            if (__any(nrec > kRecCapI8 - 16)) process();
+            const int x = in ? kq[(int64_t)pp * (kI8Rows * 4) + j] : INT_MAX;
+            const bool take = x <= thr;
+            int total;
+            const int at = row_scan(take ? 1 : 0, total) - (take ? 1 : 0);
+            if (take) { myrec[2 * (nrec + at)] = x; myrec[2 * (nrec + at) + 1] = rec_info(x, t0x, 3 * pp + j); }
+            nrec += total;
+        }
     }
     if (trace && threadIdx.x == 0) { trace[16 * bidt + 2] = wall_clock64(); trace[16 * bidt + 13] = nrec; }
     process();
@@ -3030,10 +3049,10 @@ __device__ __forceinline__ void refine_q8_body(
         openm &= ~(0xFFFFull << (16 * wl));
         const int src = 16 * wl;
         const int cq_w = __shfl(cq, src, 64), qloc_w = __shfl(qloc, src, 64);
-        const int* __restrict__ kw = kq + (qloc_w - qloc);         // the open query's key column
+        const int* __restrict__ kw = kq + 4 * (qloc_w - qloc);     // the open query's key slots
         const bool mine = sub == wl;
         for (int c3 = 2; c3 < NC; c3 += 3) {
-            const int key3 = kw[(int64_t)c3 * kI8Rows];            // (uniform)
+            const int key3 = key_slot(kw, c3);                     // (uniform)
             // the owner's lanes decide (their slack, their current second distance); everyone follows
             const bool hid = hides_nothing(key3, b.d[1]);
             const unsigned long long vote = __ballot(mine && !hid);
@@ -3819,7 +3838,7 @@ struct KnnWs {
     int* bwmax;
     unsigned short* rmq;          // [B][s_qn] / [B][s_tn]: bit c = chunk c (8 elements) of the row exists in the byte image only
     unsigned short* rmt;
-    int* keys8;                   // [B][row blocks][stream slots][2][3][1024] packed keys
+    int* keys8;                   // [B][row blocks][stream slots][2][1024 queries][4] packed keys (three per stream and half-wave, one 16-byte slot)
     int* sttab8;                  // [row blocks of the batch][stream slots][2]: first tile, tile count of a stream
     int64_t* wg_begin8;
     int* rb_first8;
@@ -3866,7 +3885,7 @@ KnnWs carve_ws(void* ws, int64_t nq, int64_t nt, const Plan& p, const Plan* p8) 
     if (p8) {
         w.s_qi8 = (int64_t)(p.nq_pad / 32) * kI8QTileBytes;
         w.s_ti8 = (int64_t)p.tiles * kI8TileBytes;
-        w.s_keys8 = (int64_t)p8->n_rb1 * p8->smax * p8->nsub * 6 * kI8Rows;
+        w.s_keys8 = (int64_t)p8->n_rb1 * p8->smax * p8->nsub * 2 * kI8Rows * 4;    // [row block][stream slot][half-wave][1024 queries][3 keys + pad]
         w.qi8 = c.take<unsigned char>(B * (size_t)w.s_qi8);
         w.ti8 = c.take<unsigned char>(B * (size_t)w.s_ti8);
         w.wq = c.take<int>(B * (size_t)w.s_qn);
