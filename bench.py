@@ -160,8 +160,10 @@ def cpu_knn_baseline(nq, nt, seed_q, seed_t):
 
 
 def knn_source_hash():
-    import hashlib
-    return hashlib.sha256(open(os.path.join(ROOT, "sfm_mvs_amd", "csrc", "knn.hip"), "rb").read()).hexdigest()
+    """sha256 of csrc/knn.hip's code (comments and whitespace removed): what the PMC traffic stamps under profiles/ carry."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    from knn_code_hash import knn_code_hash
+    return knn_code_hash()
 
 
 def bench_knn(args, world, rank, dev):
@@ -294,7 +296,7 @@ def bench_knn(args, world, rank, dev):
     tpath = os.path.join(ROOT, "profiles", "knn_traffic.json")
     if os.path.exists(tpath) and (nq, nt) == (10000, 10000):
         tj = json.load(open(tpath))
-        if tj.get("knn_hip_sha256") == knn_source_hash() and tj.get("pairs_per_launch", 1) == pbatch:
+        if tj.get("knn_hip_code_sha256") == knn_source_hash() and tj.get("pairs_per_launch", 1) == pbatch:
             traffic, traffic_note = tj.get("bytes_per_launch"), f"profiles/knn_traffic.json ({tj.get('source')})"
         else:
             traffic_note = "profiles/knn_traffic.json is stale (csrc/knn.hip or the pair batch changed since the PMC passes): not reported"
@@ -436,7 +438,7 @@ def bench_knn(args, world, rank, dev):
         t8 = os.path.join(ROOT, "profiles", "knn_i8_traffic.json")
         if os.path.exists(t8) and (nq, nt) == (10000, 10000):
             tj8 = json.load(open(t8))
-            if tj8.get("knn_hip_sha256") == knn_source_hash() and tj8.get("pairs_per_launch", 1) == pbatch:
+            if tj8.get("knn_hip_code_sha256") == knn_source_hash() and tj8.get("pairs_per_launch", 1) == pbatch:
                 i8_traffic, i8_traffic_note = tj8.get("bytes_per_launch"), f"profiles/knn_i8_traffic.json ({tj8.get('source')})"
             else:
                 i8_traffic_note = "profiles/knn_i8_traffic.json is stale (csrc/knn.hip or the pair batch changed since the PMC passes): not reported"

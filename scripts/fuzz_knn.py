@@ -26,7 +26,8 @@ and a fourth group of float data with COMPACT support — what filter="auto" QUA
 Batches mix the families: a u8 pair next to a float pair exercises the conversion of byte-image chunks to fp16 (mixed batch),
 a quantised pair next to a Gaussian one the repair of pairs quantised in vain.
 Most cases are small (the oracle dominates the wall time); one in eight is large, `big` adds 20k-70k train rows.
-The log ends with the sha256 of csrc/knn.hip: profiles/r04_fuzz_knn_*.log are checked against the tree by tests/test_gpu_knn.py.
+The log ends with the sha256 of csrc/knn.hip and of its CODE (comments and whitespace removed, scripts/knn_code_hash.py):
+profiles/r04_fuzz_knn_*.log are checked against the tree's code hash by tests/test_gpu_knn.py.
 """
 import hashlib
 import os
@@ -270,9 +271,12 @@ while time.time() < t_end:
 
 worst, scale = ops.knn_mfma_selftest_result()
 sha = hashlib.sha256(open(os.path.join(ROOT, "sfm_mvs_amd", "csrc", "knn.hip"), "rb").read()).hexdigest()
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+from knn_code_hash import knn_code_hash                  # comments / whitespace removed: a documentation-only edit keeps the logs valid
 print(f"fuzz: {cases} cases ({batched} of them batches of 2..8 pairs), {fails} mismatches, seed {seed}, {time.time() - t_start:.0f} s")
 print(f"  filter arithmetic modes that ran {dict(sorted(modes.items()))}; variants {per_variant}; rescanned queries in total {rescans}")
 print(f"  families {per_kind}")
 print(f"  runtime MFMA self-test on this device: worst E = {worst:.2f} units, chain scale {scale}")
 print(f"knn_hip_sha256 {sha}")
+print(f"knn_hip_code_sha256 {knn_code_hash()}")
 sys.exit(1 if fails else 0)

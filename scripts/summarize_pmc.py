@@ -44,6 +44,7 @@ for k, v in agg.items():
 # HBM-side bytes per launch of the dominant kernel, stamped with the kernel source it was measured on (bench.py reports
 # it only while csrc/knn.hip is unchanged)
 import hashlib, json
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 for k, v in agg.items():
     if k.startswith("knn_filter_q4_kernel") and "FETCH_SIZE" in v:
         m = {c: sum(x) / len(x) for c, x in v.items()}
@@ -53,6 +54,7 @@ for k, v in agg.items():
                "mfma_pipe_busy_frac": (m["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * m["SQ_BUSY_CU_CYCLES"])) if "SQ_BUSY_CU_CYCLES" in m else None,
                "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE doubled per MI355X_MICROARCH.md gfx950 correction; workload 10k x 10k",
                "source": f"profiles/{tag}_knn_i8_pmc.md" if variant == "i8" else f"profiles/{tag}_knn_f16_pmc.md" if variant == "f16" else f"profiles/{tag}_knn_pmc.md",
-               "knn_hip_sha256": hashlib.sha256(open(os.path.join(root, "sfm_mvs_amd", "csrc", "knn.hip"), "rb").read()).hexdigest()}
+               "knn_hip_sha256": hashlib.sha256(open(os.path.join(root, "sfm_mvs_amd", "csrc", "knn.hip"), "rb").read()).hexdigest(),
+               "knn_hip_code_sha256": __import__("knn_code_hash").knn_code_hash()}
         json.dump(out, open(os.path.join(d, "..", "knn_i8_traffic.json" if variant == "i8" else "knn_f16_traffic.json" if variant == "f16" else "knn_traffic.json"), "w"), indent=1)
         break

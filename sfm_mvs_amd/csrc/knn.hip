@@ -2089,8 +2089,8 @@ __device__ __forceinline__ void filter_q4_body(
 //     the key's low 8 bits are (tile inside a 128-tile substream) << 1 | e;
 //   * i32 accumulation: scores are exact (up to the parity bit, see the images' comment), keys hold the whole score
 //     (acc << 8 | tile), the accumulator init is one i8 MFMA per tile shared by the 8 groups (C operand of their first products);
-//   * records are the three packed keys per stream, stored transposed ([row block][stream][h][k][1024 queries]: every store
-//     instruction writes 128 contiguous bytes per half-wave) — 12 B per stream and query instead of 24.
+//   * records are the three packed keys per stream and half-wave, ONE 16-byte slot per query ([row block][stream][h][1024
+//     queries][3 keys + pad]: a store instruction writes 512 contiguous bytes per half-wave) — see the flush below.
 // Row blocks are 1024 queries; the partition tables are those of the i8 plan (wg_begin8 ...).
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 #define SFM_MFMA_I8(acc, a, b) asm volatile("v_mfma_i32_32x32x32_i8 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "a"(b))

@@ -389,11 +389,14 @@ def test_runtime_selftest_gates_the_certificate(hip, oracle):
 @pytest.mark.gpu
 def test_committed_fuzz_logs_are_those_of_this_kernel_source():
     """The long randomised parity sweeps (scripts/fuzz_knn.py: >= 20 000 cases per round incl. the margin-aimed families)
-    are committed under profiles/ with the sha256 of csrc/knn.hip they ran on.  A log of another source proves nothing about
-    this binary: the sweep has to be re-run after the last edit of the kernel file."""
-    import glob, hashlib, os, re
+    are committed under profiles/ with the sha256 of the CODE of csrc/knn.hip they ran on (comments and whitespace removed,
+    scripts/knn_code_hash.py: a documentation-only edit keeps them valid).  A log of another source proves nothing about this
+    binary: the sweep has to be re-run after the last edit of the kernel's code."""
+    import glob, os, re, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    sha = hashlib.sha256(open(os.path.join(root, "sfm_mvs_amd", "csrc", "knn.hip"), "rb").read()).hexdigest()
+    sys.path.insert(0, os.path.join(root, "scripts"))
+    from knn_code_hash import knn_code_hash
+    sha = knn_code_hash()
     logs = sorted(glob.glob(os.path.join(root, "profiles", "r04_fuzz_knn_*.log")))
     assert logs, "no profiles/r04_fuzz_knn_*.log"
     total = 0
@@ -401,6 +404,6 @@ def test_committed_fuzz_logs_are_those_of_this_kernel_source():
         text = open(path).read()
         m = re.search(r"fuzz: (\d+) cases .*?, (\d+) mismatches", text)
         assert m and int(m.group(2)) == 0, f"{path}: no clean summary line"
-        assert f"knn_hip_sha256 {sha}" in text, f"{path} was produced by another csrc/knn.hip (stale): re-run scripts/fuzz_knn.py"
+        assert f"knn_hip_code_sha256 {sha}" in text, f"{path} was produced by another csrc/knn.hip (stale): re-run scripts/fuzz_knn.py"
         total += int(m.group(1))
     assert total >= 20000, f"only {total} fuzz cases on this source"
