@@ -1,4 +1,4 @@
-"""sha256 of csrc/knn.hip's CODE: comments and whitespace runs removed (string literals kept as they are), so that the fuzz
+"""sha256 of csrc/knn.hip's CODE: comments and whitespace runs removed (string literals keep their text; runs of whitespace collapse everywhere), so that the fuzz
 logs and PMC traffic stamps under profiles/ stay valid across documentation-only edits of the kernel source and go stale on
 any change of a token.  Used by scripts/fuzz_knn.py, scripts/summarize_pmc.py, bench.py and tests/test_gpu_knn.py.
   python scripts/knn_code_hash.py [path]"""
