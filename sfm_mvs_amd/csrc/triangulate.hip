@@ -316,9 +316,11 @@ inline int fixup_chunk(int64_t n) {
     return (int)std::min<int64_t>(std::max<int64_t>(c, kFixStep), kFixChunkMax);
 }
 __global__ __launch_bounds__(256) void triangulate_fixup_kernel(ProjPair P, const float* __restrict__ x1, const float* __restrict__ x2, int64_t n,
-                                                               int64_t spt, int64_t sxy, int chunk, float* __restrict__ X4) {
+                                                               int64_t spt, int64_t sxy, int chunk, float* __restrict__ X4,
+                                                               const int* __restrict__ list /*null, or the first pass's reject list: {count, overflow, indices ...}*/) {
     extern __shared__ unsigned short queue[];                       // [chunk] offsets inside the chunk (< 20 480)
     __shared__ int qn;
+    if (list && list[1] == 0) return;                               // (uniform) every rejected point was listed: triangulate_fixlist_kernel redid them
     for (int64_t base = (int64_t)blockIdx.x * chunk; base < n; base += (int64_t)gridDim.x * chunk) {
         __syncthreads();                                            // (the previous chunk's queue has been worked off)
         if (threadIdx.x == 0) qn = 0;
@@ -343,6 +345,21 @@ __global__ __launch_bounds__(256) void triangulate_fixup_kernel(ProjPair P, cons
             dlt_nullvec<4>(At, Xd);
             store_point<4>(Xd, 1, n, i, X4);
         }
+    }
+}
+
+// Second pass from the first pass's COMPACT list of rejected points (large calls: sfm_triangulate_dlt allocates it stream-ordered):
+// no scan of the 4 n floats for marks — at 1e7 points the scan was 35 of the fixup's 57 us — and every wave but the last is full.
+__global__ __launch_bounds__(256) void triangulate_fixlist_kernel(ProjPair P, const float* __restrict__ x1, const float* __restrict__ x2, int64_t n,
+                                                                 int64_t spt, int64_t sxy, const int* __restrict__ list, float* __restrict__ X4) {
+    if (list[1] != 0) return;                                       // (uniform) the list overflowed: the marks are scanned instead
+    const int total = list[0];
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int64_t i = list[2 + e];
+        double At[4][4], Xd[4];
+        dlt_build<4>(At, P.p[0], P.p[1], (double)x1[i * spt], (double)x1[i * spt + sxy], (double)x2[i * spt], (double)x2[i * spt + sxy]);
+        dlt_nullvec<4>(At, Xd);
+        store_point<4>(Xd, 1, n, i, X4);
     }
 }
 
@@ -403,7 +420,14 @@ __global__ __launch_bounds__(256) void triangulate_kernel(ProjPair P, const floa
 template <bool PACKED>
 __global__ __launch_bounds__(256) void triangulate_guarded_kernel(ProjPair P, const float* __restrict__ x1, const float* __restrict__ x2, int64_t n,
                                                                   int64_t spt, int64_t sxy, double sens_factor, double base_guard,
-                                                                  float* __restrict__ X4) {
+                                                                  float* __restrict__ X4, int* __restrict__ list /*null, or {count, overflow, indices[cap]}*/, int cap) {
+    // Rejected points are marked in X4 (the scan pass finds them) and, when the caller provides a list, also queued per workgroup
+    // (LDS) and appended to it with ONE global atomic per workgroup at the end of its walk (per point that would be ~70 000
+    // arrivals on one address at 1e7 points: ~0.8 ms).
+    constexpr int kQ = 1024;
+    __shared__ int rq[kQ];
+    __shared__ int rqn, rbase;
+    if (list) { if (threadIdx.x == 0) rqn = 0; __syncthreads(); }
     const int64_t T = (int64_t)gridDim.x * 256;
     int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x;
     float xa = 0.f, ya = 0.f, xb = 0.f, yb = 0.f;
@@ -431,9 +455,28 @@ __global__ __launch_bounds__(256) void triangulate_guarded_kernel(ProjPair P, co
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k) X4[k * n + i] = __uint_as_float(kRedoMark);
+            if (list) {
+                const int at = atomicAdd(&rqn, 1);
+                if (at < kQ) rq[at] = (int)i;                         // (list mode is offered for n < 2^31 only)
+            }
         }
         xa = nxa; ya = nya; xb = nxb; yb = nyb;
         i = nx;
+    }
+    if (list) {
+        __syncthreads();
+        const int total = rqn;                                      // (uniform)
+        if (total > kQ) {                                           // more rejects than the queue holds: leave it to the scan
+            if (threadIdx.x == 0) atomicExch(&list[1], 1);
+            return;
+        }
+        if (threadIdx.x == 0) rbase = total ? atomicAdd(&list[0], total) : 0;
+        __syncthreads();
+        if (rbase + total > cap) {
+            if (threadIdx.x == 0) atomicExch(&list[1], 1);
+            return;
+        }
+        for (int e = threadIdx.x; e < total; e += 256) list[2 + rbase + e] = rq[e];
     }
 }
 
@@ -641,15 +684,30 @@ extern "C" int sfm_triangulate_dlt(const double* P1, const double* P2, const flo
     constexpr double sens_factor = kSensFactor, base_guard = kCastGuard;
 #endif
     sfm::prof_begin(sfm::kProfTriangulate, sfm::as_stream(stream_));
+    int* list = nullptr;
+    int cap = 0;
+    if (normalise_w == 3 && n >= (1 << 18) && n < INT_MAX) {
+        // large calls: a stream-ordered scratch list for the first pass's rejects ({count, overflow flag, indices}; ~0.7 % of the
+        // points are rejected, room for 1/8 of them).  If the allocation is refused the marks are scanned as for small calls.
+        cap = (int)(n / 8);
+        if (hipMallocAsync(reinterpret_cast<void**>(&list), sizeof(int) * (size_t)(cap + 2), sfm::as_stream(stream_)) != hipSuccess) {
+            (void)hipGetLastError();
+            list = nullptr;
+        } else if (hipMemsetAsync(list, 0, 2 * sizeof(int), sfm::as_stream(stream_)) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFreeAsync(list, sfm::as_stream(stream_));
+            list = nullptr;
+        }
+    }
     if (normalise_w == 3) {
         // (rows == 4) a grid sized to the chip: 256 CUs x the kernel's resident workgroups, a lane walks its points
         const dim3 pgrid((unsigned)std::min<int64_t>((n + 255) / 256, 256 * 6));
         if (stride_pt == 2 && stride_xy == 1 && ((uintptr_t)x1 & 7) == 0 && ((uintptr_t)x2 & 7) == 0)
             hipLaunchKernelGGL(triangulate_guarded_kernel<true>, pgrid, dim3(256), 0, sfm::as_stream(stream_), P, x1, x2, n, stride_pt, stride_xy,
-                               sens_factor, base_guard, X4);
+                               sens_factor, base_guard, X4, list, cap);
         else
             hipLaunchKernelGGL(triangulate_guarded_kernel<false>, pgrid, dim3(256), 0, sfm::as_stream(stream_), P, x1, x2, n, stride_pt, stride_xy,
-                               sens_factor, base_guard, X4);
+                               sens_factor, base_guard, X4, list, cap);
     } else if (rows == 4)
         hipLaunchKernelGGL(triangulate_kernel<4>, grid, dim3(256), 0, sfm::as_stream(stream_), P, x1, x2, n, stride_pt,
                            stride_xy, normalise_w, sens_factor, base_guard, X4);
@@ -659,8 +717,11 @@ extern "C" int sfm_triangulate_dlt(const double* P1, const double* P2, const flo
     if (normalise_w == 3)
     {
         const int chunk = fixup_chunk(n);
+        if (list)
+            hipLaunchKernelGGL(triangulate_fixlist_kernel, dim3(512), dim3(256), 0, sfm::as_stream(stream_), P, x1, x2, n, stride_pt, stride_xy, (const int*)list, X4);
         hipLaunchKernelGGL(triangulate_fixup_kernel, dim3((unsigned)std::min<int64_t>((n + chunk - 1) / chunk, 1024)), dim3(256), sizeof(unsigned short) * (size_t)chunk,
-                           sfm::as_stream(stream_), P, x1, x2, n, stride_pt, stride_xy, chunk, X4);
+                           sfm::as_stream(stream_), P, x1, x2, n, stride_pt, stride_xy, chunk, X4, (const int*)list);
+        if (list) (void)hipFreeAsync(list, sfm::as_stream(stream_));
     }
     sfm::prof_end(sfm::kProfTriangulate, sfm::as_stream(stream_));
     SFM_CHECK_LAUNCH();
