@@ -320,7 +320,17 @@ __global__ __launch_bounds__(256) void triangulate_fixup_kernel(ProjPair P, cons
                                                                const int* __restrict__ list /*null, or the first pass's reject list: {count, overflow, indices ...}*/) {
     extern __shared__ unsigned short queue[];                       // [chunk] offsets inside the chunk (< 20 480)
     __shared__ int qn;
-    if (list && list[1] == 0) return;                               // (uniform) every rejected point was listed: triangulate_fixlist_kernel redid them
+    if (list && list[1] == 0) {                                     // (uniform) every rejected point is on the first pass's compact list:
+        const int total = list[0];                                  // no scan — at 1e7 points it was 35 of this pass's 57 us — and every wave but the last is full
+        for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+            const int64_t i = list[2 + e];
+            double At[4][4], Xd[4];
+            dlt_build<4>(At, P.p[0], P.p[1], (double)x1[i * spt], (double)x1[i * spt + sxy], (double)x2[i * spt], (double)x2[i * spt + sxy]);
+            dlt_nullvec<4>(At, Xd);
+            store_point<4>(Xd, 1, n, i, X4);
+        }
+        return;
+    }
     for (int64_t base = (int64_t)blockIdx.x * chunk; base < n; base += (int64_t)gridDim.x * chunk) {
         __syncthreads();                                            // (the previous chunk's queue has been worked off)
         if (threadIdx.x == 0) qn = 0;
@@ -345,21 +355,6 @@ __global__ __launch_bounds__(256) void triangulate_fixup_kernel(ProjPair P, cons
             dlt_nullvec<4>(At, Xd);
             store_point<4>(Xd, 1, n, i, X4);
         }
-    }
-}
-
-// Second pass from the first pass's COMPACT list of rejected points (large calls: sfm_triangulate_dlt allocates it stream-ordered):
-// no scan of the 4 n floats for marks — at 1e7 points the scan was 35 of the fixup's 57 us — and every wave but the last is full.
-__global__ __launch_bounds__(256) void triangulate_fixlist_kernel(ProjPair P, const float* __restrict__ x1, const float* __restrict__ x2, int64_t n,
-                                                                 int64_t spt, int64_t sxy, const int* __restrict__ list, float* __restrict__ X4) {
-    if (list[1] != 0) return;                                       // (uniform) the list overflowed: the marks are scanned instead
-    const int total = list[0];
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
-        const int64_t i = list[2 + e];
-        double At[4][4], Xd[4];
-        dlt_build<4>(At, P.p[0], P.p[1], (double)x1[i * spt], (double)x1[i * spt + sxy], (double)x2[i * spt], (double)x2[i * spt + sxy]);
-        dlt_nullvec<4>(At, Xd);
-        store_point<4>(Xd, 1, n, i, X4);
     }
 }
 
@@ -717,8 +712,6 @@ extern "C" int sfm_triangulate_dlt(const double* P1, const double* P2, const flo
     if (normalise_w == 3)
     {
         const int chunk = fixup_chunk(n);
-        if (list)
-            hipLaunchKernelGGL(triangulate_fixlist_kernel, dim3(512), dim3(256), 0, sfm::as_stream(stream_), P, x1, x2, n, stride_pt, stride_xy, (const int*)list, X4);
         hipLaunchKernelGGL(triangulate_fixup_kernel, dim3((unsigned)std::min<int64_t>((n + chunk - 1) / chunk, 1024)), dim3(256), sizeof(unsigned short) * (size_t)chunk,
                            sfm::as_stream(stream_), P, x1, x2, n, stride_pt, stride_xy, chunk, X4, (const int*)list);
         if (list) (void)hipFreeAsync(list, sfm::as_stream(stream_));
