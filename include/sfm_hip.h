@@ -224,6 +224,10 @@ int sfm_mask_indices(const uint8_t* mask_dev, int64_t n, int mode, int32_t* idx_
  *   two backward-stable solutions of this point can have; lambda1/lambda3 is read off the iteration), the other points —
  *   a fraction of a percent on well-conditioned geometry, all of them when the baseline vanishes — are redone by the
  *   Jacobi sweeps in a second, compacted pass: bit-identical to normalise_w = 1 on every point.
+ *   Scratch: this entry point takes no workspace.  For n >= 2^18 the guarded path asks the device's default memory pool
+ *   for n / 8 + 2 ints ON THE CALLER'S STREAM (hipMallocAsync / hipFreeAsync: stream-ordered, no synchronisation) — the
+ *   first pass's compact list of rejected points; if the request is refused, or the list overflows, the second pass finds
+ *   the marked points by scanning X4 as it does for smaller calls.  Same results either way.
  *
  *   P1, P2        HOST pointers, 12 doubles each, row-major 3x4
  *   x1_dev,x2_dev float32; point i has x at [i*stride_pt] and y at
