@@ -164,3 +164,24 @@ def test_full_size_batch_quantised_equals_noquant(hip):
         m = int(res["auto"][1][b].item())
         assert torch.equal(res["auto"][2][b, :m], res["noquant"][2][b, :m]) and torch.equal(res["auto"][3][b, :m], res["noquant"][3][b, :m])
     assert res["auto"][5] < 8 * 10000 // 50, "more than 2 % of the queries rescanned on uniform data"
+
+
+def test_config5_shape_quantised_equals_noquant(hip):
+    """BASELINE configs[4]'s shape — 50 000 x 50 000 — on uniform float descriptors: 1 563 train tiles, 49 streams x 2 half-waves of
+    key slots per query (the loops beyond the 32 pairs a lane fetches up front): the quantised body and the fp16 body agree bit
+    for bit, Lowe lists included."""
+    gen = lambda seed, n: torch.rand((n, 128), generator=torch.Generator().manual_seed(seed)).cuda()
+    q, t = gen(41, 50000), gen(42, 50000)
+    t[::7] = q[::7] * 1.0005                                      # ratio survivors
+    res = {}
+    for variant in ("auto", "noquant"):
+        pm = hip.PairMatcher(50000, 50000, "cuda", ratio=0.70, filter=variant)
+        idx, dist, oq, ot, cnt = pm.run(q, t)
+        torch.cuda.synchronize()
+        m = int(cnt.item())
+        res[variant] = (idx.clone(), dist.clone(), oq[:m].clone(), ot[:m].clone(), m, pm.stats.cpu().tolist())
+    assert res["auto"][5][3] == 5 and res["noquant"][5][3] == 1
+    assert torch.equal(res["auto"][0], res["noquant"][0]) and torch.equal(res["auto"][1], res["noquant"][1])
+    assert res["auto"][4] == res["noquant"][4] and res["auto"][4] > 5000
+    assert torch.equal(res["auto"][2], res["noquant"][2]) and torch.equal(res["auto"][3], res["noquant"][3])
+    assert res["auto"][5][0] < 50000 // 20, f"{res['auto'][5][0]} rescanned queries"
