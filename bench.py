@@ -2,7 +2,9 @@
 """Hot-path benchmark (contract in the task prompt; workload = BASELINE.json configs[1]).
 
   python bench.py --gpus 1 --steps K --warmup W                      # config 2: 10k x 10k BF-KNN + ratio
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N   # pair-sharded, weak scaling
+  python bench.py --gpus N                                           # N > 1: starts its own N ranks (self_launch) ...
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N   # ... or runs as one rank of a launcher's N; pair-sharded, weak scaling
+  python bench.py --gpus N --dry-run-dist                            # no GPU: the N-rank launch + exchange protocol over gloo
 
 A "step" is one pass of the hot path over one batch of synthetic input: knnMatch(k=2) + Lowe ratio for a batch of
 PAIR_BATCH independent image pairs of 10 000 x 10 000 128-D float32 descriptors per rank (one launch set of
@@ -64,19 +66,55 @@ def parse():
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--pipe-depth", type=int, default=PIPE_DEPTH, help="launch sets in flight per GPU (1 = one stream)")
     ap.add_argument("--pair-batch", type=int, default=PAIR_BATCH, help="independent pairs per launch set (1..8)")
+    ap.add_argument("--dry-run-dist", action="store_true",
+                    help="no GPU: run the N-rank launch, rendezvous, batched all-gather and timing protocol of the knn / c5 legs on CPU tensors over gloo "
+                         "(the slots are filled with a rank-stamped pattern instead of KNN blocks); the JSON line carries dry_run: true and no throughput")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment (the driver's command line for the scaling
+    curve): re-exec this script under torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1.  The children find
+    WORLD_SIZE set and take the normal path; rank 0 prints the one JSON line on the inherited stdout.  GPU_MAX_HW_QUEUES and
+    HSA_ENABLE_IPC_MODE_LEGACY are exported BEFORE any child touches HIP (sharded.py: streams sharing a hardware queue
+    serialise, -14 %; the host driver supports dmabuf IPC only).  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    if not args.dry_run_dist:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            print(f"[bench] --gpus {args.gpus} but this node shows {have} GPU(s): refusing to oversubscribe", file=sys.stderr)
+            return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("GPU_MAX_HW_QUEUES", "8")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {args.gpus}: launching {args.gpus} ranks: {' '.join(cmd[2:9])} bench.py ...", file=sys.stderr)
+    sys.stdout.flush()
+    return subprocess.call(cmd, env=env)
 
 
 def init_dist(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 or os.environ.get("SFM_BENCH_EXCHANGE"):     # (the env switch runs the N > 1 code path on one rank: dev/test)
+    if args.dry_run_dist:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", world_size=world, rank=rank)
+    elif world > 1 or os.environ.get("SFM_BENCH_EXCHANGE"):     # (the env switch runs the N > 1 code path on one rank: dev/test)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local), world_size=world, rank=rank)
+        assert dist.get_world_size() == world          # n_gpus in the JSON line = the RCCL group's rank count
     else:
         torch.cuda.set_device(0)
         local = 0
@@ -86,11 +124,14 @@ def init_dist(args):
 
 
 def barrier_sync(world):
-    torch.cuda.synchronize()
+    gpu = torch.cuda.is_available()
+    if gpu:
+        torch.cuda.synchronize()
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
-        torch.cuda.synchronize()
+        if gpu:
+            torch.cuda.synchronize()
 
 
 def max_over_ranks(x, world, dev):
@@ -1287,13 +1328,79 @@ def bench_sfm(args, world, rank, dev):
             "parity": parity}
 
 
+def bench_dry_run(args, world, rank):
+    """--dry-run-dist: what the N-rank launch does around the kernels, on CPU tensors over gloo.  The knn leg's step protocol
+    (next_slot -> fill -> commit -> flush, one all-gather per EXCH_BATCH pairs, barrier + max-over-ranks timing) and, for
+    --workload c5, the strong-scaling partition (contiguous pair blocks + one halo image) run for real; a slot is filled with
+    a (rank, pair) stamp instead of a KNN block — there is no CPU compute path — and every rank checks every gathered slot."""
+    import torch.distributed as dist
+    from sfm_mvs_amd import sharded
+    dev = torch.device("cpu")
+    nq = 64
+    pbatch = max(1, min(8, args.pair_batch))
+    steps = max(1, min(args.steps, 8))
+    ex = sharded.BatchedExchange((2, nq, 2), torch.int32, dev, batch=EXCH_BATCH, nbuf=args.pipe_depth + 1)
+    assert ex.world == world == dist.get_world_size() and ex.rank == rank
+    ok, serial = True, 0
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        for b in range(pbatch):
+            slot, _ = ex.next_slot()
+            slot.fill_(rank * 1_000_000 + serial)
+            serial += 1
+            if ex.commit():
+                got, filled = ex.flush(())
+                base = serial - filled
+                for r in range(world):
+                    for k in range(filled):
+                        ok = ok and bool((got[r, k] == r * 1_000_000 + base + k).all())
+    if ex.fill:
+        ex.flush(())
+    barrier_sync(world)
+    elapsed = max_over_ranks(time.perf_counter() - t0, world, dev)
+    out = {"metric": "descriptor-pair distances/sec (BF-KNN k=2 + Lowe ratio)", "value": None, "unit": "distances/s", "dry_run": True,
+           "n_gpus": dist.get_world_size(), "steps": steps, "warmup": 0, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "none (dry run: no kernels)", "data": "rank-stamped slots",
+           "config": {"workload": f"dry run of the {args.workload} leg's N-rank protocol on CPU tensors", "backend": dist.get_backend(),
+                      "parallelism": f"pair-sharded x{world} + one all-gather of the match records per {EXCH_BATCH} pairs",
+                      "exchange": {"collectives": ex.collectives, "pairs_per_collective": EXCH_BATCH, "ranks": dist.get_world_size(),
+                                   "gathered_slots_verified": ok},
+                      "launched_by": "bench.py self_launch" if os.environ.get("TORCHELASTIC_RUN_ID") else "external launcher"}}
+    if args.workload == "c5":
+        n_img = max(2, args.images or 256)
+        pairs = sharded.sequential_pairs(n_img)
+        lo, hi = sharded.shard_range(len(pairs), world, rank)
+        held = sharded.halo_images(pairs, world, rank)
+        counts = [None] * world
+        dist.all_gather_object(counts, {"pairs": hi - lo, "images_held": len(held)})
+        out["scaling"] = "strong"
+        out["config"]["partition"] = counts
+        ok = ok and sum(c["pairs"] for c in counts) == len(pairs) and all(c["images_held"] == c["pairs"] + (1 if c["pairs"] else 0) for c in counts)
+        out["config"]["exchange"]["gathered_slots_verified"] = ok
+    if not ok:
+        raise SystemExit("dry run: a gathered slot did not carry its (rank, pair) stamp")
+    return out
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     # stdout carries exactly ONE line (the JSON): libraries that write to the C-level stdout (RCCL prints a version banner
-    # from its own stdio buffer at exit) are sent to stderr for the whole run, the JSON goes to the saved descriptor
+    # from its own stdio buffer at exit, gloo its connection notes) are sent to stderr for the whole run, the JSON goes to
+    # the saved descriptor
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    if args.dry_run_dist:
+        world, rank, _ = init_dist(args)
+        out = bench_dry_run(args, world, rank)
+        import torch.distributed as dist
+        if rank == 0:
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
+        dist.destroy_process_group()
+        return
     world, rank, local = init_dist(args)
     dev = torch.device("cuda", local)
     import sfm_mvs_amd
