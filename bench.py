@@ -201,10 +201,10 @@ def cpu_knn_baseline(nq, nt, seed_q, seed_t):
 
 
 def knn_source_hash():
-    """sha256 of csrc/knn.hip's code (comments and whitespace removed): what the PMC traffic stamps under profiles/ carry."""
-    sys.path.insert(0, os.path.join(ROOT, "scripts"))
-    from knn_code_hash import knn_code_hash
-    return knn_code_hash()
+    """sha256 of the csrc/knn.hip CODE the LOADED library was built from (sfm_build_id(): baked in at build time; comments and
+    whitespace do not count): what the PMC traffic stamps under profiles/ must carry to be reported."""
+    from sfm_mvs_amd import _lib
+    return _lib.knn_code_hash_of_binary()
 
 
 def bench_knn(args, world, rank, dev):

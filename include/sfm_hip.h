@@ -38,6 +38,10 @@ extern "C" {
 
 int         sfm_abi_version(void);
 const char* sfm_last_error(void);
+/* What the loaded binary was built from: "knn.hip:<sha256 of csrc/knn.hip's code>" (comments and whitespace do not count;
+ * scripts/knn_code_hash.py), " dev-build" appended when the library honours the SFM_KNN_* tuning variables (release builds
+ * read nothing from the environment).  The parity sweeps and PMC stamps under profiles/ name the same hash. */
+const char* sfm_build_id(void);
 
 /* ------------------------------------------------------------------------
  * A2  cv2.BFMatcher().knnMatch(des0, des1, k=2)           sfm.py:259-260

@@ -273,10 +273,15 @@ worst, scale = ops.knn_mfma_selftest_result()
 sha = hashlib.sha256(open(os.path.join(ROOT, "sfm_mvs_amd", "csrc", "knn.hip"), "rb").read()).hexdigest()
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
 from knn_code_hash import knn_code_hash                  # comments / whitespace removed: a documentation-only edit keeps the logs valid
+from sfm_mvs_amd import _lib as _sfm_lib
+if _sfm_lib.knn_code_hash_of_binary() != knn_code_hash():      # the sweep ran on the LOADED binary: its id is what the log must name
+    print(f"fuzz: the loaded library ({_sfm_lib.build_id()}) was not built from this csrc/knn.hip ({knn_code_hash()}): rebuild first")
+    sys.exit(2)
 print(f"fuzz: {cases} cases ({batched} of them batches of 2..8 pairs), {fails} mismatches, seed {seed}, {time.time() - t_start:.0f} s")
 print(f"  filter arithmetic modes that ran {dict(sorted(modes.items()))}; variants {per_variant}; rescanned queries in total {rescans}")
 print(f"  families {per_kind}")
 print(f"  runtime MFMA self-test on this device: worst E = {worst:.2f} units, chain scale {scale}")
 print(f"knn_hip_sha256 {sha}")
-print(f"knn_hip_code_sha256 {knn_code_hash()}")
+print(f"knn_hip_code_sha256 {_sfm_lib.knn_code_hash_of_binary()}")
+print(f"sfm_build_id {_sfm_lib.build_id()}")
 sys.exit(1 if fails else 0)

@@ -55,6 +55,7 @@ for k, v in agg.items():
                "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE doubled per MI355X_MICROARCH.md gfx950 correction; workload 10k x 10k",
                "source": f"profiles/{tag}_knn_i8_pmc.md" if variant == "i8" else f"profiles/{tag}_knn_f16_pmc.md" if variant == "f16" else f"profiles/{tag}_knn_pmc.md",
                "knn_hip_sha256": hashlib.sha256(open(os.path.join(root, "sfm_mvs_amd", "csrc", "knn.hip"), "rb").read()).hexdigest(),
-               "knn_hip_code_sha256": __import__("knn_code_hash").knn_code_hash()}
+               "knn_hip_code_sha256": __import__("knn_code_hash").knn_code_hash()}      # (collect_profiles.sh runs on the box the tree's own build travelled to;
+        #  bench.py reports the stamp only while the LOADED binary's sfm_build_id() names the same hash)
         json.dump(out, open(os.path.join(d, "..", "knn_i8_traffic.json" if variant == "i8" else "knn_f16_traffic.json" if variant == "f16" else "knn_traffic.json"), "w"), indent=1)
         break

@@ -14,7 +14,8 @@ import os
 import torch  # noqa: F401  (loads the ROCm runtime torch was built with before our .so binds to it)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("SFM_HIP_LIB") or os.path.join(_HERE, "lib", "libsfmhip.so")   # (the override is a dev switch for A/B runs of two builds)
+LIB_PATH = os.environ.get("SFM_HIP_LIB") or os.path.join(_HERE, "lib", "libsfmhip.so")   # (the override is a dev switch for A/B runs of two builds:
+#                                                                                          whichever binary is loaded names itself — build_id())
 
 ABI_VERSION = 2
 
@@ -31,6 +32,7 @@ _i64, _i32, _int, _f32, _f64, _sz, _vp = (_c.c_int64, _c.c_int32, _c.c_int, _c.c
 SIGNATURES = {
     "sfm_abi_version": (_int, []),
     "sfm_last_error": (_c.c_char_p, []),
+    "sfm_build_id": (_c.c_char_p, []),
     "sfm_knn2_l2_f32_ws_bytes": (_sz, [_i64, _i64, _int, _int]),
     "sfm_knn2_l2_f32": (_int, [_vp, _i64, _i64, _vp, _i64, _i64, _int, _int, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sfm_ratio_compact_ws_bytes": (_sz, [_i64]),
@@ -115,6 +117,17 @@ def lib():
         raise ImportError(f"libsfmhip.so ABI {got} != binding ABI {ABI_VERSION}; rebuild")
     _lib = handle
     return _lib
+
+
+def build_id():
+    """sfm_build_id() of the LOADED binary: 'knn.hip:<code sha256>' (+ ' dev-build')."""
+    return lib().sfm_build_id().decode()
+
+
+def knn_code_hash_of_binary():
+    """The sha256 of csrc/knn.hip's code the loaded library was compiled from (what profiles/*fuzz*.log and the traffic stamps
+    must name)."""
+    return build_id().split(":", 1)[1].split()[0]
 
 
 def check(rc, what):

@@ -149,9 +149,16 @@ __host__ __device__ inline int64_t part_begin(const Partition& pt, int b) {
     return x < pt.units ? x : pt.units;
 }
 constexpr int kSegCostTiles = 5;
-int g_seg_cost = [] { const char* e = getenv("SFM_KNN_SEGCOST"); return e ? atoi(e) : kSegCostTiles; }();   // dev override
-int g_q8 = [] { const char* e = getenv("SFM_KNN_Q8"); return e ? atoi(e) : 1; }();   // dev override: 0 = kFilterAuto never quantises (= kFilterNoQuant)
-int g_seg_cost_q4 = [] { const char* e = getenv("SFM_KNN_SEGCOST_Q4"); return e ? atoi(e) : 5; }();              // q4 kernel: a segment's prologue in tile-steps
+// Tuning switches read from the environment exist in DEV builds only (make CXXFLAGS+=-DSFM_DEV_BUILD, scripts/dev/): a release
+// library takes no override — what the parity sweeps ran on is what ships (sfm_build_id() names it).
+#ifdef SFM_DEV_BUILD
+int dev_env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#else
+constexpr int dev_env_int(const char*, int dflt) { return dflt; }
+#endif
+const int g_seg_cost = dev_env_int("SFM_KNN_SEGCOST", kSegCostTiles);
+const int g_q8 = dev_env_int("SFM_KNN_Q8", 1);                  // 0 = kFilterAuto never quantises (= kFilterNoQuant)
+const int g_seg_cost_q4 = dev_env_int("SFM_KNN_SEGCOST_Q4", 5); // q4 kernel: a segment's prologue in tile-steps
 
 // One workgroup fills the partition tables the filter / refine kernels read: begin[G+1], and per query row block the
 // first and last block that touches it.
@@ -233,7 +240,7 @@ Plan make_plan(int64_t nq, int64_t nt, int B, int filter) {
 Plan make_plan_uncached(int64_t nq, int64_t nt, int B, int filter) {
     Plan p;
     p.B = B;
-    static const int env_w = [] { const char* e = getenv("SFM_KNN_WAVES"); return e ? atoi(e) : 0; }();   // dev override
+    static const int env_w = dev_env_int("SFM_KNN_WAVES", 0);
     p.waves = (env_w == 4 || env_w == 8 || env_w == 16) ? env_w : 8;
     p.split = filter == kFilterF32 ? 0 : 1;
     p.q4 = (filter == kFilterLds || filter == kFilterLdsSplit || filter == kFilterF32) ? 0 : 1;
@@ -252,7 +259,7 @@ Plan make_plan_uncached(int64_t nq, int64_t nt, int B, int filter) {
     if (p.i8) p.nq_pad = (int)((nq + 1023) / 1024) * 1024;      // (the query images serve the i8 body's 1024-query row blocks too)
     p.tiles = (int)((nt + kTileT - 1) / kTileT);
     p.units = (int64_t)p.n_rb * p.tiles;
-    static const int env_res = [] { const char* e = getenv("SFM_KNN_RESIDENT"); return e ? atoi(e) : 0; }();   // dev override
+    static const int env_res = dev_env_int("SFM_KNN_RESIDENT", 0);
     int64_t g = (env_res > 0 ? env_res : kResidentWaves / p.qg) / p.waves;
     if (i8plan) g = 256;                       // (one workgroup per CU, as the q4 bodies: they are bodies of one kernel)
     if (g > p.units) g = p.units;
@@ -626,7 +633,8 @@ __device__ __forceinline__ int knn_filter_mode(const int* __restrict__ flags, co
 constexpr int kMinfoPairMode = 0, kMinfoBatchMode = kMaxBatch, kMinfoTmax = 16, kMinfoTerr = 24, kMinfoQmax = 32, kMinfoBase = 40, kMinfoI8 = 48,
               kMinfoQ8 = 49,      // 1: the integer body runs on QUANTISED data (some pair of the batch is float data): refine_q8_body certifies
               kMinfoSub8 = 50,    // tiles per substream of the integer body for this launch set (written by the prep launch's partition workgroup)
-              kMinfoBar = 51,     // arrival counter of the repair's grid barrier in knn_split_images_kernel (zeroed by the prep launch)
+              kMinfoTicket = 51,  // knn_split_images_kernel's repair: arrival ticket — the workgroup that draws the LAST one reduces the rewritten words
+                                  // (zeroed by the prep launch)
               kMinfoQ8S = 56, kMinfoQ8Lo = 64,   // per pair: the quantisation grid x ~ lo + s k, k = 0 .. 255 (float bits; written by the prep launch)
               kMinfoWords = 72;   // written by knn_split_images_kernel (block 0); kMinfoI8: 1 = the exact-integer body runs, kMinfoBase: its per-pair score offset
 __device__ __forceinline__ int knn_batch_mode(const int* __restrict__ flags, const float* __restrict__ bmax, int n_pairs, int lane) {
@@ -844,7 +852,7 @@ __global__ __launch_bounds__(kPrepThreads) void knn_prep_kernel(BatchPtrs P, int
                 if (q8)
                     for (int b = 0; b < (int)gridDim.y; ++b)
                         if (q8_sample_grid(P.q[b], ldq, nq, P.t[b], ldt, nt, q8red).kind == 1) sub8 = kQ8SubTiles;
-                if (threadIdx.x == 0) { minfo[kMinfoSub8] = sub8; minfo[kMinfoBar] = 0; }
+                if (threadIdx.x == 0) { minfo[kMinfoSub8] = sub8; minfo[kMinfoTicket] = 0; }
                 fill_partition_tables(make_partition(units8, tiles, G8, seg_cost), n_rb8, wg_begin8, rb_first8, rb_last8, wg_sbase8, sub8);
             }
         }
@@ -1107,7 +1115,7 @@ __global__ __launch_bounds__(kSplitThreads) void knn_split_images_kernel(BatchPt
     // 8-10 us of dependent loads at the head of the filter launch), workgroup 0 leaves the result — per pair the mode,
     // ||t||max and the largest fp16 residual, and the batch's mode — in `minfo` for the filter and refine kernels.
     __shared__ int smode[kMaxBatch], s8ok[kMaxBatch], s8base[kMaxBatch], s8some[kMaxBatch], sq8[kMaxBatch];
-    auto reduce_modes = [&]() {
+    auto reduce_modes = [&](bool leave /*this workgroup leaves the per-pair results in minfo*/) {
         const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
         static_assert(kSplitThreads / 64 >= kMaxBatch, "one wave per pair");
         if (wave < B) {
@@ -1156,7 +1164,7 @@ __global__ __launch_bounds__(kSplitThreads) void knn_split_images_kernel(BatchPt
             }
             if (lane == 0) {
                 smode[wave] = m;
-                if (blockIdx.x == 0) {
+                if (leave) {
                     minfo[kMinfoPairMode + wave] = m;
                     minfo[kMinfoTmax + wave] = __float_as_int(tmax);
                     minfo[kMinfoTerr + wave] = __float_as_int(te);
@@ -1166,11 +1174,11 @@ __global__ __launch_bounds__(kSplitThreads) void knn_split_images_kernel(BatchPt
         }
         __syncthreads();
     };
-    reduce_modes();
+    reduce_modes(blockIdx.x == 0);
     // The exact-integer body runs iff EVERY pair of the batch qualifies (one launch, one body).
     bool i8 = ti8 != nullptr;
     for (int b = 0; b < B && i8; ++b) i8 = s8ok[b] != 0;
-    bool q8any = false;
+    bool q8any = false, repaired = false;
     for (int b = 0; b < B && ti8; ++b) q8any = q8any || sq8[b] != 0;
     __shared__ int sq8r[kMaxBatch];                                    // pairs repaired below (their byte image must not be read back as values)
     if (threadIdx.x < kMaxBatch) sq8r[threadIdx.x] = (ti8 && q8any && !i8 && threadIdx.x < B) ? sq8[threadIdx.x] : 0;
@@ -1180,8 +1188,7 @@ __global__ __launch_bounds__(kSplitThreads) void knn_split_images_kernel(BatchPt
         // grid did not fit, the init product's range is exceeded, or another pair of the batch is not integer-body material.
         // Those pairs get their fp16 image, residuals and flags now, from the original floats.  Rows are dealt exactly as in the
         // prep launch (workgroup x of kNormBlocks, sixteen lanes per row), so workgroup x simply REWRITES the pair's per-block
-        // words x; then a grid-wide barrier (kNormBlocks workgroups of 8 waves: always co-resident) and the reduction again.
-        // Rare by construction (the sample rule), so it only has to be right.
+        // words x.  Rare by construction (the sample rule), so it only has to be right.
         __shared__ int rfl[kSplitThreads / 64];
         __shared__ float rme[kSplitThreads / 64];
         const int c = threadIdx.x & 15, rows = nq_pad + nt_pad;
@@ -1228,28 +1235,41 @@ __global__ __launch_bounds__(kSplitThreads) void knn_split_images_kernel(BatchPt
                 bmaxerr[pb * kNormBlocks + blockIdx.x] = me;
             }
         }
+        // No grid-wide barrier (round 4 had a spin barrier here: it assumed every workgroup of this launch co-resident — false beside
+        // other launch sets' kernels or on a partitioned device — and trapped on time-out).  "Last one out": every workgroup
+        // publishes its words (release fence) and draws a ticket; the one that draws the LAST ticket sees them all (acquire
+        // fence) and reduces the modes again, alone.  Nobody waits for anybody, so the others cannot know the outcome: they do below
+        // whatever ANY outcome could need — the u8 chunks' fp16 image and the bf16 planes of every pair — and leave `minfo` alone.
+        __shared__ int last_s;
         __syncthreads();
         if (threadIdx.x == 0) {
-            __threadfence();
-            atomicAdd(&minfo[kMinfoBar], 1);
-            long long spins = 0;
-            while (__hip_atomic_load(&minfo[kMinfoBar], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (int)gridDim.x) {
-                __builtin_amdgcn_s_sleep(16);
-                if (++spins > (1ll << 24)) __builtin_trap();             // (never: fail loudly rather than continue on half-repaired images)
-            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (the flag must not overtake the write-back: MI355X_MICROARCH.md, compiler hazard)
+            last_s = atomicAdd(&minfo[kMinfoTicket], 1) == (int)gridDim.x - 1 ? 1 : 0;
         }
         __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");               // the other workgroups' words, not this CU's cached copies
-        reduce_modes();
+        repaired = true;
         i8 = false;
         q8any = false;
+        if (last_s) {                                                    // (uniform)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");           // the other workgroups' words, not this CU's cached copies
+            reduce_modes(true);
+            if (threadIdx.x == 0) {
+                int m = kModeHalfExact;
+                for (int b = 0; b < B; ++b) m = max(m, smode[b]);
+                minfo[kMinfoBatchMode] = m;
+                minfo[kMinfoI8] = 0;
+                minfo[kMinfoQ8] = 0;
+            }
+        }
     }
     int mode = kModeHalfExact;
     for (int b = 0; b < B; ++b) mode = max(mode, smode[b]);
-    if (blockIdx.x == 0 && threadIdx.x == 0) minfo[kMinfoBatchMode] = mode;
+    // (repaired: workgroup 0's view of the modes is the one from BEFORE the repair — the last workgroup out has written them)
+    if (!repaired && blockIdx.x == 0 && threadIdx.x == 0) minfo[kMinfoBatchMode] = mode;
     // The integer body's init fragments (frag_init_i8: the digits of floor(w_t / 2) - base) need the pair's base, so they are
     // written here, not by the prep pass.
-    if (blockIdx.x == 0 && threadIdx.x < kMaxBatch + 1) {
+    if (!repaired && blockIdx.x == 0 && threadIdx.x < kMaxBatch + 1) {
         if (threadIdx.x == kMaxBatch) { minfo[kMinfoI8] = i8 ? 1 : 0; minfo[kMinfoQ8] = (i8 && q8any) ? 1 : 0; }
         else if (threadIdx.x < B && ti8) minfo[kMinfoBase + threadIdx.x] = s8base[threadIdx.x];
     }
@@ -1298,7 +1318,7 @@ __global__ __launch_bounds__(kSplitThreads) void knn_split_images_kernel(BatchPt
         }
     }
     if (force_mode >= 0) mode = force_mode;
-    if (mode != kModeSplit) return;
+    if (mode != kModeSplit && !repaired) return;                 // (repaired: the mode is not known yet — see above)
     const bool frag = qhm0 != nullptr;
     const int l = threadIdx.x & 31;
     const int rows = nq_pad + nt_pad;
@@ -4037,7 +4057,10 @@ static float mfma_chain_scale() {
     }
     ChainCal& c = g_chain_cal[dev];
     std::call_once(c.once, [&] {
-        const char* skip = getenv("SFM_KNN_ASSUME_E");           // dev/test: pretend the self-test measured this E
+        // test hook (tests/test_gpu_knn.py): pretend the self-test measured this E.  Honoured only for E >= 8, i.e. only where it
+        // WIDENS the certificate's slack — no setting of the environment can make a release library less conservative.
+        const char* skip = getenv("SFM_KNN_ASSUME_E");
+        if (skip && !(atof(skip) >= 8.0)) skip = nullptr;
         double worst = skip ? atof(skip) : 0.0;
         if (!skip) {
             void* ws = nullptr;
@@ -4071,6 +4094,20 @@ extern "C" int sfm_knn_mfma_selftest_result(double* worst_units, float* chain_sc
     if (worst_units) *worst_units = g_chain_cal[dev].worst;
     if (chain_scale) *chain_scale = s;
     return SFM_OK;
+}
+
+// What this BINARY was built from: the sha256 of csrc/knn.hip's code (scripts/knn_code_hash.py: comments and whitespace do not
+// count), handed in by the Makefile.  The committed fuzz logs and PMC traffic stamps name the same hash; tests/test_gpu_knn.py
+// and bench.py compare them with the LOADED library's id, not with the source tree beside it.
+#ifndef SFM_KNN_CODE_HASH
+#define SFM_KNN_CODE_HASH "unknown"
+#endif
+extern "C" const char* sfm_build_id(void) {
+#ifdef SFM_DEV_BUILD
+    return "knn.hip:" SFM_KNN_CODE_HASH " dev-build";
+#else
+    return "knn.hip:" SFM_KNN_CODE_HASH;
+#endif
 }
 
 extern "C" int sfm_debug_set_trace(void* dev_buf) {
@@ -4136,7 +4173,7 @@ int knn_batch_impl(int B, const BatchPtrs& P, int64_t nq, int64_t ldq, int64_t n
 
     const dim3 grid((unsigned)p.G);
     const int prof_reps = p.split ? sfm::prof_repeat() : 1;
-    static const int abl = [] { const char* e = getenv("SFM_KNN_ABL"); return e ? atoi(e) : 0; }();   // dev only
+    static const int abl = dev_env_int("SFM_KNN_ABL", 0);       // timing ablations (WRONG results): dev builds only
     if (p.split) {
         hipLaunchKernelGGL(knn_prep_kernel, dim3(kNormBlocks + 2, (unsigned)B), dim3(kPrepThreads), 0, stream, P, ldq, (int)nq, p.nq_pad, ldt, (int)nt,
                            p.tiles * kTileT, w.qsplit, w.qn, w.tsplit, w.tn, w.bmax, w.midflag, w.qerr, w.bmaxerr, w.bqmax, w.s_qsplit, w.s_tsplit, w.s_qn, w.s_tn,

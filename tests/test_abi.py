@@ -2,6 +2,7 @@
 include/sfm_hip.h declares, and refuses to run on host memory (no CPU fallback)."""
 import ctypes
 import os
+import sys
 import re
 
 import numpy as np
@@ -57,6 +58,22 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert rc == -1 and b"dim must be 128" in L.sfm_last_error()
     rc = L.sfm_triangulate_dlt(None, None, None, None, 4, 1, 4, 5, 0, None, None)
     assert rc == -1 and b"rows must be 4 or 6" in L.sfm_last_error()
+
+
+def test_build_id_names_the_source_and_release_library_reads_no_tuning_overrides():
+    """sfm_build_id() = the hash of the csrc/knn.hip code the binary was compiled from (what the fuzz logs and traffic stamps
+    under profiles/ name); a release build carries none of the SFM_KNN_* / SFM_TRI_* tuning switches (dev builds only)."""
+    import re
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    from knn_code_hash import knn_code_hash
+    from sfm_mvs_amd import _lib
+    bid = _lib.build_id()
+    assert bid == "knn.hip:" + knn_code_hash(), f"{bid}: stale or dev build of libsfmhip.so"
+    text = subprocess.run(["strings", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    envs = set(re.findall(r"^SFM_[A-Z0-9_]+$", text, re.M))
+    # SFM_KNN_ASSUME_E: honoured only where it widens the certificate (E >= 8); SFM_PNP_PROF: prints host timings at exit
+    assert envs <= {"SFM_KNN_ASSUME_E", "SFM_PNP_PROF"}, f"environment switches in the release library: {sorted(envs)}"
 
 
 def test_cpu_tensors_are_rejected_loudly():

@@ -387,23 +387,30 @@ def test_runtime_selftest_gates_the_certificate(hip, oracle):
 
 
 @pytest.mark.gpu
-def test_committed_fuzz_logs_are_those_of_this_kernel_source():
+def test_committed_fuzz_logs_are_those_of_the_loaded_binary():
     """The long randomised parity sweeps (scripts/fuzz_knn.py: >= 20 000 cases per round incl. the margin-aimed families)
     are committed under profiles/ with the sha256 of the CODE of csrc/knn.hip they ran on (comments and whitespace removed,
-    scripts/knn_code_hash.py: a documentation-only edit keeps them valid).  A log of another source proves nothing about this
-    binary: the sweep has to be re-run after the last edit of the kernel's code."""
+    scripts/knn_code_hash.py: a documentation-only edit keeps them valid).  The hash is compared with the id of the LOADED
+    library (sfm_build_id(): baked in at build time) — the binary the box runs travels un-tracked, so a check against the source
+    tree beside it would prove nothing about it — and the binary's id with the source tree, so that a stale build fails here
+    rather than passing on yesterday's kernels.  A release build is required: a dev build reads tuning overrides from the
+    environment."""
     import glob, os, re, sys
+    from sfm_mvs_amd import _lib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "scripts"))
     from knn_code_hash import knn_code_hash
-    sha = knn_code_hash()
-    logs = sorted(glob.glob(os.path.join(root, "profiles", "r04_fuzz_knn_*.log")))
-    assert logs, "no profiles/r04_fuzz_knn_*.log"
+    bid = _lib.build_id()
+    assert "dev-build" not in bid, f"the loaded library is a dev build ({bid})"
+    sha = _lib.knn_code_hash_of_binary()
+    assert sha == knn_code_hash(), f"libsfmhip.so was built from another csrc/knn.hip ({bid}): rebuild (make -C sfm_mvs_amd/csrc)"
+    logs = sorted(glob.glob(os.path.join(root, "profiles", "r05_fuzz_knn_*.log")))
+    assert logs, "no profiles/r05_fuzz_knn_*.log"
     total = 0
     for path in logs:
         text = open(path).read()
         m = re.search(r"fuzz: (\d+) cases .*?, (\d+) mismatches", text)
         assert m and int(m.group(2)) == 0, f"{path}: no clean summary line"
-        assert f"knn_hip_code_sha256 {sha}" in text, f"{path} was produced by another csrc/knn.hip (stale): re-run scripts/fuzz_knn.py"
+        assert f"knn_hip_code_sha256 {sha}" in text, f"{path} was produced by another csrc/knn.hip than the loaded binary's (stale): re-run scripts/fuzz_knn.py"
         total += int(m.group(1))
-    assert total >= 20000, f"only {total} fuzz cases on this source"
+    assert total >= 20000, f"only {total} fuzz cases on this binary's source"

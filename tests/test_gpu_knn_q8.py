@@ -185,3 +185,30 @@ def test_config5_shape_quantised_equals_noquant(hip):
     assert res["auto"][4] == res["noquant"][4] and res["auto"][4] > 5000
     assert torch.equal(res["auto"][2], res["noquant"][2]) and torch.equal(res["auto"][3], res["noquant"][3])
     assert res["auto"][5][0] < 50000 // 20, f"{res['auto'][5][0]} rescanned queries"
+
+
+def test_repair_path_with_three_launch_sets_in_flight(hip, oracle):
+    """ADVICE r04 / VERDICT r04 item 7: the repair of pairs that were quantised in vain ran behind a hand-rolled spin grid barrier
+    that assumed all 256 workgroups of the launch co-resident — false with several launch sets in flight, and a time-out trapped.
+    It is now "last workgroup out reduces" (no waiting).  Here: batches that NEED the repair (uniform pairs beside a Gaussian one)
+    alternate with plain quantised batches on a three-deep pipeline, 60 launch sets back to back; every result is the oracle's."""
+    rng = np.random.default_rng(77)
+    nq, nt = 2100, 4300
+    def uni(): return rng.random((nq, 128), dtype=np.float32), rng.random((nt, 128), dtype=np.float32)
+    def gau(): return rng.standard_normal((nq, 128)).astype(np.float32), rng.standard_normal((nt, 128)).astype(np.float32)
+    sets = [[uni(), gau(), uni(), uni()], [uni(), uni(), uni(), uni()], [gau(), uni(), uni(), uni()]]
+    want = [[oracle.knn2(q, t, nthreads=8) for q, t in s] for s in sets]
+    dev_sets = [[(torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda()) for q, t in s] for s in sets]
+    pipe = hip.BatchPipeline(nq, nt, "cuda", ratio=0.70, depth=3, batch=4)
+    for rnd in range(20):
+        for s in dev_sets:
+            for q, t in s:
+                pipe.submit(q, t, after=False)
+    pipe.flush()
+    pipe.synchronize()
+    # what the three matchers hold now: the last launch set each ran (set index = matcher index: 60 sets over 3 matchers in order)
+    for k, bm in enumerate(pipe.matchers):
+        assert int(bm.stats[0, 3].item()) == (5 if k == 1 else 1), (k, bm.stats[0].tolist())
+        for b in range(4):
+            wi, wd = want[k][b]
+            assert np.array_equal(bm.idx[b].cpu().numpy(), wi) and np.array_equal(bm.dist[b].cpu().numpy().view(np.uint32), wd.view(np.uint32)), (k, b)
