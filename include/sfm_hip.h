@@ -535,6 +535,14 @@ int sfm_profile_enable(int on);
  * int64[16] phase ticks at dev_buf[16384 + 16*w..]; NULL disables. */
 int sfm_debug_set_trace(void* dev_buf);
 int sfm_profile_read(int slot, double* total_ms_host, int64_t* launches_host);
+/* How often library calls of this process have WAITED for the device so far (cumulative; the RANSAC entry points read the
+ * hypothesis scores back chunk by chunk, the Schur solver its convergence scalars).  Diagnostics: bench.py reports the
+ * difference over a 57-camera run per registered camera. */
+int64_t sfm_host_sync_count(void);
+/* Where sfm_solve_pnp_ransac's host time went since the last reset (microseconds, accumulated over calls): out10[0] calls,
+ * [1..7] copy-in, EPnP hypotheses (host), scoring + wait, mask / inlier bookkeeping, DLT initialisation, LM sweeps (device +
+ * wait), LM host algebra; [8] hypothesis chunks, [9] LM sweeps.  reset != 0 clears the accumulators. */
+int sfm_pnp_profile_read(double* out10_host, int reset);
 
 #ifdef __cplusplus
 }

@@ -90,6 +90,8 @@ SIGNATURES = {
     "sfm_recover_pose_score": (_int, [_vp, _int, _vp, _vp, _i64, _f64, _int, _vp, _vp, _vp]),
     "sfm_score_pnp": (_int, [_vp, _int, _vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp]),
     "sfm_profile_enable": (_int, [_int]),
+    "sfm_host_sync_count": (_i64, []),
+    "sfm_pnp_profile_read": (_int, [_c.POINTER(_f64), _int]),
     "sfm_debug_set_trace": (_int, [_vp]),
     "sfm_profile_read": (_int, [_int, _c.POINTER(_f64), _c.POINTER(_i64)]),
 }

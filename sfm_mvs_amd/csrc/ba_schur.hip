@@ -708,7 +708,7 @@ extern "C" int sfm_ba_schur_solve(const double* cams, int64_t ncam, const double
         if (it % 5 == 0) {
             double h[kScalWords];
             SFM_CHECK_HIP(hipMemcpyAsync(h, w.scal, sizeof(h), hipMemcpyDeviceToHost, stream));
-            SFM_CHECK_HIP(hipStreamSynchronize(stream));
+            SFM_CHECK_HIP(sfm::stream_sync(stream));
             if (h[kScalRr] <= h[kScalStop2]) break;
         }
         sfm::prof_begin(sfm::kProfBaSchur, stream);
@@ -727,7 +727,7 @@ extern "C" int sfm_ba_schur_solve(const double* cams, int64_t ncam, const double
     SFM_CHECK_LAUNCH();
     int st[4] = {0, 0, 0, 0};
     SFM_CHECK_HIP(hipMemcpyAsync(st, w.status, sizeof(st), hipMemcpyDeviceToHost, stream));
-    SFM_CHECK_HIP(hipStreamSynchronize(stream));
+    SFM_CHECK_HIP(sfm::stream_sync(stream));
     if (iters_host) *iters_host = it;
     if (status_host) *status_host = st[0];
     return SFM_OK;

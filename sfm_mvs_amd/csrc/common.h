@@ -20,6 +20,12 @@ int prof_repeat();   // launches per event pair requested with sfm_profile_enabl
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Every point at which a library call WAITS for the device (the RANSAC entry points read hypothesis scores back chunk by chunk,
+// the Schur solver its convergence scalars) goes through this: sfm_host_sync_count() is what bench.py divides by the cameras
+// registered to state "host synchronisations per frame" (VERDICT r04 item 5).
+void note_host_sync();
+inline hipError_t stream_sync(hipStream_t s) { note_host_sync(); return hipStreamSynchronize(s); }
+
 // Camera chunks of the dense BA kernels (grid = point tiles x chunks, a workgroup walks ncam / chunks cameras for its tile
 // of points): the launch takes ceil(tiles * chunks / slots) rounds of ceil(ncam / chunks) cameras each, `slots` = the
 // workgroups the chip holds at once for that kernel (256 CUs x its occupancy).  Round 2 aimed at ">= 1024 workgroups" and

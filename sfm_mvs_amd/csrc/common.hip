@@ -3,9 +3,13 @@
 #include <cstring>
 #include <mutex>
 #include <utility>
+#include <atomic>
 #include <vector>
 
 namespace sfm {
+static std::atomic<long long> g_host_syncs{0};
+void note_host_sync() { g_host_syncs.fetch_add(1, std::memory_order_relaxed); }
+
 static thread_local char g_err[512] = "";
 
 void set_error(const char* fmt, ...) {
@@ -80,5 +84,6 @@ extern "C" int sfm_profile_read(int slot, double* total_ms, int64_t* launches) {
     return SFM_OK;
 }
 
+extern "C" int64_t sfm_host_sync_count(void) { return (int64_t)sfm::g_host_syncs.load(std::memory_order_relaxed); }
 extern "C" int sfm_abi_version(void) { return SFM_ABI_VERSION; }
 extern "C" const char* sfm_last_error(void) { return sfm::g_err; }

@@ -4026,7 +4026,7 @@ extern "C" int sfm_selftest_mfma_accumulation(int use_bf16, int trials_per_wave,
         else hipLaunchKernelGGL(mfma_selftest_kernel<0>, dim3(kBlocks), dim3(256), 0, stream, regs[r], trials_per_wave, 17u + 4096u * r, d);
         SFM_CHECK_LAUNCH();
         SFM_CHECK_HIP(hipMemcpyAsync(host.data(), d, sizeof(double) * host.size(), hipMemcpyDeviceToHost, stream));
-        SFM_CHECK_HIP(hipStreamSynchronize(stream));
+        SFM_CHECK_HIP(sfm::stream_sync(stream));
         double w = 0;
         for (double v : host) w = std::max(w, v);
         regime_max_host[r] = w;

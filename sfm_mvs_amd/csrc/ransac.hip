@@ -300,7 +300,7 @@ extern "C" int sfm_find_essential_mat(const float* pts0_dev, const float* pts1_d
     std::vector<float> h0(2 * (size_t)n), h1(2 * (size_t)n);
     SFM_CHECK_HIP(hipMemcpyAsync(h0.data(), pts0_dev, sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost, stream));
     SFM_CHECK_HIP(hipMemcpyAsync(h1.data(), pts1_dev, sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost, stream));
-    SFM_CHECK_HIP(hipStreamSynchronize(stream));
+    SFM_CHECK_HIP(sfm::stream_sync(stream));
     auto sample = [&](const int* idx, double* s0, double* s1) {
         for (int k = 0; k < 5; ++k) {
             s0[2 * k] = (double)h0[2 * idx[k]] * kn.ifx + kn.bx; s0[2 * k + 1] = (double)h0[2 * idx[k] + 1] * kn.ify + kn.by;
@@ -353,7 +353,7 @@ extern "C" int sfm_find_essential_mat(const float* pts0_dev, const float* pts1_d
             const int rc = sfm_score_essential(models_dev, H, x0n, x1n, n, thr2, counts_dev, masks_dev, stream_);
             if (rc != SFM_OK) return rc;
             SFM_CHECK_HIP(hipMemcpyAsync(counts.data(), counts_dev, sizeof(int32_t) * (size_t)H, hipMemcpyDeviceToHost, stream));
-            SFM_CHECK_HIP(hipStreamSynchronize(stream));
+            SFM_CHECK_HIP(sfm::stream_sync(stream));
             bool stop;
             const int bj = replay_chunk(st, it, owner, counts.data(), stop);
             if (bj >= 0) {
@@ -415,7 +415,7 @@ extern "C" int sfm_recover_pose(const double* E, const float* pts0_dev, const fl
         const int rc = sfm_recover_pose_score(Ps, 4, x0n, x1n, n, distance_thresh, rows, counts_dev, masks_dev, stream_);
         if (rc != SFM_OK) return rc;
         SFM_CHECK_HIP(hipMemcpyAsync(g, counts_dev, sizeof(g), hipMemcpyDeviceToHost, stream));
-        SFM_CHECK_HIP(hipStreamSynchronize(stream));
+        SFM_CHECK_HIP(sfm::stream_sync(stream));
     }
     int k;      // OpenCV's cascade of >= tests in candidate order
     if (g[0] >= g[1] && g[0] >= g[2] && g[0] >= g[3]) k = 0;
@@ -485,7 +485,7 @@ extern "C" int sfm_solve_pnp_ransac(const float* X_dev, const float* uv_dev, int
     bool host_mask_valid = false;
     SFM_CHECK_HIP(hipMemcpyAsync(hX, X_dev, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, stream));
     SFM_CHECK_HIP(hipMemcpyAsync(huv, uv_dev, sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost, stream));
-    SFM_CHECK_HIP(hipStreamSynchronize(stream));
+    SFM_CHECK_HIP(sfm::stream_sync(stream));
     lap(0);
     const double ifx = 1. / K[0], ify = 1. / K[4];
     // solvePnP(EPNP) on a sample: undistortPoints writes float32 normalised coordinates (the image points' type) and
@@ -519,7 +519,7 @@ extern "C" int sfm_solve_pnp_ransac(const float* X_dev, const float* uv_dev, int
         std::memcpy(tvec_host, t, 24);
         const int32_t all[4] = {0, 1, 2, 3};
         SFM_CHECK_HIP(hipMemcpyAsync(inliers_dev, all, sizeof(all), hipMemcpyHostToDevice, stream));
-        SFM_CHECK_HIP(hipStreamSynchronize(stream));
+        SFM_CHECK_HIP(sfm::stream_sync(stream));
         info_host[0] = 1;
         info_host[1] = 4;
         return SFM_OK;
@@ -532,7 +532,7 @@ extern "C" int sfm_solve_pnp_ransac(const float* X_dev, const float* uv_dev, int
         std::memcpy(tvec_host, model + 3, 24);
         const int32_t all[5] = {0, 1, 2, 3, 4};
         SFM_CHECK_HIP(hipMemcpyAsync(inliers_dev, all, sizeof(all), hipMemcpyHostToDevice, stream));
-        SFM_CHECK_HIP(hipStreamSynchronize(stream));
+        SFM_CHECK_HIP(sfm::stream_sync(stream));
         info_host[0] = 1;
         info_host[1] = 5;
         return SFM_OK;
@@ -569,7 +569,7 @@ extern "C" int sfm_solve_pnp_ransac(const float* X_dev, const float* uv_dev, int
             SFM_CHECK_HIP(hipMemcpyAsync(hcounts, counts_dev, sizeof(int32_t) * (size_t)H, hipMemcpyDeviceToHost, stream));
             const bool with_masks = ride_along && H <= kSmallMasks;
             if (with_masks) SFM_CHECK_HIP(hipMemcpyAsync(hchunk, masks_dev, (size_t)H * (size_t)n, hipMemcpyDeviceToHost, stream));
-            SFM_CHECK_HIP(hipStreamSynchronize(stream));
+            SFM_CHECK_HIP(sfm::stream_sync(stream));
             bool stop;
             const int bj = replay_chunk(st, it, owner, hcounts, stop);
             if (bj >= 0) {
@@ -587,7 +587,7 @@ extern "C" int sfm_solve_pnp_ransac(const float* X_dev, const float* uv_dev, int
     // inlier list (ascending, as OpenCV pushes them) — the one piece of the mask the host needs
     if (!host_mask_valid) {
         SFM_CHECK_HIP(hipMemcpyAsync(hmask, best_dev, (size_t)n, hipMemcpyDeviceToHost, stream));
-        SFM_CHECK_HIP(hipStreamSynchronize(stream));
+        SFM_CHECK_HIP(sfm::stream_sync(stream));
     }
     std::vector<int32_t> inl;
     inl.reserve((size_t)st.best);
@@ -617,7 +617,7 @@ extern "C" int sfm_solve_pnp_ransac(const float* X_dev, const float* uv_dev, int
         if (blocks > 1)
             hipLaunchKernelGGL(pnp_sweep_fold_kernel, dim3(1), dim3(64), 0, stream, sweep_dev, blocks, sums);
         SFM_CHECK_LAUNCH();
-        SFM_CHECK_HIP(hipStreamSynchronize(stream));
+        SFM_CHECK_HIP(sfm::stream_sync(stream));
         lap(5);
         return SFM_OK;
     };
@@ -734,6 +734,22 @@ extern "C" int sfm_host_rodrigues(const double* src, int src_is_matrix, double* 
     } else {
         double J[27];
         rodrigues_with_jac(src, dst, jac ? jac : J);
+    }
+    return SFM_OK;
+}
+
+// Where sfm_solve_pnp_ransac's HOST time went since the last reset (accumulated over calls, microseconds):
+// out[0] calls, out[1..7] = copy-in, EPnP hypotheses on the host, scoring + wait, mask / inlier bookkeeping, DLT initialisation,
+// Levenberg-Marquardt sweeps (device + wait), Levenberg-Marquardt host algebra; out[8] hypothesis chunks, out[9] LM sweeps.
+extern "C" int sfm_pnp_profile_read(double* out10, int reset) {
+    SFM_CHECK_ARG(out10 != nullptr, "sfm_pnp_profile_read: null pointer");
+    out10[0] = (double)g_pnp_prof.calls;
+    for (int k = 0; k < 7; ++k) out10[1 + k] = g_pnp_prof.t[k];
+    out10[8] = (double)g_pnp_prof.chunks;
+    out10[9] = (double)g_pnp_prof.sweeps;
+    if (reset) {
+        for (double& v : g_pnp_prof.t) v = 0.0;
+        g_pnp_prof.calls = g_pnp_prof.chunks = g_pnp_prof.sweeps = 0;
     }
     return SFM_OK;
 }

@@ -111,14 +111,15 @@ def features_from_images(images, depth=3, on_device=False):
             feats.append((eng.keypoints[:n, :2].cpu().numpy(), eng.descriptors[:n].cpu().numpy()))
 
     for img in images:
-        img = np.ascontiguousarray(img, np.uint8)
+        if not torch.is_tensor(img):
+            img = np.ascontiguousarray(img, np.uint8)
         h, w = img.shape[:2]
         pipe = pipes.get((w, h))
         if pipe is None:
             pipe = pipes[(w, h)] = _sift.SiftPipeline(w, h, dev, depth=depth)
         if len(pending) == depth:
             collect()
-        d = torch.as_tensor(img).to(dev)
+        d = img if torch.is_tensor(img) else torch.as_tensor(img).to(dev)      # (a frame already in HBM — run_sfm_images' downscaled ones — is taken as it is)
         gray = _sift.bgr2gray(d) if d.dim() == 3 else d
         _, st, eng = pipe.submit(gray)
         gray.record_stream(st)
@@ -128,12 +129,146 @@ def features_from_images(images, depth=3, on_device=False):
     return feats
 
 
-def run_sfm_images(images, K, downscale=2, log=None, be=None, bundle_adjustment=False, gtol_thresh=0.5):
+def run_sfm_images(images, K, downscale=2, log=None, be=None, bundle_adjustment=False, gtol_thresh=0.5, profile=None):
     """sfm.py's main loop from pixels: img_downscale (:40), cvtColor + SIFT (:243-252) and the driver (:274-423).
-    `images`: BGR uint8 frames in sequence order; K is scaled by the caller as in sfm.py:20-26."""
-    small = [img_downscale(im, downscale, be) for im in images]
-    return run_sfm(features_from_images(small, on_device=be is None), K, images=small, log=log, be=be,
-                   bundle_adjustment=bundle_adjustment, gtol_thresh=gtol_thresh)
+    `images`: BGR uint8 frames in sequence order; K is scaled by the caller as in sfm.py:20-26.
+    profile: a DriverProfile — the run is then a PROFILED one (the device is drained at every stage boundary)."""
+    import time
+    t_all = t0 = time.perf_counter()
+    if be is None:
+        # HIP path: a frame crosses PCIe once (the full-size upload); the halved frame stays in HBM for cvtColor + SIFT and for
+        # the colour lookup at the end of the run (round 4 downloaded every halved frame and uploaded it again for SIFT)
+        from . import sift as _sift
+        dev = torch.device("cuda")
+        small = []
+        for im in images:
+            d = im.to(dev) if torch.is_tensor(im) else torch.as_tensor(np.ascontiguousarray(im, np.uint8)).to(dev)
+            for _ in range(int(downscale / 2)):
+                d = _sift.pyrdown(d)
+            small.append(d)
+    else:
+        small = [img_downscale(im, downscale, be) for im in images]
+    if profile is not None:
+        torch.cuda.synchronize()
+        profile.add("img_downscale (sfm.py:40: upload + pyrDown)", time.perf_counter() - t0, len(images))
+        t0 = time.perf_counter()
+    feats = features_from_images(small, on_device=be is None)
+    if profile is not None:
+        torch.cuda.synchronize()
+        profile.add("cvtColor + SIFT detectAndCompute (sfm.py:243-252)", time.perf_counter() - t0, len(images))
+    out = run_sfm(feats, K, images=small, log=log, be=be, bundle_adjustment=bundle_adjustment, gtol_thresh=gtol_thresh, profile=profile)
+    if profile is not None:
+        torch.cuda.synchronize()
+        profile.wall = time.perf_counter() - t_all
+    out["features"] = feats
+    return out
+
+
+class DriverProfile:
+    """Where a driver run's wall time goes, stage by stage, and how often the host WAITS for the device.
+
+    A profiled run drains the device at every stage boundary (torch.cuda.synchronize() before and after each engine call), so
+    its stages add up to more than the free-running time: a breakdown, not the pipeline's speed.  `host_syncs` counts, over
+    the driver loop only, the library-side waits (sfm_host_sync_count: the RANSAC entry points read hypothesis scores back
+    chunk by chunk) and the Python-side ones (.item() / .cpu() / .tolist() / .numpy() of a device tensor, synchronize());
+    the drains the profiler itself adds are not counted."""
+
+    def __init__(self):
+        self.seconds, self.calls = {}, {}
+        self.host_syncs_python = self.host_syncs_library = 0
+        self.pnp_host_us = None
+        self.wall = None
+
+    def add(self, stage, dt, n=1):
+        self.seconds[stage] = self.seconds.get(stage, 0.0) + dt
+        self.calls[stage] = self.calls.get(stage, 0) + n
+
+    def report(self, cameras):
+        tot = sum(self.seconds.values())
+        return {"stage_ms": {k: round(v * 1e3, 3) for k, v in sorted(self.seconds.items(), key=lambda kv: -kv[1])},
+                "stage_calls": dict(self.calls), "profiled_total_ms": round(tot * 1e3, 3),
+                "profiled_wall_ms": None if self.wall is None else round(self.wall * 1e3, 3),
+                "between_stages_ms": None if self.wall is None else round((self.wall - tot) * 1e3, 3),
+                "between_stages_note": "Python between the operator calls (pose algebra, state hand-over, the final cloud / colour gather and their downloads) + the profiler's own drains",
+                "host_syncs": {"python_side": self.host_syncs_python, "library_side": self.host_syncs_library,
+                               "per_registered_camera": round((self.host_syncs_python + self.host_syncs_library) / max(cameras, 1), 2)},
+                "solve_pnp_ransac_host_us_per_call": self.pnp_host_us}
+
+
+class _count_python_syncs:
+    """Context manager: counts Tensor.item / .cpu / .tolist / .numpy on DEVICE tensors and the synchronize() calls while active
+    (diagnostics for DriverProfile; the patched methods call straight through)."""
+
+    def __init__(self, prof):
+        self.prof, self.saved = prof, []
+
+    def __enter__(self):
+        prof = self.prof
+
+        def wrap_tensor(name):
+            orig = getattr(torch.Tensor, name)
+
+            def f(t, *a, **k):
+                if t.is_cuda and not prof._muted:
+                    prof.host_syncs_python += 1
+                return orig(t, *a, **k)
+            self.saved.append((torch.Tensor, name, orig))
+            setattr(torch.Tensor, name, f)
+
+        def wrap_fn(obj, name):
+            orig = getattr(obj, name)
+
+            def f(*a, **k):
+                if not prof._muted:
+                    prof.host_syncs_python += 1
+                return orig(*a, **k)
+            self.saved.append((obj, name, orig))
+            setattr(obj, name, f)
+        prof._muted = False
+        for n in ("item", "cpu", "tolist", "numpy"):
+            wrap_tensor(n)
+        wrap_fn(torch.cuda, "synchronize")
+        wrap_fn(torch.cuda.Stream, "synchronize")
+        wrap_fn(torch.cuda.Event, "synchronize")
+        return self
+
+    def __exit__(self, *exc):
+        for obj, name, orig in reversed(self.saved):
+            setattr(obj, name, orig)
+        return False
+
+
+class _ProfiledEngine:
+    """An engine whose operator calls are timed one by one (device drained before and after each)."""
+    _STAGES = {"match": "knnMatch + ratio + gather (sfm.py:259-268)", "essential": "findEssentialMat (sfm.py:307)",
+               "recover_pose": "recoverPose (sfm.py:311)", "triangulate": "triangulatePoints (sfm.py:53-54)",
+               "error": "ReprojectionError (sfm.py:79-100)", "pnp": "solvePnPRansac + inlier gathers (sfm.py:67-76)",
+               "associate": "common_points (sfm.py:215-239)", "take": "row gathers", "errors": "error download"}
+
+    def __init__(self, eng, prof):
+        self._eng, self._prof = eng, prof
+
+    def __getattr__(self, name):
+        attr = getattr(self._eng, name)
+        stage = self._STAGES.get(name)
+        if stage is None or not callable(attr):
+            return attr
+        prof = self._prof
+
+        def timed(*a, **k):
+            import time
+            prof._muted = True
+            torch.cuda.synchronize()
+            prof._muted = False
+            t0 = time.perf_counter()
+            r = attr(*a, **k)
+            prof._muted = True
+            torch.cuda.synchronize()
+            prof._muted = False
+            prof.add(stage, time.perf_counter() - t0)
+            return r
+        return timed
+
 
 def Triangulation(P1, P2, pts1, pts2, K, repeat, be=None):
     """sfm.py:45-56."""
@@ -530,7 +665,7 @@ def register_next(eng, state, i, bundle_adjustment=False, gtol_thresh=0.5):
     return FrameState(state.P2.copy(), P.copy(), pts_, pts2), out
 
 
-def run_sfm(features, K, images=None, log=None, be=None, device_resident=None, bundle_adjustment=False, gtol_thresh=0.5):
+def run_sfm(features, K, images=None, log=None, be=None, device_resident=None, bundle_adjustment=False, gtol_thresh=0.5, profile=None):
     """The reference's driver, sfm.py:274-423; `bundle_adjustment` / `gtol_thresh` are its globals of sfm.py:33,337 (default:
     no bundle adjustment, as shipped).
     features: list of (kp (n,2) float32, des (n,128) float32) per image, in sequence order.
@@ -538,7 +673,42 @@ def run_sfm(features, K, images=None, log=None, be=None, device_resident=None, b
     Returns dict(posearr (9+12*n_cam,), Xtot (m,3), colorstot (m,3), errors [per-frame], first_error).
     On the HIP back-end (be=None) the per-frame state stays in HBM (`_HipEngine`); device_resident=False, or a substituted
     backend (the tests' CPU twin), runs the same driver over NumPy arrays (`_ArrayEngine`): same operators, same results."""
+    if profile is not None:
+        return _run_sfm_profiled(features, K, images, log, be, device_resident, bundle_adjustment, gtol_thresh, profile)
     eng = make_engine(features, K, be, device_resident)
+    return _drive(eng, features, images, log, bundle_adjustment, gtol_thresh)
+
+
+def _run_sfm_profiled(features, K, images, log, be, device_resident, bundle_adjustment, gtol_thresh, profile):
+    """run_sfm with every engine call timed (DriverProfile) and the host's waits for the device counted."""
+    import ctypes
+    import time
+    from . import _lib
+    L = _lib.lib()
+    buf = (ctypes.c_double * 10)()
+    L.sfm_pnp_profile_read(buf, 1)
+    lib0 = int(L.sfm_host_sync_count())
+    with _count_python_syncs(profile):
+        profile._muted = True
+        torch.cuda.synchronize()
+        profile._muted = False
+        t0 = time.perf_counter()
+        eng = make_engine(features, K, be, device_resident)
+        profile._muted = True
+        torch.cuda.synchronize()
+        profile._muted = False
+        profile.add("engine set-up: uploads + the up-front batched knnMatch of equally shaped pairs", time.perf_counter() - t0)
+        out = _drive(_ProfiledEngine(eng, profile), features, images, log, bundle_adjustment, gtol_thresh)
+    profile.host_syncs_library = int(L.sfm_host_sync_count()) - lib0
+    L.sfm_pnp_profile_read(buf, 0)
+    calls = max(buf[0], 1.0)
+    names = ("copy_in", "epnp_hypotheses_host", "device_scoring_and_wait", "mask_and_inlier_bookkeeping", "dlt_init_host", "lm_sweeps_device_and_wait", "lm_algebra_host")
+    profile.pnp_host_us = {"calls": int(buf[0]), **{n: round(buf[1 + i] / calls, 2) for i, n in enumerate(names)},
+                           "hypothesis_chunks_per_call": round(buf[8] / calls, 2), "lm_sweeps_per_call": round(buf[9] / calls, 2)}
+    return out
+
+
+def _drive(eng, features, images, log, bundle_adjustment, gtol_thresh):
     say = log or (lambda *a: None)
     state, first = bootstrap_pair(eng)
     poses = [eng.K.ravel(), state.P1.ravel(), state.P2.ravel()]
@@ -554,9 +724,18 @@ def run_sfm(features, K, images=None, log=None, be=None, device_resident=None, b
     errs = eng.errors(handles)
     Xtot = np.vstack([np.zeros((1, 3))] + [eng.host(c) for c in clouds])             # quirk 8: leading zero row
     cols = [np.zeros((1, 3))]
-    for i, pts in enumerate(lookups):
-        reg = np.array(eng.host(pts), dtype=np.int32)                                # quirk 10: truncation toward zero
-        cols.append(images[i + 2][reg[:, 1], reg[:, 0]].reshape(-1, 3) if images is not None else np.zeros((len(reg), 3)))
+    if images is not None and len(lookups) and torch.is_tensor(images[0]) and all(torch.is_tensor(p) for p in lookups):
+        # frames and lookup points both in HBM: gather on the device, ONE download (same truncation toward zero, quirk 10)
+        picked = []
+        for i, pts in enumerate(lookups):
+            reg = pts.to(torch.int32).long()
+            picked.append(images[i + 2][reg[:, 1], reg[:, 0]].reshape(-1, 3))
+        cols.append(torch.cat(picked).cpu().numpy().astype(np.float64))
+    else:
+        for i, pts in enumerate(lookups):
+            reg = np.array(eng.host(pts), dtype=np.int32)                            # quirk 10: truncation toward zero
+            img = None if images is None else (images[i + 2].cpu().numpy() if torch.is_tensor(images[i + 2]) else images[i + 2])
+            cols.append(img[reg[:, 1], reg[:, 0]].reshape(-1, 3) if img is not None else np.zeros((len(reg), 3)))
     return dict(posearr=np.hstack(poses), Xtot=Xtot, colorstot=np.vstack(cols), errors=errs[1:], first_error=errs[0])
 
 

@@ -235,3 +235,107 @@ def ring_scene(n_images, n_desc, n_scene, seed=0, desc_noise=1.5, pix_noise=0.3)
         return np.vstack([kp, ckp])[order], np.vstack([des, cdes])[order], np.hstack([np.arange(n_scene), -np.ones(nc, int)])[order]
 
     return K, P, image
+
+
+def fast_texture(n, seed, device="cpu"):
+    """An n x n uint8 texture (torch tensor on `device`) for the rendered views: 1/f noise (FFT-shaped Gaussian noise: structure
+    at every scale, so SIFT finds blobs in several octaves), a few hundred random rectangles (corners and edges; a 2-D difference
+    array summed twice: O(n^2) whatever their number) — non-periodic content, unlike tiling a small image (repeated structure
+    would fail the ratio test).  The random draws come from NumPy (seeded), the arithmetic runs in torch float64."""
+    import torch
+    rng = np.random.default_rng(seed)
+    dev = torch.device(device)
+    fy, fx = torch.fft.fftfreq(n, dtype=torch.float64, device=dev)[:, None], torch.fft.rfftfreq(n, dtype=torch.float64, device=dev)[None, :]
+    rad = torch.sqrt(fx * fx + fy * fy)
+    rad[0, 0] = 1.0
+    re, im = rng.standard_normal((n, n // 2 + 1)), rng.standard_normal((n, n // 2 + 1))
+    spec = torch.complex(torch.from_numpy(re).to(dev), torch.from_numpy(im).to(dev)) / rad ** 1.3
+    spec[0, 0] = 0.0
+    spec = spec * torch.exp(-(rad / 0.18) ** 2)              # nothing above ~0.18 cycles per texel: survives the view's resampling
+    img = torch.fft.irfft2(spec, s=(n, n))
+    img = 55.0 * img / img.std()
+    m = 12 * n // 32
+    x0, y0 = rng.integers(0, n, m), rng.integers(0, n, m)
+    ww, hh = rng.integers(4, max(5, n // 10), m), rng.integers(4, max(5, n // 10), m)
+    x1, y1 = np.minimum(x0 + ww, n), np.minimum(y0 + hh, n)
+    amp = rng.uniform(-45, 45, m)
+    diff = np.zeros((n + 1, n + 1))
+    np.add.at(diff, (y0, x0), amp)
+    np.add.at(diff, (y0, x1), -amp)
+    np.add.at(diff, (y1, x0), -amp)
+    np.add.at(diff, (y1, x1), amp)
+    img = img + torch.cumsum(torch.cumsum(torch.from_numpy(diff).to(dev), 0), 1)[:n, :n]
+    return torch.clamp(torch.round(img + 120.0), 0, 255).to(torch.uint8)
+
+
+def gustav_views(n_images=57, w=968, h=648, seed=0, n_planes=7, scale=2, tex=1024, device=None):
+    """The reference's camera path SEEN THROUGH PIXELS (BASELINE configs[2]; the Gustav II Adolf photographs are not available):
+    the `n_images` first cameras of pose.csv (sfm.py:423's own output) look at a scene of `n_planes` two-sided textured quads
+    placed through the bounding box of the reference's cloud (sparse.ply) — real 3-D structure with parallax and occlusion, so
+    that SIFT -> knnMatch -> findEssentialMat / recoverPose -> triangulate -> solvePnPRansac (sfm.py:301-409) has something to
+    reconstruct — inside a far textured box (no empty pixels).  Frames are rendered at scale x (w, h) — sfm.py:40 halves every
+    photograph before anything else — by exact ray / plane intersection (per plane a homography of the pixel grid), nearest hit
+    wins, bilinear texture lookup.  Test-data generation, not product: torch float64 on `device` (the GPU when there is one —
+    57 full-size frames take a second there and minutes in NumPy); the SAME uint8 frames then feed the HIP path and the oracle.
+    Returns (images: list of (scale h, scale w, 3) uint8 BGR NumPy arrays, K for the DOWNSCALED frames as in pose.csv, P [n, 3, 4])."""
+    import torch
+    dev = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
+    K, P = load_pose_csv()
+    P = np.asarray(P[:n_images], np.float64)
+    X = sparse_points()
+    lo, hi = np.percentile(X, 10, axis=0), np.percentile(X, 90, axis=0)
+    ctr, ext = 0.5 * (lo + hi), float(np.linalg.norm(hi - lo))
+    rng = np.random.default_rng(seed)
+    planes = []
+    for p in range(n_planes):
+        nrm = rng.standard_normal(3)
+        nrm /= np.linalg.norm(nrm)
+        u = np.cross(nrm, rng.standard_normal(3))
+        u /= np.linalg.norm(u)
+        v = np.cross(nrm, u)
+        o = ctr + rng.uniform(-0.25, 0.25, 3) * ext
+        half = rng.uniform(0.35, 0.6) * ext
+        planes.append((o, u, v, nrm, half))
+    big = 6.0 * ext
+    for ax in range(3):
+        for sgn in (-1.0, 1.0):
+            nrm = np.zeros(3); nrm[ax] = sgn
+            u = np.zeros(3); u[(ax + 1) % 3] = 1.0
+            v = np.cross(nrm, u)
+            planes.append((ctr + nrm * big, u, v, nrm, 1.2 * big))
+    texs = torch.stack([fast_texture(tex, seed * 101 + p, dev) for p in range(len(planes))]).to(torch.float32)
+    W, H = scale * w, scale * h
+    Ks = K.copy()
+    Ks[:2] *= scale                                          # the full-size frame's intrinsics (sfm.py:20-26 divides them back)
+    Kinv = np.linalg.inv(Ks)
+    xs = torch.arange(W, dtype=torch.float64, device=dev)[None, :]
+    ys = torch.arange(H, dtype=torch.float64, device=dev)[:, None]
+    images = []
+    for k in range(n_images):
+        R, t = decompose_P(K, P[k])
+        Cc = -R.T @ t
+        M = R.T @ Kinv                                       # world direction of pixel (x, y): M @ [x, y, 1]; camera depth of a hit = its ray parameter
+        best = torch.full((H, W), float("inf"), dtype=torch.float64, device=dev)
+        ta = torch.zeros((H, W), dtype=torch.float64, device=dev)
+        tb = torch.zeros((H, W), dtype=torch.float64, device=dev)
+        ti = torch.zeros((H, W), dtype=torch.int64, device=dev)
+        for pi, (o, u, v, nrm, half) in enumerate(planes):
+            dn, du, dv = nrm @ M, u @ M, v @ M               # linear forms in (x, y, 1)
+            den = dn[0] * xs + dn[1] * ys + dn[2]
+            s = float(nrm @ (o - Cc)) / torch.where(den.abs() < 1e-12, torch.full_like(den, 1e-12), den)
+            a = float((Cc - o) @ u) + s * (du[0] * xs + du[1] * ys + du[2])
+            b = float((Cc - o) @ v) + s * (dv[0] * xs + dv[1] * ys + dv[2])
+            hit = (s > 0.05) & (a.abs() < half) & (b.abs() < half) & (s < best)
+            best = torch.where(hit, s, best)
+            sc = (tex - 1) / (2.0 * half)
+            ta = torch.where(hit, (a + half) * sc, ta)
+            tb = torch.where(hit, (b + half) * sc, tb)
+            ti = torch.where(hit, torch.full_like(ti, pi), ti)
+        x0 = torch.clamp(torch.floor(ta).long(), 0, tex - 2)
+        y0 = torch.clamp(torch.floor(tb).long(), 0, tex - 2)
+        fx, fy = torch.clamp(ta - x0, 0, 1).float(), torch.clamp(tb - y0, 0, 1).float()
+        g = (texs[ti, y0, x0] * (1 - fx) * (1 - fy) + texs[ti, y0, x0 + 1] * fx * (1 - fy)
+             + texs[ti, y0 + 1, x0] * (1 - fx) * fy + texs[ti, y0 + 1, x0 + 1] * fx * fy)
+        g = torch.clamp(torch.round(g), 0, 255).to(torch.uint8).cpu().numpy()
+        images.append(np.stack([g, g, g], -1))
+    return images, K, P

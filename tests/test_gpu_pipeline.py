@@ -482,3 +482,44 @@ def test_mask_indices_kernel(hip):
         assert np.array_equal(hip.mask_indices(torch.from_numpy(m > 0).cuda(), nonzero=True).cpu().numpy(), np.flatnonzero(m > 0))
     with pytest.raises(hip.SfmHipError):
         hip.mask_indices(torch.zeros(4, dtype=torch.float32, device="cuda"))
+
+
+@pytest.mark.gpu
+def test_driver_from_pixels_on_the_reference_camera_path(hip, oracle):
+    """sfm.py:301-409 from PIXELS along the reference's own camera path (pose.csv): full-size frames rendered around textured 3-D
+    structure -> img_downscale -> cvtColor + SIFT -> the driver.  The HIP features of every frame equal the oracle's bit for
+    bit, the free-running chain equals the oracle twin's (<= 1e-4 asserted; identical in practice), a profiled run changes
+    nothing and reports every stage and the host's waits, and the planted cameras come back (pose.csv's gauge: first camera at
+    the origin, unit first baseline — what recoverPose fixes)."""
+    from datagen import decompose_P, gustav_views
+    from oracle_backend import oracle_pipeline_backend
+    from sfm_mvs_amd import pipeline as pl
+    n = 5
+    images, K, P = gustav_views(n, seed=5)
+    assert images[0].shape == (1296, 1936, 3)
+    out = pl.run_sfm_images(images, K, downscale=2)
+    prof = pl.DriverProfile()
+    outp = pl.run_sfm_images(images, K, downscale=2, profile=prof)
+    assert np.array_equal(outp["posearr"], out["posearr"]) and np.array_equal(outp["Xtot"], out["Xtot"])
+    rep = prof.report(n - 2)
+    assert {"findEssentialMat (sfm.py:307)", "solvePnPRansac + inlier gathers (sfm.py:67-76)", "cvtColor + SIFT detectAndCompute (sfm.py:243-252)"} <= set(rep["stage_ms"])
+    assert rep["host_syncs"]["library_side"] > 0 and rep["host_syncs"]["per_registered_camera"] < 200
+    assert rep["solve_pnp_ransac_host_us_per_call"]["calls"] == n - 1          # bootstrap's discarded call + one per registered camera
+    feats_o = []
+    for im in images:
+        kp, des = oracle.sift(oracle.bgr2gray(oracle.pyrdown(im)))
+        feats_o.append((np.ascontiguousarray(kp[:, :2]), des))
+    for (kp, des), (okp, odes) in zip(out["features"], feats_o):
+        assert len(okp) > 2000
+        assert np.array_equal(kp.cpu().numpy().view(np.int32), okp.view(np.int32)) and np.array_equal(des.cpu().numpy(), odes)
+    want = pl.run_sfm(feats_o, K, images=[oracle.pyrdown(im) for im in images], be=oracle_pipeline_backend(oracle))
+    assert out["posearr"].shape == want["posearr"].shape and out["Xtot"].shape == want["Xtot"].shape
+    assert np.abs(out["posearr"] - want["posearr"]).max() <= 1e-4 * np.abs(want["posearr"]).max()
+    assert np.abs(out["Xtot"] - want["Xtot"]).max() <= 1e-4 * np.abs(want["Xtot"]).max()
+    assert np.array_equal(out["colorstot"], want["colorstot"])
+    got = out["posearr"][9:].reshape(-1, 3, 4)
+    for k in range(n):
+        Rg, tg = decompose_P(K, got[k])
+        Rp, tp = decompose_P(K, P[k])
+        assert np.abs(Rg - Rp).max() < 3e-2 and np.linalg.norm(Rg.T @ tg - Rp.T @ tp) < 0.12      # (five frames of an incremental chain without bundle adjustment)
+    assert max(out["errors"]) < 2.0
