@@ -324,6 +324,19 @@ def pnp_dlt_init(K, X, uv):
     return int(st), r, t
 
 
+def lm_sums(J, err, mode):
+    """The 28 sums of one Levenberg-Marquardt sweep (upper triangle of J^T J, J^T e, |e|^2): mode 0 the fixed tree the HIP library
+    shares, mode 1 a plain long-double sum in index order (independent check)."""
+    J, err = _f64(J).reshape(-1, 6), _f64(err).reshape(-1)
+    out = np.zeros(28)
+    lib().orc_lm_sums(_p(J), _p(err), C.c_int64(len(err) // 2), C.c_int(mode), _p(out))
+    return out
+
+
+def set_lm_sum_mode(mode):
+    lib().orc_set_lm_sum_mode(C.c_int(mode))
+
+
 def levmarq_pose(K, X, uv, rvec, tvec):
     X, uv = _f64(X).reshape(-1, 3), _f64(uv).reshape(-1, 2)
     r, t = _f64(rvec).reshape(3).copy(), _f64(tvec).reshape(3).copy()

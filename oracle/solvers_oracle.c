@@ -1028,7 +1028,31 @@ int orc_pnp_dlt_init(const double* X, const double* uv, int64_t n, const double*
  *   total:             G = 1: the group's sum;  G > 1: 0 + group 0 + group 1 + ...                                          */
 #define LM_SLOTS 1024
 #define LM_MAXG 64
+/* An INDEPENDENT evaluation of the same 28 sums, for the tests only (orc_set_lm_sum_mode(1)): one long-double accumulator per
+ * sum, points in index order — no slots, no butterflies, nothing shared with the device's tree.  tests/test_oracle_solvers.py
+ * holds the tree to it within 1e-12 relative and the Levenberg-Marquardt result to the one this plain sum gives: agreement
+ * between the HIP library and the oracle is then not "by construction of one shared tree" alone. */
+static int g_lm_sum_mode = 0;
+void orc_set_lm_sum_mode(int mode) { g_lm_sum_mode = mode; }
+static void lm_plain_sums(const double* J, const double* err, int64_t n, double* out) {
+    long double a[28];
+    for (int k = 0; k < 28; ++k) a[k] = 0.0L;
+    for (int64_t o = 0; o < n; ++o) {
+        const long double ru = err[2 * o], rv = err[2 * o + 1];
+        a[27] += ru * ru + rv * rv;
+        if (J) {
+            const double* ju = J + 12 * o;
+            const double* jv = ju + 6;
+            int q = 0;
+            for (int i = 0; i < 6; ++i)
+                for (int j = i; j < 6; ++j) a[q++] += (long double)ju[i] * ju[j] + (long double)jv[i] * jv[j];
+            for (int i = 0; i < 6; ++i) a[21 + i] += (long double)ju[i] * ru + (long double)jv[i] * rv;
+        }
+    }
+    for (int k = J ? 0 : 27; k < 28; ++k) out[k] = (double)a[k];
+}
 static void lm_tree_sums(const double* J /*2n x 6 or NULL*/, const double* err /*2n*/, int64_t n, double* out /*28*/) {
+    if (g_lm_sum_mode == 1) { lm_plain_sums(J, err, n, out); return; }
     int64_t G = (n + LM_SLOTS - 1) / LM_SLOTS;
     if (G > LM_MAXG) G = LM_MAXG;
     if (G < 1) G = 1;
@@ -1066,6 +1090,14 @@ static void lm_tree_sums(const double* J /*2n x 6 or NULL*/, const double* err /
         out[k] = total;
     }
     free(acc);
+}
+
+/* tests: the 28 sums of J (2n x 6) and err (2n) by the fixed tree (mode 0) or by the plain long-double sum (mode 1) */
+void orc_lm_sums(const double* J, const double* err, int64_t n, int mode, double* out28) {
+    const int keep = g_lm_sum_mode;
+    g_lm_sum_mode = mode;
+    lm_tree_sums(J, err, n, out28);
+    g_lm_sum_mode = keep;
 }
 
 int orc_levmarq_pose(const double* X, const double* uv, int64_t n, const double* K, double* rvec, double* tvec, int* iters_out) {

@@ -93,8 +93,11 @@ def _epnp_betas(L, rho, cols):
 
 
 
-def epnp_numpy(K, Xw, uv):
-    """The same algorithm in NumPy (reference for the C++ solver's tests; large samples)."""
+def epnp_numpy(K, Xw, uv, axis_signs=(1, 1, 1)):
+    """The same algorithm in NumPy (reference for the C++ solver's tests; large samples).
+    axis_signs: orientation of the three principal axes the control points sit on.  An SVD fixes them only up to sign; on
+    exact data the pose does not depend on the choice, on NOISY data it does at the noise level (other control points, other
+    algebraic error) — OpenCV's answer is the one its own SVD's signs give, so a comparison has to try the eight mirrorings."""
     Xw = np.asarray(Xw, np.float64)
     uv = np.asarray(uv, np.float64)
     n = len(Xw)
@@ -105,7 +108,7 @@ def epnp_numpy(K, Xw, uv):
     P0 = Xw - cws[0]
     U, dc, _ = np.linalg.svd(P0.T @ P0)
     for i in range(1, 4):
-        cws[i] = cws[0] + np.sqrt(dc[i - 1] / n) * U[:, i - 1]
+        cws[i] = cws[0] + axis_signs[i - 1] * np.sqrt(dc[i - 1] / n) * U[:, i - 1]
     # barycentric coordinates
     CC = (cws[1:] - cws[0]).T
     try:
