@@ -372,10 +372,18 @@ __global__ __launch_bounds__(256) void triangulate_kernel(ProjPair P, const floa
     bool have = false;
     if constexpr (M == 4) {
         double sens = 0;
-        if (normalise_w >= 2) have = dlt_nullvec_fast(At, Xd, &sens);
+        // (normalise_w = 3, the guarded path, never comes here: it is triangulate_guarded_kernel + triangulate_fixup_kernel)
+        if (normalise_w == 2) have = dlt_nullvec_fast(At, Xd, &sens);
 #ifdef SFM_DEV_BUILD
-        if (normalise_w == 4) {      // dev calibration (scripts/dev/dev_tri_calib.py; not in release builds): X4[0] = max |fast - jacobi| over the components (sign-aligned), X4[1] = sens
-            double Xj[4];
+        if (normalise_w == 4) {
+            // dev calibration of the guard (scripts/dev/dev_tri_calib.py; not in release builds) on the SHIPPED configuration: the
+            // inverse iteration on the FMA-fused system (dlt_build<4, true>: what triangulate_guarded_kernel / tri_matches_points_kernel
+            // solve) against the Jacobi path on the unfused one (what the fix-up pass and the faithful kernel solve).  Fusing moves
+            // every entry of A by ~1 ulp, i.e. the null vector by the order of `sens` itself, so the two must be measured together.
+            // X4[0] = max |fast - jacobi| over the components (sign-aligned), X4[1] = sens
+            double Af[4][4], Xj[4];
+            dlt_build<4, true>(Af, P.p[0], P.p[1], (double)x1[i * spt], (double)x1[i * spt + sxy], (double)x2[i * spt], (double)x2[i * spt + sxy]);
+            have = dlt_nullvec_fast(Af, Xd, &sens);
             dlt_nullvec<M>(At, Xj);
             const double sg = (Xj[0] * Xd[0] + Xj[1] * Xd[1] + Xj[2] * Xd[2] + Xj[3] * Xd[3]) < 0 ? -1.0 : 1.0;
             double d = 0;
@@ -388,19 +396,6 @@ __global__ __launch_bounds__(256) void triangulate_kernel(ProjPair P, const floa
             return;
         }
 #endif
-        if (normalise_w == 3) {
-            // guarded: keep the fast result only where its float32 casts cannot differ from the Jacobi path's; mark the rest
-            // (the components are relative to a UNIT vector: a perturbation of the vector moves a small component by the same
-            // absolute amount, so the margin is taken relative to 1, not to the component)
-            const double margin = fmax(base_guard, sens_factor * sens);
-            const bool keep = have && margin < 1e-3 && cast_margin_ok(Xd[0], margin) && cast_margin_ok(Xd[1], margin) &&
-                              cast_margin_ok(Xd[2], margin) && cast_margin_ok(Xd[3], margin);
-            if (!keep) {
-#pragma unroll
-                for (int k = 0; k < 4; ++k) X4[k * n + i] = __uint_as_float(kRedoMark);
-                return;
-            }
-        }
     }
     if (!have) dlt_nullvec<M>(At, Xd);
     store_point<M>(Xd, normalise_w, n, i, X4);

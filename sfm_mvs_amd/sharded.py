@@ -184,7 +184,13 @@ class HipMatchEngine:
         current stream — descriptors still being produced there (an asynchronous SIFT or upload) are safe to pass in."""
         from . import ops
         nq, nt = des0.shape[0], des1.shape[0]
-        key = (nq, nt)
+        # the pairs of one launch set share their row strides (sfm_match_batch_l2_f32 takes one ldq / ldt): a sliced view and a
+        # contiguous tensor of the same shape go to different pipelines instead of failing mid-round; rows must be unit-stride
+        if des0.dim() == 2 and des0.stride(1) != 1:
+            des0 = des0.contiguous()
+        if des1.dim() == 2 and des1.stride(1) != 1:
+            des1 = des1.contiguous()
+        key = (nq, nt, des0.stride(0) if nq else 128, des1.stride(0) if nt else 128)
         pipe = self.pipes.pop(key, None)
         if pipe is None:
             while len(self.pipes) >= self.max_shapes:       # evict the least recently used shape
@@ -198,9 +204,10 @@ class HipMatchEngine:
         direct = block.shape[1] == nq and block.is_contiguous()
         if pipe.pending and direct != (not self._padded[key]):     # a launch set writes either into blocks or into its own result
             self._launch(key, pipe.flush())
+        rec = pipe.submit(des0, des1, after=after, result=block if direct else None)     # (may raise: nothing is queued then)
         if not direct:
-            self._padded[key].append(block)
-        self._launch(key, pipe.submit(des0, des1, after=after, result=block if direct else None))
+            self._padded[key].append(block)                # only once the pair IS queued: the list stays in step with the pipeline
+        self._launch(key, rec)
 
     def _launch(self, key, rec):
         """rec: BatchPipeline's launch record (or None: the batch is still filling).  Padded blocks get their rows copied

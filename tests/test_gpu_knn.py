@@ -414,3 +414,32 @@ def test_committed_fuzz_logs_are_those_of_the_loaded_binary():
         assert f"knn_hip_code_sha256 {sha}" in text, f"{path} was produced by another csrc/knn.hip than the loaded binary's (stale): re-run scripts/fuzz_knn.py"
         total += int(m.group(1))
     assert total >= 20000, f"only {total} fuzz cases on this binary's source"
+
+
+@pytest.mark.gpu
+def test_match_engine_takes_contiguous_and_sliced_descriptors_of_one_shape(hip, oracle):
+    """sharded.HipMatchEngine batches pairs by shape; a sequence that mixed contiguous and sliced descriptor
+    tensors of the same shape failed mid-round ("the pairs of a batch share their row strides") and left its block list out
+    of step with the pipeline.  The row strides are part of the pipeline key now: every pair comes back, each the oracle's."""
+    from sfm_mvs_amd import sharded
+    rng = np.random.default_rng(31)
+    nq, nt = 700, 900
+    pairs = []
+    for k in range(6):
+        q, t, _ = planted_pair(rng, nq, nt, 0.3)
+        pairs.append((q, t))
+    eng = sharded.HipMatchEngine("cuda", depth=2, batch=4)
+    blocks = [torch.zeros((2, nq, 2), dtype=torch.int32, device="cuda") for _ in pairs]
+    wide = [torch.zeros((nq, 160), device="cuda") for _ in pairs]       # row stride 160: a sliced view [:, :128]
+    for k, (q, t) in enumerate(pairs):
+        dq = torch.from_numpy(q).cuda()
+        if k % 2:
+            wide[k][:, :128] = dq
+            dq = wide[k][:, :128]
+            assert dq.stride(0) == 160
+        eng.match(dq, torch.from_numpy(t).cuda(), blocks[k], after=False)
+    eng.flush()
+    torch.cuda.synchronize()
+    for k, (q, t) in enumerate(pairs):
+        wi, wd = oracle.knn2(q, t, nthreads=8)
+        assert np.array_equal(blocks[k][0].cpu().numpy(), wi) and np.array_equal(blocks[k][1].cpu().numpy().view(np.float32).view(np.uint32), wd.view(np.uint32)), k
