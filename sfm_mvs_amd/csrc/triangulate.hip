@@ -270,7 +270,7 @@ __device__ __forceinline__ bool dlt_nullvec_fast(const double (&At)[4][4], doubl
 // lanes whose iteration did not converge are marked and redone by triangulate_fixup_kernel with the Jacobi sweeps,
 // compacted so that no wave runs the slow path for a single lane.
 constexpr double kCastGuard = 9.094947017729282e-13;    // 2^-40: 300 x the rounding floor of the two vectors' difference (<= 3.5e-15 measured)
-constexpr double kSensFactor = 16.0;                    // margin = max(kCastGuard, kSensFactor * sens); measured |fast - Jacobi| <= 2.5 sens
+constexpr double kSensFactor = 16.0;                    // margin = max(kCastGuard, kSensFactor * sens); measured |fast on the fused system - Jacobi on the unfused one| <= 2.0 sens (profiles/r05_tri_guard_calibration.txt)
 constexpr unsigned kRedoMark = 0x7FC0DEADu;             // quiet-NaN payload written to all four outputs of a point to redo
 
 __device__ __forceinline__ bool cast_margin_ok(double x, double margin) {
