@@ -27,7 +27,7 @@ Batches mix the families: a u8 pair next to a float pair exercises the conversio
 a quantised pair next to a Gaussian one the repair of pairs quantised in vain.
 Most cases are small (the oracle dominates the wall time); one in eight is large, `big` adds 20k-70k train rows.
 The log ends with the sha256 of csrc/knn.hip and of its CODE (comments and whitespace removed, scripts/knn_code_hash.py):
-profiles/r04_fuzz_knn_*.log are checked against the tree's code hash by tests/test_gpu_knn.py.
+the round's logs under profiles/ are checked against the LOADED binary's code hash (sfm_build_id) by tests/test_gpu_knn.py.
 """
 import hashlib
 import os

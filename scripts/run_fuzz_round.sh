@@ -8,4 +8,5 @@ for seed in $((BASE+1)) $((BASE+2)) $((BASE+3)) $((BASE+4)); do
   tail -3 $R/gpurun_out/${TAG}_fuzz_knn_seed$seed.log | head -1
 done
 python $R/scripts/fuzz_knn.py $SEC $((BASE+5)) big 2>&1 | grep -v amdgpu.ids > $R/gpurun_out/${TAG}_fuzz_knn_seed$((BASE+5))_big.log
+python $R/scripts/fuzz_knn.py $((SEC*3/2)) $((BASE+6)) q8 2>&1 | grep -v amdgpu.ids > $R/gpurun_out/${TAG}_fuzz_knn_seed$((BASE+6))_q8.log
 grep "^fuzz:" $R/gpurun_out/${TAG}_fuzz_knn_seed*.log
