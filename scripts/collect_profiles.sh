@@ -62,6 +62,16 @@ python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_knn.json 2>> $OUT/trac
 python bench.py --workload c5 > $OUT/${TAG}_bench_c5.json 2>> $OUT/trace.log
 python bench.py --workload allpairs > $OUT/${TAG}_bench_allpairs.json 2>> $OUT/trace.log
 python bench.py --workload sfm --steps 3 > $OUT/${TAG}_bench_sfm.json 2>> $OUT/trace.log
+python bench.py --workload sfm --from-pixels --steps 3 > $OUT/${TAG}_bench_sfm_pixels.json 2>> $OUT/trace.log
+# launch sets in flight: the headline step at pipeline depth 1 .. 5 (bench.py's default is 3)
+for d in 1 2 3 4 5; do
+  python bench.py --steps 60 --warmup 10 --pipe-depth $d --no-cpu-baseline --no-extras 2>> $OUT/trace.log | python -c "
+import sys, json; d = json.loads(sys.stdin.read()); print('pipe-depth $d: value %.4g distances/s  ms_per_step %.4f  frac_step %.3f' % (d['value'], d['ms_per_step'], d['roofline']['frac_step']))" >> $OUT/${TAG}_knn_pipe_depth.txt
+done
+# HIP API census of the from-pixels job (how often the host waits: hipStreamSynchronize / hipMemcpy / hipEventSynchronize)
+( cd /tmp && rocprofv3 --hip-trace --stats --output-format csv -d $OUT/trace_hip -o sfmpx -- python $R/bench.py --workload sfm --from-pixels --steps 1 --no-cpu-baseline > /dev/null 2>> $OUT/trace.log )
+cp $OUT/trace_hip/sfmpx_hip_api_stats.csv $OUT/${TAG}_sfm_pixels_hip_api_stats.csv 2>/dev/null
+rm -rf $OUT/trace_hip
 python bench.py --workload tri --steps 5 --warmup 1 > $OUT/${TAG}_bench_tri.json 2>> $OUT/trace.log
 python bench.py --workload ba --steps 5 --warmup 1 > $OUT/${TAG}_bench_ba.json 2>> $OUT/trace.log
 python bench.py --workload sift --steps 30 --warmup 5 > $OUT/${TAG}_bench_sift.json 2>> $OUT/trace.log
