@@ -40,7 +40,10 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf1
 I8_MFMA_PEAK_TOPS = 5000.0        # dense int8 MFMA (v_mfma_i32_32x32x32_i8: 2x the bf16 rate; the guide measured 4 404 TOPS for 32x32)
 F16_MFMA_SUSTAINED_TFLOPS, I8_MFMA_SUSTAINED_TOPS = 1691.0, 3619.0   # pure MFMA stream on RANDOM operands, measured: profiles/r04_mfma_ceiling.md
 PROF_SAMPLES = 6                   # profiled steps, run alone AFTER the timed region
-PIPE_DEPTH = 3                     # launch sets in flight (one stream + workspace each)
+PIPE_DEPTH = 3                     # KNN launch sets in flight (one stream + workspace each).  Two are 2.5-4.5 % faster WHEN their streams land on distinct hardware
+                                   # queues (0.176 vs 0.184 ms) and as slow as one (0.22 ms) when they share one — seen in 2 of 9 fresh pipelines; three are robust
+                                   # (profiles/r05_knn_pipe_depth.txt, scripts/dev/depth_ab.py, scripts/dev/engine_depth_ab.py)
+SIFT_DEPTH = 3                     # SIFT frames in flight
 N_SETS = 2                         # sets of PAIR_BATCH distinct image pairs rotating over the steps
 PAIR_BATCH = 8                     # independent pairs per launch set = per step (sfm_match_batch_l2_f32): prologue / ramp / kernel boundaries once per batch
 PROF_REPEAT = 3                    # filter launches per HIP-event pair on a profiled step (an event pair adds ~7 us to one)
@@ -64,7 +67,7 @@ def parse():
     ap.add_argument("--verify-images", type=int, default=6, help="workload allpairs: essential-matrix RANSAC + recoverPose (isfm.py:80-94) on the pairs among the first N images")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
-    ap.add_argument("--pipe-depth", type=int, default=PIPE_DEPTH, help="launch sets in flight per GPU (1 = one stream)")
+    ap.add_argument("--pipe-depth", type=int, default=None, help=f"launch sets (knn: default {PIPE_DEPTH}) / frames (sift: default {SIFT_DEPTH}) in flight per GPU (1 = one stream)")
     ap.add_argument("--pair-batch", type=int, default=PAIR_BATCH, help="independent pairs per launch set (1..8)")
     ap.add_argument("--from-pixels", action="store_true",
                     help="workload sfm: BASELINE configs[2] FROM PIXELS — 57 rendered full-size frames through img_downscale, cvtColor + SIFT and the "
@@ -213,7 +216,7 @@ def knn_source_hash():
 def bench_knn(args, world, rank, dev):
     from sfm_mvs_amd import ops
     nq, nt = args.nq, args.nt
-    depth = max(1, args.pipe_depth)
+    depth = max(1, args.pipe_depth or PIPE_DEPTH)
     pbatch = max(1, min(8, args.pair_batch))
     # DISTINCT pairs: a launch set matches `pbatch` different (query, train) images (seeds 2 (pbatch (N_SETS rank + s) + b)
     # and + 1), and N_SETS such sets rotate over the steps — the caches, the arithmetic-mode decision and the rescan counts
@@ -1238,7 +1241,8 @@ def bench_sift(args, world, rank, dev):
     w, h = 968, 648
     g_host = scene_image(w, h, 3 + rank)
     gray = torch.as_tensor(g_host).to(dev)
-    pipe = sift.SiftPipeline(w, h, dev, depth=args.pipe_depth)
+    sift_depth = max(1, args.pipe_depth or SIFT_DEPTH)
+    pipe = sift.SiftPipeline(w, h, dev, depth=sift_depth)
     eng = pipe.engines[0]
     for _ in range(max(2, args.warmup)):
         pipe.submit(gray, after=False)
@@ -1272,7 +1276,7 @@ def bench_sift(args, world, rank, dev):
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "SURVEY 8f-1: SIFT (3 layers/octave, 0.04, 10, 1.6) on 968 x 648 procedural frames, one frame per step",
                       "keypoints_per_frame": nkp, "octaves": n_oct,
-                      "parallelism": f"frame-sharded x{world}; {args.pipe_depth} frames in flight per GPU"},
+                      "parallelism": f"frame-sharded x{world}; {sift_depth} frames in flight per GPU"},
            "frame_latency_ms_single_stream": single_ms,
            "keypoints_per_sec": world * nkp * args.steps / elapsed,
            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
@@ -1435,7 +1439,7 @@ def bench_dry_run(args, world, rank):
     nq = 64
     pbatch = max(1, min(8, args.pair_batch))
     steps = max(1, min(args.steps, 8))
-    ex = sharded.BatchedExchange((2, nq, 2), torch.int32, dev, batch=EXCH_BATCH, nbuf=args.pipe_depth + 1)
+    ex = sharded.BatchedExchange((2, nq, 2), torch.int32, dev, batch=EXCH_BATCH, nbuf=(args.pipe_depth or PIPE_DEPTH) + 1)
     assert ex.world == world == dist.get_world_size() and ex.rank == rank
     ok, serial = True, 0
     barrier_sync(world)
