@@ -65,7 +65,7 @@ const char* sfm_build_id(void);
  *
  * dim must be 128 (SIFT); q_dev/t_dev 16-byte aligned; ldq, ldt multiples of 4; nt <= 4 000 000.
  * The result is bit-identical to the direct-form float32 evaluation for any finite input whose squared row
- * norms are finite in float32 (|x| up to ~1e18; see DESIGN.md "certified filter + exact refine").  Beyond that the
+ * norms are finite in float32 (|x| up to ~1e18; see docs/knn.md, "Domain of the parity claim").  Beyond that the
  * filters' scores ||t||^2 + ||q||^2 - 2 q.t are +inf / NaN while some direct-form distances are still finite: measured
  * wrong at 3e18, right again from 1e19 on, where every distance is +inf and the index order decides (scripts/dev/q8_huge.py).
  *

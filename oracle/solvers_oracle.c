@@ -1015,7 +1015,7 @@ int orc_pnp_dlt_init(const double* X, const double* uv, int64_t n, const double*
 }
 
 /* The 28 sums of one Levenberg-Marquardt sweep — upper triangle of J^T J (21), J^T e (6), |e|^2 — in ONE FIXED TREE, the same
- * in this file and in the HIP library (its pnp_sweep_kernel / pnp_sweep_fold_kernel).  OpenCV forms them with cvMulTransposed /
+ * in this file and in the HIP library (its pnp_sweep_kernel / pnp_sweep_fold_kernel; docs/oracle.md).  OpenCV forms them with cvMulTransposed /
  * cvGEMM / cvNorm, whose SIMD summation order is not pinned by anything in the reference; a plain sequential sum here and a
  * parallel one on the device would differ in the last bits, LM's accept / reject test (errNorm > prevErrNorm) would now and
  * then go the other way, and because every camera is registered against points triangulated from the earlier ones the two

@@ -4,7 +4,7 @@ ops.BatchMatcher) against the CPU oracle: indices, float32 distances (bit patter
   python scripts/fuzz_knn.py [seconds] [seed] [big | q8]
 
 Data families: the ordinary ones (uniform, scaled normals, SIFT-like integers, planted twins, duplicates, near-ties, unit
-vectors, mixed magnitudes) and a second group aimed at the margins of the exactness certificate:
+vectors, mixed magnitudes) and a second group aimed at the margins of the exactness certificate (docs/knn.md):
   cancel     operands that maximise |c| + sum |a b| while the score itself cancels to almost nothing (alternating signs,
              large common offset): the regime in which the matrix pipe's accumulation error is largest (7.1 units measured)
   tie23      every query has its 2nd and 3rd neighbour at distances that differ by 0 .. a few float32 ulps (and the 1st / 2nd

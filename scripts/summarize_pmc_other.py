@@ -1,5 +1,5 @@
 """Turns the PMC passes of scripts/collect_pmc_other.sh (gpurun_out/pmc_<tag>_{tri,ba,sift}) into profiles/<tag>_other_pmc.md:
-per kernel the mean counters per launch and the derived figures DESIGN.md quotes (HBM bytes, VALU instructions per work item,
+per kernel the mean counters per launch and the derived figures DESIGN.md and docs/*.md quote (HBM bytes, VALU instructions per work item,
 issue / wait split)."""
 import collections, csv, glob, os, sys
 

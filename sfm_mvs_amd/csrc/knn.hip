@@ -2404,7 +2404,7 @@ constexpr float kU = 5.9604645e-8f;
 constexpr float kEpsF32 = 600.f * kU;
 static_assert(kKeyBits == 8, "kKeyTrunc = 2^(kKeyBits-23)");
 constexpr float kKeyTrunc = 3.0517578e-5f * 1.002f;
-constexpr float kEpsRound = 200.f * kU;                      // fp32 rounding around the product (budget: DESIGN.md 4.1 "error budget")
+constexpr float kEpsRound = 200.f * kU;                      // fp32 rounding around the product (budget: docs/knn.md "Error budget of the certificate")
 constexpr float kChainHalf = 256.f * kU, kChainSplit = 640.f * kU;   // MFMA chain at E = 16 units per MFMA; x chain_scale (mfma_chain_scale)
 constexpr float kEpsSplitOp = 2.33e-5f;
 constexpr float kEpsHalfOp = 4.8840e-4f;

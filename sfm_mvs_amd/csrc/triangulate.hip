@@ -9,7 +9,7 @@
 //
 // north_star words this as "one-warp-per-point SVD"; a 4x4 problem has 6 column pairs per sweep —
 // spreading it over 64 lanes would leave >90 % of the wave idle and add cross-lane traffic, so a
-// lane owns a point and a wave solves 64 points in lockstep.
+// lane owns a point and a wave solves 64 points in lockstep (see docs/geometry.md).
 #include "common.h"
 #include <algorithm>
 #include <cfloat>

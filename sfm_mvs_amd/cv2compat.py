@@ -8,7 +8,7 @@ part of find_features :259-268, findEssentialMat/recoverPose :307-311) run on th
 NumPy in, NumPy out; every call uploads, launches the kernels of libsfmhip.so and downloads.
 Also provided: `SIFT_create` / `xfeatures2d.SIFT_create` (`detectAndCompute`), `cvtColor(BGR2GRAY)`,
 `pyrDown`, `KeyPoint`, and `imread` (host-side decode through PIL: file I/O, not a kernel).  Not provided (out of scope,
-DESIGN.md §7): GUI.
+DESIGN.md §6): GUI.
 """
 import numpy as np
 import torch
@@ -22,7 +22,7 @@ RANSAC = 8
 NORM_L2 = 4
 SOLVEPNP_ITERATIVE = 0
 COLOR_BGR2GRAY = 6
-TRIANGULATE_ROWS = 4        # 4: current OpenCV DLT system; 6: legacy cvTriangulatePoints
+TRIANGULATE_ROWS = 4        # 4: current OpenCV DLT system; 6: legacy cvTriangulatePoints (see docs/oracle.md)
 
 
 def _dev():

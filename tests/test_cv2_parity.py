@@ -6,7 +6,7 @@ the observed worst case is printed (`pytest -s`) rather than assumed."""
 import numpy as np
 import pytest
 
-cv2 = pytest.importorskip("cv2", reason="OpenCV is not installed here: oracle parity stays unpinned (DESIGN.md 2)")
+cv2 = pytest.importorskip("cv2", reason="OpenCV is not installed here: oracle parity stays unpinned (docs/oracle.md)")
 
 from datagen import decompose_P, gustav_pair, planted_pair, scene_image  # noqa: E402
 
