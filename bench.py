@@ -1512,6 +1512,29 @@ def main():
                 out["extra"] = extras(dev)
                 out["extra"]["config4"] = extra_c4(dev)
                 out["extra"].update(extra_other_workloads(args, dev))
+                # The driver's record keeps `config` in full but only the KEYS of everything else: the other legs' headline figures
+                # ride in config.secondary so that they are driver-timed values too, each measured in this run.
+                ex = out["extra"]
+                def val(*path):
+                    d = ex
+                    for k in path:
+                        d = d.get(k) if isinstance(d, dict) else None
+                    return d
+                pix = ex.get("sfm57_from_pixels", {})
+                out["config"]["secondary"] = {
+                    "sift_like_u8_distances_per_sec": out.get("sift_like", {}).get("distances_per_sec"),
+                    "sift_like_u8_ms_per_step": out.get("sift_like", {}).get("ms_per_step"),
+                    "fp16_body_distances_per_sec": out.get("fp16_body_variant", {}).get("distances_per_sec"),
+                    "config5_one_gpu_distances_per_sec": val("config5", "value"), "config5_job_seconds": val("config5", "job_seconds"),
+                    "allpairs_distances_per_sec": val("allpairs", "value"),
+                    "triangulated_points_per_sec_1e7": val("triangulate_product_path_1e7", "pts_per_sec"),
+                    "ba_dense_observations_per_sec": val("config4", "value"), "ba_dense_fp64_valu_frac": val("config4", "roofline", "frac"),
+                    "sift_frames_per_sec": val("sift", "value"),
+                    "sfm57_from_features_seconds": val("sfm57", "value"),
+                    "sfm57_from_pixels_seconds": pix.get("value"), "sfm57_from_pixels_ms_per_camera": pix.get("ms_per_registered_camera"),
+                    "sfm57_from_pixels_host_waits_per_camera": (pix.get("profile") or {}).get("host_syncs", {}).get("per_registered_camera"),
+                    "sfm57_from_pixels_vs_oracle_twin_max_rel_diff_P": ((pix.get("parity") or {}).get("vs_oracle_twin_from_pixels") or {}).get("max_rel_diff_P"),
+                    "note": "the other legs of this same run (details under `extra`, `sift_like`, `fp16_body_variant`); frames of the sfm legs are SURROGATES of the Gustav photographs"}
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_knn_baseline(args.nq, args.nt, 0, 1)
     elif args.workload == "tri":
