@@ -129,10 +129,112 @@ def features_from_images(images, depth=3, on_device=False):
     return feats
 
 
+class FeatureStream:
+    """sfm.py:301-302 (read + img_downscale) and :243-252 (cvtColor + SIFT) AHEAD of the driver.
+
+    The driver is sequential and host-bound — RANSAC hypotheses, Levenberg-Marquardt algebra, a dozen host waits per camera —
+    and leaves the GPU mostly idle; feature extraction is the opposite.  Round 4 ran them one after the other (all frames' SIFT,
+    then the chain).  Here a producer THREAD uploads frame k, halves it, and runs cvtColor + SIFT on its own streams (`depth`
+    frames in flight, at most `lookahead` frames ahead of the consumer); `stream[i]` blocks until frame i's (keypoints (n, 2),
+    descriptors (n, 128)) are in HBM.  Same kernels on the same pixels: results are bit-identical to the serial order.
+    The library calls release the GIL (ctypes), torch releases it around copies and launches."""
+
+    lazy = True      # (_HipEngine: no up-front pass over every frame's shape)
+
+    def __init__(self, images, downscale=2, depth=3, lookahead=8):
+        import threading
+        self.images, self.downscale, self.depth, self.lookahead = images, downscale, int(depth), max(int(lookahead), int(depth) + 1)
+        self.dev = torch.device("cuda", torch.cuda.current_device())
+        self.small = [None] * len(images)             # the halved frames (HBM): colour lookup at the end of the run
+        self._res, self._err, self._wanted = {}, None, 1
+        self._cv = threading.Condition()
+        self._thread = threading.Thread(target=self._produce, name="sfm-feature-stream", daemon=True)
+        self._thread.start()
+
+    def __len__(self):
+        return len(self.images)
+
+    def __getitem__(self, i):
+        if i < 0:
+            i += len(self.images)
+        with self._cv:
+            if i > self._wanted:
+                self._wanted = i
+                self._cv.notify_all()
+            while i not in self._res and self._err is None:
+                self._cv.wait()
+            if i not in self._res:
+                raise self._err
+            return self._res[i]
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self.images)))
+
+    def close(self):
+        self._thread.join()
+
+    def _produce(self):
+        from . import sift as _sift
+        try:
+            torch.cuda.set_device(self.dev)
+            pipes, pending = {}, []                   # pending: (frame, stream, engine) in submission order
+
+            def collect():
+                k, st, eng = pending.pop(0)
+                st.synchronize()
+                n = eng.check_capacity()
+                with torch.cuda.stream(st):
+                    kp, des = eng.keypoints[:n, :2].contiguous(), eng.descriptors[:n].clone()
+                st.synchronize()
+                with self._cv:
+                    self._res[k] = (kp, des)
+                    self._cv.notify_all()
+
+            for k, im in enumerate(self.images):
+                with self._cv:                        # stay at most `lookahead` frames ahead of what the driver has asked for
+                    while k > self._wanted + self.lookahead:
+                        self._cv.wait()
+                h, w = im.shape[0], im.shape[1]
+                for _ in range(int(self.downscale / 2)):
+                    h, w = (h + 1) // 2, (w + 1) // 2
+                pipe = pipes.get((w, h))
+                if pipe is None:
+                    pipe = pipes[(w, h)] = [_sift.SiftPipeline(w, h, self.dev, depth=self.depth), 0]
+                while len(pending) >= self.depth or any(e is pipe[0].engines[pipe[1] % self.depth] for _, _, e in pending):
+                    collect()
+                slot = pipe[1] % self.depth
+                pipe[1] += 1
+                st, eng = pipe[0].streams[slot], pipe[0].engines[slot]
+                with torch.cuda.stream(st):
+                    d = im.to(self.dev) if torch.is_tensor(im) else torch.as_tensor(np.ascontiguousarray(im, np.uint8)).to(self.dev)
+                    for _ in range(int(self.downscale / 2)):
+                        d = _sift.pyrdown(d)
+                    self.small[k] = d
+                    eng.launch(_sift.bgr2gray(d) if d.dim() == 3 else d)
+                pending.append((k, st, eng))
+            while pending:
+                collect()
+        except BaseException as e:      # noqa: BLE001 — handed to the consumer
+            with self._cv:
+                self._err = e
+                self._cv.notify_all()
+
+
 def run_sfm_images(images, K, downscale=2, log=None, be=None, bundle_adjustment=False, gtol_thresh=0.5, profile=None):
     """sfm.py's main loop from pixels: img_downscale (:40), cvtColor + SIFT (:243-252) and the driver (:274-423).
     `images`: BGR uint8 frames in sequence order; K is scaled by the caller as in sfm.py:20-26.
     profile: a DriverProfile — the run is then a PROFILED one (the device is drained at every stage boundary)."""
+    import time
+    if be is None and profile is None:
+        # the product path: features are produced AHEAD of the sequential driver by a second host thread (FeatureStream)
+        feats = FeatureStream(images, downscale)
+        try:
+            out = run_sfm(feats, K, images=feats.small, log=log, bundle_adjustment=bundle_adjustment, gtol_thresh=gtol_thresh)
+            out["features"] = list(feats)
+        finally:
+            feats.close()
+        return out
+    # a PROFILED run (or a substituted backend) keeps the stages apart: every frame's preprocessing, then every frame's SIFT, then the chain
     import time
     t_all = t0 = time.perf_counter()
     if be is None:
@@ -511,7 +613,7 @@ class _HipEngine:
         # launch set (sfm_match_batch_l2_f32: bit-identical to per-pair calls), their survivor counts come back in ONE
         # download; pairs of a shape that occurs once are matched when the driver asks for them.
         shapes = {}
-        for k in range(len(features) - 1):
+        for k in range(len(features) - 1 if not getattr(features, "lazy", False) else 0):     # (a FeatureStream is still being produced: frames of a real sequence never share a shape anyway)
             shapes.setdefault((len(features[k][0]), len(features[k + 1][0])), []).append(k)
         self.keep_all = set()
         for plist in shapes.values():
