@@ -9,6 +9,8 @@ find_features, :243-252) produce them from pixels on the GPU, `r
 
 Behavioural quirks that are load-bearing for parity are reproduced and marked `# quirk`.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -229,7 +231,14 @@ def run_sfm_images(images, K, downscale=2, log=None, be=None, bundle_adjustment=
         # the product path: features are produced AHEAD of the sequential driver by a second host thread (FeatureStream)
         feats = FeatureStream(images, downscale)
         try:
-            out = run_sfm(feats, K, images=feats.small, log=log, bundle_adjustment=bundle_adjustment, gtol_thresh=gtol_thresh)
+            # the chain's kernels are tiny and each is waited for by the host: on a HIGH-priority stream they are dispatched ahead
+            # of the feature streams' queued workgroups instead of behind them
+            cur = torch.cuda.current_stream()
+            hp = torch.cuda.Stream(priority=-1)
+            hp.wait_stream(cur)
+            with torch.cuda.stream(hp):
+                out = run_sfm(feats, K, images=feats.small, log=log, bundle_adjustment=bundle_adjustment, gtol_thresh=gtol_thresh)
+            cur.wait_stream(hp)
             out["features"] = list(feats)
         finally:
             feats.close()
