@@ -118,7 +118,7 @@ def features_from_images(images, depth=3, on_device=False):
         h, w = img.shape[:2]
         pipe = pipes.get((w, h))
         if pipe is None:
-            pipe = pipes[(w, h)] = _sift.SiftPipeline(w, h, dev, depth=depth)
+            pipe = pipes[(w, h)] = _sift_pipeline(w, h, dev, depth)
         if len(pending) == depth:
             collect()
         d = img if torch.is_tensor(img) else torch.as_tensor(img).to(dev)      # (a frame already in HBM — run_sfm_images' downscaled ones — is taken as it is)
@@ -129,6 +129,21 @@ def features_from_images(images, depth=3, on_device=False):
     while pending:
         collect()
     return feats
+
+
+_SIFT_PIPES = {}      # (w, h, depth, device index) -> sift.SiftPipeline: workspaces (3 x 268 MB at 968 x 648) and streams are kept between runs —
+#                       new streams every run mean cold per-stream allocator pools, i.e. hipMalloc calls (device-wide waits) in the middle of the job
+
+
+def _sift_pipeline(w, h, dev, depth):
+    from . import sift as _sift
+    key = (int(w), int(h), int(depth), torch.device(dev).index)
+    pipe = _SIFT_PIPES.get(key)
+    if pipe is None:
+        for old in [k for k in _SIFT_PIPES if k[0] != "chain stream"][:max(0, len(_SIFT_PIPES) - 4)]:      # a handful of frame sizes at most
+            _SIFT_PIPES.pop(old)
+        pipe = _SIFT_PIPES[key] = _sift.SiftPipeline(w, h, dev, depth=depth)
+    return pipe
 
 
 class FeatureStream:
@@ -201,7 +216,7 @@ class FeatureStream:
                     h, w = (h + 1) // 2, (w + 1) // 2
                 pipe = pipes.get((w, h))
                 if pipe is None:
-                    pipe = pipes[(w, h)] = [_sift.SiftPipeline(w, h, self.dev, depth=self.depth), 0]
+                    pipe = pipes[(w, h)] = [_sift_pipeline(w, h, self.dev, self.depth), 0]
                 while len(pending) >= self.depth or any(e is pipe[0].engines[pipe[1] % self.depth] for _, _, e in pending):
                     collect()
                 slot = pipe[1] % self.depth
@@ -234,7 +249,9 @@ def run_sfm_images(images, K, downscale=2, log=None, be=None, bundle_adjustment=
             # the chain's kernels are tiny and each is waited for by the host: on a HIGH-priority stream they are dispatched ahead
             # of the feature streams' queued workgroups instead of behind them
             cur = torch.cuda.current_stream()
-            hp = torch.cuda.Stream(priority=-1)
+            hp = _SIFT_PIPES.get(("chain stream", cur.device.index))     # (kept between runs for the same reason as the SIFT pipelines)
+            if hp is None:
+                hp = _SIFT_PIPES[("chain stream", cur.device.index)] = torch.cuda.Stream(priority=-1)
             hp.wait_stream(cur)
             with torch.cuda.stream(hp):
                 out = run_sfm(feats, K, images=feats.small, log=log, bundle_adjustment=bundle_adjustment, gtol_thresh=gtol_thresh)
