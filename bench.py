@@ -916,7 +916,7 @@ def extra_other_workloads(args, dev):
     out = {}
     for key, fn, over in (("config5", bench_c5, {}), ("allpairs", bench_allpairs, {"images": 32, "verify_images": 4}),
                           ("sift", bench_sift, {"steps": 30, "warmup": 5}), ("sfm57", bench_sfm, {"steps": 2, "warmup": 1}),
-                          ("sfm57_from_pixels", bench_sfm_pixels, {"steps": 2, "warmup": 1, "images": 57})):
+                          ("sfm57_from_pixels", bench_sfm_pixels, {"steps": 3, "warmup": 1, "images": 57})):
         a = copy.copy(args)
         for k, v in over.items():
             setattr(a, k, v)
