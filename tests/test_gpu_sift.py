@@ -204,3 +204,28 @@ def test_sift_pipeline_matches_single_engine(hip):
     assert len(got) == len(want)
     for (ka, da), (kb, db) in zip(got, want):
         assert torch.equal(ka.view(torch.int32), kb.view(torch.int32)) and torch.equal(da, db)
+
+
+def test_feature_stream_is_the_serial_order_and_fails_loudly(hip):
+    """pipeline.FeatureStream (features produced ahead of the driver by a second host thread): every frame's keypoints and
+    descriptors equal features_from_images' bit for bit, random access blocks until the frame is there, and a frame the kernels
+    reject surfaces in the CONSUMER as the library's error instead of hanging it."""
+    from datagen import scene_image
+    from sfm_mvs_amd import SfmHipError
+    from sfm_mvs_amd import pipeline as pl
+    frames = [np.stack([scene_image(320, 240, 40 + k)] * 3, -1) for k in range(7)]
+    big = [np.repeat(np.repeat(f, 2, axis=0), 2, axis=1) for f in frames]
+    want = pl.features_from_images([pl.img_downscale(b, 2) for b in big], on_device=True)
+    fs = pl.FeatureStream(big, 2, depth=2, lookahead=3)
+    kp5, des5 = fs[5]                                              # out of order: blocks until frame 5 exists
+    assert torch.equal(kp5, want[5][0]) and torch.equal(des5, want[5][1])
+    for k, (kp, des) in enumerate(fs):
+        assert torch.equal(kp, want[k][0]) and torch.equal(des, want[k][1]), k
+    fs.close()
+    assert all(s is not None and tuple(s.shape) == (240, 320, 3) for s in fs.small)
+    bad = list(big)
+    bad[3] = torch.from_numpy(big[3].astype(np.float32))           # a tensor frame that is not uint8: pyrdown refuses
+    fs = pl.FeatureStream(bad, 2)
+    with pytest.raises(SfmHipError):
+        fs[6]
+    fs.close()
