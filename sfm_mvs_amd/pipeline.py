@@ -128,22 +128,40 @@ def features_from_images(images, depth=3, on_device=False):
         pending.append((st, eng))
     while pending:
         collect()
+    for pipe in pipes.values():
+        _sift_pipeline_done(pipe)
     return feats
 
 
 _SIFT_PIPES = {}      # (w, h, depth, device index) -> sift.SiftPipeline: workspaces (3 x 268 MB at 968 x 648) and streams are kept between runs —
 #                       new streams every run mean cold per-stream allocator pools, i.e. hipMalloc calls (device-wide waits) in the middle of the job
+_SIFT_PIPES_BUSY = set()
+_SIFT_PIPES_LOCK = __import__("threading").Lock()
 
 
 def _sift_pipeline(w, h, dev, depth):
+    """A SiftPipeline for this frame size, taken from the cache when nobody else holds it (give it back with _sift_pipeline_done);
+    a second concurrent user gets a private, uncached one."""
     from . import sift as _sift
     key = (int(w), int(h), int(depth), torch.device(dev).index)
-    pipe = _SIFT_PIPES.get(key)
-    if pipe is None:
-        for old in [k for k in _SIFT_PIPES if k[0] != "chain stream"][:max(0, len(_SIFT_PIPES) - 4)]:      # a handful of frame sizes at most
-            _SIFT_PIPES.pop(old)
-        pipe = _SIFT_PIPES[key] = _sift.SiftPipeline(w, h, dev, depth=depth)
-    return pipe
+    with _SIFT_PIPES_LOCK:
+        pipe = _SIFT_PIPES.get(key)
+        if pipe is not None and id(pipe) not in _SIFT_PIPES_BUSY:
+            _SIFT_PIPES_BUSY.add(id(pipe))
+            return pipe
+    fresh = _sift.SiftPipeline(w, h, dev, depth=depth)
+    with _SIFT_PIPES_LOCK:
+        if pipe is None:                                  # first of its size: cache it (a handful of frame sizes at most)
+            for old in [k for k in _SIFT_PIPES if k[0] != "chain stream" and id(_SIFT_PIPES[k]) not in _SIFT_PIPES_BUSY][:max(0, len(_SIFT_PIPES) - 4)]:
+                _SIFT_PIPES.pop(old)
+            _SIFT_PIPES[key] = fresh
+        _SIFT_PIPES_BUSY.add(id(fresh))
+    return fresh
+
+
+def _sift_pipeline_done(pipe):
+    with _SIFT_PIPES_LOCK:
+        _SIFT_PIPES_BUSY.discard(id(pipe))
 
 
 class FeatureStream:
@@ -163,7 +181,7 @@ class FeatureStream:
         self.images, self.downscale, self.depth, self.lookahead = images, downscale, int(depth), max(int(lookahead), int(depth) + 1)
         self.dev = torch.device("cuda", torch.cuda.current_device())
         self.small = [None] * len(images)             # the halved frames (HBM): colour lookup at the end of the run
-        self._res, self._err, self._wanted = {}, None, 1
+        self._res, self._err, self._wanted, self._stop = {}, None, 1, False
         self._cv = threading.Condition()
         self._thread = threading.Thread(target=self._produce, name="sfm-feature-stream", daemon=True)
         self._thread.start()
@@ -188,13 +206,17 @@ class FeatureStream:
         return (self[i] for i in range(len(self.images)))
 
     def close(self):
+        """Stop producing (a consumer that gives up mid-sequence must not leave the producer waiting for it) and join the thread."""
+        with self._cv:
+            self._stop = True
+            self._cv.notify_all()
         self._thread.join()
 
     def _produce(self):
         from . import sift as _sift
+        pipes, pending = {}, []                       # pending: (frame, stream, engine) in submission order
         try:
             torch.cuda.set_device(self.dev)
-            pipes, pending = {}, []                   # pending: (frame, stream, engine) in submission order
 
             def collect():
                 k, st, eng = pending.pop(0)
@@ -209,8 +231,10 @@ class FeatureStream:
 
             for k, im in enumerate(self.images):
                 with self._cv:                        # stay at most `lookahead` frames ahead of what the driver has asked for
-                    while k > self._wanted + self.lookahead:
+                    while k > self._wanted + self.lookahead and not self._stop:
                         self._cv.wait()
+                    if self._stop:
+                        break
                 h, w = im.shape[0], im.shape[1]
                 for _ in range(int(self.downscale / 2)):
                     h, w = (h + 1) // 2, (w + 1) // 2
@@ -234,6 +258,17 @@ class FeatureStream:
         except BaseException as e:      # noqa: BLE001 — handed to the consumer
             with self._cv:
                 self._err = e
+                self._cv.notify_all()
+        finally:
+            for pipe in pipes.values():
+                try:
+                    pipe[0].synchronize()             # nothing of this thread's is in flight when the pipelines go back
+                except Exception:      # noqa: BLE001
+                    pass
+                _sift_pipeline_done(pipe[0])
+            with self._cv:
+                if self._err is None and len(self._res) < len(self.images):
+                    self._err = ops.SfmHipError("FeatureStream was closed before every frame was produced")
                 self._cv.notify_all()
 
 

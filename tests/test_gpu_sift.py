@@ -229,3 +229,21 @@ def test_feature_stream_is_the_serial_order_and_fails_loudly(hip):
     with pytest.raises(SfmHipError):
         fs[6]
     fs.close()
+
+
+def test_feature_stream_abandoned_mid_sequence_does_not_hang(hip):
+    """A consumer that gives up (an exception in the driver) closes the stream: the producer stops instead of waiting for the
+    consumer to catch up, the cached pipelines go back, and the next run gets them."""
+    from datagen import scene_image
+    from sfm_mvs_amd import pipeline as pl
+    big = [np.stack([np.repeat(np.repeat(scene_image(160, 120, 60 + k), 2, 0), 2, 1)] * 3, -1) for k in range(20)]
+    fs = pl.FeatureStream(big, 2, depth=2, lookahead=3)
+    _ = fs[1]
+    fs.close()                                                     # frames 6.. were never asked for
+    assert not fs._thread.is_alive()
+    with pytest.raises(Exception):
+        fs[19]
+    fs2 = pl.FeatureStream(big, 2, depth=2, lookahead=3)
+    assert len(list(fs2)) == 20
+    fs2.close()
+    assert not pl._SIFT_PIPES_BUSY
