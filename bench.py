@@ -40,9 +40,11 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_bf1
 I8_MFMA_PEAK_TOPS = 5000.0        # dense int8 MFMA (v_mfma_i32_32x32x32_i8: 2x the bf16 rate; the guide measured 4 404 TOPS for 32x32)
 F16_MFMA_SUSTAINED_TFLOPS, I8_MFMA_SUSTAINED_TOPS = 1691.0, 3619.0   # pure MFMA stream on RANDOM operands, measured: profiles/r04_mfma_ceiling.md
 PROF_SAMPLES = 6                   # profiled steps, run alone AFTER the timed region
-PIPE_DEPTH = 3                     # KNN launch sets in flight (one stream + workspace each).  Two are 2.5-4.5 % faster WHEN their streams land on distinct hardware
-                                   # queues (0.176 vs 0.184 ms) and as slow as one (0.22 ms) when they share one — seen in 2 of 9 fresh pipelines; three are robust
-                                   # (profiles/r05_knn_pipe_depth.txt, scripts/dev/depth_ab.py, scripts/dev/engine_depth_ab.py)
+PIPE_DEPTH = 2                     # KNN launch sets in flight (one stream + workspace each).  Two are ~4 % faster than three (0.176 vs 0.185 ms) — but about one
+                                   # fresh pair of streams in 24 is served one after the other by the runtime (0.22 ms, the one-stream figure), so the set-up
+                                   # probes the pipeline's streams and keeps the fastest of STREAM_TRIES sets (ops.BatchPipeline.tune_streams; untimed;
+                                   # profiles/r05_knn_pipe_depth.txt, scripts/dev/depth2_streams.py)
+STREAM_TRIES = 3
 SIFT_DEPTH = 3                     # SIFT frames in flight
 N_SETS = 2                         # sets of PAIR_BATCH distinct image pairs rotating over the steps
 PAIR_BATCH = 8                     # independent pairs per launch set = per step (sfm_match_batch_l2_f32): prologue / ramp / kernel boundaries once per batch
@@ -278,6 +280,9 @@ def bench_knn(args, world, rank, dev):
             pmx.run(sets[0])
             pmx.run(sets[0][:1])
     torch.cuda.synchronize()
+    # (3) streams that the runtime really serves concurrently (see PIPE_DEPTH): probe, replace, keep the fastest (one rank only: with an
+    # exchange in the loop the ranks would have to agree on the collectives the probe issues)
+    stream_probe_ms = pipe.tune_streams(sets, tries=STREAM_TRIES) if depth > 1 and ex is None else []
     # COLD figure: the same K steps right after an idle period, before the clock ramp (kernels and streams are loaded, the
     # device is not at its sustained clock) — what a caller that matches one batch now and then sees.
     time.sleep(0.5)
@@ -385,11 +390,14 @@ def bench_knn(args, world, rank, dev):
                    "pairs_per_launch": pbatch,
                    "cold_value": world * pbatch * nq * nt * args.steps / cold_elapsed, "cold_ms_per_step": cold_elapsed / args.steps * 1e3,
                    "cold_note": "`value` is the sustained rate; cold_value = the same K steps after 0.5 s of idle, before the clock ramp",
+                   "stream_probe_ms_per_launch_set": stream_probe_ms,
+                   "stream_probe_note": f"set-up, untimed: the pipeline's {depth} streams are probed and replaced up to {STREAM_TRIES - 1} times, the fastest set is kept "
+                                        "(two launch sets overlap fully only when the runtime serves their streams concurrently: ~1 fresh pair in 24 does not)",
                    "setup": f"streams and kernels loaded, then {CLOCK_WARMUP_STEPS} untimed steps of the same workload (~60 ms: the device reaches its sustained clock) before the W warm-up steps"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak_hl, "unit": unit_hl,
                      "frac": achieved / peak_hl, "frac_of_sustained": achieved / sus_hl,
                      # the WHOLE step against the same roof: algorithmic work of a launch set / the timed region's time per step
-                     # (prep + mode/split + filter + refine + scatter, three launch sets in flight) — `frac` is the filter kernel alone
+                     # (prep + mode/split + filter + refine + scatter, `pipe_depth` launch sets in flight) — `frac` is the filter kernel alone
                      "frac_step": algo_flop / (elapsed / args.steps) / 1e12 / peak_hl,
                      "frac_step_note": "algorithmic ops of one launch set / ms_per_step / peak: the step as a whole, not its dominant kernel",
                      "sustained_note": ("a pure i8 MFMA stream on random bytes holds 3 619 TOPS on this part (power-limited clock), profiles/r04_mfma_ceiling.md" if int_body else
@@ -529,6 +537,8 @@ def bench_knn(args, world, rank, dev):
                                  "note": "pinned-host descriptors in, results out, same stream (not the headline value)"}
         # the 16-bit body on the SAME data, box and pipeline (filter="noquant": what ran by default before the quantised body)
         pipe16 = ops.BatchPipeline(nq, nt, dev, ratio=0.70, depth=depth, batch=pbatch, filter="noquant")
+        if depth > 1:
+            pipe16.tune_streams(sets, tries=STREAM_TRIES)
         def run16(n):
             for i in range(n):
                 for qb, tb in sets[i % N_SETS]:
@@ -558,7 +568,7 @@ def bench_knn(args, world, rank, dev):
                                     "frac_of_sustained": algo_flop / (f16_avg * 1e-3) / 1e12 / F16_MFMA_SUSTAINED_TFLOPS,
                                     "results_identical_to_default": same16,
                                     "frac_step": algo_flop / (dt16 / 60) / 1e12 / BF16_MFMA_PEAK_TFLOPS,
-                                    "note": "the same launch sets through the fp16 single-product body (3 launch sets in flight): the headline value runs the i8 MFMA "
+                                    "note": "the same launch sets through the fp16 single-product body (same pipeline depth): the headline value runs the i8 MFMA "
                                             "body on 8-bit quantised operands instead; bit-identical results (tests/test_gpu_knn_q8.py::test_full_size_batch_quantised_equals_noquant)"}
         # ADVICE r04 / VERDICT r04 item 4: the headline ran the i8 body on QUANTISED operands, which only data of compact support
         # (uniform, beta) qualify for; Gaussian / heavy-tailed float descriptors take the fp16 body — that rate, on the same box and

@@ -16,9 +16,10 @@ def run(pipe, n):
     pipe.flush(); pipe.synchronize()
 warm = ops.BatchPipeline(nq, nt, dev, depth=3, batch=8); run(warm, 300)
 keep = []
-for trial in range(16):
-    p = ops.BatchPipeline(nq, nt, dev, depth=2, batch=8)
-    keep.append(p)                                   # keep the streams alive: the pool hands out the next ones
+DEPTH = int(os.environ.get("DEPTH", "2"))
+for trial in range(int(os.environ.get("TRIALS", "16"))):
+    p = ops.BatchPipeline(nq, nt, dev, depth=DEPTH, batch=8)
+    keep.append(p); keep[:] = keep[-2:]              # (workspaces are 1.5 GB per launch set: keep only the last two pipelines alive)
     run(p, 20)
     t0 = time.perf_counter(); run(p, 100); dt = (time.perf_counter() - t0) / 100
     print(f"trial {trial:2d}: {dt*1e3:.4f} ms   streams {[hex(s.cuda_stream) for s in p.streams]}", flush=True)

@@ -677,6 +677,40 @@ class BatchPipeline:
         self.n = 0
         self._pairs, self._results, self._after = [], [], []
 
+    def probe_ms(self, sets, steps=40, warm=10):
+        """Milliseconds per launch set over `steps` launch sets of `sets` (a list of lists of (des0, des1) pairs, `batch` each, rotated):
+        what tune_streams() compares.  Drains the pipeline before and after."""
+        import time
+
+        def run(n):
+            for i in range(n):
+                for q, t in sets[i % len(sets)]:
+                    self.submit(q, t, after=False)
+            self.flush()
+            self.synchronize()
+        run(warm)
+        t0 = time.perf_counter()
+        run(steps)
+        return (time.perf_counter() - t0) / steps * 1e3
+
+    def tune_streams(self, sets, tries=3, steps=40):
+        """Two launch sets in flight are ~4 % faster than three (MI355X, 10k x 10k: 0.176 against 0.185 ms) — when the runtime happens to
+        serve their two streams concurrently; about one fresh pair of streams in 24 runs them one after the other instead (0.22 ms,
+        the one-stream figure; profiles/r05_knn_pipe_depth.txt).  Nothing in the HIP API pins that choice, so: probe this pipeline's
+        streams on the caller's data, replace them by fresh ones up to `tries - 1` times, keep the fastest set.  Set-up work, a few
+        milliseconds per try; results are unaffected.  Returns the per-launch-set milliseconds of every try."""
+        seen = []
+        best, best_streams = None, None
+        for _ in range(max(1, tries)):
+            ms = self.probe_ms(sets, steps)
+            seen.append(ms)
+            if best is None or ms < best:
+                best, best_streams = ms, self.streams
+            if len(seen) < tries:
+                self.streams = [torch.cuda.Stream(device=self.streams[0].device) for _ in range(self.depth)]
+        self.streams = best_streams
+        return seen
+
     def submit(self, des0, des1, after=None, result=None):
         """Queue one pair.  `after`: None -> the launch set waits for everything already enqueued on the caller's current
         stream when it is launched; an Event -> it waits for that event (e.g. "the consumer has read this result block");

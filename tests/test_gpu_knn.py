@@ -443,3 +443,23 @@ def test_match_engine_takes_contiguous_and_sliced_descriptors_of_one_shape(hip, 
     for k, (q, t) in enumerate(pairs):
         wi, wd = oracle.knn2(q, t, nthreads=8)
         assert np.array_equal(blocks[k][0].cpu().numpy(), wi) and np.array_equal(blocks[k][1].cpu().numpy().view(np.float32).view(np.uint32), wd.view(np.uint32)), k
+
+
+@pytest.mark.gpu
+def test_tune_streams_changes_streams_not_results(hip, oracle):
+    """ops.BatchPipeline.tune_streams probes the pipeline's streams on the caller's data and keeps the fastest of a few fresh sets
+    (two launch sets in flight overlap fully only when the runtime serves their streams concurrently): a set-up step that must
+    leave every result what it was."""
+    rng = np.random.default_rng(41)
+    nq, nt = 900, 1100
+    sets = [[tuple(torch.from_numpy(a).cuda() for a in planted_pair(rng, nq, nt, 0.3)[:2]) for _ in range(4)] for _ in range(2)]
+    pipe = hip.BatchPipeline(nq, nt, "cuda", ratio=0.70, depth=2, batch=4)
+    seen = pipe.tune_streams(sets, tries=3, steps=6)
+    assert len(seen) == 3 and all(ms > 0 for ms in seen) and len(pipe.streams) == 2
+    for q, t in sets[1]:
+        pipe.submit(q, t, after=False)
+    pipe.flush(); pipe.synchronize()
+    bm = pipe.matchers[(pipe.n - 1) % pipe.depth]
+    for b, (q, t) in enumerate(sets[1]):
+        wi, wd = oracle.knn2(q.cpu().numpy(), t.cpu().numpy(), nthreads=8)
+        assert np.array_equal(bm.idx[b].cpu().numpy(), wi) and np.array_equal(bm.dist[b].cpu().numpy().view(np.uint32), wd.view(np.uint32)), b
