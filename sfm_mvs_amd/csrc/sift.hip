@@ -763,15 +763,16 @@ __global__ __launch_bounds__(1024) void dedupe_kernel(const float* __restrict__ 
 // holding integers.  (Four keypoints per wave with one lane per cell does the same work per wave but leaves a wave
 // alone on its SIMD when a frame has few keypoints: 1 174 keypoints took 315 us, as long as 15 000.)
 constexpr int kDescBinsUsed = kDescBins + 1;   // o0 in 0..7 writes bins o0 and o0+1: bin 9 of the 10 stays zero
-__global__ __launch_bounds__(256) void descriptor_kernel(Geom geo, const float* __restrict__ kp, const int* __restrict__ counters, int cap,
-                                                         const int* __restrict__ perm, float* __restrict__ desc) {
-    __shared__ float shist[4][16 * kDescBinsUsed];
-    __shared__ float sdst[4][128];
+constexpr int kDescLdsFloats = 4 * (16 * kDescBinsUsed + 128);   // per wave: the 16 cells' bins, then the keypoint's 128 raw values
+__device__ __forceinline__ void descriptor_cells(const Geom& geo, const float* __restrict__ kp, int nkp, const int* __restrict__ perm,
+                                                 float* __restrict__ desc, float* sbuf) {
+    float (*shist)[16 * kDescBinsUsed] = reinterpret_cast<float (*)[16 * kDescBinsUsed]>(sbuf);
+    float (*sdst)[128] = reinterpret_cast<float (*)[128]>(sbuf + 4 * 16 * kDescBinsUsed);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cell = lane >> 2, sub = lane & 3;
-    const int nkp = min(counters[2], cap);
+    if ((int)blockIdx.x * 4 >= nkp) return;                     // whole workgroup
     const int slot = blockIdx.x * 4 + wave;
-    if (slot >= nkp) return;
-    const int id = perm[slot];                                  // largest windows first
+    const bool have = slot < nkp;                               // (the last workgroup's idle waves still meet the barrier below)
+    const int id = perm[have ? slot : nkp - 1];                 // largest windows first
     const int d = kDescWidth, n = kDescBins;
     const int ri = 1 + (cell >> 2), ci = 1 + (cell & 3);        // my cell in the (d+2) x (d+2) grid
     float* mine = shist[wave] + cell * kDescBinsUsed;
@@ -805,16 +806,22 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom geo, const float* 
     const int tj = (int)rintf(C * ccen + S * rcen), ti = (int)rintf(C * rcen - S * ccen);
     const float ext = fabsf(cos_t) + fabsf(sin_t);
     const float B = 1.f + 0.5f * ext + 1e-3f;
-    const int U = (int)ceilf(B * hist_width * hist_width * ext) + 1;
+    // columns j that can enter at all: |j| <= radius and 1 <= px + j <= w - 2 (none: the histogram stays zero)
+    const int jlo = max(-radius, 1 - px), jhi = min(radius, w - 2 - px);
+    const unsigned jspan = (unsigned)(jhi - jlo);
+    const int U = have && jhi >= jlo ? (int)ceilf(B * hist_width * hist_width * ext) : -1;
     const bool use_c = fabsf(cos_t) > 1e-4f, use_s = fabsf(sin_t) > 1e-4f;
     const float inv_c = use_c ? 1.f / cos_t : 0.f, inv_s = use_s ? 1.f / sin_t : 0.f;
+    // row u of the template spans [max(m1 u - e1, m2 u - e2), min(m1 u + e1, m2 u + e2)]: |v cos_t - u sin_t| <= B and
+    // |v sin_t + u cos_t| <= B solved for v (a bound whose coefficient vanishes is replaced by the window, 4 radius)
+    const float m1 = sin_t * inv_c, e1 = use_c ? B * fabsf(inv_c) : 4.f * radius;
+    const float m2 = -cos_t * inv_s, e2 = use_s ? B * fabsf(inv_s) : 4.f * radius;
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xc07f);
     for (int u = -U; u <= U; ++u) {                               // wave-uniform
-        float lo = -4.f * radius, hi = 4.f * radius;
-        if (use_c) { const float a = (u * sin_t - B) * inv_c, b = (u * sin_t + B) * inv_c; lo = fmaxf(lo, fminf(a, b)); hi = fminf(hi, fmaxf(a, b)); }
-        if (use_s) { const float a = (-u * cos_t - B) * inv_s, b = (-u * cos_t + B) * inv_s; lo = fmaxf(lo, fminf(a, b)); hi = fminf(hi, fmaxf(a, b)); }
-        const int v0 = (int)floorf(lo), v1 = (int)ceilf(hi);
+        const float fu = (float)u;
+        const float lo = fmaxf(m1 * fu - e1, m2 * fu - e2), hi = fminf(m1 * fu + e1, m2 * fu + e2);
+        const int v0 = (int)floorf(lo), v1 = lo <= hi ? (int)ceilf(hi) : v0 - 1;
         const int i = ti + u;
         const int r = py + i;
         const bool row_ok = i >= -radius && i <= radius && (unsigned)(r - 1) < (unsigned)(h - 2);
@@ -822,22 +829,20 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom geo, const float* 
             const int j = tj + vb + sub;
             const float c_rot = j * cos_t - i * sin_t, r_rot = j * sin_t + i * cos_t;
             float rbin = r_rot + d / 2 - 0.5f, cbin = c_rot + d / 2 - 0.5f;
-            const int c = px + j;
             const int r0 = cv_floor(rbin), c0 = cv_floor(cbin);
             const int dr = ri - (r0 + 1), dc = ci - (c0 + 1);
-            const bool inside = row_ok & (rbin > -1) & (rbin < d) & (cbin > -1) & (cbin < d) & ((unsigned)(c - 1) < (unsigned)(w - 2)) &
-                                ((unsigned)(j + radius) <= (unsigned)(2 * radius)) & ((unsigned)(dr | dc) <= 1u);
+            // rbin < d and cbin < d follow from dr, dc <= 1 (r0 <= ri - 1 <= 3)
+            const bool inside = row_ok & (rbin > -1) & (cbin > -1) & ((unsigned)(j - jlo) <= jspan) & ((unsigned)(dr | dc) <= 1u);
             int o0 = 0;
             float vo0 = 0.f, vo1 = 0.f;
             if (inside) {
                 const float W = sift_expf_unclamped((c_rot * c_rot + r_rot * r_rot) * exp_scale);   // argument in (-1.6, 0]
-                const float2 mo = grad[(unsigned)(r * w + c)];
+                const float2 mo = grad[(unsigned)(r * w + px + j)];
                 float obin = (mo.y - ori) * bins_per_rad;
                 const float mag = mo.x * W;
                 o0 = cv_floor(obin);
                 rbin -= r0; cbin -= c0; obin -= o0;
-                if (o0 < 0) o0 += n;
-                if (o0 >= n) o0 -= n;
+                o0 &= n - 1;                                   // obin in (-8, 8]: the same as { if (o0 < 0) o0 += n; if (o0 >= n) o0 -= n; }
                 const float vr1 = mag * rbin;
                 const float vr = dr ? vr1 : mag - vr1;
                 const float vrc1 = vr * cbin;
@@ -861,21 +866,33 @@ __global__ __launch_bounds__(256) void descriptor_kernel(Geom geo, const float* 
 #pragma unroll
         for (int k = 0; k < kDescBins; ++k) dst[cell * n + k] = mine[k];
     }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xc07f);
+    // normalisation: ONE wave does the four keypoints of the workgroup, sixteen lanes each (the two sequential sums cost a
+    // wave the same whether it carries one keypoint or four)
+    __syncthreads();
+    if (wave != 0) return;
+    const int kq = lane >> 4, l16 = lane & 15;
+    const float* dk = sdst[kq];
     const int len = d * d * n;
     float nrm2 = 0.f;
-    for (int k = 0; k < len; ++k) nrm2 += dst[k] * dst[k];     // sequential: the order is part of the result
+    for (int k = 0; k < len; ++k) nrm2 += dk[k] * dk[k];       // sequential: the order is part of the result
     const float thr = sqrtf(nrm2) * kDescMagThr;
     nrm2 = 0.f;
-    for (int k = 0; k < len; ++k) { const float v = fminf(dst[k], thr); nrm2 += v * v; }
+    for (int k = 0; k < len; ++k) { const float v = fminf(dk[k], thr); nrm2 += v * v; }
     const float mul = kIntDescrFctr / fmaxf(sqrtf(nrm2), FLT_EPSILON);
-    {
-        const float a = dst[2 * lane], b = dst[2 * lane + 1];      // 128 values, two per lane
-        const int ia = cv_round(fminf(a, thr) * mul), ib = cv_round(fminf(b, thr) * mul);
-        *reinterpret_cast<float2*>(desc + (size_t)id * 128 + 2 * lane) =
-            make_float2((float)(ia < 0 ? 0 : ia > 255 ? 255 : ia), (float)(ib < 0 ? 0 : ib > 255 ? 255 : ib));
+    if ((int)blockIdx.x * 4 + kq < nkp) {
+        float out[kDescBins];
+#pragma unroll
+        for (int k = 0; k < kDescBins; ++k) { const int iv = cv_round(fminf(dk[l16 * kDescBins + k], thr) * mul); out[k] = (float)(iv < 0 ? 0 : iv > 255 ? 255 : iv); }
+        float4* o4 = reinterpret_cast<float4*>(desc + (size_t)perm[blockIdx.x * 4 + kq] * 128 + l16 * kDescBins);
+        o4[0] = make_float4(out[0], out[1], out[2], out[3]);
+        o4[1] = make_float4(out[4], out[5], out[6], out[7]);
     }
+}
+
+__global__ __launch_bounds__(256) void descriptor_kernel(Geom geo, const float* __restrict__ kp, const int* __restrict__ counters, int cap,
+                                                         const int* __restrict__ perm, float* __restrict__ desc) {
+    __shared__ float sbuf[kDescLdsFloats];
+    descriptor_cells(geo, kp, min(counters[2], cap), perm, desc, sbuf);
 }
 
 int gauss_taps(double sigma, Taps* t) {   // getGaussianKernel(cvRound(sigma*8+1)|1, sigma, CV_32F)
