@@ -490,7 +490,9 @@ extern "C" int sfm_solve_pnp_ransac(const float* X_dev, const float* uv_dev, int
     const double ifx = 1. / K[0], ify = 1. / K[4];
     // solvePnP(EPNP) on a sample: undistortPoints writes float32 normalised coordinates (the image points' type) and
     // epnp::init_points maps them back with u = x fu + uc
-    auto epnp_model = [&](const int* idx, double* model) -> bool {
+    // (reject_nonfinite: a RANSAC hypothesis with a NaN scores zero inliers in OpenCV and is dropped here; the plain
+    // solvePnP(EPNP) of the five-point case returns whatever the solver produced)
+    auto epnp_model = [&](const int* idx, double* model, bool reject_nonfinite = true) -> bool {
         double Xs[15], us[10], R[9], t[3];
         for (int k = 0; k < 5; ++k) {
             for (int j = 0; j < 3; ++j) Xs[3 * k + j] = (double)hX[3 * (size_t)idx[k] + j];
@@ -498,10 +500,12 @@ extern "C" int sfm_solve_pnp_ransac(const float* X_dev, const float* uv_dev, int
             us[2 * k + 1] = (double)(float)(((double)huv[2 * (size_t)idx[k] + 1] - K[5]) * ify) * K[4] + K[5];
         }
         hs::Epnp(K, Xs, us, 5).compute_pose(R, t);
-        for (int k = 0; k < 9; ++k)
-            if (!std::isfinite(R[k])) return false;
-        for (int k = 0; k < 3; ++k)
-            if (!std::isfinite(t[k])) return false;
+        if (reject_nonfinite) {
+            for (int k = 0; k < 9; ++k)
+                if (!std::isfinite(R[k])) return false;
+            for (int k = 0; k < 3; ++k)
+                if (!std::isfinite(t[k])) return false;
+        }
         hs::rodrigues_mat2vec(R, model);
         std::memcpy(model + 3, t, sizeof(t));
         return true;
@@ -527,7 +531,7 @@ extern "C" int sfm_solve_pnp_ransac(const float* X_dev, const float* uv_dev, int
     if (n == 5) {                     // model_points == npoints: plain solvePnP(EPNP), every point an inlier
         const int idx[5] = {0, 1, 2, 3, 4};
         double model[6];
-        if (!epnp_model(idx, model)) return SFM_OK;
+        epnp_model(idx, model, false);
         std::memcpy(rvec_host, model, 24);
         std::memcpy(tvec_host, model + 3, 24);
         const int32_t all[5] = {0, 1, 2, 3, 4};

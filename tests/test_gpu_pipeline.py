@@ -65,6 +65,13 @@ def test_ransac_entry_point_edge_cases(hip, oracle):
     assert ok4o and ok4h and np.array_equal(r4o, r4h) and np.array_equal(t4o, t4h) and np.array_equal(i4o, i4h)
     with pytest.raises(SfmHipError):
         ransac.solve_pnp_ransac(Xf[:3], x2[:3], K)                                            # OpenCV asserts npoints >= 4
+    # five correspondences of which three are distinct (found by scripts/fuzz_geometry.py): model_points == npoints is a plain
+    # solvePnP(EPNP) — it reports success with whatever the solver produced, it does not filter like the RANSAC loop
+    pick = np.array([0, 1, 2, 0, 1])
+    okdo, rdo, tdo, ido = oracle.solve_pnp_ransac(Xf[pick], x2[pick], K)
+    okdh, rdh, tdh, idh = ransac.solve_pnp_ransac(Xf[pick], x2[pick], K)
+    assert bool(okdo) == bool(okdh) and np.array_equal(ido, idh)
+    assert np.array_equal(np.isnan(rdo), np.isnan(rdh)) and np.array_equal(np.isnan(tdo), np.isnan(tdh))
     # pure outliers: no model survives (good must exceed modelPoints - 1)
     rng = np.random.default_rng(0)
     junk = rng.uniform(0, 900, (60, 2)).astype(np.float32)
