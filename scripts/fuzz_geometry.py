@@ -13,6 +13,8 @@ Families (one case = one random draw of a family; the bars are those of tests/te
   common    common_points (sfm.py:215-239) on coarse grids with duplicates, x-only / y-only hits, empty intersections: indices
             bit-exact.
   resid     reprojection error / normal-equation sums of one camera (fp64 sums within 1e-10 relative, inlier mask bit-exact).
+  sweep     the dense and the indexed multi-camera Gauss-Newton sweeps (1 .. 40 cameras, fp64 blocks within 1e-9 relative).
+  score     the RANSAC scoring kernels (PnP poses / essential matrices): inlier counts and masks bit-exact.
 """
 import os
 import sys
@@ -140,16 +142,17 @@ def case_ransac():
                 return None if np.array_equal(nan_o, nan_h) else tag + ": PnP NaN pattern differs"
             close = np.abs(r_o - r_h).max() <= 1e-9 and np.abs(t_o - t_h).max() <= 1e-9 * max(1.0, np.abs(t_o).max())
             if not close:
-                # A rank-deficient refinement (three distinct points, a handful of inliers) amplifies the last bit of the sums:
-                # the two poses must then at least explain the inliers equally well
+                # A rank-deficient or ill-conditioned refinement (three distinct points, a handful of inliers, image points on a line)
+                # amplifies the last bit of the sums along its flat directions: the two poses must then explain the inliers
+                # equally well (RMS within 1e-7) and, with eight or more distinct points, still agree to 1e-6
                 sel = io.ravel()
                 def rms(r, t):
                     p = O.project_points_f64(np.asarray(r, float).ravel(), np.asarray(t, float).ravel(), K, Xf[sel].astype(np.float64))
                     return float(np.sqrt(((p - x2[sel]) ** 2).sum(1).mean()))
                 distinct = len(np.unique(Xf[sel], axis=0))
                 eo_, eh_ = rms(r_o, t_o), rms(r_h, t_h)
-                if distinct >= 8 or abs(eo_ - eh_) > 1e-6 * max(1.0, eo_):
-                    return tag + f": PnP pose differs by {np.abs(r_o - r_h).max():.3g} / {np.abs(t_o - t_h).max():.3g} (inliers {len(sel)}, distinct {distinct}, rms {eo_:.6g} vs {eh_:.6g})"
+                if abs(eo_ - eh_) > 1e-7 * max(1.0, eo_) or (distinct >= 8 and np.abs(r_o - r_h).max() > 1e-6):
+                    return tag + f": PnP pose differs by {np.abs(r_o - r_h).max():.3g} / {np.abs(t_o - t_h).max():.3g} (inliers {len(sel)}, distinct {distinct}, rms {eo_:.12g} vs {eh_:.12g})"
     return None
 
 
@@ -228,7 +231,69 @@ def case_resid():
     return None
 
 
-FAMILIES = [("ransac", case_ransac, 5), ("tri", case_tri, 3), ("common", case_common, 2), ("resid", case_resid, 2)]
+def case_sweep():
+    """The dense Gauss-Newton sweep (every camera sees every point) and the indexed one (sparse visibility, arbitrary order)."""
+    ncam = int(rng.integers(1, 41)); npt = int(np.exp(rng.uniform(0, np.log(6000))))
+    sigma = float(rng.choice([0.0, 0.5, 5.0]))
+    K, cams, X, obs = ba_problem(ncam, npt, sigma, seed=int(rng.integers(1 << 30)), perturb=float(rng.choice([0.0, 0.01, 0.05])))
+    tag = f"sweep ncam {ncam} npt {npt} sigma {sigma}"
+    if rng.random() < 0.5:
+        ci = np.repeat(np.arange(ncam), npt).astype(np.int32); pi = np.tile(np.arange(npt), ncam).astype(np.int32)
+        want = O.project_residual(cams, K, X, obs.reshape(-1, 2), ci, pi)
+        out = ops.ba_dense_sweep(cu(cams), K, cu(X), cu(obs))
+        tag += " dense"
+    else:
+        m = max(1, int(ncam * npt * rng.uniform(0.05, 1.0)))
+        sel = rng.permutation(ncam * npt)[:m]
+        ci, pi = (sel // npt).astype(np.int32), (sel % npt).astype(np.int32)
+        o = obs.reshape(-1, 2)[sel]
+        want = O.project_residual(cams, K, X, o, ci, pi)
+        out = ops.project_residual(cu(cams), K, cu(X), cu(o), cu(ci), cu(pi), want_jac=True, want_pt_jac=True)
+        tag += f" indexed {m}"
+    # J^T r is a sum that CANCELS when the residuals are rounding noise (sigma = 0): its error is relative to the size of its
+    # terms, sqrt(max diag(J^T J) * sum r^2) by Cauchy-Schwarz, not to the sum itself; the two sides add in different orders
+    for key in ("JtJ_cam", "Jtr_cam", "JtJ_pt", "Jtr_pt"):
+        g, w = out[key].cpu().numpy(), want[key]
+        scale = np.abs(w).max()
+        if key.startswith("Jtr"):
+            JJ = want["JtJ" + key[3:]]
+            # (a residual obs - proj of ~1e-5 px carries the projection's own rounding, ~1e-13 px absolute = 1e-8 of itself:
+            # the floor of 1e-4 px per observation stands for that)
+            scale = max(scale, float(np.sqrt(np.abs(JJ).max() * max(want["sumsq"][0], 1e-8 * len(ci)))))
+        if not np.abs(g - w).max() <= 1e-9 * max(scale, 1e-300):
+            return tag + f": {key} off by {np.abs(g - w).max() / max(scale, 1e-300):.3g} of its terms' size"
+    if not abs(out["sumsq"].item() - want["sumsq"][0]) <= 1e-11 * max(want["sumsq"][0], 1e-300):
+        return tag + f": sum of squares differs by {abs(out['sumsq'].item() - want['sumsq'][0]) / max(want['sumsq'][0], 1e-300):.3g} relative"
+    return None
+
+
+def case_score():
+    """RANSAC scoring kernels: inlier counts and masks of several models, bit-exact."""
+    if rng.random() < 0.5:
+        ncam = int(rng.integers(1, 17)); npt = int(np.exp(rng.uniform(0, np.log(8000))))
+        K, cams, X, obs = ba_problem(ncam, npt, float(rng.choice([0.5, 4.0, 20.0])), seed=int(rng.integers(1 << 30)), perturb=float(rng.choice([0.0, 0.002, 0.02])))
+        thr2 = float(rng.choice([64.0, 4.0, 1.0]))
+        j = int(rng.integers(0, ncam))
+        wc, wm = O.score_pnp(cams, K, X, obs[j], thr2=thr2)
+        gc, gm = ops.score_pnp(cu(cams), K, cu(X), cu(obs[j]), thr2, want_mask=True)
+        tag = f"score pnp ncam {ncam} npt {npt} thr2 {thr2}"
+    else:
+        n = int(np.exp(rng.uniform(0, np.log(8000)))); m = int(rng.integers(1, 11))
+        x1 = rng.uniform(-0.4, 0.4, (n, 2))
+        x2 = x1 + [0.05, 0.0] + rng.normal(0, float(rng.choice([0.0, 2e-4, 2e-3])), (n, 2))
+        E = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0.]])
+        Es = np.stack([E + rng.normal(0, sg, (3, 3)) for sg in rng.choice([0, 1e-4, 1e-3, 1e-2, 0.1], m)])
+        thr2 = np.float32((float(rng.choice([0.4, 1.0, 3.0])) / 1198.0) ** 2)
+        wc, wm = O.score_essential(Es, x1, x2, thr2)
+        gc, gm = ops.score_essential(cu(Es), cu(x1), cu(x2), thr2, want_mask=True)
+        tag = f"score essential n {n} models {m} thr2 {thr2}"
+    if not (np.array_equal(gc.cpu().numpy(), wc) and np.array_equal(gm.cpu().numpy(), wm)):
+        return tag + ": counts / masks differ"
+    return None
+
+
+FAMILIES = [("ransac", case_ransac, 5), ("tri", case_tri, 3), ("common", case_common, 2), ("resid", case_resid, 2), ("sweep", case_sweep, 2),
+            ("score", case_score, 2)]
 weights = np.array([w for _, _, w in FAMILIES], float); weights /= weights.sum()
 t0 = time.time(); counts = {n: 0 for n, _, _ in FAMILIES}; bad = 0
 O.lib(); sfm_mvs_amd.lib()
