@@ -665,6 +665,55 @@ class PairPipeline:
             st.synchronize()
 
 
+_PROBE_BUF = {}        # device index -> a 64 Mi-float scratch tensor for streams_overlap()
+_REJECTED_STREAMS = []  # streams independent_streams() turned down stay alive: destroying one hands its queue slot to the next creation
+
+
+def streams_overlap(a, b):
+    """Does work on stream `b` run beside work queued EARLIER on stream `a`?  HIP maps streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default) in
+    creation order; two streams on one queue execute strictly one after the other whatever their priorities.  Nothing in the API
+    tells which queue a stream got, so: a long elementwise kernel goes to `a`, then a one-wave kernel to `b` — if that one finishes
+    while the long one is still running, the streams are independent.  ~0.3 ms of device time."""
+    dev = a.device
+    buf = _PROBE_BUF.get(dev.index)
+    if buf is None:
+        buf = _PROBE_BUF[dev.index] = torch.zeros(1 << 26, dtype=torch.float32, device=dev)
+    small = buf[:64]
+    e0, ea, eb = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    torch.cuda.synchronize(dev)
+    with torch.cuda.stream(a):
+        e0.record(a)
+        buf[64:].mul_(1.0)
+        buf[64:].mul_(1.0)
+        ea.record(a)
+    with torch.cuda.stream(b):
+        small.mul_(1.0)
+        eb.record(b)
+    torch.cuda.synchronize(dev)
+    return e0.elapsed_time(eb) < 0.5 * e0.elapsed_time(ea)
+
+
+def release_probe_scratch(device):
+    """Give streams_overlap()'s 256 MB scratch tensor of this device back to the allocator."""
+    _PROBE_BUF.pop(torch.device(device).index, None)
+
+
+def independent_streams(count, device, priority=0, avoid=(), tries=16):
+    """`count` new streams that overlap with each other and with the streams in `avoid` (streams_overlap): candidates that landed
+    on a hardware queue already taken are set aside and another one is created, at most `tries` candidates in all (then the rest
+    are taken as they come).  One-time set-up, a few milliseconds; which streams a job runs on never changes its results."""
+    device = torch.device(device)
+    taken, out, made = list(avoid), [], 0
+    while len(out) < count:
+        s = torch.cuda.Stream(device=device, priority=priority)
+        made += 1
+        if made > tries or all(streams_overlap(t, s) and streams_overlap(s, t) for t in taken + out):     # (not symmetric when priorities differ)
+            out.append(s)
+        else:
+            _REJECTED_STREAMS.append(s)
+    return out
+
+
 class BatchPipeline:
     """Independent pairs of one shape, `batch` per launch set (BatchMatcher), launch sets pipelined over `depth` HIP streams.
     submit() queues a pair; the batch is launched on the next stream when it is full (or on flush()).  Results of launch

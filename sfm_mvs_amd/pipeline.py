@@ -149,10 +149,14 @@ def _sift_pipeline(w, h, dev, depth):
         if pipe is not None and id(pipe) not in _SIFT_PIPES_BUSY:
             _SIFT_PIPES_BUSY.add(id(pipe))
             return pipe
-    fresh = _sift.SiftPipeline(w, h, dev, depth=depth)
+    with _SIFT_PIPES_LOCK:
+        js = _SIFT_PIPES.get(("job streams", torch.device(dev).index, int(depth)))
+    # the cached pipeline of a size runs on the device's probed feature streams when they exist (_job_streams); a second,
+    # concurrent user's private pipeline gets streams of its own
+    fresh = _sift.SiftPipeline(w, h, dev, depth=depth, streams=js[0] if js is not None and pipe is None else None)
     with _SIFT_PIPES_LOCK:
         if pipe is None:                                  # first of its size: cache it (a handful of frame sizes at most)
-            for old in [k for k in _SIFT_PIPES if k[0] != "chain stream" and id(_SIFT_PIPES[k]) not in _SIFT_PIPES_BUSY][:max(0, len(_SIFT_PIPES) - 4)]:
+            for old in [k for k in _SIFT_PIPES if isinstance(k[0], int) and id(_SIFT_PIPES[k]) not in _SIFT_PIPES_BUSY][:max(0, len(_SIFT_PIPES) - 5)]:
                 _SIFT_PIPES.pop(old)
             _SIFT_PIPES[key] = fresh
         _SIFT_PIPES_BUSY.add(id(fresh))
@@ -162,6 +166,28 @@ def _sift_pipeline(w, h, dev, depth):
 def _sift_pipeline_done(pipe):
     with _SIFT_PIPES_LOCK:
         _SIFT_PIPES_BUSY.discard(id(pipe))
+
+
+def _job_streams(dev, depth):
+    """(feature streams [depth], chain stream) of this device, created ONCE and probed to reach different hardware queues
+    (ops.independent_streams).  HIP deals streams onto its few hardware queues in creation order and two streams on one queue run
+    one after the other: created late in a process that already made dozens of streams, the four streams of a from-pixels job
+    collide about every other time (the job then takes 78 instead of 63 ms: the chain's kernels queue behind a frame's).
+    Call it from the thread that owns the device context before any producer thread starts (the probe drains the device)."""
+    dev = torch.device(dev)
+    key = ("job streams", dev.index, int(depth))
+    with _SIFT_PIPES_LOCK:
+        js = _SIFT_PIPES.get(key)
+    if js is None:
+        # the chain's kernels are tiny and each is waited for by the host: on a HIGH-priority stream they are dispatched ahead
+        # of the feature streams' queued workgroups instead of behind them
+        chain = ops.independent_streams(1, dev, priority=-1)[0]
+        feat = ops.independent_streams(int(depth), dev, avoid=[chain])
+        ops.release_probe_scratch(dev)
+        js = (feat, chain)
+        with _SIFT_PIPES_LOCK:
+            js = _SIFT_PIPES.setdefault(key, js)
+    return js
 
 
 class FeatureStream:
@@ -183,6 +209,7 @@ class FeatureStream:
         self.small = [None] * len(images)             # the halved frames (HBM): colour lookup at the end of the run
         self._res, self._err, self._wanted, self._stop = {}, None, 1, False
         self._cv = threading.Condition()
+        self.chain_stream = _job_streams(self.dev, self.depth)[1]     # (made here, in the caller's thread: the probe drains the device)
         self._thread = threading.Thread(target=self._produce, name="sfm-feature-stream", daemon=True)
         self._thread.start()
 
@@ -281,12 +308,9 @@ def run_sfm_images(images, K, downscale=2, log=None, be=None, bundle_adjustment=
         # the product path: features are produced AHEAD of the sequential driver by a second host thread (FeatureStream)
         feats = FeatureStream(images, downscale)
         try:
-            # the chain's kernels are tiny and each is waited for by the host: on a HIGH-priority stream they are dispatched ahead
-            # of the feature streams' queued workgroups instead of behind them
+            # the chain runs on the device's probed high-priority stream, beside the feature streams (_job_streams)
             cur = torch.cuda.current_stream()
-            hp = _SIFT_PIPES.get(("chain stream", cur.device.index))     # (kept between runs for the same reason as the SIFT pipelines)
-            if hp is None:
-                hp = _SIFT_PIPES[("chain stream", cur.device.index)] = torch.cuda.Stream(priority=-1)
+            hp = feats.chain_stream
             hp.wait_stream(cur)
             with torch.cuda.stream(hp):
                 out = run_sfm(feats, K, images=feats.small, log=log, bundle_adjustment=bundle_adjustment, gtol_thresh=gtol_thresh)

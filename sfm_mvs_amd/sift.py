@@ -91,10 +91,18 @@ class SiftPipeline:
     on separate streams fill those gaps.  Results of submit() number i live in engine i % depth until submit() number
     i + depth reuses it."""
 
-    def __init__(self, width, height, device, depth=3, **params):
+    def __init__(self, width, height, device, depth=3, streams=None, **params):
         self.depth = int(depth)
         self.engines = [Sift(width, height, device, **params) for _ in range(self.depth)]
-        self.streams = [torch.cuda.Stream(device=device) for _ in range(self.depth)]
+        # `streams`: the caller's choice; by default streams probed to reach different hardware queues (two frames on one queue
+        # run one after the other: -2..4 % frames/s for a pair that collides; the probe is a few milliseconds of set-up)
+        if streams is None:
+            from . import ops
+            streams = ops.independent_streams(self.depth, device)
+            ops.release_probe_scratch(device)
+        self.streams = list(streams)
+        if len(self.streams) != self.depth:
+            raise ValueError("SiftPipeline: one stream per frame in flight")
         self.n = 0
 
     def submit(self, gray, after=None, want_descriptors=True):

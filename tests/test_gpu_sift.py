@@ -247,3 +247,20 @@ def test_feature_stream_abandoned_mid_sequence_does_not_hang(hip):
     assert len(list(fs2)) == 20
     fs2.close()
     assert not pl._SIFT_PIPES_BUSY
+
+
+def test_independent_streams_probe(hip):
+    """ops.independent_streams: the streams it returns run beside each other (ops.streams_overlap, both directions) — what the
+    from-pixels job needs of its chain stream and feature streams (a chain stream that shares a hardware queue with a feature
+    stream costs the job 20 %: profiles/r05_stream_lottery.txt, docs/measurement.md) — and a stream never overlaps itself."""
+    import torch
+    from sfm_mvs_amd import ops
+    dev = torch.device("cuda", 0)
+    chain = ops.independent_streams(1, dev, priority=-1)[0]
+    feat = ops.independent_streams(3, dev, avoid=[chain])
+    ops.release_probe_scratch(dev)
+    assert len(feat) == 3 and len({s.cuda_stream for s in feat + [chain]}) == 4
+    assert not ops.streams_overlap(chain, chain)                 # one queue: strictly in order
+    ok = sum(ops.streams_overlap(a, b) for a in feat + [chain] for b in feat + [chain] if a is not b)
+    assert ok >= 10, ok                                          # 12 ordered pairs; the probe itself is a timing measurement: allow two misses
+    ops.release_probe_scratch(dev)
