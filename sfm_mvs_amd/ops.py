@@ -678,8 +678,12 @@ def streams_overlap(a, b):
     buf = _PROBE_BUF.get(dev.index)
     if buf is None:
         buf = _PROBE_BUF[dev.index] = torch.zeros(1 << 26, dtype=torch.float32, device=dev)
+        buf[64:].mul_(1.0); buf[:64].mul_(1.0)        # (first launches load the code objects: not inside a timed probe)
     small = buf[:64]
     e0, ea, eb = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    for s in (a, b):                                  # a stream's hardware queue is set up at its FIRST use (0.3-5 ms): not inside the probe
+        with torch.cuda.stream(s):
+            small.mul_(1.0)
     torch.cuda.synchronize(dev)
     with torch.cuda.stream(a):
         e0.record(a)
