@@ -640,7 +640,7 @@ class PairPipeline:
     def __init__(self, nq, nt, device, ratio=0.70, depth=3, filter="auto"):
         self.depth = int(depth)
         self.matchers = [PairMatcher(nq, nt, device, ratio, filter=filter) for _ in range(self.depth)]
-        self.streams = [torch.cuda.Stream(device=device) for _ in range(self.depth)]
+        self.streams = _pipeline_streams(self.depth, device)
         self.n = 0
 
     def submit(self, des0, des1, after=None, result=None):
@@ -697,6 +697,13 @@ def streams_overlap(a, b):
     return e0.elapsed_time(eb) < 0.5 * e0.elapsed_time(ea)
 
 
+def _pipeline_streams(depth, device):
+    """The streams of a launch-set / pair pipeline: probed to reach different hardware queues (independent_streams)."""
+    st = independent_streams(depth, device) if depth > 1 else [torch.cuda.Stream(device=device)]
+    release_probe_scratch(device)
+    return st
+
+
 def release_probe_scratch(device):
     """Give streams_overlap()'s 256 MB scratch tensor of this device back to the allocator."""
     _PROBE_BUF.pop(torch.device(device).index, None)
@@ -726,7 +733,7 @@ class BatchPipeline:
     def __init__(self, nq, nt, device, ratio=0.70, depth=3, batch=4, filter="auto"):
         self.depth, self.batch = int(depth), int(batch)
         self.matchers = [BatchMatcher(nq, nt, device, ratio, batch, filter=filter) for _ in range(self.depth)]
-        self.streams = [torch.cuda.Stream(device=device) for _ in range(self.depth)]
+        self.streams = _pipeline_streams(self.depth, device)
         self.n = 0
         self._pairs, self._results, self._after = [], [], []
 
@@ -760,7 +767,7 @@ class BatchPipeline:
             if best is None or ms < best:
                 best, best_streams = ms, self.streams
             if len(seen) < tries:
-                self.streams = [torch.cuda.Stream(device=self.streams[0].device) for _ in range(self.depth)]
+                self.streams = _pipeline_streams(self.depth, self.streams[0].device)
         self.streams = best_streams
         return seen
 
