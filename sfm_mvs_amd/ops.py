@@ -722,6 +722,7 @@ def independent_streams(count, device, priority=0, avoid=(), tries=16):
             out.append(s)
         else:
             _REJECTED_STREAMS.append(s)
+            del _REJECTED_STREAMS[:-64]                       # (bounded: the oldest go back to the runtime)
     return out
 
 
@@ -730,10 +731,13 @@ class BatchPipeline:
     submit() queues a pair; the batch is launched on the next stream when it is full (or on flush()).  Results of launch
     set i live in matcher i % depth until launch set i + depth reuses it — or in the caller's `result` blocks."""
 
-    def __init__(self, nq, nt, device, ratio=0.70, depth=3, batch=4, filter="auto"):
+    def __init__(self, nq, nt, device, ratio=0.70, depth=3, batch=4, filter="auto", streams=None):
         self.depth, self.batch = int(depth), int(batch)
         self.matchers = [BatchMatcher(nq, nt, device, ratio, batch, filter=filter) for _ in range(self.depth)]
-        self.streams = _pipeline_streams(self.depth, device)
+        # `streams`: an owner of several pipelines (sharded.HipMatchEngine: one per pair shape) hands all of them the same set
+        self.streams = list(streams) if streams is not None else _pipeline_streams(self.depth, device)
+        if len(self.streams) != self.depth:
+            raise SfmHipError("BatchPipeline: one stream per launch set in flight")
         self.n = 0
         self._pairs, self._results, self._after = [], [], []
 

@@ -168,6 +168,7 @@ class HipMatchEngine:
     def __init__(self, device, ratio=0.70, depth=3, batch=8, max_shapes=4):
         self.device, self.ratio, self.depth, self.batch = torch.device(device), ratio, depth, batch
         self.pipes = {}                                    # (nq, nt) -> BatchPipeline, most recently used last
+        self._streams = None                               # ONE probed stream set for all of them (ops.independent_streams), made at first use
         self._padded = {}                                  # per pipe: blocks of queued pairs that are wider than nq
         # A pipeline owns depth x (workspace + outputs) for `batch` pairs of its shape (2 GB per launch set at 50k x 50k): a
         # sequence of real images has a different descriptor count per image, so only the `max_shapes` most recently used shapes
@@ -176,7 +177,7 @@ class HipMatchEngine:
 
     @property
     def streams(self):
-        return [st for p in self.pipes.values() for st in p.streams]
+        return list(self._streams or ())
 
     def match(self, des0, des1, block, after=None):
         """block: int32 [2][cap][2] view (cap >= nq) receiving (trainIdx x2, distance bits x2) of the nq queries.
@@ -198,7 +199,9 @@ class HipMatchEngine:
                 self._launch(old, self.pipes[old].flush())
                 self.pipes[old].synchronize()
                 del self.pipes[old], self._padded[old]
-            pipe = ops.BatchPipeline(nq, nt, self.device, ratio=self.ratio, depth=self.depth, batch=self.batch)
+            if self._streams is None:
+                self._streams = ops._pipeline_streams(self.depth, self.device)
+            pipe = ops.BatchPipeline(nq, nt, self.device, ratio=self.ratio, depth=self.depth, batch=self.batch, streams=self._streams)
             self._padded[key] = []
         self.pipes[key] = pipe                             # (re-inserted: most recently used)
         direct = block.shape[1] == nq and block.is_contiguous()
