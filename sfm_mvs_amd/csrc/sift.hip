@@ -405,51 +405,81 @@ __device__ bool adjust_local_extrema(const float* __restrict__ dog, int w, int h
     return true;
 }
 
-// tiles of 64 x 4 pixels of the bordered interior, nL layers per octave, all octaves in one launch
+// tiles of 64 x 16 pixels of the bordered interior, nL layers per octave, all octaves in one launch
+constexpr int kExtRows = 4;                                   // rows per thread (a wave: 64 columns x 4 rows; a workgroup: 64 x 16)
 __device__ __host__ inline int extrema_tiles(const Geom& g, int o) {
     const int iw = g.w(o) - 2 * kImgBorder, ih = g.h(o) - 2 * kImgBorder;
-    return iw > 0 && ih > 0 ? ((iw + 63) / 64) * ((ih + 3) / 4) * g.nL : 0;
+    return iw > 0 && ih > 0 ? ((iw + 63) / 64) * ((ih + 4 * kExtRows - 1) / (4 * kExtRows)) * g.nL : 0;
 }
 
+// A pixel is an extremum when it is >= (<=) all 26 neighbours, i.e. >= their MAXIMUM (<= their minimum): comparisons are
+// exact, so max3 / min3 trees give the sequential test's answer with a quarter of its instructions.  A thread takes four
+// consecutive rows of one column: the 3-wide row maxima / minima of the six rows it touches (three planes) are formed once
+// and shared by its four pixels — 13.5 loads and ~20 vector instructions per pixel instead of 27 and ~100 (53 -> 32 us
+// per 968 x 648 frame).  Tiles whose pixels are all below the threshold read their centre values only.
 __global__ __launch_bounds__(256) void extrema_kernel(Geom geo, int threshold, int4* __restrict__ raw, int raw_cap, int* __restrict__ counters) {
     int o = 0, t = blockIdx.x;
     for (;; ++o) { const int k = extrema_tiles(geo, o); if (t < k) break; t -= k; }
     const int w = geo.w(o), h = geo.h(o);
-    const int tx = (w - 2 * kImgBorder + 63) / 64, ty = (h - 2 * kImgBorder + 3) / 4;
+    const int tx = (w - 2 * kImgBorder + 63) / 64, ty = (h - 2 * kImgBorder + 4 * kExtRows - 1) / (4 * kExtRows);
     const int layer = 1 + t / (tx * ty);
     t -= (layer - 1) * tx * ty;
     const int lane = threadIdx.x & 63;
-    const int c = kImgBorder + (t % tx) * 64 + lane, r = kImgBorder + (t / tx) * 4 + (threadIdx.x >> 6);
-    bool ext = false;
-    if (c < w - kImgBorder && r < h - kImgBorder) {
-        const size_t plane = geo.plane(o);
-        const float* img = geo.D(o, 0) + plane * layer + (size_t)r * w + c;
-        const float val = img[0];
-        if (fabsf(val) > (float)threshold) {
-            bool is_max = val > 0, is_min = val < 0;
+    const int c = kImgBorder + (t % tx) * 64 + lane, r0 = kImgBorder + (t / tx) * (4 * kExtRows) + (threadIdx.x >> 6) * kExtRows;
+    const size_t plane = geo.plane(o);
+    const bool live = c < w - kImgBorder && r0 < h - kImgBorder;      // (then rows r0 - 1 .. r0 + 4 and columns c +- 1 are inside the plane)
+    const float* img = geo.D(o, 0) + plane * layer + (size_t)r0 * w + c;
+    float val[kExtRows];
+    bool cand[kExtRows], ext[kExtRows];
+    bool some = false;
 #pragma unroll
-            for (int dl = -1; dl <= 1; ++dl)
-#pragma unroll
-                for (int dr = -1; dr <= 1; ++dr)
-#pragma unroll
-                    for (int dc = -1; dc <= 1; ++dc) {
-                        const float v = img[(long)dl * (long)plane + dr * w + dc];
-                        is_max = is_max && val >= v;
-                        is_min = is_min && val <= v;
-                    }
-            ext = is_max || is_min;
-        }
+    for (int k = 0; k < kExtRows; ++k) {
+        val[k] = live ? img[k * w] : 0.f;
+        cand[k] = live && r0 + k < h - kImgBorder && fabsf(val[k]) > (float)threshold;
+        ext[k] = false;
+        some |= cand[k];
     }
-    // The raw list is kRawSegs independent segments, each with its own counter on its own cache line: tens of
-    // thousands of atomics on ONE address serialise in L2 (they, not the 27 loads, bounded this kernel: 250 us).
-    const unsigned long long bal = __ballot(ext);
-    if (bal) {                                                                  // wave-uniform: one atomic per wave
-        const int seg = blockIdx.x % kRawSegs, seg_cap = raw_cap / kRawSegs;
-        int base = 0;
-        if (lane == 0) base = atomicAdd(&counters[kCntRawSeg + seg * kSegStride], __popcll(bal));
-        base = __shfl(base, 0);
-        const int at = base + __popcll(bal & ((1ull << lane) - 1ull));
-        if (ext && at < seg_cap) raw[(size_t)seg * seg_cap + at] = make_int4(o, layer, r, c);
+    if (__any(some)) {
+        if (live) {
+            float mx[3][kExtRows + 2], mn[3][kExtRows + 2], sx[kExtRows + 2], sn[kExtRows + 2];   // row maxima / minima; own plane: without the centre
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int q = 0; q < kExtRows + 2; ++q) {
+                    const float* row = img + (long)(p - 1) * (long)plane + (q - 1) * w;
+                    const float a = row[-1], b = row[0], d = row[1];
+                    mx[p][q] = fmaxf(fmaxf(a, b), d);
+                    mn[p][q] = fminf(fminf(a, b), d);
+                    if (p == 1) { sx[q] = fmaxf(a, d); sn[q] = fminf(a, d); }
+                }
+#pragma unroll
+            for (int k = 0; k < kExtRows; ++k) {
+                const float hi = fmaxf(fmaxf(fmaxf(fmaxf(mx[0][k], mx[0][k + 1]), mx[0][k + 2]), fmaxf(fmaxf(mx[2][k], mx[2][k + 1]), mx[2][k + 2])),
+                                       fmaxf(fmaxf(mx[1][k], sx[k + 1]), mx[1][k + 2]));
+                const float lo = fminf(fminf(fminf(fminf(mn[0][k], mn[0][k + 1]), mn[0][k + 2]), fminf(fminf(mn[2][k], mn[2][k + 1]), mn[2][k + 2])),
+                                       fminf(fminf(mn[1][k], sn[k + 1]), mn[1][k + 2]));
+                ext[k] = cand[k] && ((val[k] > 0 && val[k] >= hi) || (val[k] < 0 && val[k] <= lo));
+            }
+        }
+        // The raw list is kRawSegs independent segments, each with its own counter on its own cache line: tens of
+        // thousands of atomics on ONE address serialise in L2 (they, not the loads, bounded the first version: 250 us).
+        unsigned long long bal[kExtRows];
+        int total = 0, below = 0;
+#pragma unroll
+        for (int k = 0; k < kExtRows; ++k) {
+            bal[k] = __ballot(ext[k]);
+            total += __popcll(bal[k]);
+            below += __popcll(bal[k] & ((1ull << lane) - 1ull));
+        }
+        if (total) {                                                                // wave-uniform: one atomic per wave
+            const int seg = blockIdx.x % kRawSegs, seg_cap = raw_cap / kRawSegs;
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&counters[kCntRawSeg + seg * kSegStride], total);
+            int at = __shfl(base, 0) + below;
+#pragma unroll
+            for (int k = 0; k < kExtRows; ++k)
+                if (ext[k]) { if (at < seg_cap) raw[(size_t)seg * seg_cap + at] = make_int4(o, layer, r0 + k, c); ++at; }
+        }
     }
 }
 
