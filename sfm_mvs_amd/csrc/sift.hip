@@ -483,6 +483,8 @@ __global__ __launch_bounds__(256) void extrema_kernel(Geom geo, int threshold, i
     }
 }
 
+constexpr int kDescGrid = 8192;       // workgroups of descriptor_kernel: one keypoint per wave up to 32 768 keypoints, strided beyond
+constexpr int kOriGrid = 2048;        // workgroups of orientation_kernel: 8 192 waves = every wave slot of the chip once
 constexpr int kRawPerKeypoint = 8;   // capacity of the raw-extrema list (before contrast / edge rejection) per keypoint slot
 
 // sub-pixel refinement, contrast and edge tests of the raw extrema: one lane each
@@ -490,10 +492,14 @@ __global__ __launch_bounds__(256) void refine_kernel(Geom geo, const int4* __res
                                                      float sigma, Cand* __restrict__ cand, int* __restrict__ counters, int cap) {
     const int seg_cap = raw_cap / kRawSegs;
     const int id = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
-    const int seg = id / seg_cap, at = id - seg * seg_cap;
+    // thread -> (segment, slot) INTERLEAVED (id = slot * kRawSegs + segment): the filled slots of all 64 segments are then the
+    // first ids of the grid — the workgroups that have work start at once and the (many) empty ones behind them only return;
+    // segment-major, each segment's two busy workgroups sat in front of its 62 empty ones and the last segment's started
+    // after the whole grid had been dispatched
+    const int seg = id % kRawSegs, at = id / kRawSegs;
     bool ok = false;
     Cand k;
-    if (seg < kRawSegs) {
+    if (at < seg_cap) {
         const int cnt = counters[kCntRawSeg + seg * kSegStride];
         if (at == 0) { atomicAdd(&counters[3], cnt); if (cnt > seg_cap) atomicMax(&counters[4], cnt); }   // totals for the caller
         if (at < min(cnt, seg_cap)) {
@@ -544,9 +550,10 @@ __global__ __launch_bounds__(256) void orientation_kernel(Geom geo, const Cand* 
     __shared__ __attribute__((aligned(16))) unsigned char sbin[4][kOriChunk];      // 255 = no sample
     __shared__ float shist[4][kOriBins + 4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int id = blockIdx.x * 4 + wave;
     const int ncand = min(counters[0], cap);
-    if (id >= ncand) return;
+    // The grid is a FIXED number of workgroups and a wave strides over the candidates: sized for `cap` (the host does not
+    // know the count), 32 768 workgroups of which nine in ten only return took 56 us to dispatch — as long as the work.
+    for (int id = blockIdx.x * 4 + wave; id < ncand; id += gridDim.x * 4) {
     const Cand k = cand[id];
     const int w = geo.w(k.o), h = geo.h(k.o);
     const float2* grad = geo.grad + geo.moff(k.o, k.layer);
@@ -624,6 +631,8 @@ __global__ __launch_bounds__(256) void orientation_kernel(Geom geo, const Cand* 
             float* q = kp_raw + ((size_t)seg * seg_cap + slot) * 8;
             q[0] = k.x; q[1] = k.y; q[2] = k.size; q[3] = angle; q[4] = k.response; q[5] = __int_as_float(k.octave); q[6] = __int_as_float(-1); q[7] = 0.f;
         }
+    }
+    __builtin_amdgcn_wave_barrier();                              // (the wave's LDS rows are reused by its next candidate)
     }
 }
 
@@ -824,12 +833,12 @@ __global__ __launch_bounds__(1024) void dedupe_kernel(const float* __restrict__ 
 constexpr int kDescBinsUsed = kDescBins + 1;   // o0 in 0..7 writes bins o0 and o0+1: bin 9 of the 10 stays zero
 constexpr int kDescLdsFloats = 4 * (16 * kDescBinsUsed + 128);   // per wave: the 16 cells' bins, then the keypoint's 128 raw values
 __device__ __forceinline__ void descriptor_cells(const Geom& geo, const float* __restrict__ kp, int nkp, const int* __restrict__ perm,
-                                                 float* __restrict__ desc, float* sbuf) {
+                                                 float* __restrict__ desc, float* sbuf, int wg /* the workgroup's number in the list: keypoints 4 wg .. 4 wg + 3 */) {
     float (*shist)[16 * kDescBinsUsed] = reinterpret_cast<float (*)[16 * kDescBinsUsed]>(sbuf);
     float (*sdst)[128] = reinterpret_cast<float (*)[128]>(sbuf + 4 * 16 * kDescBinsUsed);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, cell = lane >> 2, sub = lane & 3;
-    if ((int)blockIdx.x * 4 >= nkp) return;                     // whole workgroup
-    const int slot = blockIdx.x * 4 + wave;
+    if (wg * 4 >= nkp) return;                     // whole workgroup
+    const int slot = wg * 4 + wave;
     const bool have = slot < nkp;                               // (the last workgroup's idle waves still meet the barrier below)
     const int id = perm[have ? slot : nkp - 1];                 // largest windows first
     const int d = kDescWidth, n = kDescBins;
@@ -938,20 +947,30 @@ __device__ __forceinline__ void descriptor_cells(const Geom& geo, const float* _
     nrm2 = 0.f;
     for (int k = 0; k < len; ++k) { const float v = fminf(dk[k], thr); nrm2 += v * v; }
     const float mul = kIntDescrFctr / fmaxf(sqrtf(nrm2), FLT_EPSILON);
-    if ((int)blockIdx.x * 4 + kq < nkp) {
+    if (wg * 4 + kq < nkp) {
         float out[kDescBins];
 #pragma unroll
         for (int k = 0; k < kDescBins; ++k) { const int iv = cv_round(fminf(dk[l16 * kDescBins + k], thr) * mul); out[k] = (float)(iv < 0 ? 0 : iv > 255 ? 255 : iv); }
-        float4* o4 = reinterpret_cast<float4*>(desc + (size_t)perm[blockIdx.x * 4 + kq] * 128 + l16 * kDescBins);
+        float4* o4 = reinterpret_cast<float4*>(desc + (size_t)perm[wg * 4 + kq] * 128 + l16 * kDescBins);
         o4[0] = make_float4(out[0], out[1], out[2], out[3]);
         o4[1] = make_float4(out[4], out[5], out[6], out[7]);
     }
 }
 
+// The grid is at most kDescGrid workgroups (the host does not know the count and `cap` is generous: dispatching 32 768 workgroups
+// that only return takes ~50 us, a floor under every small frame): one keypoint per wave for the first 4 kDescGrid keypoints;
+// a second, small launch (kRest) strides over what is beyond them and returns at once on ordinary frames.
+template <bool kRest>
 __global__ __launch_bounds__(256) void descriptor_kernel(Geom geo, const float* __restrict__ kp, const int* __restrict__ counters, int cap,
                                                          const int* __restrict__ perm, float* __restrict__ desc) {
     __shared__ float sbuf[kDescLdsFloats];
-    descriptor_cells(geo, kp, min(counters[2], cap), perm, desc, sbuf);
+    const int nkp = min(counters[2], cap);
+    if (!kRest) descriptor_cells(geo, kp, nkp, perm, desc, sbuf, blockIdx.x);
+    else
+        for (int wg = kDescGrid + blockIdx.x; wg * 4 < nkp; wg += gridDim.x) {
+            descriptor_cells(geo, kp, nkp, perm, desc, sbuf, wg);
+            __syncthreads();                                    // (the workgroup's LDS is reused by its next four keypoints)
+        }
 }
 
 int gauss_taps(double sigma, Taps* t) {   // getGaussianKernel(cvRound(sigma*8+1)|1, sigma, CV_32F)
@@ -1137,7 +1156,7 @@ extern "C" int sfm_sift_detect_and_compute(const uint8_t* gray, int64_t w, int64
         hipLaunchKernelGGL(gradient_kernel, dim3((unsigned)((grad_px + 255) / 256)), dim3(256), 0, stream, geo);
         SFM_CHECK_LAUNCH();
     }
-    const unsigned wave_blocks = (unsigned)((cap + 3) / 4);
+    const unsigned wave_blocks = (unsigned)std::min((cap + 3) / 4, kOriGrid);
     hipLaunchKernelGGL(orientation_kernel, dim3(wave_blocks), dim3(256), 0, stream, geo, (const Cand*)cand, counters, cap, kp_raw);
     SFM_CHECK_LAUNCH();
     hipLaunchKernelGGL(bucket_scatter_kernel, dim3((unsigned)((cap + 255) / 256)), dim3(256), 0, stream, (const float*)kp_raw, counters, cap, geo.W0,
@@ -1150,9 +1169,14 @@ extern "C" int sfm_sift_detect_and_compute(const uint8_t* gray, int64_t w, int64
     SFM_CHECK_LAUNCH();
     if (descriptors) {
         sfm::prof_begin(sfm::kProfSiftDescriptor, stream);
-        hipLaunchKernelGGL(descriptor_kernel, dim3((unsigned)((cap + 3) / 4)), dim3(256), 0, stream, geo, (const float*)keypoints, (const int*)counters, cap,
-                           (const int*)perm, descriptors);
+        hipLaunchKernelGGL(descriptor_kernel<false>, dim3((unsigned)std::min((cap + 3) / 4, kDescGrid)), dim3(256), 0, stream, geo,
+                           (const float*)keypoints, (const int*)counters, cap, (const int*)perm, descriptors);
         SFM_CHECK_LAUNCH();
+        if ((cap + 3) / 4 > kDescGrid) {
+            hipLaunchKernelGGL(descriptor_kernel<true>, dim3(2048), dim3(256), 0, stream, geo, (const float*)keypoints, (const int*)counters, cap,
+                               (const int*)perm, descriptors);
+            SFM_CHECK_LAUNCH();
+        }
         sfm::prof_end(sfm::kProfSiftDescriptor, stream);
     }
     return SFM_OK;
