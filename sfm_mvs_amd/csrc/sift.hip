@@ -678,8 +678,8 @@ __global__ __launch_bounds__(256) void bucket_scatter_kernel(const float* __rest
     bucket_starts(counters, start);
     const int seg_cap = cap / kRawSegs;
     const int id = blockIdx.x * 256 + threadIdx.x;
-    const int seg = id / max(seg_cap, 1), at = id - seg * seg_cap;
-    if (seg >= kRawSegs || seg_cap == 0) return;
+    const int seg = id % kRawSegs, at = id / kRawSegs;           // interleaved, as in refine_kernel: the filled slots are the grid's first ids
+    if (at >= seg_cap) return;
     const int cnt = counters[kCntKpSeg + seg * kSegStride];
     if (at == 0) { atomicAdd(&counters[1], min(cnt, seg_cap)); if (cnt > seg_cap) atomicMax(&counters[5], cnt); }   // dense count for the next kernels
     if (at >= min(cnt, seg_cap)) return;
