@@ -5,10 +5,10 @@
 //
 // Everything is stream-ordered device work; nothing is copied to the host:
 //   upsample 2x (u8 -> f32, bilinear) -> per octave { fused separable Gaussian (LDS tile, rows then columns) that also
-//   emits the DoG plane; 2x decimation is a stride-2 read of the next octave's first blur } -> extrema of all octaves (one lane per pixel, raw list) -> sub-pixel
+//   emits the DoG plane; 2x decimation is a stride-2 read of the next octave's first blur } -> extrema of all octaves (one lane per column and four rows, raw list) -> sub-pixel
 //   refinement (one lane per raw extremum) -> gradient (magnitude, orientation) planes -> orientation histograms (one
 //   wave per extremum) -> x-bucketed ranking in OpenCV's keypoint order + duplicate removal (ordered compaction) ->
-//   descriptors (sixteen lanes per keypoint, one per histogram cell).
+//   descriptors (one wave per keypoint, four lanes per histogram cell).
 //
 // Arithmetic contract: float32 operations in the order of the sequential algorithm (oracle/sift_oracle.c restates
 // it), no contraction (-ffp-contract=off), IEEE divide/sqrt, and fixed polynomial programs for exp / sincos / atan2,
