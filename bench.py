@@ -54,6 +54,7 @@ CLOCK_WARMUP_STEPS = 1600 // PAIR_BATCH   # untimed launch sets (~60 ms of load)
 SPLIT_MFMA_PER_TILE, F32_MFMA_PER_TILE = 24, 65
 FLOP_PER_DISTANCE = 256           # GEMM form 2*D
 HBM_PEAK_GBS = 8000.0
+CPU_BASELINE_SECONDS = 4.0         # wall time of the all-cores oracle sample (cores x 4 s of CPU work)
 FP64_VALU_PEAK_TFLOPS = 78.6
 
 
@@ -152,7 +153,7 @@ def max_over_ranks(x, world, dev):
 
 
 def cpu_knn_baseline(nq, nt, seed_q, seed_t):
-    """Oracle (kind 'port') on all host cores, bounded to roughly 10-30 s."""
+    """Oracle (kind 'port') on all host cores, bounded to ~5 s of wall time (the default run must stay short)."""
     from oracle import oracle as O
     cores = os.cpu_count() or 1
     q = torch.rand((nq, 128), generator=torch.Generator().manual_seed(seed_q)).numpy()
@@ -161,8 +162,8 @@ def cpu_knn_baseline(nq, nt, seed_q, seed_t):
     t0 = time.perf_counter()
     O.knn2(q[:probe], t, nthreads=cores)
     rate = probe * nt / (time.perf_counter() - t0)
-    rows = int(min(nq, max(probe, rate * 12.0 / nt)))
-    passes = max(1, int(round(rate * 12.0 / (rows * nt))))          # ~12 s of CPU work in total
+    rows = int(min(nq, max(probe, rate * CPU_BASELINE_SECONDS / nt)))
+    passes = max(1, int(round(rate * CPU_BASELINE_SECONDS / (rows * nt))))
     t0 = time.perf_counter()
     for _ in range(passes):
         O.knn2(q[:rows], t, nthreads=cores)
@@ -1493,6 +1494,93 @@ def bench_dry_run(args, world, rank):
     return out
 
 
+COMPACT_MAX = 5500                 # bytes of the ONE stdout line (the driver keeps an 8 KB tail of stdout + stderr: round 5's 22.5 KB line was not parsed)
+FULL_JSON = os.path.join(ROOT, "gpurun_out", "bench_full.json")
+
+
+def _finite(x):
+    """Strict JSON: NaN / Infinity become null."""
+    if isinstance(x, float):
+        return x if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {str(k): _finite(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_finite(v) for v in x]
+    if isinstance(x, (np.floating, np.integer)):
+        return _finite(x.item())
+    return x
+
+
+def _sig(x, n=6):
+    """Numbers to n significant digits (the compact line only; the full record keeps every digit)."""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    return float(f"{x:.{n}g}")
+
+
+def _clip(s, n):
+    return s if not isinstance(s, str) or len(s) <= n else s[:n - 3].rstrip() + "..."
+
+
+def _pick(d, keys, clip=120):
+    return {k: _clip(_sig(d[k]), clip) for k in keys if isinstance(d, dict) and k in d}
+
+
+def compact_line(out):
+    """The ONE stdout line: the contract's fields + `roofline` + `cpu_baseline`, numbers and short labels only.
+    Everything else — `extra`, variants, notes — goes to gpurun_out/bench_full.json.  Always < COMPACT_MAX bytes: optional
+    blocks are dropped, last first, until it fits."""
+    top = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "data", "dry_run")
+    c = {k: _clip(_sig(out[k], 10), 160) for k in top if k in out}
+    c["dtype"] = _clip(out.get("dtype"), 200)
+    cfg = out.get("config") or {}
+    c["config"] = _pick(cfg, ("workload",), clip=330)
+    c["config"].update(_pick(cfg, ("nq", "nt", "dim", "pairs_per_step", "images", "descriptors", "pairs", "frame", "working_size", "cameras", "points", "observations",
+                                   "backend", "launched_by", "cold_value", "general_float_value", "rccl_ranks"), clip=80))
+    c["config"].update(_pick(cfg, ("parallelism",), clip=240))
+    for k in ("exchange", "partition"):
+        if k in cfg:
+            c["config"][k] = cfg[k]
+    if isinstance(cfg.get("secondary"), dict):
+        c["config"]["secondary"] = {k: _sig(v) for k, v in cfg["secondary"].items() if not isinstance(v, str)}
+    if isinstance(out.get("roofline"), dict):
+        c["roofline"] = _pick(out["roofline"], ("bound", "achieved", "peak", "unit", "frac", "frac_step", "frac_of_sustained", "traffic", "algorithmic_bytes_per_launch",
+                                                 "algorithmic_bytes", "kernel", "avg_launch_ms", "launches"), clip=100)
+    if isinstance(out.get("cpu_baseline"), dict):
+        cb = out["cpu_baseline"]
+        c["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind"), clip=40)
+        c["cpu_baseline"]["sample"] = _clip(cb.get("sample"), 260)
+        c["cpu_baseline"].update(_pick(cb, ("one_thread_distances_per_sec", "torch_cdist_topk_distances_per_sec", "cpu_model"), clip=60))
+        c["cpu_baseline"]["opencv"] = _pick(cb["opencv"], ("value", "unit", "kind", "version", "threads")) if isinstance(cb.get("opencv"), dict) else None
+    for k in ("exchange", "parity", "job_seconds", "kernels_ms", "cold_value", "cold_ms_per_step"):      # small, optional: dropped first if the line is too long
+        if k in out:
+            v = out[k]
+            c[k] = {kk: _sig(vv) for kk, vv in v.items() if not isinstance(vv, (str, dict, list))} if isinstance(v, dict) else _sig(v)
+    c["full_record"] = "gpurun_out/bench_full.json"
+    c = _finite(c)
+    for drop in ("kernels_ms", "parity", "exchange", "cold_ms_per_step", "cold_value", "job_seconds"):
+        if len(json.dumps(c, allow_nan=False)) < COMPACT_MAX:
+            break
+        c.pop(drop, None)
+    if len(json.dumps(c, allow_nan=False)) >= COMPACT_MAX:
+        c["config"].pop("secondary", None)
+    line = json.dumps(c, allow_nan=False)
+    assert len(line) < COMPACT_MAX and "\n" not in line, len(line)
+    return line
+
+
+def emit(out, json_fd):
+    """Full record -> gpurun_out/bench_full.json (never stdout / stderr: the driver's 8 KB tail holds both); compact line -> stdout."""
+    try:
+        os.makedirs(os.path.dirname(FULL_JSON), exist_ok=True)
+        with open(FULL_JSON, "w") as f:
+            json.dump(_finite(out), f, indent=1, allow_nan=False)
+            f.write("\n")
+    except OSError as e:
+        print(f"[bench] could not write {FULL_JSON}: {e}", file=sys.stderr)
+    os.write(json_fd, (compact_line(out) + "\n").encode())
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -1508,7 +1596,7 @@ def main():
         out = bench_dry_run(args, world, rank)
         import torch.distributed as dist
         if rank == 0:
-            os.write(json_fd, (json.dumps(out) + "\n").encode())
+            emit(out, json_fd)
         dist.destroy_process_group()
         return
     world, rank, local = init_dist(args)
@@ -1560,7 +1648,7 @@ def main():
     else:
         out = bench_ba(args, world, rank, dev)
     if rank == 0:
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        emit(out, json_fd)
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
