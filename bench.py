@@ -159,15 +159,17 @@ def cpu_knn_baseline(nq, nt, seed_q, seed_t):
     q = torch.rand((nq, 128), generator=torch.Generator().manual_seed(seed_q)).numpy()
     t = torch.rand((nt, 128), generator=torch.Generator().manual_seed(seed_t)).numpy()
     probe = min(nq, 64 * cores)
+    O.knn2(q[:probe], t, nthreads=cores)                     # (first call: thread pool start-up, page faults)
     t0 = time.perf_counter()
     O.knn2(q[:probe], t, nthreads=cores)
     rate = probe * nt / (time.perf_counter() - t0)
     rows = int(min(nq, max(probe, rate * CPU_BASELINE_SECONDS / nt)))
-    passes = max(1, int(round(rate * CPU_BASELINE_SECONDS / (rows * nt))))
+    passes, dt = 0, 0.0
     t0 = time.perf_counter()
-    for _ in range(passes):
+    while dt < CPU_BASELINE_SECONDS and passes < 1000:       # whole passes until the time budget is spent
         O.knn2(q[:rows], t, nthreads=cores)
-    dt = time.perf_counter() - t0
+        passes += 1
+        dt = time.perf_counter() - t0
     out = {"value": passes * rows * nt / dt, "unit": "distances/s", "cores": cores, "kind": "port",
            "sample": f"{passes} pass(es) over the first {rows} of {nq} query rows x {nt} train rows of the same synthetic "
                      f"set, oracle orc_knn2_l2_f32 (direct-form f32, OpenMP over query rows, {cores} threads), {dt:.1f} s"}

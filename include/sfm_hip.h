@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SFM_ABI_VERSION 2
+#define SFM_ABI_VERSION 3   /* 3 (round 6): + sfm_host_poll_count, sfm_debug_pnp_sweep_server; sfm_build_id() names every source file */
 
 #define SFM_OK             0
 #define SFM_ERR_ARG       -1   /* null pointer, negative size, unsupported dim, misaligned pointer/stride */
@@ -543,6 +543,13 @@ int64_t sfm_host_sync_count(void);
  * [1..7] copy-in, EPnP hypotheses (host), scoring + wait, mask / inlier bookkeeping, DLT initialisation, LM sweeps (device +
  * wait), LM host algebra; [8] hypothesis chunks, [9] LM sweeps.  reset != 0 clears the accumulators. */
 int sfm_pnp_profile_read(double* out10_host, int reset);
+/* sfm_solve_pnp_ransac's Levenberg-Marquardt sweeps are answered by ONE resident workgroup per call (the "sweep server",
+ * csrc/ransac.hip) that the host drives through its pinned mailbox instead of a launch + stream synchronisation per sweep.
+ * sfm_host_poll_count: spins of the host's waiting loop since load (a measure of time spent waiting on the mailbox, not of API
+ * calls; those waits do NOT count in sfm_host_sync_count).  sfm_debug_pnp_sweep_server(0) selects the launch-per-sweep path
+ * (A/B measurements, parity tests of one path against the other), (1) the server (default); returns the previous setting. */
+int64_t sfm_host_poll_count(void);
+int sfm_debug_pnp_sweep_server(int on);
 
 #ifdef __cplusplus
 }

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SFM_HIP_LIB") or os.path.join(_HERE, "lib", "libsfmhip.so")   # (the override is a dev switch for A/B runs of two builds:
 #                                                                                          whichever binary is loaded names itself — build_id())
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class SfmHipError(RuntimeError):
@@ -92,6 +92,8 @@ SIGNATURES = {
     "sfm_profile_enable": (_int, [_int]),
     "sfm_host_sync_count": (_i64, []),
     "sfm_pnp_profile_read": (_int, [_c.POINTER(_f64), _int]),
+    "sfm_host_poll_count": (_i64, []),
+    "sfm_debug_pnp_sweep_server": (_int, [_int]),
     "sfm_debug_set_trace": (_int, [_vp]),
     "sfm_profile_read": (_int, [_int, _c.POINTER(_f64), _c.POINTER(_i64)]),
 }
@@ -110,13 +112,19 @@ def lib():
             "Run `python -c 'import __graft_entry__ as g; g.build()'` (or `make -C sfm_mvs_amd/csrc`). "
             "There is no CPU fallback for the hot path.")
     handle = ctypes.CDLL(LIB_PATH)
-    for name, (res, args) in SIGNATURES.items():
-        fn = getattr(handle, name)  # AttributeError here = header/library mismatch
-        fn.restype = res
-        fn.argtypes = args
+    # the version first: a stale library must say "rebuild", not fail on the first symbol it lacks
+    handle.sfm_abi_version.restype = _int
+    handle.sfm_abi_version.argtypes = []
     got = handle.sfm_abi_version()
     if got != ABI_VERSION:
-        raise ImportError(f"libsfmhip.so ABI {got} != binding ABI {ABI_VERSION}; rebuild")
+        raise ImportError(f"{LIB_PATH}: ABI {got} != binding ABI {ABI_VERSION}; rebuild (python -c 'import __graft_entry__ as g; g.build()')")
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError as e:
+            raise ImportError(f"{LIB_PATH} (ABI {got}) does not export {name}: header / library mismatch; rebuild") from e
+        fn.restype = res
+        fn.argtypes = args
     _lib = handle
     return _lib
 

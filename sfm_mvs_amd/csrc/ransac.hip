@@ -21,6 +21,9 @@
 #include "common.h"
 #include "host_solvers.h"
 #include <algorithm>
+#include <atomic>
+#include <cfloat>
+#include <cstring>
 #include <chrono>
 #include <cstdlib>
 #include <utility>
@@ -65,6 +68,55 @@ struct PnpCam {
 constexpr int kSweepAcc = 28;        // 21 + 6 + 1
 constexpr int kSweepThreads = 1024, kSweepMaxBlocks = 64;
 
+// one correspondence's terms added to a lane's 28 running sums (shared by the launch-per-sweep kernel and the sweep server)
+template <int MODE>
+__device__ __forceinline__ void pnp_sweep_point(const PnpCam& cam, const float* __restrict__ X, const float* __restrict__ uv, int64_t i,
+                                                double (&acc)[kSweepAcc]) {
+    const double Xw = X[3 * i], Yw = X[3 * i + 1], Zw = X[3 * i + 2];
+    double x = cam.R[0] * Xw + cam.R[1] * Yw + cam.R[2] * Zw + cam.t[0];
+    double y = cam.R[3] * Xw + cam.R[4] * Yw + cam.R[5] * Zw + cam.t[1];
+    double z = cam.R[6] * Xw + cam.R[7] * Yw + cam.R[8] * Zw + cam.t[2];
+    z = z != 0.0 ? 1. / z : 1.;
+    x *= z;
+    y *= z;
+    const double ru = (x * cam.fx + cam.cx) - (double)uv[2 * i], rv = (y * cam.fy + cam.cy) - (double)uv[2 * i + 1];
+    acc[27] += ru * ru + rv * rv;
+    if (MODE == 1) {
+        double Ju[6], Jv[6];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const double* d = cam.dR + 9 * j;
+            const double dx0 = Xw * d[0] + Yw * d[1] + Zw * d[2];
+            const double dy0 = Xw * d[3] + Yw * d[4] + Zw * d[5];
+            const double dz0 = Xw * d[6] + Yw * d[7] + Zw * d[8];
+            Ju[j] = cam.fx * (z * (dx0 - x * dz0));
+            Jv[j] = cam.fy * (z * (dy0 - y * dz0));
+        }
+        Ju[3] = cam.fx * z; Ju[4] = 0;          Ju[5] = cam.fx * (-x * z);
+        Jv[3] = 0;          Jv[4] = cam.fy * z; Jv[5] = cam.fy * (-y * z);
+        int q = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = a; b < 6; ++b) acc[q++] += Ju[a] * Ju[b] + Jv[a] * Jv[b];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) acc[21 + a] += Ju[a] * ru + Jv[a] * rv;
+    }
+}
+
+// a lane's sums -> its wave's (butterfly v[l] += v[l ^ s], s = 32 .. 1) -> wacc[wave][k]
+template <int KFIRST>
+__device__ __forceinline__ void pnp_sweep_wave_fold(const double (&acc)[kSweepAcc], double (*wacc)[kSweepAcc]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = KFIRST; k < kSweepAcc; ++k) {
+        double v = acc[k];
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
+        if (lane == 0) wacc[wave][k] = v;
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(kSweepThreads) void pnp_sweep_kernel(PnpCam cam, const float* __restrict__ X, const float* __restrict__ uv,
                                                                   const int32_t* __restrict__ sel, int64_t m,
@@ -73,53 +125,104 @@ __global__ __launch_bounds__(kSweepThreads) void pnp_sweep_kernel(PnpCam cam, co
     double acc[kSweepAcc];
 #pragma unroll
     for (int k = 0; k < kSweepAcc; ++k) acc[k] = 0;
-    for (int64_t o = blockIdx.x * (int64_t)kSweepThreads + threadIdx.x; o < m; o += (int64_t)gridDim.x * kSweepThreads) {
-        const int64_t i = sel ? sel[o] : o;
-        const double Xw = X[3 * i], Yw = X[3 * i + 1], Zw = X[3 * i + 2];
-        double x = cam.R[0] * Xw + cam.R[1] * Yw + cam.R[2] * Zw + cam.t[0];
-        double y = cam.R[3] * Xw + cam.R[4] * Yw + cam.R[5] * Zw + cam.t[1];
-        double z = cam.R[6] * Xw + cam.R[7] * Yw + cam.R[8] * Zw + cam.t[2];
-        z = z != 0.0 ? 1. / z : 1.;
-        x *= z;
-        y *= z;
-        const double ru = (x * cam.fx + cam.cx) - (double)uv[2 * i], rv = (y * cam.fy + cam.cy) - (double)uv[2 * i + 1];
-        acc[27] += ru * ru + rv * rv;
-        if (MODE == 1) {
-            double Ju[6], Jv[6];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const double* d = cam.dR + 9 * j;
-                const double dx0 = Xw * d[0] + Yw * d[1] + Zw * d[2];
-                const double dy0 = Xw * d[3] + Yw * d[4] + Zw * d[5];
-                const double dz0 = Xw * d[6] + Yw * d[7] + Zw * d[8];
-                Ju[j] = cam.fx * (z * (dx0 - x * dz0));
-                Jv[j] = cam.fy * (z * (dy0 - y * dz0));
-            }
-            Ju[3] = cam.fx * z; Ju[4] = 0;          Ju[5] = cam.fx * (-x * z);
-            Jv[3] = 0;          Jv[4] = cam.fy * z; Jv[5] = cam.fy * (-y * z);
-            int q = 0;
-#pragma unroll
-            for (int a = 0; a < 6; ++a)
-#pragma unroll
-                for (int b = a; b < 6; ++b) acc[q++] += Ju[a] * Ju[b] + Jv[a] * Jv[b];
-#pragma unroll
-            for (int a = 0; a < 6; ++a) acc[21 + a] += Ju[a] * ru + Jv[a] * rv;
-        }
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t o = blockIdx.x * (int64_t)kSweepThreads + threadIdx.x; o < m; o += (int64_t)gridDim.x * kSweepThreads)
+        pnp_sweep_point<MODE>(cam, X, uv, sel ? sel[o] : o, acc);
     constexpr int kFirst = MODE == 1 ? 0 : 27;
-#pragma unroll
-    for (int k = kFirst; k < kSweepAcc; ++k) {
-        double v = acc[k];
-#pragma unroll
-        for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
-        if (lane == 0) wacc[wave][k] = v;
-    }
+    pnp_sweep_wave_fold<kFirst>(acc, wacc);
     __syncthreads();
     if (threadIdx.x >= kFirst && threadIdx.x < kSweepAcc) {
         double s = 0;
         for (int w = 0; w < kSweepThreads / 64; ++w) s += wacc[w][threadIdx.x];
         partials[(int64_t)blockIdx.x * kSweepAcc + threadIdx.x] = s;
+    }
+}
+
+// ---- the sweep SERVER: Levenberg-Marquardt without a launch or a stream synchronisation per iteration -------------------------
+// cvFindExtrinsicCameraParams2's loop is a chain  parameters -> sweep -> 6x6 damped SVD solve -> accept / reject -> parameters  of
+// 5-6 links per camera.  Round 5 paid a kernel launch, a completion signal and a host wake-up per link (~30 us, of which the sweep
+// itself is ~3).  The 6x6 one-sided Jacobi SVD is ~90 strictly sequential rotations, each a dependent chain of a division, two
+// square roots and a hypot: ~2 us on a host core, an estimated 30-35 us on ONE lane of a CU (docs/geometry.md) — moving the algebra
+// to the device would cost what the round trip costs.  So the device side of the loop becomes a SERVER instead: ONE workgroup,
+// launched once per call, that holds the inlier set and answers "sweep at these parameters" requests posted in the caller's pinned,
+// fine-grained mailbox (LmMailbox): the host writes R, t, dR/dr and bumps `cmd_seq`; lane 0 polls it (system-scope loads), the
+// workgroup sweeps with the SAME fixed reduction tree as pnp_sweep_kernel (its G workgroups are walked one after the other), writes
+// the 28 sums back and bumps `done_seq`; the host — spinning on its own cache line — runs CvLevMarq's algebra exactly as before
+// (glibc sin / cos, the SVD of host_solvers.h) and posts the next request.  A link is two PCIe hops + the sweep.  The kernel leaves
+// on "quit", or on its own after kServerTimeoutTicks without a request (the host then relaunches it: a descheduled host thread must
+// not be able to hang a queue).
+constexpr int kServerMaxG = 8;                       // inlier sets up to 8 192 points; larger ones keep the launch-per-sweep path
+constexpr long long kServerTimeoutTicks = 100000000; // 1 s of the 100 MHz wall clock
+enum : uint32_t { kLmCmdSweep = 1, kLmCmdQuit = 2, kLmServerLeft = 0xFFFFFFFFu };
+struct alignas(64) LmMailbox {
+    uint32_t cmd_seq, cmd, pad0[14];                 // host -> device (cmd_seq written last)
+    PnpCam cam;
+    alignas(64) uint32_t done_seq, pad1[15];         // device -> host (written last); kLmServerLeft: the server gave up waiting
+    double sums[kSweepAcc];
+};
+
+__device__ __forceinline__ uint32_t sys_load_u32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+__global__ __launch_bounds__(kSweepThreads) void pnp_sweep_server_kernel(LmMailbox* __restrict__ mb, const float* __restrict__ X,
+                                                                         const float* __restrict__ uv, const int32_t* __restrict__ sel,
+                                                                         int m, int G, uint32_t first_seq) {
+    __shared__ double wacc[kSweepThreads / 64][kSweepAcc];
+    __shared__ double total[kSweepAcc];
+    __shared__ PnpCam cam;
+    __shared__ uint32_t s_cmd;
+    const int tid = threadIdx.x;
+    // a lane's correspondences do not change between requests: G == 1 (<= 1 024 inliers, the usual case) keeps them in registers
+    const int i0 = tid < m ? (sel ? sel[tid] : tid) : -1;
+    for (uint32_t seq = first_seq;; ++seq) {
+        if (tid == 0) {
+            const long long t0 = wall_clock64();
+            uint32_t c = 0;
+            for (;;) {
+                if (sys_load_u32(&mb->cmd_seq) == seq) {
+                    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+                    c = sys_load_u32(&mb->cmd);
+                    break;
+                }
+                if (wall_clock64() - t0 > kServerTimeoutTicks) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            s_cmd = c;
+        }
+        __syncthreads();
+        const uint32_t cmd = s_cmd;
+        if (cmd != kLmCmdSweep) {
+            if (tid == 0) {
+                __hip_atomic_store(&mb->done_seq, cmd == kLmCmdQuit ? seq : (uint32_t)kLmServerLeft, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            return;
+        }
+        if (tid < (int)(sizeof(PnpCam) / sizeof(double)))
+            reinterpret_cast<double*>(&cam)[tid] =
+                __hip_atomic_load(reinterpret_cast<const double*>(&mb->cam) + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __syncthreads();
+        for (int g = 0; g < G; ++g) {                       // the G workgroups of pnp_sweep_kernel's tree, one after the other
+            double acc[kSweepAcc];
+#pragma unroll
+            for (int k = 0; k < kSweepAcc; ++k) acc[k] = 0;
+            if (G == 1) {
+                if (i0 >= 0) pnp_sweep_point<1>(cam, X, uv, i0, acc);
+            } else {
+                for (int o = g * kSweepThreads + tid; o < m; o += G * kSweepThreads) pnp_sweep_point<1>(cam, X, uv, sel ? sel[o] : o, acc);
+            }
+            pnp_sweep_wave_fold<0>(acc, wacc);
+            __syncthreads();
+            if (tid < kSweepAcc) {
+                double s = 0;
+                for (int w = 0; w < kSweepThreads / 64; ++w) s += wacc[w][tid];
+                total[tid] = G == 1 ? s : (g == 0 ? 0.0 : total[tid]) + s;      // G > 1: 0 + workgroup 0 + workgroup 1 + ... (pnp_sweep_fold_kernel)
+            }
+            __syncthreads();
+        }
+        if (tid < kSweepAcc) __hip_atomic_store(&mb->sums[tid], total[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __syncthreads();
+        if (tid == 0) {
+            __atomic_thread_fence(__ATOMIC_RELEASE);
+            __hip_atomic_store(&mb->done_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -246,11 +349,12 @@ struct HostMailbox {
             p = nullptr;
             cap = 0;
             const size_t want = sfm::align_up(bytes + (bytes >> 1), 4096);
-            if (hipHostMalloc(&p, want, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess) {
+            if (hipHostMalloc(&p, want, hipHostMallocMapped | hipHostMallocPortable | hipHostMallocCoherent) != hipSuccess) {   // coherent = fine-grained: the sweep server polls it
                 p = nullptr;
                 return nullptr;
             }
             cap = want;
+            std::memset(p, 0, want);
         }
         return p;
     }
@@ -259,6 +363,81 @@ struct HostMailbox {
     }
 };
 thread_local HostMailbox g_mailbox;
+
+
+// Host side of pnp_sweep_server_kernel (see there).  One per sfm_solve_pnp_ransac call, on the caller's stream; the destructor
+// posts "quit" on every exit path, so a server never outlives its call.
+std::atomic<long long> g_mailbox_polls{0};
+bool g_no_sweep_server = false;                     // sfm_debug_pnp_sweep_server(0): the launch-per-sweep path (A/B, tests)
+struct SweepServer {
+    LmMailbox* mb;
+    const float *X, *uv;
+    const int32_t* sel;
+    int m, G;
+    hipStream_t stream;
+    uint32_t seq = 0;
+    bool running = false;
+    SweepServer(LmMailbox* mb_, const float* X_, const float* uv_, const int32_t* sel_, int m_, int G_, hipStream_t s)
+        : mb(mb_), X(X_), uv(uv_), sel(sel_), m(m_), G(G_), stream(s) {}
+    ~SweepServer() { (void)stop(); }
+    int start() {
+        // sequence numbers continue across calls (the mailbox is per host thread): a request can never be mistaken for an old one
+        seq = __atomic_load_n(&mb->cmd_seq, __ATOMIC_RELAXED);
+        if (seq >= 0xFFFF0000u) seq = 0;            // (the block sits at a size-dependent offset of the mailbox: whatever was there; never near kLmServerLeft)
+        __atomic_store_n(&mb->cmd_seq, seq, __ATOMIC_RELAXED);
+        __atomic_store_n(&mb->done_seq, seq, __ATOMIC_RELEASE);
+        hipLaunchKernelGGL(pnp_sweep_server_kernel, dim3(1), dim3(kSweepThreads), 0, stream, mb, X, uv, sel, m, G, seq + 1);
+        SFM_CHECK_LAUNCH();
+        running = true;
+        return SFM_OK;
+    }
+    // wait until the server has answered request `want`; 0 = answered, 1 = the server left (timeout on its side), < 0 = error
+    int wait(uint32_t want) {
+        const double t0 = now_us();
+        for (long long spins = 1;; ++spins) {
+            const uint32_t d = __atomic_load_n(&mb->done_seq, __ATOMIC_ACQUIRE);
+            if (d == want) { g_mailbox_polls.fetch_add(spins, std::memory_order_relaxed); return 0; }
+            if (d == (uint32_t)kLmServerLeft) return 1;
+            __builtin_ia32_pause();
+            if ((spins & 0xFFF) == 0) {
+                if (hipStreamQuery(stream) == hipSuccess && __atomic_load_n(&mb->done_seq, __ATOMIC_ACQUIRE) != want) return 1;   // the kernel is gone
+                if (now_us() - t0 > 5e6) {
+                    sfm::set_error("sfm_solve_pnp_ransac: the sweep server did not answer within 5 s");
+                    return SFM_ERR_DEVICE;
+                }
+            }
+        }
+    }
+    int post(uint32_t cmd) {
+        mb->cmd = cmd;
+        __atomic_store_n(&mb->cmd_seq, ++seq, __ATOMIC_RELEASE);
+        return wait(seq);
+    }
+    int sweep(const PnpCam& cam, double* sums_out) {
+        for (int attempt = 0; attempt < 3; ++attempt) {
+            std::memcpy(&mb->cam, &cam, sizeof(cam));
+            const int r = post(kLmCmdSweep);
+            if (r == 0) {
+                std::memcpy(sums_out, mb->sums, sizeof(double) * kSweepAcc);
+                return SFM_OK;
+            }
+            if (r < 0) return r;
+            // the server left on its own (this thread was away for more than a second): wait for the kernel, start another
+            running = false;
+            SFM_CHECK_HIP(sfm::stream_sync(stream));
+            const int rs = start();
+            if (rs != SFM_OK) return rs;
+        }
+        sfm::set_error("sfm_solve_pnp_ransac: the sweep server keeps leaving");
+        return SFM_ERR_DEVICE;
+    }
+    int stop() {
+        if (!running) return SFM_OK;
+        running = false;
+        const int r = post(kLmCmdQuit);
+        return r < 0 ? r : SFM_OK;
+    }
+};
 
 size_t essential_ws(int64_t n) {
     const size_t hmax = 64 * 10;
@@ -468,7 +647,8 @@ extern "C" int sfm_solve_pnp_ransac(const float* X_dev, const float* uv_dev, int
     const size_t o_uv = sizeof(float) * 3 * (size_t)n, o_mask = o_uv + sizeof(float) * 2 * (size_t)n;
     const size_t o_pose = sfm::align_up(o_mask + (size_t)n, 64), o_cnt = o_pose + sizeof(double) * 6 * hmax;
     const size_t o_sum = sfm::align_up(o_cnt + sizeof(int32_t) * hmax, 64);
-    const size_t o_cm = sfm::align_up(o_sum + sizeof(double) * kSweepAcc, 64);
+    const size_t o_lm = sfm::align_up(o_sum + sizeof(double) * kSweepAcc, 64);
+    const size_t o_cm = o_lm + sizeof(LmMailbox);
     const bool ride_along = (size_t)n * kSmallMasks <= (1u << 18);
     char* mb = static_cast<char*>(g_mailbox.get(o_cm + (ride_along ? (size_t)n * kSmallMasks : 0)));
     if (!mb) {
@@ -601,11 +781,19 @@ extern "C" int sfm_solve_pnp_ransac(const float* X_dev, const float* uv_dev, int
     SFM_CHECK_HIP(hipMemcpyAsync(inliers_dev, inl.data(), sizeof(int32_t) * (size_t)m_in, hipMemcpyHostToDevice, stream));
     lap(3);
     // solvePnP(ITERATIVE) on the inliers: DLT initialisation on the host, Levenberg-Marquardt with the sweeps on the device
+    const int blocks = (int)std::min<int64_t>((m_in + kSweepThreads - 1) / kSweepThreads, kSweepMaxBlocks);
+    // <= 8 192 inliers: the sweep server (one launch per call, requests through the mailbox); more: a launch set per sweep.
+    // The server is started BEFORE the DLT initialisation so that its launch latency hides behind ~30 us of host work.
+    SweepServer server(reinterpret_cast<LmMailbox*>(mb + o_lm), X_dev, uv_dev, inliers_dev, (int)m_in, blocks, stream);
+    const bool served = blocks <= kServerMaxG && !g_no_sweep_server;
+    if (served) {
+        const int rc0 = server.start();
+        if (rc0 != SFM_OK) return rc0;
+    }
     double param[6];
     const int init_status = hs::pnp_dlt_init<float>(hX, huv, inl.data(), m_in, K, param, param + 3);
     if (init_status != 0) std::memcpy(param, best_model, sizeof(param));      // planar / < 6 inliers: refine the RANSAC model
     lap(4);
-    const int blocks = (int)std::min<int64_t>((m_in + kSweepThreads - 1) / kSweepThreads, kSweepMaxBlocks);
     auto sweep = [&](const double* p, bool jac) -> int {
         lap(6);
         ++g_pnp_prof.sweeps;
@@ -613,6 +801,11 @@ extern "C" int sfm_solve_pnp_ransac(const float* X_dev, const float* uv_dev, int
         rodrigues_with_jac(p, cam.R, cam.dR);
         cam.t[0] = p[3]; cam.t[1] = p[4]; cam.t[2] = p[5];
         cam.fx = K[0]; cam.fy = K[4]; cam.cx = K[2]; cam.cy = K[5];
+        if (served) {
+            const int rcs = server.sweep(cam, sums);
+            lap(5);
+            return rcs;
+        }
         double* out = blocks == 1 ? sums : sweep_dev;           // one workgroup: its 28 sums go straight to the pinned mailbox
         if (jac)
             hipLaunchKernelGGL(pnp_sweep_kernel<1>, dim3(blocks), dim3(kSweepThreads), 0, stream, cam, X_dev, uv_dev, inliers_dev, m_in, out);
@@ -674,6 +867,7 @@ extern "C" int sfm_solve_pnp_ransac(const float* X_dev, const float* uv_dev, int
         prevErrNorm = errNorm;
     }
     lap(6);
+    if (served && (rc = server.stop()) != SFM_OK) return rc;
     std::memcpy(rvec_host, param, 24);
     std::memcpy(tvec_host, param + 3, 24);
     info_host[0] = 1;
@@ -740,6 +934,15 @@ extern "C" int sfm_host_rodrigues(const double* src, int src_is_matrix, double* 
         rodrigues_with_jac(src, dst, jac ? jac : J);
     }
     return SFM_OK;
+}
+
+// Mailbox polls of the sweep server's host side since load (spins of the waiting loop: a measure of time, not of API calls), and the
+// A/B switch between the server and the launch-per-sweep path (on = 1 default; returns the previous setting).
+extern "C" int64_t sfm_host_poll_count(void) { return (int64_t)g_mailbox_polls.load(std::memory_order_relaxed); }
+extern "C" int sfm_debug_pnp_sweep_server(int on) {
+    const int was = g_no_sweep_server ? 0 : 1;
+    g_no_sweep_server = on == 0;
+    return was;
 }
 
 // Where sfm_solve_pnp_ransac's HOST time went since the last reset (accumulated over calls, microseconds):

@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
 def test_binding_table_matches_header():
     from sfm_mvs_amd import _lib
     assert sorted(_lib.SIGNATURES) == declared_symbols()
-    assert _lib.lib().sfm_abi_version() == 2          # ABI 2: the KNN filter variant is a per-call argument
+    assert _lib.lib().sfm_abi_version() == 3          # ABI 2: the KNN filter variant is a per-call argument; 3: sweep-server exports, per-file build id
 
 
 def test_ws_bytes_twins():

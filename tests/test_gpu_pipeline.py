@@ -47,6 +47,39 @@ def test_ransac_entry_points_vs_sequential_oracle(hip, oracle, pair, n, sigma, n
     assert np.abs(oracle.rodrigues_vec2mat(rh.ravel()) - R).max() < 5e-3 and np.abs(tvh.ravel() - t).max() < 5e-2
 
 
+@pytest.mark.parametrize("pair,n,sigma,n_bad,seed", [(0, 900, 0.3, 200, 11), (5, 64, 1.0, 10, 5), (30, 3000, 0.3, 300, 6), (12, 9000, 0.4, 500, 7),
+                                                      (21, 1024, 0.2, 0, 8), (21, 1025, 0.2, 0, 9)])
+def test_sweep_server_equals_launch_per_sweep(hip, pair, n, sigma, n_bad, seed):
+    """solvePnPRansac's Levenberg-Marquardt loop through the resident sweep server (one launch per call, requests through the pinned
+    mailbox: csrc/ransac.hip pnp_sweep_server_kernel) and through a launch + stream synchronisation per sweep: the same sums in
+    the same tree, so rvec, tvec, the iteration count and the inlier list are bit-identical — one workgroup (<= 1 024 inliers), several
+    virtual workgroups (1 025 .. 8 192) and beyond the server's range (both runs take the launch path).  Calls in a row reuse the
+    mailbox: the sequence numbers carry over."""
+    from sfm_mvs_amd import ransac, _lib
+    K, P1, P2, X, x1, x2 = gustav_pair(pair, n, sigma, seed=seed)
+    x2, _ = _corrupt(x2, n_bad, 10, 150, seed)
+    Xf = X.astype(np.float32)
+    L = _lib.lib()
+    polls0, syncs0 = L.sfm_host_poll_count(), L.sfm_host_sync_count()
+    got = [ransac.solve_pnp_ransac(Xf, x2, K, want_info=True) for _ in range(3)]
+    polls1, syncs1 = L.sfm_host_poll_count(), L.sfm_host_sync_count()
+    assert L.sfm_debug_pnp_sweep_server(0) == 1
+    try:
+        want = ransac.solve_pnp_ransac(Xf, x2, K, want_info=True)
+        syncs2 = L.sfm_host_sync_count()
+    finally:
+        assert L.sfm_debug_pnp_sweep_server(1) == 0
+    assert want[0] and want[4][3] >= 1                                                    # LM iterations ran
+    for g in got:
+        assert g[0] and np.array_equal(g[1], want[1]) and np.array_equal(g[2], want[2]) and np.array_equal(g[3], want[3])
+        assert list(g[4]) == list(want[4])
+    inl = int(want[4][1])
+    if inl <= 8192:                                   # served: polls instead of stream synchronisations
+        assert polls1 > polls0 and (syncs1 - syncs0) / 3 < (syncs2 - syncs1)
+    else:
+        assert polls1 == polls0
+
+
 def test_ransac_entry_point_edge_cases(hip, oracle):
     from sfm_mvs_amd import ransac
     from sfm_mvs_amd._lib import SfmHipError
