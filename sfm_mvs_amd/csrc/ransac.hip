@@ -104,17 +104,48 @@ __device__ __forceinline__ void pnp_sweep_point(const PnpCam& cam, const float* 
     }
 }
 
-// a lane's sums -> its wave's (butterfly v[l] += v[l ^ s], s = 32 .. 1) -> wacc[wave][k]
+// A lane's 28 sums -> its wave's, wacc[wave][k].  The TREE is the butterfly v[l] += v[l ^ s], s = 32 .. 1 (what the oracle walks);
+// the SCHEDULE is a reduce-scatter: at step s a lane keeps half of its values and hands the other half to lane l ^ s, which
+// keeps exactly those — every pair sum a[l] + a[l ^ s] is still formed (by one of the two lanes instead of both: IEEE addition
+// commutes, so the bits are the same), but 28 values cost 14 + 7 + 4 + 2 + 1 + 1 = 29 exchanges instead of 28 x 6 = 168.
+// After the last step lanes l and l ^ 1 hold the wave's sum of value
+//   idx(l) = 14 b5 + 7 b4 + (4 b3 + 2 b2 + b1)        (b_i = bit i of l; 4 b3 + 2 b2 + b1 = 7 is an unused slot).
+template <int N>
+__device__ __forceinline__ void scatter_step(double (&v)[14], int bit, int s) {
+    constexpr int H = (N + 1) / 2;
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+        const double hi = H + j < N ? v[H + j] : 0.0;
+        const double send = bit ? v[j] : hi, keep = bit ? hi : v[j];
+        v[j] = keep + __shfl_xor(send, s, 64);
+    }
+}
 template <int KFIRST>
 __device__ __forceinline__ void pnp_sweep_wave_fold(const double (&acc)[kSweepAcc], double (*wacc)[kSweepAcc]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = KFIRST; k < kSweepAcc; ++k) {
-        double v = acc[k];
+    if (KFIRST != 0) {                                   // |e|^2 alone: the plain butterfly
+        double v = acc[kSweepAcc - 1];
 #pragma unroll
         for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
-        if (lane == 0) wacc[wave][k] = v;
+        if (lane == 0) wacc[wave][kSweepAcc - 1] = v;
+        return;
     }
+    double v[14];
+    {
+        const int b = lane & 32;
+#pragma unroll
+        for (int j = 0; j < 14; ++j) {
+            const double send = b ? acc[j] : acc[14 + j], keep = b ? acc[14 + j] : acc[j];
+            v[j] = keep + __shfl_xor(send, 32, 64);
+        }
+    }
+    scatter_step<14>(v, lane & 16, 16);
+    scatter_step<7>(v, lane & 8, 8);
+    scatter_step<4>(v, lane & 4, 4);
+    scatter_step<2>(v, lane & 2, 2);
+    v[0] = v[0] + __shfl_xor(v[0], 1, 64);
+    const int low = (lane >> 1) & 7;
+    if ((lane & 1) == 0 && low != 7) wacc[wave][(lane & 32 ? 14 : 0) + (lane & 16 ? 7 : 0) + low] = v[0];
 }
 
 template <int MODE>
@@ -128,7 +159,10 @@ __global__ __launch_bounds__(kSweepThreads) void pnp_sweep_kernel(PnpCam cam, co
     for (int64_t o = blockIdx.x * (int64_t)kSweepThreads + threadIdx.x; o < m; o += (int64_t)gridDim.x * kSweepThreads)
         pnp_sweep_point<MODE>(cam, X, uv, sel ? sel[o] : o, acc);
     constexpr int kFirst = MODE == 1 ? 0 : 27;
-    pnp_sweep_wave_fold<kFirst>(acc, wacc);
+    if (blockIdx.x * (int64_t)kSweepThreads + (threadIdx.x & ~63) < m)
+        pnp_sweep_wave_fold<kFirst>(acc, wacc);
+    else if ((threadIdx.x & 63) < kSweepAcc)             // a wave without points: the butterfly of zeros is +0
+        wacc[threadIdx.x >> 6][threadIdx.x & 63] = 0.0;
     __syncthreads();
     if (threadIdx.x >= kFirst && threadIdx.x < kSweepAcc) {
         double s = 0;
@@ -150,11 +184,12 @@ __global__ __launch_bounds__(kSweepThreads) void pnp_sweep_kernel(PnpCam cam, co
 // (glibc sin / cos, the SVD of host_solvers.h) and posts the next request.  A link is two PCIe hops + the sweep.  The kernel leaves
 // on "quit", or on its own after kServerTimeoutTicks without a request (the host then relaunches it: a descheduled host thread must
 // not be able to hang a queue).
-constexpr int kServerMaxG = 8;                       // inlier sets up to 8 192 points; larger ones keep the launch-per-sweep path
+constexpr int kServerMaxG = 1;                       // inlier sets up to 1 024 points (what a frame of the chain has); larger ones keep the launch-per-sweep path:
+                                                     // walking G > 1 virtual workgroups in one costs 17 us per extra pass (measured), more than G launches side by side
 constexpr long long kServerTimeoutTicks = 100000000; // 1 s of the 100 MHz wall clock
 enum : uint32_t { kLmCmdSweep = 1, kLmCmdQuit = 2, kLmServerLeft = 0xFFFFFFFFu };
 struct alignas(64) LmMailbox {
-    uint32_t cmd_seq, cmd, pad0[14];                 // host -> device (cmd_seq written last)
+    uint32_t cmd_seq, pad0[15];                      // host -> device, written last: request number << 2 | command
     PnpCam cam;
     alignas(64) uint32_t done_seq, pad1[15];         // device -> host (written last); kLmServerLeft: the server gave up waiting
     double sums[kSweepAcc];
@@ -177,9 +212,10 @@ __global__ __launch_bounds__(kSweepThreads) void pnp_sweep_server_kernel(LmMailb
             const long long t0 = wall_clock64();
             uint32_t c = 0;
             for (;;) {
-                if (sys_load_u32(&mb->cmd_seq) == seq) {
+                const uint32_t w = sys_load_u32(&mb->cmd_seq);
+                if ((w >> 2) == seq) {
                     __atomic_thread_fence(__ATOMIC_ACQUIRE);
-                    c = sys_load_u32(&mb->cmd);
+                    c = w & 3u;
                     break;
                 }
                 if (wall_clock64() - t0 > kServerTimeoutTicks) break;
@@ -208,7 +244,10 @@ __global__ __launch_bounds__(kSweepThreads) void pnp_sweep_server_kernel(LmMailb
             } else {
                 for (int o = g * kSweepThreads + tid; o < m; o += G * kSweepThreads) pnp_sweep_point<1>(cam, X, uv, sel ? sel[o] : o, acc);
             }
-            pnp_sweep_wave_fold<0>(acc, wacc);
+            if (g * kSweepThreads + (tid & ~63) < m)
+                pnp_sweep_wave_fold<0>(acc, wacc);
+            else if ((tid & 63) < kSweepAcc)                // a wave without points: the butterfly of zeros is +0
+                wacc[tid >> 6][tid & 63] = 0.0;
             __syncthreads();
             if (tid < kSweepAcc) {
                 double s = 0;
@@ -382,9 +421,9 @@ struct SweepServer {
     ~SweepServer() { (void)stop(); }
     int start() {
         // sequence numbers continue across calls (the mailbox is per host thread): a request can never be mistaken for an old one
-        seq = __atomic_load_n(&mb->cmd_seq, __ATOMIC_RELAXED);
-        if (seq >= 0xFFFF0000u) seq = 0;            // (the block sits at a size-dependent offset of the mailbox: whatever was there; never near kLmServerLeft)
-        __atomic_store_n(&mb->cmd_seq, seq, __ATOMIC_RELAXED);
+        seq = __atomic_load_n(&mb->cmd_seq, __ATOMIC_RELAXED) >> 2;
+        if (seq >= 0x3FFF0000u) seq = 0;            // (the block sits at a size-dependent offset of the mailbox: whatever was there; never near kLmServerLeft)
+        __atomic_store_n(&mb->cmd_seq, seq << 2, __ATOMIC_RELAXED);
         __atomic_store_n(&mb->done_seq, seq, __ATOMIC_RELEASE);
         hipLaunchKernelGGL(pnp_sweep_server_kernel, dim3(1), dim3(kSweepThreads), 0, stream, mb, X, uv, sel, m, G, seq + 1);
         SFM_CHECK_LAUNCH();
@@ -409,8 +448,8 @@ struct SweepServer {
         }
     }
     int post(uint32_t cmd) {
-        mb->cmd = cmd;
-        __atomic_store_n(&mb->cmd_seq, ++seq, __ATOMIC_RELEASE);
+        ++seq;
+        __atomic_store_n(&mb->cmd_seq, seq << 2 | cmd, __ATOMIC_RELEASE);
         return wait(seq);
     }
     int sweep(const PnpCam& cam, double* sums_out) {
@@ -782,7 +821,7 @@ extern "C" int sfm_solve_pnp_ransac(const float* X_dev, const float* uv_dev, int
     lap(3);
     // solvePnP(ITERATIVE) on the inliers: DLT initialisation on the host, Levenberg-Marquardt with the sweeps on the device
     const int blocks = (int)std::min<int64_t>((m_in + kSweepThreads - 1) / kSweepThreads, kSweepMaxBlocks);
-    // <= 8 192 inliers: the sweep server (one launch per call, requests through the mailbox); more: a launch set per sweep.
+    // <= 1 024 inliers: the sweep server (one launch per call, requests through the mailbox); more: a launch set per sweep.
     // The server is started BEFORE the DLT initialisation so that its launch latency hides behind ~30 us of host work.
     SweepServer server(reinterpret_cast<LmMailbox*>(mb + o_lm), X_dev, uv_dev, inliers_dev, (int)m_in, blocks, stream);
     const bool served = blocks <= kServerMaxG && !g_no_sweep_server;
