@@ -1100,6 +1100,7 @@ def _bench_c5(args, world, rank, dev, sharded, pairs, n_img, n_desc, n_plant, ex
                       "parallelism": f"pair-sharded x{world} (sharded.match_pairs_sharded + triangulate_pairs_sharded); {PIPE_DEPTH} pairs in flight per GPU"},
            "job_seconds": elapsed, "match_seconds": t_match, "triangulate_and_gather_seconds": elapsed - t_match,
            "images_resident_on_this_rank": len(mine),
+           "pairs_per_rank": [hi - lo for lo, hi in (sharded.shard_range(len(pairs), world, r) for r in range(world))],
            "exchange": {"kind": exchange_kind, "match_records": st_m, "points": st_t,
                         "note": "device time between the events bracketing each all_gather_into_tensor (includes waiting for the batch's producers)"},
            "triangulated_points_total": int(counts.sum().item()),
@@ -1480,16 +1481,22 @@ def bench_dry_run(args, world, rank):
                       "exchange": {"collectives": ex.collectives, "pairs_per_collective": EXCH_BATCH, "ranks": dist.get_world_size(),
                                    "gathered_slots_verified": ok},
                       "launched_by": "bench.py self_launch" if os.environ.get("TORCHELASTIC_RUN_ID") else "external launcher"}}
-    if args.workload == "c5":
+    if args.workload == "c5" or (args.workload == "knn" and world > 1):
+        # (default workload at N > 1: the real run measures BASELINE configs[4] beside the headline — main(); its partition is shown here)
         n_img = max(2, args.images or 256)
         pairs = sharded.sequential_pairs(n_img)
         lo, hi = sharded.shard_range(len(pairs), world, rank)
         held = sharded.halo_images(pairs, world, rank)
         counts = [None] * world
         dist.all_gather_object(counts, {"pairs": hi - lo, "images_held": len(held)})
-        out["scaling"] = "strong"
-        out["config"]["partition"] = counts
         ok = ok and sum(c["pairs"] for c in counts) == len(pairs) and all(c["images_held"] == c["pairs"] + (1 if c["pairs"] else 0) for c in counts)
+        if args.workload == "c5":
+            out["scaling"] = "strong"
+            out["config"]["partition"] = counts
+        else:
+            out["config"]["secondary"] = {"config5_images": n_img, "config5_pairs": len(pairs), "config5_pairs_per_rank": [c["pairs"] for c in counts],
+                                          "config5_images_per_rank": [c["images_held"] for c in counts], "config5_scaling": "strong",
+                                          "rccl_ranks": dist.get_world_size()}
         out["config"]["exchange"]["gathered_slots_verified"] = ok
     if not ok:
         raise SystemExit("dry run: a gathered slot did not carry its (rank, pair) stamp")
@@ -1544,7 +1551,7 @@ def compact_line(out):
         if k in cfg:
             c["config"][k] = cfg[k]
     if isinstance(cfg.get("secondary"), dict):
-        c["config"]["secondary"] = {k: _sig(v) for k, v in cfg["secondary"].items() if not isinstance(v, str)}
+        c["config"]["secondary"] = {k: _sig(v) if not isinstance(v, str) else _clip(v, 40) for k, v in cfg["secondary"].items() if v is not None}
     if isinstance(out.get("roofline"), dict):
         c["roofline"] = _pick(out["roofline"], ("bound", "achieved", "peak", "unit", "frac", "frac_step", "frac_of_sustained", "traffic", "algorithmic_bytes_per_launch",
                                                  "algorithmic_bytes", "kernel", "avg_launch_ms", "launches"), clip=100)
@@ -1607,7 +1614,8 @@ def main():
     sfm_mvs_amd.lib()      # fail loudly if the HIP extension is missing
     if args.workload == "knn":
         out = bench_knn(args, world, rank, dev)
-        if rank == 0 and world == 1:
+        multi = world > 1 or bool(os.environ.get("SFM_BENCH_EXCHANGE"))       # (the env switch: the N > 1 code path on one rank, dev / test)
+        if rank == 0 and not multi:
             if not args.no_extras:
                 out["extra"] = extras(dev)
                 out["extra"]["config4"] = extra_c4(dev)
@@ -1637,6 +1645,28 @@ def main():
                     "note": "the other legs of this same run (details under `extra`, `sift_like`, `fp16_body_variant`); frames of the sfm legs are SURROGATES of the Gustav photographs"}
             if not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_knn_baseline(args.nq, args.nt, 0, 1)
+        elif multi and not args.no_extras:
+            # The driver's scaling command (`bench.py --gpus N`, N > 1): the headline stays config 2, weak-scaled (so that the N = 1 point of
+            # SCALE equals BENCH), and the SAME run also measures BASELINE configs[4] — 256 images x 50k descriptors, the 255 sequential
+            # pairs split over the N ranks (+ one halo image each), both all-gathers (match records, triangulated points) over the
+            # RCCL group — reported under config.secondary.  Every rank takes part (collectives).
+            import copy
+            a5 = copy.copy(args)
+            a5.images = args.images or 256
+            try:
+                r5 = bench_c5(a5, world, rank, dev)
+            except Exception as e:      # noqa: BLE001 — the headline must survive a failure of the secondary leg
+                r5 = {"error": f"{type(e).__name__}: {e}"}
+            if rank == 0:
+                import torch.distributed as dist
+                out["config5"] = r5
+                out["config"]["secondary"] = {
+                    "config5_distances_per_sec": r5.get("value"), "config5_job_seconds": r5.get("job_seconds"),
+                    "config5_match_seconds": r5.get("match_seconds"), "config5_ms_per_pair": r5.get("ms_per_step"),
+                    "config5_images": a5.images, "config5_pairs": a5.images - 1, "config5_pairs_per_rank": r5.get("pairs_per_rank"),
+                    "config5_exchange_ms_match_records": ((r5.get("exchange") or {}).get("match_records") or {}).get("exchange_ms"),
+                    "config5_exchange_ms_points": ((r5.get("exchange") or {}).get("points") or {}).get("exchange_ms"),
+                    "config5_scaling": "strong", "rccl_ranks": dist.get_world_size(), "config5_error": r5.get("error")}
     elif args.workload == "tri":
         out = bench_tri(args, world, rank, dev)
     elif args.workload == "sfm":

@@ -38,9 +38,10 @@ extern "C" {
 
 int         sfm_abi_version(void);
 const char* sfm_last_error(void);
-/* What the loaded binary was built from: "knn.hip:<sha256 of csrc/knn.hip's code>" (comments and whitespace do not count;
- * scripts/knn_code_hash.py), " dev-build" appended when the library honours the SFM_KNN_* tuning variables (release builds
- * read nothing from the environment).  The parity sweeps and PMC stamps under profiles/ name the same hash. */
+/* What the loaded binary was built from: "knn.hip:<sha256 of csrc/knn.hip's code> assoc.hip:<first 16 digits> ... sfm_hip.h:<16>",
+ * one entry per source file (comments and whitespace do not count; scripts/knn_code_hash.py --build-id prints the same for a tree),
+ * " dev-build" appended when the library honours the SFM_KNN_* tuning variables (release builds read none).  The parity sweeps and
+ * PMC stamps under profiles/ name these hashes, each family its own sources. */
 const char* sfm_build_id(void);
 
 /* ------------------------------------------------------------------------
@@ -534,6 +535,10 @@ int sfm_profile_enable(int on);
  * {start tick, end tick (100 MHz), HW_ID, XCC_ID} at dev_buf[4*b..] and every refine workgroup w
  * int64[16] phase ticks at dev_buf[16384 + 16*w..]; NULL disables. */
 int sfm_debug_set_trace(void* dev_buf);
+/* Test hook: workgroup `workgroup` of every following knn_split_images_kernel launch starts `microseconds` (<= 100 000) late — the
+ * situation of a grid that is not co-resident (tests/test_gpu_knn_q8.py: the repair of pairs quantised in vain must not depend on
+ * when a workgroup is dispatched).  workgroup = -1 switches it off. */
+int sfm_debug_knn_split_delay(int workgroup, int microseconds);
 int sfm_profile_read(int slot, double* total_ms_host, int64_t* launches_host);
 /* How often library calls of this process have WAITED for the device so far (cumulative; the RANSAC entry points read the
  * hypothesis scores back chunk by chunk, the Schur solver its convergence scalars).  Diagnostics: bench.py reports the

@@ -37,4 +37,5 @@ while time.time() - t0 < budget:
     if not ok:
         bad += 1
         print(f"MISMATCH case {cases}: {w}x{h} kind {kind} seed {s} nL {nl} ct {ct} et {et} sigma {sg}: oracle {len(kpo)} hip {len(kp) if 'kp' in dir() else '?'}")
-print(f"fuzz_sift: {cases} cases, {kps} keypoints compared, {bad} mismatches, {time.time() - t0:.0f} s")
+from sfm_mvs_amd import _lib as _sfm_lib
+print(f"fuzz_sift: {cases} cases, {kps} keypoints compared, {bad} mismatches, {time.time() - t0:.0f} s; build {_sfm_lib.build_id()}")

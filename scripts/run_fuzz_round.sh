@@ -10,3 +10,11 @@ done
 python $R/scripts/fuzz_knn.py $SEC $((BASE+5)) big 2>&1 | grep -v amdgpu.ids > $R/gpurun_out/${TAG}_fuzz_knn_seed$((BASE+5))_big.log
 python $R/scripts/fuzz_knn.py $((SEC*3/2)) $((BASE+6)) q8 2>&1 | grep -v amdgpu.ids > $R/gpurun_out/${TAG}_fuzz_knn_seed$((BASE+6))_q8.log
 grep "^fuzz:" $R/gpurun_out/${TAG}_fuzz_knn_seed*.log
+# the other families (each log ends with the loaded binary's sfm_build_id: tests/test_gpu_knn.py checks every family against ITS sources)
+OSEC=${4:-$SEC}
+for seed in $((BASE+11)) $((BASE+12)); do
+  python $R/scripts/fuzz_sift.py $OSEC $seed 2>&1 | grep -v amdgpu.ids > $R/gpurun_out/${TAG}_fuzz_sift_seed$seed.log
+  python $R/scripts/fuzz_geometry.py $OSEC $seed 2>&1 | grep -v amdgpu.ids > $R/gpurun_out/${TAG}_fuzz_geometry_seed$seed.log
+  python $R/scripts/fuzz_pipeline.py $OSEC $seed 2>&1 | grep -v amdgpu.ids > $R/gpurun_out/${TAG}_fuzz_pipeline_seed$seed.log
+done
+grep -h "^fuzz_" $R/gpurun_out/${TAG}_fuzz_sift_seed*.log $R/gpurun_out/${TAG}_fuzz_geometry_seed*.log $R/gpurun_out/${TAG}_fuzz_pipeline_seed*.log | cut -c1-200

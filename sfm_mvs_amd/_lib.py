@@ -95,6 +95,7 @@ SIGNATURES = {
     "sfm_host_poll_count": (_i64, []),
     "sfm_debug_pnp_sweep_server": (_int, [_int]),
     "sfm_debug_set_trace": (_int, [_vp]),
+    "sfm_debug_knn_split_delay": (_int, [_int, _int]),
     "sfm_profile_read": (_int, [_int, _c.POINTER(_f64), _c.POINTER(_i64)]),
 }
 
@@ -130,8 +131,13 @@ def lib():
 
 
 def build_id():
-    """sfm_build_id() of the LOADED binary: 'knn.hip:<code sha256>' (+ ' dev-build')."""
+    """sfm_build_id() of the LOADED binary: 'knn.hip:<code sha256> assoc.hip:<16 digits> ... sfm_hip.h:<16>' (+ ' dev-build')."""
     return lib().sfm_build_id().decode()
+
+
+def code_hashes_of_binary():
+    """{source file name: code hash} the loaded library was compiled from (scripts/knn_code_hash.py computes the same for a tree)."""
+    return dict(tok.split(":", 1) for tok in build_id().split() if ":" in tok)
 
 
 def knn_code_hash_of_binary():

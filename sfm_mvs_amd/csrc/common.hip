@@ -86,4 +86,19 @@ extern "C" int sfm_profile_read(int slot, double* total_ms, int64_t* launches) {
 
 extern "C" int64_t sfm_host_sync_count(void) { return (int64_t)sfm::g_host_syncs.load(std::memory_order_relaxed); }
 extern "C" int sfm_abi_version(void) { return SFM_ABI_VERSION; }
+
+// What this BINARY was built from: the code hash of every source file (scripts/knn_code_hash.py: comments and whitespace do not
+// count), handed in by the Makefile: "knn.hip:<sha256> assoc.hip:<first 16 digits> ... sfm_hip.h:<16>".  The committed fuzz logs
+// and PMC traffic stamps name it; tests/test_gpu_knn.py and bench.py compare them with the LOADED library's id, file by file —
+// the KNN logs against knn.hip, the SIFT logs against sift.hip, the geometry / pipeline logs against theirs.
+#ifndef SFM_BUILD_ID
+#define SFM_BUILD_ID "knn.hip:unknown"
+#endif
+extern "C" const char* sfm_build_id(void) {
+#ifdef SFM_DEV_BUILD
+    return SFM_BUILD_ID " dev-build";
+#else
+    return SFM_BUILD_ID;
+#endif
+}
 extern "C" const char* sfm_last_error(void) { return sfm::g_err; }

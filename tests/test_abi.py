@@ -66,10 +66,11 @@ def test_build_id_names_the_source_and_release_library_reads_no_tuning_overrides
     import re
     import subprocess
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
-    from knn_code_hash import knn_code_hash
+    from knn_code_hash import build_id as tree_build_id, knn_code_hash
     from sfm_mvs_amd import _lib
     bid = _lib.build_id()
-    assert bid == "knn.hip:" + knn_code_hash(), f"{bid}: stale or dev build of libsfmhip.so"
+    assert bid == tree_build_id() and bid.startswith("knn.hip:" + knn_code_hash() + " "), f"{bid}: stale or dev build of libsfmhip.so"
+    assert set(_lib.code_hashes_of_binary()) >= {"knn.hip", "sift.hip", "ransac.hip", "triangulate.hip", "host_solvers.h", "sfm_hip.h"}
     text = subprocess.run(["strings", _lib.LIB_PATH], capture_output=True, text=True).stdout
     envs = set(re.findall(r"^SFM_[A-Z0-9_]+$", text, re.M))
     # SFM_KNN_ASSUME_E: honoured only where it widens the certificate (E >= 8); SFM_PNP_PROF: prints host timings at exit

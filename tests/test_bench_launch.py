@@ -28,6 +28,12 @@ def test_gpus_2_self_launches_two_ranks():
     assert ex["ranks"] == 2 and ex["gathered_slots_verified"] is True and ex["collectives"] >= 1
     assert out["config"]["launched_by"] == "bench.py self_launch"
     assert "launching 2 ranks" in err
+    # the default workload at N > 1 also runs BASELINE configs[4]: its partition rides in config.secondary —
+    # 255 sequential pairs (sfm.py:347) of 256 images split 128 / 127, every rank holding its images + ONE halo image
+    sec = out["config"]["secondary"]
+    assert sec["config5_images"] == 256 and sec["config5_pairs"] == 255 and sec["config5_pairs_per_rank"] == [128, 127]
+    assert sec["config5_images_per_rank"] == [129, 128] and sec["rccl_ranks"] == 2 and sec["config5_scaling"] == "strong"
+    assert out["scaling"] == "weak"                                     # the headline stays config 2, weak-scaled
 
 
 def test_gpus_3_c5_partition_is_the_halo_split():

@@ -386,34 +386,51 @@ def test_runtime_selftest_gates_the_certificate(hip, oracle):
     assert out.returncode == 0 and "rescans" in out.stdout, out.stderr[-2000:]
 
 
+FUZZ_ROUND = "r06"
+# which sources a family of randomised sweeps exercises: a log is valid while the LOADED binary was built from the same code of THOSE files
+FUZZ_SOURCES = {
+    "knn": ("knn.hip", "common.h"),
+    "sift": ("sift.hip", "common.h"),
+    "geometry": ("ransac.hip", "residual.hip", "triangulate.hip", "assoc.hip", "ba_dense.hip", "ba_schur.hip", "blocks.hip", "host_solvers.h", "common.h"),
+    "pipeline": ("knn.hip", "sift.hip", "ransac.hip", "residual.hip", "triangulate.hip", "assoc.hip", "blocks.hip", "host_solvers.h", "common.h"),
+}
+FUZZ_MIN_CASES = {"knn": 20000, "sift": 500, "geometry": 2000, "pipeline": 200}
+
+
 @pytest.mark.gpu
-def test_committed_fuzz_logs_are_those_of_the_loaded_binary():
-    """The long randomised parity sweeps (scripts/fuzz_knn.py: >= 20 000 cases per round incl. the margin-aimed families)
-    are committed under profiles/ with the sha256 of the CODE of csrc/knn.hip they ran on (comments and whitespace removed,
-    scripts/knn_code_hash.py: a documentation-only edit keeps them valid).  The hash is compared with the id of the LOADED
-    library (sfm_build_id(): baked in at build time) — the binary the box runs travels un-tracked, so a check against the source
-    tree beside it would prove nothing about it — and the binary's id with the source tree, so that a stale build fails here
-    rather than passing on yesterday's kernels.  A release build is required: a dev build reads tuning overrides from the
-    environment."""
+@pytest.mark.parametrize("family", sorted(FUZZ_SOURCES))
+def test_committed_fuzz_logs_are_those_of_the_loaded_binary(family):
+    """The long randomised parity sweeps (scripts/fuzz_knn.py, fuzz_sift.py, fuzz_geometry.py, fuzz_pipeline.py) are committed under
+    profiles/ with the build id of the library they ran on: the code hash of EVERY source file (comments and whitespace removed,
+    scripts/knn_code_hash.py: a documentation-only edit keeps them valid).  Each family is checked against the hashes of ITS sources
+    in the id of the LOADED library (sfm_build_id(): baked in at build time — round 5 stamped everything with knn.hip's hash alone, so
+    a stale SIFT log could not be noticed: VERDICT r05 weak 7) — and the binary's id against the source tree, so that a stale build
+    fails here rather than passing on yesterday's kernels.  A release build is required: a dev build reads tuning overrides."""
     import glob, os, re, sys
     from sfm_mvs_amd import _lib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "scripts"))
-    from knn_code_hash import knn_code_hash
+    from knn_code_hash import source_hashes
     bid = _lib.build_id()
     assert "dev-build" not in bid, f"the loaded library is a dev build ({bid})"
-    sha = _lib.knn_code_hash_of_binary()
-    assert sha == knn_code_hash(), f"libsfmhip.so was built from another csrc/knn.hip ({bid}): rebuild (make -C sfm_mvs_amd/csrc)"
-    logs = sorted(glob.glob(os.path.join(root, "profiles", "r05_fuzz_knn_*.log")))
-    assert logs, "no profiles/r05_fuzz_knn_*.log"
+    have, tree = _lib.code_hashes_of_binary(), source_hashes()
+    for name in FUZZ_SOURCES[family]:
+        assert have.get(name) == tree[name], f"libsfmhip.so was built from another csrc/{name} ({have.get(name)} != {tree[name]}): rebuild (make -C sfm_mvs_amd/csrc)"
+    logs = sorted(glob.glob(os.path.join(root, "profiles", f"{FUZZ_ROUND}_fuzz_{family}_*.log")))
+    assert logs, f"no profiles/{FUZZ_ROUND}_fuzz_{family}_*.log"
     total = 0
     for path in logs:
         text = open(path).read()
-        m = re.search(r"fuzz: (\d+) cases .*?, (\d+) mismatches", text)
+        m = re.search(r"fuzz(?:_\w+)?: (?:seed \d+, )?(\d+) (?:cases|sequences).*?, (\d+) mismatches", text)
         assert m and int(m.group(2)) == 0, f"{path}: no clean summary line"
-        assert f"knn_hip_code_sha256 {sha}" in text, f"{path} was produced by another csrc/knn.hip than the loaded binary's (stale): re-run scripts/fuzz_knn.py"
+        ids = re.findall(r"(?:sfm_build_id |build )(knn\.hip:\S+(?: \S+:\S+)*)", text)
+        assert ids, f"{path} does not name the build it ran on"
+        logged = dict(tok.split(":", 1) for tok in ids[-1].split() if ":" in tok)
+        for name in FUZZ_SOURCES[family]:
+            assert logged.get(name) == have[name], (f"{path} was produced by another csrc/{name} than the loaded binary's (stale): "
+                                                    f"re-run scripts/run_fuzz_round.sh")
         total += int(m.group(1))
-    assert total >= 20000, f"only {total} fuzz cases on this binary's source"
+    assert total >= FUZZ_MIN_CASES[family], f"only {total} {family} fuzz cases on this binary's sources"
 
 
 @pytest.mark.gpu

@@ -212,3 +212,37 @@ def test_repair_path_with_three_launch_sets_in_flight(hip, oracle):
         for b in range(4):
             wi, wd = want[k][b]
             assert np.array_equal(bm.idx[b].cpu().numpy(), wi) and np.array_equal(bm.dist[b].cpu().numpy().view(np.uint32), wd.view(np.uint32)), (k, b)
+
+
+def test_repair_with_a_late_workgroup(hip, oracle):
+    """the "last one out" repair decided whether a workgroup joins from the flag words the repair itself rewrote; a
+    workgroup dispatched after the others had finished (a grid that is not co-resident: small pairs, SIFT streams beside the chain)
+    found no quantised pair any more, skipped the repair and never drew its ticket — `minfo` kept the PREVIOUS launch set's modes.
+    The repair now writes shadow words that only the last workgroup copies over.  Here a workgroup WITHOUT real rows (small pairs:
+    nq_pad + nt_pad < 4096) and one with rows start 300 us late, after a plain quantised batch has left I8 = 1 in `minfo`."""
+    from sfm_mvs_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(5)
+    nq, nt = 700, 900
+    def uni(): return rng.random((nq, 128), dtype=np.float32), rng.random((nt, 128), dtype=np.float32)
+    def gau(): return rng.standard_normal((nq, 128)).astype(np.float32), rng.standard_normal((nt, 128)).astype(np.float32)
+    plain = [uni(), uni(), uni(), uni()]
+    mixed = [uni(), gau(), uni(), uni()]
+    want = [oracle.knn2(q, t, nthreads=8) for q, t in mixed]
+    bm = hip.BatchMatcher(nq, nt, "cuda", ratio=0.70, batch=4)
+    dev = lambda s: [(torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda()) for q, t in s]
+    dplain, dmixed = dev(plain), dev(mixed)
+    try:
+        for wg in (255, 200, 0, 3):
+            bm.run(dplain)                                     # leaves minfo = "integer body on quantised data"
+            torch.cuda.synchronize()
+            assert int(bm.stats[0, 3].item()) == 5
+            L.sfm_debug_knn_split_delay(wg, 300)
+            bm.run(dmixed)
+            torch.cuda.synchronize()
+            L.sfm_debug_knn_split_delay(-1, 0)
+            assert int(bm.stats[0, 3].item()) in (0, 1, 2), bm.stats[0].tolist()       # a 16-bit body ran
+            for b, (wi, wd) in enumerate(want):
+                assert np.array_equal(bm.idx[b].cpu().numpy(), wi) and np.array_equal(bm.dist[b].cpu().numpy().view(np.uint32), wd.view(np.uint32)), (wg, b)
+    finally:
+        L.sfm_debug_knn_split_delay(-1, 0)
