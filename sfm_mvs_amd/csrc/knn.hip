@@ -2515,6 +2515,9 @@ __device__ __forceinline__ void best2_reduce16_from_quad_lane2(Best2& b) {
 
 constexpr int kRatioBlock = 1024; // queries per ratio workgroup (256 threads x 4 consecutive queries)
 constexpr int kRefQ = 16;        // queries per refine workgroup: 16 lanes each
+constexpr int kQbStride = 144;   // integer bodies: bytes between the queries' byte rows in LDS (128 + 16: the four queries of a wave read four different bank groups;
+                                 // at 128 queries 0 / 2 and 1 / 3 collided: 9.8e5 bank conflicts per launch, profiles/r05_knn_pmc.md)
+static_assert(kRefQ * kQbStride <= kRefQ * 128 * 2, "the byte rows live in the fp16 body's qhalf / qrows arrays");
 constexpr int kS1 = 6;           // candidate records per lane fetched up front by sweep 1 (96 per query)
 constexpr int kRescanRows = 1;   // trains a quad has in flight during a rescan (32 VGPRs each)
 constexpr int kRefItems = 512;   // rescan work list (query, stream); more → 16 candidate slots per query at a time (<= 96)
@@ -2596,7 +2599,7 @@ __device__ __forceinline__ void refine_i8_body(
 #endif
 
     // the query's bytes -> LDS in element order (chunk 2 f + h of the fragment image = elements 32 f + 16 h .. + 15); wave-local
-    if (sl < 8) *reinterpret_cast<uint4*>(qb + ql * kDim + 16 * sl) =
+    if (sl < 8) *reinterpret_cast<uint4*>(qb + ql * kQbStride + 16 * sl) =
         *reinterpret_cast<const uint4*>(qi8 + (int64_t)(qc >> 5) * kI8QTileBytes + (sl >> 1) * 1024 + (((sl & 1) * 32 + (qc & 31)) << 4));
     const int cq = wq[qc] - 128;
     int kv[kS1];                                                 // kv[3 m + j]: key j of pair sl + 16 m (slot 3 (sl + 16 m) + j)
@@ -2652,7 +2655,7 @@ __device__ __forceinline__ void refine_i8_body(
         int s0 = 0, s1 = 0;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            const uint4 qv = *reinterpret_cast<const uint4*>(qb + qslot * kDim + 16 * c);
+            const uint4 qv = *reinterpret_cast<const uint4*>(qb + qslot * kQbStride + 16 * c);
             s0 = __builtin_amdgcn_sdot4((int)tv[c].x, (int)qv.x, s0, false);
             s1 = __builtin_amdgcn_sdot4((int)tv[c].y, (int)qv.y, s1, false);
             s0 = __builtin_amdgcn_sdot4((int)tv[c].z, (int)qv.z, s0, false);
@@ -2829,6 +2832,7 @@ __device__ __forceinline__ void refine_i8_body(
 // Everything below is float32 arithmetic in units of s on numbers <= 2^23; kQ8Rho = 4e-6 carries rho (1.9e-6) AND the roundings
 // of these few operations (each <= 6e-8 relative, a dozen of them): every bound is pushed outwards by it at every use.
 constexpr float kQ8Rho = 4e-6f, kQ8Eta = 1e-17f;
+
 __device__ __forceinline__ void refine_q8_body(
     const BatchPtrs& P, int B, int64_t ldq, int nq, int64_t ldt, int nt, int tiles, const int* __restrict__ minfo, const unsigned char* __restrict__ qi8,
     const unsigned char* __restrict__ ti8, int64_t s_qi8, int64_t s_ti8, const int* __restrict__ wq, const int* __restrict__ wt, int64_t s_qn, int64_t s_tn,
@@ -2860,7 +2864,7 @@ __device__ __forceinline__ void refine_q8_body(
     if (bid == 0 && threadIdx.x == 0 && stats) { stats[1] = G8; stats[2] = 2 * nstr; stats[3] = 5; }
 
     // the query's bytes (element order) and its float32 row -> LDS; wave-local
-    if (sl < 8) *reinterpret_cast<uint4*>(qb + ql * kDim + 16 * sl) =
+    if (sl < 8) *reinterpret_cast<uint4*>(qb + ql * kQbStride + 16 * sl) =
         *reinterpret_cast<const uint4*>(qi8 + (int64_t)(qc >> 5) * kI8QTileBytes + (sl >> 1) * 1024 + (((sl & 1) * 32 + (qc & 31)) << 4));
     {
         const float* src = Q + (int64_t)qc * ldq + 8 * sl;
@@ -2955,7 +2959,7 @@ __device__ __forceinline__ void refine_q8_body(
         int s0 = 0, s1 = 0;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            const uint4 qv = *reinterpret_cast<const uint4*>(qb + qslot * kDim + 16 * c);
+            const uint4 qv = *reinterpret_cast<const uint4*>(qb + qslot * kQbStride + 16 * c);
             s0 = __builtin_amdgcn_sdot4((int)tv[c].x, (int)qv.x, s0, false);
             s1 = __builtin_amdgcn_sdot4((int)tv[c].y, (int)qv.y, s1, false);
             s0 = __builtin_amdgcn_sdot4((int)tv[c].z, (int)qv.z, s0, false);
@@ -3088,8 +3092,28 @@ __device__ __forceinline__ void refine_q8_body(
         const int cq_w = __shfl(cq, src, 64), qloc_w = __shfl(qloc, src, 64);
         const int* __restrict__ kw = kq + 4 * (qloc_w - qloc);     // the open query's key slots
         const bool mine = sub == wl;
+        // Which streams are open?  The owner's lanes still HOLD the third keys of its first 16 kS1P pairs (kv[3 m + 2] of pair sl + 16 m):
+        // one ballot per m lists the pairs whose bound fails at the CURRENT second distance — a superset of what fails later, the
+        // distance only shrinks — and the walk visits those alone, in ascending pair order as before.  (Round 5 re-read every
+        // stream's third key from memory, one dependent load per pair: 32-64 round trips, most of the +17 us a rescanning wave cost.)
+        unsigned long long failm = 0;                              // bit pp: pair pp (< 16 kS1P) is open at the current bound
+#pragma unroll
+        for (int m = 0; m < kS1P; ++m)
+            failm |= ((__ballot(mine && !hides_nothing(kv[3 * m + 2], b.d[1])) >> src) & 0xFFFFull) << (16 * m);
         for (int c3 = 2; c3 < NC; c3 += 3) {
-            const int key3 = key_slot(kw, c3);                     // (uniform)
+            int key3;
+            if (c3 < 3 * 16 * kS1P) {
+                if (!failm) { c3 = 3 * 16 * kS1P - 1; continue; }  // (the pairs beyond the registers, if any, follow)
+                const int pp = (int)__builtin_ctzll(failm);
+                failm &= failm - 1;
+                c3 = 3 * pp + 2;
+                int held = kv[2];
+#pragma unroll
+                for (int m = 1; m < kS1P; ++m) held = (pp >> 4) == m ? kv[3 * m + 2] : held;
+                key3 = __shfl(held, src + (pp & 15), 64);          // (uniform)
+            } else {
+                key3 = key_slot(kw, c3);                           // (uniform)
+            }
             // the owner's lanes decide (their slack, their current second distance); everyone follows
             const bool hid = hides_nothing(key3, b.d[1]);
             const unsigned long long vote = __ballot(mine && !hid);
