@@ -184,8 +184,7 @@ __global__ __launch_bounds__(kSweepThreads) void pnp_sweep_kernel(PnpCam cam, co
 // (glibc sin / cos, the SVD of host_solvers.h) and posts the next request.  A link is two PCIe hops + the sweep.  The kernel leaves
 // on "quit", or on its own after kServerTimeoutTicks without a request (the host then relaunches it: a descheduled host thread must
 // not be able to hang a queue).
-constexpr int kServerMaxG = 1;                       // inlier sets up to 1 024 points (what a frame of the chain has); larger ones keep the launch-per-sweep path:
-                                                     // walking G > 1 virtual workgroups in one costs 17 us per extra pass (measured), more than G launches side by side
+constexpr int kServerMaxG = 8;                       // inlier sets up to 8 192 points; larger ones keep the launch-per-sweep path
 constexpr long long kServerTimeoutTicks = 100000000; // 1 s of the 100 MHz wall clock
 enum : uint32_t { kLmCmdSweep = 1, kLmCmdQuit = 2, kLmServerLeft = 0xFFFFFFFFu };
 struct alignas(64) LmMailbox {
@@ -197,16 +196,28 @@ struct alignas(64) LmMailbox {
 
 __device__ __forceinline__ uint32_t sys_load_u32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
-__global__ __launch_bounds__(kSweepThreads) void pnp_sweep_server_kernel(LmMailbox* __restrict__ mb, const float* __restrict__ X,
+// Layout of the server: the tree's lane L (virtual workgroup L / 1024, wave (L % 1024) / 64) is point L — G = ceil(m / 1024) <= kServerMaxG,
+// so a lane never has a second point.  The tree's WAVES are dealt four to a real workgroup of 256 lanes (one wave per SIMD: a wave
+// alone on its SIMD issues four times as fast as sixteen sharing a CU), only waves that own points exist, every workgroup polls the
+// mailbox itself, and wave sums meet in device memory: part[wave][28], a release fence, one ticket per workgroup on `arrive`; the
+// leader (workgroup 0) waits for the request's tickets, and adds   0 + wave 0 + ... + wave 15   per virtual workgroup, then
+// 0 + workgroup 0 + ... (G > 1) — pnp_sweep_kernel's order; an absent wave's sum is +0, which changes no partial sum.
+// (<= 1 024 inliers: ONE workgroup of 1 024 lanes instead — no ticket, no second hop: 34 against 40 us per five sweeps, measured.)
+template <int kServerThreads>
+__global__ __launch_bounds__(kServerThreads) void pnp_sweep_server_kernel(LmMailbox* __restrict__ mb, const float* __restrict__ X,
                                                                          const float* __restrict__ uv, const int32_t* __restrict__ sel,
-                                                                         int m, int G, uint32_t first_seq) {
-    __shared__ double wacc[kSweepThreads / 64][kSweepAcc];
-    __shared__ double total[kSweepAcc];
+                                                                         int m, int G, uint32_t first_seq, double* __restrict__ part,
+                                                                         unsigned int* __restrict__ arrive /*zeroed before the launch*/) {
+    constexpr int kServerWavesPerWg = kServerThreads / 64;
+    __shared__ double wacc[kServerWavesPerWg][kSweepAcc];
+    __shared__ double fold[kServerThreads == 1024 ? 1 : kServerMaxG * 16][kSweepAcc + 1];
     __shared__ PnpCam cam;
     __shared__ uint32_t s_cmd;
-    const int tid = threadIdx.x;
-    // a lane's correspondences do not change between requests: G == 1 (<= 1 024 inliers, the usual case) keeps them in registers
-    const int i0 = tid < m ? (sel ? sel[tid] : tid) : -1;
+    const int tid = threadIdx.x, wg = blockIdx.x, nwg = gridDim.x;
+    const int nwaves = (m + 63) >> 6;
+    const int L = wg * kServerThreads + tid;                   // the tree's lane = the point
+    const int i0 = L < m ? (sel ? sel[L] : L) : -1;             // (does not change between requests)
+    unsigned int served = 0;
     for (uint32_t seq = first_seq;; ++seq) {
         if (tid == 0) {
             const long long t0 = wall_clock64();
@@ -226,41 +237,64 @@ __global__ __launch_bounds__(kSweepThreads) void pnp_sweep_server_kernel(LmMailb
         __syncthreads();
         const uint32_t cmd = s_cmd;
         if (cmd != kLmCmdSweep) {
-            if (tid == 0) {
+            if (wg == 0 && tid == 0)
                 __hip_atomic_store(&mb->done_seq, cmd == kLmCmdQuit ? seq : (uint32_t)kLmServerLeft, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
             return;
         }
         if (tid < (int)(sizeof(PnpCam) / sizeof(double)))
             reinterpret_cast<double*>(&cam)[tid] =
                 __hip_atomic_load(reinterpret_cast<const double*>(&mb->cam) + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __syncthreads();
-        for (int g = 0; g < G; ++g) {                       // the G workgroups of pnp_sweep_kernel's tree, one after the other
-            double acc[kSweepAcc];
+        double acc[kSweepAcc];
 #pragma unroll
-            for (int k = 0; k < kSweepAcc; ++k) acc[k] = 0;
-            if (G == 1) {
-                if (i0 >= 0) pnp_sweep_point<1>(cam, X, uv, i0, acc);
-            } else {
-                for (int o = g * kSweepThreads + tid; o < m; o += G * kSweepThreads) pnp_sweep_point<1>(cam, X, uv, sel ? sel[o] : o, acc);
-            }
-            if (g * kSweepThreads + (tid & ~63) < m)
-                pnp_sweep_wave_fold<0>(acc, wacc);
-            else if ((tid & 63) < kSweepAcc)                // a wave without points: the butterfly of zeros is +0
-                wacc[tid >> 6][tid & 63] = 0.0;
-            __syncthreads();
+        for (int k = 0; k < kSweepAcc; ++k) acc[k] = 0;
+        if (i0 >= 0) pnp_sweep_point<1>(cam, X, uv, i0, acc);
+        if ((L & ~63) < m) pnp_sweep_wave_fold<0>(acc, wacc);   // (a wave without points, in the last workgroup: never read)
+        __syncthreads();
+        ++served;
+        if (nwg == 1) {                                          // <= 256 inliers: nothing leaves the workgroup
             if (tid < kSweepAcc) {
                 double s = 0;
-                for (int w = 0; w < kSweepThreads / 64; ++w) s += wacc[w][tid];
-                total[tid] = G == 1 ? s : (g == 0 ? 0.0 : total[tid]) + s;      // G > 1: 0 + workgroup 0 + workgroup 1 + ... (pnp_sweep_fold_kernel)
+                for (int w = 0; w < nwaves; ++w) s += wacc[w][tid];
+                __hip_atomic_store(&mb->sums[tid], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        } else {
+            if (tid < kServerWavesPerWg * kSweepAcc && wg * kServerWavesPerWg + tid / kSweepAcc < nwaves)
+                part[(size_t)(wg * kServerWavesPerWg + tid / kSweepAcc) * kSweepAcc + tid % kSweepAcc] = wacc[tid / kSweepAcc][tid % kSweepAcc];
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the ticket must not overtake the write-back)
+                __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (wg != 0) continue;
+            if (tid == 0) {
+                const unsigned int want = served * (unsigned int)nwg;
+                while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
             __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // every reader's cache, not only lane 0's
+            for (int e = tid; e < nwaves * kSweepAcc; e += kServerThreads)
+                fold[e / kSweepAcc][e % kSweepAcc] = __hip_atomic_load(&part[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (tid < kSweepAcc) {
+                double total = 0;
+                for (int g = 0; g < G; ++g) {
+                    double s = 0;
+                    const int w1 = min(16 * (g + 1), nwaves);
+                    for (int w = 16 * g; w < w1; ++w) s += fold[w][tid];
+                    total = G == 1 ? s : total + s;
+                }
+                __hip_atomic_store(&mb->sums[tid], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
-        if (tid < kSweepAcc) __hip_atomic_store(&mb->sums[tid], total[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __syncthreads();
-        if (tid == 0) {
-            __atomic_thread_fence(__ATOMIC_RELEASE);
-            __hip_atomic_store(&mb->done_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (wg == 0) {
+            __syncthreads();
+            if (tid == 0) {
+                __atomic_thread_fence(__ATOMIC_RELEASE);
+                __hip_atomic_store(&mb->done_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
 }
@@ -414,10 +448,11 @@ struct SweepServer {
     const int32_t* sel;
     int m, G;
     hipStream_t stream;
+    double* part;                                   // device: [<= 128 waves][28] wave sums, then the arrival counter
     uint32_t seq = 0;
     bool running = false;
-    SweepServer(LmMailbox* mb_, const float* X_, const float* uv_, const int32_t* sel_, int m_, int G_, hipStream_t s)
-        : mb(mb_), X(X_), uv(uv_), sel(sel_), m(m_), G(G_), stream(s) {}
+    SweepServer(LmMailbox* mb_, const float* X_, const float* uv_, const int32_t* sel_, int m_, int G_, hipStream_t s, double* part_)
+        : mb(mb_), X(X_), uv(uv_), sel(sel_), m(m_), G(G_), stream(s), part(part_) {}
     ~SweepServer() { (void)stop(); }
     int start() {
         // sequence numbers continue across calls (the mailbox is per host thread): a request can never be mistaken for an old one
@@ -425,7 +460,13 @@ struct SweepServer {
         if (seq >= 0x3FFF0000u) seq = 0;            // (the block sits at a size-dependent offset of the mailbox: whatever was there; never near kLmServerLeft)
         __atomic_store_n(&mb->cmd_seq, seq << 2, __ATOMIC_RELAXED);
         __atomic_store_n(&mb->done_seq, seq, __ATOMIC_RELEASE);
-        hipLaunchKernelGGL(pnp_sweep_server_kernel, dim3(1), dim3(kSweepThreads), 0, stream, mb, X, uv, sel, m, G, seq + 1);
+        unsigned int* arrive = reinterpret_cast<unsigned int*>(part + (size_t)kSweepAcc * kServerMaxG * 16);
+        if (m <= 1024) {
+            hipLaunchKernelGGL(pnp_sweep_server_kernel<1024>, dim3(1), dim3(1024), 0, stream, mb, X, uv, sel, m, G, seq + 1, part, arrive);
+        } else {
+            SFM_CHECK_HIP(hipMemsetAsync(arrive, 0, sizeof(unsigned int), stream));
+            hipLaunchKernelGGL(pnp_sweep_server_kernel<256>, dim3((m + 255) / 256), dim3(256), 0, stream, mb, X, uv, sel, m, G, seq + 1, part, arrive);
+        }
         SFM_CHECK_LAUNCH();
         running = true;
         return SFM_OK;
@@ -652,7 +693,8 @@ extern "C" size_t sfm_solve_pnp_ransac_ws_bytes(int64_t n) {
     if (n < 0) return 0;
     const size_t hmax = 64;
     return sfm::align_up(sizeof(double) * 6 * hmax, 256) + sfm::align_up(sizeof(int32_t) * hmax, 256) + sfm::align_up(hmax * (size_t)n, 256) +
-           sfm::align_up((size_t)n, 256) + sfm::align_up(sizeof(double) * kSweepAcc * (kSweepMaxBlocks + 1), 256) + 1024;
+           sfm::align_up((size_t)n, 256) + sfm::align_up(sizeof(double) * kSweepAcc * (kSweepMaxBlocks + 1), 256) +
+           sfm::align_up(sizeof(double) * kSweepAcc * kServerMaxG * 16 + 64, 256) + 1024;
 }
 
 extern "C" int sfm_solve_pnp_ransac(const float* X_dev, const float* uv_dev, int64_t n, const double* K, int iterations,
@@ -675,6 +717,7 @@ extern "C" int sfm_solve_pnp_ransac(const float* X_dev, const float* uv_dev, int
     uint8_t* masks_dev = c.take<uint8_t>(hmax * (size_t)n);
     uint8_t* best_dev = c.take<uint8_t>((size_t)n);
     double* sweep_dev = c.take<double>((size_t)kSweepAcc * (kSweepMaxBlocks + 1));
+    double* server_part = c.take<double>((size_t)kSweepAcc * kServerMaxG * 16 + 8);      // the sweep server's wave sums, then its arrival counter
 
     double tp = now_us();
     auto lap = [&](int k) { const double t1 = now_us(); g_pnp_prof.t[k] += t1 - tp; tp = t1; };
@@ -821,9 +864,9 @@ extern "C" int sfm_solve_pnp_ransac(const float* X_dev, const float* uv_dev, int
     lap(3);
     // solvePnP(ITERATIVE) on the inliers: DLT initialisation on the host, Levenberg-Marquardt with the sweeps on the device
     const int blocks = (int)std::min<int64_t>((m_in + kSweepThreads - 1) / kSweepThreads, kSweepMaxBlocks);
-    // <= 1 024 inliers: the sweep server (one launch per call, requests through the mailbox); more: a launch set per sweep.
+    // <= 8 192 inliers: the sweep server (one launch per call, requests through the mailbox); more: a launch set per sweep.
     // The server is started BEFORE the DLT initialisation so that its launch latency hides behind ~30 us of host work.
-    SweepServer server(reinterpret_cast<LmMailbox*>(mb + o_lm), X_dev, uv_dev, inliers_dev, (int)m_in, blocks, stream);
+    SweepServer server(reinterpret_cast<LmMailbox*>(mb + o_lm), X_dev, uv_dev, inliers_dev, (int)m_in, blocks, stream, server_part);
     const bool served = blocks <= kServerMaxG && !g_no_sweep_server;
     if (served) {
         const int rc0 = server.start();
