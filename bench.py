@@ -26,7 +26,7 @@ import time
 
 # The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); two streams sharing one are serialised by
 # each other's barrier packets.  A rank uses three launch-set streams + the stream that issues the collectives + RCCL's
-# own: with 4 queues the exchange path lost 14 % (scripts/dev/dev_exchange.py).  Must be set before the runtime initialises.
+# own: with 4 queues the exchange path lost 14 % (scripts/dev/dev_exchange.py of the round-5 tree).  Must be set before the runtime initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np
@@ -43,7 +43,7 @@ PROF_SAMPLES = 6                   # profiled steps, run alone AFTER the timed r
 PIPE_DEPTH = 2                     # KNN launch sets in flight (one stream + workspace each).  Two are ~4 % faster than three (0.176 vs 0.185 ms) — but about one
                                    # fresh pair of streams in 24 is served one after the other by the runtime (0.22 ms, the one-stream figure), so the set-up
                                    # probes the pipeline's streams and keeps the fastest of STREAM_TRIES sets (ops.BatchPipeline.tune_streams; untimed;
-                                   # profiles/r05_knn_pipe_depth.txt, scripts/dev/depth2_streams.py)
+                                   # profiles/r05_knn_pipe_depth.txt, scripts/dev/depth2_streams.py of the round-5 tree)
 STREAM_TRIES = 3
 SIFT_DEPTH = 3                     # SIFT frames in flight
 N_SETS = 2                         # sets of PAIR_BATCH distinct image pairs rotating over the steps
@@ -275,7 +275,7 @@ def bench_knn(args, world, rank, dev):
 
     # Set-up, not steps.  (1) every stream is created and every matcher's kernels are loaded once (a HIP stream's first
     # launch costs milliseconds).  (2) The device is brought to its sustained clock: after an idle period the MI355X runs the
-    # same launch set ~20 % slower and takes ~25 ms of load to ramp up (scripts/dev/dev_ramp.py: 43 -> 36 us per pair over the
+    # same launch set ~20 % slower and takes ~25 ms of load to ramp up (scripts/dev/dev_ramp.py of the round-5 tree: 43 -> 36 us per pair over the
     # first 200 launch sets), far longer than W warm-up steps; the path is a throughput path (thousands of pairs per job), so
     # the steady state is what is measured.  CLOCK_WARMUP_STEPS untimed steps (~60 ms of load), then the W warm-up steps.
     for st, pmx in zip(pipe.streams, pipe.matchers):

@@ -68,7 +68,7 @@ const char* sfm_build_id(void);
  * The result is bit-identical to the direct-form float32 evaluation for any finite input whose squared row
  * norms are finite in float32 (|x| up to ~1e18; see docs/knn.md, "Domain of the parity claim").  Beyond that the
  * filters' scores ||t||^2 + ||q||^2 - 2 q.t are +inf / NaN while some direct-form distances are still finite: measured
- * wrong at 3e18, right again from 1e19 on, where every distance is +inf and the index order decides (scripts/dev/q8_huge.py).
+ * wrong at 3e18, right again from 1e19 on, where every distance is +inf and the index order decides (scripts/dev/q8_huge.py of the round-5 tree).
  *
  * `filter` — the candidate filter that runs before the exact refine.  A per-call argument (ABI 1 had
  * a process-global switch); results are bit-identical whichever runs, the _ws_bytes twin takes the same value:

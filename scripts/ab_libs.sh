@@ -1,6 +1,6 @@
 #!/bin/bash
 # Dev: same-box A/B of two library builds: batched kernel stats (uniform = quantised body, SIFT-like = exact-integer body) + bench line.
-# usage (via gpurun): bash scripts/dev/ab_r05.sh libsfmhip_old.so libsfmhip.so
+# usage (via gpurun): bash scripts/ab_libs.sh libsfmhip_old.so libsfmhip.so
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=/root/repo
 cd /tmp && export TMPDIR=/tmp
 stats() {   # $1 lib, rest: run_knn_* command

@@ -1,5 +1,5 @@
 """Dev: per-basic-block instruction census of one kernel in a hipcc -S listing.
-usage: python scripts/dev/isa_loops.py build/isa/knn.s <kernel-name-substring> <opcode that marks the blocks of interest> [min count]"""
+usage: python scripts/isa_loops.py build/isa/knn.s <kernel-name-substring> <opcode that marks the blocks of interest> [min count]"""
 import re, sys
 path, kern, mark = sys.argv[1:4]
 minc = int(sys.argv[4]) if len(sys.argv) > 4 else 4

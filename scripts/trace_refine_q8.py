@@ -1,7 +1,7 @@
 """Dev diagnostics: per-workgroup phase timestamps of refine_q8_body for one BATCHED launch set (SFM_KNN_Q8=1)."""
 import os, sys, ctypes
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sfm_mvs_amd import ops, _lib
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 nq = nt = 10000

@@ -149,7 +149,7 @@ __host__ __device__ inline int64_t part_begin(const Partition& pt, int b) {
     return x < pt.units ? x : pt.units;
 }
 constexpr int kSegCostTiles = 5;
-// Tuning switches read from the environment exist in DEV builds only (make CXXFLAGS+=-DSFM_DEV_BUILD, scripts/dev/): a release
+// Tuning switches read from the environment exist in DEV builds only (make CXXFLAGS+=-DSFM_DEV_BUILD): a release
 // library takes no override — what the parity sweeps ran on is what ships (sfm_build_id() names it).
 #ifdef SFM_DEV_BUILD
 int dev_env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }

@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256) void triangulate_kernel(ProjPair P, const floa
         if (normalise_w == 2) have = dlt_nullvec_fast(At, Xd, &sens);
 #ifdef SFM_DEV_BUILD
         if (normalise_w == 4) {
-            // dev calibration of the guard (scripts/dev/dev_tri_calib.py; not in release builds) on the SHIPPED configuration: the
+            // dev calibration of the guard (scripts/dev/dev_tri_calib.py of the round-5 tree; not in release builds) on the SHIPPED configuration: the
             // inverse iteration on the FMA-fused system (dlt_build<4, true>: what triangulate_guarded_kernel / tri_matches_points_kernel
             // solve) against the Jacobi path on the unfused one (what the fix-up pass and the faithful kernel solve).  Fusing moves
             // every entry of A by ~1 ulp, i.e. the null vector by the order of `sens` itself, so the two must be measured together.
@@ -650,7 +650,7 @@ extern "C" int sfm_triangulate_dlt(const double* P1, const double* P2, const flo
                                    void* stream_) {
     SFM_CHECK_ARG(rows == 4 || rows == 6, "sfm_triangulate_dlt: rows must be 4 or 6 (got %d)", rows);
 #ifdef SFM_DEV_BUILD
-    constexpr int kMaxMode = 4;     // + the calibration mode of scripts/dev/dev_tri_calib.py
+    constexpr int kMaxMode = 4;     // + the calibration mode of scripts/dev/dev_tri_calib.py of the round-5 tree
 #else
     constexpr int kMaxMode = 3;
 #endif
