@@ -1252,6 +1252,7 @@ __global__ __launch_bounds__(kSplitThreads) void knn_split_images_kernel(BatchPt
         // fence) and reduces the modes again, alone.  Nobody waits for anybody, so the others cannot know the outcome: they do below
         // whatever ANY outcome could need — the u8 chunks' fp16 image and the bf16 planes of every pair — and leave `minfo` alone.
         __shared__ int last_s;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");               // every lane: its own image / residual stores have left
         __syncthreads();
         if (threadIdx.x == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");

@@ -171,76 +171,162 @@ __global__ __launch_bounds__(kSweepThreads) void pnp_sweep_kernel(PnpCam cam, co
     }
 }
 
-// ---- the sweep SERVER: Levenberg-Marquardt without a launch or a stream synchronisation per iteration -------------------------
-// cvFindExtrinsicCameraParams2's loop is a chain  parameters -> sweep -> 6x6 damped SVD solve -> accept / reject -> parameters  of
-// 5-6 links per camera.  Round 5 paid a kernel launch, a completion signal and a host wake-up per link (~30 us, of which the sweep
-// itself is ~3).  The 6x6 one-sided Jacobi SVD is ~90 strictly sequential rotations, each a dependent chain of a division, two
-// square roots and a hypot: ~2 us on a host core, an estimated 30-35 us on ONE lane of a CU (docs/geometry.md) — moving the algebra
-// to the device would cost what the round trip costs.  So the device side of the loop becomes a SERVER instead: ONE workgroup,
-// launched once per call, that holds the inlier set and answers "sweep at these parameters" requests posted in the caller's pinned,
-// fine-grained mailbox (LmMailbox): the host writes R, t, dR/dr and bumps `cmd_seq`; lane 0 polls it (system-scope loads), the
-// workgroup sweeps with the SAME fixed reduction tree as pnp_sweep_kernel (its G workgroups are walked one after the other), writes
-// the 28 sums back and bumps `done_seq`; the host — spinning on its own cache line — runs CvLevMarq's algebra exactly as before
-// (glibc sin / cos, the SVD of host_solvers.h) and posts the next request.  A link is two PCIe hops + the sweep.  The kernel leaves
-// on "quit", or on its own after kServerTimeoutTicks without a request (the host then relaunches it: a descheduled host thread must
-// not be able to hang a queue).
-constexpr int kServerMaxG = 8;                       // inlier sets up to 8 192 points; larger ones keep the launch-per-sweep path
+// ---- the PnP SERVER: sfm_solve_pnp_ransac without a launch, a copy or a stream synchronisation per step -------------------------
+// solvePnPRansac is a chain of small dependent steps — read the correspondences, score a chunk of hypotheses, list the inliers,
+// then cvFindExtrinsicCameraParams2's loop  parameters -> sweep -> 6x6 damped SVD solve -> accept / reject  (5-6 links) — each of
+// which round 5 paid for with a launch, a completion signal and a host wake-up (~30 us per link; the work itself is 1-3 us).  The
+// algebra stays on the host: the 6x6 one-sided Jacobi SVD is ~90 strictly sequential rotations, each a dependent chain of a division,
+// two square roots and a hypot — ~2 us on a host core, an estimated 30-35 us on ONE lane of a CU (a dependent fp64 operation issues
+// every 13 ns there: scripts/ubench/idle_clock.hip) — so moving it to the device would cost what the round trip costs.  The DEVICE
+// side becomes a server instead: a few workgroups, launched once per call, resident for its duration, that answer requests posted in
+// the caller's pinned, fine-grained mailbox (PnpMailbox).  The host writes the payload, then ONE 64-bit word (request number,
+// command, argument); lane 0 of every workgroup polls that word (system-scope loads); the answer goes back into the mailbox and the
+// leader bumps `done_seq`, on which the host spins in its own cache.  A link is two PCIe hops + the work.  Commands:
+//   copy-in    the correspondences (float32 X, uv) -> mailbox: what the host-side hypothesis generators sample from
+//   score      H models (R, t computed by the HOST: the Rodrigues the oracle and cv2 evaluate on the CPU) -> one 64-bit inlier mask per
+//              wave and model; the host counts bits, replays OpenCV's bookkeeping and reads the winner's inlier list off the mask
+//   inliers    the winner's ascending inlier list -> the lanes' selection (point of tree lane L) and the caller's `inliers_dev`
+//   sweep      R, t, dR/dr -> the 28 sums of J^T J, J^T e, |e|^2 over the inliers, pnp_sweep_kernel's FIXED TREE
+//   quit
+// Layout: the tree's lane L (virtual workgroup L / 1024, wave (L % 1024) / 64) is point L of the current selection.  <= 1 024
+// points: ONE workgroup of 1 024 lanes.  More: workgroups of 256 lanes (one tree wave per SIMD: a wave alone on its SIMD issues four
+// times as fast as sixteen sharing a CU); results meet in device memory behind one ticket per workgroup and request, and the leader
+// (workgroup 0) adds   0 + wave 0 + ... + wave 15   per virtual workgroup, then   0 + workgroup 0 + ...   — pnp_sweep_kernel's
+// order; a wave without points contributes +0, which changes no partial sum.  The server leaves on "quit", or on its own after
+// kServerTimeoutTicks without a request (the host then starts another and replays the selection: a descheduled host thread must not
+// be able to hang a queue).
+constexpr int kServerMaxG = 8, kServerMaxN = 1024 * kServerMaxG;   // correspondences a served call may have; larger ones keep the launch path
+constexpr int kServerMaxWaves = kServerMaxN / 64, kServerMaxModels = 64;
 constexpr long long kServerTimeoutTicks = 100000000; // 1 s of the 100 MHz wall clock
-enum : uint32_t { kLmCmdSweep = 1, kLmCmdQuit = 2, kLmServerLeft = 0xFFFFFFFFu };
-struct alignas(64) LmMailbox {
-    uint32_t cmd_seq, pad0[15];                      // host -> device, written last: request number << 2 | command
-    PnpCam cam;
-    alignas(64) uint32_t done_seq, pad1[15];         // device -> host (written last); kLmServerLeft: the server gave up waiting
+enum : uint32_t { kCmdNone = 0, kCmdSweep = 1, kCmdQuit = 2, kCmdCopyIn = 3, kCmdScore = 4, kCmdInliers = 5, kServerLeft = 0xFFFFFFFFu };
+struct alignas(64) PnpMailbox {
+    unsigned long long request, pad0[7];             // host -> device, written last: number << 40 | command << 32 | argument
+    PnpCam cam;                                      // sweep: R, t, dR/dr, intrinsics (score: intrinsics only)
+    alignas(64) uint32_t done_seq, pad1[15];         // device -> host (written last); kServerLeft: the server gave up waiting
     double sums[kSweepAcc];
+    alignas(64) double models[kServerMaxModels * 12];               // score: R (9, row-major), t (3) per model
+    unsigned long long bits[kServerMaxModels * kServerMaxWaves];    // score: [model][wave] inlier masks
 };
+constexpr unsigned long long kSeqMask = 0xFFFFFFull;
 
-__device__ __forceinline__ uint32_t sys_load_u32(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ unsigned long long sys_load_u64(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
-// Layout of the server: the tree's lane L (virtual workgroup L / 1024, wave (L % 1024) / 64) is point L — G = ceil(m / 1024) <= kServerMaxG,
-// so a lane never has a second point.  The tree's WAVES are dealt four to a real workgroup of 256 lanes (one wave per SIMD: a wave
-// alone on its SIMD issues four times as fast as sixteen sharing a CU), only waves that own points exist, every workgroup polls the
-// mailbox itself, and wave sums meet in device memory: part[wave][28], a release fence, one ticket per workgroup on `arrive`; the
-// leader (workgroup 0) waits for the request's tickets, and adds   0 + wave 0 + ... + wave 15   per virtual workgroup, then
-// 0 + workgroup 0 + ... (G > 1) — pnp_sweep_kernel's order; an absent wave's sum is +0, which changes no partial sum.
-// (<= 1 024 inliers: ONE workgroup of 1 024 lanes instead — no ticket, no second hop: 34 against 40 us per five sweeps, measured.)
 template <int kServerThreads>
-__global__ __launch_bounds__(kServerThreads) void pnp_sweep_server_kernel(LmMailbox* __restrict__ mb, const float* __restrict__ X,
-                                                                         const float* __restrict__ uv, const int32_t* __restrict__ sel,
-                                                                         int m, int G, uint32_t first_seq, double* __restrict__ part,
-                                                                         unsigned int* __restrict__ arrive /*zeroed before the launch*/) {
-    constexpr int kServerWavesPerWg = kServerThreads / 64;
-    __shared__ double wacc[kServerWavesPerWg][kSweepAcc];
-    __shared__ double fold[kServerThreads == 1024 ? 1 : kServerMaxG * 16][kSweepAcc + 1];
+__global__ __launch_bounds__(kServerThreads) void pnp_server_kernel(PnpMailbox* __restrict__ mb, const float* __restrict__ X, const float* __restrict__ uv,
+                                                                    int n, float thr2, float* __restrict__ hX, float* __restrict__ huv,
+                                                                    const int32_t* __restrict__ hinl, int32_t* __restrict__ inliers_dev,
+                                                                    uint32_t first_seq, double* __restrict__ part, unsigned int* __restrict__ arrive) {
+    constexpr int kWavesPerWg = kServerThreads / 64;
+    constexpr bool kSingle = kServerThreads == 1024;
+    __shared__ double wacc[kWavesPerWg][kSweepAcc];
+    __shared__ double fold[kSingle ? 1 : kServerMaxWaves][kSweepAcc + 1];
+    __shared__ double models[kServerMaxModels * 12];
     __shared__ PnpCam cam;
-    __shared__ uint32_t s_cmd;
+    __shared__ unsigned long long s_req;
     const int tid = threadIdx.x, wg = blockIdx.x, nwg = gridDim.x;
-    const int nwaves = (m + 63) >> 6;
-    const int L = wg * kServerThreads + tid;                   // the tree's lane = the point
-    const int i0 = L < m ? (sel ? sel[L] : L) : -1;             // (does not change between requests)
+    const int L = wg * kServerThreads + tid, lane = tid & 63;     // the tree's lane; its wave: L >> 6
+    int m = 0, nwaves = 0, i0 = -1;                                // the current selection (set by "inliers")
     unsigned int served = 0;
-    for (uint32_t seq = first_seq;; ++seq) {
+    // every workgroup's stores have left, and (several workgroups) every workgroup has arrived, before the leader answers
+    // Every store that leaves a workgroup here is WRITE-THROUGH — the mailbox is fine-grained host memory (uncached on the device),
+    // `part` is written with agent-scope atomic stores — so "has left" is a wait for the lane's own outstanding stores, not a cache
+    // write-back (a system-scope release fence per wave walks the L2: 37 us per request with 24 workgroups, measured).
+    auto finish = [&](uint32_t seq) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // EVERY lane: its own stores have been acknowledged
+        __syncthreads();
+        if (!kSingle) {
+            ++served;
+            if (tid == 0) {
+                __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (wg == 0) {
+                    const unsigned int want = served * (unsigned int)nwg;
+                    while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+            }
+            __syncthreads();
+        }
+        (void)seq;
+    };
+    auto answer = [&](uint32_t seq) {                              // (leader, after its last mailbox store)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (wg == 0 && tid == 0) __hip_atomic_store(&mb->done_seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    };
+    for (uint32_t seq = first_seq & (uint32_t)kSeqMask;; seq = (seq + 1) & (uint32_t)kSeqMask) {
         if (tid == 0) {
             const long long t0 = wall_clock64();
-            uint32_t c = 0;
+            unsigned long long r = 0;
             for (;;) {
-                const uint32_t w = sys_load_u32(&mb->cmd_seq);
-                if ((w >> 2) == seq) {
+                const unsigned long long w = sys_load_u64(&mb->request);
+                if ((uint32_t)(w >> 40) == seq) {
                     __atomic_thread_fence(__ATOMIC_ACQUIRE);
-                    c = w & 3u;
+                    r = w;
                     break;
                 }
                 if (wall_clock64() - t0 > kServerTimeoutTicks) break;
                 __builtin_amdgcn_s_sleep(1);
             }
-            s_cmd = c;
+            s_req = r;
         }
         __syncthreads();
-        const uint32_t cmd = s_cmd;
-        if (cmd != kLmCmdSweep) {
+        const unsigned long long req = s_req;
+        const uint32_t cmd = (uint32_t)(req >> 32) & 0xFFu, arg = (uint32_t)req;
+        if (cmd == kCmdQuit || cmd == kCmdNone) {
             if (wg == 0 && tid == 0)
-                __hip_atomic_store(&mb->done_seq, cmd == kLmCmdQuit ? seq : (uint32_t)kLmServerLeft, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(&mb->done_seq, cmd == kCmdQuit ? seq : (uint32_t)kServerLeft, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             return;
         }
+        if (cmd == kCmdCopyIn) {
+            // plain, lane-contiguous dword stores: a wave's 256 bytes leave as whole 64-byte writes (one system-scope store per value
+            // was 90 ns EACH over PCIe: 139 us for 300 points)
+            const int stride = nwg * kServerThreads;
+            for (int e = L; e < 3 * n; e += stride) hX[e] = X[e];
+            for (int e = L; e < 2 * n; e += stride) huv[e] = uv[e];
+            __atomic_thread_fence(__ATOMIC_RELEASE);                 // (plain stores: written back to host memory here — the one request that needs it)
+            finish(seq);
+            answer(seq);
+            continue;
+        }
+        if (cmd == kCmdScore) {
+            // score_pnp_kernel's arithmetic on R, t the host evaluated: err = (float)(ex^2 + ey^2) of the float32 differences, in <= thr2
+            const int H = (int)arg;
+            for (int e = tid; e < 12 * H; e += kServerThreads)
+                models[e] = __hip_atomic_load(&mb->models[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (tid < 4) reinterpret_cast<double*>(&cam.fx)[tid] = __hip_atomic_load(&mb->cam.fx + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __syncthreads();
+            float Xw = 0.f, Yw = 0.f, Zw = 0.f, ou = 0.f, ov = 0.f;
+            if (L < n) { Xw = X[3 * L]; Yw = X[3 * L + 1]; Zw = X[3 * L + 2]; ou = uv[2 * L]; ov = uv[2 * L + 1]; }
+            if ((L & ~63) < n)
+                for (int h = 0; h < H; ++h) {
+                    const double* e = models + 12 * h;
+                    double x = e[0] * (double)Xw + e[1] * (double)Yw + e[2] * (double)Zw + e[9];
+                    double y = e[3] * (double)Xw + e[4] * (double)Yw + e[5] * (double)Zw + e[10];
+                    double z = e[6] * (double)Xw + e[7] * (double)Yw + e[8] * (double)Zw + e[11];
+                    z = z != 0.0 ? 1. / z : 1.;
+                    x *= z;
+                    y *= z;
+                    const double u = x * cam.fx + cam.cx, v = y * cam.fy + cam.cy;
+                    const float ex = ou - (float)u, ey = ov - (float)v;
+                    const float err = (float)((double)ex * (double)ex + (double)ey * (double)ey);
+                    const unsigned long long bal = __ballot(L < n && err <= thr2);
+                    if (lane == 0) __hip_atomic_store(&mb->bits[(size_t)h * kServerMaxWaves + (L >> 6)], bal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            finish(seq);
+            answer(seq);
+            continue;
+        }
+        if (cmd == kCmdInliers) {                                  // (no answer: the next request follows in order)
+            m = (int)arg;
+            nwaves = (m + 63) >> 6;
+            i0 = -1;
+            if (L < m) {
+                i0 = __hip_atomic_load(&hinl[L], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                inliers_dev[L] = i0;
+            }
+            continue;
+        }
+        // ---- sweep
         if (tid < (int)(sizeof(PnpCam) / sizeof(double)))
             reinterpret_cast<double*>(&cam)[tid] =
                 __hip_atomic_load(reinterpret_cast<const double*>(&mb->cam) + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -249,53 +335,38 @@ __global__ __launch_bounds__(kServerThreads) void pnp_sweep_server_kernel(LmMail
 #pragma unroll
         for (int k = 0; k < kSweepAcc; ++k) acc[k] = 0;
         if (i0 >= 0) pnp_sweep_point<1>(cam, X, uv, i0, acc);
-        if ((L & ~63) < m) pnp_sweep_wave_fold<0>(acc, wacc);   // (a wave without points, in the last workgroup: never read)
+        if ((L & ~63) < m) pnp_sweep_wave_fold<0>(acc, wacc);       // (a wave without points: never read)
         __syncthreads();
-        ++served;
-        if (nwg == 1) {                                          // <= 256 inliers: nothing leaves the workgroup
+        const int G = (m + 1023) >> 10;
+        if (kSingle) {
             if (tid < kSweepAcc) {
                 double s = 0;
                 for (int w = 0; w < nwaves; ++w) s += wacc[w][tid];
                 __hip_atomic_store(&mb->sums[tid], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         } else {
-            if (tid < kServerWavesPerWg * kSweepAcc && wg * kServerWavesPerWg + tid / kSweepAcc < nwaves)
-                part[(size_t)(wg * kServerWavesPerWg + tid / kSweepAcc) * kSweepAcc + tid % kSweepAcc] = wacc[tid / kSweepAcc][tid % kSweepAcc];
-            __syncthreads();
-            if (tid == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the ticket must not overtake the write-back)
-                __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (wg != 0) continue;
-            if (tid == 0) {
-                const unsigned int want = served * (unsigned int)nwg;
-                while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) __builtin_amdgcn_s_sleep(1);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            }
-            __syncthreads();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // every reader's cache, not only lane 0's
-            for (int e = tid; e < nwaves * kSweepAcc; e += kServerThreads)
-                fold[e / kSweepAcc][e % kSweepAcc] = __hip_atomic_load(&part[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();
-            if (tid < kSweepAcc) {
-                double total = 0;
-                for (int g = 0; g < G; ++g) {
-                    double s = 0;
-                    const int w1 = min(16 * (g + 1), nwaves);
-                    for (int w = 16 * g; w < w1; ++w) s += fold[w][tid];
-                    total = G == 1 ? s : total + s;
+            if (tid < kWavesPerWg * kSweepAcc && wg * kWavesPerWg + tid / kSweepAcc < nwaves)
+                __hip_atomic_store(&part[(size_t)(wg * kWavesPerWg + tid / kSweepAcc) * kSweepAcc + tid % kSweepAcc], wacc[tid / kSweepAcc][tid % kSweepAcc],
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            finish(seq);
+            if (wg == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // every reader's cache, not only lane 0's
+                for (int e = tid; e < nwaves * kSweepAcc; e += kServerThreads)
+                    fold[e / kSweepAcc][e % kSweepAcc] = __hip_atomic_load(&part[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __syncthreads();
+                if (tid < kSweepAcc) {
+                    double total = 0;
+                    for (int g = 0; g < G; ++g) {
+                        double s = 0;
+                        const int w1 = min(16 * (g + 1), nwaves);
+                        for (int w = 16 * g; w < w1; ++w) s += fold[w][tid];
+                        total = G == 1 ? s : total + s;
+                    }
+                    __hip_atomic_store(&mb->sums[tid], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
-                __hip_atomic_store(&mb->sums[tid], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
-        if (wg == 0) {
-            __syncthreads();
-            if (tid == 0) {
-                __atomic_thread_fence(__ATOMIC_RELEASE);
-                __hip_atomic_store(&mb->done_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
+        answer(seq);
     }
 }
 
@@ -438,34 +509,36 @@ struct HostMailbox {
 thread_local HostMailbox g_mailbox;
 
 
-// Host side of pnp_sweep_server_kernel (see there).  One per sfm_solve_pnp_ransac call, on the caller's stream; the destructor
-// posts "quit" on every exit path, so a server never outlives its call.
+// Host side of pnp_server_kernel (see there).  One per sfm_solve_pnp_ransac call, on the caller's stream; the destructor posts "quit"
+// on every exit path, so a server never outlives its call.
 std::atomic<long long> g_mailbox_polls{0};
-bool g_no_sweep_server = false;                     // sfm_debug_pnp_sweep_server(0): the launch-per-sweep path (A/B, tests)
-struct SweepServer {
-    LmMailbox* mb;
+bool g_no_sweep_server = false;                     // sfm_debug_pnp_sweep_server(0): the launch-per-step path (A/B, tests)
+struct PnpServer {
+    PnpMailbox* mb;
     const float *X, *uv;
-    const int32_t* sel;
-    int m, G;
+    int n;
+    float thr2;
+    float *hX, *huv;                                // mailbox: the correspondences as the host reads them
+    int32_t* hinl;                                  // mailbox: the inlier list the host posts
+    int32_t* inliers_dev;
     hipStream_t stream;
     double* part;                                   // device: [<= 128 waves][28] wave sums, then the arrival counter
     uint32_t seq = 0;
+    int m_sel = -1;                                 // the selection the server holds (replayed if it had to be restarted)
     bool running = false;
-    SweepServer(LmMailbox* mb_, const float* X_, const float* uv_, const int32_t* sel_, int m_, int G_, hipStream_t s, double* part_)
-        : mb(mb_), X(X_), uv(uv_), sel(sel_), m(m_), G(G_), stream(s), part(part_) {}
-    ~SweepServer() { (void)stop(); }
+    ~PnpServer() { (void)stop(); }
     int start() {
-        // sequence numbers continue across calls (the mailbox is per host thread): a request can never be mistaken for an old one
-        seq = __atomic_load_n(&mb->cmd_seq, __ATOMIC_RELAXED) >> 2;
-        if (seq >= 0x3FFF0000u) seq = 0;            // (the block sits at a size-dependent offset of the mailbox: whatever was there; never near kLmServerLeft)
-        __atomic_store_n(&mb->cmd_seq, seq << 2, __ATOMIC_RELAXED);
+        // request numbers continue across calls (the mailbox is per host thread): a request can never be mistaken for an old one
+        seq = (uint32_t)((__atomic_load_n(&mb->request, __ATOMIC_RELAXED) >> 40) & kSeqMask);
+        __atomic_store_n(&mb->request, (unsigned long long)seq << 40, __ATOMIC_RELAXED);
         __atomic_store_n(&mb->done_seq, seq, __ATOMIC_RELEASE);
-        unsigned int* arrive = reinterpret_cast<unsigned int*>(part + (size_t)kSweepAcc * kServerMaxG * 16);
-        if (m <= 1024) {
-            hipLaunchKernelGGL(pnp_sweep_server_kernel<1024>, dim3(1), dim3(1024), 0, stream, mb, X, uv, sel, m, G, seq + 1, part, arrive);
+        unsigned int* arrive = reinterpret_cast<unsigned int*>(part + (size_t)kSweepAcc * kServerMaxWaves);
+        const uint32_t first = (seq + 1) & (uint32_t)kSeqMask;
+        if (n <= 1024) {
+            hipLaunchKernelGGL(pnp_server_kernel<1024>, dim3(1), dim3(1024), 0, stream, mb, X, uv, n, thr2, hX, huv, hinl, inliers_dev, first, part, arrive);
         } else {
             SFM_CHECK_HIP(hipMemsetAsync(arrive, 0, sizeof(unsigned int), stream));
-            hipLaunchKernelGGL(pnp_sweep_server_kernel<256>, dim3((m + 255) / 256), dim3(256), 0, stream, mb, X, uv, sel, m, G, seq + 1, part, arrive);
+            hipLaunchKernelGGL(pnp_server_kernel<256>, dim3((n + 255) / 256), dim3(256), 0, stream, mb, X, uv, n, thr2, hX, huv, hinl, inliers_dev, first, part, arrive);
         }
         SFM_CHECK_LAUNCH();
         running = true;
@@ -477,44 +550,47 @@ struct SweepServer {
         for (long long spins = 1;; ++spins) {
             const uint32_t d = __atomic_load_n(&mb->done_seq, __ATOMIC_ACQUIRE);
             if (d == want) { g_mailbox_polls.fetch_add(spins, std::memory_order_relaxed); return 0; }
-            if (d == (uint32_t)kLmServerLeft) return 1;
+            if (d == (uint32_t)kServerLeft) return 1;
             __builtin_ia32_pause();
             if ((spins & 0xFFF) == 0) {
                 if (hipStreamQuery(stream) == hipSuccess && __atomic_load_n(&mb->done_seq, __ATOMIC_ACQUIRE) != want) return 1;   // the kernel is gone
                 if (now_us() - t0 > 5e6) {
-                    sfm::set_error("sfm_solve_pnp_ransac: the sweep server did not answer within 5 s");
+                    sfm::set_error("sfm_solve_pnp_ransac: the PnP server did not answer within 5 s");
                     return SFM_ERR_DEVICE;
                 }
             }
         }
     }
-    int post(uint32_t cmd) {
-        ++seq;
-        __atomic_store_n(&mb->cmd_seq, seq << 2 | cmd, __ATOMIC_RELEASE);
-        return wait(seq);
+    void post(uint32_t cmd, uint32_t arg) {
+        seq = (seq + 1) & (uint32_t)kSeqMask;
+        __atomic_store_n(&mb->request, (unsigned long long)seq << 40 | (unsigned long long)cmd << 32 | arg, __ATOMIC_RELEASE);
     }
-    int sweep(const PnpCam& cam, double* sums_out) {
+    // post a request whose payload is already in the mailbox and wait for the answer; a server that left is restarted and the
+    // request repeated (every request is idempotent; the selection is replayed first)
+    int request(uint32_t cmd, uint32_t arg) {
         for (int attempt = 0; attempt < 3; ++attempt) {
-            std::memcpy(&mb->cam, &cam, sizeof(cam));
-            const int r = post(kLmCmdSweep);
-            if (r == 0) {
-                std::memcpy(sums_out, mb->sums, sizeof(double) * kSweepAcc);
-                return SFM_OK;
-            }
-            if (r < 0) return r;
-            // the server left on its own (this thread was away for more than a second): wait for the kernel, start another
+            post(cmd, arg);
+            const int r = wait(seq);
+            if (r <= 0) return r < 0 ? r : SFM_OK;
             running = false;
             SFM_CHECK_HIP(sfm::stream_sync(stream));
             const int rs = start();
             if (rs != SFM_OK) return rs;
+            if (m_sel >= 0 && cmd != kCmdInliers) post(kCmdInliers, (uint32_t)m_sel);
         }
-        sfm::set_error("sfm_solve_pnp_ransac: the sweep server keeps leaving");
+        sfm::set_error("sfm_solve_pnp_ransac: the PnP server keeps leaving");
         return SFM_ERR_DEVICE;
+    }
+    int select(int m) {                             // (hinl[0 .. m) holds the list; no answer is awaited: requests are served in order)
+        m_sel = m;
+        post(kCmdInliers, (uint32_t)m);
+        return SFM_OK;
     }
     int stop() {
         if (!running) return SFM_OK;
         running = false;
-        const int r = post(kLmCmdQuit);
+        post(kCmdQuit, 0);
+        const int r = wait(seq);
         return r < 0 ? r : SFM_OK;
     }
 };
@@ -694,7 +770,7 @@ extern "C" size_t sfm_solve_pnp_ransac_ws_bytes(int64_t n) {
     const size_t hmax = 64;
     return sfm::align_up(sizeof(double) * 6 * hmax, 256) + sfm::align_up(sizeof(int32_t) * hmax, 256) + sfm::align_up(hmax * (size_t)n, 256) +
            sfm::align_up((size_t)n, 256) + sfm::align_up(sizeof(double) * kSweepAcc * (kSweepMaxBlocks + 1), 256) +
-           sfm::align_up(sizeof(double) * kSweepAcc * kServerMaxG * 16 + 64, 256) + 1024;
+           sfm::align_up(sizeof(double) * kSweepAcc * kServerMaxWaves + 64, 256) + 1024;
 }
 
 extern "C" int sfm_solve_pnp_ransac(const float* X_dev, const float* uv_dev, int64_t n, const double* K, int iterations,
@@ -717,7 +793,7 @@ extern "C" int sfm_solve_pnp_ransac(const float* X_dev, const float* uv_dev, int
     uint8_t* masks_dev = c.take<uint8_t>(hmax * (size_t)n);
     uint8_t* best_dev = c.take<uint8_t>((size_t)n);
     double* sweep_dev = c.take<double>((size_t)kSweepAcc * (kSweepMaxBlocks + 1));
-    double* server_part = c.take<double>((size_t)kSweepAcc * kServerMaxG * 16 + 8);      // the sweep server's wave sums, then its arrival counter
+    double* server_part = c.take<double>((size_t)kSweepAcc * kServerMaxWaves + 8);      // the PnP server's wave sums, then its arrival counter
 
     double tp = now_us();
     auto lap = [&](int k) { const double t1 = now_us(); g_pnp_prof.t[k] += t1 - tp; tp = t1; };
@@ -730,7 +806,8 @@ extern "C" int sfm_solve_pnp_ransac(const float* X_dev, const float* uv_dev, int
     const size_t o_pose = sfm::align_up(o_mask + (size_t)n, 64), o_cnt = o_pose + sizeof(double) * 6 * hmax;
     const size_t o_sum = sfm::align_up(o_cnt + sizeof(int32_t) * hmax, 64);
     const size_t o_lm = sfm::align_up(o_sum + sizeof(double) * kSweepAcc, 64);
-    const size_t o_cm = o_lm + sizeof(LmMailbox);
+    const size_t o_inl = o_lm + sizeof(PnpMailbox);                        // served calls: the inlier list the host posts
+    const size_t o_cm = sfm::align_up(o_inl + sizeof(int32_t) * (size_t)n, 64);
     const bool ride_along = (size_t)n * kSmallMasks <= (1u << 18);
     char* mb = static_cast<char*>(g_mailbox.get(o_cm + (ride_along ? (size_t)n * kSmallMasks : 0)));
     if (!mb) {
@@ -745,9 +822,22 @@ extern "C" int sfm_solve_pnp_ransac(const float* X_dev, const float* uv_dev, int
     double* sums = reinterpret_cast<double*>(mb + o_sum);
     uint8_t* hchunk = reinterpret_cast<uint8_t*>(mb + o_cm);
     bool host_mask_valid = false;
-    SFM_CHECK_HIP(hipMemcpyAsync(hX, X_dev, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, stream));
-    SFM_CHECK_HIP(hipMemcpyAsync(huv, uv_dev, sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost, stream));
-    SFM_CHECK_HIP(sfm::stream_sync(stream));
+    const float thr2 = (float)((double)reproj_error * (double)reproj_error);
+    // 6 .. 8 192 correspondences: the whole call is served by ONE resident launch (pnp_server_kernel) through the mailbox — no copy,
+    // no further launch, no stream synchronisation; otherwise a copy / launch / synchronisation per step, as in round 5
+    PnpMailbox* const pmb = reinterpret_cast<PnpMailbox*>(mb + o_lm);
+    int32_t* const hinl = reinterpret_cast<int32_t*>(mb + o_inl);
+    const bool served = n >= 6 && n <= kServerMaxN && !g_no_sweep_server;
+    PnpServer server{pmb, X_dev, uv_dev, (int)n, thr2, hX, huv, hinl, inliers_dev, stream, server_part};
+    if (served) {
+        int rc0 = server.start();
+        if (rc0 == SFM_OK) rc0 = server.request(kCmdCopyIn, 0);
+        if (rc0 != SFM_OK) return rc0;
+    } else {
+        SFM_CHECK_HIP(hipMemcpyAsync(hX, X_dev, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, stream));
+        SFM_CHECK_HIP(hipMemcpyAsync(huv, uv_dev, sizeof(float) * 2 * (size_t)n, hipMemcpyDeviceToHost, stream));
+        SFM_CHECK_HIP(sfm::stream_sync(stream));
+    }
     lap(0);
     const double ifx = 1. / K[0], ify = 1. / K[4];
     // solvePnP(EPNP) on a sample: undistortPoints writes float32 normalised coordinates (the image points' type) and
@@ -803,7 +893,6 @@ extern "C" int sfm_solve_pnp_ransac(const float* X_dev, const float* uv_dev, int
         info_host[1] = 5;
         return SFM_OK;
     }
-    const float thr2 = (float)((double)reproj_error * (double)reproj_error);
     hs::CvRng rng;
     RansacState st;
     st.niters = std::max(iterations, 1);
@@ -814,6 +903,7 @@ extern "C" int sfm_solve_pnp_ransac(const float* X_dev, const float* uv_dev, int
                         // iterations; 10 % outliers need log(0.01) / log(1 - 0.9^5) ~ 6 = chunks of 2 + 4
     std::vector<int> owner;
     double best_model[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long best_bits[kServerMaxWaves];            // served calls: the best model's inlier masks
     int it = 0;
     while (it < st.niters) {
         const int m = ch.next(st.niters - it);
@@ -829,7 +919,33 @@ extern "C" int sfm_solve_pnp_ransac(const float* X_dev, const float* uv_dev, int
         const int H = (int)owner.size();
         lap(1);
         ++g_pnp_prof.chunks;
-        if (H > 0) {
+        if (H > 0 && served) {
+            // R, t of every model on the host (cv::Rodrigues as the error function of OpenCV's RANSAC evaluates it, on the CPU), one
+            // request, one 64-bit inlier mask per wave and model back; the counts are the masks' bit counts
+            for (int j = 0; j < H; ++j) {
+                double R[9], J[27];
+                rodrigues_with_jac(hposes + 6 * (size_t)j, R, J);
+                std::memcpy(pmb->models + 12 * (size_t)j, R, sizeof(R));
+                std::memcpy(pmb->models + 12 * (size_t)j + 9, hposes + 6 * (size_t)j + 3, 3 * sizeof(double));
+            }
+            pmb->cam.fx = K[0]; pmb->cam.fy = K[4]; pmb->cam.cx = K[2]; pmb->cam.cy = K[5];
+            const int rc = server.request(kCmdScore, (uint32_t)H);
+            if (rc != SFM_OK) return rc;
+            const int nw = (int)((n + 63) >> 6);
+            for (int j = 0; j < H; ++j) {
+                int cnt = 0;
+                for (int w = 0; w < nw; ++w) cnt += __builtin_popcountll(pmb->bits[(size_t)j * kServerMaxWaves + w]);
+                hcounts[j] = cnt;
+            }
+            bool stop;
+            const int bj = replay_chunk(st, it, owner, hcounts, stop);
+            if (bj >= 0) {
+                std::memcpy(best_model, hposes + 6 * (size_t)bj, sizeof(best_model));
+                std::memcpy(best_bits, pmb->bits + (size_t)bj * kServerMaxWaves, sizeof(unsigned long long) * (size_t)nw);
+            }
+            lap(2);
+            if (stop) break;
+        } else if (H > 0) {
             const int rc = sfm_score_pnp(hposes, H, K, X_dev, uv_dev, n, thr2, counts_dev, masks_dev, stream_);
             if (rc != SFM_OK) return rc;
             SFM_CHECK_HIP(hipMemcpyAsync(hcounts, counts_dev, sizeof(int32_t) * (size_t)H, hipMemcpyDeviceToHost, stream));
@@ -851,27 +967,29 @@ extern "C" int sfm_solve_pnp_ransac(const float* X_dev, const float* uv_dev, int
     }
     if (st.best <= 0) return SFM_OK;
     // inlier list (ascending, as OpenCV pushes them) — the one piece of the mask the host needs
-    if (!host_mask_valid) {
-        SFM_CHECK_HIP(hipMemcpyAsync(hmask, best_dev, (size_t)n, hipMemcpyDeviceToHost, stream));
-        SFM_CHECK_HIP(sfm::stream_sync(stream));
-    }
     std::vector<int32_t> inl;
     inl.reserve((size_t)st.best);
-    for (int64_t i = 0; i < n; ++i)
-        if (hmask[(size_t)i]) inl.push_back((int32_t)i);
+    if (served) {
+        for (int w = 0; w < (int)((n + 63) >> 6); ++w)
+            for (unsigned long long b = best_bits[w]; b; b &= b - 1) inl.push_back((int32_t)(64 * w + __builtin_ctzll(b)));
+    } else {
+        if (!host_mask_valid) {
+            SFM_CHECK_HIP(hipMemcpyAsync(hmask, best_dev, (size_t)n, hipMemcpyDeviceToHost, stream));
+            SFM_CHECK_HIP(sfm::stream_sync(stream));
+        }
+        for (int64_t i = 0; i < n; ++i)
+            if (hmask[(size_t)i]) inl.push_back((int32_t)i);
+    }
     const int64_t m_in = (int64_t)inl.size();
-    SFM_CHECK_HIP(hipMemcpyAsync(inliers_dev, inl.data(), sizeof(int32_t) * (size_t)m_in, hipMemcpyHostToDevice, stream));
+    if (served) {                                             // the server takes the list as its selection and writes `inliers_dev`
+        std::memcpy(hinl, inl.data(), sizeof(int32_t) * (size_t)m_in);
+        server.select((int)m_in);
+    } else {
+        SFM_CHECK_HIP(hipMemcpyAsync(inliers_dev, inl.data(), sizeof(int32_t) * (size_t)m_in, hipMemcpyHostToDevice, stream));
+    }
     lap(3);
     // solvePnP(ITERATIVE) on the inliers: DLT initialisation on the host, Levenberg-Marquardt with the sweeps on the device
     const int blocks = (int)std::min<int64_t>((m_in + kSweepThreads - 1) / kSweepThreads, kSweepMaxBlocks);
-    // <= 8 192 inliers: the sweep server (one launch per call, requests through the mailbox); more: a launch set per sweep.
-    // The server is started BEFORE the DLT initialisation so that its launch latency hides behind ~30 us of host work.
-    SweepServer server(reinterpret_cast<LmMailbox*>(mb + o_lm), X_dev, uv_dev, inliers_dev, (int)m_in, blocks, stream, server_part);
-    const bool served = blocks <= kServerMaxG && !g_no_sweep_server;
-    if (served) {
-        const int rc0 = server.start();
-        if (rc0 != SFM_OK) return rc0;
-    }
     double param[6];
     const int init_status = hs::pnp_dlt_init<float>(hX, huv, inl.data(), m_in, K, param, param + 3);
     if (init_status != 0) std::memcpy(param, best_model, sizeof(param));      // planar / < 6 inliers: refine the RANSAC model
@@ -884,7 +1002,9 @@ extern "C" int sfm_solve_pnp_ransac(const float* X_dev, const float* uv_dev, int
         cam.t[0] = p[3]; cam.t[1] = p[4]; cam.t[2] = p[5];
         cam.fx = K[0]; cam.fy = K[4]; cam.cx = K[2]; cam.cy = K[5];
         if (served) {
-            const int rcs = server.sweep(cam, sums);
+            std::memcpy(&pmb->cam, &cam, sizeof(cam));
+            const int rcs = server.request(kCmdSweep, 0);
+            if (rcs == SFM_OK) std::memcpy(sums, pmb->sums, sizeof(double) * kSweepAcc);
             lap(5);
             return rcs;
         }
