@@ -2,7 +2,10 @@
 
 cv2 is not installable here and the reference holds no keypoint vectors ("parity unpinned", see the oracle header),
 so the restatement is pinned by OpenCV's documented constants and by the invariances the algorithm must have."""
+import os
+
 import numpy as np
+import pytest
 
 from datagen import scene_image
 
@@ -136,3 +139,35 @@ def test_scale_space_against_an_independent_gaussian_filter(oracle):
         want = gaussian_filter(prev, sig, mode="mirror", truncate=4.0)
         assert np.abs(pyr[i] - want).max() < 0.02           # grey levels of 255; the 27-tap layer differs by its last tap
         prev = pyr[i].astype(np.float64)
+
+
+@pytest.mark.parametrize("view", ["decimated_by_4", "half_resolution_crop"])
+def test_oracle_against_an_independent_float64_sift_on_the_photograph(oracle, view):
+    """the SIFT oracle against tests/np_sift.py — a float64 NumPy / SciPy SIFT that shares no code with
+    oracle/sift_oracle.c (gaussian_filter1d scale space, maximum / minimum filters, numpy.linalg.solve, numpy.add.at histograms) —
+    on the reference's own photograph (tests/golden/photo_gray.npz = /root/reference/image.jpg in grey).  Every stage is covered, not
+    only the scale space: >= 95 % of the keypoints of either side have a partner within 0.5 px, 10 % in scale and 5 degrees, and the
+    matched descriptors agree to a cosine >= 0.97.  (The oracle rounds like a float32 SIMD loop, the NumPy side not at all: agreement
+    is statistical by design; the oracle <-> HIP comparison is the bit-exact one.)"""
+    import np_sift
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "photo_gray.npz"))["gray"]
+    img = np.ascontiguousarray(g[::4, ::4][:240, :320] if view == "decimated_by_4" else g[::2, ::2][150:390, 300:620])
+    okp, odes = oracle.sift(img)
+    kp, des = np_sift.detect_and_compute(img)
+    assert len(okp) > 150 and abs(len(kp) - len(okp)) <= 0.05 * len(okp)
+
+    def partners(a, b, i):
+        d = np.hypot(b[:, 0] - a[i, 0], b[:, 1] - a[i, 1])
+        da = np.abs((b[:, 3] - a[i, 3] + 180) % 360 - 180)
+        return np.flatnonzero((d < 0.5) & (np.abs(b[:, 2] / a[i, 2] - 1) < 0.1) & (da < 5))
+    cos, found = [], 0
+    for i in range(len(okp)):
+        ok = partners(okp, kp, i)
+        if len(ok):
+            found += 1
+            cos.append(max(float(des[j] @ odes[i] / (np.linalg.norm(des[j]) * np.linalg.norm(odes[i]) + 1e-12)) for j in ok))
+    back = sum(1 for i in range(len(kp)) if len(partners(kp, okp, i)))
+    cos = np.array(cos)
+    print(f"{view}: oracle {len(okp)} keypoints, numpy {len(kp)}; found {found} / back {back}; cosine min {cos.min():.4f} median {np.median(cos):.5f}")
+    assert found >= 0.95 * len(okp) and back >= 0.95 * len(kp)
+    assert (cos >= 0.97).mean() >= 0.99 and np.median(cos) > 0.999
