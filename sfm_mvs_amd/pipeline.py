@@ -112,24 +112,28 @@ def features_from_images(images, depth=3, on_device=False):
         else:
             feats.append((eng.keypoints[:n, :2].cpu().numpy(), eng.descriptors[:n].cpu().numpy()))
 
-    for img in images:
-        if not torch.is_tensor(img):
-            img = np.ascontiguousarray(img, np.uint8)
-        h, w = img.shape[:2]
-        pipe = pipes.get((w, h))
-        if pipe is None:
-            pipe = pipes[(w, h)] = _sift_pipeline(w, h, dev, depth)
-        if len(pending) == depth:
+    try:
+        for img in images:
+            if not torch.is_tensor(img):
+                img = np.ascontiguousarray(img, np.uint8)
+            h, w = img.shape[:2]
+            pipe = pipes.get((w, h))
+            if pipe is None:
+                pipe = pipes[(w, h)] = _sift_pipeline(w, h, dev, depth)
+            if len(pending) == depth:
+                collect()
+            d = img if torch.is_tensor(img) else torch.as_tensor(img).to(dev)      # (a frame already in HBM — run_sfm_images' downscaled ones — is taken as it is)
+            gray = _sift.bgr2gray(d) if d.dim() == 3 else d
+            _, st, eng = pipe.submit(gray)
+            gray.record_stream(st)
+            pending.append((st, eng))
+        while pending:
             collect()
-        d = img if torch.is_tensor(img) else torch.as_tensor(img).to(dev)      # (a frame already in HBM — run_sfm_images' downscaled ones — is taken as it is)
-        gray = _sift.bgr2gray(d) if d.dim() == 3 else d
-        _, st, eng = pipe.submit(gray)
-        gray.record_stream(st)
-        pending.append((st, eng))
-    while pending:
-        collect()
-    for pipe in pipes.values():
-        _sift_pipeline_done(pipe)
+    finally:
+        #  also when collect() / check_capacity / the device raised: a cached pipeline left BUSY would make every later
+        # call of this frame size build a private one — 3 x 268 MB and a device-draining stream probe in the middle of a job
+        for pipe in pipes.values():
+            _sift_pipeline_done(pipe)
     return feats
 
 
@@ -756,6 +760,8 @@ class _HipEngine:
         return R, t, ops.mask_indices(mask, nonzero=True)          # quirk 4: rows of the {0,255} mask
 
     def take(self, x, rows):
+        if torch.is_tensor(rows) and rows.dtype in (torch.int32, torch.int64) and rows.dim() == 1:
+            return x.index_select(0, rows)                         # one launch (x[rows.long()] is two: the index conversion, then the gather)
         return x[rows.long() if torch.is_tensor(rows) else rows]
 
     def triangulate(self, Pa, Pb, a, b):
@@ -767,14 +773,23 @@ class _HipEngine:
         cams = torch.as_tensor(np.hstack([hg.rodrigues_mat2vec(Rt[:3, :3]), Rt[:3, 3]])[None]).to(self.dev)
         return ops.project_residual(cams, self.K, X, obs.contiguous(), want_proj=False)["sumsq"], len(obs)
 
-    def pnp(self, X, p, p0):
+    lazy_pnp = True       # register_next may ask for the pose and the inlier COUNT only (gather=False)
+
+    def pnp(self, X, p, p0, gather=True):
+        """sfm.py:60-76.  gather=False: (R, t, inliers (k, 1) int32 in HBM, None, None) — sfm.py:73-75 gathers p, X and p_0 by the
+        inliers, but the reference's loop (sfm.py:341-409) reads none of the three after the call: the driver takes the pose and the
+        inlier count, and the three gathers (and the p_0 argument's own gather) are not launched.  The bootstrap pair, whose filtered
+        points survive (sfm.py:326-329), calls with gather=True."""
         from . import hostgeom as hg
         from . import ransac
         ok, rvec, t, inl = ransac.solve_pnp_ransac(X, p, self.K, return_device_inliers=True)
+        R = hg.rodrigues_vec2mat(rvec)
+        if not gather:
+            return R, t, (inl if inl is not None else p), None, None
         if inl is not None:
-            sel = inl[:, 0].long()
-            p, X, p0 = p[sel], X[sel], p0[sel]
-        return hg.rodrigues_vec2mat(rvec), t, p, X, p0
+            sel = inl[:, 0]
+            p, X, p0 = p.index_select(0, sel), X.index_select(0, sel), p0.index_select(0, sel)
+        return R, t, p, X, p0
 
     def associate(self, pts1, pts_):
         indx1, indx2, keep = ops.common_points(pts1, pts_)
@@ -836,7 +851,10 @@ def register_next(eng, state, i, bundle_adjustment=False, gtol_thresh=0.5):
     cloud = state.cloud0 if state.cloud0 is not None else eng.triangulate(state.P1, state.P2, state.pts0, state.pts1)
     indx1, indx2, rest = eng.associate(state.pts1, pts_)
     new1, new2 = eng.take(pts_, rest), eng.take(pts2, rest)
-    R, t, p_in, _, _ = eng.pnp(eng.take(cloud, indx1), eng.take(pts2, indx2), eng.take(pts_, indx2))
+    if getattr(eng, "lazy_pnp", False):       # (HBM-resident engine: the filtered p / X / p_0 of sfm.py:73-75 are never read below)
+        R, t, p_in, _, _ = eng.pnp(eng.take(cloud, indx1), eng.take(pts2, indx2), None, gather=False)
+    else:
+        R, t, p_in, _, _ = eng.pnp(eng.take(cloud, indx1), eng.take(pts2, indx2), eng.take(pts_, indx2))
     Rt = np.hstack((np.asarray(R, np.float64), np.asarray(t, np.float64).reshape(3, 1)))
     P = K @ Rt
     X = eng.triangulate(state.P2, P, new1, new2)
