@@ -58,12 +58,16 @@ rm -rf $OUT/trace_i8 $OUT/trace $OUT/traceb $OUT/trace1 $OUT/trace_tri $OUT/trac
 # the bench lines themselves, un-profiled (a profiled run clocks 2-5 % lower): the driver's flags, config 5 through a
 # one-rank RCCL group, the 57-camera driver
 cd $R
-python bench.py --steps 20 --warmup 5 > $OUT/${TAG}_bench_knn.json 2>> $OUT/trace.log
-python bench.py --workload c5 > $OUT/${TAG}_bench_c5.json 2>> $OUT/trace.log
-python bench.py --workload allpairs > $OUT/${TAG}_bench_allpairs.json 2>> $OUT/trace.log
-python bench.py --workload sfm --steps 3 > $OUT/${TAG}_bench_sfm.json 2>> $OUT/trace.log
-python bench.py --workload sfm --from-pixels --steps 3 > $OUT/${TAG}_bench_sfm_pixels.json 2>> $OUT/trace.log
-# launch sets in flight: the headline step at pipeline depth 1 .. 5 (bench.py's default is 3)
+# (round 6: stdout carries the compact line; the FULL record of a run is gpurun_out/bench_full.json — that is what is kept as rNN_bench_*.json,
+#  the line itself beside it as *.line)
+runb() { name=$1; shift; python bench.py "$@" > $OUT/${TAG}_bench_$name.line 2>> $OUT/trace.log; cp $R/gpurun_out/bench_full.json $OUT/${TAG}_bench_$name.json; }
+runb default --gpus 1 --steps 20 --warmup 5
+cp $OUT/${TAG}_bench_default.json $OUT/${TAG}_bench_knn.json
+runb c5 --workload c5
+runb allpairs --workload allpairs
+runb sfm --workload sfm --steps 3
+runb sfm_pixels --workload sfm --from-pixels --steps 3
+# launch sets in flight: the headline step at pipeline depth 1 .. 5 (bench.py's default is 2)
 for d in 1 2 3 4 5; do
   python bench.py --steps 60 --warmup 10 --pipe-depth $d --no-cpu-baseline --no-extras 2>> $OUT/trace.log | python -c "
 import sys, json; d = json.loads(sys.stdin.read()); print('pipe-depth $d: value %.4g distances/s  ms_per_step %.4f  frac_step %.3f' % (d['value'], d['ms_per_step'], d['roofline']['frac_step']))" >> $OUT/${TAG}_knn_pipe_depth.txt
@@ -72,9 +76,9 @@ done
 ( cd /tmp && rocprofv3 --hip-trace --stats --output-format csv -d $OUT/trace_hip -o sfmpx -- python $R/bench.py --workload sfm --from-pixels --steps 1 --no-cpu-baseline > /dev/null 2>> $OUT/trace.log )
 cp $OUT/trace_hip/sfmpx_hip_api_stats.csv $OUT/${TAG}_sfm_pixels_hip_api_stats.csv 2>/dev/null
 rm -rf $OUT/trace_hip
-python bench.py --workload tri --steps 5 --warmup 1 > $OUT/${TAG}_bench_tri.json 2>> $OUT/trace.log
-python bench.py --workload ba --steps 5 --warmup 1 > $OUT/${TAG}_bench_ba.json 2>> $OUT/trace.log
-python bench.py --workload sift --steps 30 --warmup 5 > $OUT/${TAG}_bench_sift.json 2>> $OUT/trace.log
+runb tri --workload tri --steps 5 --warmup 1
+runb ba --workload ba --steps 5 --warmup 1
+runb sift --workload sift --steps 30 --warmup 5
 # PMC passes of the non-KNN legs (triangulation, BA, SIFT)
 bash $R/scripts/collect_pmc_other.sh $TAG > $OUT/pmc_other.log 2>&1
 python $R/scripts/summarize_pmc_other.py $TAG > $OUT/${TAG}_other_pmc.md

@@ -697,11 +697,34 @@ def streams_overlap(a, b):
     return e0.elapsed_time(eb) < 0.5 * e0.elapsed_time(ea)
 
 
+_STREAM_SETS = {}      # (kind, device index, depth) -> streams probed ONCE per process (shared_streams)
+_STREAM_SETS_LOCK = __import__("threading").Lock()
+
+
+def shared_streams(kind, depth, device, probe=True):
+    """The `depth` streams pipelines of one kind ("pipeline": launch-set / pair pipelines, "sift": frame pipelines) run on, for this
+    device: probed ONCE per process to reach different hardware queues (independent_streams) and then shared by every pipeline of
+    that kind and depth.  (every constructor used to probe — a 256 MB scratch tensor and several device-wide drains per
+    pipeline, also from a producer thread in the middle of a job, where the wall-clock probe can return either answer.)  Pipelines
+    that share a stream set run one after the other on it; an owner that needs concurrency between pipelines passes its own.
+    probe=False (a non-owner thread, or work in flight): plain streams, nothing drained, nothing cached."""
+    device = torch.device(device)
+    depth = int(depth)
+    if not probe:
+        return [torch.cuda.Stream(device=device) for _ in range(depth)]
+    key = (kind, device.index if device.index is not None else torch.cuda.current_device(), depth)
+    with _STREAM_SETS_LOCK:
+        st = _STREAM_SETS.get(key)
+        if st is None:
+            st = independent_streams(depth, device) if depth > 1 else [torch.cuda.Stream(device=device)]
+            release_probe_scratch(device)
+            _STREAM_SETS[key] = st
+    return list(st)
+
+
 def _pipeline_streams(depth, device):
-    """The streams of a launch-set / pair pipeline: probed to reach different hardware queues (independent_streams)."""
-    st = independent_streams(depth, device) if depth > 1 else [torch.cuda.Stream(device=device)]
-    release_probe_scratch(device)
-    return st
+    """The streams of a launch-set / pair pipeline (shared_streams: probed once per device and depth, then reused)."""
+    return shared_streams("pipeline", depth, device)
 
 
 def release_probe_scratch(device):
@@ -770,8 +793,9 @@ class BatchPipeline:
             seen.append(ms)
             if best is None or ms < best:
                 best, best_streams = ms, self.streams
-            if len(seen) < tries:
-                self.streams = _pipeline_streams(self.depth, self.streams[0].device)
+            if len(seen) < tries:                           # (fresh ones, not the device's shared set: this IS the owner's explicit probe)
+                self.streams = independent_streams(self.depth, self.streams[0].device) if self.depth > 1 else [torch.cuda.Stream(device=self.streams[0].device)]
+                release_probe_scratch(self.streams[0].device)
         self.streams = best_streams
         return seen
 

@@ -157,7 +157,10 @@ def _sift_pipeline(w, h, dev, depth):
         js = _SIFT_PIPES.get(("job streams", torch.device(dev).index, int(depth)))
     # the cached pipeline of a size runs on the device's probed feature streams when they exist (_job_streams); a second,
     # concurrent user's private pipeline gets streams of its own
-    fresh = _sift.SiftPipeline(w, h, dev, depth=depth, streams=js[0] if js is not None and pipe is None else None)
+    # (a private pipeline is built while its size's cached one is busy, possibly from a producer thread in the middle of a job: plain
+    #  streams, no probe — ops.shared_streams(probe=False))
+    fresh = _sift.SiftPipeline(w, h, dev, depth=depth,
+                               streams=js[0] if js is not None and pipe is None else (ops.shared_streams("sift", depth, dev, probe=False) if pipe is not None else None))
     with _SIFT_PIPES_LOCK:
         if pipe is None:                                  # first of its size: cache it (a handful of frame sizes at most)
             for old in [k for k in _SIFT_PIPES if isinstance(k[0], int) and id(_SIFT_PIPES[k]) not in _SIFT_PIPES_BUSY][:max(0, len(_SIFT_PIPES) - 5)]:

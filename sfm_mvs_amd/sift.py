@@ -98,8 +98,7 @@ class SiftPipeline:
         # run one after the other: -2..4 % frames/s for a pair that collides; the probe is a few milliseconds of set-up)
         if streams is None:
             from . import ops
-            streams = ops.independent_streams(self.depth, device)
-            ops.release_probe_scratch(device)
+            streams = ops.shared_streams("sift", self.depth, device)      # (probed once per device and depth: the probe drains the device)
         self.streams = list(streams)
         if len(self.streams) != self.depth:
             raise ValueError("SiftPipeline: one stream per frame in flight")
