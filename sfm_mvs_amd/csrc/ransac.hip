@@ -185,8 +185,8 @@ __global__ __launch_bounds__(kSweepThreads) void pnp_sweep_kernel(PnpCam cam, co
 //   copy-in    the correspondences (float32 X, uv) -> mailbox: what the host-side hypothesis generators sample from
 //   score      H models (R, t computed by the HOST: the Rodrigues the oracle and cv2 evaluate on the CPU) -> one 64-bit inlier mask per
 //              wave and model; the host counts bits, replays OpenCV's bookkeeping and reads the winner's inlier list off the mask
-//   inliers    the winner's ascending inlier list -> the lanes' selection (point of tree lane L) and the caller's `inliers_dev`
-//   sweep      R, t, dR/dr -> the 28 sums of J^T J, J^T e, |e|^2 over the inliers, pnp_sweep_kernel's FIXED TREE
+//   sweep      [first of a selection: the winner's ascending inlier list -> the lanes' selection (point of tree lane L) and the caller's
+//              `inliers_dev`;]  R, t, dR/dr -> the 28 sums of J^T J, J^T e, |e|^2 over the inliers, pnp_sweep_kernel's FIXED TREE
 //   quit
 // Layout: the tree's lane L (virtual workgroup L / 1024, wave (L % 1024) / 64) is point L of the current selection.  <= 1 024
 // points: ONE workgroup of 1 024 lanes.  More: workgroups of 256 lanes (one tree wave per SIMD: a wave alone on its SIMD issues four
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(kSweepThreads) void pnp_sweep_kernel(PnpCam cam, co
 constexpr int kServerMaxG = 8, kServerMaxN = 1024 * kServerMaxG;   // correspondences a served call may have; larger ones keep the launch path
 constexpr int kServerMaxWaves = kServerMaxN / 64, kServerMaxModels = 64;
 constexpr long long kServerTimeoutTicks = 100000000; // 1 s of the 100 MHz wall clock
-enum : uint32_t { kCmdNone = 0, kCmdSweep = 1, kCmdQuit = 2, kCmdCopyIn = 3, kCmdScore = 4, kCmdInliers = 5, kServerLeft = 0xFFFFFFFFu };
+enum : uint32_t { kCmdNone = 0, kCmdSweep = 1, kCmdQuit = 2, kCmdCopyIn = 3, kCmdScore = 4, kServerLeft = 0xFFFFFFFFu };
 struct alignas(64) PnpMailbox {
     unsigned long long request, pad0[7];             // host -> device, written last: number << 40 | command << 32 | argument
     PnpCam cam;                                      // sweep: R, t, dR/dr, intrinsics (score: intrinsics only)
@@ -316,17 +316,19 @@ __global__ __launch_bounds__(kServerThreads) void pnp_server_kernel(PnpMailbox* 
             answer(seq);
             continue;
         }
-        if (cmd == kCmdInliers) {                                  // (no answer: the next request follows in order)
-            m = (int)arg;
+        // ---- sweep (argument m + 1 > 0: FIRST take the host's ascending inlier list as the selection — point of tree lane L — and
+        // write the caller's `inliers_dev`; a separate, unacknowledged "inliers" request could be overwritten by the sweep request
+        // that follows it before a workgroup had polled it: found by scripts/fuzz_geometry.py on the calls whose DLT initialisation
+        // returns at once)
+        if (arg) {
+            m = (int)arg - 1;
             nwaves = (m + 63) >> 6;
             i0 = -1;
             if (L < m) {
                 i0 = __hip_atomic_load(&hinl[L], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 inliers_dev[L] = i0;
             }
-            continue;
         }
-        // ---- sweep
         if (tid < (int)(sizeof(PnpCam) / sizeof(double)))
             reinterpret_cast<double*>(&cam)[tid] =
                 __hip_atomic_load(reinterpret_cast<const double*>(&mb->cam) + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -524,7 +526,8 @@ struct PnpServer {
     hipStream_t stream;
     double* part;                                   // device: [<= 128 waves][28] wave sums, then the arrival counter
     uint32_t seq = 0;
-    int m_sel = -1;                                 // the selection the server holds (replayed if it had to be restarted)
+    int m_sel = -1;                                 // the selection (hinl[0 .. m_sel)) the sweeps run on
+    bool send_sel = false;                          // ... and whether the next sweep request has to carry it (new selection, or a restarted server)
     bool running = false;
     ~PnpServer() { (void)stop(); }
     int start() {
@@ -542,6 +545,7 @@ struct PnpServer {
         }
         SFM_CHECK_LAUNCH();
         running = true;
+        send_sel = m_sel >= 0;
         return SFM_OK;
     }
     // wait until the server has answered request `want`; 0 = answered, 1 = the server left (timeout on its side), < 0 = error
@@ -565,26 +569,27 @@ struct PnpServer {
         seq = (seq + 1) & (uint32_t)kSeqMask;
         __atomic_store_n(&mb->request, (unsigned long long)seq << 40 | (unsigned long long)cmd << 32 | arg, __ATOMIC_RELEASE);
     }
-    // post a request whose payload is already in the mailbox and wait for the answer; a server that left is restarted and the
-    // request repeated (every request is idempotent; the selection is replayed first)
-    int request(uint32_t cmd, uint32_t arg) {
+    // Post a request whose payload is already in the mailbox and wait for the answer.  EVERY request is answered before the next is
+    // posted (the mailbox holds one).  A server that left is restarted and the request repeated (all of them are idempotent).
+    int request(uint32_t cmd, uint32_t arg = 0) {
         for (int attempt = 0; attempt < 3; ++attempt) {
-            post(cmd, arg);
+            post(cmd, cmd == kCmdSweep && send_sel ? (uint32_t)m_sel + 1u : arg);
             const int r = wait(seq);
-            if (r <= 0) return r < 0 ? r : SFM_OK;
+            if (r <= 0) {
+                if (r == 0 && cmd == kCmdSweep) send_sel = false;
+                return r < 0 ? r : SFM_OK;
+            }
             running = false;
             SFM_CHECK_HIP(sfm::stream_sync(stream));
             const int rs = start();
             if (rs != SFM_OK) return rs;
-            if (m_sel >= 0 && cmd != kCmdInliers) post(kCmdInliers, (uint32_t)m_sel);
         }
         sfm::set_error("sfm_solve_pnp_ransac: the PnP server keeps leaving");
         return SFM_ERR_DEVICE;
     }
-    int select(int m) {                             // (hinl[0 .. m) holds the list; no answer is awaited: requests are served in order)
+    void select(int m) {                            // (hinl[0 .. m) holds the list: it travels with the next sweep request)
         m_sel = m;
-        post(kCmdInliers, (uint32_t)m);
-        return SFM_OK;
+        send_sel = true;
     }
     int stop() {
         if (!running) return SFM_OK;

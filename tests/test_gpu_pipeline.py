@@ -82,6 +82,45 @@ def test_sweep_server_equals_launch_per_sweep(hip, pair, n, sigma, n_bad, seed):
         assert polls1 == polls0
 
 
+def test_pnp_server_on_small_and_degenerate_sets_never_waits_for_a_timeout(hip):
+    """Found by scripts/fuzz_geometry.py: the inlier list used to travel as its own, unacknowledged request; when the DLT
+    initialisation that follows returns at once (fewer than six inliers, coplanar sets) the first sweep request overwrote it in the
+    one-slot mailbox before a workgroup had polled it, the server waited a second for a request that never came, left, was restarted
+    — three times, then the call failed ("the PnP server keeps leaving").  The list now travels WITH the first sweep request.  Many
+    small / outlier-heavy / degenerate calls: each equals the launch-per-step path bit for bit and none takes as long as a time-out."""
+    import time
+    from sfm_mvs_amd import ransac, _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(12)
+    worst = 0.0
+    for case in range(120):
+        n = int(rng.integers(6, 40))
+        K, P1, P2, X, x1, x2 = gustav_pair(int(rng.integers(0, 55)), n, float(rng.choice([0.0, 0.3, 3.0])), seed=1000 + case)
+        x2, _ = _corrupt(x2, int(rng.integers(0, n)), 10, 150, case)
+        Xf = X.astype(np.float32)
+        kind = case % 4
+        if kind == 1:
+            Xf[:, 2] = 0.2 * Xf[:, 0] - 0.1 * Xf[:, 1] + 6.0          # coplanar object points
+        elif kind == 2:
+            pick = rng.integers(0, 3, n)
+            Xf, x2 = Xf[pick], x2[pick]                                  # three distinct correspondences
+        its, conf, rep = int(rng.choice([10, 100, 500])), float(rng.choice([0.9, 0.99, 0.9999])), float(rng.choice([2.0, 8.0, 20.0]))
+        t0 = time.perf_counter()
+        got = ransac.solve_pnp_ransac(Xf, x2, K, iterations_count=its, reprojection_error=rep, confidence=conf, want_info=True)
+        worst = max(worst, time.perf_counter() - t0)
+        assert L.sfm_debug_pnp_sweep_server(0) == 1
+        try:
+            want = ransac.solve_pnp_ransac(Xf, x2, K, iterations_count=its, reprojection_error=rep, confidence=conf, want_info=True)
+        finally:
+            L.sfm_debug_pnp_sweep_server(1)
+        assert bool(got[0]) == bool(want[0]) and list(got[4]) == list(want[4]), (case, n, got[4], want[4])
+        if got[0]:
+            assert np.array_equal(got[3], want[3]), case
+            for a, b in ((got[1], want[1]), (got[2], want[2])):
+                assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(a[~np.isnan(a)], b[~np.isnan(b)]), case
+    assert worst < 0.25, f"a served call took {worst:.2f} s: a request was lost and the server timed out"
+
+
 def test_ransac_entry_point_edge_cases(hip, oracle):
     from sfm_mvs_amd import ransac
     from sfm_mvs_amd._lib import SfmHipError
