@@ -1531,8 +1531,8 @@ def _clip(s, n):
     return s if not isinstance(s, str) or len(s) <= n else s[:n - 3].rstrip() + "..."
 
 
-def _pick(d, keys, clip=120):
-    return {k: _clip(_sig(d[k]), clip) for k in keys if isinstance(d, dict) and k in d}
+def _pick(d, keys, clip=120, digits=9):
+    return {k: _clip(_sig(d[k], digits), clip) for k in keys if isinstance(d, dict) and k in d}
 
 
 def compact_line(out):
