@@ -116,9 +116,10 @@ def gather_matches(kp0, kp1, out_q, out_t, count):
     return pts0, pts1
 
 
-def common_points(pts1, pts2):
+def common_points(pts1, pts2, raw=False):
     """sfm.py:215-239 association on device: (indx1 int32[m], indx2 int32[m], keep2 bool[n2]) — x OR y bit-equality,
-    first hit, ascending order."""
+    first hit, ascending order.  raw=True: no host read — (indx1 [n1] unsliced, indx2 [n1] unsliced, keep2 uint8 [n2], count int32 [1] on
+    the device); the caller slices after ONE download of all the counts it is waiting for."""
     require_cuda(pts1, pts2)
     pts1 = pts1.contiguous().float().reshape(-1, 2)
     pts2 = pts2.contiguous().float().reshape(-1, 2)
@@ -132,11 +133,13 @@ def common_points(pts1, pts2):
     with on_device(dev):
         check(_lib.lib().sfm_common_points(ptr(pts1), n1, ptr(pts2), n2, ptr(first), ptr(idx1), ptr(idx2), ptr(count),
                                            ptr(keep2), stream_ptr()), "sfm_common_points")
+    if raw:
+        return idx1, idx2, keep2[:n2], count
     m = int(count.item())
     return idx1[:m], idx2[:m], keep2[:n2].bool()
 
 
-def mask_indices(mask, nonzero=False):
+def mask_indices(mask, nonzero=False, raw=False):
     """Rows of a uint8 mask that pass, ascending, as an int32 CUDA tensor (sfm_mask_indices): `mask.ravel() == 1` (OpenCV's
     {0,1} essential-matrix mask, sfm.py:309) or, nonzero=True, `mask.ravel() > 0` (the {0,255} cheirality mask, sfm.py:313; the
     complement of common_points).  One host read (the count sizes the result)."""
@@ -154,6 +157,8 @@ def mask_indices(mask, nonzero=False):
     ws = _workspace(m.device, lib.sfm_mask_indices_ws_bytes(n))
     with on_device(m.device):
         check(lib.sfm_mask_indices(ptr(m), n, 1 if nonzero else 0, ptr(out), ptr(count), ptr(ws), ws.numel(), stream_ptr()), "sfm_mask_indices")
+    if raw:
+        return out, count
     return out[:int(count.item())]
 
 

@@ -795,8 +795,11 @@ class _HipEngine:
         return R, t, p, X, p0
 
     def associate(self, pts1, pts_):
-        indx1, indx2, keep = ops.common_points(pts1, pts_)
-        return indx1, indx2, ops.mask_indices(keep, nonzero=True)
+        # association + complement list, ONE host read for both counts (round 5: two)
+        indx1, indx2, keep, c1 = ops.common_points(pts1, pts_, raw=True)
+        rest, c2 = ops.mask_indices(keep, nonzero=True, raw=True)
+        m, k = torch.cat([c1, c2]).tolist()
+        return indx1[:m], indx2[:m], rest[:k]
 
     def errors(self, handles):
         if not handles:
