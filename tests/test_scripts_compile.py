@@ -9,7 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_every_script_compiles():
     paths = sorted(glob.glob(os.path.join(ROOT, "scripts", "*.py")) +
-                   [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")])
+                   [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")] + glob.glob(os.path.join(ROOT, "benchlib", "*.py")))
     assert len(paths) > 10
     for p in paths:
         compile(open(p, encoding="utf-8").read(), p, "exec")
