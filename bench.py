@@ -43,6 +43,9 @@ from benchlib.features import bench_sfm, bench_sfm_pixels, bench_sift    # noqa:
 from benchlib.line import COMPACT_MAX, FULL_JSON, compact_line, emit     # noqa: E402,F401
 
 
+SECONDARY_LEG_TIMEOUT = float(os.environ.get("SFM_BENCH_C5_TIMEOUT", "240"))          # seconds the configs[4] leg of a default N > 1 run may take before the watchdog reports the headline alone
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -205,12 +208,28 @@ def main():
             # pairs split over the N ranks (+ one halo image each), both all-gathers (match records, triangulated points) over the
             # RCCL group — reported under config.secondary.  Every rank takes part (collectives).
             import copy
+            import threading
             a5 = copy.copy(args)
             a5.images = args.images or 256
+            # The headline must survive the secondary leg, whatever happens to it.  An exception on one rank is caught below; a HANG —
+            # ranks that disagree on a collective: this leg has never run on more than one rank of real hardware — is not an exception,
+            # so a watchdog on every rank ends the process after SECONDARY_LEG_TIMEOUT seconds, rank 0 printing the headline line first.
+            done = threading.Event()
+
+            def watchdog():
+                if done.wait(SECONDARY_LEG_TIMEOUT):
+                    return
+                if rank == 0:
+                    out["config"]["secondary"] = {"config5_error": f"timed out after {SECONDARY_LEG_TIMEOUT} s (the headline above was measured before it started)",
+                                                  "config5_images": a5.images, "config5_pairs": a5.images - 1, "rccl_ranks": world}
+                    emit(out, json_fd)
+                os._exit(0)
+            threading.Thread(target=watchdog, daemon=True).start()
             try:
                 r5 = bench_c5(a5, world, rank, dev)
             except Exception as e:      # noqa: BLE001 — the headline must survive a failure of the secondary leg
                 r5 = {"error": f"{type(e).__name__}: {e}"}
+            done.set()
             if rank == 0:
                 import torch.distributed as dist
                 out["config5"] = r5

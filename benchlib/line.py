@@ -49,7 +49,8 @@ def compact_line(out):
         if k in cfg:
             c["config"][k] = cfg[k]
     if isinstance(cfg.get("secondary"), dict):
-        c["config"]["secondary"] = {k: _sig(v) for k, v in cfg["secondary"].items() if v is not None and (not isinstance(v, str) or k.endswith("_scaling"))}   # numbers (+ the one-word scaling kind)
+        c["config"]["secondary"] = {k: (_clip(v, 100) if isinstance(v, str) else _sig(v)) for k, v in cfg["secondary"].items()
+                                    if v is not None and (not isinstance(v, str) or k.endswith(("_scaling", "_error")))}   # numbers (+ the scaling kind, an error if any)
     if isinstance(out.get("roofline"), dict):
         c["roofline"] = _pick(out["roofline"], ("bound", "achieved", "peak", "unit", "frac", "frac_step", "frac_of_sustained", "traffic", "algorithmic_bytes_per_launch",
                                                  "algorithmic_bytes", "kernel", "avg_launch_ms", "launches"), clip=100)

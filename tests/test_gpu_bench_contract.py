@@ -74,7 +74,7 @@ def test_driver_command_line_gives_one_short_strict_json_line(hip):
         assert k in c, k
     assert c["kind"] == "port" and c["unit"] == "distances/s" and c["value"] > 1e6 and c["cores"] >= 1
     sec = d["config"]["secondary"]                                  # the other legs of the same run: numbers only
-    assert all(not isinstance(v, str) or k.endswith("_scaling") for k, v in sec.items()) and sec["sift_frames_per_sec"] > 100 and sec["sfm57_from_pixels_seconds"] < 1.0
+    assert all(not isinstance(v, str) or k.endswith(("_scaling", "_error")) for k, v in sec.items()) and sec["sift_frames_per_sec"] > 100 and sec["sfm57_from_pixels_seconds"] < 1.0
     # everything else went to the side file, itself strict JSON
     rec = _strict_loads(open(full).read())
     assert "extra" in rec and rec["value"] == pytest.approx(d["value"], rel=1e-6)
