@@ -1,3 +1,4 @@
+#define _GNU_SOURCE   /* sincos */
 /*
  * sfm_oracle.c — CPU restatement of the hot path of FlagArihant2000/sfm-mvs (sfm.py).
  *
@@ -345,7 +346,11 @@ void orc_rodrigues_vec2mat(const double* rv, double* R, double* J) {
         }
         return;
     }
-    const double c = cos(theta), s = sin(theta), c1 = 1. - c, itheta = 1. / theta;
+    /* ONE sincos() call, explicitly: gcc merges a cos(theta) / sin(theta) pair into it anyway (so does the compiler of any cv2 wheel),
+     * and glibc's sincos rounds 0.12 % of the arguments differently from sin() and cos() called one by one — the product calls it too */
+    double c, s;
+    sincos(theta, &s, &c);
+    const double c1 = 1. - c, itheta = 1. / theta;
     const double r[3] = {rv[0] * itheta, rv[1] * itheta, rv[2] * itheta};
     const double rrt[9] = {r[0] * r[0], r[0] * r[1], r[0] * r[2], r[0] * r[1], r[1] * r[1],
                            r[1] * r[2], r[0] * r[2], r[1] * r[2], r[2] * r[2]};

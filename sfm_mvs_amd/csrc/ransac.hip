@@ -404,7 +404,13 @@ void rodrigues_with_jac(const double* rv, double* R, double* J) {
         J[7] = J[11] = J[21] = 1;
         return;
     }
-    const double c = std::cos(theta), s = std::sin(theta), c1 = 1. - c, itheta = 1. / theta;
+    // sin and cos from ONE glibc sincos() call — what gcc makes of cv::Rodrigues' `cos(theta)` / `sin(theta)` pair (and of the oracle's) — not
+    // from sin() and cos(): glibc rounds the two differently for 0.12 % of the arguments (247 of 200 000 random rotation vectors, 1 ulp),
+    // and one such ulp in a trial step's R flips a Levenberg-Marquardt accept / reject at convergence: the 1e-10 pose differences that 3 %
+    // of the sequences of scripts/fuzz_pipeline.py showed in rounds 4-5 (found in round 6 by tracing both sides' sweeps)
+    double c, s;
+    ::sincos(theta, &s, &c);
+    const double c1 = 1. - c, itheta = 1. / theta;
     const double r[3] = {rv[0] * itheta, rv[1] * itheta, rv[2] * itheta};
     const double rrt[9] = {r[0] * r[0], r[0] * r[1], r[0] * r[2], r[0] * r[1], r[1] * r[1], r[1] * r[2], r[0] * r[2], r[1] * r[2], r[2] * r[2]};
     const double rx[9] = {0, -r[2], r[1], r[2], 0, -r[0], -r[1], r[0], 0};
