@@ -104,7 +104,7 @@ def test_rodrigues_is_bit_identical_to_the_oracle_over_many_vectors(oracle):
     """Round 6: the product's host Rodrigues called sin() and cos(), the oracle's C file — through gcc's merging of the pair — glibc's
     sincos(); the two round differently for 0.12 % of the arguments (1 ulp in R).  One such ulp in a trial step of solvePnPRansac's
     refinement flips an accept / reject at convergence, which is where the 1e-10 pose differences of ~3 % of the sequences of
-    scripts/fuzz_pipeline.py came from (profiles/r06_pipeline_drift_case.txt).  Both sides now call sincos() explicitly: R and dR/dr are
+    scripts/fuzz_pipeline.py came from (profiles/r06_sincos_finding.txt).  Both sides now call sincos() explicitly: R and dR/dr are
     bit-identical on 60 000 random rotation vectors (the old pair differed on ~70 of them)."""
     from sfm_mvs_amd import hostgeom as hg
     rng = np.random.default_rng(0)
